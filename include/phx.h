@@ -1,0 +1,169 @@
+/* phx.h -- C ABI of libphx.so: the MI355X (gfx950) kernels of the PHiSeg ELBO hot path.
+ *
+ * Drop-in boundary.  The reference (baumgach/PHiSeg-code) has no FFI: its
+ * arithmetic sits behind TensorFlow 1.12's Python API.  Each entry point below therefore replaces the
+ * TF op(s) invoked at the cited reference call site; the Python host in phiseg_code_amd/ (same function
+ * names / arguments as the reference's tfwrapper.layers etc.) is the only caller.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative PHX_E_* otherwise; phx_last_error() gives text;
+ *   - the caller owns every device buffer (plain pointers + sizes, no hidden allocation, no torch types);
+ *   - every launch takes the hipStream_t (passed as void*) it is enqueued on; nothing synchronises;
+ *   - activations are NHWC contiguous; conv weights are TF's HWIO fp32 ([kh][kw][Cin][Cout]);
+ *   - dtype codes: PHX_F32 = 0, PHX_BF16 = 1 (storage type; arithmetic is always fp32-accumulate);
+ *   - act codes: 0 identity, 1 relu, 2 softplus.
+ */
+#ifndef PHX_H
+#define PHX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { PHX_F32 = 0, PHX_BF16 = 1 };
+enum { PHX_ACT_ID = 0, PHX_ACT_RELU = 1, PHX_ACT_SOFTPLUS = 2 };
+enum { PHX_OK = 0, PHX_E_INVAL = -1, PHX_E_SHAPE = -2, PHX_E_ALIGN = -3, PHX_E_LAUNCH = -4, PHX_E_RUNTIME = -5 };
+
+/* ---- runtime plumbing ------------------------------------------------------------------------------ */
+int phx_abi_version(void);
+int phx_last_error(char* buf, size_t n);
+int phx_device_info(int* cu_count, int* clock_khz, size_t* hbm_bytes, char* name, size_t name_n);
+int phx_stream_create(void** stream);
+int phx_stream_destroy(void* stream);
+int phx_stream_sync(void* stream);
+int phx_event_create(void** ev);
+int phx_event_destroy(void* ev);
+int phx_event_record(void* ev, void* stream);
+int phx_event_sync(void* ev);
+int phx_event_elapsed_ms(void* start, void* stop, float* ms);
+int phx_stream_wait_event(void* stream, void* ev);
+/* hipGraph capture of a launch sequence (replaces tf.Session.run's per-step dispatch, phiseg_model.py:194) */
+int phx_graph_begin_capture(void* stream);
+int phx_graph_end_capture(void* stream, void** graph_exec);
+int phx_graph_launch(void* graph_exec, void* stream);
+int phx_graph_destroy(void* graph_exec);
+int phx_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
+int phx_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int phx_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+int phx_memset(void* dst, int value, size_t bytes, void* stream);
+
+/* ---- convolution: tf.nn.conv2d(x, W, [1,1,1,1], 'SAME') + bias_add + activation -------------------- */
+/* tfwrapper/layers.py:122-135.  Generic fp32-math kernel: any odd k (1 or 3), any Cin / Cout, x and y in
+ * f32 or bf16.  transpose_flip = 1 evaluates the data-gradient instead (x := dy [.., Cout], y := dx [.., Cin],
+ * filter flipped + in/out swapped; `Cin`/`Cout` are always those of W).  stats (nullable) += per-channel
+ * {sum, sum of squares} of the stored output, [channels][2] fp32 (= sums[1][C][2] of phx_norm_finalize). */
+int phx_conv2d_direct(const void* x, int x_dt, const float* w_hwio, const float* bias, void* y, int y_dt,
+                      int B, int H, int W, int Cin, int Cout, int ksize, int act, int transpose_flip,
+                      float* stats, void* stream);
+/* filter / bias gradient of the same op (what optimizer.minimize derives, phiseg_model.py:141):
+ * dw[kh][kw][ci][co] += sum_{b,y,x} x[b,y+kh-p,x+kw-p,ci] * dy[b,y,x,co];  dbias[co] += sum dy. */
+int phx_conv2d_direct_wgrad(const void* x, int x_dt, const void* dy, int dy_dt, float* dw_hwio, float* dbias,
+                            int B, int H, int W, int Cin, int Cout, int ksize, void* stream);
+
+/* bf16 MFMA path (v_mfma_f32_32x32x16_bf16), 3x3 only, Cin % 32 == 0, Cout % 32 == 0.
+ * wpk is the packed filter [9][N][K] (bf16, K contiguous) written by phx_pack_conv3x3_bf16:
+ *   forward:  N = Cout, K = Cin, tap t = kh*3+kw          (wpk_fwd)
+ *   dgrad:    N = Cin,  K = Cout, tap t = (2-kh)*3+(2-kw) (wpk_dgrad); call with x := dy, K := Cout, N := Cin.
+ * Optional epilogue: + bias[N], act, and per-channel {sum, sumsq} of the bf16-rounded output into
+ * stats_partial[gridDim.x][2][N] (one row per pixel-tile, no atomics; reduced by phx_norm_finalize). */
+int phx_pack_conv3x3_bf16(const float* w_hwio, void* wpk_fwd, void* wpk_dgrad, int Cin, int Cout, void* stream);
+int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* bias, int act,
+                          float* stats_partial, int B, int H, int W, int K, int N, void* stream);
+int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W);     /* number of pixel tiles (= rows of stats_partial) */
+/* dw_hwio[kh][kw][ci][co] += sum x * dy (fp32 atomics), Cin % 32 == 0, Cout % 32 == 0. */
+int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, int B, int H, int W,
+                                int Cin, int Cout, void* stream);
+
+/* ---- normalisation (tfwrapper/normalisation.py:3-36,145-163) --------------------------------------- */
+/* One implementation for batch / group / instance norm.  A statistic is taken over P pixels x (C/G) channels
+ * for each of NS sample-groups and G channel-groups:  batch norm: NS=1, P=B*H*W, G=C;  group norm: NS=B,
+ * P=H*W, G=groups;  instance norm: NS=B, P=H*W, G=C.
+ *   sums[NS][C][2]   per-channel {sum x, sum x^2}            (phx_norm_stats accumulates; zero it first)
+ *   mean/rstd[NS][G], scale/shift[NS][C]: y = act(x*scale+shift), scale = gamma*rstd, shift = beta-mean*scale */
+int phx_norm_stats(const void* x, int dt, float* sums, int NS, int P, int C, void* stream);
+/* partial[T][2][C] (conv epilogue rows) -> sums[1][C][2] */
+int phx_norm_reduce_partials(const float* partial, int T, int C, float* sums, void* stream);
+int phx_norm_finalize(const float* sums, const float* gamma, const float* beta, float eps, int NS, int P, int C,
+                      int G, float* mean, float* rstd, float* scale, float* shift,
+                      float* moving_mean, float* moving_var, float momentum /* 0 => no moving update */,
+                      void* stream);
+/* inference-mode batch norm: scale/shift from the moving statistics */
+int phx_bn_infer_scale_shift(const float* gamma, const float* beta, const float* moving_mean,
+                             const float* moving_var, float eps, int C, float* scale, float* shift, void* stream);
+int phx_affine_act(const void* x, int x_dt, const float* scale, const float* shift, void* y, int y_dt,
+                   int NS, int P, int C, int act, void* stream);
+/* backward of y = act(norm(x)):  g = dA * act'(.);  sums2[NS][C][2] += {sum g, sum g*xhat} */
+int phx_norm_bwd_reduce(const void* dA, int da_dt, const void* x, int x_dt, const float* scale,
+                        const float* shift, const float* mean, const float* rstd, float* sums2,
+                        int NS, int P, int C, int G, int act, void* stream);
+/* per (ns,g): S[ns][g][2] = sum_{c in g} gamma_c * sums2[ns][c][*];  dgamma[c] += sum_ns sums2[..][1], dbeta += [..][0] */
+int phx_norm_bwd_finalize(const float* sums2, const float* gamma, float* S, float* dgamma, float* dbeta,
+                          int NS, int C, int G, void* stream);
+/* dx = rstd * (gamma*g - S0/m - xhat*S1/m),  m = P*C/G */
+int phx_norm_bwd_apply(const void* dA, int da_dt, const void* x, int x_dt, const float* scale,
+                       const float* shift, const float* mean, const float* rstd, const float* gamma,
+                       const float* S, void* dx, int dx_dt, int NS, int P, int C, int G, int act, void* stream);
+/* act backward without a norm: dpre = dy * act'(y) evaluated from the stored OUTPUT y */
+int phx_act_bwd(const void* dy, int dy_dt, const void* y, int y_dt, void* dpre, int dpre_dt, size_t n, int act,
+                void* stream);
+
+/* ---- pooling / resize / concat (tfwrapper/layers.py:44-54, 336-345, 70-78; tf.concat) --------------- */
+int phx_avgpool2x2_fwd(const void* x, int dt, void* y, int B, int H, int W, int C, void* stream);
+int phx_avgpool2x2_bwd(const void* dy, int dt, void* dx, int B, int H, int W, int C, void* stream);
+/* TF 1.12 ResizeBilinear(align_corners=False), legacy coordinates, factor 2 */
+int phx_bilinear_up2x_fwd(const void* x, int dt, void* y, int B, int h, int w, int C, void* stream);
+int phx_bilinear_up2x_bwd(const void* dy, int dt, void* dx, int B, int h, int w, int C, void* stream);
+int phx_concat2(const void* a, int Ca, const void* b, int Cb, void* out, size_t npix, int dt, void* stream);
+int phx_split2(const void* in, void* a, int Ca, void* b, int Cb, size_t npix, int dt, void* stream);
+int phx_add_inplace(void* dst, const void* src, size_t n, int dt, void* stream);
+/* out[c] += sum over npix of x[p][c]  (bias gradient of the MFMA conv path) */
+int phx_channel_sum_accumulate(const void* x, int dt, float* out, size_t npix, int C, void* stream);
+int phx_cast(const void* src, int src_dt, void* dst, int dst_dt, size_t n, void* stream);
+/* posterior input: concat[x, one_hot(s) - 0.5] (phiseg_model.py:29, posteriors.py:87) -> [npix][1+C] */
+int phx_posterior_input(const float* x, const uint8_t* s, void* out, int out_dt, size_t npix, int nlabels,
+                        void* stream);
+/* global average pool [B,P,C] -> [B,C] and its adjoint; broadcast [B,C] -> [B,P,C] and its adjoint */
+int phx_global_avgpool_fwd(const float* x, float* y, int B, int P, int C, void* stream);
+int phx_global_avgpool_bwd(const float* dy, float* dx, int B, int P, int C, void* stream);
+int phx_broadcast_pixels_fwd(const float* z, void* out, int out_dt, int B, int P, int C, void* stream);
+int phx_broadcast_pixels_bwd(const void* dout, int dt, float* dz, int B, int P, int C, void* stream);
+
+/* ---- reparameterisation: z = mu + sigma * N(0,1) (posteriors.py:108,128; priors.py:100,120) --------- */
+/* Philox4x32-10, counter = (e/4, sample_offset + b, stream_id, *step), key = seed; see oracle/philox.py. */
+int phx_reparam_fwd(const float* mu, const float* sigma, float* z, int B, int per_sample, uint64_t seed,
+                    const int32_t* step_dev, int stream_id, int sample_offset, void* stream);
+int phx_reparam_bwd(const float* dz, float* dsigma, int B, int per_sample, uint64_t seed,
+                    const int32_t* step_dev, int stream_id, int sample_offset, void* stream);
+int phx_philox_normal(float* out, int B, int per_sample, uint64_t seed, const int32_t* step_dev, int stream_id,
+                      int sample_offset, void* stream);
+
+/* ---- losses (phiseg_model.py:210-262) -------------------------------------------------------------- */
+/* residual multinoulli loss over L levels: logits s[l] are [B, H>>shift[l], W>>shift[l], C] fp32 (the
+ * NEAREST_NEIGHBOR resize of likelihoods.py:221 is folded into the read).  losses[l] = inv_batch * sum CE_l
+ * (written; `losses` must hold 8 + 512 floats, the tail is scratch for the partial sums; nullable).
+ * ds[l] (nullable; level 0 is written, coarser levels must be zeroed) += weight*inv_batch * d(sum_l CE_l)/d s[l].
+ * labels may be NULL when only s_out (= sum_l s[l] at full resolution, nullable) / sm_out (= softmax(s_out),
+ * nullable) are wanted (sampling path, phiseg_model.py:106-109). */
+int phx_residual_ce(const float* const* s, float* const* ds, const int* shift, int L, const uint8_t* labels,
+                    int B, int H, int W, int C, float weight, float inv_batch, float* losses, float* s_out,
+                    float* sm_out, void* stream);
+/* KL(N(mu0,s0^2) || N(mu1,s1^2)) summed over n = B*per_sample elements: loss += level_w*inv_batch*0.5*sum(...);
+ * gradients (nullable) are WRITTEN (not accumulated), scaled by grad_scale*level_w*inv_batch. */
+int phx_kl_diag_gauss(const float* mu0, const float* s0, const float* mu1, const float* s1, size_t n,
+                      float level_w, float inv_batch, float grad_scale, float* loss, float* dmu0, float* ds0,
+                      float* dmu1, float* ds1, void* stream);
+
+/* ---- optimiser: tf.train.AdamOptimizer (phiseg_model.py:137-141), TF 1.12 epsilon-hat form ---------- */
+/* t = *step_dev + 1;  lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  m,v EMA;  p -= lr_t*m/(sqrt(v)+eps).  One launch over
+ * the flat parameter arena.  grad_scale multiplies g first (1/world for averaged all-reduce). */
+int phx_adam_tf1(float* p, const float* g, float* m, float* v, size_t n, const float* lr_dev, float beta1,
+                 float beta2, float eps, const int32_t* step_dev, void* stream);
+int phx_step_increment(int32_t* step_dev, void* stream);
+int phx_sum_scalars(const float* in, int n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHX_H */

@@ -7,7 +7,8 @@ The reference draws its reparameterisation noise with an UNSEEDED ``tf.random_no
 
   counter = (block, sample, stream, step)     key = (seed_lo, seed_hi)
   one Philox call -> 4 uint32 (x0..x3) -> 4 normals:
-      u1 = (x0 + 1) * 2^-32  in (0, 1]       u2 = x1 * 2^-32  in [0, 1)
+      u1 = ((x0 >> 8) + 1) * 2^-24 in (0, 1]   u2 = (x1 >> 8) * 2^-24 in [0, 1)
+      (24-bit mantissas: exactly representable in fp32, so the HIP kernel forms the same u1/u2)
       n0 = sqrt(-2 ln u1) * cos(2 pi u2)     n1 = sqrt(-2 ln u1) * sin(2 pi u2)
       n2, n3 likewise from (x2, x3)
   element e of sample b (e indexes the per-sample NHWC-flattened tensor):
@@ -57,12 +58,12 @@ def normal(seed, step, stream, n_samples, per_sample, sample_offset=0, dtype=np.
     ctr[..., 2] = np.uint32(stream)
     ctr[..., 3] = np.uint32(step)
     key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
-    x = philox4x32_10(ctr, key).astype(np.float64)
-    two32 = 2.0 ** -32
+    x = (philox4x32_10(ctr, key) >> np.uint32(8)).astype(np.float64)
+    two24 = 2.0 ** -24
     out = np.empty((n_samples, nblk, 4), dtype=np.float64)
     for j in (0, 2):
-        u1 = (x[..., j] + 1.0) * two32
-        u2 = x[..., j + 1] * two32
+        u1 = (x[..., j] + 1.0) * two24
+        u2 = x[..., j + 1] * two24
         r = np.sqrt(-2.0 * np.log(u1))
         out[..., j] = r * np.cos(2.0 * np.pi * u2)
         out[..., j + 1] = r * np.sin(2.0 * np.pi * u2)

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build libphx.so (gfx950) in-tree.  hipcc cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+OUT=../libphx.so
+SRCS="runtime.hip elementwise.hip losses_opt.hip conv_direct.hip conv_mfma.hip"
+OBJS=""
+for s in $SRCS; do
+  o="build_${s%.hip}.o"
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ phx_common.h -nt "$o" ] || [ philox.h -nt "$o" ] || [ ../../include/phx.h -nt "$o" ]; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$s" -o "$o" &
+  fi
+  OBJS="$OBJS $o"
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT
+echo "built $(realpath $OUT)"

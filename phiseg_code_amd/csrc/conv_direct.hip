@@ -1,0 +1,240 @@
+// Generic fp32-math convolution (tf.nn.conv2d SAME stride 1, tfwrapper/layers.py:122-135) for every
+// shape the bf16 MFMA kernels do not take: the fp32 parity path, Cin in {1,2,3} image / latent inputs,
+// the 1x1 / 3x3 mu, sigma, y_lvl heads (Cout = zdim0 or nlabels) and prob_unet2D's 1x1 recombination.
+// One thread = one output pixel x COT output channels; input patch and filter slab staged in LDS.
+#include "phx_common.h"
+
+#define CI_T 8
+
+struct TileGeo {
+    int tws, ths, tb;       // tile = tb images x (1<<ths) rows x (1<<tws) cols = 256 pixels
+    int tiles_x, tiles_y, tiles_b;
+};
+
+static TileGeo make_geo(int B, int H, int W) {
+    TileGeo g;
+    int tw = 1, th = 1;
+    g.tws = g.ths = 0;
+    while (tw < W && tw < 16) { tw <<= 1; g.tws++; }
+    while (th < H && th < 16) { th <<= 1; g.ths++; }
+    g.tb = 256 / (tw * th);
+    g.tiles_x = (W + tw - 1) / tw;
+    g.tiles_y = (H + th - 1) / th;
+    g.tiles_b = (B + g.tb - 1) / g.tb;
+    return g;
+}
+
+template <typename TI, typename TO, int COT, int KS>
+__global__ __launch_bounds__(256) void k_conv_direct(const TI* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, TO* __restrict__ y,
+                                                     float* __restrict__ stats, int B, int H, int W, int Cx, int Cy,
+                                                     int wCin, int wCout, int act, int tflip, TileGeo g) {
+    constexpr int PAD = KS / 2;
+    const int tw = 1 << g.tws, th = 1 << g.ths;
+    const int pw = tw + KS - 1, ph = th + KS - 1;
+    const int npatch = g.tb * ph * pw;
+    extern __shared__ float smem[];
+    float* sx = smem;                         // [CI_T][npatch]
+    float* sw = smem + CI_T * npatch;         // [KS*KS][CI_T][COT]
+
+    int t = blockIdx.x;
+    const int tx0 = (t % g.tiles_x) << g.tws; t /= g.tiles_x;
+    const int ty0 = (t % g.tiles_y) << g.ths; t /= g.tiles_y;
+    const int b0 = t * g.tb;
+    const int co0 = blockIdx.y * COT;
+
+    const int m = threadIdx.x;
+    const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
+    const int ox = tx0 + lx, oy = ty0 + ly, ob = b0 + lb;
+    const bool valid = ox < W && oy < H && ob < B;
+    const int pbase = (lb * ph + ly) * pw + lx;
+
+    float acc[COT];
+#pragma unroll
+    for (int j = 0; j < COT; ++j) acc[j] = 0.f;
+
+    for (int c0 = 0; c0 < Cx; c0 += CI_T) {
+        __syncthreads();
+        // stage the input patch (zero padded), channel fastest in the global read
+        for (int i = threadIdx.x; i < npatch * CI_T; i += 256) {
+            const int ci = i % CI_T, pp = i / CI_T;
+            const int px = pp % pw, py = (pp / pw) % ph, pb = pp / (pw * ph);
+            const int gx = tx0 + px - PAD, gy = ty0 + py - PAD, gb = b0 + pb;
+            float v = 0.f;
+            if (gx >= 0 && gx < W && gy >= 0 && gy < H && gb < B && c0 + ci < Cx)
+                v = ldf<TI>(x, (((size_t)gb * H + gy) * W + gx) * Cx + c0 + ci);
+            sx[ci * npatch + pp] = v;
+        }
+        // stage the filter slab
+        for (int i = threadIdx.x; i < KS * KS * CI_T * COT; i += 256) {
+            const int j = i % COT, ci = (i / COT) % CI_T, tap = i / (COT * CI_T);
+            const int inc = c0 + ci, outc = co0 + j;
+            float v = 0.f;
+            if (inc < Cx && outc < Cy) {
+                if (!tflip) v = w[((size_t)tap * wCin + inc) * wCout + outc];
+                else v = w[((size_t)(KS * KS - 1 - tap) * wCin + outc) * wCout + inc];
+            }
+            sw[i] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw) {
+                const int poff = pbase + kh * pw + kw;
+                const float* wt = sw + (kh * KS + kw) * CI_T * COT;
+#pragma unroll
+                for (int ci = 0; ci < CI_T; ++ci) {
+                    const float xv = sx[ci * npatch + poff];
+#pragma unroll
+                    for (int j = 0; j < COT; ++j) acc[j] = fmaf(xv, wt[ci * COT + j], acc[j]);
+                }
+            }
+    }
+    float s1[COT], s2[COT];
+#pragma unroll
+    for (int j = 0; j < COT; ++j) {
+        const int co = co0 + j;
+        float v = acc[j];
+        if (co < Cy) {
+            if (bias) v += bias[co];
+            v = act_fwd(v, act);
+            if (valid) stf<TO>(y, (((size_t)ob * H + oy) * W + ox) * Cy + co, v);
+        }
+        const float r = (valid && co < Cy) ? roundf_as<TO>(v) : 0.f;
+        s1[j] = r;
+        s2[j] = r * r;
+    }
+    if (stats) {
+#pragma unroll
+        for (int j = 0; j < COT; ++j) {
+            const float a = wave_sum(s1[j]), bq = wave_sum(s2[j]);
+            if ((threadIdx.x & 63) == 0 && co0 + j < Cy) {
+                atomicAdd(&stats[(co0 + j) * 2], a);
+                atomicAdd(&stats[(co0 + j) * 2 + 1], bq);
+            }
+        }
+    }
+}
+
+// dw[tap][ci][co] += sum_pixels x[p+tap][ci]*dy[p][co];  thread = (ci in 8) x (co in 32), KS*KS accumulators
+#define WG_CI 8
+#define WG_CO 32
+template <typename TX, typename TD, int KS>
+__global__ __launch_bounds__(256) void k_conv_direct_wgrad(const TX* __restrict__ x, const TD* __restrict__ dy,
+                                                           float* __restrict__ dw, float* __restrict__ dbias, int B,
+                                                           int H, int W, int Cin, int Cout, TileGeo g, int tiles_per_block) {
+    constexpr int PAD = KS / 2;
+    const int tw = 1 << g.tws, th = 1 << g.ths;
+    const int pw = tw + KS - 1, ph = th + KS - 1;
+    const int npatch = g.tb * ph * pw;
+    extern __shared__ float smem[];
+    float* sx = smem;                       // [WG_CI][npatch]
+    float* sd = smem + WG_CI * npatch;      // [256][WG_CO]
+    const int ci_l = threadIdx.x / WG_CO, co_l = threadIdx.x % WG_CO;
+    const int ci0 = blockIdx.y * WG_CI, co0 = blockIdx.z * WG_CO;
+    const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
+    float acc[KS * KS];
+#pragma unroll
+    for (int k = 0; k < KS * KS; ++k) acc[k] = 0.f;
+    float accb = 0.f;
+
+    for (int tt = 0; tt < tiles_per_block; ++tt) {
+        int t = blockIdx.x * tiles_per_block + tt;
+        if (t >= ntiles) break;
+        const int tx0 = (t % g.tiles_x) << g.tws; t /= g.tiles_x;
+        const int ty0 = (t % g.tiles_y) << g.ths; t /= g.tiles_y;
+        const int b0 = t * g.tb;
+        __syncthreads();
+        for (int i = threadIdx.x; i < npatch * WG_CI; i += 256) {
+            const int ci = i % WG_CI, pp = i / WG_CI;
+            const int px = pp % pw, py = (pp / pw) % ph, pb = pp / (pw * ph);
+            const int gx = tx0 + px - PAD, gy = ty0 + py - PAD, gb = b0 + pb;
+            float v = 0.f;
+            if (gx >= 0 && gx < W && gy >= 0 && gy < H && gb < B && ci0 + ci < Cin)
+                v = ldf<TX>(x, (((size_t)gb * H + gy) * W + gx) * Cin + ci0 + ci);
+            sx[ci * npatch + pp] = v;
+        }
+        for (int i = threadIdx.x; i < 256 * WG_CO; i += 256) {
+            const int co = i % WG_CO, m = i / WG_CO;
+            const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
+            const int ox = tx0 + lx, oy = ty0 + ly, ob = b0 + lb;
+            float v = 0.f;
+            if (ox < W && oy < H && ob < B && co0 + co < Cout)
+                v = ldf<TD>(dy, (((size_t)ob * H + oy) * W + ox) * Cout + co0 + co);
+            sd[i] = v;
+        }
+        __syncthreads();
+        for (int m = 0; m < 256; ++m) {
+            const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
+            const int pbase = (lb * ph + ly) * pw + lx;
+            const float d = sd[m * WG_CO + co_l];
+            accb += d;
+#pragma unroll
+            for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < KS; ++kw)
+                    acc[kh * KS + kw] = fmaf(sx[ci_l * npatch + pbase + kh * pw + kw], d, acc[kh * KS + kw]);
+        }
+    }
+    const int ci = ci0 + ci_l, co = co0 + co_l;
+    if (ci < Cin && co < Cout) {
+#pragma unroll
+        for (int k = 0; k < KS * KS; ++k) atomicAdd(&dw[((size_t)k * Cin + ci) * Cout + co], acc[k]);
+    }
+    if (dbias && blockIdx.y == 0 && ci_l == 0 && co < Cout) atomicAdd(&dbias[co], accb);
+}
+
+extern "C" {
+
+int phx_conv2d_direct(const void* x, int x_dt, const float* w_hwio, const float* bias, void* y, int y_dt, int B, int H,
+                      int W, int Cin, int Cout, int ksize, int act, int transpose_flip, float* stats, void* stream) {
+    PHX_REQUIRE(ksize == 1 || ksize == 3, PHX_E_SHAPE, "conv2d_direct: ksize must be 1 or 3");
+    PHX_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, PHX_E_SHAPE, "conv2d_direct: bad shape");
+    const int Cx = transpose_flip ? Cout : Cin, Cy = transpose_flip ? Cin : Cout;
+    TileGeo g = make_geo(B, H, W);
+    const int tw = 1 << g.tws, th = 1 << g.ths;
+    const int npatch = g.tb * (th + ksize - 1) * (tw + ksize - 1);
+    const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
+#define CD_LAUNCH(COT, KS)                                                                                           \
+    do {                                                                                                             \
+        const size_t sh = (size_t)(CI_T * npatch + KS * KS * CI_T * COT) * sizeof(float);                            \
+        hipLaunchKernelGGL((k_conv_direct<TI, TO, COT, KS>), dim3(ntiles, (Cy + COT - 1) / COT), dim3(256), sh,      \
+                           (hipStream_t)stream, (const TI*)x, w_hwio, bias, (TO*)y, stats, B, H, W, Cx, Cy, Cin, Cout, \
+                           act, transpose_flip, g);                                                                  \
+    } while (0)
+    PHX_DT_SWITCH(x_dt, TI, PHX_DT_SWITCH(y_dt, TO, {
+        if (Cy <= 4) { if (ksize == 3) CD_LAUNCH(4, 3); else CD_LAUNCH(4, 1); }
+        else { if (ksize == 3) CD_LAUNCH(16, 3); else CD_LAUNCH(16, 1); }
+    }));
+#undef CD_LAUNCH
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_conv2d_direct_wgrad(const void* x, int x_dt, const void* dy, int dy_dt, float* dw_hwio, float* dbias, int B,
+                            int H, int W, int Cin, int Cout, int ksize, void* stream) {
+    PHX_REQUIRE(ksize == 1 || ksize == 3, PHX_E_SHAPE, "conv2d_direct_wgrad: ksize must be 1 or 3");
+    TileGeo g = make_geo(B, H, W);
+    const int tw = 1 << g.tws, th = 1 << g.ths;
+    const int npatch = g.tb * (th + ksize - 1) * (tw + ksize - 1);
+    const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
+    int tpb = (ntiles + 255) / 256;          // <= 256 blocks along the pixel axis -> bounded atomic traffic
+    if (tpb < 1) tpb = 1;
+    const int gx = (ntiles + tpb - 1) / tpb;
+    const size_t sh = (size_t)(WG_CI * npatch + 256 * WG_CO) * sizeof(float);
+    PHX_DT_SWITCH(x_dt, TX, PHX_DT_SWITCH(dy_dt, TD, {
+        if (ksize == 3)
+            hipLaunchKernelGGL((k_conv_direct_wgrad<TX, TD, 3>), dim3(gx, (Cin + WG_CI - 1) / WG_CI, (Cout + WG_CO - 1) / WG_CO),
+                               dim3(256), sh, (hipStream_t)stream, (const TX*)x, (const TD*)dy, dw_hwio, dbias, B, H, W,
+                               Cin, Cout, g, tpb);
+        else
+            hipLaunchKernelGGL((k_conv_direct_wgrad<TX, TD, 1>), dim3(gx, (Cin + WG_CI - 1) / WG_CI, (Cout + WG_CO - 1) / WG_CO),
+                               dim3(256), sh, (hipStream_t)stream, (const TX*)x, (const TD*)dy, dw_hwio, dbias, B, H, W,
+                               Cin, Cout, g, tpb);
+    }));
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,368 @@
+// bf16 MFMA 3x3 convolution for gfx950 (v_mfma_f32_32x32x16_bf16), NHWC, im2col-free implicit GEMM.
+//   forward / data-gradient : k_conv3x3_mfma   (M = pixels, N = output channels, K = 9 * input channels)
+//   filter-gradient         : k_conv3x3_wgrad  (M = Cin, N = Cout, K = pixels; LDS transpose reads)
+// Replaces tf.nn.conv2d 3x3 SAME (tfwrapper/layers.py:123) and the two gradients TF derives for it.
+//
+// Tile geometry (all kernels): a block owns 256 output pixels = tb images x th rows x tw cols with
+// th, tw = min(16, pow2ceil(H|W)), so 128x128 maps use 16x16 patches and the 2x2 .. 8x8 levels pack several
+// images into one tile.  The (th+2) x (tw+2) zero-padded input patch is staged once per 32-channel chunk and
+// re-used by all nine filter taps from LDS.
+#include "phx_common.h"
+
+#define KC 32            // input channels per LDS stage (two MFMA k-steps)
+#define ROWB 80          // bytes per pixel / filter row in LDS: 32 bf16 + 16 B pad -> conflict-free ds_read_b128
+
+struct MTile {
+    int tws, ths, tb, tiles_x, tiles_y, tiles_b;
+};
+static MTile make_mtile(int B, int H, int W) {
+    MTile g;
+    int tw = 1, th = 1;
+    g.tws = g.ths = 0;
+    while (tw < W && tw < 16) { tw <<= 1; g.tws++; }
+    while (th < H && th < 16) { th <<= 1; g.ths++; }
+    g.tb = 256 / (tw * th);
+    g.tiles_x = (W + tw - 1) / tw;
+    g.tiles_y = (H + th - 1) / th;
+    g.tiles_b = (B + g.tb - 1) / g.tb;
+    return g;
+}
+
+// ---- filter packing ---------------------------------------------------------------------------------
+// wpk_fwd[t][co][ci] = w[t][ci][co];  wpk_dgrad[t][ci][co] = w[8-t][ci][co]
+__global__ void k_pack_conv3x3(const float* __restrict__ w, unsigned short* __restrict__ wf,
+                               unsigned short* __restrict__ wd, int Cin, int Cout) {
+    const size_t n = (size_t)9 * Cin * Cout;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        const int ci = (int)((i / Cout) % Cin);
+        const int t = (int)(i / ((size_t)Cout * Cin));
+        const unsigned short v = f2bf(w[i]);
+        if (wf) wf[((size_t)t * Cout + co) * Cin + ci] = v;
+        if (wd) wd[((size_t)(8 - t) * Cin + ci) * Cout + co] = v;
+    }
+}
+
+// ---- forward / dgrad ----------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(const unsigned short* __restrict__ x,
+                                                         const unsigned short* __restrict__ wpk,
+                                                         unsigned short* __restrict__ y, const float* __restrict__ bias,
+                                                         int act, float* __restrict__ stats_partial, int B, int H, int W,
+                                                         int K, int N, MTile g) {
+    constexpr int NJ = BN / 32;
+    const int tw = 1 << g.tws, th = 1 << g.ths;
+    const int pw = tw + 2, ph = th + 2;
+    const int npatch = g.tb * ph * pw;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;                    // [npatch][ROWB]
+    unsigned char* sB = smem + npatch * ROWB;    // [9][BN][ROWB]
+
+    int t = blockIdx.x;
+    const int tx0 = (t % g.tiles_x) << g.tws; t /= g.tiles_x;
+    const int ty0 = (t % g.tiles_y) << g.ths; t /= g.tiles_y;
+    const int b0 = t * g.tb;
+    const int n0 = blockIdx.y * BN;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    int aoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = wave * 64 + i * 32 + l31;
+        const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
+        aoff[i] = ((lb * ph + ly) * pw + lx) * ROWB + khalf * 16;
+    }
+    const int boff = l31 * ROWB + khalf * 16;
+
+    f32x16 acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int c0 = 0; c0 < K; c0 += KC) {
+        __syncthreads();
+        // input patch: 4 x 16 B per pixel
+        for (int i = threadIdx.x; i < npatch * 4; i += 256) {
+            const int q = i & 3, pp = i >> 2;
+            const int px = pp % pw, py = (pp / pw) % ph, pb = pp / (pw * ph);
+            const int gx = tx0 + px - 1, gy = ty0 + py - 1, gb = b0 + pb;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gx >= 0 && gx < W && gy >= 0 && gy < H && gb < B)
+                v = *reinterpret_cast<const uint4*>(x + (((size_t)gb * H + gy) * W + gx) * K + c0 + q * 8);
+            *reinterpret_cast<uint4*>(sA + pp * ROWB + q * 16) = v;
+        }
+        // filter slab: 9 taps x BN rows x 32 channels
+        for (int i = threadIdx.x; i < 9 * BN * 4; i += 256) {
+            const int q = i & 3, row = i >> 2;               // row = tap*BN + n
+            const int tap = row / BN, n = row - tap * BN;
+            const uint4 v = *reinterpret_cast<const uint4*>(wpk + ((size_t)tap * N + n0 + n) * K + c0 + q * 8);
+            *reinterpret_cast<uint4*>(sB + row * ROWB + q * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int tapoff = (kh * pw + kw) * ROWB;
+                const int tap = kh * 3 + kw;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 a[2], b[NJ];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        a[i] = *reinterpret_cast<const bf16x8*>(sA + aoff[i] + tapoff + ks * 32);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        b[j] = *reinterpret_cast<const bf16x8*>(sB + (tap * BN + j * 32) * ROWB + boff + ks * 32);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+            }
+    }
+
+    // epilogue: C layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
+    float s1[NJ], s2[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
+            const int ox = tx0 + lx, oy = ty0 + ly, ob = b0 + lb;
+            const bool valid = ox < W && oy < H && ob < B;
+            const size_t obase = (((size_t)ob * H + oy) * W + ox) * N + n0 + l31;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float v = acc[i][j][r];
+                if (bias) v += bias[n0 + j * 32 + l31];
+                v = act_fwd(v, act);
+                const unsigned short h = f2bf(v);
+                if (valid) {
+                    y[obase + j * 32] = h;
+                    const float rv = bf2f(h);
+                    s1[j] += rv;
+                    s2[j] += rv * rv;
+                }
+            }
+        }
+    if (stats_partial) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);      // [4 waves][2][BN]
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float a = s1[j] + __shfl_xor(s1[j], 32, 64);
+            const float bq = s2[j] + __shfl_xor(s2[j], 32, 64);
+            if (khalf == 0) {
+                red[(wave * 2 + 0) * BN + j * 32 + l31] = a;
+                red[(wave * 2 + 1) * BN + j * 32 + l31] = bq;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * BN) {
+            const int which = threadIdx.x / BN, n = threadIdx.x % BN;
+            const float v = red[(0 * 2 + which) * BN + n] + red[(1 * 2 + which) * BN + n] +
+                            red[(2 * 2 + which) * BN + n] + red[(3 * 2 + which) * BN + n];
+            stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + n] = v;
+        }
+    }
+}
+
+// ---- filter gradient --------------------------------------------------------------------------------------
+// Block tile: TCI input channels x TCO output channels (32 or 64 each) x all 9 taps.  The 4 waves split the tile
+// into 32x32 sub-tiles (WI x WJ) and, when the tile has fewer than four sub-tiles, the pixel (k) steps WK ways;
+// each wave keeps 9 accumulators (one per tap).  Reduction index = pixel, so both MFMA operands need "k" along
+// the pixel axis of channel-contiguous NHWC data: ds_read_b64_tr_b16 (LDS transpose read) delivers, for a
+// 16-lane group, column (lane&15) of a 4 (pixels) x 16 (channels) block -- 4 k-values per lane per read.
+template <int RB>   // RB = bytes per pixel row in LDS (64 or 128); 128-byte rows XOR-swizzle their halves
+__device__ __forceinline__ int wswz(int pix, int byte_in_row) {
+    if (RB == 128) return pix * 128 + (byte_in_row ^ (((pix >> 1) & 1) << 6));
+    return pix * RB + byte_in_row;
+}
+
+template <int TCI, int TCO>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(const unsigned short* __restrict__ x,
+                                                          const unsigned short* __restrict__ dy,
+                                                          float* __restrict__ dw, int B, int H, int W, int Cin, int Cout,
+                                                          MTile g, int ntiles, int tiles_per_block) {
+    constexpr int WI = TCI / 32, WJ = TCO / 32, WK = 4 / (WI * WJ);
+    constexpr int RBX = TCI * 2, RBD = TCO * 2;
+    const int tw = 1 << g.tws, th = 1 << g.ths;
+    const int pw = tw + 2, ph = th + 2;
+    const int npatch = g.tb * ph * pw;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sX = smem;                    // [npatch][RBX]
+    unsigned char* sD = smem + npatch * RBX;     // [256][RBD]
+    const int ci0 = blockIdx.y * TCI, co0 = blockIdx.z * TCO;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wi = wave % WI, wj = (wave / WI) % WJ, wk = wave / (WI * WJ);
+    const int c16 = lane & 15, cb16 = (lane >> 4) & 1, khalf = lane >> 5;
+    // this lane supplies the 8-byte chunk of pixel-slot (c16>>2) and channels 16*cb16 + 4*(c16&3) .. +3
+    const int chan_byte_x = (wi * 32 + cb16 * 16 + (c16 & 3) * 4) * 2;
+    const int chan_byte_d = (wj * 32 + cb16 * 16 + (c16 & 3) * 4) * 2;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+    for (int tt = 0; tt < tiles_per_block; ++tt) {
+        int t = blockIdx.x * tiles_per_block + tt;
+        if (t >= ntiles) break;
+        const int tx0 = (t % g.tiles_x) << g.tws; t /= g.tiles_x;
+        const int ty0 = (t % g.tiles_y) << g.ths; t /= g.tiles_y;
+        const int b0 = t * g.tb;
+        __syncthreads();
+        constexpr int QX = TCI / 8, QD = TCO / 8;                    // 16-byte pieces per pixel
+        for (int i = threadIdx.x; i < npatch * QX; i += 256) {
+            const int q = i % QX, pp = i / QX;
+            const int px = pp % pw, py = (pp / pw) % ph, pb = pp / (pw * ph);
+            const int gx = tx0 + px - 1, gy = ty0 + py - 1, gb = b0 + pb;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gx >= 0 && gx < W && gy >= 0 && gy < H && gb < B)
+                v = *reinterpret_cast<const uint4*>(x + (((size_t)gb * H + gy) * W + gx) * Cin + ci0 + q * 8);
+            *reinterpret_cast<uint4*>(sX + wswz<RBX>(pp, q * 16)) = v;
+        }
+        for (int i = threadIdx.x; i < 256 * QD; i += 256) {
+            const int q = i % QD, m = i / QD;
+            const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
+            const int ox = tx0 + lx, oy = ty0 + ly, ob = b0 + lb;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ox < W && oy < H && ob < B)
+                v = *reinterpret_cast<const uint4*>(dy + (((size_t)ob * H + oy) * W + ox) * Cout + co0 + q * 8);
+            *reinterpret_cast<uint4*>(sD + wswz<RBD>(m, q * 16)) = v;
+        }
+        __syncthreads();
+        for (int ks = wk; ks < 16; ks += WK) {
+            // the two pixel slots this lane addresses in this k-step (r = 0, 1): m = 16*ks + 8*khalf + 4*r + (c16>>2)
+            int mpix[2], ppix[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int m = ks * 16 + khalf * 8 + r * 4 + (c16 >> 2);
+                const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
+                mpix[r] = m;
+                ppix[r] = (lb * ph + ly) * pw + lx;
+            }
+            const s16x4 d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(sD + wswz<RBD>(mpix[0], chan_byte_d)));
+            const s16x4 d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(sD + wswz<RBD>(mpix[1], chan_byte_d)));
+            const s16x8 dtmp = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, dtmp);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int sh = kh * pw + kw;
+                    const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4 __attribute__((address_space(3)))*)(sX + wswz<RBX>(ppix[0] + sh, chan_byte_x)));
+                    const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4 __attribute__((address_space(3)))*)(sX + wswz<RBX>(ppix[1] + sh, chan_byte_x)));
+                    const s16x8 atmp = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    const bf16x8 afrag = __builtin_bit_cast(bf16x8, atmp);
+                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[kh * 3 + kw], 0, 0, 0);
+                }
+        }
+    }
+    // C layout: col = lane&31 -> co, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> ci
+    const int co = co0 + wj * 32 + (lane & 31);
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            atomicAdd(&dw[((size_t)k * Cin + ci) * Cout + co], acc[k][r]);
+        }
+}
+
+extern "C" {
+
+int phx_pack_conv3x3_bf16(const float* w_hwio, void* wpk_fwd, void* wpk_dgrad, int Cin, int Cout, void* stream) {
+    const size_t n = (size_t)9 * Cin * Cout;
+    hipLaunchKernelGGL(k_pack_conv3x3, dim3(phx_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, w_hwio,
+                       (unsigned short*)wpk_fwd, (unsigned short*)wpk_dgrad, Cin, Cout);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W) {
+    MTile g = make_mtile(B, H, W);
+    return g.tiles_x * g.tiles_y * g.tiles_b;
+}
+
+int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
+                          int B, int H, int W, int K, int N, void* stream) {
+    PHX_REQUIRE(K % KC == 0 && N % 32 == 0, PHX_E_SHAPE, "conv3x3_mfma: K % 32 == 0 and N % 32 == 0 required");
+    PHX_REQUIRE((((uintptr_t)x | (uintptr_t)wpk | (uintptr_t)y) & 15) == 0, PHX_E_ALIGN, "conv3x3_mfma: 16-byte alignment");
+    MTile g = make_mtile(B, H, W);
+    const int tw = 1 << g.tws, th = 1 << g.ths;
+    const int npatch = g.tb * (th + 2) * (tw + 2);
+    const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_mfma<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_mfma<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    if (N % 64 == 0) {
+        const size_t sh = (size_t)npatch * ROWB + 9 * 64 * ROWB;
+        hipLaunchKernelGGL((k_conv3x3_mfma<64>), dim3(ntiles, N / 64), dim3(256), sh, (hipStream_t)stream,
+                           (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act,
+                           stats_partial, B, H, W, K, N, g);
+    } else {
+        const size_t sh = (size_t)npatch * ROWB + 9 * 32 * ROWB;
+        hipLaunchKernelGGL((k_conv3x3_mfma<32>), dim3(ntiles, N / 32), dim3(256), sh, (hipStream_t)stream,
+                           (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act,
+                           stats_partial, B, H, W, K, N, g);
+    }
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, int B, int H, int W, int Cin, int Cout,
+                                void* stream) {
+    PHX_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, PHX_E_SHAPE, "conv3x3_wgrad_mfma: Cin % 32 == 0 and Cout % 32 == 0 required");
+    MTile g = make_mtile(B, H, W);
+    const int tw = 1 << g.tws, th = 1 << g.ths;
+    const int npatch = g.tb * (th + 2) * (tw + 2);
+    const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
+    const int tci = Cin % 64 == 0 ? 64 : 32, tco = Cout % 64 == 0 ? 64 : 32;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad<64, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad<32, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    // split the pixel reduction so that ~2 blocks per CU exist; every block atomically adds 9*TCI*TCO floats
+    const int cblocks = (Cin / tci) * (Cout / tco);
+    int split = (512 + cblocks - 1) / cblocks;
+    if (split > ntiles) split = ntiles;
+    if (split < 1) split = 1;
+    const int tpb = (ntiles + split - 1) / split;
+    const int gx = (ntiles + tpb - 1) / tpb;
+    const size_t sh = (size_t)npatch * tci * 2 + (size_t)256 * tco * 2;
+#define WG_LAUNCH(A, Bq)                                                                                            \
+    hipLaunchKernelGGL((k_conv3x3_wgrad<A, Bq>), dim3(gx, Cin / A, Cout / Bq), dim3(256), sh, (hipStream_t)stream,  \
+                       (const unsigned short*)x, (const unsigned short*)dy, dw_hwio, B, H, W, Cin, Cout, g, ntiles, tpb)
+    if (tci == 64 && tco == 64) WG_LAUNCH(64, 64);
+    else if (tci == 64) WG_LAUNCH(64, 32);
+    else if (tco == 64) WG_LAUNCH(32, 64);
+    else WG_LAUNCH(32, 32);
+#undef WG_LAUNCH
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+}  // extern "C"

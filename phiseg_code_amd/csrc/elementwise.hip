@@ -1,0 +1,734 @@
+// HBM-bound kernels of the PHiSeg step: normalisation (batch/group/instance), affine+activation,
+// pooling, TF1 bilinear resize, concat/split, casts, posterior input assembly, global pooling.
+// All are streaming kernels: 16-byte vector access along the NHWC channel axis when C % 8 == 0.
+#include "phx_common.h"
+
+// ---- 8-wide vector access ----------------------------------------------------------------------
+template <typename T, int V> struct VecIO;
+template <> struct VecIO<float, 8> {
+    static __device__ __forceinline__ void load(const float* p, size_t i, float o[8]) {
+        const float4* q = reinterpret_cast<const float4*>(p + i);
+        float4 a = q[0], b = q[1];
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    }
+    static __device__ __forceinline__ void store(float* p, size_t i, const float o[8]) {
+        float4* q = reinterpret_cast<float4*>(p + i);
+        q[0] = make_float4(o[0], o[1], o[2], o[3]);
+        q[1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+};
+template <> struct VecIO<bf16_t, 8> {
+    static __device__ __forceinline__ void load(const bf16_t* p, size_t i, float o[8]) {
+        uint4 r = *reinterpret_cast<const uint4*>(p + i);
+        unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[2 * k] = __uint_as_float(w[k] << 16);
+            o[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, size_t i, const float o[8]) {
+        unsigned w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = (unsigned)f2bf(o[2 * k]) | ((unsigned)f2bf(o[2 * k + 1]) << 16);
+        *reinterpret_cast<uint4*>(p + i) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+template <typename T> struct VecIO<T, 1> {
+    static __device__ __forceinline__ void load(const T* p, size_t i, float o[1]) { o[0] = ldf<T>(p, i); }
+    static __device__ __forceinline__ void store(T* p, size_t i, const float o[1]) { stf<T>(p, i, o[0]); }
+};
+
+#define PHX_VEC_SWITCH(C, V, ...)                         \
+    do {                                                  \
+        if ((C) % 8 == 0) { constexpr int V = 8; __VA_ARGS__; } \
+        else { constexpr int V = 1; __VA_ARGS__; }        \
+    } while (0)
+
+// =================================================================================================
+// normalisation statistics: sums[ns][c][2] += {sum x, sum x^2} over the P pixels of sample-group ns
+template <typename T, int V>
+__global__ void k_norm_stats(const T* __restrict__ x, float* __restrict__ sums, int P, int C, int PL, int chunk) {
+    const int CV = C / V;
+    const int ns = blockIdx.y;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    extern __shared__ float red[];   // [PL][C][2]
+    float s1[V], s2[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) s1[j] = s2[j] = 0.f;
+    const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
+    if (pl < PL) {
+        for (int p = p0 + pl; p < p1; p += PL) {
+            float v[V];
+            VecIO<T, V>::load(x, ((size_t)ns * P + p) * C + (size_t)cv * V, v);
+#pragma unroll
+            for (int j = 0; j < V; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            red[(pl * C + cv * V + j) * 2 + 0] = s1[j];
+            red[(pl * C + cv * V + j) * 2 + 1] = s2[j];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        float a = 0.f;
+        for (int q = 0; q < PL; ++q) a += red[q * 2 * C + i];
+        atomicAdd(&sums[(size_t)ns * 2 * C + i], a);
+    }
+}
+
+static int norm_geometry(int P, int C, int V, int* PL, int* threads, int* chunk, int* nchunks, int NS) {
+    int CV = C / V;
+    if (CV > 256) return -1;
+    *PL = 256 / CV;
+    *threads = CV * (*PL);
+    int want = (P + (*PL) * 16 - 1) / ((*PL) * 16);          // >= 16 pixels per thread
+    int cap = 2048 / (NS > 0 ? NS : 1);
+    if (cap < 1) cap = 1;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    *chunk = (P + want - 1) / want;
+    *nchunks = (P + *chunk - 1) / (*chunk);
+    return 0;
+}
+
+// partial[T][2][C] -> sums[c][2]
+__global__ void k_reduce_partials(const float* __restrict__ partial, int T, int C, float* __restrict__ sums) {
+    const int i = blockIdx.x;                 // 0 .. 2C-1 : (which, c)
+    const int which = i / C, c = i % C;
+    float a = 0.f;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) a += partial[((size_t)t * 2 + which) * C + c];
+    __shared__ float sh[4];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[c * 2 + which] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// per (ns, g): mean / rstd; per (ns, c): scale / shift; optional TF1 fused-batch-norm moving update
+__global__ void k_norm_finalize(const float* __restrict__ sums, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float eps, int NS, int P, int C, int G,
+                                float* mean, float* rstd, float* scale, float* shift, float* moving_mean,
+                                float* moving_var, float momentum) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NS * G) return;
+    const int ns = idx / G, g = idx % G, cg = C / G;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = g * cg; c < (g + 1) * cg; ++c) {
+        s1 += sums[((size_t)ns * C + c) * 2];
+        s2 += sums[((size_t)ns * C + c) * 2 + 1];
+    }
+    const float m = (float)P * (float)cg;
+    const float mu = s1 / m;
+    float var = s2 / m - mu * mu;
+    var = var > 0.f ? var : 0.f;
+    const float rs = rsqrtf(var + eps);
+    mean[idx] = mu;
+    rstd[idx] = rs;
+    for (int c = g * cg; c < (g + 1) * cg; ++c) {
+        const float sc = gamma[c] * rs;
+        scale[(size_t)ns * C + c] = sc;
+        shift[(size_t)ns * C + c] = beta[c] - mu * sc;
+    }
+    if (momentum > 0.f && moving_mean) {      // batch norm only (NS == 1, G == C): tf.contrib.layers.batch_norm
+        const float unbiased = var * (m / fmaxf(m - 1.f, 1.f));
+        moving_mean[g] -= (moving_mean[g] - mu) * momentum;
+        moving_var[g] -= (moving_var[g] - unbiased) * momentum;
+    }
+}
+
+__global__ void k_bn_infer_scale_shift(const float* gamma, const float* beta, const float* mm, const float* mv,
+                                       float eps, int C, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] * rsqrtf(mv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - mm[c] * sc;
+}
+
+// y = act(x*scale[ns][c] + shift[ns][c])
+template <typename TI, typename TO, int V>
+__global__ void k_affine_act(const TI* __restrict__ x, const float* __restrict__ scale,
+                             const float* __restrict__ shift, TO* __restrict__ y, int P, int C, size_t items,
+                             int act) {
+    const int CV = C / V;
+    for (size_t it = blockIdx.x * (size_t)blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = it / CV;
+        const int cv = (int)(it - pix * CV);
+        const int ns = (int)(pix / P);
+        float v[V];
+        VecIO<TI, V>::load(x, it * V, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int c = cv * V + j;
+            v[j] = act_fwd(v[j] * scale[(size_t)ns * C + c] + shift[(size_t)ns * C + c], act);
+        }
+        VecIO<TO, V>::store(y, it * V, v);
+    }
+}
+
+// sums2[ns][c][2] += {sum g, sum g*xhat},  g = dA * act'(x*scale+shift), xhat = (x-mean)*rstd
+template <typename TD, typename TX, int V>
+__global__ void k_norm_bwd_reduce(const TD* __restrict__ dA, const TX* __restrict__ x,
+                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                  float* __restrict__ sums2, int P, int C, int G, int PL, int chunk, int act) {
+    const int CV = C / V;
+    const int ns = blockIdx.y;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    extern __shared__ float red[];
+    float s1[V], s2[V], sc[V], sh[V], mu[V], rs[V];
+    const int cg = C / G;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int c = cv * V + j;
+        s1[j] = s2[j] = 0.f;
+        sc[j] = scale[(size_t)ns * C + c];
+        sh[j] = shift[(size_t)ns * C + c];
+        mu[j] = mean[(size_t)ns * G + c / cg];
+        rs[j] = rstd[(size_t)ns * G + c / cg];
+    }
+    const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
+    if (pl < PL) {
+        for (int p = p0 + pl; p < p1; p += PL) {
+            float xv[V], dv[V];
+            const size_t off = ((size_t)ns * P + p) * C + (size_t)cv * V;
+            VecIO<TX, V>::load(x, off, xv);
+            VecIO<TD, V>::load(dA, off, dv);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float g = dv[j] * act_grad_pre(xv[j] * sc[j] + sh[j], act);
+                s1[j] += g;
+                s2[j] += g * (xv[j] - mu[j]) * rs[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            red[(pl * C + cv * V + j) * 2 + 0] = s1[j];
+            red[(pl * C + cv * V + j) * 2 + 1] = s2[j];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        float a = 0.f;
+        for (int q = 0; q < PL; ++q) a += red[q * 2 * C + i];
+        atomicAdd(&sums2[(size_t)ns * 2 * C + i], a);
+    }
+}
+
+__global__ void k_norm_bwd_finalize(const float* __restrict__ sums2, const float* __restrict__ gamma, float* S,
+                                    float* dgamma, float* dbeta, int NS, int C, int G) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cg = C / G;
+    if (idx < NS * G) {
+        const int ns = idx / G, g = idx % G;
+        float a = 0.f, b = 0.f;
+        for (int c = g * cg; c < (g + 1) * cg; ++c) {
+            a += gamma[c] * sums2[((size_t)ns * C + c) * 2];
+            b += gamma[c] * sums2[((size_t)ns * C + c) * 2 + 1];
+        }
+        S[idx * 2] = a;
+        S[idx * 2 + 1] = b;
+    }
+    if (idx < C) {
+        float a = 0.f, b = 0.f;
+        for (int ns = 0; ns < NS; ++ns) {
+            a += sums2[((size_t)ns * C + idx) * 2];
+            b += sums2[((size_t)ns * C + idx) * 2 + 1];
+        }
+        dbeta[idx] += a;
+        dgamma[idx] += b;
+    }
+}
+
+template <typename TD, typename TX, typename TO, int V>
+__global__ void k_norm_bwd_apply(const TD* __restrict__ dA, const TX* __restrict__ x,
+                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                 const float* __restrict__ gamma, const float* __restrict__ S, TO* __restrict__ dx,
+                                 int P, int C, int G, size_t items, int act) {
+    const int CV = C / V, cg = C / G;
+    const float inv_m = 1.f / ((float)P * (float)cg);
+    for (size_t it = blockIdx.x * (size_t)blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = it / CV;
+        const int cv = (int)(it - pix * CV);
+        const int ns = (int)(pix / P);
+        float xv[V], dv[V], o[V];
+        VecIO<TX, V>::load(x, it * V, xv);
+        VecIO<TD, V>::load(dA, it * V, dv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int c = cv * V + j;
+            const int sg = ns * G + c / cg;
+            const float g = dv[j] * act_grad_pre(xv[j] * scale[(size_t)ns * C + c] + shift[(size_t)ns * C + c], act);
+            const float rs = rstd[sg];
+            const float xh = (xv[j] - mean[sg]) * rs;
+            o[j] = rs * (gamma[c] * g - S[sg * 2] * inv_m - xh * S[sg * 2 + 1] * inv_m);
+        }
+        VecIO<TO, V>::store(dx, it * V, o);
+    }
+}
+
+template <typename TD, typename TY, typename TO>
+__global__ void k_act_bwd(const TD* __restrict__ dy, const TY* __restrict__ y, TO* __restrict__ dpre, size_t n, int act) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        stf<TO>(dpre, i, ldf<TD>(dy, i) * act_grad_out(ldf<TY>(y, i), act));
+}
+
+// =================================================================================================
+// tf.nn.avg_pool 2x2 stride 2 SAME
+template <typename T, int V>
+__global__ void k_avgpool_fwd(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
+    const int OH = (H + 1) / 2, OW = (W + 1) / 2, CV = C / V;
+    const size_t items = (size_t)B * OH * OW * CV;
+    for (size_t it = blockIdx.x * (size_t)blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(it % CV);
+        size_t r = it / CV;
+        const int ox = (int)(r % OW); r /= OW;
+        const int oy = (int)(r % OH);
+        const int b = (int)(r / OH);
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = 0.f;
+        int cnt = 0;
+        for (int dy = 0; dy < 2; ++dy)
+            for (int dx = 0; dx < 2; ++dx) {
+                const int iy = 2 * oy + dy, ix = 2 * ox + dx;
+                if (iy < H && ix < W) {
+                    float v[V];
+                    VecIO<T, V>::load(x, (((size_t)b * H + iy) * W + ix) * C + (size_t)cv * V, v);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) acc[j] += v[j];
+                    ++cnt;
+                }
+            }
+        const float inv = 1.f / (float)cnt;
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] *= inv;
+        VecIO<T, V>::store(y, it * V, acc);
+    }
+}
+
+template <typename T, int V>
+__global__ void k_avgpool_bwd(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int C) {
+    const int OH = (H + 1) / 2, OW = (W + 1) / 2, CV = C / V;
+    const size_t items = (size_t)B * H * W * CV;
+    for (size_t it = blockIdx.x * (size_t)blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(it % CV);
+        size_t r = it / CV;
+        const int ix = (int)(r % W); r /= W;
+        const int iy = (int)(r % H);
+        const int b = (int)(r / H);
+        const int oy = iy >> 1, ox = ix >> 1;
+        const int cnt = ((2 * oy + 1 < H) ? 2 : 1) * ((2 * ox + 1 < W) ? 2 : 1);
+        float v[V];
+        VecIO<T, V>::load(dy, (((size_t)b * OH + oy) * OW + ox) * C + (size_t)cv * V, v);
+        const float inv = 1.f / (float)cnt;
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] *= inv;
+        VecIO<T, V>::store(dx, it * V, v);
+    }
+}
+
+// TF 1.12 ResizeBilinear x2, legacy coordinates: out[2k] = in[k], out[2k+1] = (in[k] + in[min(k+1,n-1)])/2
+template <typename T, int V>
+__global__ void k_bilinear_up2x_fwd(const T* __restrict__ x, T* __restrict__ y, int B, int h, int w, int C) {
+    const int OH = 2 * h, OW = 2 * w, CV = C / V;
+    const size_t items = (size_t)B * OH * OW * CV;
+    for (size_t it = blockIdx.x * (size_t)blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(it % CV);
+        size_t r = it / CV;
+        const int ox = (int)(r % OW); r /= OW;
+        const int oy = (int)(r % OH);
+        const int b = (int)(r / OH);
+        const int y0 = oy >> 1, y1 = min(y0 + 1, h - 1), x0 = ox >> 1, x1 = min(x0 + 1, w - 1);
+        const float fy = (oy & 1) ? 0.5f : 0.f, fx = (ox & 1) ? 0.5f : 0.f;
+        float a[V], bb[V], c[V], d[V], o[V];
+        const size_t base = (size_t)b * h;
+        VecIO<T, V>::load(x, ((base + y0) * w + x0) * C + (size_t)cv * V, a);
+        VecIO<T, V>::load(x, ((base + y0) * w + x1) * C + (size_t)cv * V, bb);
+        VecIO<T, V>::load(x, ((base + y1) * w + x0) * C + (size_t)cv * V, c);
+        VecIO<T, V>::load(x, ((base + y1) * w + x1) * C + (size_t)cv * V, d);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float top = a[j] + (bb[j] - a[j]) * fx;
+            const float bot = c[j] + (d[j] - c[j]) * fx;
+            o[j] = top + (bot - top) * fy;
+        }
+        VecIO<T, V>::store(y, it * V, o);
+    }
+}
+
+// adjoint (gather): 1-D taps of input k: (2k, 1), (2k+1, 1/2 [+1/2 if k == n-1]), (2k-1, 1/2 if k >= 1)
+template <typename T, int V>
+__global__ void k_bilinear_up2x_bwd(const T* __restrict__ dy, T* __restrict__ dx, int B, int h, int w, int C) {
+    const int OH = 2 * h, OW = 2 * w, CV = C / V;
+    const size_t items = (size_t)B * h * w * CV;
+    for (size_t it = blockIdx.x * (size_t)blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(it % CV);
+        size_t r = it / CV;
+        const int ix = (int)(r % w); r /= w;
+        const int iy = (int)(r % h);
+        const int b = (int)(r / h);
+        int ty[3], tx[3];
+        float wy[3], wx[3];
+        ty[0] = 2 * iy; wy[0] = 1.f;
+        ty[1] = 2 * iy + 1; wy[1] = (iy == h - 1) ? 1.f : 0.5f;
+        ty[2] = 2 * iy - 1; wy[2] = (iy >= 1) ? 0.5f : 0.f;
+        tx[0] = 2 * ix; wx[0] = 1.f;
+        tx[1] = 2 * ix + 1; wx[1] = (ix == w - 1) ? 1.f : 0.5f;
+        tx[2] = 2 * ix - 1; wx[2] = (ix >= 1) ? 0.5f : 0.f;
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = 0.f;
+        for (int a = 0; a < 3; ++a) {
+            if (wy[a] == 0.f) continue;
+            for (int c = 0; c < 3; ++c) {
+                if (wx[c] == 0.f) continue;
+                float v[V];
+                VecIO<T, V>::load(dy, (((size_t)b * OH + ty[a]) * OW + tx[c]) * C + (size_t)cv * V, v);
+                const float ww = wy[a] * wx[c];
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[j] += ww * v[j];
+            }
+        }
+        VecIO<T, V>::store(dx, it * V, acc);
+    }
+}
+
+// channel concat / split of two NHWC tensors
+template <typename T>
+__global__ void k_concat2(const T* __restrict__ a, int Ca, const T* __restrict__ b, int Cb, T* __restrict__ out, size_t npix) {
+    const int C = Ca + Cb;
+    const size_t n = npix * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / C;
+        const int c = (int)(i - p * C);
+        out[i] = c < Ca ? a[p * Ca + c] : b[p * Cb + (c - Ca)];
+    }
+}
+template <typename T>
+__global__ void k_split2(const T* __restrict__ in, T* __restrict__ a, int Ca, T* __restrict__ b, int Cb, size_t npix) {
+    const int C = Ca + Cb;
+    const size_t n = npix * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / C;
+        const int c = (int)(i - p * C);
+        if (c < Ca) { if (a) a[p * Ca + c] = in[i]; }
+        else { if (b) b[p * Cb + (c - Ca)] = in[i]; }
+    }
+}
+// 16-byte-chunk variants (Ca, Cb multiples of 8 elements for bf16 / 4 for f32): T16 = uint4
+__global__ void k_concat2_v16(const uint4* __restrict__ a, int Ca16, const uint4* __restrict__ b, int Cb16,
+                              uint4* __restrict__ out, size_t npix) {
+    const int C = Ca16 + Cb16;
+    const size_t n = npix * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / C;
+        const int c = (int)(i - p * C);
+        out[i] = c < Ca16 ? a[p * Ca16 + c] : b[p * Cb16 + (c - Ca16)];
+    }
+}
+__global__ void k_split2_v16(const uint4* __restrict__ in, uint4* __restrict__ a, int Ca16, uint4* __restrict__ b,
+                             int Cb16, size_t npix) {
+    const int C = Ca16 + Cb16;
+    const size_t n = npix * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / C;
+        const int c = (int)(i - p * C);
+        if (c < Ca16) { if (a) a[p * Ca16 + c] = in[i]; }
+        else { if (b) b[p * Cb16 + (c - Ca16)] = in[i]; }
+    }
+}
+
+template <typename T>
+__global__ void k_add_inplace(T* __restrict__ dst, const T* __restrict__ src, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        stf<T>(dst, i, ldf<T>(dst, i) + ldf<T>(src, i));
+}
+template <typename T>
+__global__ void k_channel_sum(const T* __restrict__ x, float* __restrict__ out, size_t npix, int C) {
+    // block (c-chunk of 64 channels) x pixel slab; lanes along channels for coalescing
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+    const int prow = threadIdx.x >> 6;
+    float a = 0.f;
+    if (c < C)
+        for (size_t p = blockIdx.x * 4 + prow; p < npix; p += (size_t)gridDim.x * 4) a += ldf<T>(x, p * C + c);
+    __shared__ float sh[256];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    if (prow == 0 && c < C) atomicAdd(&out[c], sh[threadIdx.x] + sh[threadIdx.x + 64] + sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
+}
+template <typename TI, typename TO>
+__global__ void k_cast(const TI* __restrict__ src, TO* __restrict__ dst, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        stf<TO>(dst, i, ldf<TI>(src, i));
+}
+
+template <typename TO>
+__global__ void k_posterior_input(const float* __restrict__ x, const uint8_t* __restrict__ s, TO* __restrict__ out,
+                                  size_t npix, int nlabels) {
+    const int C = 1 + nlabels;
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
+        stf<TO>(out, p * C, x[p]);
+        const int lab = s[p];
+        for (int c = 0; c < nlabels; ++c) stf<TO>(out, p * C + 1 + c, (c == lab ? 1.f : 0.f) - 0.5f);
+    }
+}
+
+// global average pool [B][P][C] -> [B][C] (tiny tensors: one block per (b, c))
+__global__ void k_gap_fwd(const float* __restrict__ x, float* __restrict__ y, int P, int C) {
+    const int b = blockIdx.x / C, c = blockIdx.x % C;
+    float a = 0.f;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) a += x[((size_t)b * P + p) * C + c];
+    a = wave_sum(a);
+    if (threadIdx.x == 0) y[blockIdx.x] = a / (float)P;
+}
+__global__ void k_gap_bwd(const float* __restrict__ dy, float* __restrict__ dx, int P, int C, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t b = i / ((size_t)P * C);
+        dx[i] = dy[b * C + c] / (float)P;
+    }
+}
+template <typename TO>
+__global__ void k_bcast_fwd(const float* __restrict__ z, TO* __restrict__ out, int P, int C, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t b = i / ((size_t)P * C);
+        stf<TO>(out, i, z[b * C + c]);
+    }
+}
+template <typename T>
+__global__ void k_bcast_bwd(const T* __restrict__ dout, float* __restrict__ dz, int P, int C) {
+    const int b = blockIdx.x / C, c = blockIdx.x % C;
+    float a = 0.f;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) a += ldf<T>(dout, ((size_t)b * P + p) * C + c);
+    __shared__ float sh[4];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+        dz[blockIdx.x] = t;
+    }
+}
+
+// =================================================================================================
+extern "C" {
+
+int phx_norm_stats(const void* x, int dt, float* sums, int NS, int P, int C, void* stream) {
+    PHX_REQUIRE(NS > 0 && P > 0 && C > 0, PHX_E_SHAPE, "norm_stats: bad shape");
+    PHX_DT_SWITCH(dt, T, PHX_VEC_SWITCH(C, V, {
+        int PL, threads, chunk, nchunks;
+        PHX_REQUIRE(norm_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_stats: C too large");
+        hipLaunchKernelGGL((k_norm_stats<T, V>), dim3(nchunks, NS), dim3(threads), (size_t)PL * C * 2 * sizeof(float),
+                           (hipStream_t)stream, (const T*)x, sums, P, C, PL, chunk);
+    }));
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_norm_reduce_partials(const float* partial, int T, int C, float* sums, void* stream) {
+    hipLaunchKernelGGL(k_reduce_partials, dim3(2 * C), dim3(256), 0, (hipStream_t)stream, partial, T, C, sums);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_norm_finalize(const float* sums, const float* gamma, const float* beta, float eps, int NS, int P, int C, int G,
+                      float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,
+                      float momentum, void* stream) {
+    PHX_REQUIRE(G > 0 && C % G == 0, PHX_E_SHAPE, "norm_finalize: C % G != 0");
+    PHX_REQUIRE(momentum == 0.f || (NS == 1 && G == C), PHX_E_INVAL, "moving update only for batch norm");
+    const int n = NS * G;
+    hipLaunchKernelGGL(k_norm_finalize, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, sums, gamma, beta, eps,
+                       NS, P, C, G, mean, rstd, scale, shift, moving_mean, moving_var, momentum);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_bn_infer_scale_shift(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                             float eps, int C, float* scale, float* shift, void* stream) {
+    hipLaunchKernelGGL(k_bn_infer_scale_shift, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, gamma, beta,
+                       moving_mean, moving_var, eps, C, scale, shift);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_affine_act(const void* x, int x_dt, const float* scale, const float* shift, void* y, int y_dt, int NS, int P,
+                   int C, int act, void* stream) {
+    PHX_DT_SWITCH(x_dt, TI, PHX_DT_SWITCH(y_dt, TO, PHX_VEC_SWITCH(C, V, {
+        const size_t items = (size_t)NS * P * (C / V);
+        hipLaunchKernelGGL((k_affine_act<TI, TO, V>), dim3(phx_grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const TI*)x, scale, shift, (TO*)y, P, C, items, act);
+    })));
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_norm_bwd_reduce(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
+                        const float* mean, const float* rstd, float* sums2, int NS, int P, int C, int G, int act,
+                        void* stream) {
+    PHX_DT_SWITCH(da_dt, TD, PHX_DT_SWITCH(x_dt, TX, PHX_VEC_SWITCH(C, V, {
+        int PL, threads, chunk, nchunks;
+        PHX_REQUIRE(norm_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_bwd_reduce: C too large");
+        hipLaunchKernelGGL((k_norm_bwd_reduce<TD, TX, V>), dim3(nchunks, NS), dim3(threads),
+                           (size_t)PL * C * 2 * sizeof(float), (hipStream_t)stream, (const TD*)dA, (const TX*)x, scale,
+                           shift, mean, rstd, sums2, P, C, G, PL, chunk, act);
+    })));
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_norm_bwd_finalize(const float* sums2, const float* gamma, float* S, float* dgamma, float* dbeta, int NS, int C,
+                          int G, void* stream) {
+    const int n = NS * G > C ? NS * G : C;
+    hipLaunchKernelGGL(k_norm_bwd_finalize, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, sums2, gamma, S,
+                       dgamma, dbeta, NS, C, G);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_norm_bwd_apply(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
+                       const float* mean, const float* rstd, const float* gamma, const float* S, void* dx, int dx_dt,
+                       int NS, int P, int C, int G, int act, void* stream) {
+    PHX_REQUIRE(da_dt == dx_dt, PHX_E_INVAL, "norm_bwd_apply: dA and dx dtypes must match");
+    PHX_DT_SWITCH(da_dt, TD, PHX_DT_SWITCH(x_dt, TX, PHX_VEC_SWITCH(C, V, {
+        const size_t items = (size_t)NS * P * (C / V);
+        hipLaunchKernelGGL((k_norm_bwd_apply<TD, TX, TD, V>), dim3(phx_grid_for(items, 256)), dim3(256), 0,
+                           (hipStream_t)stream, (const TD*)dA, (const TX*)x, scale, shift, mean, rstd, gamma, S, (TD*)dx,
+                           P, C, G, items, act);
+    })));
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_act_bwd(const void* dy, int dy_dt, const void* y, int y_dt, void* dpre, int dpre_dt, size_t n, int act,
+                void* stream) {
+    PHX_REQUIRE(dy_dt == dpre_dt, PHX_E_INVAL, "act_bwd: dy and dpre dtypes must match");
+    PHX_DT_SWITCH(dy_dt, TD, PHX_DT_SWITCH(y_dt, TY, {
+        hipLaunchKernelGGL((k_act_bwd<TD, TY, TD>), dim3(phx_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const TD*)dy, (const TY*)y, (TD*)dpre, n, act);
+    }));
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+#define PHX_SPATIAL_LAUNCH(kern, items_expr, ...)                                                              \
+    PHX_DT_SWITCH(dt, T, PHX_VEC_SWITCH(C, V, {                                                                \
+        const size_t items = (items_expr) * (size_t)(C / V);                                                   \
+        hipLaunchKernelGGL((kern<T, V>), dim3(phx_grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream,    \
+                           __VA_ARGS__);                                                                       \
+    }));                                                                                                       \
+    PHX_CHECK_LAUNCH();                                                                                        \
+    return PHX_OK;
+
+int phx_avgpool2x2_fwd(const void* x, int dt, void* y, int B, int H, int W, int C, void* stream) {
+    PHX_SPATIAL_LAUNCH(k_avgpool_fwd, (size_t)B * ((H + 1) / 2) * ((W + 1) / 2), (const T*)x, (T*)y, B, H, W, C)
+}
+int phx_avgpool2x2_bwd(const void* dy, int dt, void* dx, int B, int H, int W, int C, void* stream) {
+    PHX_SPATIAL_LAUNCH(k_avgpool_bwd, (size_t)B * H * W, (const T*)dy, (T*)dx, B, H, W, C)
+}
+int phx_bilinear_up2x_fwd(const void* x, int dt, void* y, int B, int h, int w, int C, void* stream) {
+    PHX_SPATIAL_LAUNCH(k_bilinear_up2x_fwd, (size_t)B * 4 * h * w, (const T*)x, (T*)y, B, h, w, C)
+}
+int phx_bilinear_up2x_bwd(const void* dy, int dt, void* dx, int B, int h, int w, int C, void* stream) {
+    PHX_SPATIAL_LAUNCH(k_bilinear_up2x_bwd, (size_t)B * h * w, (const T*)dy, (T*)dx, B, h, w, C)
+}
+
+int phx_concat2(const void* a, int Ca, const void* b, int Cb, void* out, size_t npix, int dt, void* stream) {
+    const int es = dt == PHX_BF16 ? 2 : 4, per16 = 16 / es;
+    if (Ca % per16 == 0 && Cb % per16 == 0) {
+        const size_t n = npix * (size_t)((Ca + Cb) / per16);
+        hipLaunchKernelGGL(k_concat2_v16, dim3(phx_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)a,
+                           Ca / per16, (const uint4*)b, Cb / per16, (uint4*)out, npix);
+    } else {
+        PHX_DT_SWITCH(dt, T, {
+            hipLaunchKernelGGL((k_concat2<T>), dim3(phx_grid_for(npix * (Ca + Cb), 256)), dim3(256), 0,
+                               (hipStream_t)stream, (const T*)a, Ca, (const T*)b, Cb, (T*)out, npix);
+        });
+    }
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+int phx_split2(const void* in, void* a, int Ca, void* b, int Cb, size_t npix, int dt, void* stream) {
+    const int es = dt == PHX_BF16 ? 2 : 4, per16 = 16 / es;
+    if (Ca % per16 == 0 && Cb % per16 == 0) {
+        const size_t n = npix * (size_t)((Ca + Cb) / per16);
+        hipLaunchKernelGGL(k_split2_v16, dim3(phx_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)in,
+                           (uint4*)a, Ca / per16, (uint4*)b, Cb / per16, npix);
+    } else {
+        PHX_DT_SWITCH(dt, T, {
+            hipLaunchKernelGGL((k_split2<T>), dim3(phx_grid_for(npix * (Ca + Cb), 256)), dim3(256), 0,
+                               (hipStream_t)stream, (const T*)in, (T*)a, Ca, (T*)b, Cb, npix);
+        });
+    }
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+int phx_add_inplace(void* dst, const void* src, size_t n, int dt, void* stream) {
+    PHX_DT_SWITCH(dt, T, {
+        hipLaunchKernelGGL((k_add_inplace<T>), dim3(phx_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (T*)dst,
+                           (const T*)src, n);
+    });
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+int phx_channel_sum_accumulate(const void* x, int dt, float* out, size_t npix, int C, void* stream) {
+    int gx = (int)((npix + 63) / 64);
+    if (gx > 256) gx = 256;
+    if (gx < 1) gx = 1;
+    PHX_DT_SWITCH(dt, T, {
+        hipLaunchKernelGGL((k_channel_sum<T>), dim3(gx, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const T*)x, out,
+                           npix, C);
+    });
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+int phx_cast(const void* src, int src_dt, void* dst, int dst_dt, size_t n, void* stream) {
+    PHX_DT_SWITCH(src_dt, TI, PHX_DT_SWITCH(dst_dt, TO, {
+        hipLaunchKernelGGL((k_cast<TI, TO>), dim3(phx_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const TI*)src, (TO*)dst, n);
+    }));
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+int phx_posterior_input(const float* x, const uint8_t* s, void* out, int out_dt, size_t npix, int nlabels, void* stream) {
+    PHX_DT_SWITCH(out_dt, TO, {
+        hipLaunchKernelGGL((k_posterior_input<TO>), dim3(phx_grid_for(npix, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                           s, (TO*)out, npix, nlabels);
+    });
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+int phx_global_avgpool_fwd(const float* x, float* y, int B, int P, int C, void* stream) {
+    hipLaunchKernelGGL(k_gap_fwd, dim3(B * C), dim3(64), 0, (hipStream_t)stream, x, y, P, C);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+int phx_global_avgpool_bwd(const float* dy, float* dx, int B, int P, int C, void* stream) {
+    const size_t n = (size_t)B * P * C;
+    hipLaunchKernelGGL(k_gap_bwd, dim3(phx_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, P, C, n);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+int phx_broadcast_pixels_fwd(const float* z, void* out, int out_dt, int B, int P, int C, void* stream) {
+    const size_t n = (size_t)B * P * C;
+    PHX_DT_SWITCH(out_dt, TO, {
+        hipLaunchKernelGGL((k_bcast_fwd<TO>), dim3(phx_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, z, (TO*)out,
+                           P, C, n);
+    });
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+int phx_broadcast_pixels_bwd(const void* dout, int dt, float* dz, int B, int P, int C, void* stream) {
+    PHX_DT_SWITCH(dt, T, {
+        hipLaunchKernelGGL((k_bcast_bwd<T>), dim3(B * C), dim3(256), 0, (hipStream_t)stream, (const T*)dout, dz, P, C);
+    });
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+// libphx runtime plumbing: errors, streams, events, hipGraph capture/replay, copies.
+// Replaces what tf.Session owns in the reference (phiseg/phiseg_model.py:151-157, 194).
+#include <stdarg.h>
+
+#include "phx_common.h"
+
+static thread_local char g_err[512] = "";
+
+void phx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int phx_abi_version(void) { return 1; }
+
+int phx_last_error(char* buf, size_t n) {
+    if (!buf || n == 0) return PHX_E_INVAL;
+    strncpy(buf, g_err, n - 1);
+    buf[n - 1] = 0;
+    return PHX_OK;
+}
+
+int phx_device_info(int* cu_count, int* clock_khz, size_t* hbm_bytes, char* name, size_t name_n) {
+    int dev = 0;
+    PHX_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    PHX_CHECK_HIP(hipGetDeviceProperties(&p, dev));
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (clock_khz) *clock_khz = p.clockRate;
+    if (hbm_bytes) *hbm_bytes = p.totalGlobalMem;
+    if (name && name_n) {
+        snprintf(name, name_n, "%s (%s)", p.name, p.gcnArchName);
+    }
+    return PHX_OK;
+}
+
+int phx_stream_create(void** stream) {
+    hipStream_t s;
+    PHX_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void*)s;
+    return PHX_OK;
+}
+int phx_stream_destroy(void* stream) { PHX_CHECK_HIP(hipStreamDestroy((hipStream_t)stream)); return PHX_OK; }
+int phx_stream_sync(void* stream) { PHX_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream)); return PHX_OK; }
+
+int phx_event_create(void** ev) {
+    hipEvent_t e;
+    PHX_CHECK_HIP(hipEventCreate(&e));
+    *ev = (void*)e;
+    return PHX_OK;
+}
+int phx_event_destroy(void* ev) { PHX_CHECK_HIP(hipEventDestroy((hipEvent_t)ev)); return PHX_OK; }
+int phx_event_record(void* ev, void* stream) {
+    PHX_CHECK_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return PHX_OK;
+}
+int phx_event_sync(void* ev) { PHX_CHECK_HIP(hipEventSynchronize((hipEvent_t)ev)); return PHX_OK; }
+int phx_event_elapsed_ms(void* start, void* stop, float* ms) {
+    PHX_CHECK_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return PHX_OK;
+}
+int phx_stream_wait_event(void* stream, void* ev) {
+    PHX_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0));
+    return PHX_OK;
+}
+
+int phx_graph_begin_capture(void* stream) {
+    PHX_CHECK_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    return PHX_OK;
+}
+int phx_graph_end_capture(void* stream, void** graph_exec) {
+    hipGraph_t g;
+    PHX_CHECK_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+    hipGraphExec_t ge;
+    hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) {
+        phx_set_error("hipGraphInstantiate -> %s", hipGetErrorString(e));
+        return PHX_E_RUNTIME;
+    }
+    *graph_exec = (void*)ge;
+    return PHX_OK;
+}
+int phx_graph_launch(void* graph_exec, void* stream) {
+    PHX_CHECK_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+    return PHX_OK;
+}
+int phx_graph_destroy(void* graph_exec) {
+    PHX_CHECK_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return PHX_OK;
+}
+
+int phx_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+    PHX_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return PHX_OK;
+}
+int phx_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+    PHX_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return PHX_OK;
+}
+int phx_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+    PHX_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PHX_OK;
+}
+int phx_memset(void* dst, int value, size_t bytes, void* stream) {
+    PHX_CHECK_HIP(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+    return PHX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,438 @@
+"""Per-kernel parity (MI355X): every C-ABI entry point of libphx.so against the CPU oracle
+(oracle.tf1_ops restates the TF 1.12 op; torch autograd of the oracle gives the expected gradients).
+
+Tolerances: fp32 kernels 1e-5 relative-to-max (fp32 accumulation order); bf16 storage paths are compared
+with an oracle evaluated on the SAME bf16-rounded inputs, so the only differences are fp32 accumulation
+order and the final bf16 rounding of the output (2^-8 relative)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import philox
+from oracle import tf1_ops as T
+
+pytestmark = pytest.mark.gpu
+
+F32, BF16 = 0, 1
+
+
+@pytest.fixture(scope="module")
+def L():
+    from phiseg_code_amd import runtime as rt
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return rt.lib()
+
+
+def S():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dev(a, dt=F32):
+    t = torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).cuda()
+    return t.to(torch.bfloat16).contiguous() if dt == BF16 else t.contiguous()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.float().cpu().double().numpy()
+
+
+def rounded(a, dt):
+    """value of `a` after storage in dt (so the oracle sees what the kernel sees)."""
+    t = torch.as_tensor(a, dtype=torch.float32)
+    return (t.to(torch.bfloat16).float() if dt == BF16 else t).double()
+
+
+def tdt(dt):
+    return torch.bfloat16 if dt == BF16 else torch.float32
+
+
+def close(got, ref, rel, what=""):
+    ref = np.asarray(ref, dtype=np.float64)
+    scale = max(np.abs(ref).max(), 1e-30)
+    err = np.abs(np.asarray(got, dtype=np.float64) - ref).max() / scale
+    assert err <= rel, "%s: rel-to-max err %.3e > %.1e" % (what, err, rel)
+
+
+RNG = np.random.default_rng(0)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_philox_normal_matches_oracle(L):
+    step = torch.tensor([7], dtype=torch.int32).cuda()
+    for (B, per, stream, off) in [(3, 2048, 5, 0), (2, 37, 33, 10)]:
+        out = torch.empty(B, per, dtype=torch.float32).cuda()
+        L.philox_normal(out.data_ptr(), B, per, 42 + (1 << 40), step.data_ptr(), stream, off, S())
+        ref = philox.normal(42 + (1 << 40), 7, stream, B, per, sample_offset=off, dtype=np.float64)
+        np.testing.assert_allclose(host(out), ref, rtol=0, atol=3e-6)
+
+
+CONV_DIRECT_CASES = [
+    # B, H, W, Cin, Cout, k, act, bias, xdt, ydt
+    (2, 16, 16, 3, 32, 3, "relu", False, F32, F32),
+    (2, 64, 64, 1, 4, 3, "identity", True, F32, F32),
+    (3, 8, 8, 24, 2, 1, "softplus", True, F32, F32),
+    (2, 4, 4, 24, 2, 3, "identity", True, F32, F32),
+    (5, 2, 2, 24, 24, 3, "relu", False, F32, F32),
+    (2, 32, 32, 2, 64, 3, "identity", False, F32, BF16),
+    (2, 16, 16, 128, 2, 1, "identity", True, BF16, F32),
+    (1, 6, 6, 38, 32, 1, "relu", False, BF16, BF16),
+    (2, 3, 3, 20, 17, 3, "identity", True, F32, F32),
+    (1, 128, 128, 32, 32, 3, "identity", False, F32, F32),
+]
+ACT = {"identity": 0, "relu": 1, "softplus": 2}
+
+
+def oracle_conv(x, w, b, act):
+    y = T.conv2d_same(x, w)
+    if b is not None:
+        y = T.bias_add(y, b)
+    return {"identity": lambda v: v, "relu": T.relu, "softplus": T.softplus}[act](y)
+
+
+@pytest.mark.parametrize("case", CONV_DIRECT_CASES)
+def test_conv2d_direct_fwd_dgrad_wgrad(L, case):
+    B, H, W, Cin, Cout, k, act, use_bias, xdt, ydt = case
+    x = RNG.standard_normal((B, H, W, Cin))
+    w = RNG.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)
+    b = RNG.standard_normal(Cout) * 0.3
+    xr = rounded(x, xdt).requires_grad_(True)
+    wr = torch.as_tensor(w, dtype=torch.float32).double().requires_grad_(True)
+    br = torch.as_tensor(b, dtype=torch.float32).double().requires_grad_(True)
+    yr = oracle_conv(xr, wr, br if use_bias else None, act)
+    xd, wd, bd = dev(x, xdt), dev(w), dev(b)
+    y = torch.empty(B, H, W, Cout, dtype=tdt(ydt)).cuda()
+    stats = torch.zeros(2 * Cout, dtype=torch.float32).cuda()
+    L.conv2d_direct(xd.data_ptr(), xdt, wd.data_ptr(), bd.data_ptr() if use_bias else None, y.data_ptr(), ydt,
+                    B, H, W, Cin, Cout, k, ACT[act], 0, stats.data_ptr(), S())
+    tol = 1e-5 if ydt == F32 else 6e-3
+    close(host(y), yr.detach().numpy(), tol, "fwd")
+    yst = host(y)
+    close(host(stats)[0::2], yst.sum(axis=(0, 1, 2)), 1e-4 if ydt == F32 else 1e-3, "stats sum")
+    close(host(stats)[1::2], (yst ** 2).sum(axis=(0, 1, 2)), 1e-4 if ydt == F32 else 1e-3, "stats sumsq")
+    # gradients of sum(conv(x, w) * dy) (pre-activation): dgrad via transpose_flip, wgrad kernel
+    dy = RNG.standard_normal((B, H, W, Cout))
+    dyr = rounded(dy, ydt)
+    pre = T.conv2d_same(xr, wr) + (br.reshape(1, 1, 1, -1) if use_bias else 0.0)
+    (pre * dyr).sum().backward()
+    dyd = dev(dy, ydt)
+    dx = torch.empty(B, H, W, Cin, dtype=tdt(xdt)).cuda()
+    L.conv2d_direct(dyd.data_ptr(), ydt, wd.data_ptr(), None, dx.data_ptr(), xdt, B, H, W, Cin, Cout, k, 0, 1,
+                    None, S())
+    close(host(dx), xr.grad.numpy(), 1e-5 if xdt == F32 else 6e-3, "dgrad")
+    dw = torch.zeros(k, k, Cin, Cout, dtype=torch.float32).cuda()
+    db = torch.zeros(Cout, dtype=torch.float32).cuda()
+    L.conv2d_direct_wgrad(xd.data_ptr(), xdt, dyd.data_ptr(), ydt, dw.data_ptr(), db.data_ptr(), B, H, W, Cin,
+                          Cout, k, S())
+    close(host(dw), wr.grad.numpy(), 2e-5, "wgrad")
+    if use_bias:
+        close(host(db), br.grad.numpy(), 2e-5, "dbias")
+
+
+MFMA_CASES = [
+    # B, H, W, K(Cin), N(Cout)
+    (2, 16, 16, 32, 32),
+    (1, 32, 32, 64, 64),
+    (3, 8, 8, 64, 128),
+    (5, 4, 4, 192, 64),
+    (40, 2, 2, 32, 96),
+    (2, 12, 12, 32, 64),
+    (3, 3, 3, 64, 32),
+    (1, 128, 128, 32, 32),
+    (2, 64, 64, 128, 192),
+    (1, 48, 48, 96, 32),
+]
+
+
+@pytest.mark.parametrize("case", MFMA_CASES)
+def test_conv3x3_mfma_fwd_dgrad_wgrad(L, case):
+    B, H, W, K, N = case
+    x = RNG.standard_normal((B, H, W, K))
+    w = RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K)
+    b = RNG.standard_normal(N) * 0.3
+    xr = rounded(x, BF16).requires_grad_(True)
+    wr = rounded(w, BF16).requires_grad_(True)       # the packed filter is bf16
+    xd, wd, bd = dev(x, BF16), dev(w), dev(b)
+    wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    wg = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    L.pack_conv3x3_bf16(wd.data_ptr(), wf.data_ptr(), wg.data_ptr(), K, N, S())
+    ntile = L.conv3x3_mfma_bf16_tiles(B, H, W)
+    part = torch.zeros(ntile, 2, N, dtype=torch.float32).cuda()
+    y = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
+    L.conv3x3_mfma_bf16(xd.data_ptr(), wf.data_ptr(), y.data_ptr(), bd.data_ptr(), 1, part.data_ptr(), B, H, W, K,
+                        N, S())
+    yr = oracle_conv(xr, wr, torch.as_tensor(b, dtype=torch.float32).double(), "relu")
+    close(host(y), yr.detach().numpy(), 6e-3, "mfma fwd")
+    yst = host(y)
+    sums = torch.zeros(N, 2, dtype=torch.float32).cuda()
+    L.norm_reduce_partials(part.data_ptr(), ntile, N, sums.data_ptr(), S())
+    close(host(sums)[:, 0], yst.sum(axis=(0, 1, 2)), 1e-3, "epilogue sum")
+    close(host(sums)[:, 1], (yst ** 2).sum(axis=(0, 1, 2)), 1e-3, "epilogue sumsq")
+    # no-bias identity
+    L.conv3x3_mfma_bf16(xd.data_ptr(), wf.data_ptr(), y.data_ptr(), None, 0, None, B, H, W, K, N, S())
+    pre = T.conv2d_same(xr, wr)
+    close(host(y), pre.detach().numpy(), 6e-3, "mfma fwd id")
+    dy = RNG.standard_normal((B, H, W, N))
+    dyr = rounded(dy, BF16)
+    (pre * dyr).sum().backward()
+    dyd = dev(dy, BF16)
+    dx = torch.empty(B, H, W, K, dtype=torch.bfloat16).cuda()
+    L.conv3x3_mfma_bf16(dyd.data_ptr(), wg.data_ptr(), dx.data_ptr(), None, 0, None, B, H, W, N, K, S())
+    close(host(dx), xr.grad.numpy(), 6e-3, "mfma dgrad")
+    dw = torch.zeros(3, 3, K, N, dtype=torch.float32).cuda()
+    L.conv3x3_wgrad_mfma_bf16(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), B, H, W, K, N, S())
+    close(host(dw), wr.grad.numpy(), 1e-4, "mfma wgrad")
+
+
+NORM_CASES = [
+    # kind, B, H, W, C, G, dt
+    ("batch", 3, 8, 8, 32, None, F32),
+    ("batch", 2, 16, 16, 6, None, F32),
+    ("batch", 2, 16, 16, 192, None, BF16),
+    ("group", 3, 8, 8, 32, 2, F32),
+    ("group", 2, 4, 4, 24, 2, F32),
+    ("group", 2, 8, 8, 192, 12, BF16),
+    ("instance", 3, 8, 8, 12, None, F32),
+]
+
+
+@pytest.mark.parametrize("case", NORM_CASES)
+def test_norm_fwd_bwd(L, case):
+    kind, B, H, W, C, G, dt = case
+    x = RNG.standard_normal((B, H, W, C)) * 1.5 + 0.3
+    gamma = 1.0 + 0.2 * RNG.standard_normal(C)
+    beta = 0.1 * RNG.standard_normal(C)
+    xr = rounded(x, dt).requires_grad_(True)
+    gr = torch.as_tensor(gamma, dtype=torch.float32).double().requires_grad_(True)
+    br = torch.as_tensor(beta, dtype=torch.float32).double().requires_grad_(True)
+    if kind == "batch":
+        NS, P, GG, eps = 1, B * H * W, C, 1e-3
+        yr, mean_r, varu_r = T.batch_norm_train(xr, gr, br)
+    elif kind == "group":
+        NS, P, GG, eps = B, H * W, G, 1e-5
+        yr = T.group_norm(xr, gr, br, G)
+    else:
+        NS, P, GG, eps = B, H * W, C, 1e-5
+        yr = T.instance_norm(xr, gr, br)
+    ar = T.relu(yr)
+    xd, gd, bd = dev(x, dt), dev(gamma), dev(beta)
+    sums = torch.zeros(NS, C, 2, dtype=torch.float32).cuda()
+    L.norm_stats(xd.data_ptr(), dt, sums.data_ptr(), NS, P, C, S())
+    mean = torch.empty(NS * GG, dtype=torch.float32).cuda()
+    rstd = torch.empty_like(mean)
+    scale = torch.empty(NS * C, dtype=torch.float32).cuda()
+    shift = torch.empty_like(scale)
+    mm = dev(0.1 * RNG.standard_normal(C))
+    mv = dev(1.0 + 0.3 * RNG.random(C))
+    mm0, mv0 = host(mm).copy(), host(mv).copy()
+    L.norm_finalize(sums.data_ptr(), gd.data_ptr(), bd.data_ptr(), eps, NS, P, C, GG, mean.data_ptr(),
+                    rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                    mm.data_ptr() if kind == "batch" else None, mv.data_ptr() if kind == "batch" else None,
+                    0.01 if kind == "batch" else 0.0, S())
+    a = torch.empty(B, H, W, C, dtype=tdt(dt)).cuda()
+    L.affine_act(xd.data_ptr(), dt, scale.data_ptr(), shift.data_ptr(), a.data_ptr(), dt, NS, P, C, 1, S())
+    close(host(a), ar.detach().numpy(), 2e-5 if dt == F32 else 6e-3, kind + " fwd")
+    if kind == "batch":
+        close(host(mm), mm0 - (mm0 - mean_r.detach().numpy()) * 0.01, 1e-5, "moving_mean")
+        close(host(mv), mv0 - (mv0 - varu_r.detach().numpy()) * 0.01, 1e-5, "moving_var")
+    dA = RNG.standard_normal((B, H, W, C))
+    dAr = rounded(dA, dt)
+    (ar * dAr).sum().backward()
+    dAd = dev(dA, dt)
+    sums2 = torch.zeros(NS, C, 2, dtype=torch.float32).cuda()
+    L.norm_bwd_reduce(dAd.data_ptr(), dt, xd.data_ptr(), dt, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                      rstd.data_ptr(), sums2.data_ptr(), NS, P, C, GG, 1, S())
+    Sg = torch.empty(NS * GG * 2, dtype=torch.float32).cuda()
+    dgamma = torch.zeros(C, dtype=torch.float32).cuda()
+    dbeta = torch.zeros(C, dtype=torch.float32).cuda()
+    L.norm_bwd_finalize(sums2.data_ptr(), gd.data_ptr(), Sg.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), NS, C,
+                        GG, S())
+    dx = torch.empty(B, H, W, C, dtype=tdt(dt)).cuda()
+    L.norm_bwd_apply(dAd.data_ptr(), dt, xd.data_ptr(), dt, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                     rstd.data_ptr(), gd.data_ptr(), Sg.data_ptr(), dx.data_ptr(), dt, NS, P, C, GG, 1, S())
+    close(host(dx), xr.grad.numpy(), 5e-5 if dt == F32 else 8e-3, kind + " dx")
+    close(host(dgamma), gr.grad.numpy(), 5e-5 if dt == F32 else 2e-3, kind + " dgamma")
+    close(host(dbeta), br.grad.numpy(), 5e-5 if dt == F32 else 2e-3, kind + " dbeta")
+
+
+def test_bn_infer_scale_shift(L):
+    C = 24
+    g, b, mm, mv = RNG.random(C) + 0.5, RNG.standard_normal(C), RNG.standard_normal(C), RNG.random(C) + 0.5
+    x = RNG.standard_normal((2, 4, 4, C))
+    sc, sh = torch.empty(C).cuda(), torch.empty(C).cuda()
+    gd, bd, mmd, mvd, xd = dev(g), dev(b), dev(mm), dev(mv), dev(x)      # keep the device buffers alive
+    L.bn_infer_scale_shift(gd.data_ptr(), bd.data_ptr(), mmd.data_ptr(), mvd.data_ptr(), 1e-3, C,
+                           sc.data_ptr(), sh.data_ptr(), S())
+    y = torch.empty(2, 4, 4, C).cuda()
+    L.affine_act(xd.data_ptr(), F32, sc.data_ptr(), sh.data_ptr(), y.data_ptr(), F32, 1, 32, C, 0, S())
+    f = lambda v: torch.as_tensor(v, dtype=torch.float32).double()
+    ref = T.batch_norm_infer(f(x), f(g), f(b), f(mm), f(mv))
+    close(host(y), ref.numpy(), 1e-5)
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 16, F32), (2, 5, 3, 6, F32), (1, 6, 6, 32, BF16), (3, 2, 2, 24, F32)])
+def test_avgpool_and_bilinear(L, case):
+    B, H, W, C, dt = case
+    x = RNG.standard_normal((B, H, W, C))
+    xr = rounded(x, dt).requires_grad_(True)
+    xd = dev(x, dt)
+    tol = 1e-6 if dt == F32 else 6e-3
+    # avg pool
+    pr = T.avg_pool_2x2_same(xr)
+    OH, OW = (H + 1) // 2, (W + 1) // 2
+    p = torch.empty(B, OH, OW, C, dtype=tdt(dt)).cuda()
+    L.avgpool2x2_fwd(xd.data_ptr(), dt, p.data_ptr(), B, H, W, C, S())
+    close(host(p), pr.detach().numpy(), tol, "pool fwd")
+    dp = RNG.standard_normal((B, OH, OW, C))
+    (pr * rounded(dp, dt)).sum().backward()
+    dx = torch.empty(B, H, W, C, dtype=tdt(dt)).cuda()
+    dpd = dev(dp, dt)
+    L.avgpool2x2_bwd(dpd.data_ptr(), dt, dx.data_ptr(), B, H, W, C, S())
+    close(host(dx), xr.grad.numpy(), tol, "pool bwd")
+    # bilinear x2 (TF1 legacy)
+    xr.grad = None
+    ur = T.resize_bilinear_legacy(xr, 2 * H, 2 * W)
+    u = torch.empty(B, 2 * H, 2 * W, C, dtype=tdt(dt)).cuda()
+    L.bilinear_up2x_fwd(xd.data_ptr(), dt, u.data_ptr(), B, H, W, C, S())
+    close(host(u), ur.detach().numpy(), tol, "bilinear fwd")
+    du = RNG.standard_normal((B, 2 * H, 2 * W, C))
+    (ur * rounded(du, dt)).sum().backward()
+    dud = dev(du, dt)
+    L.bilinear_up2x_bwd(dud.data_ptr(), dt, dx.data_ptr(), B, H, W, C, S())
+    close(host(dx), xr.grad.numpy(), tol if dt == F32 else 1e-2, "bilinear bwd")
+
+
+def test_concat_split_add_cast_misc(L):
+    for (Ca, Cb, dt) in [(32, 32, BF16), (128, 64, BF16), (32, 6, F32), (1, 2, F32), (8, 4, F32)]:
+        a, b = RNG.standard_normal((2, 4, 4, Ca)), RNG.standard_normal((2, 4, 4, Cb))
+        ad, bd = dev(a, dt), dev(b, dt)
+        out = torch.empty(2, 4, 4, Ca + Cb, dtype=tdt(dt)).cuda()
+        L.concat2(ad.data_ptr(), Ca, bd.data_ptr(), Cb, out.data_ptr(), 32, dt, S())
+        ref = torch.cat([ad, bd], dim=3)
+        assert torch.equal(out, ref)
+        a2, b2 = torch.empty_like(ad), torch.empty_like(bd)
+        L.split2(out.data_ptr(), a2.data_ptr(), Ca, b2.data_ptr(), Cb, 32, dt, S())
+        assert torch.equal(a2, ad) and torch.equal(b2, bd)
+        L.add_inplace(a2.data_ptr(), ad.data_ptr(), a2.numel(), dt, S())
+        close(host(a2), 2 * host(ad), 1e-2 if dt == BF16 else 1e-7)
+        cs = torch.zeros(Ca, dtype=torch.float32).cuda()
+        L.channel_sum_accumulate(ad.data_ptr(), dt, cs.data_ptr(), 32, Ca, S())
+        close(host(cs), host(ad).sum(axis=(0, 1, 2)), 1e-5, "channel_sum")
+    x = RNG.standard_normal((2, 8, 8, 1)).astype(np.float32)
+    s = RNG.integers(0, 4, (2, 8, 8)).astype(np.uint8)
+    out = torch.empty(2, 8, 8, 5).cuda()
+    xd, sdv = dev(x), torch.as_tensor(s).cuda()
+    L.posterior_input(xd.data_ptr(), sdv.data_ptr(), out.data_ptr(), F32, 128, 4, S())
+    ref = np.concatenate([x, np.eye(4)[s] - 0.5], axis=-1)
+    close(host(out), ref, 1e-7)
+    z = RNG.standard_normal((3, 6))
+    bo = torch.empty(3, 10, 6).cuda()
+    zd = dev(z)
+    L.broadcast_pixels_fwd(zd.data_ptr(), bo.data_ptr(), F32, 3, 10, 6, S())
+    close(host(bo), np.repeat(z[:, None, :], 10, 1), 1e-6)
+    dz = torch.empty(3, 6).cuda()
+    L.broadcast_pixels_bwd(bo.data_ptr(), F32, dz.data_ptr(), 3, 10, 6, S())
+    close(host(dz), 10 * z, 1e-5)
+    g = torch.empty(3, 6).cuda()
+    L.global_avgpool_fwd(bo.data_ptr(), g.data_ptr(), 3, 10, 6, S())
+    close(host(g), z, 1e-5)
+    gb = torch.empty(3, 10, 6).cuda()
+    L.global_avgpool_bwd(zd.data_ptr(), gb.data_ptr(), 3, 10, 6, S())
+    close(host(gb), np.repeat(z[:, None, :], 10, 1) / 10, 1e-6)
+
+
+@pytest.mark.parametrize("C,H,Ls", [(2, 64, 5), (4, 48, 5), (2, 32, 1), (3, 16, 3)])
+def test_residual_ce(L, C, H, Ls):
+    B = 3
+    shifts = list(range(Ls))
+    s_np = [RNG.standard_normal((B, H >> sh, H >> sh, C)) for sh in shifts]
+    lab = RNG.integers(0, C, (B, H, H)).astype(np.uint8)
+    sr = [torch.as_tensor(v, dtype=torch.float32).double().requires_grad_(True) for v in s_np]
+    oh = T.one_hot(torch.as_tensor(lab), C, torch.float64)
+    full = [T.resize_nearest(v, H, H) for v in sr]
+    acc, losses_r, tot = None, [None] * Ls, 0.0
+    for l in reversed(range(Ls)):
+        acc = full[l] if acc is None else acc + full[l]
+        losses_r[l] = T.multinoulli_loss_with_logits(oh, acc)
+        tot = tot + 0.7 * losses_r[l]
+    tot.backward()
+    sd = [dev(v) for v in s_np]
+    dsd = [torch.zeros_like(v) for v in sd]
+    from phiseg_code_amd import runtime as rt
+    losses = torch.zeros(8 + 512).cuda()
+    s_out = torch.empty(B, H, H, C).cuda()
+    sm = torch.empty(B, H, H, C).cuda()
+    labd = torch.as_tensor(lab).cuda()
+    L.residual_ce(rt.ptr_array([v.data_ptr() for v in sd]), rt.ptr_array([v.data_ptr() for v in dsd]),
+                  rt.int_array(shifts), Ls, labd.data_ptr(), B, H, H, C, 0.7, 1.0 / B,
+                  losses.data_ptr(), s_out.data_ptr(), sm.data_ptr(), S())
+    close(host(losses)[:Ls], [float(v) for v in losses_r], 2e-5, "ce losses")
+    close(host(s_out), acc.detach().numpy(), 1e-5, "s_out")
+    close(host(sm), torch.softmax(acc, dim=-1).detach().numpy(), 1e-5, "softmax")
+    for l in range(Ls):
+        close(host(dsd[l]), sr[l].grad.numpy(), 3e-5, "ds[%d]" % l)
+
+
+def test_kl_and_adam(L):
+    n, B = 2 * 32 * 32 * 2, 2
+    mu0, mu1 = RNG.standard_normal(n), RNG.standard_normal(n)
+    s0, s1 = RNG.random(n) + 0.2, RNG.random(n) + 0.2
+    f = lambda v: torch.as_tensor(v, dtype=torch.float32).double().reshape(B, -1).requires_grad_(True)
+    a, b, c, d = f(mu0), f(s0), f(mu1), f(s1)
+    kl = 16 * T.kl_two_gauss_with_diag_cov(a, b, c, d)
+    (0.5 * kl).backward()
+    loss = torch.zeros(1).cuda()
+    outs = [torch.empty(n).cuda() for _ in range(4)]
+    ins = [dev(mu0), dev(s0), dev(mu1), dev(s1)]
+    L.kl_diag_gauss(ins[0].data_ptr(), ins[1].data_ptr(), ins[2].data_ptr(), ins[3].data_ptr(), n, 16.0,
+                    1.0 / B, 0.5, loss.data_ptr(), *[o.data_ptr() for o in outs], S())
+    close(host(loss), [float(kl)], 1e-5, "kl")
+    for o, r in zip(outs, (a, b, c, d)):
+        close(host(o), r.grad.reshape(-1).numpy(), 2e-5, "kl grad")
+    # Adam, 3 steps, n not a multiple of 4
+    n = 1003
+    p, g = RNG.standard_normal(n), RNG.standard_normal(n)
+    pd, gd = dev(p), dev(g)
+    md, vd = torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    step = torch.zeros(1, dtype=torch.int32).cuda()
+    lr = torch.tensor([1e-3]).cuda()
+    pr = torch.as_tensor(p, dtype=torch.float32).double()
+    gr = torch.as_tensor(g, dtype=torch.float32).double()
+    mr, vr = torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+    for t in range(3):
+        L.adam_tf1(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), n, lr.data_ptr(), 0.9, 0.999, 1e-8,
+                   step.data_ptr(), S())
+        L.step_increment(step.data_ptr(), S())
+        pr, mr, vr = T.adam_tf1_step(pr, gr, mr, vr, t + 1, 1e-3)
+    np.testing.assert_allclose(host(pd), pr.numpy(), rtol=0, atol=2e-6)
+    assert int(step.cpu()[0]) == 3
+
+
+def test_reparam_and_graph_capture(L):
+    B, per = 4, 2 * 8 * 8
+    mu, sg = RNG.standard_normal((B, per)), RNG.random((B, per)) + 0.1
+    step = torch.tensor([2], dtype=torch.int32).cuda()
+    z = torch.empty(B, per).cuda()
+    mud, sgd = dev(mu), dev(sg)
+    st = ctypes.c_void_p()
+    L.stream_create(ctypes.byref(st))
+    torch.cuda.synchronize()
+    L.graph_begin_capture(st)
+    L.reparam_fwd(mud.data_ptr(), sgd.data_ptr(), z.data_ptr(), B, per, 42, step.data_ptr(), 3, 0, st)
+    L.step_increment(step.data_ptr(), st)
+    ge = ctypes.c_void_p()
+    L.graph_end_capture(st, ctypes.byref(ge))
+    for it in range(2):          # the replay must pick up the incremented device-side step
+        L.graph_launch(ge, st)
+        L.stream_sync(st)
+        eps = philox.normal(42, 2 + it, 3, B, per, dtype=np.float64)
+        close(host(z), np.float32(mu).astype(np.float64) + np.float32(sg).astype(np.float64) * eps, 1e-5)
+    dz = RNG.standard_normal((B, per))
+    dsg = torch.empty(B, per).cuda()
+    dzd = dev(dz)
+    L.reparam_bwd(dzd.data_ptr(), dsg.data_ptr(), B, per, 42, step.data_ptr(), 3, 0, S())
+    close(host(dsg), np.float32(dz).astype(np.float64) * philox.normal(42, 4, 3, B, per, dtype=np.float64), 1e-5)
+    L.graph_destroy(ge)
+    L.stream_destroy(st)
