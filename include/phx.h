@@ -82,11 +82,13 @@ int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, i
  * P=H*W, G=groups;  instance norm: NS=B, P=H*W, G=C.
  *   sums[NS][C][2]   per-channel {sum x, sum x^2}            (phx_norm_stats accumulates; zero it first)
  *   mean/rstd[NS][G], scale/shift[NS][C]: y = act(x*scale+shift), scale = gamma*rstd, shift = beta-mean*scale */
-int phx_norm_stats(const void* x, int dt, float* sums, int NS, int P, int C, void* stream);
+/* pivot (nullable) [NS][C]: when given, the kernel writes pivot = x[ns][pixel 0][c] and accumulates the sums of
+ * (x - pivot), (x - pivot)^2 instead -- no catastrophic cancellation when var << mean^2 (few samples). */
+int phx_norm_stats(const void* x, int dt, float* sums, float* pivot, int NS, int P, int C, void* stream);
 /* partial[T][2][C] (conv epilogue rows) -> sums[1][C][2] */
 int phx_norm_reduce_partials(const float* partial, int T, int C, float* sums, void* stream);
-int phx_norm_finalize(const float* sums, const float* gamma, const float* beta, float eps, int NS, int P, int C,
-                      int G, float* mean, float* rstd, float* scale, float* shift,
+int phx_norm_finalize(const float* sums, const float* pivot, const float* gamma, const float* beta, float eps, int NS,
+                      int P, int C, int G, float* mean, float* rstd, float* scale, float* shift,
                       float* moving_mean, float* moving_var, float momentum /* 0 => no moving update */,
                       void* stream);
 /* inference-mode batch norm: scale/shift from the moving statistics */
@@ -162,6 +164,9 @@ int phx_adam_tf1(float* p, const float* g, float* m, float* v, size_t n, const f
                  float beta2, float eps, const int32_t* step_dev, void* stream);
 int phx_step_increment(int32_t* step_dev, void* stream);
 int phx_sum_scalars(const float* in, int n, float* out, void* stream);
+/* out = sum_i weights[i] * (*ptrs[i]), n <= 16; ptrs / weights are HOST arrays of device pointers / floats
+ * (loss_tot of phiseg_model.py:118-130) */
+int phx_weighted_sum(const float* const* ptrs, const float* weights, int n, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,22 @@
+"""phiseg_code_amd -- MI355X-native engine for the PHiSeg ELBO hot path.
+
+Layout (mirrors the reference's top-level packages so it is a drop-in for that path):
+  tfwrapper/   layers, normalisation, utils      (reference: tfwrapper/)
+  phiseg/      model_zoo, experiments, phiseg_model   (reference: phiseg/)
+  config/      system                             (reference: config/)
+  graph.py engine.py runtime.py distributed.py    symbolic graph -> HIP launch plan -> hipGraph
+  csrc/        hand-written HIP kernels + the C ABI (include/phx.h) -> libphx.so
+"""
+import sys
+
+
+def install_dropin_aliases():
+    """Make ``import tfwrapper.layers`` / ``from phiseg.model_zoo import posteriors`` / ``import config.system``
+    resolve to this package, the way scripts written against the reference import them."""
+    import importlib
+    for top in ("tfwrapper", "phiseg", "config"):
+        mod = importlib.import_module("phiseg_code_amd." + top)
+        sys.modules.setdefault(top, mod)
+        for name, m in list(sys.modules.items()):
+            if name.startswith("phiseg_code_amd.%s." % top):
+                sys.modules.setdefault(name[len("phiseg_code_amd."):], m)

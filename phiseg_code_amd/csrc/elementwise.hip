@@ -48,21 +48,29 @@ template <typename T> struct VecIO<T, 1> {
 // =================================================================================================
 // normalisation statistics: sums[ns][c][2] += {sum x, sum x^2} over the P pixels of sample-group ns
 template <typename T, int V>
-__global__ void k_norm_stats(const T* __restrict__ x, float* __restrict__ sums, int P, int C, int PL, int chunk) {
+__global__ void k_norm_stats(const T* __restrict__ x, float* __restrict__ sums, float* __restrict__ pivot, int P,
+                             int C, int PL, int chunk) {
     const int CV = C / V;
     const int ns = blockIdx.y;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
     extern __shared__ float red[];   // [PL][C][2]
-    float s1[V], s2[V];
+    float s1[V], s2[V], pv[V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) s1[j] = s2[j] = 0.f;
+    for (int j = 0; j < V; ++j) s1[j] = s2[j] = pv[j] = 0.f;
     const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
     if (pl < PL) {
+        if (pivot) {      // shifted sums: pivot = first pixel of the sample-group -> no catastrophic cancellation
+            VecIO<T, V>::load(x, ((size_t)ns * P) * C + (size_t)cv * V, pv);
+            if (blockIdx.x == 0 && pl == 0) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) pivot[(size_t)ns * C + cv * V + j] = pv[j];
+            }
+        }
         for (int p = p0 + pl; p < p1; p += PL) {
             float v[V];
             VecIO<T, V>::load(x, ((size_t)ns * P + p) * C + (size_t)cv * V, v);
 #pragma unroll
-            for (int j = 0; j < V; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+            for (int j = 0; j < V; ++j) { const float d = v[j] - pv[j]; s1[j] += d; s2[j] += d * d; }
         }
 #pragma unroll
         for (int j = 0; j < V; ++j) {
@@ -107,22 +115,34 @@ __global__ void k_reduce_partials(const float* __restrict__ partial, int T, int 
 }
 
 // per (ns, g): mean / rstd; per (ns, c): scale / shift; optional TF1 fused-batch-norm moving update
-__global__ void k_norm_finalize(const float* __restrict__ sums, const float* __restrict__ gamma,
+__global__ void k_norm_finalize(const float* __restrict__ sums, const float* __restrict__ pivot,
+                                const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float eps, int NS, int P, int C, int G,
                                 float* mean, float* rstd, float* scale, float* shift, float* moving_mean,
                                 float* moving_var, float momentum) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= NS * G) return;
     const int ns = idx / G, g = idx % G, cg = C / G;
-    float s1 = 0.f, s2 = 0.f;
+    // per-channel mean / variance from the (pivot-shifted) sums, then the stable parallel-variance combination
+    // over the channels of the group: var_g = mean_c[var_c + (mu_c - mu_g)^2]
+    const float invP = 1.f / (float)P;
+    float mu = 0.f;
     for (int c = g * cg; c < (g + 1) * cg; ++c) {
-        s1 += sums[((size_t)ns * C + c) * 2];
-        s2 += sums[((size_t)ns * C + c) * 2 + 1];
+        const float pv = pivot ? pivot[(size_t)ns * C + c] : 0.f;
+        mu += pv + sums[((size_t)ns * C + c) * 2] * invP;
     }
+    mu /= (float)cg;
+    float var = 0.f;
+    for (int c = g * cg; c < (g + 1) * cg; ++c) {
+        const float pv = pivot ? pivot[(size_t)ns * C + c] : 0.f;
+        const float d1 = sums[((size_t)ns * C + c) * 2] * invP;
+        float vc = sums[((size_t)ns * C + c) * 2 + 1] * invP - d1 * d1;
+        vc = vc > 0.f ? vc : 0.f;
+        const float dm = pv + d1 - mu;
+        var += vc + dm * dm;
+    }
+    var /= (float)cg;
     const float m = (float)P * (float)cg;
-    const float mu = s1 / m;
-    float var = s2 / m - mu * mu;
-    var = var > 0.f ? var : 0.f;
     const float rs = rsqrtf(var + eps);
     mean[idx] = mu;
     rstd[idx] = rs;
@@ -519,13 +539,13 @@ __global__ void k_bcast_bwd(const T* __restrict__ dout, float* __restrict__ dz, 
 // =================================================================================================
 extern "C" {
 
-int phx_norm_stats(const void* x, int dt, float* sums, int NS, int P, int C, void* stream) {
+int phx_norm_stats(const void* x, int dt, float* sums, float* pivot, int NS, int P, int C, void* stream) {
     PHX_REQUIRE(NS > 0 && P > 0 && C > 0, PHX_E_SHAPE, "norm_stats: bad shape");
     PHX_DT_SWITCH(dt, T, PHX_VEC_SWITCH(C, V, {
         int PL, threads, chunk, nchunks;
         PHX_REQUIRE(norm_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_stats: C too large");
         hipLaunchKernelGGL((k_norm_stats<T, V>), dim3(nchunks, NS), dim3(threads), (size_t)PL * C * 2 * sizeof(float),
-                           (hipStream_t)stream, (const T*)x, sums, P, C, PL, chunk);
+                           (hipStream_t)stream, (const T*)x, sums, pivot, P, C, PL, chunk);
     }));
     PHX_CHECK_LAUNCH();
     return PHX_OK;
@@ -537,13 +557,14 @@ int phx_norm_reduce_partials(const float* partial, int T, int C, float* sums, vo
     return PHX_OK;
 }
 
-int phx_norm_finalize(const float* sums, const float* gamma, const float* beta, float eps, int NS, int P, int C, int G,
+int phx_norm_finalize(const float* sums, const float* pivot, const float* gamma, const float* beta, float eps, int NS,
+                      int P, int C, int G,
                       float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,
                       float momentum, void* stream) {
     PHX_REQUIRE(G > 0 && C % G == 0, PHX_E_SHAPE, "norm_finalize: C % G != 0");
     PHX_REQUIRE(momentum == 0.f || (NS == 1 && G == C), PHX_E_INVAL, "moving update only for batch norm");
     const int n = NS * G;
-    hipLaunchKernelGGL(k_norm_finalize, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, sums, gamma, beta, eps,
+    hipLaunchKernelGGL(k_norm_finalize, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, sums, pivot, gamma, beta, eps,
                        NS, P, C, G, mean, rstd, scale, shift, moving_mean, moving_var, momentum);
     PHX_CHECK_LAUNCH();
     return PHX_OK;

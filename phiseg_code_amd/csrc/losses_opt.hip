@@ -222,7 +222,26 @@ __global__ void k_sum_scalars(const float* in, int n, float* out) {
     *out = a;
 }
 
+struct WSArgs {
+    const float* p[16];
+    float w[16];
+};
+__global__ void k_weighted_sum(WSArgs a, int n, float* out) {
+    float acc = 0.f;
+    for (int i = 0; i < n; ++i) acc += a.w[i] * (*a.p[i]);
+    *out = acc;
+}
+
 extern "C" {
+
+int phx_weighted_sum(const float* const* ptrs, const float* weights, int n, float* out, void* stream) {
+    PHX_REQUIRE(n >= 1 && n <= 16, PHX_E_SHAPE, "weighted_sum: 1 <= n <= 16");
+    WSArgs a;
+    for (int i = 0; i < 16; ++i) { a.p[i] = i < n ? ptrs[i] : nullptr; a.w[i] = i < n ? weights[i] : 0.f; }
+    hipLaunchKernelGGL(k_weighted_sum, dim3(1), dim3(1), 0, (hipStream_t)stream, a, n, out);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
 
 int phx_reparam_fwd(const float* mu, const float* sigma, float* z, int B, int per_sample, uint64_t seed,
                     const int32_t* step_dev, int stream_id, int sample_offset, void* stream) {

@@ -1,0 +1,691 @@
+"""Lowering of a symbolic PHiSeg graph to a fixed HIP launch list + hipGraph replay.
+
+This is the run-time half of the TF1 replacement: where the reference calls
+``sess.run([train_step, loss_tot], feed_dict)`` (phiseg/phiseg_model.py:194) this module
+
+* keeps all variables in flat fp32 device arenas (parameters, gradients, Adam m / v) so the optimiser and
+  the data-parallel gradient all-reduce are single flat operations (``ParamStore``);
+* compiles (fetches, loss) for one batch size / training flag into a list of libphx launches: forward of
+  the live graph, reverse-mode backward (Appendix C of SURVEY.md), TF1 Adam (``Plan``);
+* captures the list into a hipGraph and replays it per step (device-side step counter / learning rate, so a
+  replay needs no host-side argument patching).
+
+torch is used for device memory and, in ``distributed.py``, for torch.distributed -- plumbing only; every
+arithmetic operation is a libphx kernel and a missing library is a hard error.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from phiseg_code_amd import graph as G
+from phiseg_code_amd import runtime as rt
+from phiseg_code_amd.tfwrapper import normalisation as tfnorm
+
+F32, BF16, U8 = rt.F32, rt.BF16, 2
+_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, U8: torch.uint8}
+_NP_DT = {F32: np.float32, U8: np.uint8}
+_ESIZE = {F32: 4, BF16: 2, U8: 1}
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise rt.PhxError("no GPU visible: the PHiSeg engine has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class Buf:
+    """A device buffer: torch owns the memory, libphx sees the raw pointer."""
+
+    def __init__(self, shape, dt, zero=False, like=None):
+        self.shape = tuple(int(s) for s in shape)
+        self.dt = dt
+        n = int(np.prod(self.shape)) if self.shape else 1
+        self.n = n
+        if like is not None:
+            self.t = like
+        else:
+            self.t = (torch.zeros if zero else torch.empty)(max(n, 1), dtype=_TORCH_DT[dt], device=_device())
+        self.ptr = self.t.data_ptr()
+        self.shift = 0           # nearest-neighbour view: logical size = stored size << shift
+
+    @property
+    def nbytes(self):
+        return self.n * _ESIZE[self.dt]
+
+    def numpy(self):
+        torch.cuda.synchronize()
+        a = self.t[:self.n].float().cpu().numpy() if self.dt != U8 else self.t[:self.n].cpu().numpy()
+        return a.reshape(self.shape)
+
+
+class ParamStore:
+    """Flat arenas for every variable of a graph (created once, shared by all plans of a model)."""
+
+    def __init__(self, graph, seed=0):
+        self.graph = graph
+        self.offset, self.state_offset = {}, {}
+        off = soff = 0
+        for name, v in graph.variables.items():
+            if v.trainable:
+                self.offset[name] = off
+                off += (v.size + 3) // 4 * 4
+            else:
+                self.state_offset[name] = soff
+                soff += (v.size + 3) // 4 * 4
+        self.n_train, self.n_state = off, soff
+        dev = _device()
+        self.params = torch.zeros(max(off, 4), dtype=torch.float32, device=dev)
+        self.grads = torch.zeros_like(self.params)
+        self.adam_m = torch.zeros_like(self.params)
+        self.adam_v = torch.zeros_like(self.params)
+        self.state = torch.zeros(max(soff, 4), dtype=torch.float32, device=dev)
+        self.step = torch.zeros(1, dtype=torch.int32, device=dev)          # optimiser step t-1 (also the noise step)
+        self.noise_step = torch.zeros(1, dtype=torch.int32, device=dev)    # Philox step word of sampling plans
+        self.lr = torch.full((1,), 1e-3, dtype=torch.float32, device=dev)
+        self.initialize(seed)
+
+    def initialize(self, seed=0):
+        """tf.global_variables_initializer() (phiseg_model.py:175)."""
+        self.load({name: v.initial_value(seed) for name, v in self.graph.variables.items()})
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        self.step.zero_()
+
+    def _slot(self, name):
+        v = self.graph.variables[name]
+        if v.trainable:
+            return self.params, self.offset[name], v
+        return self.state, self.state_offset[name], v
+
+    def ptr(self, var):
+        arena, off, _ = self._slot(var.name)
+        return arena.data_ptr() + 4 * off
+
+    def grad_ptr(self, var):
+        assert var.trainable
+        return self.grads.data_ptr() + 4 * self.offset[var.name]
+
+    def load(self, values):
+        for name, val in values.items():
+            arena, off, v = self._slot(name)
+            a = torch.as_tensor(np.asarray(val, dtype=np.float32).reshape(-1))
+            assert a.numel() == v.size, "shape mismatch for %s" % name
+            arena[off:off + v.size] = a.to(arena.device)
+        torch.cuda.synchronize()
+
+    def export(self, grads=False):
+        torch.cuda.synchronize()
+        out = {}
+        for name, v in self.graph.variables.items():
+            if grads and not v.trainable:
+                continue
+            arena, off, _ = (self.grads, self.offset[name], v) if grads else self._slot(name)
+            out[name] = arena[off:off + v.size].cpu().numpy().reshape(v.shape)
+        return out
+
+    def set_lr(self, lr):
+        self.lr.fill_(float(lr))
+
+    def set_step(self, step):
+        self.step.fill_(int(step))
+
+
+class Plan:
+    """One compiled (fetches, loss) program for a fixed batch size / training flag / compute dtype."""
+
+    def __init__(self, store, fetches, loss=None, batch=1, training=True, compute_dtype="f32", optimize=True,
+                 rng_seed=42, sample_offset=0, loss_inv_batch=None, stream=None, use_hip_graph=True,
+                 split_optimizer=False):
+        self.L = rt.lib()
+        self.store = store
+        self.graph = store.graph
+        self.B = int(batch)
+        self.training = bool(training)
+        self.act_dt = {"f32": F32, "bf16": BF16}[compute_dtype]
+        self.rng_seed = int(rng_seed)
+        self.sample_offset = int(sample_offset)
+        self.inv_batch = float(loss_inv_batch) if loss_inv_batch is not None else 1.0 / self.B
+        self.loss = loss
+        self.optimize = bool(optimize and loss is not None)
+        self.split_optimizer = split_optimizer      # data-parallel: [fwd+bwd] | all-reduce | [adam]
+        self.use_hip_graph = use_hip_graph
+        if stream is None:
+            st = ctypes.c_void_p()
+            self.L.stream_create(ctypes.byref(st))
+            self.stream, self._own_stream = st, True
+        else:
+            self.stream, self._own_stream = stream, False
+        self.launches, self.opt_launches = [], []
+        self._cur = self.launches
+        self.val, self.grad, self.saved = {}, {}, {}
+        self.feeds = {}
+        self._keep = []
+        self._wpk = {}
+        self.fetches = list(fetches)
+        self.n_launch_fwd = self.n_launch_bwd = 0
+        self._build()
+        torch.cuda.synchronize()
+        self._graph_exec = self._graph_exec_opt = None
+
+    # ---------------------------------------------------------------------------------------------
+    def _emit(self, fn, *args):
+        self._cur.append((fn, args))
+
+    def _alloc(self, shape, dt, zero=False):
+        b = Buf(shape, dt, zero=zero)
+        self._keep.append(b)
+        return b
+
+    def _dt_of(self, t):
+        return {G.KIND_ACT: self.act_dt, G.KIND_F32: F32, G.KIND_U8: U8}[t.kind]
+
+    def _cshape(self, t):
+        return tuple(self.B if s is None else s for s in t.shape)
+
+    def _alloc_like(self, t, zero=False):
+        return self._alloc(self._cshape(t), self._dt_of(t), zero=zero)
+
+    def _noise_step_ptr(self):
+        """Training plans key the noise by the optimiser step; sampling plans by their own counter."""
+        return (self.store.step if self.loss is not None else self.store.noise_step).data_ptr()
+
+    def _needed_ops(self):
+        want = set()
+        stack = [t.op for t in self.fetches] + ([self.loss.op] if self.loss is not None else [])
+        while stack:
+            op = stack.pop()
+            if op in want:
+                continue
+            want.add(op)
+            stack.extend(i.op for i in op.inputs)
+        return [op for op in self.graph.ops if op in want]
+
+    def _build(self):
+        ops = self._needed_ops()
+        self.ops = ops
+        # which tensors depend on trainable variables
+        self.req = {}
+        for op in ops:
+            r = op.type == "conv_unit" or any(self.req.get(i, False) for i in op.inputs)
+            for o in op.outputs:
+                self.req[o] = r
+        self.loss_weight = {}
+        if self.loss is not None:
+            assert self.loss.op.type == "weighted_sum", "loss must be built with graph.weighted_sum"
+            for t, w in zip(self.loss.op.inputs, self.loss.op.attrs["weights"]):
+                self.loss_weight[t] = w
+        with_bw = self.loss is not None
+        if with_bw:
+            self._emit(self.L.memset, self.store.grads.data_ptr(), 0, self.store.grads.numel() * 4, self.stream)
+        for op in ops:
+            getattr(self, "_fw_" + op.type)(op, with_bw)
+        self.n_launch_fwd = len(self.launches)
+        if with_bw:
+            for op in reversed(ops):
+                if any(o in self.grad for o in op.outputs) or op.type in ("residual_ce", "kl"):
+                    getattr(self, "_bw_" + op.type)(op)
+            self.n_launch_bwd = len(self.launches) - self.n_launch_fwd
+        if self.optimize:
+            if self.split_optimizer:
+                self._cur = self.opt_launches
+            s = self.store
+            self._emit(self.L.adam_tf1, s.params.data_ptr(), s.grads.data_ptr(), s.adam_m.data_ptr(),
+                       s.adam_v.data_ptr(), s.n_train, s.lr.data_ptr(), 0.9, 0.999, 1e-8, s.step.data_ptr(),
+                       self.stream)
+            self._emit(self.L.step_increment, s.step.data_ptr(), self.stream)
+            self._cur = self.launches
+
+    # ---- forward emitters -----------------------------------------------------------------------
+    def _fw_placeholder(self, op, bw):
+        t = op.outputs[0]
+        b = self._alloc_like(t, zero=True)
+        self.val[t] = b
+        self.feeds[op.name.rsplit("/", 1)[-1]] = b
+
+    def _fw_one_hot(self, op, bw):
+        pass            # virtual: consumed by the fused posterior-input kernel / the loss kernel
+
+    def _fw_sub_const(self, op, bw):
+        pass
+
+    def _fw_nn_resize(self, op, bw):
+        src = self.val[op.inputs[0]]
+        v = Buf(src.shape, src.dt, like=src.t)
+        v.shift = op.attrs["shift"]
+        self.val[op.outputs[0]] = v
+
+    def _fw_random_normal(self, op, bw):
+        pass
+
+    def _fw_mul(self, op, bw):
+        pass
+
+    def _fw_concat(self, op, bw):
+        a, b = op.inputs
+        out = self._alloc_like(op.outputs[0])
+        self.val[op.outputs[0]] = out
+        npix = int(np.prod(out.shape[:-1]))
+        if b.op.type == "sub_const" and b.op.inputs[0].op.type == "one_hot":
+            # concat[x, one_hot(s) - 0.5] (posteriors.py:87) in one kernel
+            oh = b.op.inputs[0].op
+            assert abs(b.op.attrs["c"] - 0.5) < 1e-12 and a.shape[-1] == 1
+            xb, sb = self.val[a], self.val[oh.inputs[0]]
+            self._emit(self.L.posterior_input, xb.ptr, sb.ptr, out.ptr, out.dt, npix, oh.attrs["depth"], self.stream)
+            return
+        ab, bb = self._as_dt(self.val[a], out.dt), self._as_dt(self.val[b], out.dt)
+        self._emit(self.L.concat2, ab.ptr, ab.shape[-1], bb.ptr, bb.shape[-1], out.ptr, npix, out.dt, self.stream)
+
+    def _as_dt(self, buf, dt):
+        if buf.dt == dt:
+            return buf
+        c = self._alloc(buf.shape, dt)
+        self._emit(self.L.cast, buf.ptr, buf.dt, c.ptr, dt, buf.n, self.stream)
+        return c
+
+    def _packed(self, W):
+        """bf16 packed copies of a 3x3 filter, refreshed at the head of every run (after Adam moved W)."""
+        if W.name not in self._wpk:
+            kh, kw, cin, cout = W.shape
+            wf, wd = self._alloc((9 * cin * cout,), BF16), self._alloc((9 * cin * cout,), BF16)
+            self._wpk[W.name] = (wf, wd)
+            self._emit(self.L.pack_conv3x3_bf16, self.store.ptr(W), wf.ptr, wd.ptr, cin, cout, self.stream)
+        return self._wpk[W.name]
+
+    def _fw_conv_unit(self, op, bw):
+        a = op.attrs
+        x = self.val[op.inputs[0]]
+        W, b = a["W"], a["b"]
+        k, (_, _, cin, cout) = a["ksize"], W.shape
+        B, H, Wd = x.shape[0], x.shape[1], x.shape[2]
+        out = self._alloc_like(op.outputs[0])
+        self.val[op.outputs[0]] = out
+        act = rt.ACT_CODES[a["act"]]
+        training = a["training"] if isinstance(a["training"], bool) else self.training
+        mfma = (self.act_dt == BF16 and x.dt == BF16 and out.dt == BF16 and k == 3 and cin % 32 == 0
+                and cout % 32 == 0)
+        st = dict(x=x, out=out, mfma=mfma, norm=a["norm"])
+        wptr, bptr = self.store.ptr(W), (self.store.ptr(b) if b is not None else None)
+        S, Lb = self.stream, self.L
+        if mfma:
+            wf, _ = self._packed(W)
+
+        def conv_into(y, act_code, stats_direct=None, stats_part=None):
+            if mfma:
+                self._emit(Lb.conv3x3_mfma_bf16, x.ptr, wf.ptr, y.ptr, bptr, act_code,
+                           stats_part.ptr if stats_part is not None else None, B, H, Wd, cin, cout, S)
+            else:
+                self._emit(Lb.conv2d_direct, x.ptr, x.dt, wptr, bptr, y.ptr, y.dt, B, H, Wd, cin, cout, k, act_code,
+                           0, stats_direct.ptr if stats_direct is not None else None, S)
+
+        norm = a["norm"]
+        if norm is None:
+            conv_into(out, act)
+            self.saved[op] = st
+            return
+        nv = a["norm_vars"]
+        gptr, beptr = self.store.ptr(nv["gamma"]), self.store.ptr(nv["beta"])
+        y = self._alloc(out.shape, out.dt)
+        if norm == "batch":
+            NS, P, Gn = 1, B * H * Wd, cout
+        else:
+            Gn = cout if norm == "instance" else (a["num_groups"] or max(2, cout // 16))
+            NS, P = B, H * Wd
+        scale, shift = self._alloc((NS * cout,), F32), self._alloc((NS * cout,), F32)
+        mean, rstd = self._alloc((NS * Gn,), F32), self._alloc((NS * Gn,), F32)
+        eps = tfnorm.EPS[norm]
+        if norm == "batch" and not training:
+            self._emit(Lb.bn_infer_scale_shift, gptr, beptr, self.store.ptr(nv["moving_mean"]),
+                       self.store.ptr(nv["moving_variance"]), eps, cout, scale.ptr, shift.ptr, S)
+            conv_into(y, 0)
+        else:
+            sums = self._alloc((NS * cout * 2,), F32)
+            pivot = None
+            # shifted (pivot) sums in a stand-alone pass: always on the fp32 parity path, and on the bf16 path when
+            # a statistic has few samples (cheap there); otherwise the sums come from the conv epilogue.
+            small = P <= 16384 or self.act_dt == F32
+            if norm == "batch" and mfma and not small:
+                ntile = Lb.conv3x3_mfma_bf16_tiles(B, H, Wd)
+                part = self._alloc((ntile * 2 * cout,), F32)
+                conv_into(y, 0, stats_part=part)
+                self._emit(Lb.norm_reduce_partials, part.ptr, ntile, cout, sums.ptr, S)
+            elif norm == "batch" and not small:
+                self._emit(Lb.memset, sums.ptr, 0, sums.nbytes, S)
+                conv_into(y, 0, stats_direct=sums)
+            else:
+                pivot = self._alloc((NS * cout,), F32)
+                conv_into(y, 0)
+                self._emit(Lb.memset, sums.ptr, 0, sums.nbytes, S)
+                self._emit(Lb.norm_stats, y.ptr, y.dt, sums.ptr, pivot.ptr, NS, P, cout, S)
+            upd = norm == "batch" and training and self.loss is not None
+            self._emit(Lb.norm_finalize, sums.ptr, pivot.ptr if pivot is not None else None, gptr, beptr, eps, NS, P, cout, Gn, mean.ptr, rstd.ptr, scale.ptr,
+                       shift.ptr, self.store.ptr(nv["moving_mean"]) if upd else None,
+                       self.store.ptr(nv["moving_variance"]) if upd else None,
+                       (1.0 - tfnorm.BN_DECAY) if upd else 0.0, S)
+        self._emit(Lb.affine_act, y.ptr, y.dt, scale.ptr, shift.ptr, out.ptr, out.dt, NS, P, cout, act, S)
+        st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn)
+        self.saved[op] = st
+
+    def _fw_avgpool(self, op, bw):
+        x = self.val[op.inputs[0]]
+        out = self._alloc(self._cshape(op.outputs[0]), x.dt)
+        self.val[op.outputs[0]] = out
+        self._emit(self.L.avgpool2x2_fwd, x.ptr, x.dt, out.ptr, x.shape[0], x.shape[1], x.shape[2], x.shape[3],
+                   self.stream)
+
+    def _fw_bilinear_up(self, op, bw):
+        x = self.val[op.inputs[0]]
+        out = self._alloc(self._cshape(op.outputs[0]), x.dt)
+        self.val[op.outputs[0]] = out
+        self._emit(self.L.bilinear_up2x_fwd, x.ptr, x.dt, out.ptr, x.shape[0], x.shape[1], x.shape[2], x.shape[3],
+                   self.stream)
+
+    def _fw_add(self, op, bw):
+        mu_t, m = op.inputs
+        if m.op.type != "mul" or m.op.inputs[1].op.type != "random_normal":
+            raise NotImplementedError("only z = mu + sigma * random_normal(...) is on the hot path")
+        sigma_t, eps_t = m.op.inputs
+        mu, sigma = self.val[mu_t], self.val[sigma_t]
+        z = self._alloc(mu.shape, F32)
+        self.val[op.outputs[0]] = z
+        per = mu.n // mu.shape[0]
+        stream_id = eps_t.op.attrs["stream"]
+        self._emit(self.L.reparam_fwd, mu.ptr, sigma.ptr, z.ptr, mu.shape[0], per, self.rng_seed,
+                   self._noise_step_ptr(), stream_id, self.sample_offset, self.stream)
+        self.saved[op] = dict(mu_t=mu_t, sigma_t=sigma_t, per=per, stream_id=stream_id)
+
+    def _fw_global_avgpool(self, op, bw):
+        x = self._as_dt(self.val[op.inputs[0]], F32)
+        out = self._alloc_like(op.outputs[0])
+        self.val[op.outputs[0]] = out
+        self._emit(self.L.global_avgpool_fwd, x.ptr, out.ptr, x.shape[0], x.shape[1] * x.shape[2], x.shape[3],
+                   self.stream)
+
+    def _fw_tile_pixels(self, op, bw):
+        z = self.val[op.inputs[0]]
+        out = self._alloc_like(op.outputs[0])
+        self.val[op.outputs[0]] = out
+        self._emit(self.L.broadcast_pixels_fwd, z.ptr, out.ptr, out.dt, out.shape[0], out.shape[1] * out.shape[2],
+                   out.shape[3], self.stream)
+
+    def _level_args(self, tensors):
+        bufs = [self.val[t] for t in tensors]
+        for b in bufs:
+            assert b.dt == F32, "logit levels are fp32 heads"
+        return bufs, rt.ptr_array([b.ptr for b in bufs]), rt.int_array([b.shift for b in bufs])
+
+    def _fw_residual_ce(self, op, bw):
+        Ls = op.attrs["L"]
+        s_t, lab_t = op.inputs[:Ls], op.inputs[Ls]
+        bufs, sp, shp = self._level_args(s_t)
+        lab = self.val[lab_t]
+        B, H, W = lab.shape
+        C = bufs[0].shape[3]
+        losses = self._alloc((8 + 512,), F32)
+        s_out = self._alloc_like(op.outputs[Ls])
+        self.val[op.outputs[Ls]] = s_out
+        for l in range(Ls):
+            v = Buf((), F32, like=losses.t[l:l + 1])
+            self._keep.append(v)
+            self.val[op.outputs[l]] = v
+        dsp, dbufs, w = None, None, 0.0
+        if bw:
+            ws = [self.loss_weight.get(op.outputs[l], 0.0) for l in range(Ls)]
+            assert all(abs(x - ws[0]) < 1e-12 for x in ws), "one weight for all residual-CE levels"
+            w = ws[0]
+            dbufs = [self._alloc(b.shape, F32) for b in bufs]
+            for b in dbufs:
+                if b.shape[1] != H:
+                    self._emit(self.L.memset, b.ptr, 0, b.nbytes, self.stream)
+            dsp = rt.ptr_array([b.ptr for b in dbufs])
+            self.saved[op] = dict(dbufs=dbufs, src=[t.op.inputs[0] if t.op.type == "nn_resize" else t for t in s_t])
+        self._emit(self.L.residual_ce, sp, dsp, shp, Ls, lab.ptr, B, H, W, C, w, self.inv_batch, losses.ptr,
+                   s_out.ptr, None, self.stream)
+
+    def _fw_aggregate(self, op, bw):
+        Ls = op.attrs["L"]
+        bufs, sp, shp = self._level_args(op.inputs)
+        s_out, sm = self._alloc_like(op.outputs[0]), self._alloc_like(op.outputs[1])
+        self.val[op.outputs[0]], self.val[op.outputs[1]] = s_out, sm
+        B, H, W, C = s_out.shape
+        self._emit(self.L.residual_ce, sp, None, shp, Ls, None, B, H, W, C, 0.0, 1.0, None, s_out.ptr, sm.ptr,
+                   self.stream)
+
+    def _fw_kl(self, op, bw):
+        mu0, s0, mu1, s1 = [self.val[t] for t in op.inputs]
+        loss = self._alloc((), F32)
+        self.val[op.outputs[0]] = loss
+        gs = [None] * 4
+        gscale = 0.0
+        if bw:
+            gscale = self.loss_weight.get(op.outputs[0], 0.0)
+            gs = [self._alloc(mu0.shape, F32) for _ in range(4)]
+            self.saved[op] = dict(gs=gs)
+        self._emit(self.L.kl_diag_gauss, mu0.ptr, s0.ptr, mu1.ptr, s1.ptr, mu0.n, op.attrs["level_weight"],
+                   self.inv_batch, gscale, loss.ptr, *[g.ptr if g is not None else None for g in gs], self.stream)
+
+    def _fw_weighted_sum(self, op, bw):
+        out = self._alloc((), F32)
+        self.val[op.outputs[0]] = out
+        ptrs = rt.ptr_array([self.val[t].ptr for t in op.inputs])
+        ws = (ctypes.c_float * len(op.inputs))(*op.attrs["weights"])
+        self._keep.append(ws)
+        self._emit(self.L.weighted_sum, ptrs, ctypes.cast(ws, ctypes.c_void_p), len(op.inputs), out.ptr, self.stream)
+
+    # ---- backward -------------------------------------------------------------------------------
+    def _add_grad(self, t, write_fn=None, buf=None):
+        """Accumulate a gradient contribution for tensor t: either `buf` (already complete) or produced by
+        write_fn(target).  The first contribution owns the buffer; later ones are added in place."""
+        if not self.req.get(t, False):
+            return
+        if t not in self.grad:
+            if buf is None:
+                buf = self._alloc(self.val[t].shape, self.val[t].dt)
+                write_fn(buf)
+            self.grad[t] = buf
+            return
+        if buf is None:
+            buf = self._alloc(self.val[t].shape, self.val[t].dt)
+            write_fn(buf)
+        g = self.grad[t]
+        assert g.dt == buf.dt and g.n == buf.n
+        self._emit(self.L.add_inplace, g.ptr, buf.ptr, g.n, g.dt, self.stream)
+
+    def _bw_placeholder(self, op):
+        pass
+
+    _bw_one_hot = _bw_sub_const = _bw_random_normal = _bw_mul = _bw_weighted_sum = _bw_aggregate = _bw_placeholder
+
+    def _bw_nn_resize(self, op):
+        raise NotImplementedError("nearest-resized logits only feed the fused loss kernel")
+
+    def _bw_residual_ce(self, op):
+        sv = self.saved.get(op)
+        if sv:
+            for t, d in zip(sv["src"], sv["dbufs"]):
+                self._add_grad(t, buf=d)
+
+    def _bw_kl(self, op):
+        sv = self.saved.get(op)
+        if sv:
+            for t, g in zip(op.inputs, sv["gs"]):
+                self._add_grad(t, buf=g)
+
+    def _bw_add(self, op):
+        sv, dz = self.saved[op], self.grad[op.outputs[0]]
+        self._add_grad(sv["mu_t"], buf=dz)
+        B = dz.shape[0]
+
+        def wr(target):
+            self._emit(self.L.reparam_bwd, dz.ptr, target.ptr, B, sv["per"], self.rng_seed,
+                       self._noise_step_ptr(), sv["stream_id"], self.sample_offset, self.stream)
+        self._add_grad(sv["sigma_t"], write_fn=wr)
+
+    def _bw_concat(self, op):
+        a, b = op.inputs
+        d = self.grad[op.outputs[0]]
+        if b.op.type == "sub_const":
+            return                       # posterior input: x and s are data
+        npix = int(np.prod(d.shape[:-1]))
+        ca, cb = self.val[a].shape[-1], self.val[b].shape[-1]
+        da = self._alloc(self.val[a].shape, d.dt) if self.req.get(a) else None
+        db = self._alloc(self.val[b].shape, d.dt) if self.req.get(b) else None
+        self._emit(self.L.split2, d.ptr, da.ptr if da else None, ca, db.ptr if db else None, cb, npix, d.dt,
+                   self.stream)
+        for t, g in ((a, da), (b, db)):
+            if g is not None:
+                self._add_grad(t, buf=self._as_dt(g, self.val[t].dt))
+
+    def _bw_avgpool(self, op):
+        x, d = self.val[op.inputs[0]], self.grad[op.outputs[0]]
+        self._add_grad(op.inputs[0], write_fn=lambda g: self._emit(
+            self.L.avgpool2x2_bwd, d.ptr, d.dt, g.ptr, x.shape[0], x.shape[1], x.shape[2], x.shape[3], self.stream))
+
+    def _bw_bilinear_up(self, op):
+        x, d = self.val[op.inputs[0]], self.grad[op.outputs[0]]
+        self._add_grad(op.inputs[0], write_fn=lambda g: self._emit(
+            self.L.bilinear_up2x_bwd, d.ptr, d.dt, g.ptr, x.shape[0], x.shape[1], x.shape[2], x.shape[3], self.stream))
+
+    def _bw_global_avgpool(self, op):
+        x, d = self.val[op.inputs[0]], self.grad[op.outputs[0]]
+        self._add_grad(op.inputs[0], write_fn=lambda g: self._emit(
+            self.L.global_avgpool_bwd, d.ptr, g.ptr, x.shape[0], x.shape[1] * x.shape[2], x.shape[3], self.stream))
+
+    def _bw_tile_pixels(self, op):
+        d = self.grad[op.outputs[0]]
+        self._add_grad(op.inputs[0], write_fn=lambda g: self._emit(
+            self.L.broadcast_pixels_bwd, d.ptr, d.dt, g.ptr, d.shape[0], d.shape[1] * d.shape[2], d.shape[3],
+            self.stream))
+
+    def _bw_conv_unit(self, op):
+        a, sv = op.attrs, self.saved[op]
+        dA = self.grad[op.outputs[0]]
+        x, out = sv["x"], sv["out"]
+        W, b = a["W"], a["b"]
+        k, (_, _, cin, cout) = a["ksize"], W.shape
+        B, H, Wd = x.shape[0], x.shape[1], x.shape[2]
+        act = rt.ACT_CODES[a["act"]]
+        S, Lb = self.stream, self.L
+        if sv["norm"] is not None:
+            if "y" not in sv or "mean" not in sv or (sv["norm"] == "batch" and not self.training):
+                raise NotImplementedError("backward through inference-mode batch norm is not on the hot path")
+            nv = a["norm_vars"]
+            y, NS, P, Gn = sv["y"], sv["NS"], sv["P"], sv["G"]
+            sums2 = self._alloc((NS * cout * 2,), F32)
+            Sg = self._alloc((NS * Gn * 2,), F32)
+            dY = self._alloc(y.shape, y.dt)
+            self._emit(Lb.memset, sums2.ptr, 0, sums2.nbytes, S)
+            self._emit(Lb.norm_bwd_reduce, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
+                       sv["mean"].ptr, sv["rstd"].ptr, sums2.ptr, NS, P, cout, Gn, act, S)
+            self._emit(Lb.norm_bwd_finalize, sums2.ptr, self.store.ptr(nv["gamma"]), Sg.ptr,
+                       self.store.grad_ptr(nv["gamma"]), self.store.grad_ptr(nv["beta"]), NS, cout, Gn, S)
+            self._emit(Lb.norm_bwd_apply, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
+                       sv["mean"].ptr, sv["rstd"].ptr, self.store.ptr(nv["gamma"]), Sg.ptr, dY.ptr, dY.dt, NS, P,
+                       cout, Gn, act, S)
+        elif act != rt.ACT_ID:
+            dY = self._alloc(out.shape, dA.dt)
+            self._emit(Lb.act_bwd, dA.ptr, dA.dt, out.ptr, out.dt, dY.ptr, dY.dt, dA.n, act, S)
+        else:
+            dY = dA
+        dw = self.store.grad_ptr(W)
+        db = self.store.grad_ptr(b) if b is not None else None
+        if sv["mfma"]:
+            self._emit(Lb.conv3x3_wgrad_mfma_bf16, x.ptr, dY.ptr, dw, B, H, Wd, cin, cout, S)
+            if db is not None:
+                self._emit(Lb.channel_sum_accumulate, dY.ptr, dY.dt, db, B * H * Wd, cout, S)
+        else:
+            self._emit(Lb.conv2d_direct_wgrad, x.ptr, x.dt, dY.ptr, dY.dt, dw, db, B, H, Wd, cin, cout, k, S)
+        xin = op.inputs[0]
+        if self.req.get(xin, False):
+            if sv["mfma"]:
+                _, wd = self._packed(W)
+                self._add_grad(xin, write_fn=lambda g: self._emit(
+                    Lb.conv3x3_mfma_bf16, dY.ptr, wd.ptr, g.ptr, None, 0, None, B, H, Wd, cout, cin, S))
+            else:
+                self._add_grad(xin, write_fn=lambda g: self._emit(
+                    Lb.conv2d_direct, dY.ptr, dY.dt, self.store.ptr(W), None, g.ptr, g.dt, B, H, Wd, cin, cout, k, 0,
+                    1, None, S))
+
+    # ---- execution ------------------------------------------------------------------------------
+    def set_input(self, name, array):
+        b = self.feeds[name]
+        a = np.ascontiguousarray(array, dtype=_NP_DT[b.dt]).reshape(-1)
+        assert a.size == b.n, "feed %s: got %d elements, plan expects %d" % (name, a.size, b.n)
+        self.L.memcpy_h2d(b.ptr, a.ctypes.data, a.nbytes, self.stream)
+        self.L.stream_sync(self.stream)
+
+    def _run_list(self, lst):
+        for fn, args in lst:
+            fn(*args)
+
+    def run_eager(self, opt=True):
+        self._run_list(self.launches)
+        if opt:
+            self._run_list(self.opt_launches)
+
+    def _capture(self, lst):
+        self.L.stream_sync(self.stream)
+        self.L.graph_begin_capture(self.stream)
+        try:
+            self._run_list(lst)
+        finally:
+            ge = ctypes.c_void_p()
+            self.L.graph_end_capture(self.stream, ctypes.byref(ge))
+        return ge
+
+    def run(self, sync=False):
+        """One step.  First call runs eagerly (sets kernel attributes, validates), the second captures the
+        launch list into a hipGraph, later calls replay it."""
+        if not self.use_hip_graph:
+            self.run_eager()
+        elif self._graph_exec is None:
+            if not getattr(self, "_warm", False):
+                self.run_eager()
+                self._warm = True
+            else:
+                self._graph_exec = self._capture(self.launches)
+                self.L.graph_launch(self._graph_exec, self.stream)
+                if self.opt_launches:
+                    self._graph_exec_opt = self._capture(self.opt_launches)
+                    self.L.graph_launch(self._graph_exec_opt, self.stream)
+        else:
+            self.L.graph_launch(self._graph_exec, self.stream)
+            if self._graph_exec_opt is not None:
+                self.L.graph_launch(self._graph_exec_opt, self.stream)
+        if sync:
+            self.sync()
+
+    def run_main(self):
+        """Data-parallel use: forward+backward only (graph 1); run_opt() applies Adam after the all-reduce."""
+        if not self.use_hip_graph or not getattr(self, "_warm", False):
+            self._run_list(self.launches)
+            self._warm = True
+        else:
+            if self._graph_exec is None:
+                self._graph_exec = self._capture(self.launches)
+            self.L.graph_launch(self._graph_exec, self.stream)
+
+    def run_opt(self):
+        if not self.use_hip_graph or not getattr(self, "_warm_opt", False):
+            self._run_list(self.opt_launches)
+            self._warm_opt = True
+        else:
+            if self._graph_exec_opt is None:
+                self._graph_exec_opt = self._capture(self.opt_launches)
+            self.L.graph_launch(self._graph_exec_opt, self.stream)
+
+    def sync(self):
+        self.L.stream_sync(self.stream)
+
+    def fetch(self, t):
+        self.sync()
+        b = self.val[t]
+        a = b.numpy()
+        if b.shift:                     # nearest-neighbour view (likelihoods.py:221): expand on the host
+            f = 1 << b.shift
+            a = np.repeat(np.repeat(a, f, axis=1), f, axis=2)
+        return a
+
+    def fetch_grad(self, t):
+        self.sync()
+        return self.grad[t].numpy()

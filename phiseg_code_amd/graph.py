@@ -1,0 +1,267 @@
+"""Symbolic graph of the PHiSeg step (the role TF1's graph mode plays in the reference).
+
+The reference builds a static TensorFlow graph once (phiseg/phiseg_model.py:20-157) and then runs it
+with ``sess.run``.  This module is the build-time half of the replacement: ``tfwrapper.layers`` /
+``phiseg.model_zoo`` (our own code, same call signatures) create ``Op`` nodes over ``Tensor`` handles with
+static NHWC shapes (batch dimension ``None``), variables live under nested ``variable_scope`` names that
+match the reference's TF variable names.  ``engine.Plan`` then lowers a set of
+fetches, for a concrete batch size and training flag, to a fixed list of HIP kernel launches that is
+captured into a hipGraph -- HIP streams and graphs instead of a tracing compiler.
+"""
+import contextlib
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+KIND_ACT, KIND_F32, KIND_U8 = "act", "f32", "u8"     # "act" = stored in the plan's compute dtype
+
+
+class _Shape(list):
+    def as_list(self):
+        return list(self)
+
+
+class Tensor:
+    def __init__(self, op, shape, kind=KIND_ACT, name=None):
+        self.op = op
+        self.shape = tuple(shape)
+        self.kind = kind
+        self.name = name or (op.name if op is not None else "t")
+        self.consumers = []
+
+    def get_shape(self):
+        return _Shape(self.shape)
+
+    # the few arithmetic forms the zoo uses: s_oh - 0.5 ; sigma * eps ; mu + (sigma * eps)
+    def __sub__(self, c):
+        if not isinstance(c, (int, float)):
+            raise NotImplementedError("only tensor - constant is part of the hot path")
+        return get_default_graph().add_op("sub_const", [self], dict(c=float(c)), [(self.shape, self.kind)])[0]
+
+    def __mul__(self, o):
+        if not isinstance(o, Tensor) or o.shape != self.shape:
+            raise NotImplementedError("only same-shape tensor * tensor is part of the hot path")
+        return get_default_graph().add_op("mul", [self, o], {}, [(self.shape, KIND_F32)])[0]
+
+    def __add__(self, o):
+        if not isinstance(o, Tensor) or o.shape != self.shape:
+            raise NotImplementedError("only same-shape tensor + tensor is part of the hot path")
+        return get_default_graph().add_op("add", [self, o], {}, [(self.shape, KIND_F32)])[0]
+
+    def __repr__(self):
+        return "<Tensor %s %s %s>" % (self.name, self.shape, self.kind)
+
+
+class Op:
+    def __init__(self, type_, inputs, attrs, name):
+        self.type = type_
+        self.inputs = list(inputs)
+        self.attrs = attrs
+        self.name = name
+        self.outputs = []
+
+
+class Variable:
+    def __init__(self, name, shape, initializer, trainable=True):
+        self.name = name
+        self.shape = tuple(int(s) for s in shape)
+        self.initializer = initializer
+        self.trainable = trainable
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape))
+
+    def initial_value(self, seed=0):
+        rng = np.random.default_rng([seed, zlib.crc32(self.name.encode())])
+        return np.asarray(self.initializer(self.shape, rng), dtype=np.float32).reshape(self.shape)
+
+    def __bool__(self):
+        return True
+
+
+class _ScopeHandle:
+    def __init__(self, graph, name):
+        self.graph, self.name = graph, name
+
+    def reuse_variables(self):
+        self.graph._reuse[self.name] = True
+
+
+class Graph:
+    def __init__(self):
+        self.ops = []
+        self.variables = OrderedDict()
+        self._scope = []
+        self._reuse = {}
+        self.collections = {}
+        self._names = {}
+
+    # ---- scopes / variables (tf.variable_scope / tf.get_variable) --------------------------------
+    def scope_name(self):
+        return "/".join(self._scope)
+
+    @contextlib.contextmanager
+    def variable_scope(self, name):
+        self._scope.append(name)
+        full = self.scope_name()
+        try:
+            yield _ScopeHandle(self, full)
+        finally:
+            self._scope.pop()
+
+    def _reusing(self):
+        return any(self._reuse.get("/".join(self._scope[:i + 1]), False) for i in range(len(self._scope)))
+
+    def get_variable(self, name, shape, initializer, trainable=True):
+        full = (self.scope_name() + "/" if self._scope else "") + name
+        if full in self.variables:
+            if not self._reusing():
+                raise ValueError("Variable %s already exists (enter the scope with scope_reuse=True)" % full)
+            v = self.variables[full]
+            if tuple(shape) != v.shape:
+                raise ValueError("Variable %s re-used with shape %s != %s" % (full, tuple(shape), v.shape))
+            return v
+        if self._reusing():
+            raise ValueError("Variable %s does not exist but the scope is in reuse mode" % full)
+        v = Variable(full, shape, initializer, trainable)
+        self.variables[full] = v
+        return v
+
+    def add_to_collection(self, name, v):
+        self.collections.setdefault(name, []).append(v)
+
+    def get_collection(self, name):
+        return list(self.collections.get(name, []))
+
+    # ---- ops -------------------------------------------------------------------------------------
+    def unique_name(self, base):
+        k = self._names.get(base, 0)
+        self._names[base] = k + 1
+        return base if k == 0 else "%s_%d" % (base, k)
+
+    def add_op(self, type_, inputs, attrs, out_specs, name=None):
+        op = Op(type_, inputs, attrs, self.unique_name((self.scope_name() + "/" if self._scope else "") + (name or type_)))
+        for i, (shape, kind) in enumerate(out_specs):
+            op.outputs.append(Tensor(op, shape, kind, op.name + (":%d" % i if len(out_specs) > 1 else "")))
+        for t in inputs:
+            t.consumers.append(op)
+        self.ops.append(op)
+        return op.outputs
+
+
+_default = Graph()
+
+
+def get_default_graph():
+    return _default
+
+
+def reset_default_graph():
+    global _default
+    _default = Graph()
+    return _default
+
+
+def variable_scope(name):
+    return get_default_graph().variable_scope(name)
+
+
+# --------------------------------------------------------------------------------------------------
+# op constructors (the symbols our tfwrapper / model_zoo / phiseg_model are written against)
+def placeholder(kind, shape, name):
+    return get_default_graph().add_op("placeholder", [], dict(), [(tuple(shape), kind)], name=name)[0]
+
+
+def one_hot(s, depth):
+    """tf.one_hot (phiseg_model.py:29): [.., H, W] u8 -> [.., H, W, depth]."""
+    return get_default_graph().add_op("one_hot", [s], dict(depth=int(depth)), [(s.shape + (int(depth),), KIND_ACT)])[0]
+
+
+def concat(values, axis=-1, name=None):
+    """tf.concat along the channel axis of exactly two NHWC tensors (all the zoo needs)."""
+    if len(values) != 2:
+        raise NotImplementedError("concat of exactly two tensors")
+    a, b = values
+    if axis not in (-1, 3) or a.shape[:-1] != b.shape[:-1]:
+        raise ValueError("concat: channel axis only, equal spatial shapes (%s vs %s)" % (a.shape, b.shape))
+    kind = KIND_F32 if (a.kind == KIND_F32 and b.kind == KIND_F32) else KIND_ACT
+    return get_default_graph().add_op("concat", [a, b], {}, [(a.shape[:-1] + (a.shape[-1] + b.shape[-1],), kind)],
+                                      name=name or "concat")[0]
+
+
+def random_normal(like, stream):
+    """tf.random_normal(tf.shape(like), 0, 1): the Philox stream id fixes the noise contract
+    (oracle/philox.py): stream = 16 * net + level."""
+    return get_default_graph().add_op("random_normal", [like], dict(stream=int(stream)), [(like.shape, KIND_F32)])[0]
+
+
+def conv_unit(x, W, b, ksize, norm, norm_vars, act, training, num_groups=None, head=False, name="conv"):
+    """conv (SAME, stride 1) -> [+bias] -> [norm] -> act as ONE node (tfwrapper/layers.py:122-135)."""
+    cout = W.shape[3]
+    kind = KIND_F32 if head else KIND_ACT
+    attrs = dict(W=W, b=b, ksize=int(ksize), norm=norm, norm_vars=norm_vars, act=act, training=training,
+                 num_groups=num_groups, head=head)
+    return get_default_graph().add_op("conv_unit", [x], attrs, [(x.shape[:3] + (cout,), kind)], name=name)[0]
+
+
+def avg_pool2x2(x):
+    n, h, w, c = x.shape
+    return get_default_graph().add_op("avgpool", [x], {}, [((n, (h + 1) // 2, (w + 1) // 2, c), x.kind)])[0]
+
+
+def bilinear_up2x(x, name="ups"):
+    n, h, w, c = x.shape
+    return get_default_graph().add_op("bilinear_up", [x], {}, [((n, 2 * h, 2 * w, c), x.kind)], name=name)[0]
+
+
+def resize_nearest(x, out_hw):
+    """tf.image.resize_images(..., NEAREST_NEIGHBOR) by an integer power-of-two factor (likelihoods.py:221).
+    Never materialised: the loss / aggregation kernels read the coarse logits through a shift."""
+    n, h, w, c = x.shape
+    f = out_hw[0] // h
+    if h * f != out_hw[0] or w * f != out_hw[1] or f & (f - 1) or f > 16:
+        raise ValueError("nearest resize: integer power-of-two factor <= 16 required (%s -> %s)" % ((h, w), out_hw))
+    return get_default_graph().add_op("nn_resize", [x], dict(shift=f.bit_length() - 1),
+                                      [((n, out_hw[0], out_hw[1], c), KIND_F32)])[0]
+
+
+def global_average_pool(x, name=None):
+    n, h, w, c = x.shape
+    return get_default_graph().add_op("global_avgpool", [x], {}, [((n, c), KIND_F32)], name=name or "gap")[0]
+
+
+def tile_pixels(z, h, w):
+    """tf.reshape(z,[bs,1,1,zdim]) + tf.tile (likelihoods.py:147-149): [B, C] -> [B, h, w, C]."""
+    n, c = z.shape
+    return get_default_graph().add_op("tile_pixels", [z], {}, [((n, h, w, c), KIND_ACT)])[0]
+
+
+def residual_multinoulli(s_list, labels, weight):
+    """phiseg_model.py:229-262 for all levels at once -> (list of per-level loss scalars, s_accum[0])."""
+    g = get_default_graph()
+    L = len(s_list)
+    outs = g.add_op("residual_ce", list(s_list) + [labels], dict(L=L, weight=float(weight)),
+                    [((), KIND_F32)] * L + [(s_list[0].shape, KIND_F32)], name="residual_multinoulli")
+    return outs[:L], outs[L]
+
+
+def kl_two_gauss(mu0, sigma0, mu1, sigma1, level_weight, loss_weight):
+    """level_weight * KL_two_gauss_with_diag_cov (phiseg_model.py:210-226, 271-279)."""
+    return get_default_graph().add_op("kl", [mu0, sigma0, mu1, sigma1],
+                                      dict(level_weight=float(level_weight), loss_weight=float(loss_weight)),
+                                      [((), KIND_F32)], name="KL")[0]
+
+
+def aggregate_logits(s_list):
+    """_aggregate_output_list(use_softmax=False) + tf.nn.softmax (phiseg_model.py:106-109, 304-311)
+    -> (sum of levels, softmax of the sum)."""
+    outs = get_default_graph().add_op("aggregate", list(s_list), dict(L=len(s_list)),
+                                      [(s_list[0].shape, KIND_F32), (s_list[0].shape, KIND_F32)], name="aggregate")
+    return outs[0], outs[1]
+
+
+def weighted_sum(scalars, weights):
+    return get_default_graph().add_op("weighted_sum", list(scalars), dict(weights=[float(w) for w in weights]),
+                                      [((), KIND_F32)], name="loss_tot")[0]

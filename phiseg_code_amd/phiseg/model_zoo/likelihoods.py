@@ -1,0 +1,75 @@
+"""Likelihood decoders p(s | z) -- same callables as the reference's phiseg/model_zoo/likelihoods.py."""
+from phiseg_code_amd import graph as G
+from phiseg_code_amd.phiseg.model_zoo import _common
+from phiseg_code_amd.tfwrapper import activations as act
+from phiseg_code_amd.tfwrapper import layers
+from phiseg_code_amd.tfwrapper import normalisation as tfnorm
+
+
+def det_unet2D(z_list, training, image_size, n_classes, scope_reuse=False, norm=tfnorm.batch_norm, **kwargs):
+    raise NotImplementedError("det_unet2D is the deterministic baseline (no latent path; out of scope)")
+
+
+def prob_unet2D(z_list, training, image_size, n_classes, scope_reuse=False, norm=tfnorm.batch_norm, **kwargs):
+    """likelihoods.py:81-159: U-Net on x, z broadcast over the image and mixed in by three 1x1 convs."""
+    x = kwargs.get('x')
+    z = z_list[0]
+    resolution_levels = kwargs.get('resolution_levels', 7)
+    widths = _common.channel_plan(kwargs.get('n0', 32))
+    g = G.get_default_graph()
+    with g.variable_scope('likelihood') as scope:
+        if scope_reuse:
+            scope.reuse_variables()
+        add_bias = norm is not tfnorm.batch_norm
+        cu = dict(training=training, normalisation=norm, add_bias=add_bias)
+        with g.variable_scope('encoder'):
+            enc = _common.encoder(x, 'conv_%d_%d', widths, resolution_levels, norm, training,
+                                  extra=dict(add_bias=add_bias))
+        with g.variable_scope('decoder'):
+            net = enc[-1]
+            for jj in range(resolution_levels - 1):
+                ii = resolution_levels - jj - 1
+                net = layers.bilinear_upsample2D(net, 'upsample', 2)
+                net = layers.crop_and_concat([net, enc[ii - 1]], axis=3)
+                for t in (1, 2, 3):
+                    net = layers.conv2D(net, 'conv_%d_%d' % (jj, t), num_filters=widths[ii], **cu)
+        net = G.concat([net, G.tile_pixels(z, image_size[0], image_size[1])], axis=-1)
+        for t in range(3):
+            net = layers.conv2D(net, 'recomb_%d' % t, num_filters=widths[0], kernel_size=(1, 1), **cu)
+        return [layers.conv2D(net, 'prediction', num_filters=n_classes, kernel_size=(1, 1), activation=act.identity)]
+
+
+def phiseg(z_list, training, image_size, n_classes, scope_reuse=False, norm=tfnorm.batch_norm, **kwargs):
+    """likelihoods.py:162-223: per-level refinement + upsampling, top-down fusion, one logit head per level."""
+    widths = _common.channel_plan(kwargs.get('n0', 32))
+    resolution_levels = kwargs.get('resolution_levels', 7)
+    latent_levels = kwargs.get('latent_levels', 5)
+    lvl_diff = resolution_levels - latent_levels
+    g = G.get_default_graph()
+    cu = dict(normalisation=norm, training=training)
+    with g.variable_scope('likelihood') as scope:
+        if scope_reuse:
+            scope.reuse_variables()
+        post_z = []
+        for i in range(latent_levels):
+            net = layers.conv2D(z_list[i], 'z%d_post_1' % i, num_filters=widths[i], **cu)
+            net = layers.conv2D(net, 'z%d_post_2' % i, num_filters=widths[i], **cu)
+            with g.variable_scope('preups_%d' % i):
+                for t in range(lvl_diff):
+                    net = layers.bilinear_upsample2D(net, 'ups_%d' % t, 2)
+                    net = layers.conv2D(net, 'z%d_post' % t, num_filters=widths[i], **cu)
+            post_z.append(net)
+        post_c = [None] * latent_levels
+        post_c[-1] = post_z[-1]
+        for i in reversed(range(latent_levels - 1)):
+            below = layers.bilinear_upsample2D(post_c[i + 1], name='post_z%d_ups' % (i + 1), factor=2)
+            below = layers.conv2D(below, 'post_z%d_ups_c' % (i + 1), num_filters=widths[i], **cu)
+            net = G.concat([post_z[i], below], axis=3, name='concat_%d' % i)
+            net = layers.conv2D(net, 'post_c_%d_1' % i, num_filters=widths[i + lvl_diff], **cu)
+            post_c[i] = layers.conv2D(net, 'post_c_%d_2' % i, num_filters=widths[i + lvl_diff], **cu)
+        s = []
+        for i in range(latent_levels):
+            s_in = layers.conv2D(post_c[i], 'y_lvl%d' % i, num_filters=n_classes, kernel_size=(1, 1),
+                                 activation=act.identity)
+            s.append(G.resize_nearest(s_in, image_size[0:2]))
+        return s

@@ -1,0 +1,22 @@
+"""Approximate posteriors q(z | s, x) -- same callables as the reference's phiseg/model_zoo/posteriors.py."""
+from phiseg_code_amd import graph as G
+from phiseg_code_amd.phiseg.model_zoo import _common
+from phiseg_code_amd.tfwrapper import normalisation as tfnorm
+
+
+def _inputs(x, s_oh):
+    return G.concat([x, s_oh - 0.5], axis=-1)          # posteriors.py:30,87
+
+
+def prob_unet2D(x, s_oh, zdim_0, training, scope_reuse=False, norm=tfnorm.batch_norm, **kwargs):
+    return _common.probunet_encoder_head('posterior', 'posterior', _inputs(x, s_oh), zdim_0, training, scope_reuse,
+                                         norm, kwargs)
+
+
+def phiseg(x, s_oh, zdim_0, training, scope_reuse=False, norm=tfnorm.batch_norm, **kwargs):
+    return _common.hierarchical_ladder('posterior', 'posterior', _inputs(x, s_oh), None, zdim_0, training,
+                                       scope_reuse, norm, kwargs)
+
+
+def dummy(x, s_oh, zdim_0, training, scope_reuse=False, norm=tfnorm.batch_norm, **kwargs):
+    raise NotImplementedError("posteriors.dummy belongs to the deterministic U-Net baseline (out of scope)")

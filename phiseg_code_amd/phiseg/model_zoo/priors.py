@@ -1,0 +1,22 @@
+"""Priors p(z | x) -- same callables as the reference's phiseg/model_zoo/priors.py."""
+from phiseg_code_amd.phiseg.model_zoo import _common
+from phiseg_code_amd.tfwrapper import normalisation as tfnorm
+
+
+def prob_unet2D(z_list, x, zdim_0, n_classes, generation_mode, training, scope_reuse=False, norm=tfnorm.batch_norm,
+                **kwargs):
+    # priors.py:8-48 ignores z_list / generation_mode: the prior always draws its own z
+    return _common.probunet_encoder_head('prior', 'prior_gen' if generation_mode else 'prior', x, zdim_0, training,
+                                         scope_reuse, norm, kwargs)
+
+
+def phiseg(z_list, x, zdim_0, n_classes, generation_mode, training, scope_reuse=False, norm=tfnorm.batch_norm,
+           **kwargs):
+    teacher = None if generation_mode else z_list       # priors.py:123-126
+    return _common.hierarchical_ladder('prior', 'prior_gen' if generation_mode else 'prior', x, teacher, zdim_0,
+                                       training, scope_reuse, norm, kwargs)
+
+
+def dummy(z_list, x, zdim_0, n_classes, generation_mode, training, scope_reuse=False, norm=tfnorm.batch_norm,
+          **kwargs):
+    raise NotImplementedError("priors.dummy belongs to the deterministic U-Net baseline (out of scope)")

@@ -1,0 +1,270 @@
+"""The PHiSeg model: graph wiring, ELBO, train loop, sampling API.
+
+Counterpart of the reference's phiseg/phiseg_model.py with the same public surface
+(``phiseg(exp_config)``, ``.train(data)``, ``.predict*``, ``.generate_prior_samples``, ``.load_weights``,
+attributes ``x_inp``, ``s_inp``, ``training_pl``, ``lr_pl``, ``z_list``, ``s_out_list``, ``s_out_eval``,
+``s_out_eval_sm``, ``loss_dict``, ``loss_tot``, ``train_step``, ``sess``) -- but ``sess.run`` lowers the
+requested fetches to hand-written HIP kernels replayed from a hipGraph (phiseg_code_amd.engine) instead of
+dispatching TensorFlow ops.
+
+Deliberate, documented differences from the TF1 graph:
+* Q1/Q4: only the live graph is executed per training step (the reference also runs the generation-mode
+  prior, the evaluation likelihood and the never-consumed up-sampling branches because their batch-norm
+  update ops sit in UPDATE_OPS); batch-norm moving statistics are updated once per step from the training
+  graph instance.
+* Q10: noise is a seeded Philox4x32-10 stream keyed by (seed, step, net, level, global sample index).
+"""
+import logging
+import os
+import time
+
+import numpy as np
+
+from phiseg_code_amd import engine
+from phiseg_code_amd import graph as G
+from phiseg_code_amd import utils
+
+logging.basicConfig(level=logging.INFO, format='%(asctime)s %(message)s')
+
+
+class _Flag:
+    """Scalar placeholder fed through feed_dict (training_pl, lr_pl)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __repr__(self):
+        return "<placeholder %s>" % self.name
+
+
+class TrainStep:
+    """Handle returned as ``model.train_step``: fetching it runs backward + Adam (optimizer.minimize)."""
+
+    def __init__(self, loss):
+        self.loss = loss
+
+
+class Session:
+    """``sess.run(fetches, feed_dict)`` over compiled plans (one per fetch set / batch size / training flag)."""
+
+    def __init__(self, model, compute_dtype, rng_seed=42, dist=None):
+        self.model = model
+        self.compute_dtype = compute_dtype
+        self.rng_seed = rng_seed
+        self.dist = dist
+        self.store = None
+        self.plans = {}
+
+    def _ensure_store(self):
+        if self.store is None:
+            self.store = engine.ParamStore(self.model.graph, seed=self.model.init_seed)
+        return self.store
+
+    def plan_for(self, fetch_tensors, train, batch, training):
+        key = (tuple(id(t) for t in fetch_tensors), bool(train), int(batch), bool(training))
+        if key not in self.plans:
+            store = self._ensure_store()
+            world, rank = (self.dist.world, self.dist.rank) if self.dist else (1, 0)
+            self.plans[key] = engine.Plan(
+                store, fetch_tensors, loss=self.model.loss_tot if train else None, batch=batch, training=training,
+                compute_dtype=self.compute_dtype, rng_seed=self.rng_seed, sample_offset=rank * batch,
+                loss_inv_batch=1.0 / (batch * world), split_optimizer=world > 1)
+        return self.plans[key]
+
+    def run(self, fetches, feed_dict=None):
+        feed_dict = feed_dict or {}
+        m = self.model
+        single = not isinstance(fetches, (list, tuple))
+        flat, spec = [], []
+
+        def walk(f):
+            if isinstance(f, (list, tuple)):
+                return [walk(x) for x in f]
+            flat.append(f)
+            return len(flat) - 1
+        spec = walk([fetches] if single else list(fetches))
+        train = any(isinstance(f, TrainStep) for f in flat)
+        tensors = [f for f in flat if isinstance(f, G.Tensor)]
+        x = feed_dict.get(m.x_inp)
+        if x is None:
+            raise ValueError("feed_dict must provide x_inp")
+        x = np.asarray(x)
+        training = bool(feed_dict.get(m.training_pl, False))
+        plan = self.plan_for(tensors, train, x.shape[0], training)
+        plan.set_input("x_input", x)
+        if "s_input" in plan.feeds:
+            if m.s_inp not in feed_dict:
+                raise ValueError("these fetches need s_inp")
+            plan.set_input("s_input", feed_dict[m.s_inp])
+        if m.lr_pl in feed_dict:
+            self.store.set_lr(feed_dict[m.lr_pl])
+        if train and self.dist is not None and self.dist.world > 1:
+            plan.run_main()
+            self.dist.allreduce_sum(self.store.grads, plan)
+            plan.run_opt()
+        else:
+            plan.run()
+        vals = [plan.fetch(f) if isinstance(f, G.Tensor) else None for f in flat]
+
+        def build(s):
+            return [build(x) for x in s] if isinstance(s, list) else vals[s]
+        out = build(spec)
+        return out[0] if single else out
+
+
+class phiseg():
+
+    def __init__(self, exp_config, dist=None, init_seed=0, rng_seed=42):
+        self.exp_config = exp_config
+        self.init_seed = init_seed
+        self.checks()
+        self.graph = G.reset_default_graph()
+        L = exp_config.latent_levels
+
+        # placeholders (phiseg_model.py:26-32)
+        self.x_inp = G.placeholder(G.KIND_F32, [None] + list(exp_config.image_size), name='x_input')
+        self.s_inp = G.placeholder(G.KIND_U8, [None] + list(exp_config.image_size[0:2]), name='s_input')
+        self.s_inp_oh = G.one_hot(self.s_inp, depth=exp_config.nlabels)
+        self.training_pl = _Flag('training_time')
+        self.lr_pl = _Flag('learning_rate')
+
+        # networks (phiseg_model.py:37-98)
+        net_kw = dict(n0=exp_config.n0, resolution_levels=exp_config.resolution_levels, latent_levels=L,
+                      norm=exp_config.layer_norm)
+        self.z_list, self.mu_list, self.sigma_list = exp_config.posterior(
+            self.x_inp, self.s_inp_oh, exp_config.zdim0, training=self.training_pl, **net_kw)
+        self.prior_z_list, self.prior_mu_list, self.prior_sigma_list = exp_config.prior(
+            self.z_list, self.x_inp, zdim_0=exp_config.zdim0, n_classes=exp_config.nlabels,
+            training=self.training_pl, generation_mode=False, **net_kw)
+        self.prior_z_list_gen, self.prior_mu_list_gen, self.prior_sigma_list_gen = exp_config.prior(
+            self.z_list, self.x_inp, zdim_0=exp_config.zdim0, n_classes=exp_config.nlabels,
+            training=self.training_pl, generation_mode=True, scope_reuse=True, **net_kw)
+        self.s_out_list = exp_config.likelihood(self.z_list, self.training_pl, n_classes=exp_config.nlabels,
+                                                image_size=exp_config.image_size, x=self.x_inp, **net_kw)
+        self.s_out_eval_list = exp_config.likelihood(self.prior_z_list_gen, self.training_pl, scope_reuse=True,
+                                                     n_classes=exp_config.nlabels, image_size=exp_config.image_size,
+                                                     x=self.x_inp, **net_kw)
+        # aggregated outputs (phiseg_model.py:106-109)
+        self.s_out_eval, self.s_out_eval_sm = G.aggregate_logits(self.s_out_eval_list)
+
+        # losses (phiseg_model.py:113-130)
+        self.loss_dict = {}
+        terms, weights = [], []
+        self.s_out = None
+        if getattr(exp_config, 'residual_multinoulli_loss_weight', None) is not None:
+            logging.info(' - Adding residual multinoulli loss')
+            w = exp_config.residual_multinoulli_loss_weight
+            ce, self.s_out = G.residual_multinoulli(self.s_out_list, self.s_inp, w)
+            for ii in reversed(range(L)):
+                self.loss_dict['residual_multinoulli_loss_lvl%d' % ii] = ce[ii]
+                terms.append(ce[ii])
+                weights.append(w)
+        if getattr(exp_config, 'KL_divergence_loss_weight', None) is not None:
+            logging.info(' - Adding hierarchical KL loss')
+            w = exp_config.KL_divergence_loss_weight
+            lw = [4 ** i for i in range(L)] if exp_config.exponential_weighting else [1] * L
+            for ii in reversed(range(L)):
+                kl = G.kl_two_gauss(self.mu_list[ii], self.sigma_list[ii], self.prior_mu_list[ii],
+                                    self.prior_sigma_list[ii], lw[ii], w)
+                self.loss_dict['KL_divergence_loss_lvl%d' % ii] = kl
+                terms.append(kl)
+                weights.append(w)
+        if getattr(exp_config, 'weight_decay_weight', None) is not None:
+            raise NotImplementedError("weight decay is off in every PHiSeg experiment (phiseg_model.py:126)")
+        self.loss_tot = G.weighted_sum(terms, weights)
+        self.loss_dict['total_loss'] = self.loss_tot
+        self.train_step = TrainStep(self.loss_tot)
+
+        self.sess = Session(self, getattr(exp_config, 'compute_dtype', 'f32'), rng_seed=rng_seed, dist=dist)
+        self.dist = dist
+
+    def checks(self):
+        pass
+
+    # ---- training loop (phiseg_model.py:166-207) -------------------------------------------------
+    def train(self, data, num_iter=None, log_every=100, log_dir=None):
+        cfg = self.exp_config
+        num_iter = cfg.num_iter if num_iter is None else num_iter
+        losses = []
+        t0 = time.time()
+        for step in range(num_iter):
+            lr_key, _ = utils.find_floor_in_list(cfg.lr_schedule_dict.keys(), step)
+            lr = cfg.lr_schedule_dict[lr_key]
+            x_b, s_b = data.train.next_batch(cfg.batch_size)
+            _, loss_tot_eval = self.sess.run([self.train_step, self.loss_tot],
+                                             feed_dict={self.x_inp: x_b, self.s_inp: s_b, self.training_pl: True,
+                                                        self.lr_pl: lr})
+            losses.append(float(loss_tot_eval))
+            if log_every and step % log_every == 0:
+                logging.info('step %d  loss %.4f  (%.1f img/s)', step, losses[-1],
+                             (step + 1) * cfg.batch_size / max(time.time() - t0, 1e-9))
+            vf = getattr(cfg, 'validation_frequency', None)
+            if log_dir and vf and step % vf == 0:
+                self.save_weights(os.path.join(log_dir, 'model.ckpt-%d.npz' % step))
+        return losses
+
+    # ---- checkpoints (npz keyed by the TF variable names of SURVEY.md Appendix B) -------------------
+    def save_weights(self, path):
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        store = self.sess._ensure_store()
+        np.savez(path, __step__=store.step.cpu().numpy(), **store.export())
+
+    def load_weights(self, log_dir=None, type='latest', **kwargs):
+        path = log_dir
+        if os.path.isdir(log_dir):
+            names = {'latest': 'model.ckpt', 'best_dice': 'model_best_dice.ckpt', 'best_loss': 'model_best_loss.ckpt',
+                     'best_ged': 'model_best_ged.ckpt', 'best_ncc': 'model_best_ncc.ckpt'}
+            if type not in names:
+                raise ValueError('Argument type=%s is unknown.' % type)
+            cands = sorted((f for f in os.listdir(log_dir) if f.startswith(names[type]) and f.endswith('.npz')),
+                           key=lambda f: int(''.join(c for c in f if c.isdigit()) or 0))
+            if not cands:
+                raise FileNotFoundError('no %s checkpoint in %s' % (type, log_dir))
+            path = os.path.join(log_dir, cands[-1])
+        ck = np.load(path)
+        store = self.sess._ensure_store()
+        store.load({k: ck[k] for k in ck.files if k != '__step__'})
+        if '__step__' in ck.files:
+            store.set_step(int(ck['__step__'][0]))
+
+    def set_weights(self, values):
+        self.sess._ensure_store().load(values)
+
+    # ---- inference API (phiseg_model.py:313-375) -------------------------------------------------
+    def generate_prior_samples(self, x_in, return_params=False):
+        fd = {self.training_pl: False, self.x_inp: x_in}
+        if return_params:
+            z, mu, sg = self.sess.run([self.prior_z_list_gen, self.prior_mu_list_gen, self.prior_sigma_list_gen], fd)
+            return z, mu, sg
+        return self.sess.run(self.prior_z_list_gen, fd)
+
+    def predict(self, x_in, num_samples=50, return_softmax=False):
+        fd = {self.training_pl: False, self.x_inp: x_in}
+        cumsum_sm = self.sess.run(self.s_out_eval_sm, feed_dict=fd)
+        for _ in range(num_samples - 1):
+            self._advance_noise()
+            cumsum_sm = cumsum_sm + self.sess.run(self.s_out_eval_sm, feed_dict=fd)
+        self._advance_noise()
+        if return_softmax:
+            return np.argmax(cumsum_sm, axis=-1), cumsum_sm / num_samples
+        return np.argmax(cumsum_sm, axis=-1)
+
+    def predict_segmentation_sample(self, x_in, return_softmax=False):
+        fd = {self.training_pl: False, self.x_inp: x_in}
+        out = self.sess.run(self.s_out_eval_sm if return_softmax else self.s_out_eval, feed_dict=fd)
+        self._advance_noise()
+        return out if return_softmax else np.argmax(out, axis=-1)
+
+    def predict_segmentation_sample_levels(self, x_in, return_softmax=False):
+        fd = {self.training_pl: False, self.x_inp: x_in}
+        lv = self.sess.run(self.s_out_eval_list, feed_dict=fd)
+        self._advance_noise()
+        if return_softmax:
+            e = [np.exp(v - v.max(axis=-1, keepdims=True)) for v in lv]
+            return [v / v.sum(axis=-1, keepdims=True) for v in e]
+        return lv
+
+    def _advance_noise(self):
+        """Every sampling call must see fresh noise (TF's stateful RNG): bump the Philox step word."""
+        store = self.sess._ensure_store()
+        store.noise_step += 1

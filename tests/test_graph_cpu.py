@@ -1,0 +1,86 @@
+"""Host logic without a GPU: the symbolic graph built by our tfwrapper / model_zoo / phiseg_model must
+create exactly the variables (names, shapes, creation order) the reference's code creates -- the fixture's
+var_order was recorded while executing the reference zoo (tools/make_goldens.py)."""
+import importlib
+import types
+
+import numpy as np
+import pytest
+
+from tests.helpers import load_golden
+
+from phiseg_code_amd import graph as G
+from phiseg_code_amd.phiseg import phiseg_model
+from phiseg_code_amd.phiseg.model_zoo import likelihoods, posteriors, priors
+from phiseg_code_amd.tfwrapper import normalisation as tfnorm
+
+NORMS = {"batch_norm": tfnorm.batch_norm, "group_norm": tfnorm.group_norm2D, "instance_norm": tfnorm.instance_norm2D}
+
+
+def make_config(cfg, compute_dtype="f32"):
+    base = importlib.import_module("phiseg_code_amd.phiseg.experiments.phiseg_7_5")
+    c = types.SimpleNamespace(**{k: getattr(base, k) for k in dir(base) if not k.startswith("_")})
+    arch = cfg["arch"]
+    c.posterior, c.prior, c.likelihood = getattr(posteriors, arch), getattr(priors, arch), getattr(likelihoods, arch)
+    c.layer_norm = NORMS[cfg["norm"]]
+    c.latent_levels, c.resolution_levels = cfg["latent_levels"], cfg["resolution_levels"]
+    c.n0, c.zdim0, c.nlabels = cfg["n0"], cfg["zdim0"], cfg["nlabels"]
+    c.image_size = (cfg["H"], cfg["H"], 1)
+    c.batch_size = cfg["B"]
+    c.compute_dtype = compute_dtype
+    return c
+
+
+@pytest.mark.parametrize("case", ["tiny_phiseg_bn", "tiny_phiseg_gn4", "tiny_phiseg_in", "tiny_probunet_bn",
+                                  "tiny_phiseg71_bn", "lidc_phiseg_bn"])
+def test_variables_match_reference_trace(case):
+    g, cfg, var_order = load_golden(case)
+    model = phiseg_model.phiseg(make_config(cfg))
+    ours = [(n, tuple(v.shape)) for n, v in model.graph.variables.items()]
+    assert ours == [(n, tuple(s)) for n, s in var_order]
+    # 11 loss_dict entries for 5 latent levels, same keys as the reference (phiseg_model.py:253,279,130)
+    L = cfg["latent_levels"]
+    want = {"total_loss"} | {"residual_multinoulli_loss_lvl%d" % i for i in range(L)} | \
+           {"KL_divergence_loss_lvl%d" % i for i in range(L)}
+    assert set(model.loss_dict) == want
+
+
+def test_phiseg_7_5_parameter_count_and_scope_reuse():
+    base = importlib.import_module("phiseg_code_amd.phiseg.experiments.phiseg_7_5")
+    model = phiseg_model.phiseg(base)
+    n_train = sum(v.size for v in model.graph.variables.values() if v.trainable)
+    assert n_train == 18706994           # 18 706 994 trainable parameters incl. never-used branches
+    with pytest.raises(ValueError):      # re-creating an existing variable without scope_reuse must fail
+        posteriors.phiseg(model.x_inp, model.s_inp_oh, 2, training=True)
+
+
+def test_experiment_config_surface():
+    want = ["experiment_name", "log_dir_name", "posterior", "likelihood", "prior", "layer_norm",
+            "use_logistic_transform", "latent_levels", "resolution_levels", "n0", "zdim0", "max_channel_power",
+            "data_identifier", "preproc_folder", "data_root", "dimensionality_mode", "image_size", "nlabels",
+            "num_labels_per_subject", "augmentation_options", "optimizer", "lr_schedule_dict", "deep_supervision",
+            "batch_size", "num_iter", "annotator_range", "KL_divergence_loss_weight", "exponential_weighting",
+            "residual_multinoulli_loss_weight", "do_image_summaries", "rescale_RGB", "validation_frequency",
+            "validation_samples", "num_validation_images", "tensorboard_update_frequency"]
+    for name in ["phiseg_7_5", "phiseg_7_1", "phiseg_7_5_1annot", "phiseg_7_1_1annot", "probunet", "probunet_1annot"]:
+        m = importlib.import_module("phiseg_code_amd.phiseg.experiments." + name)
+        for k in want:
+            assert hasattr(m, k), (name, k)
+    pu = importlib.import_module("phiseg_code_amd.phiseg.experiments.probunet")
+    assert pu.zdim0 == 6 and pu.latent_levels == 1 and pu.posterior is posteriors.prob_unet2D
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from phiseg_code_amd import runtime as rt
+    protos = rt.parse_header()
+    assert len(protos) >= 55
+    lib = rt.lib()                       # binds every prototype; a missing symbol raises AttributeError
+    assert lib.abi_version() == 1
+
+
+def test_dropin_aliases():
+    import phiseg_code_amd
+    phiseg_code_amd.install_dropin_aliases()
+    import tfwrapper.layers as L2
+    from phiseg_code_amd.tfwrapper import layers as L1
+    assert L1 is L2

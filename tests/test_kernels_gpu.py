@@ -219,7 +219,8 @@ def test_norm_fwd_bwd(L, case):
     ar = T.relu(yr)
     xd, gd, bd = dev(x, dt), dev(gamma), dev(beta)
     sums = torch.zeros(NS, C, 2, dtype=torch.float32).cuda()
-    L.norm_stats(xd.data_ptr(), dt, sums.data_ptr(), NS, P, C, S())
+    pivot = torch.zeros(NS, C, dtype=torch.float32).cuda()
+    L.norm_stats(xd.data_ptr(), dt, sums.data_ptr(), pivot.data_ptr(), NS, P, C, S())
     mean = torch.empty(NS * GG, dtype=torch.float32).cuda()
     rstd = torch.empty_like(mean)
     scale = torch.empty(NS * C, dtype=torch.float32).cuda()
@@ -227,7 +228,7 @@ def test_norm_fwd_bwd(L, case):
     mm = dev(0.1 * RNG.standard_normal(C))
     mv = dev(1.0 + 0.3 * RNG.random(C))
     mm0, mv0 = host(mm).copy(), host(mv).copy()
-    L.norm_finalize(sums.data_ptr(), gd.data_ptr(), bd.data_ptr(), eps, NS, P, C, GG, mean.data_ptr(),
+    L.norm_finalize(sums.data_ptr(), pivot.data_ptr(), gd.data_ptr(), bd.data_ptr(), eps, NS, P, C, GG, mean.data_ptr(),
                     rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                     mm.data_ptr() if kind == "batch" else None, mv.data_ptr() if kind == "batch" else None,
                     0.01 if kind == "batch" else 0.0, S())
