@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py -- training images/s of the PHiSeg ELBO step (phiseg_7_5, 128x128 LIDC-shaped, bf16, B=64/GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training step of the reference's hot loop (phiseg_model.py:194): forward of posterior,
+teacher-forced prior and likelihood, 5 residual cross-entropy + 5 KL terms, backward, TF1 Adam -- for N > 1 plus
+ONE flat gradient all-reduce over RCCL (weak scaling: 64 images per GPU).  Inputs are resident in HBM before the
+timed region.  Rank 0 prints one JSON line; `roofline` times the dominant kernel family (the bf16 MFMA 3x3
+convolutions) with HIP events on the plan's own stream; `cpu_baseline` times the CPU oracle (port of the
+reference's TF1 graph -- TensorFlow 1.12 itself is not installable) on a bounded sample on the host cores.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F_TRAIN_GFLOP_PER_IMAGE = 75.08       # fwd 25.026 + dgrad + wgrad, live graph, 128x128, 2 classes
+PEAK_BF16_TFLOPS = 2500.0             # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def make_config(batch, compute_dtype):
+    base = importlib.import_module("phiseg_code_amd.phiseg.experiments.phiseg_7_5")
+    cfg = types.SimpleNamespace(**{k: getattr(base, k) for k in dir(base) if not k.startswith("_")})
+    cfg.batch_size = batch
+    cfg.compute_dtype = compute_dtype
+    return cfg
+
+
+def cpu_baseline(batch=12, steps=2):
+    """The oracle (oracle/: port of the reference's TF 1.12 graph to torch-CPU, fp32) running the SAME training
+    step on the host cores: `steps` timed steps at batch 12 (the reference's own batch size) after one warm-up."""
+    import numpy as np
+    import torch
+    from oracle import init as oinit
+    from oracle import train as otrain
+    from phiseg_code_amd.phiseg import phiseg_model
+    cfg = dict(arch="phiseg", norm="batch_norm", n0=32, zdim0=2, latent_levels=5, resolution_levels=7, nlabels=2,
+               image_size=(128, 128, 1), KL_weight=1.0, CE_weight=1.0, exponential_weighting=True)
+    model = phiseg_model.phiseg(make_config(batch, "f32"))
+    var_specs = [(n, v.shape) for n, v in model.graph.variables.items()]
+    params = otrain.make_params(var_specs, 0, torch.float32, perturbed=False)
+    x, s = oinit.synthetic_batch(batch, 128, 2, 1234)
+    otrain.train_steps(params, [(x, s)], cfg, 42, lr=1e-3, n_steps=1, dtype=torch.float32)      # warm-up
+    t0 = time.time()
+    otrain.train_steps(params, [(x, s)], cfg, 42, lr=1e-3, n_steps=steps, dtype=torch.float32)
+    dt = time.time() - t0
+    return {"value": batch * steps / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d training steps (fwd+ELBO+autograd+Adam) of phiseg_7_5 128x128 at batch %d, torch-CPU fp32 "
+                      "oracle, %.1f s" % (steps, batch, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--profile-table", action="store_true", help="print the per-layer kernel timing table")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from phiseg_code_amd import distributed
+    from phiseg_code_amd.data import synthetic
+    from phiseg_code_amd.phiseg import phiseg_model
+
+    ctx = distributed.DistContext()
+    assert ctx.world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    cfg = make_config(args.batch, args.dtype)
+    model = phiseg_model.phiseg(cfg, dist=ctx if ctx.world > 1 else None)
+    sess = model.sess
+    plan = sess.plan_for([model.loss_tot], True, args.batch, True)
+    rng = np.random.default_rng(1234 + ctx.rank)
+    x, s = synthetic.make_batch(args.batch, 128, cfg.nlabels, rng)
+    plan.set_input("x_input", x)          # resident in HBM for the whole run
+    plan.set_input("s_input", s)
+    sess.store.set_lr(1e-3)
+    if ctx.world > 1:                     # identical replicas
+        ctx.broadcast_(sess.store.params)
+        ctx.broadcast_(sess.store.state)
+
+    def step():
+        if ctx.world > 1:
+            plan.run_main()
+            ctx.allreduce_sum(sess.store.grads, plan)
+            plan.run_opt()
+        else:
+            plan.run()
+
+    for _ in range(max(args.warmup, 2)):  # >= 2: eager pass, then hipGraph capture
+        step()
+    plan.sync()
+    torch.cuda.synchronize()
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    plan.sync()
+    torch.cuda.synchronize()
+    ctx.barrier()
+    dt = ctx.max_float(time.perf_counter() - t0)
+    loss = float(plan.fetch(model.loss_tot))
+    images = args.batch * ctx.world * args.steps
+    out = {
+        "metric": "training images/sec (ELBO step) phiseg_7_5 128x128 LIDC", "value": images / dt,
+        "unit": "images/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "phiseg_7_5 LIDC 128x128x1, 2 classes, %s, batch %d per GPU, full ELBO training step "
+                               "(fwd + 5 CE + 5 KL + bwd + Adam%s)" % (args.dtype, args.batch,
+                                                                       " + RCCL grad all-reduce" if ctx.world > 1 else ""),
+                   "global_batch": args.batch * ctx.world, "parallelism": "dp%d" % ctx.world,
+                   "launches_per_step": len(plan.launches) + len(plan.opt_launches), "final_loss": loss},
+        "step_tflops": images / dt * F_TRAIN_GFLOP_PER_IMAGE / 1e3,
+    }
+    if ctx.rank == 0 and not args.no_roofline and args.dtype == "bf16":
+        rows = plan.time_tagged_kernels(repeats=3)
+        fam = {}
+        for tag, fl, ms, shp in rows:
+            a = fam.setdefault(tag, [0.0, 0.0, 0])
+            a[0] += fl
+            a[1] += ms
+            a[2] += 1
+        if args.profile_table:
+            for tag, fl, ms, shp in sorted(rows, key=lambda r: -r[2])[:40]:
+                print("# %-20s %8.3f ms %8.1f TFLOP/s  %s" % (tag, ms, fl / ms / 1e9, shp), file=sys.stderr)
+        fl = sum(v[0] for k, v in fam.items() if k != "conv3x3_mfma_wgrad")
+        ms = sum(v[1] for k, v in fam.items() if k != "conv3x3_mfma_wgrad")
+        nl = sum(v[2] for k, v in fam.items() if k != "conv3x3_mfma_wgrad")
+        out["roofline"] = {
+            "bound": "mfma", "kernel": "k_conv3x3_mfma<BN> (forward + data-gradient launches of one step)",
+            "achieved": fl / ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS,
+            "traffic": None, "launches": nl, "avg_launch_ms": ms / max(nl, 1),
+            "algorithmic_gflop_per_launch_avg": fl / max(nl, 1) / 1e9,
+            "families": {k: {"tflops": v[0] / v[1] / 1e9, "ms_per_step": v[1], "launches": v[2]} for k, v in fam.items()},
+            "conv_ms_per_step": sum(v[1] for v in fam.values()),
+        }
+    if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if ctx.rank == 0:
+        print(json.dumps(out))
+    ctx.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,39 @@
+"""Synthetic LIDC-shaped batches (there is no dataset on the benchmark box).
+
+Shapes and value ranges follow the reference's data pipeline: images are stored as ``image - 0.5`` and never
+re-normalised (data/lidc_data_loader.py:92, data/batch_provider.py:117-118), labels are uint8 in [0, nlabels).
+``data.train.next_batch(B)`` mirrors the call the reference's train loop makes (phiseg_model.py:193)."""
+import numpy as np
+
+
+def make_batch(batch, size, nlabels, rng):
+    h = w = size
+    x = (rng.random((batch, h, w, 1), dtype=np.float32) - 0.5).astype(np.float32)
+    s = np.zeros((batch, h, w), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for b in range(batch):
+        if rng.random() < 0.25:            # annotators often disagree on presence: 25 % empty masks
+            continue
+        cy, cx = rng.uniform(0.3125 * h, 0.6875 * h), rng.uniform(0.3125 * w, 0.6875 * w)
+        ry, rx = rng.uniform(3, 20) * h / 128.0, rng.uniform(3, 20) * w / 128.0
+        for k in range(1, nlabels):
+            f = 1.0 - (k - 1) / float(max(nlabels - 1, 1))
+            s[b][((yy - cy) / (ry * f)) ** 2 + ((xx - cx) / (rx * f)) ** 2 <= 1.0] = k
+    return x, s
+
+
+class _Split:
+    def __init__(self, size, nlabels, seed):
+        self.size, self.nlabels = size, nlabels
+        self.rng = np.random.default_rng(seed)
+
+    def next_batch(self, batch_size):
+        return make_batch(batch_size, self.size, self.nlabels, self.rng)
+
+
+class SyntheticLIDC:
+    """Object with the ``.train`` / ``.validation`` surface of the reference's ``lidc_data`` (data/lidc_data.py)."""
+
+    def __init__(self, exp_config, seed=1234):
+        self.train = _Split(exp_config.image_size[0], exp_config.nlabels, seed)
+        self.validation = _Split(exp_config.image_size[0], exp_config.nlabels, seed + 1)

@@ -159,6 +159,7 @@ class Plan:
         self.launches, self.opt_launches = [], []
         self._cur = self.launches
         self.val, self.grad, self.saved = {}, {}, {}
+        self.tags = {}
         self.feeds = {}
         self._keep = []
         self._wpk = {}
@@ -169,7 +170,9 @@ class Plan:
         self._graph_exec = self._graph_exec_opt = None
 
     # ---------------------------------------------------------------------------------------------
-    def _emit(self, fn, *args):
+    def _emit(self, fn, *args, tag=None, flops=0.0):
+        if tag is not None:
+            self.tags[(id(self._cur), len(self._cur))] = (tag, float(flops))
         self._cur.append((fn, args))
 
     def _alloc(self, shape, dt, zero=False):
@@ -313,7 +316,8 @@ class Plan:
         def conv_into(y, act_code, stats_direct=None, stats_part=None):
             if mfma:
                 self._emit(Lb.conv3x3_mfma_bf16, x.ptr, wf.ptr, y.ptr, bptr, act_code,
-                           stats_part.ptr if stats_part is not None else None, B, H, Wd, cin, cout, S)
+                           stats_part.ptr if stats_part is not None else None, B, H, Wd, cin, cout, S,
+                           tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
             else:
                 self._emit(Lb.conv2d_direct, x.ptr, x.dt, wptr, bptr, y.ptr, y.dt, B, H, Wd, cin, cout, k, act_code,
                            0, stats_direct.ptr if stats_direct is not None else None, S)
@@ -590,7 +594,8 @@ class Plan:
         dw = self.store.grad_ptr(W)
         db = self.store.grad_ptr(b) if b is not None else None
         if sv["mfma"]:
-            self._emit(Lb.conv3x3_wgrad_mfma_bf16, x.ptr, dY.ptr, dw, B, H, Wd, cin, cout, S)
+            self._emit(Lb.conv3x3_wgrad_mfma_bf16, x.ptr, dY.ptr, dw, B, H, Wd, cin, cout, S,
+                       tag="conv3x3_mfma_wgrad", flops=18.0 * cin * cout * B * H * Wd)
             if db is not None:
                 self._emit(Lb.channel_sum_accumulate, dY.ptr, dY.dt, db, B * H * Wd, cout, S)
         else:
@@ -600,7 +605,8 @@ class Plan:
             if sv["mfma"]:
                 _, wd = self._packed(W)
                 self._add_grad(xin, write_fn=lambda g: self._emit(
-                    Lb.conv3x3_mfma_bf16, dY.ptr, wd.ptr, g.ptr, None, 0, None, B, H, Wd, cout, cin, S))
+                    Lb.conv3x3_mfma_bf16, dY.ptr, wd.ptr, g.ptr, None, 0, None, B, H, Wd, cout, cin, S,
+                    tag="conv3x3_mfma_dgrad", flops=18.0 * cin * cout * B * H * Wd))
             else:
                 self._add_grad(xin, write_fn=lambda g: self._emit(
                     Lb.conv2d_direct, dY.ptr, dY.dt, self.store.ptr(W), None, g.ptr, g.dt, B, H, Wd, cin, cout, k, 0,
@@ -676,6 +682,30 @@ class Plan:
 
     def sync(self):
         self.L.stream_sync(self.stream)
+
+    def time_tagged_kernels(self, repeats=3):
+        """Per tagged launch (the bf16 MFMA convolutions): average GPU duration over `repeats` back-to-back
+        re-launches, bracketed by HIP events on THIS plan's stream.  -> list of (tag, flops, ms, args-shape)."""
+        ev0, ev1 = ctypes.c_void_p(), ctypes.c_void_p()
+        self.L.event_create(ctypes.byref(ev0))
+        self.L.event_create(ctypes.byref(ev1))
+        out = []
+        ms = ctypes.c_float()
+        for idx, (fn, args) in enumerate(self.launches):
+            tg = self.tags.get((id(self.launches), idx))
+            if tg is None:
+                continue
+            fn(*args)                                   # warm
+            self.L.event_record(ev0, self.stream)
+            for _ in range(repeats):
+                fn(*args)
+            self.L.event_record(ev1, self.stream)
+            self.L.event_sync(ev1)
+            self.L.event_elapsed_ms(ev0, ev1, ctypes.byref(ms))
+            out.append((tg[0], tg[1], ms.value / repeats, tuple(a for a in args if isinstance(a, int) and a < 1 << 20)))
+        self.L.event_destroy(ev0)
+        self.L.event_destroy(ev1)
+        return out
 
     def fetch(self, t):
         self.sync()
