@@ -71,10 +71,27 @@ int phx_conv2d_direct_wgrad(const void* x, int x_dt, const void* dy, int dy_dt, 
 int phx_pack_conv3x3_bf16(const float* w_hwio, void* wpk_fwd, void* wpk_dgrad, int Cin, int Cout, void* stream);
 int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* bias, int act,
                           float* stats_partial, int B, int H, int W, int K, int N, void* stream);
+/* Narrow-input convolutions (image inputs Cin = 1 / 3, posteriors.py:87, priors.py:80; latent inputs Cin = zdim0 = 2,
+ * likelihoods.py:197, posteriors.py:115): zero-pad the channel axis to Cin_pad = 32 so they run on the MFMA kernels: padded bf16 copy of the input, padded packed filter, and the filter gradient of the
+ * padded problem folded back into dw_hwio[9][Cin][Cout]. */
+int phx_pack_conv3x3_bf16_pad(const float* w_hwio, void* wpk_fwd, void* wpk_dgrad /* nullable */, int Cin, int Cin_pad,
+                              int Cout, void* stream);
+int phx_pad_channels_bf16(const void* x, int dt, int C, void* out, int Cpad, size_t npix, void* stream);
+int phx_unpad_channels_bf16(const void* src, void* dst, int dst_dt, int C, int Cpad, size_t npix, void* stream);
+int phx_unpad_filter_grad_accumulate(const float* dw_pad, float* dw_hwio, int Cin, int Cin_pad, int Cout, void* stream);
 int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W);     /* number of pixel tiles (= rows of stats_partial) */
 /* dw_hwio[kh][kw][ci][co] += sum x * dy (fp32 atomics), Cin % 32 == 0, Cout % 32 == 0. */
 int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, int B, int H, int W,
                                 int Cin, int Cout, void* stream);
+
+/* 1x1 "head" convolutions with nout in {2,4,6,8} outputs (mu / sigma / y_lvl / pre_mu / prediction heads:
+ * posteriors.py:125-127, priors.py:117-119, likelihoods.py:155,220): streaming kernels, fp32 outputs.
+ * w = HWIO 1x1 filter [C][nout];  fwd: y = act(x.w + b);  dgrad: dx = dy.w^T (written);  wgrad: dw += x^T.dy, db += sum dy */
+int phx_head1x1_fwd(const void* x, int x_dt, const float* w, const float* bias, float* y, size_t npix, int C, int nout,
+                    int act, void* stream);
+int phx_head1x1_dgrad(const float* dy, const float* w, void* dx, int dx_dt, size_t npix, int C, int nout, void* stream);
+int phx_head1x1_wgrad(const void* x, int x_dt, const float* dy, float* dw, float* db, size_t npix, int C, int nout,
+                      void* stream);
 
 /* ---- normalisation (tfwrapper/normalisation.py:3-36,145-163) --------------------------------------- */
 /* One implementation for batch / group / instance norm.  A statistic is taken over P pixels x (C/G) channels

@@ -24,22 +24,35 @@ def num_channels(n0):
 class Ctx:
     """Carries parameters, the normalisation mode and the training flag through one net."""
 
-    def __init__(self, params, norm="batch_norm", training=True, num_groups=None):
+    def __init__(self, params, norm="batch_norm", training=True, num_groups=None, bf16_sim=False):
         self.p = params
         self.norm = norm
         self.training = training
         self.num_groups = num_groups
         self.moving_updates = {}     # name -> new value (training-mode batch norm)
+        # bf16_sim: model of the engine's bf16 storage policy (NOT reference behaviour): round to bfloat16 wherever
+        # the HIP path stores bf16 -- conv outputs before and after norm+activation, pooled / up-sampled maps, the
+        # packed 3x3 filters and the (padded) inputs of the MFMA convolutions; heads and latents stay fp32.
+        self.bf16_sim = bf16_sim
+
+    def r(self, t):
+        return t.to(torch.bfloat16).to(t.dtype) if self.bf16_sim else t
 
     # tfwrapper/layers.py:94-145
     def conv(self, x, scope, act="relu", normalise=True):
         """normalise=False reproduces call sites that do not pass ``normalisation=`` (the
         mu/sigma/y_lvl/pre_mu/pre_sigma/prediction heads): identity norm, bias kept."""
         p = self.p
-        y = T.conv2d_same(x, p[scope + "/W"])
+        w = p[scope + "/W"]
+        head = (not normalise) and act != "relu"
+        if self.bf16_sim and not head and w.shape[0] == 3 and w.shape[3] % 32 == 0 and (w.shape[2] % 32 == 0 or w.shape[2] < 32):
+            x, w = self.r(x), self.r(w)                # MFMA path: bf16 operands (narrow inputs are padded + rounded)
+        y = T.conv2d_same(x, w)
         norm = self.norm if normalise else "identity"
         if norm != "batch_norm":                       # layers.py:126-132
             y = T.bias_add(y, p[scope + "/b"])
+        if not head and norm != "identity":
+            y = self.r(y)                              # stored pre-norm activation
         if norm == "batch_norm":                       # normalisation.py:145-163
             bn = scope + "/batch_norm/BatchNorm/"
             if self.training:
@@ -61,7 +74,14 @@ class Ctx:
             y = T.relu(y)
         elif act == "softplus":
             y = T.softplus(y)
-        return y
+        return y if head else self.r(y)
+
+    def pool(self, x):
+        return self.r(T.avg_pool_2x2_same(x))
+
+    def up2(self, x, latent=False):
+        y = T.resize_bilinear_legacy(x, 2 * x.shape[1], 2 * x.shape[2])
+        return y if latent else self.r(y)
 
 
 def up2(x):
@@ -78,7 +98,7 @@ def _phiseg_ladder(ctx, net, x_in, z_teacher, generation_mode, eps_fn, eps_net,
     h = x_in
     for i in range(resolution_levels):
         if i > 0:
-            h = T.avg_pool_2x2_same(pre_z[i - 1])
+            h = ctx.pool(pre_z[i - 1])
         for t in (1, 2, 3):
             h = ctx.conv(h, "%s/z%d_pre_%d" % (net, i, t))
         pre_z.append(h)
@@ -90,7 +110,7 @@ def _phiseg_ladder(ctx, net, x_in, z_teacher, generation_mode, eps_fn, eps_net,
             src = pre_z[i + d]
         else:
             # live branch only: z_ups_mat[i][i+1] = 2 convs on bilinear-x2 of z_ups_mat[i+1][i+1]
-            u = up2(feed[i + 1])
+            u = ctx.up2(feed[i + 1], latent=True)
             u = ctx.conv(u, "%s/z%d_ups_to_%d_c_1" % (net, i + 1, i + 1))
             u = ctx.conv(u, "%s/z%d_ups_to_%d_c_2" % (net, i + 1, i + 1))
             src = torch.cat([pre_z[i + d], u], dim=3)
@@ -125,12 +145,12 @@ def likelihood_phiseg(ctx, z_list, image_size, n_classes, n0=32, resolution_leve
         h = ctx.conv(z_list[i], "likelihood/z%d_post_1" % i)
         h = ctx.conv(h, "likelihood/z%d_post_2" % i)
         for t in range(d):                                  # increase_resolution (170-179)
-            h = ctx.conv(up2(h), "likelihood/preups_%d/z%d_post" % (i, t))
+            h = ctx.conv(ctx.up2(h), "likelihood/preups_%d/z%d_post" % (i, t))
         post_z.append(h)
     post_c = [None] * latent_levels
     post_c[latent_levels - 1] = post_z[latent_levels - 1]
     for i in reversed(range(latent_levels - 1)):
-        u = ctx.conv(up2(post_c[i + 1]), "likelihood/post_z%d_ups_c" % (i + 1))
+        u = ctx.conv(ctx.up2(post_c[i + 1]), "likelihood/post_z%d_ups_c" % (i + 1))
         h = torch.cat([post_z[i], u], dim=3)
         h = ctx.conv(h, "likelihood/post_c_%d_1" % i)
         post_c[i] = ctx.conv(h, "likelihood/post_c_%d_2" % i)
@@ -148,7 +168,7 @@ def _probunet_encoder(ctx, prefix, x_in, n0, resolution_levels):
     h = x_in
     for ii in range(resolution_levels):
         if ii > 0:
-            h = T.avg_pool_2x2_same(enc[ii - 1])
+            h = ctx.pool(enc[ii - 1])
         for t in (1, 2, 3):
             h = ctx.conv(h, "%s/conv_%d_%d" % (prefix, ii, t))
         enc.append(h)
@@ -180,7 +200,7 @@ def likelihood_probunet(ctx, z_list, image_size, n_classes, x, n0=32, resolution
     h = enc[-1]
     for jj in range(resolution_levels - 1):
         ii = resolution_levels - jj - 1
-        h = torch.cat([up2(h), enc[ii - 1]], dim=3)          # crop_and_concat: equal sizes here
+        h = torch.cat([ctx.up2(h), enc[ii - 1]], dim=3)      # crop_and_concat: equal sizes here
         for t in (1, 2, 3):
             h = ctx.conv(h, "likelihood/decoder/conv_%d_%d" % (jj, t))
     bs, zdim = z.shape
@@ -198,7 +218,7 @@ ZOO = {
 
 
 # ---------------------------------------------------------------------------------------------
-def elbo(params, x, s, eps_fn, cfg, training=True):
+def elbo(params, x, s, eps_fn, cfg, training=True, bf16_sim=False):
     """phiseg_model.py:26-130: returns dict with every tensor the build must reproduce.
 
     cfg keys: arch ('phiseg'|'prob_unet2D'), norm, n0, zdim0, resolution_levels, latent_levels,
@@ -206,7 +226,7 @@ def elbo(params, x, s, eps_fn, cfg, training=True):
     post_fn, prior_fn, lik_fn = ZOO[cfg["arch"]]
     L = cfg["latent_levels"]
     kw = dict(n0=cfg["n0"], resolution_levels=cfg["resolution_levels"], latent_levels=L)
-    ctx = Ctx(params, cfg["norm"], training, cfg.get("num_groups"))
+    ctx = Ctx(params, cfg["norm"], training, cfg.get("num_groups"), bf16_sim=bf16_sim)
     s_oh = T.one_hot(s, cfg["nlabels"], x.dtype)
     z, mu, sigma = post_fn(ctx, x, s_oh, eps_fn, zdim_0=cfg["zdim0"], **kw)
     pz, pmu, psigma = prior_fn(ctx, z, x, False, eps_fn, zdim_0=cfg["zdim0"], **kw)

@@ -43,6 +43,47 @@ __global__ void k_pack_conv3x3(const float* __restrict__ w, unsigned short* __re
     }
 }
 
+// Cin < 32 (image-input convolutions, Cin = 1 or 3): zero-pad the channel axis to 32 so the layer runs on the MFMA
+// kernels.  wpk[t][co][ci_pad] = ci < Cin ? w[t][ci][co] : 0
+// and (optional) wpk_dgrad[t][ci_pad][co] = ci < Cin ? w[8-t][ci][co] : 0
+__global__ void k_pack_conv3x3_pad(const float* __restrict__ w, unsigned short* __restrict__ wf,
+                                   unsigned short* __restrict__ wd, int Cin, int Cpad, int Cout) {
+    const size_t n = (size_t)9 * Cout * Cpad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cpad);
+        const int co = (int)((i / Cpad) % Cout);
+        const int t = (int)(i / ((size_t)Cpad * Cout));
+        const unsigned short v = ci < Cin ? f2bf(w[((size_t)t * Cin + ci) * Cout + co]) : (unsigned short)0;
+        wf[i] = v;
+        if (wd) wd[((size_t)(8 - t) * Cpad + ci) * Cout + co] = v;
+    }
+}
+template <typename T>
+__global__ void k_unpad_channels(const unsigned short* __restrict__ src, T* __restrict__ dst, int C, int Cpad, size_t npix) {
+    const size_t n = npix * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / C;
+        const int c = (int)(i - p * C);
+        stf<T>(dst, i, bf2f(src[p * Cpad + c]));
+    }
+}
+template <typename T>
+__global__ void k_pad_channels(const T* __restrict__ x, unsigned short* __restrict__ out, int C, int Cpad, size_t npix) {
+    const size_t n = npix * Cpad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / Cpad;
+        const int c = (int)(i - p * Cpad);
+        out[i] = c < C ? f2bf(ldf<T>(x, p * C + c)) : (unsigned short)0;
+    }
+}
+__global__ void k_unpad_rows_acc(const float* __restrict__ dwp, float* __restrict__ dw, int Cin, int Cpad, int Cout) {
+    const int n = 9 * Cin * Cout;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int co = i % Cout, ci = (i / Cout) % Cin, t = i / (Cout * Cin);
+        dw[i] += dwp[((size_t)t * Cpad + ci) * Cout + co];
+    }
+}
+
 // ---- forward / dgrad ----------------------------------------------------------------------------------
 template <int BN>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(const unsigned short* __restrict__ x,
@@ -291,6 +332,38 @@ int phx_pack_conv3x3_bf16(const float* w_hwio, void* wpk_fwd, void* wpk_dgrad, i
     const size_t n = (size_t)9 * Cin * Cout;
     hipLaunchKernelGGL(k_pack_conv3x3, dim3(phx_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, w_hwio,
                        (unsigned short*)wpk_fwd, (unsigned short*)wpk_dgrad, Cin, Cout);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_pack_conv3x3_bf16_pad(const float* w_hwio, void* wpk_fwd, void* wpk_dgrad, int Cin, int Cin_pad, int Cout,
+                              void* stream) {
+    PHX_REQUIRE(Cin_pad % 32 == 0 && Cin <= Cin_pad, PHX_E_SHAPE, "pack_pad: Cin_pad % 32 == 0 and Cin <= Cin_pad");
+    const size_t n = (size_t)9 * Cin_pad * Cout;
+    hipLaunchKernelGGL(k_pack_conv3x3_pad, dim3(phx_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, w_hwio,
+                       (unsigned short*)wpk_fwd, (unsigned short*)wpk_dgrad, Cin, Cin_pad, Cout);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+int phx_pad_channels_bf16(const void* x, int dt, int C, void* out, int Cpad, size_t npix, void* stream) {
+    PHX_DT_SWITCH(dt, T, {
+        hipLaunchKernelGGL((k_pad_channels<T>), dim3(phx_grid_for(npix * Cpad, 256, 8192)), dim3(256), 0,
+                           (hipStream_t)stream, (const T*)x, (unsigned short*)out, C, Cpad, npix);
+    });
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+int phx_unpad_channels_bf16(const void* src, void* dst, int dst_dt, int C, int Cpad, size_t npix, void* stream) {
+    PHX_DT_SWITCH(dst_dt, T, {
+        hipLaunchKernelGGL((k_unpad_channels<T>), dim3(phx_grid_for(npix * C, 256, 8192)), dim3(256), 0,
+                           (hipStream_t)stream, (const unsigned short*)src, (T*)dst, C, Cpad, npix);
+    });
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+int phx_unpad_filter_grad_accumulate(const float* dw_pad, float* dw_hwio, int Cin, int Cin_pad, int Cout, void* stream) {
+    hipLaunchKernelGGL(k_unpad_rows_acc, dim3(phx_grid_for((size_t)9 * Cin * Cout, 256)), dim3(256), 0,
+                       (hipStream_t)stream, dw_pad, dw_hwio, Cin, Cin_pad, Cout);
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }

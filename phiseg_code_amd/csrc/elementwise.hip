@@ -101,6 +101,21 @@ static int norm_geometry(int P, int C, int V, int* PL, int* threads, int* chunk,
     return 0;
 }
 
+static int stream_geometry(int P, int C, int V, int* PL, int* threads, int* chunk, int* nchunks, int NS) {
+    int CV = C / V;
+    if (CV > 256) return -1;
+    *PL = 256 / CV;
+    *threads = CV * (*PL);
+    int want = (P + (*PL) * 4 - 1) / ((*PL) * 4);            // >= 4 pixels per thread
+    int cap = 8192 / (NS > 0 ? NS : 1);
+    if (cap < 1) cap = 1;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    *chunk = (P + want - 1) / want;
+    *nchunks = (P + *chunk - 1) / (*chunk);
+    return 0;
+}
+
 // partial[T][2][C] -> sums[c][2]
 __global__ void k_reduce_partials(const float* __restrict__ partial, int T, int C, float* __restrict__ sums) {
     const int i = blockIdx.x;                 // 0 .. 2C-1 : (which, c)
@@ -167,24 +182,30 @@ __global__ void k_bn_infer_scale_shift(const float* gamma, const float* beta, co
     shift[c] = beta[c] - mm[c] * sc;
 }
 
-// y = act(x*scale[ns][c] + shift[ns][c])
+// y = act(x*scale[ns][c] + shift[ns][c]).  A thread owns one channel vector (cv) and walks over pixels, so the
+// per-channel coefficients live in registers; blockDim = CV * PL (as for the statistics kernels).
 template <typename TI, typename TO, int V>
 __global__ void k_affine_act(const TI* __restrict__ x, const float* __restrict__ scale,
-                             const float* __restrict__ shift, TO* __restrict__ y, int P, int C, size_t items,
+                             const float* __restrict__ shift, TO* __restrict__ y, int P, int C, int PL, int chunk,
                              int act) {
     const int CV = C / V;
-    for (size_t it = blockIdx.x * (size_t)blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
-        const size_t pix = it / CV;
-        const int cv = (int)(it - pix * CV);
-        const int ns = (int)(pix / P);
-        float v[V];
-        VecIO<TI, V>::load(x, it * V, v);
+    const int ns = blockIdx.y;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    if (pl >= PL) return;
+    float sc[V], sh[V];
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            const int c = cv * V + j;
-            v[j] = act_fwd(v[j] * scale[(size_t)ns * C + c] + shift[(size_t)ns * C + c], act);
-        }
-        VecIO<TO, V>::store(y, it * V, v);
+    for (int j = 0; j < V; ++j) {
+        sc[j] = scale[(size_t)ns * C + cv * V + j];
+        sh[j] = shift[(size_t)ns * C + cv * V + j];
+    }
+    const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
+    for (int p = p0 + pl; p < p1; p += PL) {
+        const size_t off = ((size_t)ns * P + p) * C + (size_t)cv * V;
+        float v[V];
+        VecIO<TI, V>::load(x, off, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] = act_fwd(fmaf(v[j], sc[j], sh[j]), act);
+        VecIO<TO, V>::store(y, off, v);
     }
 }
 
@@ -262,31 +283,43 @@ __global__ void k_norm_bwd_finalize(const float* __restrict__ sums2, const float
     }
 }
 
+// dx = rstd*(gamma*g - S0/m - xhat*S1/m) folded to dx = a*g + b + c*x with per-(ns, channel) coefficients in
+// registers:  a = rstd*gamma,  c = -rstd^2*S1/m,  b = -rstd*S0/m - c*mean;  g = dA * act'(x*scale+shift).
 template <typename TD, typename TX, typename TO, int V>
 __global__ void k_norm_bwd_apply(const TD* __restrict__ dA, const TX* __restrict__ x,
                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                  const float* __restrict__ gamma, const float* __restrict__ S, TO* __restrict__ dx,
-                                 int P, int C, int G, size_t items, int act) {
+                                 int P, int C, int G, int PL, int chunk, int act) {
     const int CV = C / V, cg = C / G;
+    const int ns = blockIdx.y;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    if (pl >= PL) return;
     const float inv_m = 1.f / ((float)P * (float)cg);
-    for (size_t it = blockIdx.x * (size_t)blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
-        const size_t pix = it / CV;
-        const int cv = (int)(it - pix * CV);
-        const int ns = (int)(pix / P);
+    float sc[V], sh[V], ca[V], cb[V], cc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int c = cv * V + j;
+        const int sg = ns * G + c / cg;
+        const float rs = rstd[sg], mu = mean[sg];
+        sc[j] = scale[(size_t)ns * C + c];
+        sh[j] = shift[(size_t)ns * C + c];
+        ca[j] = rs * gamma[c];
+        cc[j] = -rs * rs * S[sg * 2 + 1] * inv_m;
+        cb[j] = -rs * S[sg * 2] * inv_m - cc[j] * mu;
+    }
+    const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
+    for (int p = p0 + pl; p < p1; p += PL) {
+        const size_t off = ((size_t)ns * P + p) * C + (size_t)cv * V;
         float xv[V], dv[V], o[V];
-        VecIO<TX, V>::load(x, it * V, xv);
-        VecIO<TD, V>::load(dA, it * V, dv);
+        VecIO<TX, V>::load(x, off, xv);
+        VecIO<TD, V>::load(dA, off, dv);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            const int c = cv * V + j;
-            const int sg = ns * G + c / cg;
-            const float g = dv[j] * act_grad_pre(xv[j] * scale[(size_t)ns * C + c] + shift[(size_t)ns * C + c], act);
-            const float rs = rstd[sg];
-            const float xh = (xv[j] - mean[sg]) * rs;
-            o[j] = rs * (gamma[c] * g - S[sg * 2] * inv_m - xh * S[sg * 2 + 1] * inv_m);
+            const float g = dv[j] * act_grad_pre(fmaf(xv[j], sc[j], sh[j]), act);
+            o[j] = fmaf(ca[j], g, fmaf(cc[j], xv[j], cb[j]));
         }
-        VecIO<TO, V>::store(dx, it * V, o);
+        VecIO<TO, V>::store(dx, off, o);
     }
 }
 
@@ -581,9 +614,10 @@ int phx_bn_infer_scale_shift(const float* gamma, const float* beta, const float*
 int phx_affine_act(const void* x, int x_dt, const float* scale, const float* shift, void* y, int y_dt, int NS, int P,
                    int C, int act, void* stream) {
     PHX_DT_SWITCH(x_dt, TI, PHX_DT_SWITCH(y_dt, TO, PHX_VEC_SWITCH(C, V, {
-        const size_t items = (size_t)NS * P * (C / V);
-        hipLaunchKernelGGL((k_affine_act<TI, TO, V>), dim3(phx_grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream,
-                           (const TI*)x, scale, shift, (TO*)y, P, C, items, act);
+        int PL, threads, chunk, nchunks;
+        PHX_REQUIRE(stream_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "affine_act: C too large");
+        hipLaunchKernelGGL((k_affine_act<TI, TO, V>), dim3(nchunks, NS), dim3(threads), 0, (hipStream_t)stream,
+                           (const TI*)x, scale, shift, (TO*)y, P, C, PL, chunk, act);
     })));
     PHX_CHECK_LAUNCH();
     return PHX_OK;
@@ -617,10 +651,11 @@ int phx_norm_bwd_apply(const void* dA, int da_dt, const void* x, int x_dt, const
                        int NS, int P, int C, int G, int act, void* stream) {
     PHX_REQUIRE(da_dt == dx_dt, PHX_E_INVAL, "norm_bwd_apply: dA and dx dtypes must match");
     PHX_DT_SWITCH(da_dt, TD, PHX_DT_SWITCH(x_dt, TX, PHX_VEC_SWITCH(C, V, {
-        const size_t items = (size_t)NS * P * (C / V);
-        hipLaunchKernelGGL((k_norm_bwd_apply<TD, TX, TD, V>), dim3(phx_grid_for(items, 256)), dim3(256), 0,
+        int PL, threads, chunk, nchunks;
+        PHX_REQUIRE(stream_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_bwd_apply: C too large");
+        hipLaunchKernelGGL((k_norm_bwd_apply<TD, TX, TD, V>), dim3(nchunks, NS), dim3(threads), 0,
                            (hipStream_t)stream, (const TD*)dA, (const TX*)x, scale, shift, mean, rstd, gamma, S, (TD*)dx,
-                           P, C, G, items, act);
+                           P, C, G, PL, chunk, act);
     })));
     PHX_CHECK_LAUNCH();
     return PHX_OK;

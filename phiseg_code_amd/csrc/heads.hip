@@ -1,0 +1,244 @@
+// 1x1 "head" convolutions with a handful of outputs: mu / sigma (zdim0 = 2 or 6 channels) and the per-level logits
+// y_lvl (nlabels channels) -- posteriors.py:125-127, priors.py:117-119, likelihoods.py:220.  They are pure streaming
+// passes over the feature map (C = 32..192 channels in, NOUT <= 8 out), so a thread owns one 8-channel vector
+// (16 bytes of bf16) of a pixel, the NOUT x 8 filter slice lives in registers, and the kernels run at HBM speed.
+#include "phx_common.h"
+
+template <typename T, int V> struct HVec;
+template <> struct HVec<float, 8> {
+    static __device__ __forceinline__ void load(const float* p, size_t i, float o[8]) {
+        const float4* q = reinterpret_cast<const float4*>(p + i);
+        float4 a = q[0], b = q[1];
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    }
+    static __device__ __forceinline__ void store(float* p, size_t i, const float o[8]) {
+        float4* q = reinterpret_cast<float4*>(p + i);
+        q[0] = make_float4(o[0], o[1], o[2], o[3]);
+        q[1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+};
+template <> struct HVec<bf16_t, 8> {
+    static __device__ __forceinline__ void load(const bf16_t* p, size_t i, float o[8]) {
+        uint4 r = *reinterpret_cast<const uint4*>(p + i);
+        unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[2 * k] = __uint_as_float(w[k] << 16);
+            o[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, size_t i, const float o[8]) {
+        unsigned w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = (unsigned)f2bf(o[2 * k]) | ((unsigned)f2bf(o[2 * k + 1]) << 16);
+        *reinterpret_cast<uint4*>(p + i) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+template <typename T> struct HVec<T, 1> {
+    static __device__ __forceinline__ void load(const T* p, size_t i, float o[1]) { o[0] = ldf<T>(p, i); }
+    static __device__ __forceinline__ void store(T* p, size_t i, const float o[1]) { stf<T>(p, i, o[0]); }
+};
+
+// y[p][o] = act(b[o] + sum_c x[p][c] * w[c][o]);  block = CV x PL threads, PL pixels per iteration
+template <typename TX, int V, int NOUT>
+__global__ void k_head1x1_fwd(const TX* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                              float* __restrict__ y, size_t npix, int C, int PL, int iters, int act) {
+    const int CV = C / V;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    extern __shared__ float red[];                  // [PL][NOUT][CV]
+    float wr[V][NOUT];
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) wr[j][o] = w[(size_t)(cv * V + j) * NOUT + o];
+    for (int it = 0; it < iters; ++it) {
+        const size_t p = ((size_t)blockIdx.x * iters + it) * PL + pl;
+        float part[NOUT];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) part[o] = 0.f;
+        if (p < npix && pl < PL) {
+            float xv[V];
+            HVec<TX, V>::load(x, p * C + (size_t)cv * V, xv);
+#pragma unroll
+            for (int j = 0; j < V; ++j)
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) part[o] = fmaf(xv[j], wr[j][o], part[o]);
+        }
+        if (pl < PL) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) red[(pl * NOUT + o) * CV + cv] = part[o];
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < PL * NOUT; t += blockDim.x) {
+            const int o = t % NOUT, q = t / NOUT;
+            const size_t pp = ((size_t)blockIdx.x * iters + it) * PL + q;
+            if (pp < npix) {
+                float a = bias ? bias[o] : 0.f;
+                for (int k = 0; k < CV; ++k) a += red[(q * NOUT + o) * CV + k];
+                y[pp * NOUT + o] = act_fwd(a, act);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// dx[p][c] = sum_o dy[p][o] * w[c][o]
+template <typename TO, int V, int NOUT>
+__global__ void k_head1x1_dgrad(const float* __restrict__ dy, const float* __restrict__ w, TO* __restrict__ dx,
+                                size_t npix, int C, int PL, int chunk) {
+    const int CV = C / V;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    if (pl >= PL) return;
+    float wr[V][NOUT];
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) wr[j][o] = w[(size_t)(cv * V + j) * NOUT + o];
+    const size_t p0 = (size_t)blockIdx.x * chunk;
+    const size_t p1 = p0 + chunk < npix ? p0 + chunk : npix;
+    for (size_t p = p0 + pl; p < p1; p += PL) {
+        float d[NOUT], o8[V];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) d[o] = dy[p * NOUT + o];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) a = fmaf(d[o], wr[j][o], a);
+            o8[j] = a;
+        }
+        HVec<TO, V>::store(dx, p * C + (size_t)cv * V, o8);
+    }
+}
+
+// dw[c][o] += sum_p x[p][c] * dy[p][o];  db[o] += sum_p dy[p][o]
+template <typename TX, int V, int NOUT>
+__global__ void k_head1x1_wgrad(const TX* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                float* __restrict__ db, size_t npix, int C, int PL, int chunk) {
+    const int CV = C / V;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    extern __shared__ float red[];                  // [PL][C][NOUT]
+    float acc[V][NOUT], accb[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        accb[o] = 0.f;
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j][o] = 0.f;
+    }
+    const size_t p0 = (size_t)blockIdx.x * chunk;
+    const size_t p1 = p0 + chunk < npix ? p0 + chunk : npix;
+    if (pl < PL) {
+        for (size_t p = p0 + pl; p < p1; p += PL) {
+            float xv[V], d[NOUT];
+            HVec<TX, V>::load(x, p * C + (size_t)cv * V, xv);
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                d[o] = dy[p * NOUT + o];
+                accb[o] += d[o];
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j)
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) acc[j][o] = fmaf(xv[j], d[o], acc[j][o]);
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) red[((size_t)pl * C + cv * V + j) * NOUT + o] = acc[j][o];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * NOUT; i += blockDim.x) {
+        float a = 0.f;
+        for (int q = 0; q < PL; ++q) a += red[(size_t)q * C * NOUT + i];
+        atomicAdd(&dw[i], a);
+    }
+    if (db) {
+        __syncthreads();
+        if (cv == 0 && pl < PL) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) red[pl * NOUT + o] = accb[o];
+        }
+        __syncthreads();
+        if (threadIdx.x < NOUT) {
+            float a = 0.f;
+            for (int q = 0; q < PL; ++q) a += red[q * NOUT + threadIdx.x];
+            atomicAdd(&db[threadIdx.x], a);
+        }
+    }
+}
+
+static int head_geo(int C, int V, int* PL, int* threads) {
+    const int CV = C / V;
+    if (CV > 256 || CV < 1) return -1;
+    *PL = 256 / CV;
+    *threads = CV * (*PL);
+    return 0;
+}
+
+#define HEAD_NOUT_SWITCH(n, N, ...)                                         \
+    do {                                                                    \
+        if ((n) <= 2) { constexpr int N = 2; __VA_ARGS__; }                 \
+        else if ((n) <= 4) { constexpr int N = 4; __VA_ARGS__; }            \
+        else if ((n) <= 6) { constexpr int N = 6; __VA_ARGS__; }            \
+        else { constexpr int N = 8; __VA_ARGS__; }                          \
+    } while (0)
+#define HEAD_VEC_SWITCH(C, V, ...)                                          \
+    do {                                                                    \
+        if ((C) % 8 == 0) { constexpr int V = 8; __VA_ARGS__; }             \
+        else { constexpr int V = 1; __VA_ARGS__; }                          \
+    } while (0)
+
+extern "C" {
+
+// w is the HWIO 1x1 filter [C][nout] fp32; nout must equal one of the instantiated widths (2, 4, 6, 8)
+int phx_head1x1_fwd(const void* x, int x_dt, const float* w, const float* bias, float* y, size_t npix, int C, int nout,
+                    int act, void* stream) {
+    PHX_REQUIRE(nout == 2 || nout == 4 || nout == 6 || nout == 8, PHX_E_SHAPE, "head1x1: nout in {2,4,6,8}");
+    PHX_DT_SWITCH(x_dt, TX, HEAD_VEC_SWITCH(C, V, HEAD_NOUT_SWITCH(nout, N, {
+        int PL, threads;
+        PHX_REQUIRE(head_geo(C, V, &PL, &threads) == 0, PHX_E_SHAPE, "head1x1: C too large");
+        size_t groups = (npix + PL - 1) / PL;
+        int iters = (int)((groups + 4095) / 4096);
+        if (iters < 1) iters = 1;
+        const int grid = (int)((groups + iters - 1) / iters);
+        hipLaunchKernelGGL((k_head1x1_fwd<TX, V, N>), dim3(grid), dim3(threads), (size_t)PL * N * (C / V) * sizeof(float),
+                           (hipStream_t)stream, (const TX*)x, w, bias, y, npix, C, PL, iters, act);
+    })));
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_head1x1_dgrad(const float* dy, const float* w, void* dx, int dx_dt, size_t npix, int C, int nout, void* stream) {
+    PHX_REQUIRE(nout == 2 || nout == 4 || nout == 6 || nout == 8, PHX_E_SHAPE, "head1x1: nout in {2,4,6,8}");
+    PHX_DT_SWITCH(dx_dt, TO, HEAD_VEC_SWITCH(C, V, HEAD_NOUT_SWITCH(nout, N, {
+        int PL, threads;
+        PHX_REQUIRE(head_geo(C, V, &PL, &threads) == 0, PHX_E_SHAPE, "head1x1: C too large");
+        int chunk = PL * 8;
+        size_t grid = (npix + chunk - 1) / chunk;
+        if (grid > 8192) { chunk = (int)((npix + 8191) / 8192); grid = (npix + chunk - 1) / chunk; }
+        hipLaunchKernelGGL((k_head1x1_dgrad<TO, V, N>), dim3((unsigned)grid), dim3(threads), 0, (hipStream_t)stream, dy, w,
+                           (TO*)dx, npix, C, PL, chunk);
+    })));
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_head1x1_wgrad(const void* x, int x_dt, const float* dy, float* dw, float* db, size_t npix, int C, int nout,
+                      void* stream) {
+    PHX_REQUIRE(nout == 2 || nout == 4 || nout == 6 || nout == 8, PHX_E_SHAPE, "head1x1: nout in {2,4,6,8}");
+    PHX_DT_SWITCH(x_dt, TX, HEAD_VEC_SWITCH(C, V, HEAD_NOUT_SWITCH(nout, N, {
+        int PL, threads;
+        PHX_REQUIRE(head_geo(C, V, &PL, &threads) == 0, PHX_E_SHAPE, "head1x1: C too large");
+        int chunk = PL * 32;
+        size_t grid = (npix + chunk - 1) / chunk;
+        if (grid > 1024) { chunk = (int)((npix + 1023) / 1024); grid = (npix + chunk - 1) / chunk; }
+        size_t sh = (size_t)PL * C * N * sizeof(float);
+        if (sh < (size_t)PL * N * sizeof(float)) sh = (size_t)PL * N * sizeof(float);
+        hipLaunchKernelGGL((k_head1x1_wgrad<TX, V, N>), dim3((unsigned)grid), dim3(threads), sh, (hipStream_t)stream,
+                           (const TX*)x, dy, dw, db, npix, C, PL, chunk);
+    })));
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+}  // extern "C"

@@ -163,6 +163,8 @@ class Plan:
         self.feeds = {}
         self._keep = []
         self._wpk = {}
+        self._zarena = torch.zeros(8 << 20, dtype=torch.float32, device=_device())     # 32 MB of per-step accumulators
+        self._zused = 0
         self.fetches = list(fetches)
         self.n_launch_fwd = self.n_launch_bwd = 0
         self._build()
@@ -177,6 +179,15 @@ class Plan:
 
     def _alloc(self, shape, dt, zero=False):
         b = Buf(shape, dt, zero=zero)
+        self._keep.append(b)
+        return b
+
+    def _alloc_zeroed(self, n):
+        """fp32 accumulator that must be zero at the start of every run: carved from one arena, ONE memset per run."""
+        n4 = (int(n) + 3) // 4 * 4
+        assert self._zused + n4 <= self._zarena.numel(), "zero arena exhausted"
+        b = Buf((int(n),), F32, like=self._zarena[self._zused:self._zused + n4])
+        self._zused += n4
         self._keep.append(b)
         return b
 
@@ -219,6 +230,7 @@ class Plan:
             for t, w in zip(self.loss.op.inputs, self.loss.op.attrs["weights"]):
                 self.loss_weight[t] = w
         with_bw = self.loss is not None
+        self._emit(self.L.memset, self._zarena.data_ptr(), 0, 4, self.stream)       # size patched below
         if with_bw:
             self._emit(self.L.memset, self.store.grads.data_ptr(), 0, self.store.grads.numel() * 4, self.stream)
         for op in ops:
@@ -229,6 +241,7 @@ class Plan:
                 if any(o in self.grad for o in op.outputs) or op.type in ("residual_ce", "kl"):
                     getattr(self, "_bw_" + op.type)(op)
             self.n_launch_bwd = len(self.launches) - self.n_launch_fwd
+        self.launches[0] = (self.L.memset, (self._zarena.data_ptr(), 0, max(self._zused, 1) * 4, self.stream))
         if self.optimize:
             if self.split_optimizer:
                 self._cur = self.opt_launches
@@ -307,16 +320,35 @@ class Plan:
         training = a["training"] if isinstance(a["training"], bool) else self.training
         mfma = (self.act_dt == BF16 and x.dt == BF16 and out.dt == BF16 and k == 3 and cin % 32 == 0
                 and cout % 32 == 0)
-        st = dict(x=x, out=out, mfma=mfma, norm=a["norm"])
-        wptr, bptr = self.store.ptr(W), (self.store.ptr(b) if b is not None else None)
         S, Lb = self.stream, self.L
-        if mfma:
+        cin_eff = cin
+        # narrow-input convolutions (image Cin = 1 / 3, latent Cin = 2): zero-pad channels to 32 -> MFMA kernels
+        padded = self.act_dt == BF16 and out.dt == BF16 and k == 3 and cin < 32 and cout % 32 == 0
+        if padded:
+            cin_eff = 32
+            xp = self._alloc((B, H, Wd, cin_eff), BF16)
+            self._emit(Lb.pad_channels_bf16, x.ptr, x.dt, cin, xp.ptr, cin_eff, B * H * Wd, S)
+            x, mfma = xp, True
+        st = dict(x=x, out=out, mfma=mfma, norm=a["norm"], padded=padded, cin_eff=cin_eff)
+        wptr, bptr = self.store.ptr(W), (self.store.ptr(b) if b is not None else None)
+        if padded:
+            wf = self._alloc((9 * cin_eff * cout,), BF16)
+            need_dgrad = bw and self.req.get(op.inputs[0], False)
+            wdp = self._alloc((9 * cin_eff * cout,), BF16) if need_dgrad else None
+            st["wd_pad"] = wdp
+            self._emit(Lb.pack_conv3x3_bf16_pad, wptr, wf.ptr, wdp.ptr if wdp else None, cin, cin_eff, cout, S)
+        elif mfma:
             wf, _ = self._packed(W)
 
+        head1x1 = (k == 1 and out.dt == F32 and cout in (2, 4, 6, 8) and a["norm"] is None and b is not None)
+        st["head1x1"] = head1x1
+
         def conv_into(y, act_code, stats_direct=None, stats_part=None):
-            if mfma:
+            if head1x1:
+                self._emit(Lb.head1x1_fwd, x.ptr, x.dt, wptr, bptr, y.ptr, B * H * Wd, cin, cout, act_code, S)
+            elif mfma:
                 self._emit(Lb.conv3x3_mfma_bf16, x.ptr, wf.ptr, y.ptr, bptr, act_code,
-                           stats_part.ptr if stats_part is not None else None, B, H, Wd, cin, cout, S,
+                           stats_part.ptr if stats_part is not None else None, B, H, Wd, cin_eff, cout, S,
                            tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
             else:
                 self._emit(Lb.conv2d_direct, x.ptr, x.dt, wptr, bptr, y.ptr, y.dt, B, H, Wd, cin, cout, k, act_code,
@@ -343,7 +375,7 @@ class Plan:
                        self.store.ptr(nv["moving_variance"]), eps, cout, scale.ptr, shift.ptr, S)
             conv_into(y, 0)
         else:
-            sums = self._alloc((NS * cout * 2,), F32)
+            sums = self._alloc_zeroed(NS * cout * 2)
             pivot = None
             # shifted (pivot) sums in a stand-alone pass: always on the fp32 parity path, and on the bf16 path when
             # a statistic has few samples (cheap there); otherwise the sums come from the conv epilogue.
@@ -354,12 +386,10 @@ class Plan:
                 conv_into(y, 0, stats_part=part)
                 self._emit(Lb.norm_reduce_partials, part.ptr, ntile, cout, sums.ptr, S)
             elif norm == "batch" and not small:
-                self._emit(Lb.memset, sums.ptr, 0, sums.nbytes, S)
                 conv_into(y, 0, stats_direct=sums)
             else:
                 pivot = self._alloc((NS * cout,), F32)
                 conv_into(y, 0)
-                self._emit(Lb.memset, sums.ptr, 0, sums.nbytes, S)
                 self._emit(Lb.norm_stats, y.ptr, y.dt, sums.ptr, pivot.ptr, NS, P, cout, S)
             upd = norm == "batch" and training and self.loss is not None
             self._emit(Lb.norm_finalize, sums.ptr, pivot.ptr if pivot is not None else None, gptr, beptr, eps, NS, P, cout, Gn, mean.ptr, rstd.ptr, scale.ptr,
@@ -437,10 +467,14 @@ class Plan:
             ws = [self.loss_weight.get(op.outputs[l], 0.0) for l in range(Ls)]
             assert all(abs(x - ws[0]) < 1e-12 for x in ws), "one weight for all residual-CE levels"
             w = ws[0]
-            dbufs = [self._alloc(b.shape, F32) for b in bufs]
-            for b in dbufs:
-                if b.shape[1] != H:
-                    self._emit(self.L.memset, b.ptr, 0, b.nbytes, self.stream)
+            dbufs = []
+            for b in bufs:
+                if b.shape[1] != H:        # coarse levels are accumulated atomically -> zero every run
+                    zb = self._alloc_zeroed(b.n)
+                    zb.shape = b.shape
+                    dbufs.append(zb)
+                else:
+                    dbufs.append(self._alloc(b.shape, F32))
             dsp = rt.ptr_array([b.ptr for b in dbufs])
             self.saved[op] = dict(dbufs=dbufs, src=[t.op.inputs[0] if t.op.type == "nn_resize" else t for t in s_t])
         self._emit(self.L.residual_ce, sp, dsp, shp, Ls, lab.ptr, B, H, W, C, w, self.inv_batch, losses.ptr,
@@ -575,10 +609,9 @@ class Plan:
                 raise NotImplementedError("backward through inference-mode batch norm is not on the hot path")
             nv = a["norm_vars"]
             y, NS, P, Gn = sv["y"], sv["NS"], sv["P"], sv["G"]
-            sums2 = self._alloc((NS * cout * 2,), F32)
+            sums2 = self._alloc_zeroed(NS * cout * 2)
             Sg = self._alloc((NS * Gn * 2,), F32)
             dY = self._alloc(y.shape, y.dt)
-            self._emit(Lb.memset, sums2.ptr, 0, sums2.nbytes, S)
             self._emit(Lb.norm_bwd_reduce, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
                        sv["mean"].ptr, sv["rstd"].ptr, sums2.ptr, NS, P, cout, Gn, act, S)
             self._emit(Lb.norm_bwd_finalize, sums2.ptr, self.store.ptr(nv["gamma"]), Sg.ptr,
@@ -593,7 +626,17 @@ class Plan:
             dY = dA
         dw = self.store.grad_ptr(W)
         db = self.store.grad_ptr(b) if b is not None else None
-        if sv["mfma"]:
+        if sv.get("head1x1"):
+            self._emit(Lb.head1x1_wgrad, x.ptr, x.dt, dY.ptr, dw, db, B * H * Wd, cin, cout, S)
+        elif sv.get("padded"):
+            ce = sv["cin_eff"]
+            dwp = self._alloc_zeroed(9 * ce * cout)
+            self._emit(Lb.conv3x3_wgrad_mfma_bf16, x.ptr, dY.ptr, dwp.ptr, B, H, Wd, ce, cout, S,
+                       tag="conv3x3_mfma_wgrad", flops=18.0 * cin * cout * B * H * Wd)
+            self._emit(Lb.unpad_filter_grad_accumulate, dwp.ptr, dw, cin, ce, cout, S)
+            if db is not None:
+                self._emit(Lb.channel_sum_accumulate, dY.ptr, dY.dt, db, B * H * Wd, cout, S)
+        elif sv["mfma"]:
             self._emit(Lb.conv3x3_wgrad_mfma_bf16, x.ptr, dY.ptr, dw, B, H, Wd, cin, cout, S,
                        tag="conv3x3_mfma_wgrad", flops=18.0 * cin * cout * B * H * Wd)
             if db is not None:
@@ -602,7 +645,19 @@ class Plan:
             self._emit(Lb.conv2d_direct_wgrad, x.ptr, x.dt, dY.ptr, dY.dt, dw, db, B, H, Wd, cin, cout, k, S)
         xin = op.inputs[0]
         if self.req.get(xin, False):
-            if sv["mfma"]:
+            if sv.get("head1x1"):
+                self._add_grad(xin, write_fn=lambda g: self._emit(
+                    Lb.head1x1_dgrad, dY.ptr, self.store.ptr(W), g.ptr, g.dt, B * H * Wd, cin, cout, S))
+            elif sv.get("padded"):
+                ce, wdp = sv["cin_eff"], sv["wd_pad"]
+
+                def wr(g):
+                    gp = self._alloc((B, H, Wd, ce), BF16)
+                    self._emit(Lb.conv3x3_mfma_bf16, dY.ptr, wdp.ptr, gp.ptr, None, 0, None, B, H, Wd, cout, ce, S,
+                               tag="conv3x3_mfma_dgrad", flops=18.0 * cin * cout * B * H * Wd)
+                    self._emit(Lb.unpad_channels_bf16, gp.ptr, g.ptr, g.dt, cin, ce, B * H * Wd, S)
+                self._add_grad(xin, write_fn=wr)
+            elif sv["mfma"]:
                 _, wd = self._packed(W)
                 self._add_grad(xin, write_fn=lambda g: self._emit(
                     Lb.conv3x3_mfma_bf16, dY.ptr, wd.ptr, g.ptr, None, 0, None, B, H, Wd, cout, cin, S,

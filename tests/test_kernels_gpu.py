@@ -437,3 +437,34 @@ def test_reparam_and_graph_capture(L):
     close(host(dsg), np.float32(dz).astype(np.float64) * philox.normal(42, 4, 3, B, per, dtype=np.float64), 1e-5)
     L.graph_destroy(ge)
     L.stream_destroy(st)
+
+
+@pytest.mark.parametrize("case", [(3, 16, 16, 128, 2, BF16, "identity"), (2, 8, 8, 192, 2, BF16, "softplus"),
+                                  (2, 4, 4, 32, 6, F32, "identity"), (2, 8, 8, 24, 4, F32, "softplus"),
+                                  (1, 128, 128, 128, 2, BF16, "identity"), (2, 2, 2, 32, 8, BF16, "identity")])
+def test_head1x1_kernels(L, case):
+    B, H, W, C, NO, xdt, act = case
+    npix = B * H * W
+    x = RNG.standard_normal((B, H, W, C))
+    w = RNG.standard_normal((1, 1, C, NO)) / np.sqrt(C)
+    b = RNG.standard_normal(NO) * 0.3
+    xr = rounded(x, xdt).requires_grad_(True)
+    wr = torch.as_tensor(w, dtype=torch.float32).double().requires_grad_(True)
+    br = torch.as_tensor(b, dtype=torch.float32).double().requires_grad_(True)
+    yr = oracle_conv(xr, wr, br, act)
+    xd, wd, bd = dev(x, xdt), dev(w), dev(b)
+    y = torch.empty(B, H, W, NO, dtype=torch.float32).cuda()
+    L.head1x1_fwd(xd.data_ptr(), xdt, wd.data_ptr(), bd.data_ptr(), y.data_ptr(), npix, C, NO, ACT[act], S())
+    close(host(y), yr.detach().numpy(), 2e-5, "head fwd")
+    dy = RNG.standard_normal((B, H, W, NO))
+    pre = T.conv2d_same(xr, wr) + br.reshape(1, 1, 1, -1)
+    (pre * torch.as_tensor(dy, dtype=torch.float32).double()).sum().backward()
+    dyd = dev(dy)
+    dx = torch.empty(B, H, W, C, dtype=tdt(xdt)).cuda()
+    L.head1x1_dgrad(dyd.data_ptr(), wd.data_ptr(), dx.data_ptr(), xdt, npix, C, NO, S())
+    close(host(dx), xr.grad.numpy(), 1e-5 if xdt == F32 else 6e-3, "head dgrad")
+    dw = torch.zeros(C, NO, dtype=torch.float32).cuda()
+    db = torch.zeros(NO, dtype=torch.float32).cuda()
+    L.head1x1_wgrad(xd.data_ptr(), xdt, dyd.data_ptr(), dw.data_ptr(), db.data_ptr(), npix, C, NO, S())
+    close(host(dw), wr.grad.numpy().reshape(C, NO), 3e-5, "head wgrad")
+    close(host(db), br.grad.numpy(), 3e-5, "head dbias")
