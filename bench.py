@@ -134,8 +134,18 @@ def main():
             a[1] += ms
             a[2] += 1
         if args.profile_table:
-            for tag, fl, ms, shp in sorted(rows, key=lambda r: -r[2])[:40]:
+            for tag, fl, ms, shp in sorted(rows, key=lambda r: -r[2]):
                 print("# %-20s %8.3f ms %8.1f TFLOP/s  %s" % (tag, ms, fl / ms / 1e9, shp), file=sys.stderr)
+            byh = {}
+            for tag, fl, ms, shp in rows:
+                h = [v for v in shp if v in (2, 4, 8, 16, 32, 64, 128)]
+                key = (tag, shp[1] if tag.endswith("wgrad") else shp[2])
+                a = byh.setdefault(key, [0.0, 0.0, 0])
+                a[0] += fl; a[1] += ms; a[2] += 1
+            for key in sorted(byh):
+                a = byh[key]
+                print("## %-20s H=%-4d launches=%3d  %8.3f ms  %8.1f TFLOP/s" % (key[0], key[1], a[2], a[1], a[0] / a[1] / 1e9),
+                      file=sys.stderr)
         fl = sum(v[0] for k, v in fam.items() if k != "conv3x3_mfma_wgrad")
         ms = sum(v[1] for k, v in fam.items() if k != "conv3x3_mfma_wgrad")
         nl = sum(v[2] for k, v in fam.items() if k != "conv3x3_mfma_wgrad")

@@ -7,6 +7,8 @@
 // th, tw = min(16, pow2ceil(H|W)), so 128x128 maps use 16x16 patches and the 2x2 .. 8x8 levels pack several
 // images into one tile.  The (th+2) x (tw+2) zero-padded input patch is staged once per 32-channel chunk and
 // re-used by all nine filter taps from LDS.
+#include <stdlib.h>
+
 #include "phx_common.h"
 
 #define KC 32            // input channels per LDS stage (two MFMA k-steps)
@@ -85,13 +87,16 @@ __global__ void k_unpad_rows_acc(const float* __restrict__ dwp, float* __restric
 }
 
 // ---- forward / dgrad ----------------------------------------------------------------------------------
-template <int BN>
+// NA = compile-time bound on the 16-byte input-patch pieces a thread stages per 32-channel chunk
+// (ceil(npatch * 4 / 256): 6 for 16x16 tiles, 7 for 8x8x4, 9 for 4x4x16, 16 for 2x2x64).
+template <int BN, int NA>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(const unsigned short* __restrict__ x,
                                                          const unsigned short* __restrict__ wpk,
                                                          unsigned short* __restrict__ y, const float* __restrict__ bias,
                                                          int act, float* __restrict__ stats_partial, int B, int H, int W,
                                                          int K, int N, MTile g) {
     constexpr int NJ = BN / 32;
+    constexpr int NB = (9 * BN * 4 + 255) / 256;          // filter-slab pieces per thread
     const int tw = 1 << g.tws, th = 1 << g.ths;
     const int pw = tw + 2, ph = th + 2;
     const int npatch = g.tb * ph * pw;
@@ -116,6 +121,27 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(const unsigned short* _
     }
     const int boff = l31 * ROWB + khalf * 16;
 
+    // staging plan, computed once: global element offsets (without the channel-chunk term) of this thread's pieces
+    int ga[NA], gb[NB];
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+        const int i = threadIdx.x + it * 256;
+        const int q = i & 3, pp = i >> 2;
+        ga[it] = -2;                                          // -2: beyond the patch (nothing to write)
+        if (pp < npatch) {
+            const int px = pp % pw, py = (pp / pw) % ph, pb = pp / (pw * ph);
+            const int gx = tx0 + px - 1, gy = ty0 + py - 1, gbi = b0 + pb;
+            ga[it] = (gx >= 0 && gx < W && gy >= 0 && gy < H && gbi < B) ? (((gbi * H + gy) * W + gx) * K + q * 8) : -1;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+        const int i = threadIdx.x + it * 256;
+        const int q = i & 3, row = i >> 2;
+        const int tap = row / BN, n = row - tap * BN;
+        gb[it] = (i < 9 * BN * 4) ? ((tap * N + n0 + n) * K + q * 8) : -1;
+    }
+
     f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -124,26 +150,35 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(const unsigned short* _
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    uint4 ra[NA], rb[NB];
+    auto prefetch = [&](int c0) {
+#pragma unroll
+        for (int it = 0; it < NA; ++it) {
+            ra[it] = make_uint4(0, 0, 0, 0);
+            if (ga[it] >= 0) ra[it] = *reinterpret_cast<const uint4*>(x + ga[it] + c0);
+        }
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            rb[it] = make_uint4(0, 0, 0, 0);
+            if (gb[it] >= 0) rb[it] = *reinterpret_cast<const uint4*>(wpk + gb[it] + c0);
+        }
+    };
+    prefetch(0);
+
     for (int c0 = 0; c0 < K; c0 += KC) {
-        __syncthreads();
-        // input patch: 4 x 16 B per pixel
-        for (int i = threadIdx.x; i < npatch * 4; i += 256) {
-            const int q = i & 3, pp = i >> 2;
-            const int px = pp % pw, py = (pp / pw) % ph, pb = pp / (pw * ph);
-            const int gx = tx0 + px - 1, gy = ty0 + py - 1, gb = b0 + pb;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (gx >= 0 && gx < W && gy >= 0 && gy < H && gb < B)
-                v = *reinterpret_cast<const uint4*>(x + (((size_t)gb * H + gy) * W + gx) * K + c0 + q * 8);
-            *reinterpret_cast<uint4*>(sA + pp * ROWB + q * 16) = v;
+        __syncthreads();                         // every wave is done reading the previous chunk from LDS
+#pragma unroll
+        for (int it = 0; it < NA; ++it) {
+            const int i = threadIdx.x + it * 256;
+            if (ga[it] != -2) *reinterpret_cast<uint4*>(sA + (i >> 2) * ROWB + (i & 3) * 16) = ra[it];
         }
-        // filter slab: 9 taps x BN rows x 32 channels
-        for (int i = threadIdx.x; i < 9 * BN * 4; i += 256) {
-            const int q = i & 3, row = i >> 2;               // row = tap*BN + n
-            const int tap = row / BN, n = row - tap * BN;
-            const uint4 v = *reinterpret_cast<const uint4*>(wpk + ((size_t)tap * N + n0 + n) * K + c0 + q * 8);
-            *reinterpret_cast<uint4*>(sB + row * ROWB + q * 16) = v;
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int i = threadIdx.x + it * 256;
+            if (gb[it] >= 0) *reinterpret_cast<uint4*>(sB + (i >> 2) * ROWB + (i & 3) * 16) = rb[it];
         }
         __syncthreads();
+        if (c0 + KC < K) prefetch(c0 + KC);      // global loads of the next chunk fly under this chunk's MFMAs
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -168,33 +203,50 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(const unsigned short* _
             }
     }
 
-    // epilogue: C layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
+    // epilogue: C layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel).  The tile is transposed
+    // through LDS ([pixel][BN] bf16, 16-byte padded rows) so that global stores are 16 bytes per lane, 128 contiguous
+    // bytes per pixel, instead of 2-byte scattered stores.
+    constexpr int OROW = BN * 2 + 16;
     float s1[NJ], s2[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) s1[j] = s2[j] = 0.f;
+    __syncthreads();                             // all MFMA operand reads of the last chunk are done
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
             const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
-            const int ox = tx0 + lx, oy = ty0 + ly, ob = b0 + lb;
-            const bool valid = ox < W && oy < H && ob < B;
-            const size_t obase = (((size_t)ob * H + oy) * W + ox) * N + n0 + l31;
+            const bool valid = (tx0 + lx) < W && (ty0 + ly) < H && (b0 + lb) < B;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 float v = acc[i][j][r];
                 if (bias) v += bias[n0 + j * 32 + l31];
                 v = act_fwd(v, act);
                 const unsigned short h = f2bf(v);
+                *reinterpret_cast<unsigned short*>(smem + m * OROW + (j * 32 + l31) * 2) = h;
                 if (valid) {
-                    y[obase + j * 32] = h;
                     const float rv = bf2f(h);
                     s1[j] += rv;
                     s2[j] += rv * rv;
                 }
             }
         }
+    __syncthreads();
+    {
+        constexpr int PPP = BN / 8;              // 16-byte pieces per pixel
+#pragma unroll
+        for (int it = 0; it < PPP; ++it) {       // 256 pixels * PPP pieces / 256 threads
+            const int i = threadIdx.x + it * 256;
+            const int m = i / PPP, q = i % PPP;
+            const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
+            const int ox = tx0 + lx, oy = ty0 + ly, ob = b0 + lb;
+            if (ox < W && oy < H && ob < B) {
+                const uint4 v = *reinterpret_cast<const uint4*>(smem + m * OROW + q * 16);
+                *reinterpret_cast<uint4*>(y + (((size_t)ob * H + oy) * W + ox) * N + n0 + q * 8) = v;
+            }
+        }
+    }
     if (stats_partial) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);      // [4 waves][2][BN]
@@ -229,13 +281,16 @@ __device__ __forceinline__ int wswz(int pix, int byte_in_row) {
     return pix * RB + byte_in_row;
 }
 
-template <int TCI, int TCO>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(const unsigned short* __restrict__ x,
+// BIGP selects the bound on the per-thread staging pieces: false -> 16x16 / 8x8x4 tiles, true -> 4x4x16 / 2x2x64 tiles
+template <int TCI, int TCO, bool BIGP>
+__global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* __restrict__ x,
                                                           const unsigned short* __restrict__ dy,
                                                           float* __restrict__ dw, int B, int H, int W, int Cin, int Cout,
                                                           MTile g, int ntiles, int tiles_per_block) {
     constexpr int WI = TCI / 32, WJ = TCO / 32, WK = 4 / (WI * WJ);
     constexpr int RBX = TCI * 2, RBD = TCO * 2;
+    constexpr int QX = TCI / 8, QD = TCO / 8;                        // 16-byte pieces per pixel
+    constexpr int NXI = ((BIGP ? 1024 : 400) * QX + 255) / 256;      // pieces of the input patch per thread
     const int tw = 1 << g.tws, th = 1 << g.ths;
     const int pw = tw + 2, ph = th + 2;
     const int npatch = g.tb * ph * pw;
@@ -257,33 +312,62 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad(const unsigned short* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
 
-    for (int tt = 0; tt < tiles_per_block; ++tt) {
-        int t = blockIdx.x * tiles_per_block + tt;
-        if (t >= ntiles) break;
+    // staging plan (tile independent): patch / tile coordinates of this thread's 16-byte pieces, packed px | py<<8 | pb<<16
+    int planx[NXI], pland[QD];
+#pragma unroll
+    for (int it = 0; it < NXI; ++it) {
+        const int i = threadIdx.x + it * 256;
+        const int pp = i / QX;
+        planx[it] = -1;
+        if (pp < npatch) planx[it] = (pp % pw) | (((pp / pw) % ph) << 8) | ((pp / (pw * ph)) << 16);
+    }
+#pragma unroll
+    for (int it = 0; it < QD; ++it) {
+        const int m = (threadIdx.x + it * 256) / QD;
+        pland[it] = (m & (tw - 1)) | (((m >> g.tws) & (th - 1)) << 8) | ((m >> (g.tws + g.ths)) << 16);
+    }
+    uint4 rx[NXI], rd[QD];
+    auto prefetch = [&](int t) {                 // global -> registers for tile t (zero fill outside the image / batch)
         const int tx0 = (t % g.tiles_x) << g.tws; t /= g.tiles_x;
         const int ty0 = (t % g.tiles_y) << g.ths; t /= g.tiles_y;
         const int b0 = t * g.tb;
-        __syncthreads();
-        constexpr int QX = TCI / 8, QD = TCO / 8;                    // 16-byte pieces per pixel
-        for (int i = threadIdx.x; i < npatch * QX; i += 256) {
-            const int q = i % QX, pp = i / QX;
-            const int px = pp % pw, py = (pp / pw) % ph, pb = pp / (pw * ph);
-            const int gx = tx0 + px - 1, gy = ty0 + py - 1, gb = b0 + pb;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (gx >= 0 && gx < W && gy >= 0 && gy < H && gb < B)
-                v = *reinterpret_cast<const uint4*>(x + (((size_t)gb * H + gy) * W + gx) * Cin + ci0 + q * 8);
-            *reinterpret_cast<uint4*>(sX + wswz<RBX>(pp, q * 16)) = v;
+#pragma unroll
+        for (int it = 0; it < NXI; ++it) {
+            rx[it] = make_uint4(0, 0, 0, 0);
+            if (planx[it] >= 0) {
+                const int gx = tx0 + (planx[it] & 255) - 1, gy = ty0 + ((planx[it] >> 8) & 255) - 1, gb = b0 + (planx[it] >> 16);
+                if (gx >= 0 && gx < W && gy >= 0 && gy < H && gb < B)
+                    rx[it] = *reinterpret_cast<const uint4*>(x + (((size_t)gb * H + gy) * W + gx) * Cin + ci0 +
+                                                             ((threadIdx.x + it * 256) % QX) * 8);
+            }
         }
-        for (int i = threadIdx.x; i < 256 * QD; i += 256) {
-            const int q = i % QD, m = i / QD;
-            const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
-            const int ox = tx0 + lx, oy = ty0 + ly, ob = b0 + lb;
-            uint4 v = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int it = 0; it < QD; ++it) {
+            const int ox = tx0 + (pland[it] & 255), oy = ty0 + ((pland[it] >> 8) & 255), ob = b0 + (pland[it] >> 16);
+            rd[it] = make_uint4(0, 0, 0, 0);
             if (ox < W && oy < H && ob < B)
-                v = *reinterpret_cast<const uint4*>(dy + (((size_t)ob * H + oy) * W + ox) * Cout + co0 + q * 8);
-            *reinterpret_cast<uint4*>(sD + wswz<RBD>(m, q * 16)) = v;
+                rd[it] = *reinterpret_cast<const uint4*>(dy + (((size_t)ob * H + oy) * W + ox) * Cout + co0 +
+                                                         ((threadIdx.x + it * 256) % QD) * 8);
+        }
+    };
+    const int t_begin = blockIdx.x * tiles_per_block;
+    const int t_end = min(ntiles, t_begin + tiles_per_block);
+    if (t_begin < t_end) prefetch(t_begin);
+
+    for (int t = t_begin; t < t_end; ++t) {
+        __syncthreads();                         // previous tile fully consumed
+#pragma unroll
+        for (int it = 0; it < NXI; ++it) {
+            const int i = threadIdx.x + it * 256;
+            if (planx[it] >= 0) *reinterpret_cast<uint4*>(sX + wswz<RBX>(i / QX, (i % QX) * 16)) = rx[it];
+        }
+#pragma unroll
+        for (int it = 0; it < QD; ++it) {
+            const int i = threadIdx.x + it * 256;
+            *reinterpret_cast<uint4*>(sD + wswz<RBD>(i / QD, (i % QD) * 16)) = rd[it];
         }
         __syncthreads();
+        if (t + 1 < t_end) prefetch(t + 1);      // next tile's global loads fly under this tile's MFMAs
         for (int ks = wk; ks < 16; ks += WK) {
             // the two pixel slots this lane addresses in this k-step (r = 0, 1): m = 16*ks + 8*khalf + 4*r + (c16>>2)
             int mpix[2], ppix[2];
@@ -381,23 +465,24 @@ int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* 
     const int tw = 1 << g.tws, th = 1 << g.ths;
     const int npatch = g.tb * (th + 2) * (tw + 2);
     const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
+    PHX_REQUIRE((double)B * H * W * (K > N ? K : N) < 2147483648.0, PHX_E_SHAPE, "conv3x3_mfma: tensor exceeds 2^31 elements");
     static bool attr_set = false;
     if (!attr_set) {
-        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_mfma<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_mfma<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_mfma<64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_mfma<32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_mfma<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_mfma<32, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    if (N % 64 == 0) {
-        const size_t sh = (size_t)npatch * ROWB + 9 * 64 * ROWB;
-        hipLaunchKernelGGL((k_conv3x3_mfma<64>), dim3(ntiles, N / 64), dim3(256), sh, (hipStream_t)stream,
-                           (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act,
-                           stats_partial, B, H, W, K, N, g);
-    } else {
-        const size_t sh = (size_t)npatch * ROWB + 9 * 32 * ROWB;
-        hipLaunchKernelGGL((k_conv3x3_mfma<32>), dim3(ntiles, N / 32), dim3(256), sh, (hipStream_t)stream,
-                           (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act,
-                           stats_partial, B, H, W, K, N, g);
-    }
+    const int na = (npatch * 4 + 255) / 256;
+    PHX_REQUIRE(na <= 16, PHX_E_SHAPE, "conv3x3_mfma: unexpected tile geometry");
+#define CM_LAUNCH(BNv, NAv)                                                                                          \
+    hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv>), dim3(ntiles, N / BNv), dim3(256),                                 \
+                       (size_t)npatch * ROWB + 9 * BNv * ROWB, (hipStream_t)stream, (const unsigned short*)x,        \
+                       (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, g)
+    if (N % 64 == 0) { if (na <= 8) CM_LAUNCH(64, 8); else CM_LAUNCH(64, 16); }
+    else { if (na <= 8) CM_LAUNCH(32, 8); else CM_LAUNCH(32, 16); }
+#undef CM_LAUNCH
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }
@@ -412,27 +497,32 @@ int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, i
     const int tci = Cin % 64 == 0 ? 64 : 32, tco = Cout % 64 == 0 ? 64 : 32;
     static bool attr_set = false;
     if (!attr_set) {
-        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad<64, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad<32, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad<32, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define WG_ATTR(A, Bq, C)                                                                                             \
+    PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad<A, Bq, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+        WG_ATTR(64, 64, false); WG_ATTR(64, 32, false); WG_ATTR(32, 64, false); WG_ATTR(32, 32, false);
+        WG_ATTR(64, 64, true); WG_ATTR(64, 32, true); WG_ATTR(32, 64, true); WG_ATTR(32, 32, true);
+#undef WG_ATTR
         attr_set = true;
     }
     // split the pixel reduction so that ~2 blocks per CU exist; every block atomically adds 9*TCI*TCO floats
     const int cblocks = (Cin / tci) * (Cout / tco);
-    int split = (512 + cblocks - 1) / cblocks;
+    int target_blocks = (tci == 32 && tco == 32) ? 256 : 512;      // measured on MI355X (tools/bench_wgrad.py)
+    if (const char* e = getenv("PHX_WGRAD_BLOCKS")) target_blocks = atoi(e);      // tuning hook
+    int split = (target_blocks + cblocks - 1) / cblocks;
     if (split > ntiles) split = ntiles;
     if (split < 1) split = 1;
     const int tpb = (ntiles + split - 1) / split;
     const int gx = (ntiles + tpb - 1) / tpb;
     const size_t sh = (size_t)npatch * tci * 2 + (size_t)256 * tco * 2;
-#define WG_LAUNCH(A, Bq)                                                                                            \
-    hipLaunchKernelGGL((k_conv3x3_wgrad<A, Bq>), dim3(gx, Cin / A, Cout / Bq), dim3(256), sh, (hipStream_t)stream,  \
+#define WG_LAUNCH(A, Bq, C)                                                                                            \
+    hipLaunchKernelGGL((k_conv3x3_wgrad<A, Bq, C>), dim3(gx, Cin / A, Cout / Bq), dim3(256), sh, (hipStream_t)stream,  \
                        (const unsigned short*)x, (const unsigned short*)dy, dw_hwio, B, H, W, Cin, Cout, g, ntiles, tpb)
-    if (tci == 64 && tco == 64) WG_LAUNCH(64, 64);
-    else if (tci == 64) WG_LAUNCH(64, 32);
-    else if (tco == 64) WG_LAUNCH(32, 64);
-    else WG_LAUNCH(32, 32);
+#define WG_LAUNCH2(A, Bq) do { if (npatch <= 400) WG_LAUNCH(A, Bq, false); else WG_LAUNCH(A, Bq, true); } while (0)
+    if (tci == 64 && tco == 64) WG_LAUNCH2(64, 64);
+    else if (tci == 64) WG_LAUNCH2(64, 32);
+    else if (tco == 64) WG_LAUNCH2(32, 64);
+    else WG_LAUNCH2(32, 32);
+#undef WG_LAUNCH2
 #undef WG_LAUNCH
     PHX_CHECK_LAUNCH();
     return PHX_OK;
