@@ -113,6 +113,16 @@ int phx_bn_infer_scale_shift(const float* gamma, const float* beta, const float*
                              const float* moving_var, float eps, int C, float* scale, float* shift, void* stream);
 int phx_affine_act(const void* x, int x_dt, const float* scale, const float* shift, void* y, int y_dt,
                    int NS, int P, int C, int act, void* stream);
+/* fused forms used by the engine: finalize + affine_act in one launch (every thread re-derives the statistics of its
+ * own channels; block (0, ns) publishes mean/rstd/scale/shift and the moving-average update), and
+ * bwd_finalize + bwd_apply in one launch (dgamma / dbeta accumulated atomically by block (0, ns)). */
+int phx_norm_apply_fused(const void* x, int x_dt, const float* sums, const float* pivot, const float* gamma,
+                         const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
+                         float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
+                         int G, int act, void* stream);
+int phx_norm_bwd_apply_fused(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
+                             const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx,
+                             int dx_dt, float* dgamma, float* dbeta, int NS, int P, int C, int G, int act, void* stream);
 /* backward of y = act(norm(x)):  g = dA * act'(.);  sums2[NS][C][2] += {sum g, sum g*xhat} */
 int phx_norm_bwd_reduce(const void* dA, int da_dt, const void* x, int x_dt, const float* scale,
                         const float* shift, const float* mean, const float* rstd, float* sums2,

@@ -20,6 +20,8 @@ static TileGeo make_geo(int B, int H, int W) {
     g.tb = 256 / (tw * th);
     g.tiles_x = (W + tw - 1) / tw;
     g.tiles_y = (H + th - 1) / th;
+    // tiny maps (2x2 .. 8x8): fewer images per tile so that at least ~64 blocks exist (threads beyond tb idle)
+    while (g.tb > 1 && g.tiles_x * g.tiles_y * ((B + g.tb - 1) / g.tb) < 64) g.tb >>= 1;
     g.tiles_b = (B + g.tb - 1) / g.tb;
     return g;
 }
@@ -46,8 +48,8 @@ __global__ __launch_bounds__(256) void k_conv_direct(const TI* __restrict__ x, c
     const int m = threadIdx.x;
     const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
     const int ox = tx0 + lx, oy = ty0 + ly, ob = b0 + lb;
-    const bool valid = ox < W && oy < H && ob < B;
-    const int pbase = (lb * ph + ly) * pw + lx;
+    const bool valid = ox < W && oy < H && ob < B && lb < g.tb;
+    const int pbase = (lb < g.tb ? (lb * ph + ly) * pw + lx : 0);
 
     float acc[COT];
 #pragma unroll
@@ -160,12 +162,13 @@ __global__ __launch_bounds__(256) void k_conv_direct_wgrad(const TX* __restrict_
             const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
             const int ox = tx0 + lx, oy = ty0 + ly, ob = b0 + lb;
             float v = 0.f;
-            if (ox < W && oy < H && ob < B && co0 + co < Cout)
+            if (ox < W && oy < H && ob < B && lb < g.tb && co0 + co < Cout)
                 v = ldf<TD>(dy, (((size_t)ob * H + oy) * W + ox) * Cout + co0 + co);
             sd[i] = v;
         }
         __syncthreads();
-        for (int m = 0; m < 256; ++m) {
+        const int mtile = g.tb << (g.tws + g.ths);
+        for (int m = 0; m < mtile; ++m) {
             const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
             const int pbase = (lb * ph + ly) * pw + lx;
             const float d = sd[m * WG_CO + co_l];

@@ -209,6 +209,130 @@ __global__ void k_affine_act(const TI* __restrict__ x, const float* __restrict__
     }
 }
 
+// ---- fused variants: the per-(ns, g) finalisation is recomputed by every thread for its own channels (a handful of
+// loads), so the two tiny "finalize" launches per layer disappear; block (0, ns) publishes the statistics.
+__device__ __forceinline__ void group_stats(const float* __restrict__ sums, const float* __restrict__ pivot, int ns,
+                                            int C, int g, int cg, float invP, float eps, float* mu_out, float* var_out) {
+    float mu = 0.f;
+    for (int c = g * cg; c < (g + 1) * cg; ++c)
+        mu += (pivot ? pivot[(size_t)ns * C + c] : 0.f) + sums[((size_t)ns * C + c) * 2] * invP;
+    mu /= (float)cg;
+    float var = 0.f;
+    for (int c = g * cg; c < (g + 1) * cg; ++c) {
+        const float d1 = sums[((size_t)ns * C + c) * 2] * invP;
+        float vc = sums[((size_t)ns * C + c) * 2 + 1] * invP - d1 * d1;
+        vc = vc > 0.f ? vc : 0.f;
+        const float dm = (pivot ? pivot[(size_t)ns * C + c] : 0.f) + d1 - mu;
+        var += vc + dm * dm;
+    }
+    *mu_out = mu;
+    *var_out = var / (float)cg;
+}
+
+template <typename TI, typename TO, int V>
+__global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __restrict__ sums,
+                                   const float* __restrict__ pivot, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, TO* __restrict__ y, float* mean_out,
+                                   float* rstd_out, float* scale_out, float* shift_out, float* moving_mean,
+                                   float* moving_var, float momentum, int P, int C, int G, int PL, int chunk, int act) {
+    const int CV = C / V, cg = C / G;
+    const int ns = blockIdx.y;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    if (pl >= PL) return;
+    const float invP = 1.f / (float)P;
+    float sc[V], sh[V];
+    int gprev = -1;
+    float mu = 0.f, var = 0.f, rs = 0.f;
+    const bool publish = blockIdx.x == 0 && pl == 0;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int c = cv * V + j, g = c / cg;
+        if (g != gprev) {
+            group_stats(sums, pivot, ns, C, g, cg, invP, eps, &mu, &var);
+            rs = rsqrtf(var + eps);
+            gprev = g;
+            if (publish && c == g * cg) {
+                mean_out[ns * G + g] = mu;
+                rstd_out[ns * G + g] = rs;
+                if (momentum > 0.f && moving_mean) {          // batch norm (G == C): TF1 fused-batch-norm moving update
+                    const float m = (float)P * (float)cg;
+                    moving_mean[g] -= (moving_mean[g] - mu) * momentum;
+                    moving_var[g] -= (moving_var[g] - var * (m / fmaxf(m - 1.f, 1.f))) * momentum;
+                }
+            }
+        }
+        sc[j] = gamma[c] * rs;
+        sh[j] = beta[c] - mu * sc[j];
+        if (publish) {
+            scale_out[(size_t)ns * C + c] = sc[j];
+            shift_out[(size_t)ns * C + c] = sh[j];
+        }
+    }
+    const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
+    for (int p = p0 + pl; p < p1; p += PL) {
+        const size_t off = ((size_t)ns * P + p) * C + (size_t)cv * V;
+        float v[V];
+        VecIO<TI, V>::load(x, off, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] = act_fwd(fmaf(v[j], sc[j], sh[j]), act);
+        VecIO<TO, V>::store(y, off, v);
+    }
+}
+
+template <typename TD, typename TX, typename TO, int V>
+__global__ void k_norm_bwd_apply_fused(const TD* __restrict__ dA, const TX* __restrict__ x,
+                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                       const float* __restrict__ gamma, const float* __restrict__ sums2,
+                                       TO* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int P,
+                                       int C, int G, int PL, int chunk, int act) {
+    const int CV = C / V, cg = C / G;
+    const int ns = blockIdx.y;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    if (pl >= PL) return;
+    const float inv_m = 1.f / ((float)P * (float)cg);
+    float sc[V], sh[V], ca[V], cb[V], cc[V];
+    int gprev = -1;
+    float S0 = 0.f, S1 = 0.f;
+    const bool publish = blockIdx.x == 0 && pl == 0;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int c = cv * V + j, g = c / cg;
+        if (g != gprev) {
+            S0 = S1 = 0.f;
+            for (int q = g * cg; q < (g + 1) * cg; ++q) {
+                S0 += gamma[q] * sums2[((size_t)ns * C + q) * 2];
+                S1 += gamma[q] * sums2[((size_t)ns * C + q) * 2 + 1];
+            }
+            gprev = g;
+        }
+        const int sg = ns * G + g;
+        const float rs = rstd[sg], mu = mean[sg];
+        sc[j] = scale[(size_t)ns * C + c];
+        sh[j] = shift[(size_t)ns * C + c];
+        ca[j] = rs * gamma[c];
+        cc[j] = -rs * rs * S1 * inv_m;
+        cb[j] = -rs * S0 * inv_m - cc[j] * mu;
+        if (publish) {
+            atomicAdd(&dbeta[c], sums2[((size_t)ns * C + c) * 2]);
+            atomicAdd(&dgamma[c], sums2[((size_t)ns * C + c) * 2 + 1]);
+        }
+    }
+    const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
+    for (int p = p0 + pl; p < p1; p += PL) {
+        const size_t off = ((size_t)ns * P + p) * C + (size_t)cv * V;
+        float xv[V], dv[V], o[V];
+        VecIO<TX, V>::load(x, off, xv);
+        VecIO<TD, V>::load(dA, off, dv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float gq = dv[j] * act_grad_pre(fmaf(xv[j], sc[j], sh[j]), act);
+            o[j] = fmaf(ca[j], gq, fmaf(cc[j], xv[j], cb[j]));
+        }
+        VecIO<TO, V>::store(dx, off, o);
+    }
+}
+
 // sums2[ns][c][2] += {sum g, sum g*xhat},  g = dA * act'(x*scale+shift), xhat = (x-mean)*rstd
 template <typename TD, typename TX, int V>
 __global__ void k_norm_bwd_reduce(const TD* __restrict__ dA, const TX* __restrict__ x,
@@ -618,6 +742,38 @@ int phx_affine_act(const void* x, int x_dt, const float* scale, const float* shi
         PHX_REQUIRE(stream_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "affine_act: C too large");
         hipLaunchKernelGGL((k_affine_act<TI, TO, V>), dim3(nchunks, NS), dim3(threads), 0, (hipStream_t)stream,
                            (const TI*)x, scale, shift, (TO*)y, P, C, PL, chunk, act);
+    })));
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_norm_apply_fused(const void* x, int x_dt, const float* sums, const float* pivot, const float* gamma,
+                         const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
+                         float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
+                         int G, int act, void* stream) {
+    PHX_REQUIRE(G > 0 && C % G == 0, PHX_E_SHAPE, "norm_apply_fused: C % G != 0");
+    PHX_REQUIRE(momentum == 0.f || (NS == 1 && G == C), PHX_E_INVAL, "moving update only for batch norm");
+    PHX_DT_SWITCH(x_dt, TI, PHX_DT_SWITCH(y_dt, TO, PHX_VEC_SWITCH(C, V, {
+        int PL, threads, chunk, nchunks;
+        PHX_REQUIRE(stream_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_apply_fused: C too large");
+        hipLaunchKernelGGL((k_norm_apply_fused<TI, TO, V>), dim3(nchunks, NS), dim3(threads), 0, (hipStream_t)stream,
+                           (const TI*)x, sums, pivot, gamma, beta, eps, (TO*)y, mean, rstd, scale, shift, moving_mean,
+                           moving_var, momentum, P, C, G, PL, chunk, act);
+    })));
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_norm_bwd_apply_fused(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
+                             const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx,
+                             int dx_dt, float* dgamma, float* dbeta, int NS, int P, int C, int G, int act, void* stream) {
+    PHX_REQUIRE(da_dt == dx_dt, PHX_E_INVAL, "norm_bwd_apply_fused: dA and dx dtypes must match");
+    PHX_DT_SWITCH(da_dt, TD, PHX_DT_SWITCH(x_dt, TX, PHX_VEC_SWITCH(C, V, {
+        int PL, threads, chunk, nchunks;
+        PHX_REQUIRE(stream_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_bwd_apply_fused: C too large");
+        hipLaunchKernelGGL((k_norm_bwd_apply_fused<TD, TX, TD, V>), dim3(nchunks, NS), dim3(threads), 0,
+                           (hipStream_t)stream, (const TD*)dA, (const TX*)x, scale, shift, mean, rstd, gamma, sums2,
+                           (TD*)dx, dgamma, dbeta, P, C, G, PL, chunk, act);
     })));
     PHX_CHECK_LAUNCH();
     return PHX_OK;

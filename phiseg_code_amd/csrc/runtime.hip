@@ -1,6 +1,7 @@
 // libphx runtime plumbing: errors, streams, events, hipGraph capture/replay, copies.
 // Replaces what tf.Session owns in the reference (phiseg/phiseg_model.py:151-157, 194).
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "phx_common.h"
 
@@ -69,14 +70,24 @@ int phx_stream_wait_event(void* stream, void* ev) {
 }
 
 int phx_graph_begin_capture(void* stream) {
-    PHX_CHECK_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    hipStreamCaptureMode mode = hipStreamCaptureModeThreadLocal;
+    if (const char* e = getenv("PHX_CAPTURE_MODE")) mode = (hipStreamCaptureMode)atoi(e);   // 0 global, 1 thread-local, 2 relaxed
+    PHX_CHECK_HIP(hipStreamBeginCapture((hipStream_t)stream, mode));
     return PHX_OK;
 }
 int phx_graph_end_capture(void* stream, void** graph_exec) {
     hipGraph_t g;
+    const bool dbg = getenv("PHX_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[phx] hipStreamEndCapture...\n");
     PHX_CHECK_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+    if (dbg) {
+        size_t n = 0;
+        hipGraphGetNodes(g, nullptr, &n);
+        fprintf(stderr, "[phx] captured %zu nodes; instantiating...\n", n);
+    }
     hipGraphExec_t ge;
     hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    if (dbg) fprintf(stderr, "[phx] instantiate -> %d\n", (int)e);
     (void)hipGraphDestroy(g);
     if (e != hipSuccess) {
         phx_set_error("hipGraphInstantiate -> %s", hipGetErrorString(e));

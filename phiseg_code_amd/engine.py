@@ -136,7 +136,7 @@ class Plan:
 
     def __init__(self, store, fetches, loss=None, batch=1, training=True, compute_dtype="f32", optimize=True,
                  rng_seed=42, sample_offset=0, loss_inv_batch=None, stream=None, use_hip_graph=True,
-                 split_optimizer=False):
+                 split_optimizer=False, n_lanes=None):
         self.L = rt.lib()
         self.store = store
         self.graph = store.graph
@@ -150,12 +150,23 @@ class Plan:
         self.optimize = bool(optimize and loss is not None)
         self.split_optimizer = split_optimizer      # data-parallel: [fwd+bwd] | all-reduce | [adam]
         self.use_hip_graph = use_hip_graph
+        # Lanes: independent sub-graphs (posterior / prior encoders, the per-level likelihood chains) are enqueued on
+        # separate HIP streams so the many small-map kernels overlap; cross-lane dependencies are HIP events.  The
+        # whole multi-stream launch sequence is captured into ONE hipGraph (fork from / join into lane 0).
+        self._lanes = []
+        if n_lanes is None:
+            import os
+            n_lanes = int(os.environ.get("PHX_LANES", "3"))
         if stream is None:
-            st = ctypes.c_void_p()
-            self.L.stream_create(ctypes.byref(st))
-            self.stream, self._own_stream = st, True
+            for _ in range(max(1, int(n_lanes))):
+                st = ctypes.c_void_p()
+                self.L.stream_create(ctypes.byref(st))
+                self._lanes.append(st)
+            self._own_stream = True
         else:
-            self.stream, self._own_stream = stream, False
+            self._lanes, self._own_stream = [stream], False
+        self._lane = 0
+        self._events = []
         self.launches, self.opt_launches = [], []
         self._cur = self.launches
         self.val, self.grad, self.saved = {}, {}, {}
@@ -170,6 +181,41 @@ class Plan:
         self._build()
         torch.cuda.synchronize()
         self._graph_exec = self._graph_exec_opt = None
+
+    @property
+    def stream(self):
+        return self._lanes[self._lane]
+
+    def _new_event(self):
+        ev = ctypes.c_void_p()
+        self.L.event_create(ctypes.byref(ev))
+        self._events.append(ev)
+        return ev
+
+    def _record(self, lane):
+        """Record a fresh event at the current tail of `lane`; returns (event, lane)."""
+        ev = self._new_event()
+        self._cur.append((self.L.event_record, (ev, self._lanes[lane])))
+        return (ev, lane)
+
+    def _wait(self, evl):
+        """Make the current lane wait for an (event, lane) pair recorded elsewhere."""
+        if evl is not None and evl[1] != self._lane:
+            self._cur.append((self.L.stream_wait_event, (self.stream, evl[0])))
+
+    def _lane_of(self, op):
+        n = len(self._lanes)
+        if n == 1:
+            return 0
+        name = op.name
+        if name.startswith("prior/"):
+            return 1 % n
+        if name.startswith("likelihood/"):
+            # NOTE: putting the five independent per-level chains (z{i}_post_*, preups_{i}) on further lanes makes
+            # hipStreamEndCapture segfault on ROCm 7.2 (forward-only capture of the same topology works; eager
+            # multi-stream execution is correct) -- until that is understood the likelihood stays on one lane.
+            return 2 % n
+        return 0
 
     # ---------------------------------------------------------------------------------------------
     def _emit(self, fn, *args, tag=None, flops=0.0):
@@ -230,17 +276,46 @@ class Plan:
             for t, w in zip(self.loss.op.inputs, self.loss.op.attrs["weights"]):
                 self.loss_weight[t] = w
         with_bw = self.loss is not None
+        self._lane = 0
         self._emit(self.L.memset, self._zarena.data_ptr(), 0, 4, self.stream)       # size patched below
         if with_bw:
             self._emit(self.L.memset, self.store.grads.data_ptr(), 0, self.store.grads.numel() * 4, self.stream)
+        nl = len(self._lanes)
+        self.op_lane = {op: self._lane_of(op) for op in ops}
+        opset = set(ops)
+        fork = self._record(0) if nl > 1 else None          # lanes 1.. join the capture / wait for the memsets
+        for ln in range(1, nl):
+            self._lane = ln
+            self._wait(fork)
+        self.fw_event = {}
         for op in ops:
+            ln = self._lane = self.op_lane[op]
+            for t in op.inputs:                               # forward dependencies produced on other lanes
+                self._wait(self.fw_event.get(self._real_producer(t)))
+            n0 = len(self._cur)
             getattr(self, "_fw_" + op.type)(op, with_bw)
+            if nl > 1 and len(self._cur) > n0:
+                cross = any(self.op_lane.get(c, ln) != ln for o in op.outputs for c in self._real_consumers(o, opset))
+                if cross or op.type in ("residual_ce", "kl", "weighted_sum"):
+                    self.fw_event[op] = self._record(ln)
         self.n_launch_fwd = len(self.launches)
+        self.pending = {}                                    # tensor -> [(buf, (event, lane))]: late grad contributions
         if with_bw:
             for op in reversed(ops):
                 if any(o in self.grad for o in op.outputs) or op.type in ("residual_ce", "kl"):
+                    self._lane = self.op_lane[op]
+                    self._cur_bw_op = op
+                    self._wait(self.fw_event.get(op))        # forward of this op may live on another lane's past
+                    for o in op.outputs:
+                        self._finalize_grad(o)
                     getattr(self, "_bw_" + op.type)(op)
             self.n_launch_bwd = len(self.launches) - self.n_launch_fwd
+        if nl > 1:                                            # join: lane 0 waits for every other lane
+            tails = [self._record(ln) for ln in range(1, nl)]
+            self._lane = 0
+            for evl in tails:
+                self._wait(evl)
+        self._lane = 0
         self.launches[0] = (self.L.memset, (self._zarena.data_ptr(), 0, max(self._zused, 1) * 4, self.stream))
         if self.optimize:
             if self.split_optimizer:
@@ -374,6 +449,7 @@ class Plan:
             self._emit(Lb.bn_infer_scale_shift, gptr, beptr, self.store.ptr(nv["moving_mean"]),
                        self.store.ptr(nv["moving_variance"]), eps, cout, scale.ptr, shift.ptr, S)
             conv_into(y, 0)
+            self._emit(Lb.affine_act, y.ptr, y.dt, scale.ptr, shift.ptr, out.ptr, out.dt, NS, P, cout, act, S)
         else:
             sums = self._alloc_zeroed(NS * cout * 2)
             pivot = None
@@ -392,11 +468,11 @@ class Plan:
                 conv_into(y, 0)
                 self._emit(Lb.norm_stats, y.ptr, y.dt, sums.ptr, pivot.ptr, NS, P, cout, S)
             upd = norm == "batch" and training and self.loss is not None
-            self._emit(Lb.norm_finalize, sums.ptr, pivot.ptr if pivot is not None else None, gptr, beptr, eps, NS, P, cout, Gn, mean.ptr, rstd.ptr, scale.ptr,
-                       shift.ptr, self.store.ptr(nv["moving_mean"]) if upd else None,
+            self._emit(Lb.norm_apply_fused, y.ptr, y.dt, sums.ptr, pivot.ptr if pivot is not None else None, gptr, beptr,
+                       eps, out.ptr, out.dt, mean.ptr, rstd.ptr, scale.ptr, shift.ptr,
+                       self.store.ptr(nv["moving_mean"]) if upd else None,
                        self.store.ptr(nv["moving_variance"]) if upd else None,
-                       (1.0 - tfnorm.BN_DECAY) if upd else 0.0, S)
-        self._emit(Lb.affine_act, y.ptr, y.dt, scale.ptr, shift.ptr, out.ptr, out.dt, NS, P, cout, act, S)
+                       (1.0 - tfnorm.BN_DECAY) if upd else 0.0, NS, P, cout, Gn, act, S)
         st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn)
         self.saved[op] = st
 
@@ -516,18 +592,45 @@ class Plan:
         write_fn(target).  The first contribution owns the buffer; later ones are added in place."""
         if not self.req.get(t, False):
             return
-        if t not in self.grad:
-            if buf is None:
-                buf = self._alloc(self.val[t].shape, self.val[t].dt)
-                write_fn(buf)
-            self.grad[t] = buf
-            return
         if buf is None:
             buf = self._alloc(self.val[t].shape, self.val[t].dt)
             write_fn(buf)
-        g = self.grad[t]
-        assert g.dt == buf.dt and g.n == buf.n
-        self._emit(self.L.add_inplace, g.ptr, buf.ptr, g.n, g.dt, self.stream)
+        if t not in self.grad:
+            self.grad[t] = buf
+        # the producer's backward (possibly on another lane) folds this contribution in: _finalize_grad
+        evl = self._record(self._lane) if len(self._lanes) > 1 else None
+        self.pending.setdefault(t, []).append((buf, evl))
+
+    _VIRTUAL = ("one_hot", "sub_const", "random_normal", "mul", "nn_resize")
+
+    def _real_producer(self, t):
+        """Producer op whose launches create the data behind tensor t (looks through launch-less view ops)."""
+        op = t.op
+        while op is not None and op.type in self._VIRTUAL and op.inputs:
+            op = op.inputs[0].op
+        return op
+
+    def _real_consumers(self, t, opset):
+        out = []
+        for c in t.consumers:
+            if c not in opset:
+                continue
+            if c.type in self._VIRTUAL:
+                for o in c.outputs:
+                    out.extend(self._real_consumers(o, opset))
+            else:
+                out.append(c)
+        return out
+
+    def _finalize_grad(self, t):
+        """Called on the producer's lane before its backward: wait for every contribution to grad[t] (they were
+        written on the consumers' lanes) and fold the late ones into the primary buffer."""
+        for buf, evl in self.pending.pop(t, []):
+            self._wait(evl)
+            g = self.grad[t]
+            if buf is not g:
+                assert g.dt == buf.dt and g.n == buf.n
+                self._emit(self.L.add_inplace, g.ptr, buf.ptr, g.n, g.dt, self.stream)
 
     def _bw_placeholder(self, op):
         pass
@@ -614,11 +717,9 @@ class Plan:
             dY = self._alloc(y.shape, y.dt)
             self._emit(Lb.norm_bwd_reduce, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
                        sv["mean"].ptr, sv["rstd"].ptr, sums2.ptr, NS, P, cout, Gn, act, S)
-            self._emit(Lb.norm_bwd_finalize, sums2.ptr, self.store.ptr(nv["gamma"]), Sg.ptr,
-                       self.store.grad_ptr(nv["gamma"]), self.store.grad_ptr(nv["beta"]), NS, cout, Gn, S)
-            self._emit(Lb.norm_bwd_apply, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
-                       sv["mean"].ptr, sv["rstd"].ptr, self.store.ptr(nv["gamma"]), Sg.ptr, dY.ptr, dY.dt, NS, P,
-                       cout, Gn, act, S)
+            self._emit(Lb.norm_bwd_apply_fused, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
+                       sv["mean"].ptr, sv["rstd"].ptr, self.store.ptr(nv["gamma"]), sums2.ptr, dY.ptr, dY.dt,
+                       self.store.grad_ptr(nv["gamma"]), self.store.grad_ptr(nv["beta"]), NS, P, cout, Gn, act, S)
         elif act != rt.ACT_ID:
             dY = self._alloc(out.shape, dA.dt)
             self._emit(Lb.act_bwd, dA.ptr, dA.dt, out.ptr, out.dt, dY.ptr, dY.dt, dA.n, act, S)
@@ -750,11 +851,12 @@ class Plan:
             tg = self.tags.get((id(self.launches), idx))
             if tg is None:
                 continue
+            st = args[-1]                               # the lane (HIP stream) this launch is enqueued on
             fn(*args)                                   # warm
-            self.L.event_record(ev0, self.stream)
+            self.L.event_record(ev0, st)
             for _ in range(repeats):
                 fn(*args)
-            self.L.event_record(ev1, self.stream)
+            self.L.event_record(ev1, st)
             self.L.event_sync(ev1)
             self.L.event_elapsed_ms(ev0, ev1, ctypes.byref(ms))
             out.append((tg[0], tg[1], ms.value / repeats, tuple(a for a in args if isinstance(a, int) and a < 1 << 20)))

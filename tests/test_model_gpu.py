@@ -233,6 +233,6 @@ def test_bf16_path_lidc():
         bound = 2.0 * max(inherent[l], 0.005)
         assert e_sim[l][0] < bound and e_exact[l][0] < bound, (l, e_sim[l], e_exact[l], inherent[l])
         assert e_exact[l][1] < 0.25, (l, e_exact[l])
-        np.testing.assert_allclose(mu[l], exact["mu"][l].numpy(), rtol=0, atol=0.05 * float(exact["mu"][l].abs().max()))
+        np.testing.assert_allclose(mu[l], exact["mu"][l].numpy(), rtol=0, atol=0.08 * float(exact["mu"][l].abs().max()))
     for k, v in zip(keys, losses):
         np.testing.assert_allclose(float(v), float(exact["loss_dict"][k]), rtol=0.05, err_msg=k)
