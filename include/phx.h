@@ -79,10 +79,15 @@ int phx_pack_conv3x3_bf16_pad(const float* w_hwio, void* wpk_fwd, void* wpk_dgra
 int phx_pad_channels_bf16(const void* x, int dt, int C, void* out, int Cpad, size_t npix, void* stream);
 int phx_unpad_channels_bf16(const void* src, void* dst, int dst_dt, int C, int Cpad, size_t npix, void* stream);
 int phx_unpad_filter_grad_accumulate(const float* dw_pad, float* dw_hwio, int Cin, int Cin_pad, int Cout, void* stream);
-int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W);     /* number of pixel tiles (= rows of stats_partial) */
-/* dw_hwio[kh][kw][ci][co] += sum x * dy (fp32 atomics), Cin % 32 == 0, Cout % 32 == 0. */
-int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, int B, int H, int W,
-                                int Cin, int Cout, void* stream);
+int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W);
+/* debug: device buffer of >= 16 uint64 that receives shader-clock phase timestamps of block 0 (NULL disables) */
+int phx_debug_set_trace(void* dev_buf);     /* number of pixel tiles (= rows of stats_partial) */
+/* dw_hwio[kh][kw][ci][co] += sum x * dy, Cin % 32 == 0, Cout % 32 == 0.  With a workspace (>= phx_conv3x3_wgrad_ws_bytes)
+ * the per-block partial filters are stored with plain writes and summed by a second kernel; workspace == NULL falls back
+ * to fp32 atomics straight into dw_hwio (a CU issues those at ~1 lane/clock: 46 us per block on MI355X). */
+size_t phx_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout);
+int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes,
+                                int B, int H, int W, int Cin, int Cout, void* stream);
 
 /* 1x1 "head" convolutions with nout in {2,4,6,8} outputs (mu / sigma / y_lvl / pre_mu / prediction heads:
  * posteriors.py:125-127, priors.py:117-119, likelihoods.py:155,220): streaming kernels, fp32 outputs.

@@ -9,6 +9,8 @@
 // re-used by all nine filter taps from LDS.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "phx_common.h"
 
 #define KC 32            // input channels per LDS stage (two MFMA k-steps)
@@ -281,12 +283,20 @@ __device__ __forceinline__ int wswz(int pix, int byte_in_row) {
     return pix * RB + byte_in_row;
 }
 
+__device__ unsigned long long* g_phx_trace = nullptr;      // debug: phase timestamps of block (0,0,0), thread 0
+#define PHX_TRACE(slot)                                                                                  \
+    do {                                                                                                 \
+        if (g_phx_trace && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)    \
+            g_phx_trace[slot] = __builtin_readcyclecounter();                                            \
+    } while (0)
+
 // BIGP selects the bound on the per-thread staging pieces: false -> 16x16 / 8x8x4 tiles, true -> 4x4x16 / 2x2x64 tiles
-template <int TCI, int TCO, bool BIGP>
+template <int TCI, int TCO, bool BIGP, bool FAST16>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* __restrict__ x,
                                                           const unsigned short* __restrict__ dy,
-                                                          float* __restrict__ dw, int B, int H, int W, int Cin, int Cout,
-                                                          MTile g, int ntiles, int tiles_per_block) {
+                                                          float* __restrict__ dw, float* __restrict__ ws, int B, int H,
+                                                          int W, int Cin, int Cout, MTile g, int ntiles,
+                                                          int tiles_per_block) {
     constexpr int WI = TCI / 32, WJ = TCO / 32, WK = 4 / (WI * WJ);
     constexpr int RBX = TCI * 2, RBD = TCO * 2;
     constexpr int QX = TCI / 8, QD = TCO / 8;                        // 16-byte pieces per pixel
@@ -305,6 +315,19 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* 
     const int chan_byte_x = (wi * 32 + cb16 * 16 + (c16 & 3) * 4) * 2;
     const int chan_byte_d = (wj * 32 + cb16 * 16 + (c16 & 3) * 4) * 2;
     typedef __attribute__((ext_vector_type(8))) short s16x8;
+    // FAST16 per-lane LDS constants: pixel column lx_r = 8*khalf + 4*r + (c16>>2) of the lane's two pixel slots
+    unsigned dcon[2], xcon[2][3][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int lxr = khalf * 8 + r * 4 + (c16 >> 2);
+        dcon[r] = (unsigned)wswz<RBD>(lxr, chan_byte_d);                  // + ks*16*RBD: the row term never flips the swizzle
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int par = 0; par < 2; ++par)                            // par = parity of the patch row
+                xcon[r][kw][par] = (unsigned)((lxr + kw) * RBX +
+                                              (RBX == 128 ? (chan_byte_x ^ (((((lxr + kw) >> 1) & 1) ^ par) << 6)) : chan_byte_x));
+    }
 
     f32x16 acc[9];
 #pragma unroll
@@ -352,10 +375,13 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* 
     };
     const int t_begin = blockIdx.x * tiles_per_block;
     const int t_end = min(ntiles, t_begin + tiles_per_block);
+    PHX_TRACE(0);
     if (t_begin < t_end) prefetch(t_begin);
+    PHX_TRACE(1);
 
     for (int t = t_begin; t < t_end; ++t) {
         __syncthreads();                         // previous tile fully consumed
+        if (t == t_begin) PHX_TRACE(2);
 #pragma unroll
         for (int it = 0; it < NXI; ++it) {
             const int i = threadIdx.x + it * 256;
@@ -367,47 +393,130 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* 
             *reinterpret_cast<uint4*>(sD + wswz<RBD>(i / QD, (i % QD) * 16)) = rd[it];
         }
         __syncthreads();
+        if (t == t_begin) PHX_TRACE(3);
         if (t + 1 < t_end) prefetch(t + 1);      // next tile's global loads fly under this tile's MFMAs
-        for (int ks = wk; ks < 16; ks += WK) {
-            // the two pixel slots this lane addresses in this k-step (r = 0, 1): m = 16*ks + 8*khalf + 4*r + (c16>>2)
-            int mpix[2], ppix[2];
+        if (t == t_begin) PHX_TRACE(4);
+        if (FAST16) {
+            // 16x16 tiles (tb = 1): every LDS address is (row * const) + per-lane constant, and the swizzle bit is
+            // parity(row) ^ per-lane bit, so with the k-steps taken in (even, odd) pairs all row terms are immediates.
+            auto kstep = [&](unsigned xb, unsigned db, auto parc) {
+                constexpr int P = decltype(parc)::value;          // parity of this k-step's tile row
+                const s16x4 d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(smem + db + dcon[0]));
+                const s16x4 d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(smem + db + dcon[1]));
+                const s16x8 dtmp = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+                const bf16x8 bfrag = __builtin_bit_cast(bf16x8, dtmp);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int m = ks * 16 + khalf * 8 + r * 4 + (c16 >> 2);
-                const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
-                mpix[r] = m;
-                ppix[r] = (lb * ph + ly) * pw + lx;
-            }
-            const s16x4 d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4 __attribute__((address_space(3)))*)(sD + wswz<RBD>(mpix[0], chan_byte_d)));
-            const s16x4 d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (s16x4 __attribute__((address_space(3)))*)(sD + wswz<RBD>(mpix[1], chan_byte_d)));
-            const s16x8 dtmp = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
-            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, dtmp);
+                for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int sh = kh * pw + kw;
-                    const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4 __attribute__((address_space(3)))*)(sX + wswz<RBX>(ppix[0] + sh, chan_byte_x)));
-                    const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4 __attribute__((address_space(3)))*)(sX + wswz<RBX>(ppix[1] + sh, chan_byte_x)));
-                    const s16x8 atmp = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                    const bf16x8 afrag = __builtin_bit_cast(bf16x8, atmp);
-                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[kh * 3 + kw], 0, 0, 0);
+                    for (int kw = 0; kw < 3; ++kw) {
+                        constexpr int dummy = 0;
+                        const int par = (P + kh) & 1;
+                        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3)))*)(smem + xb + kh * 18 * RBX + xcon[0][kw][par]));
+                        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3)))*)(smem + xb + kh * 18 * RBX + xcon[1][kw][par]));
+                        const s16x8 atmp = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                        const bf16x8 afrag = __builtin_bit_cast(bf16x8, atmp);
+                        acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[kh * 3 + kw], 0, 0, 0);
+                        (void)dummy;
+                    }
+            };
+            const unsigned xbase = 0, dbase = (unsigned)(npatch * RBX);
+            if (WK == 1) {
+#pragma unroll 2
+                for (int j = 0; j < 8; ++j) {
+                    kstep(xbase + (2 * j) * 18 * RBX, dbase + (2 * j) * 16 * RBD, std::integral_constant<int, 0>());
+                    kstep(xbase + (2 * j + 1) * 18 * RBX, dbase + (2 * j + 1) * 16 * RBD, std::integral_constant<int, 1>());
                 }
+            } else if (wk & 1) {
+                for (int ks = wk; ks < 16; ks += WK)
+                    kstep(xbase + ks * 18 * RBX, dbase + ks * 16 * RBD, std::integral_constant<int, 1>());
+            } else {
+                for (int ks = wk; ks < 16; ks += WK)
+                    kstep(xbase + ks * 18 * RBX, dbase + ks * 16 * RBD, std::integral_constant<int, 0>());
+            }
+        } else {
+            for (int ks = wk; ks < 16; ks += WK) {
+                // the two pixel slots this lane addresses in this k-step (r = 0, 1): m = 16*ks + 8*khalf + 4*r + (c16>>2)
+                int mpix[2], ppix[2];
+    #pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int m = ks * 16 + khalf * 8 + r * 4 + (c16 >> 2);
+                    const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
+                    mpix[r] = m;
+                    ppix[r] = (lb * ph + ly) * pw + lx;
+                }
+                const s16x4 d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(sD + wswz<RBD>(mpix[0], chan_byte_d)));
+                const s16x4 d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4 __attribute__((address_space(3)))*)(sD + wswz<RBD>(mpix[1], chan_byte_d)));
+                const s16x8 dtmp = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+                const bf16x8 bfrag = __builtin_bit_cast(bf16x8, dtmp);
+    #pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+    #pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int sh = kh * pw + kw;
+                        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3)))*)(sX + wswz<RBX>(ppix[0] + sh, chan_byte_x)));
+                        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3)))*)(sX + wswz<RBX>(ppix[1] + sh, chan_byte_x)));
+                        const s16x8 atmp = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                        const bf16x8 afrag = __builtin_bit_cast(bf16x8, atmp);
+                        acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[kh * 3 + kw], 0, 0, 0);
+                    }
+            }
         }
     }
     // C layout: col = lane&31 -> co, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> ci
-    const int co = co0 + wj * 32 + (lane & 31);
+    PHX_TRACE(5);
+    if (ws) {
+        // A CU issues fp32 atomics at ~1 lane/clock (measured: 36.8 K lane-atomics = 46 us per block), so the partial
+        // tile goes to a workspace with plain coalesced stores: ws[(cblock * gridDim.x + blockIdx.x)][wk][9][TCI][TCO];
+        // k_wgrad_reduce sums the slices into dw.
+        const size_t cb = (size_t)blockIdx.z * gridDim.y + blockIdx.y;
+        float* wp = ws + ((cb * gridDim.x + blockIdx.x) * WK + wk) * (size_t)(9 * TCI * TCO);
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+        for (int k = 0; k < 9; ++k)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            atomicAdd(&dw[((size_t)k * Cin + ci) * Cout + co], acc[k][r]);
-        }
+            for (int r = 0; r < 16; ++r) {
+                const int cil = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                wp[(k * TCI + cil) * TCO + wj * 32 + (lane & 31)] = acc[k][r];
+            }
+    } else {
+        const int co = co0 + wj * 32 + (lane & 31);
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                atomicAdd(&dw[((size_t)k * Cin + ci) * Cout + co], acc[k][r]);
+            }
+    }
+    PHX_TRACE(6);
+}
+
+// dw[k][ci][co] += sum over the nslice partial tiles written by k_conv3x3_wgrad.  Block = 64 filter entries x 4 slice
+// groups; gridDim.y further splits the slices (one atomic per entry per y-block).
+__global__ void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw, int nslice, int Cin, int Cout,
+                               int tci, int tco) {
+    const int tile_elems = 9 * tci * tco;
+    const int ntile_ci = Cin / tci;
+    const size_t total = (size_t)9 * Cin * Cout;
+    const size_t i = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sg = threadIdx.x >> 6;
+    float a = 0.f;
+    if (i < total) {
+        const int co = (int)(i % Cout), ci = (int)((i / Cout) % Cin), k = (int)(i / ((size_t)Cout * Cin));
+        const int cb = (co / tco) * ntile_ci + (ci / tci);
+        const float* p = ws + (size_t)cb * nslice * tile_elems + (k * tci + ci % tci) * tco + co % tco;
+        for (int sidx = blockIdx.y * 4 + sg; sidx < nslice; sidx += gridDim.y * 4) a += p[(size_t)sidx * tile_elems];
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (sg == 0 && i < total)
+        atomicAdd(&dw[i], red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
 
 extern "C" {
@@ -452,6 +561,12 @@ int phx_unpad_filter_grad_accumulate(const float* dw_pad, float* dw_hwio, int Ci
     return PHX_OK;
 }
 
+int phx_debug_set_trace(void* dev_buf) {
+    unsigned long long* p = (unsigned long long*)dev_buf;
+    PHX_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phx_trace), &p, sizeof(p)));
+    return PHX_OK;
+}
+
 int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W) {
     MTile g = make_mtile(B, H, W);
     return g.tiles_x * g.tiles_y * g.tiles_b;
@@ -487,37 +602,61 @@ int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* 
     return PHX_OK;
 }
 
-int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, int B, int H, int W, int Cin, int Cout,
-                                void* stream) {
-    PHX_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, PHX_E_SHAPE, "conv3x3_wgrad_mfma: Cin % 32 == 0 and Cout % 32 == 0 required");
-    MTile g = make_mtile(B, H, W);
-    const int tw = 1 << g.tws, th = 1 << g.ths;
-    const int npatch = g.tb * (th + 2) * (tw + 2);
-    const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
-    const int tci = Cin % 64 == 0 ? 64 : 32, tco = Cout % 64 == 0 ? 64 : 32;
-    static bool attr_set = false;
-    if (!attr_set) {
-#define WG_ATTR(A, Bq, C)                                                                                             \
-    PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad<A, Bq, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-        WG_ATTR(64, 64, false); WG_ATTR(64, 32, false); WG_ATTR(32, 64, false); WG_ATTR(32, 32, false);
-        WG_ATTR(64, 64, true); WG_ATTR(64, 32, true); WG_ATTR(32, 64, true); WG_ATTR(32, 32, true);
-#undef WG_ATTR
-        attr_set = true;
-    }
-    // split the pixel reduction so that ~2 blocks per CU exist; every block atomically adds 9*TCI*TCO floats
-    const int cblocks = (Cin / tci) * (Cout / tco);
-    int target_blocks = (tci == 32 && tco == 32) ? 256 : 512;      // measured on MI355X (tools/bench_wgrad.py)
+static int wgrad_plan(int B, int H, int W, int Cin, int Cout, MTile* g, int* tci, int* tco, int* gx, int* tpb, int* wk) {
+    *g = make_mtile(B, H, W);
+    const int ntiles = g->tiles_x * g->tiles_y * g->tiles_b;
+    *tci = Cin % 64 == 0 ? 64 : 32;
+    *tco = Cout % 64 == 0 ? 64 : 32;
+    *wk = 4 / ((*tci / 32) * (*tco / 32));
+    const int cblocks = (Cin / *tci) * (Cout / *tco);
+    int target_blocks = (*tci == 32 && *tco == 32) ? 256 : 512;      // measured on MI355X (tools/bench_wgrad.py)
     if (const char* e = getenv("PHX_WGRAD_BLOCKS")) target_blocks = atoi(e);      // tuning hook
     int split = (target_blocks + cblocks - 1) / cblocks;
     if (split > ntiles) split = ntiles;
     if (split < 1) split = 1;
-    const int tpb = (ntiles + split - 1) / split;
-    const int gx = (ntiles + tpb - 1) / tpb;
+    *tpb = (ntiles + split - 1) / split;
+    *gx = (ntiles + *tpb - 1) / *tpb;
+    return ntiles;
+}
+
+size_t phx_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout) {
+    MTile g; int tci, tco, gx, tpb, wk;
+    wgrad_plan(B, H, W, Cin, Cout, &g, &tci, &tco, &gx, &tpb, &wk);
+    return (size_t)(Cin / tci) * (Cout / tco) * gx * wk * 9 * tci * tco * sizeof(float);
+}
+
+int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes,
+                                int B, int H, int W, int Cin, int Cout, void* stream) {
+    PHX_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, PHX_E_SHAPE, "conv3x3_wgrad_mfma: Cin % 32 == 0 and Cout % 32 == 0 required");
+    MTile g; int tci, tco, gx, tpb, wk;
+    const int ntiles = wgrad_plan(B, H, W, Cin, Cout, &g, &tci, &tco, &gx, &tpb, &wk);
+    const int tw = 1 << g.tws, th = 1 << g.ths;
+    const int npatch = g.tb * (th + 2) * (tw + 2);
+    float* ws = nullptr;
+    if (workspace) {
+        PHX_REQUIRE(workspace_bytes >= phx_conv3x3_wgrad_ws_bytes(B, H, W, Cin, Cout), PHX_E_INVAL, "conv3x3_wgrad_mfma: workspace too small");
+        ws = (float*)workspace;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+#define WG_ATTR(A, Bq, C, F)                                                                                          \
+    PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad<A, Bq, C, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+        WG_ATTR(64, 64, false, false); WG_ATTR(64, 32, false, false); WG_ATTR(32, 64, false, false); WG_ATTR(32, 32, false, false);
+        WG_ATTR(64, 64, true, false); WG_ATTR(64, 32, true, false); WG_ATTR(32, 64, true, false); WG_ATTR(32, 32, true, false);
+        WG_ATTR(64, 64, false, true); WG_ATTR(64, 32, false, true); WG_ATTR(32, 64, false, true); WG_ATTR(32, 32, false, true);
+#undef WG_ATTR
+        attr_set = true;
+    }
     const size_t sh = (size_t)npatch * tci * 2 + (size_t)256 * tco * 2;
-#define WG_LAUNCH(A, Bq, C)                                                                                            \
-    hipLaunchKernelGGL((k_conv3x3_wgrad<A, Bq, C>), dim3(gx, Cin / A, Cout / Bq), dim3(256), sh, (hipStream_t)stream,  \
-                       (const unsigned short*)x, (const unsigned short*)dy, dw_hwio, B, H, W, Cin, Cout, g, ntiles, tpb)
-#define WG_LAUNCH2(A, Bq) do { if (npatch <= 400) WG_LAUNCH(A, Bq, false); else WG_LAUNCH(A, Bq, true); } while (0)
+#define WG_LAUNCH(A, Bq, C, F)                                                                                            \
+    hipLaunchKernelGGL((k_conv3x3_wgrad<A, Bq, C, F>), dim3(gx, Cin / A, Cout / Bq), dim3(256), sh, (hipStream_t)stream,  \
+                       (const unsigned short*)x, (const unsigned short*)dy, dw_hwio, ws, B, H, W, Cin, Cout, g, ntiles, tpb)
+#define WG_LAUNCH2(A, Bq)                                                                  \
+    do {                                                                                   \
+        if (g.tws == 4 && g.ths == 4 && g.tb == 1) WG_LAUNCH(A, Bq, false, true);          \
+        else if (npatch <= 400) WG_LAUNCH(A, Bq, false, false);                            \
+        else WG_LAUNCH(A, Bq, true, false);                                                \
+    } while (0)
     if (tci == 64 && tco == 64) WG_LAUNCH2(64, 64);
     else if (tci == 64) WG_LAUNCH2(64, 32);
     else if (tco == 64) WG_LAUNCH2(32, 64);
@@ -525,6 +664,16 @@ int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, i
 #undef WG_LAUNCH2
 #undef WG_LAUNCH
     PHX_CHECK_LAUNCH();
+    if (ws) {
+        const size_t total = (size_t)9 * Cin * Cout;
+        const int nslice = gx * wk;
+        int gy = nslice / 16;
+        if (gy < 1) gy = 1;
+        if (gy > 16) gy = 16;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 63) / 64), gy), dim3(256), 0, (hipStream_t)stream, ws,
+                           dw_hwio, nslice, Cin, Cout, tci, tco);
+        PHX_CHECK_LAUNCH();
+    }
     return PHX_OK;
 }
 

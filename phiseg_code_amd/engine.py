@@ -732,13 +732,17 @@ class Plan:
         elif sv.get("padded"):
             ce = sv["cin_eff"]
             dwp = self._alloc_zeroed(9 * ce * cout)
-            self._emit(Lb.conv3x3_wgrad_mfma_bf16, x.ptr, dY.ptr, dwp.ptr, B, H, Wd, ce, cout, S,
+            wsb = int(Lb.conv3x3_wgrad_ws_bytes(B, H, Wd, ce, cout))
+            wsp = self._alloc((wsb // 4,), F32)
+            self._emit(Lb.conv3x3_wgrad_mfma_bf16, x.ptr, dY.ptr, dwp.ptr, wsp.ptr, wsb, B, H, Wd, ce, cout, S,
                        tag="conv3x3_mfma_wgrad", flops=18.0 * cin * cout * B * H * Wd)
             self._emit(Lb.unpad_filter_grad_accumulate, dwp.ptr, dw, cin, ce, cout, S)
             if db is not None:
                 self._emit(Lb.channel_sum_accumulate, dY.ptr, dY.dt, db, B * H * Wd, cout, S)
         elif sv["mfma"]:
-            self._emit(Lb.conv3x3_wgrad_mfma_bf16, x.ptr, dY.ptr, dw, B, H, Wd, cin, cout, S,
+            wsb = int(Lb.conv3x3_wgrad_ws_bytes(B, H, Wd, cin, cout))
+            wsp = self._alloc((wsb // 4,), F32)      # per-layer workspace of partial filters (no cross-lane sharing)
+            self._emit(Lb.conv3x3_wgrad_mfma_bf16, x.ptr, dY.ptr, dw, wsp.ptr, wsb, B, H, Wd, cin, cout, S,
                        tag="conv3x3_mfma_wgrad", flops=18.0 * cin * cout * B * H * Wd)
             if db is not None:
                 self._emit(Lb.channel_sum_accumulate, dY.ptr, dY.dt, db, B * H * Wd, cout, S)

@@ -37,7 +37,7 @@ def parse_header(path=HEADER):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\bint\s+(phx_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int|size_t)\s+(phx_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
         name, args = m.group(1), m.group(2).strip()
         if args in ("", "void"):
             protos[name] = []
@@ -57,7 +57,9 @@ class _Lib:
             fn = getattr(self._dll, name)        # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
-            if name in ("phx_abi_version", "phx_last_error", "phx_conv3x3_mfma_bf16_tiles"):
+            if name in ("phx_abi_version", "phx_last_error", "phx_conv3x3_mfma_bf16_tiles", "phx_conv3x3_wgrad_ws_bytes"):
+                if name == "phx_conv3x3_wgrad_ws_bytes":
+                    fn.restype = ctypes.c_size_t
                 setattr(self, name[4:], fn)
             else:
                 setattr(self, name[4:], self._checked(name, fn))

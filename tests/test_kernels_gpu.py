@@ -182,8 +182,13 @@ def test_conv3x3_mfma_fwd_dgrad_wgrad(L, case):
     L.conv3x3_mfma_bf16(dyd.data_ptr(), wg.data_ptr(), dx.data_ptr(), None, 0, None, B, H, W, N, K, S())
     close(host(dx), xr.grad.numpy(), 6e-3, "mfma dgrad")
     dw = torch.zeros(3, 3, K, N, dtype=torch.float32).cuda()
-    L.conv3x3_wgrad_mfma_bf16(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), B, H, W, K, N, S())
-    close(host(dw), wr.grad.numpy(), 1e-4, "mfma wgrad")
+    L.conv3x3_wgrad_mfma_bf16(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), None, 0, B, H, W, K, N, S())
+    close(host(dw), wr.grad.numpy(), 1e-4, "mfma wgrad (atomics)")
+    wsb = int(L.conv3x3_wgrad_ws_bytes(B, H, W, K, N))
+    ws = torch.empty(wsb // 4, dtype=torch.float32).cuda()
+    dw2 = torch.zeros(3, 3, K, N, dtype=torch.float32).cuda()
+    L.conv3x3_wgrad_mfma_bf16(xd.data_ptr(), dyd.data_ptr(), dw2.data_ptr(), ws.data_ptr(), wsb, B, H, W, K, N, S())
+    close(host(dw2), wr.grad.numpy(), 1e-4, "mfma wgrad (workspace)")
 
 
 NORM_CASES = [

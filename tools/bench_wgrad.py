@@ -12,11 +12,14 @@ for (B, H, W, K, N) in shapes:
     x = torch.randn(B, H, W, K, device="cuda").to(torch.bfloat16)
     dy = torch.randn(B, H, W, N, device="cuda").to(torch.bfloat16)
     dw = torch.zeros(9 * K * N, device="cuda")
+    wsb = int(L.conv3x3_wgrad_ws_bytes(B, H, W, K, N)) if os.environ.get("PHX_WS", "1") == "1" else 0
+    ws = torch.empty(max(wsb // 4, 1), device="cuda")
+    wsp = ws.data_ptr() if wsb else None
     wf = torch.randn(9 * K * N, device="cuda").to(torch.bfloat16)
     y = torch.empty(B, H, W, N, device="cuda", dtype=torch.bfloat16)
     def run():
         if which == "wgrad":
-            L.conv3x3_wgrad_mfma_bf16(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, K, N, st)
+            L.conv3x3_wgrad_mfma_bf16(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), wsp, wsb, B, H, W, K, N, st)
         else:
             L.conv3x3_mfma_bf16(x.data_ptr(), wf.data_ptr(), y.data_ptr(), None, 0, None, B, H, W, K, N, st)
     for _ in range(3): run()
