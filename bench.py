@@ -79,7 +79,7 @@ def main():
     ctx = distributed.DistContext()
     assert ctx.world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     cfg = make_config(args.batch, args.dtype)
-    model = phiseg_model.phiseg(cfg, dist=ctx if ctx.world > 1 else None)
+    model = phiseg_model.phiseg(cfg, dist=ctx if ctx.active else None)
     sess = model.sess
     plan = sess.plan_for([model.loss_tot], True, args.batch, True)
     rng = np.random.default_rng(1234 + ctx.rank)
@@ -87,12 +87,12 @@ def main():
     plan.set_input("x_input", x)          # resident in HBM for the whole run
     plan.set_input("s_input", s)
     sess.store.set_lr(1e-3)
-    if ctx.world > 1:                     # identical replicas
+    if ctx.active:                        # identical replicas
         ctx.broadcast_(sess.store.params)
         ctx.broadcast_(sess.store.state)
 
     def step():
-        if ctx.world > 1:
+        if ctx.active:
             plan.run_main()
             ctx.allreduce_sum(sess.store.grads, plan)
             plan.run_opt()

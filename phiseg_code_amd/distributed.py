@@ -14,14 +14,16 @@ import torch.distributed as dist
 
 
 class DistContext:
-    def __init__(self, backend=None):
+    def __init__(self, backend=None, force=False):
+        """force=True initialises the process group even for a single rank (exercises the RCCL path on one GPU)."""
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.cuda = torch.cuda.is_available()
         if self.cuda:
             torch.cuda.set_device(self.local_rank % torch.cuda.device_count())
-        if self.world > 1 and not dist.is_initialized():
+        self.active = self.world > 1 or force
+        if self.active and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             backend = backend or ("nccl" if self.cuda else "gloo")
@@ -33,7 +35,7 @@ class DistContext:
     def allreduce_sum(self, tensor, plan=None, bucket_elems=8 << 20):
         """Sum `tensor` (the flat gradient arena) over ranks, in ~32 MB buckets so RCCL pipelines them over
         the xGMI links.  `plan`: the engine plan whose stream produced the gradients (synchronised first)."""
-        if self.world == 1:
+        if not self.active:
             return
         if plan is not None:
             plan.sync()
@@ -46,20 +48,20 @@ class DistContext:
             torch.cuda.current_stream().synchronize()
 
     def barrier(self):
-        if self.world > 1:
+        if self.active:
             dist.barrier()
 
     def max_float(self, v):
-        if self.world == 1:
+        if not self.active:
             return float(v)
         t = torch.tensor([float(v)], dtype=torch.float64, device="cuda" if self.cuda else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def broadcast_(self, tensor, src=0):
-        if self.world > 1:
+        if self.active:
             dist.broadcast(tensor, src=src)
 
     def shutdown(self):
-        if self.world > 1 and dist.is_initialized():
+        if self.active and dist.is_initialized():
             dist.destroy_process_group()

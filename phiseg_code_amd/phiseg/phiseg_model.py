@@ -68,7 +68,7 @@ class Session:
             self.plans[key] = engine.Plan(
                 store, fetch_tensors, loss=self.model.loss_tot if train else None, batch=batch, training=training,
                 compute_dtype=self.compute_dtype, rng_seed=self.rng_seed, sample_offset=rank * batch,
-                loss_inv_batch=1.0 / (batch * world), split_optimizer=world > 1)
+                loss_inv_batch=1.0 / (batch * world), split_optimizer=bool(self.dist and self.dist.active))
         return self.plans[key]
 
     def run(self, fetches, feed_dict=None):
@@ -98,7 +98,7 @@ class Session:
             plan.set_input("s_input", feed_dict[m.s_inp])
         if m.lr_pl in feed_dict:
             self.store.set_lr(feed_dict[m.lr_pl])
-        if train and self.dist is not None and self.dist.world > 1:
+        if train and self.dist is not None and self.dist.active:
             plan.run_main()
             self.dist.allreduce_sum(self.store.grads, plan)
             plan.run_opt()

@@ -32,7 +32,7 @@ def make_config(cfg, compute_dtype="f32"):
 
 
 @pytest.mark.parametrize("case", ["tiny_phiseg_bn", "tiny_phiseg_gn4", "tiny_phiseg_in", "tiny_probunet_bn",
-                                  "tiny_phiseg71_bn", "lidc_phiseg_bn"])
+                                  "tiny_phiseg71_bn", "tiny_phiseg_bn_192", "lidc_phiseg_bn"])
 def test_variables_match_reference_trace(case):
     g, cfg, var_order = load_golden(case)
     model = phiseg_model.phiseg(make_config(cfg))

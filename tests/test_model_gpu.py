@@ -42,7 +42,8 @@ def build(case, compute_dtype="f32"):
     return g, cfg, var_order, model, params, x_np, s_np
 
 
-TINY = ["tiny_phiseg_bn", "tiny_phiseg_gn4", "tiny_phiseg_in", "tiny_probunet_bn", "tiny_phiseg71_bn"]
+TINY = ["tiny_phiseg_bn", "tiny_phiseg_gn4", "tiny_phiseg_in", "tiny_probunet_bn", "tiny_phiseg71_bn",
+        "tiny_phiseg_bn_192"]
 
 
 @pytest.mark.parametrize("case", TINY + ["lidc_phiseg_bn"])
@@ -235,4 +236,55 @@ def test_bf16_path_lidc():
         assert e_exact[l][1] < 0.25, (l, e_exact[l])
         np.testing.assert_allclose(mu[l], exact["mu"][l].numpy(), rtol=0, atol=0.08 * float(exact["mu"][l].abs().max()))
     for k, v in zip(keys, losses):
-        np.testing.assert_allclose(float(v), float(exact["loss_dict"][k]), rtol=0.05, err_msg=k)
+        ex, sm_ = float(exact["loss_dict"][k]), float(sim["loss_dict"][k])
+        inh = abs(sm_ - ex) / abs(ex)          # what bf16 storage alone does to this ELBO term (oracle vs oracle)
+        print("ELBO term %-34s exact %.4e  sim-bf16 %+.2f%%  HIP-bf16 %+.2f%%" % (k, ex, 100 * (sm_ - ex) / ex, 100 * (float(v) - ex) / ex))
+        np.testing.assert_allclose(float(v), ex, rtol=max(0.05, 2.5 * inh), err_msg=k)
+
+
+def test_data_parallel_code_path_on_one_gpu():
+    """The N > 1 step (forward+backward graph | RCCL all-reduce of the flat gradient arena | Adam graph) exercised with
+    a single-rank NCCL process group: must reproduce the single-graph step bit-for-bit in structure (same losses)."""
+    import os
+    from phiseg_code_amd import distributed
+    from phiseg_code_amd.phiseg import phiseg_model
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    g, cfg, var_order = load_golden("tiny_phiseg_bn")
+    params, x_np, s_np = golden_inputs(cfg, var_order, dtype=torch.float64)
+    fd = None
+    losses = {}
+    ctx = distributed.DistContext(force=True)
+    try:
+        for tag, dist in (("single", None), ("dp", ctx)):
+            model = phiseg_model.phiseg(make_config(cfg, "f32"), dist=dist, rng_seed=cfg["eps_seed"])
+            model.set_weights({k: v.detach().numpy() for k, v in params.items()})
+            fd = {model.x_inp: x_np, model.s_inp: s_np, model.training_pl: True, model.lr_pl: 1e-5}
+            losses[tag] = [float(model.sess.run([model.train_step, model.loss_tot], fd)[1]) for _ in range(3)]
+    finally:
+        ctx.shutdown()
+    np.testing.assert_allclose(losses["dp"], losses["single"], rtol=2e-4)     # fp32 atomics: run-to-run order differs
+
+
+def test_bf16_sampling_192x192_four_classes():
+    """BASELINE config 5 geometry on the MFMA path: phiseg_7_5 (n0 = 32), 192x192, 4 classes, Monte-Carlo sampling
+    (prior in generation mode + likelihood, inference-mode batch norm) -- maps of 96, 48, 24, 12, 6, 3 pixels exercise
+    the partial-tile masks of the bf16 kernels.  Bound: bf16 storage (see test_bf16_path_lidc)."""
+    from oracle import init as oinit
+    from oracle import nets
+    from phiseg_code_amd.phiseg import phiseg_model
+    cfg = dict(arch="phiseg", norm="batch_norm", n0=32, zdim0=2, H=192, B=2, nlabels=4, latent_levels=5,
+               resolution_levels=7, image_size=(192, 192, 1), KL_weight=1.0, CE_weight=1.0, exponential_weighting=True)
+    model = phiseg_model.phiseg(make_config(cfg, "bf16"), rng_seed=42)
+    var_order = [(n, v.shape) for n, v in model.graph.variables.items()]
+    params = otrain.make_params(var_order, 0, torch.float64, perturbed=False)
+    model.set_weights({k: v.detach().numpy() for k, v in params.items()})
+    x_np, _ = oinit.synthetic_batch(2, 192, 4, 1234)
+    with torch.no_grad():
+        ref = nets.sample(params, torch.as_tensor(x_np, dtype=torch.float64), otrain.torch_eps_fn(42, 0, 2), cfg)
+    s_out, sm = model.sess.run([model.s_out_eval, model.s_out_eval_sm], {model.x_inp: x_np, model.training_pl: False})
+    r = ref["s_out_eval"].numpy()
+    d = s_out - r
+    assert np.sqrt((d ** 2).mean()) / np.abs(r).max() < 0.03, np.sqrt((d ** 2).mean()) / np.abs(r).max()
+    assert np.abs(sm.sum(axis=-1) - 1.0).max() < 1e-5
+    assert (sm.argmax(-1) == ref["s_out_eval_sm"].numpy().argmax(-1)).mean() > 0.97

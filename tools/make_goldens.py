@@ -53,6 +53,8 @@ CASES = {
                              latent_levels=1),
     "tiny_phiseg71_bn": dict(arch="phiseg", norm="batch_norm", n0=4, zdim0=2, H=128, B=3, nlabels=2,
                              latent_levels=1),
+    # prostate-shaped geometry of BASELINE config 5: 192x192 (maps 96, 48, 24, 12, 6, 3: not powers of two), 4 classes
+    "tiny_phiseg_bn_192": dict(arch="phiseg", norm="batch_norm", n0=4, zdim0=2, H=192, B=2, nlabels=4),
     "lidc_phiseg_bn": dict(arch="phiseg", norm="batch_norm", n0=32, zdim0=2, H=128, B=2, nlabels=2,
                            full=False),
 }
