@@ -126,7 +126,18 @@ def main():
         "step_tflops": images / dt * F_TRAIN_GFLOP_PER_IMAGE / 1e3,
     }
     if ctx.rank == 0 and not args.no_roofline and args.dtype == "bf16":
-        rows = plan.time_tagged_kernels(repeats=3)
+        rows_all = plan.time_tagged_kernels(repeats=3)
+        rows = [r for r in rows_all if r[0].startswith("conv")]
+        if args.profile_table:
+            hb = {}
+            for tag, by, ms, shp in rows_all:
+                if tag.startswith("bytes_"):
+                    a = hb.setdefault((tag, by >= 64e6), [0.0, 0.0, 0])
+                    a[0] += by; a[1] += ms; a[2] += 1
+            for key in sorted(hb):
+                a = hb[key]
+                print("### %-24s %-8s launches=%3d %8.3f ms  %8.1f GB/s" % (key[0], ">=64MB" if key[1] else "<64MB", a[2], a[1], a[0] / a[1] / 1e6),
+                      file=sys.stderr)
         fam = {}
         for tag, fl, ms, shp in rows:
             a = fam.setdefault(tag, [0.0, 0.0, 0])

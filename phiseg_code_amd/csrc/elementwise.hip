@@ -91,7 +91,10 @@ static int norm_geometry(int P, int C, int V, int* PL, int* threads, int* chunk,
     if (CV > 256) return -1;
     *PL = 256 / CV;
     *threads = CV * (*PL);
-    int want = (P + (*PL) * 16 - 1) / ((*PL) * 16);          // >= 16 pixels per thread
+    int rows = (P + *PL - 1) / (*PL);
+    int want = (rows + 15) / 16;                              // 16 pixels per thread on big maps, >= ~512 blocks on small ones
+    int floor_blocks = rows < 512 ? rows : 512;
+    if (want < floor_blocks) want = floor_blocks;
     int cap = 2048 / (NS > 0 ? NS : 1);
     if (cap < 1) cap = 1;
     if (want > cap) want = cap;
@@ -106,7 +109,12 @@ static int stream_geometry(int P, int C, int V, int* PL, int* threads, int* chun
     if (CV > 256) return -1;
     *PL = 256 / CV;
     *threads = CV * (*PL);
-    int want = (P + (*PL) * 4 - 1) / ((*PL) * 4);            // >= 4 pixels per thread
+    // 16 pixels per thread on big maps; on small maps fewer, so that >= ~1024 blocks exist (the kernels are latency-bound
+    // there: a thread's iterations are serially dependent loads)
+    int rows = (P + *PL - 1) / (*PL);
+    int want = (rows + 15) / 16;
+    int floor_blocks = rows < 1024 ? rows : 1024;
+    if (want < floor_blocks) want = floor_blocks;
     int cap = 8192 / (NS > 0 ? NS : 1);
     if (cap < 1) cap = 1;
     if (want > cap) want = cap;
@@ -247,10 +255,20 @@ __global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __rest
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         const int c = cv * V + j, g = c / cg;
-        if (g != gprev) {
-            group_stats(sums, pivot, ns, C, g, cg, invP, eps, &mu, &var);
+        if (cg == 1) {                                      // batch / instance norm: one channel per statistic
+            const float2 sq = *reinterpret_cast<const float2*>(sums + ((size_t)ns * C + c) * 2);
+            const float d1 = sq.x * invP;
+            mu = (pivot ? pivot[(size_t)ns * C + c] : 0.f) + d1;
+            var = fmaxf(sq.y * invP - d1 * d1, 0.f);
             rs = rsqrtf(var + eps);
-            gprev = g;
+            gprev = -1;
+        }
+        if (cg == 1 || g != gprev) {
+            if (cg != 1) {
+                group_stats(sums, pivot, ns, C, g, cg, invP, eps, &mu, &var);
+                rs = rsqrtf(var + eps);
+                gprev = g;
+            }
             if (publish && c == g * cg) {
                 mean_out[ns * G + g] = mu;
                 rstd_out[ns * G + g] = rs;
@@ -298,7 +316,12 @@ __global__ void k_norm_bwd_apply_fused(const TD* __restrict__ dA, const TX* __re
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         const int c = cv * V + j, g = c / cg;
-        if (g != gprev) {
+        if (cg == 1) {
+            const float2 sq = *reinterpret_cast<const float2*>(sums2 + ((size_t)ns * C + c) * 2);
+            const float gm = gamma[c];
+            S0 = gm * sq.x;
+            S1 = gm * sq.y;
+        } else if (g != gprev) {
             S0 = S1 = 0.f;
             for (int q = g * cg; q < (g + 1) * cg; ++q) {
                 S0 += gamma[q] * sums2[((size_t)ns * C + q) * 2];

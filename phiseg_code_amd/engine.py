@@ -472,7 +472,8 @@ class Plan:
                        eps, out.ptr, out.dt, mean.ptr, rstd.ptr, scale.ptr, shift.ptr,
                        self.store.ptr(nv["moving_mean"]) if upd else None,
                        self.store.ptr(nv["moving_variance"]) if upd else None,
-                       (1.0 - tfnorm.BN_DECAY) if upd else 0.0, NS, P, cout, Gn, act, S)
+                       (1.0 - tfnorm.BN_DECAY) if upd else 0.0, NS, P, cout, Gn, act, S,
+                       tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
         st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn)
         self.saved[op] = st
 
@@ -716,10 +717,12 @@ class Plan:
             Sg = self._alloc((NS * Gn * 2,), F32)
             dY = self._alloc(y.shape, y.dt)
             self._emit(Lb.norm_bwd_reduce, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
-                       sv["mean"].ptr, sv["rstd"].ptr, sums2.ptr, NS, P, cout, Gn, act, S)
+                       sv["mean"].ptr, sv["rstd"].ptr, sums2.ptr, NS, P, cout, Gn, act, S,
+                       tag="bytes_norm_bwd_reduce", flops=float(dA.nbytes + y.nbytes))
             self._emit(Lb.norm_bwd_apply_fused, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
                        sv["mean"].ptr, sv["rstd"].ptr, self.store.ptr(nv["gamma"]), sums2.ptr, dY.ptr, dY.dt,
-                       self.store.grad_ptr(nv["gamma"]), self.store.grad_ptr(nv["beta"]), NS, P, cout, Gn, act, S)
+                       self.store.grad_ptr(nv["gamma"]), self.store.grad_ptr(nv["beta"]), NS, P, cout, Gn, act, S,
+                       tag="bytes_norm_bwd_apply", flops=float(dA.nbytes + y.nbytes + dY.nbytes))
         elif act != rt.ACT_ID:
             dY = self._alloc(out.shape, dA.dt)
             self._emit(Lb.act_bwd, dA.ptr, dA.dt, out.ptr, out.dt, dY.ptr, dY.dt, dA.n, act, S)
