@@ -76,6 +76,9 @@ int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* 
  * padded problem folded back into dw_hwio[9][Cin][Cout]. */
 int phx_pack_conv3x3_bf16_pad(const float* w_hwio, void* wpk_fwd, void* wpk_dgrad /* nullable */, int Cin, int Cin_pad,
                               int Cout, void* stream);
+/* every filter of a step in one launch: descs_dev = device array of n records
+ * { const float* w_hwio; void* wpk_fwd; void* wpk_dgrad (nullable); int32 Cin, Cin_pad, Cout, 0 }  (40 bytes each) */
+int phx_pack_conv3x3_bf16_multi(const void* descs_dev, int n, void* stream);
 int phx_pad_channels_bf16(const void* x, int dt, int C, void* out, int Cpad, size_t npix, void* stream);
 int phx_unpad_channels_bf16(const void* src, void* dst, int dst_dt, int C, int Cpad, size_t npix, void* stream);
 int phx_unpad_filter_grad_accumulate(const float* dw_pad, float* dw_hwio, int Cin, int Cin_pad, int Cout, void* stream);

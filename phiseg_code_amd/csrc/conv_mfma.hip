@@ -62,6 +62,25 @@ __global__ void k_pack_conv3x3_pad(const float* __restrict__ w, unsigned short* 
         if (wd) wd[((size_t)(8 - t) * Cpad + ci) * Cout + co] = v;
     }
 }
+// all filters of a plan in ONE launch: descriptor table in device memory, blockIdx.y = filter
+struct PackDesc {
+    const float* w;
+    unsigned short* wf;       // [9][Cout][Cpad]
+    unsigned short* wd;       // [9][Cpad][Cout] taps flipped (nullable)
+    int cin, cpad, cout, _pad;
+};
+__global__ void k_pack_conv3x3_multi(const PackDesc* __restrict__ descs) {
+    const PackDesc d = descs[blockIdx.y];
+    const size_t n = (size_t)9 * d.cout * d.cpad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % d.cpad);
+        const int co = (int)((i / d.cpad) % d.cout);
+        const int t = (int)(i / ((size_t)d.cpad * d.cout));
+        const unsigned short v = ci < d.cin ? f2bf(d.w[((size_t)t * d.cin + ci) * d.cout + co]) : (unsigned short)0;
+        d.wf[i] = v;
+        if (d.wd) d.wd[((size_t)(8 - t) * d.cpad + ci) * d.cout + co] = v;
+    }
+}
 template <typename T>
 __global__ void k_unpad_channels(const unsigned short* __restrict__ src, T* __restrict__ dst, int C, int Cpad, size_t npix) {
     const size_t n = npix * C;
@@ -538,6 +557,12 @@ int phx_pack_conv3x3_bf16_pad(const float* w_hwio, void* wpk_fwd, void* wpk_dgra
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }
+int phx_pack_conv3x3_bf16_multi(const void* descs_dev, int n, void* stream) {
+    if (n <= 0) return PHX_OK;
+    hipLaunchKernelGGL(k_pack_conv3x3_multi, dim3(32, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs_dev);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
 int phx_pad_channels_bf16(const void* x, int dt, int C, void* out, int Cpad, size_t npix, void* stream) {
     PHX_DT_SWITCH(dt, T, {
         hipLaunchKernelGGL((k_pad_channels<T>), dim3(phx_grid_for(npix * Cpad, 256, 8192)), dim3(256), 0,
@@ -609,7 +634,10 @@ static int wgrad_plan(int B, int H, int W, int Cin, int Cout, MTile* g, int* tci
     *tco = Cout % 64 == 0 ? 64 : 32;
     *wk = 4 / ((*tci / 32) * (*tco / 32));
     const int cblocks = (Cin / *tci) * (Cout / *tco);
-    int target_blocks = (*tci == 32 && *tco == 32) ? 256 : 512;      // measured on MI355X (tools/bench_wgrad.py)
+    // measured on MI355X (tools/bench_wgrad.py): 512 blocks for big maps; fewer when there are few pixel tiles, because every
+    // block writes (and k_wgrad_reduce re-reads) a full 9*TCI*TCO partial filter
+    int target_blocks = (*tci == 32 && *tco == 32) ? 256 : 512;
+    if (ntiles <= 256 && target_blocks > 256) target_blocks = 256;
     if (const char* e = getenv("PHX_WGRAD_BLOCKS")) target_blocks = atoi(e);      // tuning hook
     int split = (target_blocks + cblocks - 1) / cblocks;
     if (split > ntiles) split = ntiles;

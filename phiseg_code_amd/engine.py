@@ -174,6 +174,7 @@ class Plan:
         self.feeds = {}
         self._keep = []
         self._wpk = {}
+        self._pack_jobs = []          # (w, wpk_fwd, wpk_dgrad, Cin, Cin_pad, Cout): ONE multi-filter pack launch per run
         self._zarena = torch.zeros(8 << 20, dtype=torch.float32, device=_device())     # 32 MB of per-step accumulators
         self._zused = 0
         self.fetches = list(fetches)
@@ -278,6 +279,7 @@ class Plan:
         with_bw = self.loss is not None
         self._lane = 0
         self._emit(self.L.memset, self._zarena.data_ptr(), 0, 4, self.stream)       # size patched below
+        self._emit(self.L.memset, self._zarena.data_ptr(), 0, 4, self.stream)       # slot 1: multi-filter pack, patched below
         if with_bw:
             self._emit(self.L.memset, self.store.grads.data_ptr(), 0, self.store.grads.numel() * 4, self.stream)
         nl = len(self._lanes)
@@ -317,6 +319,14 @@ class Plan:
                 self._wait(evl)
         self._lane = 0
         self.launches[0] = (self.L.memset, (self._zarena.data_ptr(), 0, max(self._zused, 1) * 4, self.stream))
+        if self._pack_jobs:           # slot 1 was reserved before the fork: refresh every packed bf16 filter in one launch
+            rec = np.zeros(len(self._pack_jobs), dtype=[("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("cin", "<i4"),
+                                                         ("cpad", "<i4"), ("cout", "<i4"), ("pad", "<i4")])
+            for i, j in enumerate(self._pack_jobs):
+                rec[i] = (j[0], j[1], j[2], j[3], j[4], j[5], 0)
+            self._pack_desc = torch.from_numpy(rec.view(np.uint8).copy()).to(_device())
+            self._keep.append(self._pack_desc)
+            self.launches[1] = (self.L.pack_conv3x3_bf16_multi, (self._pack_desc.data_ptr(), len(self._pack_jobs), self.stream))
         if self.optimize:
             if self.split_optimizer:
                 self._cur = self.opt_launches
@@ -380,7 +390,7 @@ class Plan:
             kh, kw, cin, cout = W.shape
             wf, wd = self._alloc((9 * cin * cout,), BF16), self._alloc((9 * cin * cout,), BF16)
             self._wpk[W.name] = (wf, wd)
-            self._emit(self.L.pack_conv3x3_bf16, self.store.ptr(W), wf.ptr, wd.ptr, cin, cout, self.stream)
+            self._pack_jobs.append((self.store.ptr(W), wf.ptr, wd.ptr, cin, cin, cout))
         return self._wpk[W.name]
 
     def _fw_conv_unit(self, op, bw):
@@ -411,7 +421,7 @@ class Plan:
             need_dgrad = bw and self.req.get(op.inputs[0], False)
             wdp = self._alloc((9 * cin_eff * cout,), BF16) if need_dgrad else None
             st["wd_pad"] = wdp
-            self._emit(Lb.pack_conv3x3_bf16_pad, wptr, wf.ptr, wdp.ptr if wdp else None, cin, cin_eff, cout, S)
+            self._pack_jobs.append((wptr, wf.ptr, wdp.ptr if wdp else 0, cin, cin_eff, cout))
         elif mfma:
             wf, _ = self._packed(W)
 
