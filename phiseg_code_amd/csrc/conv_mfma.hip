@@ -70,15 +70,29 @@ struct PackDesc {
     int cin, cpad, cout, _pad;
 };
 __global__ void k_pack_conv3x3_multi(const PackDesc* __restrict__ descs) {
+    // 32 (ci) x 32 (co) tiles transposed through LDS so that the fp32 read, the [t][co][ci] write and the flipped
+    // [8-t][ci][co] write are all coalesced (Cin_pad and Cout are multiples of 32 on the MFMA path).
     const PackDesc d = descs[blockIdx.y];
-    const size_t n = (size_t)9 * d.cout * d.cpad;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int ci = (int)(i % d.cpad);
-        const int co = (int)((i / d.cpad) % d.cout);
-        const int t = (int)(i / ((size_t)d.cpad * d.cout));
-        const unsigned short v = ci < d.cin ? f2bf(d.w[((size_t)t * d.cin + ci) * d.cout + co]) : (unsigned short)0;
-        d.wf[i] = v;
-        if (d.wd) d.wd[((size_t)(8 - t) * d.cpad + ci) * d.cout + co] = v;
+    __shared__ float tile[32][33];
+    const int nci = d.cpad / 32, nco = d.cout / 32;
+    const int ntile = 9 * nci * nco;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    for (int tl = blockIdx.x; tl < ntile; tl += gridDim.x) {
+        const int cot = tl % nco, cit = (tl / nco) % nci, t = tl / (nco * nci);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = cit * 32 + ty * 4 + r, co = cot * 32 + tx;
+            const float v = ci < d.cin ? d.w[((size_t)t * d.cin + ci) * d.cout + co] : 0.f;
+            tile[ty * 4 + r][tx] = v;
+            if (d.wd) d.wd[((size_t)(8 - t) * d.cpad + ci) * d.cout + co] = f2bf(v);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = cot * 32 + ty * 4 + r, ci = cit * 32 + tx;
+            d.wf[((size_t)t * d.cout + co) * d.cpad + ci] = f2bf(tile[tx][ty * 4 + r]);
+        }
     }
 }
 template <typename T>
@@ -559,7 +573,7 @@ int phx_pack_conv3x3_bf16_pad(const float* w_hwio, void* wpk_fwd, void* wpk_dgra
 }
 int phx_pack_conv3x3_bf16_multi(const void* descs_dev, int n, void* stream) {
     if (n <= 0) return PHX_OK;
-    hipLaunchKernelGGL(k_pack_conv3x3_multi, dim3(32, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs_dev);
+    hipLaunchKernelGGL(k_pack_conv3x3_multi, dim3(48, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs_dev);
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }
@@ -661,7 +675,7 @@ int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, v
     const int tw = 1 << g.tws, th = 1 << g.ths;
     const int npatch = g.tb * (th + 2) * (tw + 2);
     float* ws = nullptr;
-    if (workspace) {
+    if (workspace && tpb < 16) {       // blocks that accumulate >= 16 tiles amortise the atomic flush (<5 %): no partial round trip
         PHX_REQUIRE(workspace_bytes >= phx_conv3x3_wgrad_ws_bytes(B, H, W, Cin, Cout), PHX_E_INVAL, "conv3x3_wgrad_mfma: workspace too small");
         ws = (float*)workspace;
     }

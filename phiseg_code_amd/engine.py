@@ -156,7 +156,7 @@ class Plan:
         self._lanes = []
         if n_lanes is None:
             import os
-            n_lanes = int(os.environ.get("PHX_LANES", "3"))
+            n_lanes = int(os.environ.get("PHX_LANES", "6"))
         if stream is None:
             for _ in range(max(1, int(n_lanes))):
                 st = ctypes.c_void_p()
@@ -167,6 +167,7 @@ class Plan:
             self._lanes, self._own_stream = [stream], False
         self._lane = 0
         self._events = []
+        self._last_rec, self._lane_seq = {}, {}
         self.launches, self.opt_launches = [], []
         self._cur = self.launches
         self.val, self.grad, self.saved = {}, {}, {}
@@ -194,28 +195,39 @@ class Plan:
         return ev
 
     def _record(self, lane):
-        """Record a fresh event at the current tail of `lane`; returns (event, lane)."""
+        """Record an event at the current tail of `lane`; returns (event, lane).  Nothing enqueued on the lane since its
+        previous record -> that event is reused (two back-to-back records of distinct events on one stream, one of them
+        waited on by another stream, make hipStreamEndCapture segfault on ROCm 7.2)."""
+        last = self._last_rec.get(lane)
+        if last is not None and last[1] == self._lane_seq.get(lane, 0) and last[2] is self._cur:
+            return (last[0], lane)
         ev = self._new_event()
         self._cur.append((self.L.event_record, (ev, self._lanes[lane])))
+        self._last_rec[lane] = (ev, self._lane_seq.get(lane, 0), self._cur)
         return (ev, lane)
 
     def _wait(self, evl):
         """Make the current lane wait for an (event, lane) pair recorded elsewhere."""
         if evl is not None and evl[1] != self._lane:
             self._cur.append((self.L.stream_wait_event, (self.stream, evl[0])))
+            self._lane_seq[self._lane] = self._lane_seq.get(self._lane, 0) + 1
 
     def _lane_of(self, op):
+        """Lane plan.  Lane 0 (the capture's origin stream): posterior, the likelihood's top-down fusion path, losses.
+        Lane 1: prior.  Lanes 2..: the independent per-level likelihood chains (z{i}_post_*, preups_{i}).  Every
+        cross-lane dependency then has lane 0 on one side: on ROCm 7.2 an event wait between two NON-origin streams of a
+        multi-stream capture makes hipStreamEndCapture segfault (found by bisecting the launch list)."""
         n = len(self._lanes)
         if n == 1:
             return 0
         name = op.name
         if name.startswith("prior/"):
-            return 1 % n
-        if name.startswith("likelihood/"):
-            # NOTE: putting the five independent per-level chains (z{i}_post_*, preups_{i}) on further lanes makes
-            # hipStreamEndCapture segfault on ROCm 7.2 (forward-only capture of the same topology works; eager
-            # multi-stream execution is correct) -- until that is understood the likelihood stays on one lane.
-            return 2 % n
+            return 1
+        if n >= 3 and name.startswith("likelihood/"):
+            import re
+            m = re.match(r"likelihood/(?:z(\d+)_post_|preups_(\d+)/)", name)
+            if m:
+                return 2 + int(m.group(1) or m.group(2)) % (n - 2)
         return 0
 
     # ---------------------------------------------------------------------------------------------
@@ -223,6 +235,7 @@ class Plan:
         if tag is not None:
             self.tags[(id(self._cur), len(self._cur))] = (tag, float(flops))
         self._cur.append((fn, args))
+        self._lane_seq[self._lane] = self._lane_seq.get(self._lane, 0) + 1
 
     def _alloc(self, shape, dt, zero=False):
         b = Buf(shape, dt, zero=zero)
