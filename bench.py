@@ -160,10 +160,27 @@ def main():
         fl = sum(v[0] for k, v in fam.items() if k != "conv3x3_mfma_wgrad")
         ms = sum(v[1] for k, v in fam.items() if k != "conv3x3_mfma_wgrad")
         nl = sum(v[2] for k, v in fam.items() if k != "conv3x3_mfma_wgrad")
+        # HBM traffic of the same kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # corrected as MI355X_MICROARCH.md prescribes; see profiles/r01_pmc_hbm_traffic_final.txt): bytes per launch
+        traffic = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_final.json")))
+            ks = [v for k, v in pj.items() if k.startswith("void k_conv3x3_mfma<")]
+            calls = sum(v["calls_per_step"] for v in ks)
+            traffic = 1e6 * sum(v["fetch_x2_MB_per_step"] + v["write_MB_per_step"] for v in ks) / calls
+        except Exception:
+            pass
+        alg_bytes = 0.0
+        for tag, flp, ms_, shp in rows:
+            if tag != "conv3x3_mfma_wgrad":
+                _, Bq, Hq, Wq, Kq, Nq = shp[:6]
+                alg_bytes += 2.0 * Bq * Hq * Wq * (Kq + Nq) + 18.0 * Kq * Nq
         out["roofline"] = {
             "bound": "mfma", "kernel": "k_conv3x3_mfma<BN> (forward + data-gradient launches of one step)",
             "achieved": fl / ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS,
-            "traffic": None, "launches": nl, "avg_launch_ms": ms / max(nl, 1),
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, separate passes; profiles/r01_pmc_hbm_traffic_final.txt)",
+            "algorithmic_bytes_per_launch_avg": alg_bytes / max(nl, 1),
+            "launches": nl, "avg_launch_ms": ms / max(nl, 1),
             "algorithmic_gflop_per_launch_avg": fl / max(nl, 1) / 1e9,
             "families": {k: {"tflops": v[0] / v[1] / 1e9, "ms_per_step": v[1], "launches": v[2]} for k, v in fam.items()},
             "conv_ms_per_step": sum(v[1] for v in fam.values()),
