@@ -122,6 +122,13 @@ __global__ void k_unpad_rows_acc(const float* __restrict__ dwp, float* __restric
 }
 
 // ---- forward / dgrad ----------------------------------------------------------------------------------
+__device__ unsigned long long* g_phx_trace = nullptr;      // debug: phase timestamps of block (0,0,0), thread 0
+#define PHX_TRACE(slot)                                                                                  \
+    do {                                                                                                 \
+        if (g_phx_trace && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)    \
+            g_phx_trace[slot] = __builtin_readcyclecounter();                                            \
+    } while (0)
+
 // NA = compile-time bound on the 16-byte input-patch pieces a thread stages per 32-channel chunk
 // (ceil(npatch * 4 / 256): 6 for 16x16 tiles, 7 for 8x8x4, 9 for 4x4x16, 16 for 2x2x64).
 template <int BN, int NA>
@@ -185,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(const unsigned short* _
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    PHX_TRACE(0);
     uint4 ra[NA], rb[NB];
     auto prefetch = [&](int c0) {
 #pragma unroll
@@ -199,9 +207,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(const unsigned short* _
         }
     };
     prefetch(0);
+    PHX_TRACE(1);
 
     for (int c0 = 0; c0 < K; c0 += KC) {
         __syncthreads();                         // every wave is done reading the previous chunk from LDS
+        if (c0 == KC) PHX_TRACE(2);
 #pragma unroll
         for (int it = 0; it < NA; ++it) {
             const int i = threadIdx.x + it * 256;
@@ -213,7 +223,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(const unsigned short* _
             if (gb[it] >= 0) *reinterpret_cast<uint4*>(sB + (i >> 2) * ROWB + (i & 3) * 16) = rb[it];
         }
         __syncthreads();
+        if (c0 == KC) PHX_TRACE(3);
         if (c0 + KC < K) prefetch(c0 + KC);      // global loads of the next chunk fly under this chunk's MFMAs
+        if (c0 == KC) PHX_TRACE(4);
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -241,33 +253,52 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(const unsigned short* _
     // epilogue: C layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel).  The tile is transposed
     // through LDS ([pixel][BN] bf16, 16-byte padded rows) so that global stores are 16 bytes per lane, 128 contiguous
     // bytes per pixel, instead of 2-byte scattered stores.
+    PHX_TRACE(5);
     constexpr int OROW = BN * 2 + 16;
     float s1[NJ], s2[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) s1[j] = s2[j] = 0.f;
     __syncthreads();                             // all MFMA operand reads of the last chunk are done
+    PHX_TRACE(7);
+    if (bias != nullptr || act != PHX_ACT_ID) {  // rare (no-norm layers): kept out of the store loop so that the
+#pragma unroll                                   // softplus transcendental code is never if-converted into it
+        for (int j = 0; j < NJ; ++j) {
+            const float bv = bias ? bias[n0 + j * 32 + l31] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r] + bv, act);
+        }
+    }
+    // Lane pairs (channels n, n+1) trade one of two rows so that each lane writes ONE 32-bit word {ch n, ch n+1} per row
+    // pair: half the LDS stores, no sub-dword writes.  Even lane keeps row 2rp, odd lane row 2rp+1.
+    const int odd = lane & 1;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-            const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
-            const bool valid = (tx0 + lx) < W && (ty0 + ly) < H && (b0 + lb) < B;
+        for (int rp = 0; rp < 8; ++rp) {
+            const int r0 = 2 * rp, r1 = 2 * rp + 1;
+            const int m0 = wave * 64 + i * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * khalf;     // row of r0; r1 is the next pixel
+            const int lx0 = m0 & (tw - 1), ly0 = (m0 >> g.tws) & (th - 1), lb0 = m0 >> (g.tws + g.ths);
+            const int m1 = m0 + 1;
+            const int lx1 = m1 & (tw - 1), ly1 = (m1 >> g.tws) & (th - 1), lb1 = m1 >> (g.tws + g.ths);
+            const float f0 = ((tx0 + lx0) < W && (ty0 + ly0) < H && (b0 + lb0) < B) ? 1.f : 0.f;    // statistics mask
+            const float f1 = ((tx0 + lx1) < W && (ty0 + ly1) < H && (b0 + lb1) < B) ? 1.f : 0.f;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                float v = acc[i][j][r];
-                if (bias) v += bias[n0 + j * 32 + l31];
-                v = act_fwd(v, act);
-                const unsigned short h = f2bf(v);
-                *reinterpret_cast<unsigned short*>(smem + m * OROW + (j * 32 + l31) * 2) = h;
-                if (valid) {
-                    const float rv = bf2f(h);
-                    s1[j] += rv;
-                    s2[j] += rv * rv;
-                }
+                const unsigned w2 = f2bf_pk(acc[i][j][r0], acc[i][j][r1]);       // {lo = row r0, hi = row r1}
+                const float ra = __uint_as_float(w2 << 16) * f0, rb = __uint_as_float(w2 & 0xffff0000u) * f1;
+                s1[j] += ra + rb;
+                s2[j] += ra * ra + rb * rb;
+                const unsigned recv = (unsigned)__shfl_xor((int)(odd ? (w2 & 0xffffu) : (w2 >> 16)), 1, 64);
+                const unsigned word = odd ? (recv | (w2 & 0xffff0000u)) : ((w2 & 0xffffu) | (recv << 16));
+                const int mrow = odd ? m1 : m0;
+                *reinterpret_cast<unsigned*>(smem + mrow * OROW + (j * 32 + (l31 & ~1)) * 2) = word;
             }
         }
+    PHX_TRACE(8);
     __syncthreads();
+    PHX_TRACE(9);
     {
         constexpr int PPP = BN / 8;              // 16-byte pieces per pixel
 #pragma unroll
@@ -282,6 +313,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(const unsigned short* _
             }
         }
     }
+    PHX_TRACE(6);
     if (stats_partial) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);      // [4 waves][2][BN]
@@ -315,13 +347,6 @@ __device__ __forceinline__ int wswz(int pix, int byte_in_row) {
     if (RB == 128) return pix * 128 + (byte_in_row ^ (((pix >> 1) & 1) << 6));
     return pix * RB + byte_in_row;
 }
-
-__device__ unsigned long long* g_phx_trace = nullptr;      // debug: phase timestamps of block (0,0,0), thread 0
-#define PHX_TRACE(slot)                                                                                  \
-    do {                                                                                                 \
-        if (g_phx_trace && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)    \
-            g_phx_trace[slot] = __builtin_readcyclecounter();                                            \
-    } while (0)
 
 // BIGP selects the bound on the per-thread staging pieces: false -> 16x16 / 8x8x4 tiles, true -> 4x4x16 / 2x2x64 tiles
 template <int TCI, int TCO, bool BIGP, bool FAST16>

@@ -30,7 +30,7 @@ template <> struct HVec<bf16_t, 8> {
     static __device__ __forceinline__ void store(bf16_t* p, size_t i, const float o[8]) {
         unsigned w[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = (unsigned)f2bf(o[2 * k]) | ((unsigned)f2bf(o[2 * k + 1]) << 16);
+        for (int k = 0; k < 4; ++k) w[k] = f2bf_pk(o[2 * k], o[2 * k + 1]);
         *reinterpret_cast<uint4*>(p + i) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };

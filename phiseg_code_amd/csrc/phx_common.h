@@ -24,6 +24,14 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
     return (unsigned short)(u >> 16);
 }
 
+// two floats -> packed bf16 pair {lo = a, hi = b}: ONE v_cvt_pk_bf16_f32 on gfx950 (hardware round-to-nearest-even)
+typedef __attribute__((ext_vector_type(2))) float phx_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 phx_bf16x2;
+__device__ __forceinline__ unsigned f2bf_pk(float a, float b) {
+    const phx_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, phx_bf16x2));
+}
+
 template <typename T> __device__ __forceinline__ float ldf(const T* p, size_t i);
 template <> __device__ __forceinline__ float ldf<float>(const float* p, size_t i) { return p[i]; }
 template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p, size_t i) { return bf2f(p[i].u); }
