@@ -188,7 +188,9 @@ def main():
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if ctx.rank == 0:
+        out["config"]["hbm_peak_allocated_gb"] = torch.cuda.max_memory_allocated() / 2 ** 30
         print(json.dumps(out))
+    ctx.barrier()              # the other ranks wait for rank 0's extra measurements before tearing RCCL down
     ctx.shutdown()
 
 

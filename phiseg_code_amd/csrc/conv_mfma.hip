@@ -131,7 +131,7 @@ __device__ unsigned long long* g_phx_trace = nullptr;      // debug: phase times
 
 // NA = compile-time bound on the 16-byte input-patch pieces a thread stages per 32-channel chunk
 // (ceil(npatch * 4 / 256): 6 for 16x16 tiles, 7 for 8x8x4, 9 for 4x4x16, 16 for 2x2x64).
-template <int BN, int NA>
+template <int BN, int NA, bool FAST16>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(const unsigned short* __restrict__ x,
                                                          const unsigned short* __restrict__ wpk,
                                                          unsigned short* __restrict__ y, const float* __restrict__ bias,
@@ -171,7 +171,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(const unsigned short* _
         const int q = i & 3, pp = i >> 2;
         ga[it] = -2;                                          // -2: beyond the patch (nothing to write)
         if (pp < npatch) {
-            const int px = pp % pw, py = (pp / pw) % ph, pb = pp / (pw * ph);
+            // 16x16 tiles: the patch is 18 x 18 -> compile-time divisors (runtime division costs ~40 instructions)
+            const int px = FAST16 ? pp % 18 : pp % pw;
+            const int py = FAST16 ? pp / 18 : (pp / pw) % ph;
+            const int pb = FAST16 ? 0 : pp / (pw * ph);
             const int gx = tx0 + px - 1, gy = ty0 + py - 1, gbi = b0 + pb;
             ga[it] = (gx >= 0 && gx < W && gy >= 0 && gy < H && gbi < B) ? (((gbi * H + gy) * W + gx) * K + q * 8) : -1;
         }
@@ -400,7 +403,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* 
         const int i = threadIdx.x + it * 256;
         const int pp = i / QX;
         planx[it] = -1;
-        if (pp < npatch) planx[it] = (pp % pw) | (((pp / pw) % ph) << 8) | ((pp / (pw * ph)) << 16);
+        if (pp < npatch)
+            planx[it] = FAST16 ? ((pp % 18) | ((pp / 18) << 8)) : ((pp % pw) | (((pp / pw) % ph) << 8) | ((pp / (pw * ph)) << 16));
     }
 #pragma unroll
     for (int it = 0; it < QD; ++it) {
@@ -647,20 +651,22 @@ int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* 
     PHX_REQUIRE((double)B * H * W * (K > N ? K : N) < 2147483648.0, PHX_E_SHAPE, "conv3x3_mfma: tensor exceeds 2^31 elements");
     static bool attr_set = false;
     if (!attr_set) {
-        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_mfma<64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_mfma<32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_mfma<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_mfma<32, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define CM_ATTR(BNv, NAv, Fv)                                                                                        \
+    PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_mfma<BNv, NAv, Fv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+        CM_ATTR(64, 8, false); CM_ATTR(32, 8, false); CM_ATTR(64, 16, false); CM_ATTR(32, 16, false);
+        CM_ATTR(64, 8, true); CM_ATTR(32, 8, true);
+#undef CM_ATTR
         attr_set = true;
     }
     const int na = (npatch * 4 + 255) / 256;
     PHX_REQUIRE(na <= 16, PHX_E_SHAPE, "conv3x3_mfma: unexpected tile geometry");
-#define CM_LAUNCH(BNv, NAv)                                                                                          \
-    hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv>), dim3(ntiles, N / BNv), dim3(256),                                 \
+#define CM_LAUNCH(BNv, NAv, Fv)                                                                                      \
+    hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv>), dim3(ntiles, N / BNv), dim3(256),                             \
                        (size_t)npatch * ROWB + 9 * BNv * ROWB, (hipStream_t)stream, (const unsigned short*)x,        \
                        (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, g)
-    if (N % 64 == 0) { if (na <= 8) CM_LAUNCH(64, 8); else CM_LAUNCH(64, 16); }
-    else { if (na <= 8) CM_LAUNCH(32, 8); else CM_LAUNCH(32, 16); }
+    const bool fast16 = g.tws == 4 && g.ths == 4 && g.tb == 1;
+    if (N % 64 == 0) { if (fast16) CM_LAUNCH(64, 8, true); else if (na <= 8) CM_LAUNCH(64, 8, false); else CM_LAUNCH(64, 16, false); }
+    else { if (fast16) CM_LAUNCH(32, 8, true); else if (na <= 8) CM_LAUNCH(32, 8, false); else CM_LAUNCH(32, 16, false); }
 #undef CM_LAUNCH
     PHX_CHECK_LAUNCH();
     return PHX_OK;
