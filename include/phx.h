@@ -82,9 +82,12 @@ int phx_pack_conv3x3_bf16_multi(const void* descs_dev, int n, void* stream);
 int phx_pad_channels_bf16(const void* x, int dt, int C, void* out, int Cpad, size_t npix, void* stream);
 int phx_unpad_channels_bf16(const void* src, void* dst, int dst_dt, int C, int Cpad, size_t npix, void* stream);
 int phx_unpad_filter_grad_accumulate(const float* dw_pad, float* dw_hwio, int Cin, int Cin_pad, int Cout, void* stream);
-int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W);
+/* number of pixel tiles (= rows of stats_partial) phx_conv3x3_mfma_bf16 uses for this shape */
+int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W, int K, int N);
 /* debug: device buffer of >= 16 uint64 that receives shader-clock phase timestamps of block 0 (NULL disables) */
-int phx_debug_set_trace(void* dev_buf);     /* number of pixel tiles (= rows of stats_partial) */
+int phx_debug_set_trace(void* dev_buf);
+/* debug: device buffer of 4 uint64 per block {start, end, HW_ID | XCC_ID << 32, realtime} written by the MFMA conv kernels */
+int phx_debug_set_blocklog(void* dev_buf);
 /* dw_hwio[kh][kw][ci][co] += sum x * dy, Cin % 32 == 0, Cout % 32 == 0.  With a workspace (>= phx_conv3x3_wgrad_ws_bytes)
  * the per-block partial filters are stored with plain writes and summed by a second kernel; workspace == NULL falls back
  * to fp32 atomics straight into dw_hwio (a CU issues those at ~1 lane/clock: 46 us per block on MI355X). */

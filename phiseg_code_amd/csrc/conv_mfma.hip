@@ -13,6 +13,9 @@
 
 #include "phx_common.h"
 
+#ifndef PHX_ABLATE      // dev only (tools/build_ablate.sh): 1 no global loads, 2 no LDS staging stores, 4 no MFMAs, 8 no output stores
+#define PHX_ABLATE 0
+#endif
 #define KC 32            // input channels per LDS stage (two MFMA k-steps)
 #define ROWB 80          // bytes per pixel / filter row in LDS: 32 bf16 + 16 B pad -> conflict-free ds_read_b128
 
@@ -29,6 +32,24 @@ static MTile make_mtile(int B, int H, int W) {
     g.tiles_x = (W + tw - 1) / tw;
     g.tiles_y = (H + th - 1) / th;
     g.tiles_b = (B + g.tb - 1) / g.tb;
+    return g;
+}
+
+// forward / data-gradient tiles.  16 x 32 tiles (512 pixels, 8-wave blocks, one per CU) halve the filter-slab bytes staged
+// per FLOP but give up the overlap of two independent blocks per CU: measured, they win for 128-wide output-channel blocks
+// and for the K >= 128 -> 32 layers, when the map has at least two such tiles per CU; everything else uses 256-pixel tiles.
+static bool fwd_big_tiles(int B, int H, int W, int K, int N) {
+    const char* e = getenv("PHX_FWD_BIG");                     // 0: never, 2: whenever the map allows (tests), default: policy
+    const int en = e ? atoi(e) : 1;
+    if (!en || H % 32 != 0 || W % 16 != 0) return false;
+    if (en == 2) return true;                                  // dev: force
+    return (N % 128 == 0 || (N == 32 && K >= 128)) && (long)B * (H / 32) * (W / 16) >= 512;
+}
+static MTile make_mtile_fwd(int B, int H, int W, int K, int N) {
+    if (!fwd_big_tiles(B, H, W, K, N)) return make_mtile(B, H, W);
+    MTile g;
+    g.tws = 4; g.ths = 5; g.tb = 1;
+    g.tiles_x = W / 16; g.tiles_y = H / 32; g.tiles_b = B;
     return g;
 }
 
@@ -123,6 +144,19 @@ __global__ void k_unpad_rows_acc(const float* __restrict__ dwp, float* __restric
 
 // ---- forward / dgrad ----------------------------------------------------------------------------------
 __device__ unsigned long long* g_phx_trace = nullptr;      // debug: phase timestamps of block (0,0,0), thread 0
+__device__ unsigned long long* g_phx_blocklog = nullptr;   // debug: per-block {start, end, HW_ID | XCC_ID << 32, realtime}
+#define PHX_BLOCKLOG_BEGIN() const unsigned long long bl_t0 = g_phx_blocklog ? __builtin_readcyclecounter() : 0ull
+#define PHX_BLOCKLOG_END()                                                                               \
+    do {                                                                                                 \
+        if (g_phx_blocklog && threadIdx.x == 0) {                                                        \
+            const size_t bi = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;    \
+            g_phx_blocklog[bi * 4 + 0] = bl_t0;                                                          \
+            g_phx_blocklog[bi * 4 + 1] = __builtin_readcyclecounter();                                   \
+            g_phx_blocklog[bi * 4 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |          \
+                                         ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);   \
+            g_phx_blocklog[bi * 4 + 3] = wall_clock64();                                                 \
+        }                                                                                                \
+    } while (0)
 #define PHX_TRACE(slot)                                                                                  \
     do {                                                                                                 \
         if (g_phx_trace && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)    \
@@ -131,17 +165,21 @@ __device__ unsigned long long* g_phx_trace = nullptr;      // debug: phase times
 
 // NA = compile-time bound on the 16-byte input-patch pieces a thread stages per 32-channel chunk
 // (ceil(npatch * 4 / 256): 6 for 16x16 tiles, 7 for 8x8x4, 9 for 4x4x16, 16 for 2x2x64).
-template <int BN, int NA, bool FAST16>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(const unsigned short* __restrict__ x,
+// NW = waves per block (4: 256-pixel tiles, two blocks per CU; 8: 512-pixel 16 x 32 tiles, one block per CU -- the
+// filter slab, 64 % of the staged bytes of a 256 x 64 tile, is then shared by twice the pixels: the kernel is bound
+// by the L2 -> LDS path (~12 B/clk/CU), so bytes staged per FLOP set its speed).
+template <int BN, int NA, bool FAST16, bool BIASACT, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const unsigned short* __restrict__ x,
                                                          const unsigned short* __restrict__ wpk,
                                                          unsigned short* __restrict__ y, const float* __restrict__ bias,
                                                          int act, float* __restrict__ stats_partial, int B, int H, int W,
                                                          int K, int N, MTile g) {
     constexpr int NJ = BN / 32;
-    constexpr int NB = (9 * BN * 4 + 255) / 256;          // filter-slab pieces per thread
-    const int tw = 1 << g.tws, th = 1 << g.ths;
+    constexpr int NT = NW * 64;                            // threads; the tile has NT pixels
+    constexpr int NB = (9 * BN * 4 + NT - 1) / NT;        // filter-slab pieces per thread
+    const int tw = FAST16 ? 16 : 1 << g.tws, th = FAST16 ? NT / 16 : 1 << g.ths;
     const int pw = tw + 2, ph = th + 2;
-    const int npatch = g.tb * ph * pw;
+    const int npatch = FAST16 ? 18 * (NT / 16 + 2) : g.tb * ph * pw;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                    // [npatch][ROWB]
     unsigned char* sB = smem + npatch * ROWB;    // [9][BN][ROWB]
@@ -163,29 +201,38 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(const unsigned short* _
     }
     const int boff = l31 * ROWB + khalf * 16;
 
-    // staging plan, computed once: global element offsets (without the channel-chunk term) of this thread's pieces
-    int ga[NA], gb[NB];
+    // staging plan: BYTE offsets (without the channel-chunk term) of this thread's 16-byte pieces for raw buffer loads;
+    // 0xffffffff = outside the image / batch / slab -> the buffer range check returns zeros, so the prefetch is
+    // branch-free and can be interleaved with the MFMAs of the running chunk.
+    unsigned ga[NA];
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
-        const int i = threadIdx.x + it * 256;
+        const int i = threadIdx.x + it * NT;
         const int q = i & 3, pp = i >> 2;
-        ga[it] = -2;                                          // -2: beyond the patch (nothing to write)
+        ga[it] = 0xffffffffu;
         if (pp < npatch) {
-            // 16x16 tiles: the patch is 18 x 18 -> compile-time divisors (runtime division costs ~40 instructions)
+            // 16-wide tiles: the patch is 18 wide -> compile-time divisors (runtime division costs ~40 instructions)
             const int px = FAST16 ? pp % 18 : pp % pw;
             const int py = FAST16 ? pp / 18 : (pp / pw) % ph;
             const int pb = FAST16 ? 0 : pp / (pw * ph);
             const int gx = tx0 + px - 1, gy = ty0 + py - 1, gbi = b0 + pb;
-            ga[it] = (gx >= 0 && gx < W && gy >= 0 && gy < H && gbi < B) ? (((gbi * H + gy) * W + gx) * K + q * 8) : -1;
+            if (gx >= 0 && gx < W && gy >= 0 && gy < H && gbi < B) ga[it] = (unsigned)((((gbi * H + gy) * W + gx) * K + q * 8) * 2);
         }
     }
-#pragma unroll
-    for (int it = 0; it < NB; ++it) {
-        const int i = threadIdx.x + it * 256;
-        const int q = i & 3, row = i >> 2;
+    // filter-slab pieces: piece `it` of a thread lies it * 64 slab rows further on, i.e. a fixed byte stride -> one VGPR
+    // offset plus a scalar stride (gbl: the last piece, only partly populated when 9 * BN * 4 is not a multiple of NT)
+    unsigned gb0, gbl;
+    {
+        const int q = threadIdx.x & 3, row = threadIdx.x >> 2;
         const int tap = row / BN, n = row - tap * BN;
-        gb[it] = (i < 9 * BN * 4) ? ((tap * N + n0 + n) * K + q * 8) : -1;
+        gb0 = (unsigned)(((tap * N + n0 + n) * K + q * 8) * 2);
+        gbl = (threadIdx.x + (NB - 1) * NT < 9 * BN * 4) ? gb0 : 0xffffffffu;
     }
+    // a thread's consecutive slab pieces are NT / 4 slab rows = NT / 4 / BN taps apart (BN <= NT / 4)
+    static_assert(NT / 4 % BN == 0, "slab piece stride must be whole taps");
+    const int gbs = (NT / 4 / BN) * N * K * 2;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, (int)(9u * N * K * 2u), 0x00020000);
 
     f32x16 acc[2][NJ];
 #pragma unroll
@@ -195,148 +242,218 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_mfma(const unsigned short* _
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    PHX_BLOCKLOG_BEGIN();
     PHX_TRACE(0);
-    uint4 ra[NA], rb[NB];
-    auto prefetch = [&](int c0) {
-#pragma unroll
-        for (int it = 0; it < NA; ++it) {
-            ra[it] = make_uint4(0, 0, 0, 0);
-            if (ga[it] >= 0) ra[it] = *reinterpret_cast<const uint4*>(x + ga[it] + c0);
-        }
-#pragma unroll
-        for (int it = 0; it < NB; ++it) {
-            rb[it] = make_uint4(0, 0, 0, 0);
-            if (gb[it] >= 0) rb[it] = *reinterpret_cast<const uint4*>(wpk + gb[it] + c0);
-        }
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 ra[NA], rb[NB];
+    // piece `idx` (input-patch pieces first, then filter-slab pieces) of the chunk starting at channel c0
+    auto prefetch_piece = [&](auto idxc, int c0) {
+        constexpr int idx = decltype(idxc)::value;
+        if constexpr (PHX_ABLATE & 1) return;
+        if constexpr (idx < NA) ra[idx] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ga[idx], c0 * 2, 0);
+        else if constexpr (idx < NA + NB)
+            rb[idx - NA] = __builtin_amdgcn_raw_buffer_load_b128(rsw, idx - NA == NB - 1 ? gbl : gb0, c0 * 2 + (idx - NA) * gbs, 0);
     };
-    prefetch(0);
+    {
+        auto all = [&](auto self, auto idxc) {
+            constexpr int idx = decltype(idxc)::value;
+            if constexpr (idx < NA + NB) {
+                prefetch_piece(idxc, 0);
+                self(self, std::integral_constant<int, idx + 1>());
+            }
+        };
+        all(all, std::integral_constant<int, 0>());
+    }
     PHX_TRACE(1);
 
-    for (int c0 = 0; c0 < K; c0 += KC) {
-        __syncthreads();                         // every wave is done reading the previous chunk from LDS
-        if (c0 == KC) PHX_TRACE(2);
+    // one 32-channel chunk: registers -> LDS, then 18 (tap, k-step) groups of 2 x NJ MFMAs; with PF the global loads of the
+    // NEXT chunk are issued one or two per group, so the texture-address unit (64 B/clk: ~1 K cycles per chunk for the four
+    // waves) works underneath the matrix pipe instead of in a phase of its own.
+    constexpr int IPG = (NA + NB + 17) / 18;
+    auto chunk = [&](int cnext, auto pfc, bool tr) {   // cnext: first channel of the chunk to prefetch (plan ga/gb)
+        constexpr bool PF = decltype(pfc)::value;
+        __syncthreads();                         // every wave is done reading the previous chunk / epilogue tile from LDS
+        if (tr) PHX_TRACE(2);
 #pragma unroll
         for (int it = 0; it < NA; ++it) {
-            const int i = threadIdx.x + it * 256;
-            if (ga[it] != -2) *reinterpret_cast<uint4*>(sA + (i >> 2) * ROWB + (i & 3) * 16) = ra[it];
+            const int i = threadIdx.x + it * NT;
+            if (!(PHX_ABLATE & 2) && (i >> 2) < npatch) *reinterpret_cast<u32x4*>(sA + (i >> 2) * ROWB + (i & 3) * 16) = ra[it];
         }
 #pragma unroll
         for (int it = 0; it < NB; ++it) {
-            const int i = threadIdx.x + it * 256;
-            if (gb[it] >= 0) *reinterpret_cast<uint4*>(sB + (i >> 2) * ROWB + (i & 3) * 16) = rb[it];
+            const int i = threadIdx.x + it * NT;
+            if (!(PHX_ABLATE & 2) && i < 9 * BN * 4) *reinterpret_cast<u32x4*>(sB + (i >> 2) * ROWB + (i & 3) * 16) = rb[it];
         }
         __syncthreads();
-        if (c0 == KC) PHX_TRACE(3);
-        if (c0 + KC < K) prefetch(c0 + KC);      // global loads of the next chunk fly under this chunk's MFMAs
-        if (c0 == KC) PHX_TRACE(4);
+        if (tr) PHX_TRACE(3);
+        // software pipeline, pinned with sched_barrier: the operand reads of group gi+1 and this group's global loads are
+        // issued before the MFMAs of group gi (fragment registers double-buffered by group parity)
+        // (NJ = 4 keeps a single fragment set -- 128 accumulator registers leave no room for two; its 8 MFMAs per group
+        // cover the LDS latency of the next group's reads, which are issued right behind them)
+        constexpr int FB = NJ <= 2 ? 2 : 1;
+        bf16x8 fa[FB][2], fb[FB][NJ];
+        auto read_frags = [&](auto gc) {
+            constexpr int gi = decltype(gc)::value;
+            constexpr int tap = gi / 2, ks = gi % 2, kh = tap / 3, kw = tap % 3;
+            const int tapoff = (kh * pw + kw) * ROWB;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+            for (int i = 0; i < 2; ++i)
+                fa[gi % FB][i] = *reinterpret_cast<const bf16x8*>(sA + aoff[i] + tapoff + ks * 32);
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int tapoff = (kh * pw + kw) * ROWB;
-                const int tap = kh * 3 + kw;
+            for (int j = 0; j < NJ; ++j)
+                fb[gi % FB][j] = *reinterpret_cast<const bf16x8*>(sB + (tap * BN + j * 32) * ROWB + boff + ks * 32);
+        };
+        read_frags(std::integral_constant<int, 0>());
+        auto group = [&](auto self, auto gc) {
+            constexpr int gi = decltype(gc)::value;
+            if constexpr (gi < 18) {
+                if constexpr (FB == 2 && gi < 17) read_frags(std::integral_constant<int, gi + 1>());
+                if constexpr (PF) {
+                    auto pieces = [&](auto self2, auto pc) {
+                        constexpr int pi = decltype(pc)::value;
+                        if constexpr (pi < IPG) {
+                            prefetch_piece(std::integral_constant<int, gi * IPG + pi>(), cnext);
+                            self2(self2, std::integral_constant<int, pi + 1>());
+                        }
+                    };
+                    pieces(pieces, std::integral_constant<int, 0>());
+                }
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    bf16x8 a[2], b[NJ];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        a[i] = *reinterpret_cast<const bf16x8*>(sA + aoff[i] + tapoff + ks * 32);
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        b[j] = *reinterpret_cast<const bf16x8*>(sB + (tap * BN + j * 32) * ROWB + boff + ks * 32);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-                }
+                        if constexpr (PHX_ABLATE & 4) acc[i][j][(gi + i + j) & 15] += (float)fa[gi % FB][i][0] * (float)fb[gi % FB][j][0];
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[gi % FB][i], fb[gi % FB][j], acc[i][j], 0, 0, 0);
+                if constexpr (FB == 1 && gi < 17) read_frags(std::integral_constant<int, gi + 1>());
+                __builtin_amdgcn_sched_barrier(0);
+                self(self, std::integral_constant<int, gi + 1>());
             }
-    }
-
-    // epilogue: C layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel).  The tile is transposed
-    // through LDS ([pixel][BN] bf16, 16-byte padded rows) so that global stores are 16 bytes per lane, 128 contiguous
-    // bytes per pixel, instead of 2-byte scattered stores.
-    PHX_TRACE(5);
+        };
+        group(group, std::integral_constant<int, 0>());
+        if (tr) PHX_TRACE(4);
+    };
+    const int odd = lane & 1;
     constexpr int OROW = BN * 2 + 16;
-    float s1[NJ], s2[NJ];
+    {
+        const int cx0 = tx0, cy0 = ty0, cb0 = b0;
+        const bool tr0 = true;
+        for (int c0 = 0; c0 + KC < K; c0 += KC) chunk(c0 + KC, std::true_type(), c0 == KC);
+        chunk(0, std::false_type(), K == 2 * KC);
+
+        // epilogue: C layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel).  The tile is transposed
+        // through LDS ([pixel][BN] bf16, 16-byte padded rows) so that global stores are 16 bytes per lane, 128 contiguous
+        // bytes per pixel, instead of 2-byte scattered stores.
+        if (tr0) PHX_TRACE(5);
+        float s1[NJ], s2[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) s1[j] = s2[j] = 0.f;
-    __syncthreads();                             // all MFMA operand reads of the last chunk are done
-    PHX_TRACE(7);
-    if (bias != nullptr || act != PHX_ACT_ID) {  // rare (no-norm layers): kept out of the store loop so that the
-#pragma unroll                                   // softplus transcendental code is never if-converted into it
-        for (int j = 0; j < NJ; ++j) {
-            const float bv = bias ? bias[n0 + j * 32 + l31] : 0.f;
+        for (int j = 0; j < NJ; ++j) s1[j] = s2[j] = 0.f;
+        __syncthreads();                             // all MFMA operand reads of the last chunk are done
+        if (tr0) PHX_TRACE(7);
+        if constexpr (BIASACT) {                     // rare (no-norm layers): its own instantiation, so that the softplus
+#pragma unroll                                       // code costs the common kernels neither registers nor issue slots
+            for (int j = 0; j < NJ; ++j) {
+                const float bv = bias ? bias[n0 + j * 32 + l31] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r] + bv, act);
+            }
+        }
+        // Lane pairs (channels n, n+1) trade one of two rows so that each lane writes ONE 32-bit word {ch n, ch n+1} per
+        // row pair: half the LDS stores, no sub-dword writes.  Even lane keeps row 2rp, odd lane row 2rp+1.
+        // pack two accumulator rows, add them to the statistics, hand back this lane's LDS word
+        auto pack_pair = [&](int i, int j, int r0, float f0, float f1) -> unsigned {
+            const unsigned w2 = f2bf_pk(acc[i][j][r0], acc[i][j][r0 + 1]);           // {lo = row r0, hi = row r0 + 1}
+            const float ra_ = __uint_as_float(w2 << 16) * f0, rb_ = __uint_as_float(w2 & 0xffff0000u) * f1;
+            s1[j] += ra_ + rb_;
+            s2[j] += ra_ * ra_ + rb_ * rb_;
+            // neighbour lane's word through DPP quad_perm [1,0,3,2] (no LDS round trip)
+            const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)w2, 0xB1, 0xf, 0xf, true);
+            return odd ? ((nb >> 16) | (w2 & 0xffff0000u)) : ((w2 & 0xffffu) | (nb << 16));
+        };
+        constexpr int PPP = BN / 8;                  // 16-byte pieces per pixel
+        const bool full = (cx0 + tw) <= W && (cy0 + th) <= H && (cb0 + g.tb) <= B;
+        if (FAST16 && full) {
+            // interior 16x16 tile: every address is one per-thread base plus compile-time / scalar terms, no masks
+            unsigned char* lw = smem + (wave * 64 + 4 * khalf + odd) * OROW + (l31 & ~1) * 2;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r] + bv, act);
+                for (int rp = 0; rp < 8; ++rp)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        *reinterpret_cast<unsigned*>(lw + (i * 32 + ((2 * rp) & 3) + 8 * ((2 * rp) >> 2)) * OROW + j * 64) =
+                            pack_pair(i, j, 2 * rp, 1.f, 1.f);
+            if (tr0) PHX_TRACE(8);
+            __syncthreads();
+            if (tr0) PHX_TRACE(9);
+            const int mt = threadIdx.x / PPP, q = threadIdx.x % PPP;          // piece it: pixel mt + it * (NT / PPP)
+            const unsigned char* lr = smem + mt * OROW + q * 16;
+            unsigned short* yp = y + (((size_t)cb0 * H + cy0 + (mt >> 4)) * W + cx0 + (mt & 15)) * N + n0 + q * 8;
+            const size_t ystep = (size_t)(NT / PPP / 16) * W * N;
+#pragma unroll
+            for (int it = 0; it < PPP; ++it)
+                if (!(PHX_ABLATE & 8) || cx0 < 0)
+                    *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * (NT / PPP) * OROW);
+        } else {
+            // edge tiles and the small-map tile shapes: per-row masks and addresses
+            const int tid_o = threadIdx.x;
+            const int wave_o = tid_o >> 6, l31_o = tid_o & 31, khalf_o = (tid_o >> 5) & 1, odd_o = tid_o & 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {
+                    const int r0 = 2 * rp;
+                    const int m0 = wave_o * 64 + i * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * khalf_o;   // row of r0; r0 + 1 is the next pixel
+                    const int m1 = m0 + 1;
+                    const int lx0 = m0 & (tw - 1), ly0 = (m0 >> g.tws) & (th - 1), lb0 = m0 >> (g.tws + g.ths);
+                    const int lx1 = m1 & (tw - 1), ly1 = (m1 >> g.tws) & (th - 1), lb1 = m1 >> (g.tws + g.ths);
+                    const float f0 = ((cx0 + lx0) < W && (cy0 + ly0) < H && (cb0 + lb0) < B) ? 1.f : 0.f;   // statistics mask
+                    const float f1 = ((cx0 + lx1) < W && (cy0 + ly1) < H && (cb0 + lb1) < B) ? 1.f : 0.f;
+                    const int mrow = odd_o ? m1 : m0;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        *reinterpret_cast<unsigned*>(smem + mrow * OROW + (j * 32 + (l31_o & ~1)) * 2) = pack_pair(i, j, r0, f0, f1);
+                }
+            if (tr0) PHX_TRACE(8);
+            __syncthreads();
+            if (tr0) PHX_TRACE(9);
+#pragma unroll
+            for (int it = 0; it < PPP; ++it) {       // NT pixels * PPP pieces / NT threads
+                const int i = tid_o + it * NT;
+                const int m = i / PPP, q = i % PPP;
+                const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
+                const int ox = cx0 + lx, oy = cy0 + ly, ob = cb0 + lb;
+                if (ox < W && oy < H && ob < B) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(smem + m * OROW + q * 16);
+                    *reinterpret_cast<uint4*>(y + (((size_t)ob * H + oy) * W + ox) * N + n0 + q * 8) = v;
+                }
+            }
         }
-    }
-    // Lane pairs (channels n, n+1) trade one of two rows so that each lane writes ONE 32-bit word {ch n, ch n+1} per row
-    // pair: half the LDS stores, no sub-dword writes.  Even lane keeps row 2rp, odd lane row 2rp+1.
-    const int odd = lane & 1;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int rp = 0; rp < 8; ++rp) {
-            const int r0 = 2 * rp, r1 = 2 * rp + 1;
-            const int m0 = wave * 64 + i * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * khalf;     // row of r0; r1 is the next pixel
-            const int lx0 = m0 & (tw - 1), ly0 = (m0 >> g.tws) & (th - 1), lb0 = m0 >> (g.tws + g.ths);
-            const int m1 = m0 + 1;
-            const int lx1 = m1 & (tw - 1), ly1 = (m1 >> g.tws) & (th - 1), lb1 = m1 >> (g.tws + g.ths);
-            const float f0 = ((tx0 + lx0) < W && (ty0 + ly0) < H && (b0 + lb0) < B) ? 1.f : 0.f;    // statistics mask
-            const float f1 = ((tx0 + lx1) < W && (ty0 + ly1) < H && (b0 + lb1) < B) ? 1.f : 0.f;
+        if (tr0) PHX_TRACE(6);
+        if (stats_partial) {
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(smem);      // [NW waves][2][BN]
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const unsigned w2 = f2bf_pk(acc[i][j][r0], acc[i][j][r1]);       // {lo = row r0, hi = row r1}
-                const float ra = __uint_as_float(w2 << 16) * f0, rb = __uint_as_float(w2 & 0xffff0000u) * f1;
-                s1[j] += ra + rb;
-                s2[j] += ra * ra + rb * rb;
-                const unsigned recv = (unsigned)__shfl_xor((int)(odd ? (w2 & 0xffffu) : (w2 >> 16)), 1, 64);
-                const unsigned word = odd ? (recv | (w2 & 0xffff0000u)) : ((w2 & 0xffffu) | (recv << 16));
-                const int mrow = odd ? m1 : m0;
-                *reinterpret_cast<unsigned*>(smem + mrow * OROW + (j * 32 + (l31 & ~1)) * 2) = word;
+                const float a = s1[j] + __shfl_xor(s1[j], 32, 64);
+                const float bq = s2[j] + __shfl_xor(s2[j], 32, 64);
+                if (khalf == 0) {
+                    red[(wave * 2 + 0) * BN + j * 32 + l31] = a;
+                    red[(wave * 2 + 1) * BN + j * 32 + l31] = bq;
+                }
             }
-        }
-    PHX_TRACE(8);
-    __syncthreads();
-    PHX_TRACE(9);
-    {
-        constexpr int PPP = BN / 8;              // 16-byte pieces per pixel
+            __syncthreads();
+            if (threadIdx.x < 2 * BN) {
+                const int which = threadIdx.x / BN, n = threadIdx.x % BN;
+                float v = 0.f;
 #pragma unroll
-        for (int it = 0; it < PPP; ++it) {       // 256 pixels * PPP pieces / 256 threads
-            const int i = threadIdx.x + it * 256;
-            const int m = i / PPP, q = i % PPP;
-            const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
-            const int ox = tx0 + lx, oy = ty0 + ly, ob = b0 + lb;
-            if (ox < W && oy < H && ob < B) {
-                const uint4 v = *reinterpret_cast<const uint4*>(smem + m * OROW + q * 16);
-                *reinterpret_cast<uint4*>(y + (((size_t)ob * H + oy) * W + ox) * N + n0 + q * 8) = v;
+                for (int w = 0; w < NW; ++w) v += red[(w * 2 + which) * BN + n];
+                stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + n] = v;
             }
         }
     }
-    PHX_TRACE(6);
-    if (stats_partial) {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);      // [4 waves][2][BN]
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const float a = s1[j] + __shfl_xor(s1[j], 32, 64);
-            const float bq = s2[j] + __shfl_xor(s2[j], 32, 64);
-            if (khalf == 0) {
-                red[(wave * 2 + 0) * BN + j * 32 + l31] = a;
-                red[(wave * 2 + 1) * BN + j * 32 + l31] = bq;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 2 * BN) {
-            const int which = threadIdx.x / BN, n = threadIdx.x % BN;
-            const float v = red[(0 * 2 + which) * BN + n] + red[(1 * 2 + which) * BN + n] +
-                            red[(2 * 2 + which) * BN + n] + red[(3 * 2 + which) * BN + n];
-            stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + n] = v;
-        }
-    }
+    PHX_BLOCKLOG_END();
 }
 
 // ---- filter gradient --------------------------------------------------------------------------------------
@@ -437,6 +554,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* 
     };
     const int t_begin = blockIdx.x * tiles_per_block;
     const int t_end = min(ntiles, t_begin + tiles_per_block);
+    PHX_BLOCKLOG_BEGIN();
     PHX_TRACE(0);
     if (t_begin < t_end) prefetch(t_begin);
     PHX_TRACE(1);
@@ -556,6 +674,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* 
             }
     }
     PHX_TRACE(6);
+    PHX_BLOCKLOG_END();
 }
 
 // dw[k][ci][co] += sum over the nslice partial tiles written by k_conv3x3_wgrad.  Block = 64 filter entries x 4 slice
@@ -635,8 +754,14 @@ int phx_debug_set_trace(void* dev_buf) {
     return PHX_OK;
 }
 
-int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W) {
-    MTile g = make_mtile(B, H, W);
+int phx_debug_set_blocklog(void* dev_buf) {
+    unsigned long long* p = (unsigned long long*)dev_buf;
+    PHX_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phx_blocklog), &p, sizeof(p)));
+    return PHX_OK;
+}
+
+int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W, int K, int N) {
+    MTile g = make_mtile_fwd(B, H, W, K, N);
     return g.tiles_x * g.tiles_y * g.tiles_b;
 }
 
@@ -644,30 +769,49 @@ int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* 
                           int B, int H, int W, int K, int N, void* stream) {
     PHX_REQUIRE(K % KC == 0 && N % 32 == 0, PHX_E_SHAPE, "conv3x3_mfma: K % 32 == 0 and N % 32 == 0 required");
     PHX_REQUIRE((((uintptr_t)x | (uintptr_t)wpk | (uintptr_t)y) & 15) == 0, PHX_E_ALIGN, "conv3x3_mfma: 16-byte alignment");
-    MTile g = make_mtile(B, H, W);
+    MTile g = make_mtile_fwd(B, H, W, K, N);
+    const bool big = fwd_big_tiles(B, H, W, K, N);
     const int tw = 1 << g.tws, th = 1 << g.ths;
     const int npatch = g.tb * (th + 2) * (tw + 2);
     const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
     PHX_REQUIRE((double)B * H * W * (K > N ? K : N) < 2147483648.0, PHX_E_SHAPE, "conv3x3_mfma: tensor exceeds 2^31 elements");
     static bool attr_set = false;
+#define CM_ATTR1(BNv, NAv, Fv, Av, NWv)                                                                              \
+    PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_mfma<BNv, NAv, Fv, Av, NWv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+#define CM_ATTR(BNv, NAv, Fv, NWv) CM_ATTR1(BNv, NAv, Fv, false, NWv); CM_ATTR1(BNv, NAv, Fv, true, NWv)
     if (!attr_set) {
-#define CM_ATTR(BNv, NAv, Fv)                                                                                        \
-    PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_mfma<BNv, NAv, Fv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-        CM_ATTR(64, 8, false); CM_ATTR(32, 8, false); CM_ATTR(64, 16, false); CM_ATTR(32, 16, false);
-        CM_ATTR(64, 8, true); CM_ATTR(32, 8, true);
-#undef CM_ATTR
+        CM_ATTR(64, 8, false, 4); CM_ATTR(32, 8, false, 4); CM_ATTR(64, 16, false, 4); CM_ATTR(32, 16, false, 4);
+        CM_ATTR(64, 8, true, 4); CM_ATTR(32, 8, true, 4);
+        CM_ATTR(128, 5, true, 8); CM_ATTR(64, 5, true, 8); CM_ATTR(32, 5, true, 8);
         attr_set = true;
     }
+#undef CM_ATTR
+#undef CM_ATTR1
     const int na = (npatch * 4 + 255) / 256;
     PHX_REQUIRE(na <= 16, PHX_E_SHAPE, "conv3x3_mfma: unexpected tile geometry");
-#define CM_LAUNCH(BNv, NAv, Fv)                                                                                      \
-    hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv>), dim3(ntiles, N / BNv), dim3(256),                             \
-                       (size_t)npatch * ROWB + 9 * BNv * ROWB, (hipStream_t)stream, (const unsigned short*)x,        \
-                       (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, g)
+    const bool biasact = bias != nullptr || act != PHX_ACT_ID;
+    // (the OROW-pitched epilogue tile also has to fit: NT * (2 BN + 16) bytes)
+#define CM_LAUNCH1(BNv, NAv, Fv, Av, NWv)                                                                            \
+    do {                                                                                                             \
+        size_t sh = (size_t)npatch * ROWB + 9 * BNv * ROWB;                                                          \
+        const size_t she = (size_t)NWv * 64 * (BNv * 2 + 16);                                                        \
+        if (she > sh) sh = she;                                                                                      \
+        hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, Av, NWv>), dim3(ntiles, N / BNv), dim3(NWv * 64), sh,       \
+                           (hipStream_t)stream, (const unsigned short*)x, (const unsigned short*)wpk,                \
+                           (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, g);                          \
+    } while (0)
+#define CM_LAUNCH(BNv, NAv, Fv, NWv)                                                                                 \
+    do { if (biasact) CM_LAUNCH1(BNv, NAv, Fv, true, NWv); else CM_LAUNCH1(BNv, NAv, Fv, false, NWv); } while (0)
     const bool fast16 = g.tws == 4 && g.ths == 4 && g.tb == 1;
-    if (N % 64 == 0) { if (fast16) CM_LAUNCH(64, 8, true); else if (na <= 8) CM_LAUNCH(64, 8, false); else CM_LAUNCH(64, 16, false); }
-    else { if (fast16) CM_LAUNCH(32, 8, true); else if (na <= 8) CM_LAUNCH(32, 8, false); else CM_LAUNCH(32, 16, false); }
+    if (big) {
+        if (N % 128 == 0) CM_LAUNCH(128, 5, true, 8); else if (N % 64 == 0) CM_LAUNCH(64, 5, true, 8); else CM_LAUNCH(32, 5, true, 8);
+    } else if (N % 64 == 0) {
+        if (fast16) CM_LAUNCH(64, 8, true, 4); else if (na <= 8) CM_LAUNCH(64, 8, false, 4); else CM_LAUNCH(64, 16, false, 4);
+    } else {
+        if (fast16) CM_LAUNCH(32, 8, true, 4); else if (na <= 8) CM_LAUNCH(32, 8, false, 4); else CM_LAUNCH(32, 16, false, 4);
+    }
 #undef CM_LAUNCH
+#undef CM_LAUNCH1
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }
@@ -706,7 +850,7 @@ int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, v
     const int tw = 1 << g.tws, th = 1 << g.ths;
     const int npatch = g.tb * (th + 2) * (tw + 2);
     float* ws = nullptr;
-    if (workspace && tpb < 16) {       // blocks that accumulate >= 16 tiles amortise the atomic flush (<5 %): no partial round trip
+    if (workspace) {
         PHX_REQUIRE(workspace_bytes >= phx_conv3x3_wgrad_ws_bytes(B, H, W, Cin, Cout), PHX_E_INVAL, "conv3x3_wgrad_mfma: workspace too small");
         ws = (float*)workspace;
     }

@@ -480,7 +480,7 @@ class Plan:
             # a statistic has few samples (cheap there); otherwise the sums come from the conv epilogue.
             small = P <= 16384 or self.act_dt == F32
             if norm == "batch" and mfma and not small:
-                ntile = Lb.conv3x3_mfma_bf16_tiles(B, H, Wd)
+                ntile = Lb.conv3x3_mfma_bf16_tiles(B, H, Wd, cin_eff, cout)
                 part = self._alloc((ntile * 2 * cout,), F32)
                 conv_into(y, 0, stats_part=part)
                 self._emit(Lb.norm_reduce_partials, part.ptr, ntile, cout, sums.ptr, S)

@@ -148,6 +148,17 @@ MFMA_CASES = [
 
 @pytest.mark.parametrize("case", MFMA_CASES)
 def test_conv3x3_mfma_fwd_dgrad_wgrad(L, case):
+    _mfma_case(L, case)
+
+
+# the 16 x 32-pixel-tile / 8-wave forward kernels (chosen by policy only for large maps): forced here on small ones
+@pytest.mark.parametrize("case", [(2, 32, 32, 64, 128), (1, 64, 32, 32, 32), (3, 32, 16, 96, 64), (1, 32, 48, 32, 256)])
+def test_conv3x3_mfma_big_tiles(L, case, monkeypatch):
+    monkeypatch.setenv("PHX_FWD_BIG", "2")
+    _mfma_case(L, case)
+
+
+def _mfma_case(L, case):
     B, H, W, K, N = case
     x = RNG.standard_normal((B, H, W, K))
     w = RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K)
@@ -158,7 +169,7 @@ def test_conv3x3_mfma_fwd_dgrad_wgrad(L, case):
     wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
     wg = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
     L.pack_conv3x3_bf16(wd.data_ptr(), wf.data_ptr(), wg.data_ptr(), K, N, S())
-    ntile = L.conv3x3_mfma_bf16_tiles(B, H, W)
+    ntile = L.conv3x3_mfma_bf16_tiles(B, H, W, K, N)
     part = torch.zeros(ntile, 2, N, dtype=torch.float32).cuda()
     y = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
     L.conv3x3_mfma_bf16(xd.data_ptr(), wf.data_ptr(), y.data_ptr(), bd.data_ptr(), 1, part.data_ptr(), B, H, W, K,
