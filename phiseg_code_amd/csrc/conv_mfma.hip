@@ -13,7 +13,7 @@
 
 #include "phx_common.h"
 
-#ifndef PHX_ABLATE      // dev only (tools/build_ablate.sh): 1 no global loads, 2 no LDS staging stores, 4 no MFMAs, 8 no output stores
+#ifndef PHX_ABLATE      // dev only (tools/build_ablate.sh): fwd 1 no global loads, 2 no LDS staging stores, 4 no MFMAs, 8 no output stores; wgrad 16 no global loads, 32 no MFMAs
 #define PHX_ABLATE 0
 #endif
 #define KC 32            // input channels per LDS stage (two MFMA k-steps)
@@ -528,35 +528,78 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* 
         const int m = (threadIdx.x + it * 256) / QD;
         pland[it] = (m & (tw - 1)) | (((m >> g.tws) & (th - 1)) << 8) | ((m >> (g.tws + g.ths)) << 16);
     }
-    uint4 rx[NXI], rd[QD];
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 rx[NXI], rd[QD];
     auto prefetch = [&](int t) {                 // global -> registers for tile t (zero fill outside the image / batch)
         const int tx0 = (t % g.tiles_x) << g.tws; t /= g.tiles_x;
         const int ty0 = (t % g.tiles_y) << g.ths; t /= g.tiles_y;
         const int b0 = t * g.tb;
 #pragma unroll
         for (int it = 0; it < NXI; ++it) {
-            rx[it] = make_uint4(0, 0, 0, 0);
+            rx[it] = u32x4{0, 0, 0, 0};
             if (planx[it] >= 0) {
                 const int gx = tx0 + (planx[it] & 255) - 1, gy = ty0 + ((planx[it] >> 8) & 255) - 1, gb = b0 + (planx[it] >> 16);
                 if (gx >= 0 && gx < W && gy >= 0 && gy < H && gb < B)
-                    rx[it] = *reinterpret_cast<const uint4*>(x + (((size_t)gb * H + gy) * W + gx) * Cin + ci0 +
+                    rx[it] = *reinterpret_cast<const u32x4*>(x + (((size_t)gb * H + gy) * W + gx) * Cin + ci0 +
                                                              ((threadIdx.x + it * 256) % QX) * 8);
             }
         }
 #pragma unroll
         for (int it = 0; it < QD; ++it) {
             const int ox = tx0 + (pland[it] & 255), oy = ty0 + ((pland[it] >> 8) & 255), ob = b0 + (pland[it] >> 16);
-            rd[it] = make_uint4(0, 0, 0, 0);
+            rd[it] = u32x4{0, 0, 0, 0};
             if (ox < W && oy < H && ob < B)
-                rd[it] = *reinterpret_cast<const uint4*>(dy + (((size_t)ob * H + oy) * W + ox) * Cout + co0 +
+                rd[it] = *reinterpret_cast<const u32x4*>(dy + (((size_t)ob * H + oy) * W + ox) * Cout + co0 +
                                                          ((threadIdx.x + it * 256) % QD) * 8);
+        }
+    };
+    // FAST16 kernels stage with raw buffer loads instead: a piece outside the image gets offset 0xffffffff, which the buffer
+    // range check turns into zeros -- no branches, so single pieces can be issued between the MFMAs of the k-steps and the
+    // global-load path (~12 B/clk/CU, the scarce resource of this kernel) works underneath the matrix pipe.
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * Cin * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * H * W * Cout * 2u), 0x00020000);
+    const int qxb = (threadIdx.x % QX) * 16, qdb = (threadIdx.x % QD) * 16;      // 256 % QX == 0: the same for every piece
+    int ptx0 = 0, pty0 = 0, pb0 = 0;             // tile being prefetched
+    auto decode = [&](int t) {
+        ptx0 = (t % g.tiles_x) << g.tws; t /= g.tiles_x;
+        pty0 = (t % g.tiles_y) << g.ths; t /= g.tiles_y;
+        pb0 = t * g.tb;
+    };
+    auto prefetch_piece = [&](auto idxc) {       // piece idx (input patch first, then dy) of the tile at (ptx0, pty0, pb0)
+        constexpr int idx = decltype(idxc)::value;
+        if constexpr (PHX_ABLATE & 16) return;
+        if constexpr (idx < NXI) {
+            const int gx = ptx0 + (planx[idx] & 255) - 1, gy = pty0 + ((planx[idx] >> 8) & 255) - 1, gb = pb0 + (planx[idx] >> 16);
+            const bool ok = planx[idx] >= 0 && gx >= 0 && gx < W && gy >= 0 && gy < H && gb < B;
+            const unsigned vo = ok ? (unsigned)(((gb * H + gy) * W + gx) * Cin * 2 + qxb) : 0xffffffffu;
+            rx[idx] = __builtin_amdgcn_raw_buffer_load_b128(rsx, vo, ci0 * 2, 0);
+        } else if constexpr (idx < NXI + QD) {
+            constexpr int it = idx - NXI;
+            const int ox = ptx0 + (pland[it] & 255), oy = pty0 + ((pland[it] >> 8) & 255), ob = pb0 + (pland[it] >> 16);
+            const bool ok = ox < W && oy < H && ob < B;
+            const unsigned vo = ok ? (unsigned)(((ob * H + oy) * W + ox) * Cout * 2 + qdb) : 0xffffffffu;
+            rd[it] = __builtin_amdgcn_raw_buffer_load_b128(rsd, vo, co0 * 2, 0);
+        }
+    };
+    auto prefetch_range = [&](auto self, auto lo, auto hi) {     // pieces [lo, hi)
+        constexpr int l = decltype(lo)::value, h = decltype(hi)::value;
+        if constexpr (l < h && l < NXI + QD) {
+            prefetch_piece(lo);
+            self(self, std::integral_constant<int, l + 1>(), hi);
         }
     };
     const int t_begin = blockIdx.x * tiles_per_block;
     const int t_end = min(ntiles, t_begin + tiles_per_block);
     PHX_BLOCKLOG_BEGIN();
     PHX_TRACE(0);
-    if (t_begin < t_end) prefetch(t_begin);
+    if (t_begin < t_end) {
+        if constexpr (FAST16) {
+            decode(t_begin);
+            prefetch_range(prefetch_range, std::integral_constant<int, 0>(), std::integral_constant<int, NXI + QD>());
+        } else {
+            prefetch(t_begin);
+        }
+    }
     PHX_TRACE(1);
 
     for (int t = t_begin; t < t_end; ++t) {
@@ -565,55 +608,84 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* 
 #pragma unroll
         for (int it = 0; it < NXI; ++it) {
             const int i = threadIdx.x + it * 256;
-            if (planx[it] >= 0) *reinterpret_cast<uint4*>(sX + wswz<RBX>(i / QX, (i % QX) * 16)) = rx[it];
+            if (planx[it] >= 0) *reinterpret_cast<u32x4*>(sX + wswz<RBX>(i / QX, (i % QX) * 16)) = rx[it];
         }
 #pragma unroll
         for (int it = 0; it < QD; ++it) {
             const int i = threadIdx.x + it * 256;
-            *reinterpret_cast<uint4*>(sD + wswz<RBD>(i / QD, (i % QD) * 16)) = rd[it];
+            *reinterpret_cast<u32x4*>(sD + wswz<RBD>(i / QD, (i % QD) * 16)) = rd[it];
         }
         __syncthreads();
         if (t == t_begin) PHX_TRACE(3);
-        if (t + 1 < t_end) prefetch(t + 1);      // next tile's global loads fly under this tile's MFMAs
+        const bool more = t + 1 < t_end;
+        if constexpr (FAST16) { if (more) decode(t + 1); }
+        else if (more) prefetch(t + 1);          // next tile's global loads fly under this tile's MFMAs
         if (t == t_begin) PHX_TRACE(4);
         if (FAST16) {
             // 16x16 tiles (tb = 1): every LDS address is (row * const) + per-lane constant, and the swizzle bit is
             // parity(row) ^ per-lane bit, so with the k-steps taken in (even, odd) pairs all row terms are immediates.
-            auto kstep = [&](unsigned xb, unsigned db, auto parc) {
+            // Software pipeline over this wave's k-steps (ks = wk + WK * step): the 20 transpose reads of step s+1 are
+            // issued before the 9 MFMAs of step s (fragment registers double-buffered by step parity, order pinned with
+            // sched_barrier) -- with one wave per SIMD nothing else hides the LDS latency.
+            constexpr int NSTEP = 16 / WK;
+            s16x4 fd[2][2], fx[2][9][2];
+            auto read_step = [&](unsigned xb, unsigned db, auto parc, auto bufc) {
                 constexpr int P = decltype(parc)::value;          // parity of this k-step's tile row
-                const s16x4 d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(smem + db + dcon[0]));
-                const s16x4 d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(smem + db + dcon[1]));
-                const s16x8 dtmp = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
-                const bf16x8 bfrag = __builtin_bit_cast(bf16x8, dtmp);
+                constexpr int Bf = decltype(bufc)::value;
+                fd[Bf][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(smem + db + dcon[0]));
+                fd[Bf][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(smem + db + dcon[1]));
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw) {
-                        constexpr int dummy = 0;
                         const int par = (P + kh) & 1;
-                        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        fx[Bf][kh * 3 + kw][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                             (s16x4 __attribute__((address_space(3)))*)(smem + xb + kh * 18 * RBX + xcon[0][kw][par]));
-                        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        fx[Bf][kh * 3 + kw][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                             (s16x4 __attribute__((address_space(3)))*)(smem + xb + kh * 18 * RBX + xcon[1][kw][par]));
-                        const s16x8 atmp = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                        const bf16x8 afrag = __builtin_bit_cast(bf16x8, atmp);
-                        acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[kh * 3 + kw], 0, 0, 0);
-                        (void)dummy;
                     }
             };
-            const unsigned xbase = 0, dbase = (unsigned)(npatch * RBX);
-            if (WK == 1) {
-#pragma unroll 2
-                for (int j = 0; j < 8; ++j) {
-                    kstep(xbase + (2 * j) * 18 * RBX, dbase + (2 * j) * 16 * RBD, std::integral_constant<int, 0>());
-                    kstep(xbase + (2 * j + 1) * 18 * RBX, dbase + (2 * j + 1) * 16 * RBD, std::integral_constant<int, 1>());
+            auto mfma_step = [&](auto bufc) {
+                constexpr int Bf = decltype(bufc)::value;
+                const s16x8 dtmp = {fd[Bf][0][0], fd[Bf][0][1], fd[Bf][0][2], fd[Bf][0][3], fd[Bf][1][0], fd[Bf][1][1], fd[Bf][1][2], fd[Bf][1][3]};
+                const bf16x8 bfrag = __builtin_bit_cast(bf16x8, dtmp);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const s16x8 atmp = {fx[Bf][k][0][0], fx[Bf][k][0][1], fx[Bf][k][0][2], fx[Bf][k][0][3],
+                                        fx[Bf][k][1][0], fx[Bf][k][1][1], fx[Bf][k][1][2], fx[Bf][k][1][3]};
+                    if constexpr (PHX_ABLATE & 32) acc[k][k] += (float)atmp[0] * (float)dtmp[k & 7];
+                    else acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, atmp), bfrag, acc[k], 0, 0, 0);
                 }
-            } else if (wk & 1) {
-                for (int ks = wk; ks < 16; ks += WK)
-                    kstep(xbase + ks * 18 * RBX, dbase + ks * 16 * RBD, std::integral_constant<int, 1>());
+            };
+            const unsigned xbase = 0, dbase = (unsigned)(npatch * RBX);
+            // WK == 1: ks = step, parity compile-time per step.  WK = 2, 4: parity(ks) = parity(wk) for every step.
+            constexpr int IPK = (NXI + QD + NSTEP - 1) / NSTEP;      // next-tile pieces issued per k-step
+            auto pipeline = [&](auto wparc, auto pfc) {
+                constexpr int WP = decltype(wparc)::value;
+                constexpr bool PF = decltype(pfc)::value;
+                auto ksof = [&](int si) { return WK == 1 ? si : wk + WK * si; };
+                read_step(xbase + ksof(0) * 18 * RBX, dbase + ksof(0) * 16 * RBD, std::integral_constant<int, WP>(), std::integral_constant<int, 0>());
+                auto steps = [&](auto self, auto stepc) {
+                    constexpr int SI = decltype(stepc)::value;
+                    if constexpr (SI < NSTEP) {
+                        if constexpr (SI + 1 < NSTEP)
+                            read_step(xbase + ksof(SI + 1) * 18 * RBX, dbase + ksof(SI + 1) * 16 * RBD,
+                                      std::integral_constant<int, WK == 1 ? ((SI + 1) & 1) : WP>(), std::integral_constant<int, (SI + 1) & 1>());
+                        if constexpr (PF)
+                            prefetch_range(prefetch_range, std::integral_constant<int, SI * IPK>(), std::integral_constant<int, SI * IPK + IPK>());
+                        mfma_step(std::integral_constant<int, SI & 1>());
+                        __builtin_amdgcn_sched_barrier(0);
+                        self(self, std::integral_constant<int, SI + 1>());
+                    }
+                };
+                steps(steps, std::integral_constant<int, 0>());
+            };
+            if (more) {
+                if (WK == 1 || !(wk & 1)) pipeline(std::integral_constant<int, 0>(), std::true_type());
+                else pipeline(std::integral_constant<int, 1>(), std::true_type());
             } else {
-                for (int ks = wk; ks < 16; ks += WK)
-                    kstep(xbase + ks * 18 * RBX, dbase + ks * 16 * RBD, std::integral_constant<int, 0>());
+                if (WK == 1 || !(wk & 1)) pipeline(std::integral_constant<int, 0>(), std::false_type());
+                else pipeline(std::integral_constant<int, 1>(), std::false_type());
             }
         } else {
             for (int ks = wk; ks < 16; ks += WK) {
@@ -674,6 +746,170 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* 
             }
     }
     PHX_TRACE(6);
+    PHX_BLOCKLOG_END();
+}
+
+// ---- filter gradient, 16x16 tiles, LDS-DMA staging ---------------------------------------------------------------
+// Same tiling, LDS image and k-step code as k_conv3x3_wgrad<.., FAST16>, but the input patch and the dy tile go global ->
+// LDS directly (buffer_load ... lds): no staging registers and no ds_write pass, so the kernel fits 256 registers and TWO
+// blocks share a CU -- one block's loads (the global-load path, ~12 B/clk/CU, is what bounds this kernel) run under the
+// other block's MFMAs.  The DMA writes lane-linear (wave-uniform base + lane * 16), so the 64-byte half swizzle of the
+// 128-byte rows is applied on the SOURCE side (each lane fetches the piece that belongs in its slot); pieces outside the
+// image carry offset 0xffffffff and the buffer range check writes zeros for them.  Partial filters go to the workspace.
+template <int TCI, int TCO>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_dma(const unsigned short* __restrict__ x,
+                                                              const unsigned short* __restrict__ dy, float* __restrict__ ws,
+                                                              int B, int H, int W, int Cin, int Cout, MTile g, int ntiles,
+                                                              int tiles_per_block) {
+    constexpr int WI = TCI / 32, WJ = TCO / 32, WK = 4 / (WI * WJ);
+    constexpr int RBX = TCI * 2, RBD = TCO * 2;
+    constexpr int QX = TCI / 8, QD = TCO / 8;                        // 16-byte pieces per pixel
+    constexpr int NPATCH = 324;                                      // 18 x 18
+    constexpr int XI = (NPATCH * QX + 63) / 64, DI = 256 * QD / 64;  // wave-instructions (1 KiB each) per tile
+    constexpr int XN = (XI + 3) / 4, DN = DI / 4;                    // per wave
+    constexpr int SD_OFF = XI * 1024;                                // dy tile starts on the next 1 KiB boundary
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int ci0 = blockIdx.y * TCI, co0 = blockIdx.z * TCO;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wi = wave % WI, wj = (wave / WI) % WJ, wk = wave / (WI * WJ);
+    const int c16 = lane & 15, cb16 = (lane >> 4) & 1, khalf = lane >> 5;
+    const int chan_byte_x = (wi * 32 + cb16 * 16 + (c16 & 3) * 4) * 2;
+    const int chan_byte_d = (wj * 32 + cb16 * 16 + (c16 & 3) * 4) * 2;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    unsigned dcon[2], xcon[2][3][2];             // per-lane LDS constants, see k_conv3x3_wgrad
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int lxr = khalf * 8 + r * 4 + (c16 >> 2);
+        dcon[r] = (unsigned)(SD_OFF + wswz<RBD>(lxr, chan_byte_d));
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int par = 0; par < 2; ++par)
+                xcon[r][kw][par] = (unsigned)((lxr + kw) * RBX +
+                                              (RBX == 128 ? (chan_byte_x ^ (((((lxr + kw) >> 1) & 1) ^ par) << 6)) : chan_byte_x));
+    }
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+
+    // DMA plan: lane `lane` of wave-instruction j = wave + 4 n fills LDS slot e = 64 j + lane with the SOURCE piece p of
+    // patch pixel (px, py) / tile pixel m.  The 64 x 64 kernel keeps the (tile independent) plan in registers; the others
+    // (two MFMA code paths' worth of registers short) recompute it per tile, a dozen integer ops per load.
+    constexpr bool RPLAN = WK == 1;
+    auto plan_x = [&](int n) -> int {
+        const int e = (wave + 4 * n) * 64 + lane;
+        const int pp = e / QX, ps = e % QX;
+        const int p = RBX == 128 ? (ps ^ (((pp >> 1) & 1) << 2)) : ps;
+        return pp < NPATCH ? ((pp % 18) | ((pp / 18) << 8) | (p << 16)) : -1;
+    };
+    auto plan_d = [&](int n) -> int {
+        const int e = (wave + 4 * n) * 64 + lane;
+        const int m = e / QD, ps = e % QD;
+        const int p = RBD == 128 ? (ps ^ (((m >> 1) & 1) << 2)) : ps;
+        return (m & 15) | ((m >> 4) << 8) | (p << 16);
+    };
+    int planx[RPLAN ? XN : 1], pland[RPLAN ? DN : 1];
+    if constexpr (RPLAN) {
+#pragma unroll
+        for (int n = 0; n < XN; ++n) planx[n] = plan_x(n);
+#pragma unroll
+        for (int n = 0; n < DN; ++n) pland[n] = plan_d(n);
+    }
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * Cin * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * H * W * Cout * 2u), 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    const int t_begin = blockIdx.x * tiles_per_block;
+    const int t_end = min(ntiles, t_begin + tiles_per_block);
+    PHX_BLOCKLOG_BEGIN();
+    for (int t = t_begin; t < t_end; ++t) {
+        int tt = t;
+        const int tx0 = (tt % g.tiles_x) << 4; tt /= g.tiles_x;
+        const int ty0 = (tt % g.tiles_y) << 4; tt /= g.tiles_y;
+        const int b0 = tt;
+        __syncthreads();                         // previous tile fully consumed
+#pragma unroll
+        for (int n = 0; n < XN; ++n) {
+            if (wave + 4 * n < XI) {
+                int pk;
+                if constexpr (RPLAN) pk = planx[n]; else pk = plan_x(n);
+                const int gx = tx0 + (pk & 255) - 1, gy = ty0 + ((pk >> 8) & 255) - 1;
+                const bool ok = pk >= 0 && gx >= 0 && gx < W && gy >= 0 && gy < H;
+                const unsigned vo = ok ? (unsigned)((((b0 * H + gy) * W + gx) * Cin) * 2 + (pk >> 16) * 16) : 0xffffffffu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + (wave + 4 * n) * 1024), 16, vo, ci0 * 2, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < DN; ++n) {
+            int pk;
+            if constexpr (RPLAN) pk = pland[n]; else pk = plan_d(n);
+            const int ox = tx0 + (pk & 255), oy = ty0 + ((pk >> 8) & 255);
+            const bool ok = ox < W && oy < H;
+            const unsigned vo = ok ? (unsigned)((((b0 * H + oy) * W + ox) * Cout) * 2 + (pk >> 16) * 16) : 0xffffffffu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lds_ptr_t)(smem + SD_OFF + (wave + 4 * n) * 1024), 16, vo, co0 * 2, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // k-steps of this wave, software pipelined as in k_conv3x3_wgrad
+        constexpr int NSTEP = 16 / WK;
+        s16x4 fd[2][2], fx[2][9][2];
+        auto read_step = [&](unsigned xb, unsigned db, auto parc, auto bufc) {
+            constexpr int P = decltype(parc)::value;
+            constexpr int Bf = decltype(bufc)::value;
+            fd[Bf][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(smem + db + dcon[0]));
+            fd[Bf][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(smem + db + dcon[1]));
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int par = (P + kh) & 1;
+                    fx[Bf][kh * 3 + kw][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4 __attribute__((address_space(3)))*)(smem + xb + kh * 18 * RBX + xcon[0][kw][par]));
+                    fx[Bf][kh * 3 + kw][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4 __attribute__((address_space(3)))*)(smem + xb + kh * 18 * RBX + xcon[1][kw][par]));
+                }
+        };
+        auto mfma_step = [&](auto bufc) {
+            constexpr int Bf = decltype(bufc)::value;
+            const s16x8 dtmp = {fd[Bf][0][0], fd[Bf][0][1], fd[Bf][0][2], fd[Bf][0][3], fd[Bf][1][0], fd[Bf][1][1], fd[Bf][1][2], fd[Bf][1][3]};
+            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, dtmp);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const s16x8 atmp = {fx[Bf][k][0][0], fx[Bf][k][0][1], fx[Bf][k][0][2], fx[Bf][k][0][3],
+                                    fx[Bf][k][1][0], fx[Bf][k][1][1], fx[Bf][k][1][2], fx[Bf][k][1][3]};
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, atmp), bfrag, acc[k], 0, 0, 0);
+            }
+        };
+        // wave group wk takes the NSTEP consecutive k-steps ks = wk * NSTEP + step (NSTEP is even or 16: the parity of ks
+        // -- which selects the swizzle immediates -- is the parity of step, a compile-time value)
+        const unsigned xw = (unsigned)(wk * NSTEP * 18 * RBX), dw_ = (unsigned)(wk * NSTEP * 16 * RBD);
+        read_step(xw, dw_, std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+        auto steps = [&](auto self, auto stepc) {
+            constexpr int SI = decltype(stepc)::value;
+            if constexpr (SI < NSTEP) {
+                if constexpr (SI + 1 < NSTEP)
+                    read_step(xw + (SI + 1) * 18 * RBX, dw_ + (SI + 1) * 16 * RBD, std::integral_constant<int, (SI + 1) & 1>(),
+                              std::integral_constant<int, (SI + 1) & 1>());
+                mfma_step(std::integral_constant<int, SI & 1>());
+                __builtin_amdgcn_sched_barrier(0);
+                self(self, std::integral_constant<int, SI + 1>());
+            }
+        };
+        steps(steps, std::integral_constant<int, 0>());
+    }
+    // partial tile -> workspace (see k_conv3x3_wgrad); C layout: col = lane&31 -> co, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> ci
+    const size_t cb = (size_t)blockIdx.z * gridDim.y + blockIdx.y;
+    float* wp = ws + ((cb * gridDim.x + blockIdx.x) * WK + wk) * (size_t)(9 * TCI * TCO);
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cil = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            wp[(k * TCI + cil) * TCO + wj * 32 + (lane & 31)] = acc[k][r];
+        }
     PHX_BLOCKLOG_END();
 }
 
@@ -864,6 +1100,25 @@ int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, v
 #undef WG_ATTR
         attr_set = true;
     }
+    // 16x16 tiles with a workspace: the LDS-DMA kernel (two blocks per CU)
+    static int dma_en = -1;
+    if (dma_en < 0) { const char* e = getenv("PHX_WGRAD_DMA"); dma_en = e ? atoi(e) : 1; }
+    if (dma_en && ws && g.tws == 4 && g.ths == 4 && g.tb == 1) {
+        static bool dattr = false;
+#define WD_ATTR(A, Bq) PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_dma<A, Bq>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+        if (!dattr) { WD_ATTR(64, 64); WD_ATTR(64, 32); WD_ATTR(32, 64); WD_ATTR(32, 32); dattr = true; }
+#undef WD_ATTR
+#define WD_LAUNCH(A, Bq)                                                                                              \
+    hipLaunchKernelGGL((k_conv3x3_wgrad_dma<A, Bq>), dim3(gx, Cin / A, Cout / Bq), dim3(256),                         \
+                       (size_t)((324 * (A / 8) + 63) / 64) * 1024 + (size_t)256 * Bq * 2, (hipStream_t)stream,        \
+                       (const unsigned short*)x, (const unsigned short*)dy, ws, B, H, W, Cin, Cout, g, ntiles, tpb)
+        if (tci == 64 && tco == 64) WD_LAUNCH(64, 64);
+        else if (tci == 64) WD_LAUNCH(64, 32);
+        else if (tco == 64) WD_LAUNCH(32, 64);
+        else WD_LAUNCH(32, 32);
+#undef WD_LAUNCH
+        PHX_CHECK_LAUNCH();
+    } else {
     const size_t sh = (size_t)npatch * tci * 2 + (size_t)256 * tco * 2;
 #define WG_LAUNCH(A, Bq, C, F)                                                                                            \
     hipLaunchKernelGGL((k_conv3x3_wgrad<A, Bq, C, F>), dim3(gx, Cin / A, Cout / Bq), dim3(256), sh, (hipStream_t)stream,  \
@@ -881,6 +1136,7 @@ int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, v
 #undef WG_LAUNCH2
 #undef WG_LAUNCH
     PHX_CHECK_LAUNCH();
+    }
     if (ws) {
         const size_t total = (size_t)9 * Cin * Cout;
         const int nslice = gx * wk;
