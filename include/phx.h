@@ -133,11 +133,14 @@ int phx_norm_apply_fused(const void* x, int x_dt, const float* sums, const float
                          int G, int act, void* stream);
 int phx_norm_bwd_apply_fused(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
                              const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx,
-                             int dx_dt, float* dgamma, float* dbeta, int NS, int P, int C, int G, int act, void* stream);
-/* backward of y = act(norm(x)):  g = dA * act'(.);  sums2[NS][C][2] += {sum g, sum g*xhat} */
+                             int dx_dt, float* dgamma, float* dbeta, int NS, int P, int C, int G, int act, int nrep,
+                             void* stream);
+/* backward of y = act(norm(x)):  g = dA * act'(.);  sums2[nrep][NS][C][2] += {sum g, sum g*xhat}: block b adds into
+ * replica b % nrep (same-address atomics serialise at ~45 ns each); phx_norm_bwd_apply_fused sums the replicas, the other
+ * consumers take nrep = 1 */
 int phx_norm_bwd_reduce(const void* dA, int da_dt, const void* x, int x_dt, const float* scale,
                         const float* shift, const float* mean, const float* rstd, float* sums2,
-                        int NS, int P, int C, int G, int act, void* stream);
+                        int NS, int P, int C, int G, int act, int nrep, void* stream);
 /* per (ns,g): S[ns][g][2] = sum_{c in g} gamma_c * sums2[ns][c][*];  dgamma[c] += sum_ns sums2[..][1], dbeta += [..][0] */
 int phx_norm_bwd_finalize(const float* sums2, const float* gamma, float* S, float* dgamma, float* dbeta,
                           int NS, int C, int G, void* stream);

@@ -1,6 +1,7 @@
 // HBM-bound kernels of the PHiSeg step: normalisation (batch/group/instance), affine+activation,
 // pooling, TF1 bilinear resize, concat/split, casts, posterior input assembly, global pooling.
 // All are streaming kernels: 16-byte vector access along the NHWC channel axis when C % 8 == 0.
+#include <stdlib.h>
 #include "phx_common.h"
 
 // ---- 8-wide vector access ----------------------------------------------------------------------
@@ -66,7 +67,19 @@ __global__ void k_norm_stats(const T* __restrict__ x, float* __restrict__ sums, 
                 for (int j = 0; j < V; ++j) pivot[(size_t)ns * C + cv * V + j] = pv[j];
             }
         }
-        for (int p = p0 + pl; p < p1; p += PL) {
+        // four pixels per trip, loads first: a thread's trips are serially dependent, so the loads in flight per
+        // thread -- not the block count -- set the speed on the mid-size maps
+        int p = p0 + pl;
+        for (; p + 3 * PL < p1; p += 4 * PL) {
+            float v[4][V];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) VecIO<T, V>::load(x, ((size_t)ns * P + p + u * PL) * C + (size_t)cv * V, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < V; ++j) { const float d = v[u][j] - pv[j]; s1[j] += d; s2[j] += d * d; }
+        }
+        for (; p < p1; p += PL) {
             float v[V];
             VecIO<T, V>::load(x, ((size_t)ns * P + p) * C + (size_t)cv * V, v);
 #pragma unroll
@@ -86,16 +99,20 @@ __global__ void k_norm_stats(const T* __restrict__ x, float* __restrict__ sums, 
     }
 }
 
-static int norm_geometry(int P, int C, int V, int* PL, int* threads, int* chunk, int* nchunks, int NS) {
+static int norm_geometry(int P, int C, int V, int* PL, int* threads, int* chunk, int* nchunks, int NS, int nrep = 1) {
     int CV = C / V;
     if (CV > 256) return -1;
     *PL = 256 / CV;
     *threads = CV * (*PL);
     int rows = (P + *PL - 1) / (*PL);
     int want = (rows + 15) / 16;                              // 16 pixels per thread on big maps, >= ~512 blocks on small ones
-    int floor_blocks = rows < 512 ? rows : 512;
+    static int fl = 0;
+    if (!fl) { const char* e = getenv("PHX_NORM_FLOOR"); fl = e ? atoi(e) : 128; }      // tuning hook (measured: tools/bench_norm.py)
+    int floor_blocks = rows < fl ? rows : fl;
     if (want < floor_blocks) want = floor_blocks;
-    int cap = 2048 / (NS > 0 ? NS : 1);
+    static int capv = 0;
+    if (!capv) { const char* e = getenv("PHX_NORM_CAP"); capv = e ? atoi(e) : 2048; }    // tuning hook
+    int cap = (nrep > 1 ? capv : 2048) / (NS > 0 ? NS : 1);   // every block ends in 2C same-address atomics (see k_norm_bwd_reduce)
     if (cap < 1) cap = 1;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
@@ -113,7 +130,9 @@ static int stream_geometry(int P, int C, int V, int* PL, int* threads, int* chun
     // there: a thread's iterations are serially dependent loads)
     int rows = (P + *PL - 1) / (*PL);
     int want = (rows + 15) / 16;
-    int floor_blocks = rows < 1024 ? rows : 1024;
+    static int fl = 0;
+    if (!fl) { const char* e = getenv("PHX_STREAM_FLOOR"); fl = e ? atoi(e) : 256; }    // tuning hook (measured: tools/bench_norm.py)
+    int floor_blocks = rows < fl ? rows : fl;
     if (want < floor_blocks) want = floor_blocks;
     int cap = 8192 / (NS > 0 ? NS : 1);
     if (cap < 1) cap = 1;
@@ -207,7 +226,19 @@ __global__ void k_affine_act(const TI* __restrict__ x, const float* __restrict__
         sh[j] = shift[(size_t)ns * C + cv * V + j];
     }
     const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
-    for (int p = p0 + pl; p < p1; p += PL) {
+    int p = p0 + pl;
+    for (; p + 3 * PL < p1; p += 4 * PL) {       // four pixels per trip, loads first (see k_norm_stats)
+        float v[4][V];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) VecIO<TI, V>::load(x, ((size_t)ns * P + p + u * PL) * C + (size_t)cv * V, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) v[u][j] = act_fwd(fmaf(v[u][j], sc[j], sh[j]), act);
+            VecIO<TO, V>::store(y, ((size_t)ns * P + p + u * PL) * C + (size_t)cv * V, v[u]);
+        }
+    }
+    for (; p < p1; p += PL) {
         const size_t off = ((size_t)ns * P + p) * C + (size_t)cv * V;
         float v[V];
         VecIO<TI, V>::load(x, off, v);
@@ -287,7 +318,19 @@ __global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __rest
         }
     }
     const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
-    for (int p = p0 + pl; p < p1; p += PL) {
+    int p = p0 + pl;
+    for (; p + 3 * PL < p1; p += 4 * PL) {       // four pixels per trip, loads first (see k_norm_stats)
+        float v[4][V];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) VecIO<TI, V>::load(x, ((size_t)ns * P + p + u * PL) * C + (size_t)cv * V, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) v[u][j] = act_fwd(fmaf(v[u][j], sc[j], sh[j]), act);
+            VecIO<TO, V>::store(y, ((size_t)ns * P + p + u * PL) * C + (size_t)cv * V, v[u]);
+        }
+    }
+    for (; p < p1; p += PL) {
         const size_t off = ((size_t)ns * P + p) * C + (size_t)cv * V;
         float v[V];
         VecIO<TI, V>::load(x, off, v);
@@ -303,31 +346,49 @@ __global__ void k_norm_bwd_apply_fused(const TD* __restrict__ dA, const TX* __re
                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                        const float* __restrict__ gamma, const float* __restrict__ sums2,
                                        TO* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int P,
-                                       int C, int G, int PL, int chunk, int act) {
+                                       int C, int G, int PL, int chunk, int act, int nrep) {
     const int CV = C / V, cg = C / G;
     const int ns = blockIdx.y;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    // the block sums the accumulator replicas once, into LDS: st[c][2] = sum_r sums2[r][ns][c][2]
+    extern __shared__ float st[];
+    {
+        const size_t rstride = (size_t)gridDim.y * 2 * C;    // sums2[nrep][NS][C][2]
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+            float a = 0.f;
+            for (int r = 0; r < nrep; ++r) a += sums2[r * rstride + (size_t)ns * 2 * C + i];
+            st[i] = a;
+        }
+    }
+    __syncthreads();
     if (pl >= PL) return;
     const float inv_m = 1.f / ((float)P * (float)cg);
     float sc[V], sh[V], ca[V], cb[V], cc[V];
     int gprev = -1;
     float S0 = 0.f, S1 = 0.f;
     const bool publish = blockIdx.x == 0 && pl == 0;
+    auto rsum = [&](int c, float& a, float& b) { a = st[2 * c]; b = st[2 * c + 1]; };
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         const int c = cv * V + j, g = c / cg;
+        float t0 = 0.f, t1 = 0.f;                            // this channel's {sum g, sum g * xhat}
         if (cg == 1) {
-            const float2 sq = *reinterpret_cast<const float2*>(sums2 + ((size_t)ns * C + c) * 2);
+            rsum(c, t0, t1);
             const float gm = gamma[c];
-            S0 = gm * sq.x;
-            S1 = gm * sq.y;
-        } else if (g != gprev) {
-            S0 = S1 = 0.f;
-            for (int q = g * cg; q < (g + 1) * cg; ++q) {
-                S0 += gamma[q] * sums2[((size_t)ns * C + q) * 2];
-                S1 += gamma[q] * sums2[((size_t)ns * C + q) * 2 + 1];
+            S0 = gm * t0;
+            S1 = gm * t1;
+        } else {
+            if (g != gprev) {
+                S0 = S1 = 0.f;
+                for (int q = g * cg; q < (g + 1) * cg; ++q) {
+                    float a, b;
+                    rsum(q, a, b);
+                    S0 += gamma[q] * a;
+                    S1 += gamma[q] * b;
+                }
+                gprev = g;
             }
-            gprev = g;
+            if (publish) rsum(c, t0, t1);
         }
         const int sg = ns * G + g;
         const float rs = rstd[sg], mu = mean[sg];
@@ -337,12 +398,32 @@ __global__ void k_norm_bwd_apply_fused(const TD* __restrict__ dA, const TX* __re
         cc[j] = -rs * rs * S1 * inv_m;
         cb[j] = -rs * S0 * inv_m - cc[j] * mu;
         if (publish) {
-            atomicAdd(&dbeta[c], sums2[((size_t)ns * C + c) * 2]);
-            atomicAdd(&dgamma[c], sums2[((size_t)ns * C + c) * 2 + 1]);
+            atomicAdd(&dbeta[c], t0);
+            atomicAdd(&dgamma[c], t1);
         }
     }
     const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
-    for (int p = p0 + pl; p < p1; p += PL) {
+    int p = p0 + pl;
+    for (; p + 3 * PL < p1; p += 4 * PL) {       // four pixels per trip, loads first (see k_norm_stats)
+        float xv[4][V], dv[4][V];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t off = ((size_t)ns * P + p + u * PL) * C + (size_t)cv * V;
+            VecIO<TX, V>::load(x, off, xv[u]);
+            VecIO<TD, V>::load(dA, off, dv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float o[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float gq = dv[u][j] * act_grad_pre(fmaf(xv[u][j], sc[j], sh[j]), act);
+                o[j] = fmaf(ca[j], gq, fmaf(cc[j], xv[u][j], cb[j]));
+            }
+            VecIO<TO, V>::store(dx, ((size_t)ns * P + p + u * PL) * C + (size_t)cv * V, o);
+        }
+    }
+    for (; p < p1; p += PL) {
         const size_t off = ((size_t)ns * P + p) * C + (size_t)cv * V;
         float xv[V], dv[V], o[V];
         VecIO<TX, V>::load(x, off, xv);
@@ -361,11 +442,15 @@ template <typename TD, typename TX, int V>
 __global__ void k_norm_bwd_reduce(const TD* __restrict__ dA, const TX* __restrict__ x,
                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                   const float* __restrict__ mean, const float* __restrict__ rstd,
-                                  float* __restrict__ sums2, int P, int C, int G, int PL, int chunk, int act) {
+                                  float* __restrict__ sums2, int P, int C, int G, int PL, int chunk, int act, int nrep) {
     const int CV = C / V;
     const int ns = blockIdx.y;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
     extern __shared__ float red[];
+    // Same-address fp32 atomics retire at ~1 per 45 ns on MI355X (memory-side), so with a thousand blocks the adds into
+    // one sums2 entry -- not the streaming -- set the kernel time: block b adds into replica b % nrep, the consumer
+    // (k_norm_bwd_apply_fused) sums the replicas.
+    sums2 += (size_t)(blockIdx.x % nrep) * gridDim.y * 2 * C;
     float s1[V], s2[V], sc[V], sh[V], mu[V], rs[V];
     const int cg = C / G;
 #pragma unroll
@@ -379,7 +464,8 @@ __global__ void k_norm_bwd_reduce(const TD* __restrict__ dA, const TX* __restric
     }
     const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
     if (pl < PL) {
-        for (int p = p0 + pl; p < p1; p += PL) {
+        int p = p0 + pl;
+        for (; p < p1; p += PL) {
             float xv[V], dv[V];
             const size_t off = ((size_t)ns * P + p) * C + (size_t)cv * V;
             VecIO<TX, V>::load(x, off, xv);
@@ -789,14 +875,16 @@ int phx_norm_apply_fused(const void* x, int x_dt, const float* sums, const float
 
 int phx_norm_bwd_apply_fused(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
                              const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx,
-                             int dx_dt, float* dgamma, float* dbeta, int NS, int P, int C, int G, int act, void* stream) {
+                             int dx_dt, float* dgamma, float* dbeta, int NS, int P, int C, int G, int act, int nrep,
+                             void* stream) {
     PHX_REQUIRE(da_dt == dx_dt, PHX_E_INVAL, "norm_bwd_apply_fused: dA and dx dtypes must match");
+    PHX_REQUIRE(nrep >= 1, PHX_E_INVAL, "norm_bwd_apply_fused: nrep >= 1");
     PHX_DT_SWITCH(da_dt, TD, PHX_DT_SWITCH(x_dt, TX, PHX_VEC_SWITCH(C, V, {
         int PL, threads, chunk, nchunks;
         PHX_REQUIRE(stream_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_bwd_apply_fused: C too large");
-        hipLaunchKernelGGL((k_norm_bwd_apply_fused<TD, TX, TD, V>), dim3(nchunks, NS), dim3(threads), 0,
-                           (hipStream_t)stream, (const TD*)dA, (const TX*)x, scale, shift, mean, rstd, gamma, sums2,
-                           (TD*)dx, dgamma, dbeta, P, C, G, PL, chunk, act);
+        hipLaunchKernelGGL((k_norm_bwd_apply_fused<TD, TX, TD, V>), dim3(nchunks, NS), dim3(threads),
+                           (size_t)2 * C * sizeof(float), (hipStream_t)stream, (const TD*)dA, (const TX*)x, scale, shift, mean, rstd, gamma, sums2,
+                           (TD*)dx, dgamma, dbeta, P, C, G, PL, chunk, act, nrep);
     })));
     PHX_CHECK_LAUNCH();
     return PHX_OK;
@@ -804,13 +892,14 @@ int phx_norm_bwd_apply_fused(const void* dA, int da_dt, const void* x, int x_dt,
 
 int phx_norm_bwd_reduce(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
                         const float* mean, const float* rstd, float* sums2, int NS, int P, int C, int G, int act,
-                        void* stream) {
+                        int nrep, void* stream) {
+    PHX_REQUIRE(nrep >= 1, PHX_E_INVAL, "norm_bwd_reduce: nrep >= 1");
     PHX_DT_SWITCH(da_dt, TD, PHX_DT_SWITCH(x_dt, TX, PHX_VEC_SWITCH(C, V, {
         int PL, threads, chunk, nchunks;
-        PHX_REQUIRE(norm_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_bwd_reduce: C too large");
+        PHX_REQUIRE(norm_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS, nrep) == 0, PHX_E_SHAPE, "norm_bwd_reduce: C too large");
         hipLaunchKernelGGL((k_norm_bwd_reduce<TD, TX, V>), dim3(nchunks, NS), dim3(threads),
                            (size_t)PL * C * 2 * sizeof(float), (hipStream_t)stream, (const TD*)dA, (const TX*)x, scale,
-                           shift, mean, rstd, sums2, P, C, G, PL, chunk, act);
+                           shift, mean, rstd, sums2, P, C, G, PL, chunk, act, nrep);
     })));
     PHX_CHECK_LAUNCH();
     return PHX_OK;

@@ -736,15 +736,16 @@ class Plan:
                 raise NotImplementedError("backward through inference-mode batch norm is not on the hot path")
             nv = a["norm_vars"]
             y, NS, P, Gn = sv["y"], sv["NS"], sv["P"], sv["G"]
-            sums2 = self._alloc_zeroed(NS * cout * 2)
+            nrep = 8 if P >= 4096 else 1           # replicated accumulators: see k_norm_bwd_reduce
+            sums2 = self._alloc_zeroed(nrep * NS * cout * 2)
             Sg = self._alloc((NS * Gn * 2,), F32)
             dY = self._alloc(y.shape, y.dt)
             self._emit(Lb.norm_bwd_reduce, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
-                       sv["mean"].ptr, sv["rstd"].ptr, sums2.ptr, NS, P, cout, Gn, act, S,
+                       sv["mean"].ptr, sv["rstd"].ptr, sums2.ptr, NS, P, cout, Gn, act, nrep, S,
                        tag="bytes_norm_bwd_reduce", flops=float(dA.nbytes + y.nbytes))
             self._emit(Lb.norm_bwd_apply_fused, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
                        sv["mean"].ptr, sv["rstd"].ptr, self.store.ptr(nv["gamma"]), sums2.ptr, dY.ptr, dY.dt,
-                       self.store.grad_ptr(nv["gamma"]), self.store.grad_ptr(nv["beta"]), NS, P, cout, Gn, act, S,
+                       self.store.grad_ptr(nv["gamma"]), self.store.grad_ptr(nv["beta"]), NS, P, cout, Gn, act, nrep, S,
                        tag="bytes_norm_bwd_apply", flops=float(dA.nbytes + y.nbytes + dY.nbytes))
         elif act != rt.ACT_ID:
             dY = self._alloc(out.shape, dA.dt)

@@ -260,7 +260,7 @@ def test_norm_fwd_bwd(L, case):
     dAd = dev(dA, dt)
     sums2 = torch.zeros(NS, C, 2, dtype=torch.float32).cuda()
     L.norm_bwd_reduce(dAd.data_ptr(), dt, xd.data_ptr(), dt, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
-                      rstd.data_ptr(), sums2.data_ptr(), NS, P, C, GG, 1, S())
+                      rstd.data_ptr(), sums2.data_ptr(), NS, P, C, GG, 1, 1, S())
     Sg = torch.empty(NS * GG * 2, dtype=torch.float32).cuda()
     dgamma = torch.zeros(C, dtype=torch.float32).cuda()
     dbeta = torch.zeros(C, dtype=torch.float32).cuda()
@@ -272,6 +272,28 @@ def test_norm_fwd_bwd(L, case):
     close(host(dx), xr.grad.numpy(), 5e-5 if dt == F32 else 8e-3, kind + " dx")
     close(host(dgamma), gr.grad.numpy(), 5e-5 if dt == F32 else 2e-3, kind + " dgamma")
     close(host(dbeta), br.grad.numpy(), 5e-5 if dt == F32 else 2e-3, kind + " dbeta")
+    # fused variants (the ones the engine emits): statistics finalised inside the apply kernels, replicated bwd accumulators
+    a2 = torch.empty(B, H, W, C, dtype=tdt(dt)).cuda()
+    mean2, rstd2, scale2, shift2 = (torch.empty_like(t) for t in (mean, rstd, scale, shift))
+    L.norm_apply_fused(xd.data_ptr(), dt, sums.data_ptr(), pivot.data_ptr(), gd.data_ptr(), bd.data_ptr(), eps, a2.data_ptr(), dt,
+                       mean2.data_ptr(), rstd2.data_ptr(), scale2.data_ptr(), shift2.data_ptr(), None, None, 0.0, NS, P, C, GG,
+                       1, S())
+    close(host(a2), ar.detach().numpy(), 2e-5 if dt == F32 else 6e-3, kind + " fused fwd")
+    close(host(scale2), host(scale), 1e-6, kind + " fused scale")
+    nrep = 3
+    sums2r = torch.zeros(nrep, NS, C, 2, dtype=torch.float32).cuda()
+    L.norm_bwd_reduce(dAd.data_ptr(), dt, xd.data_ptr(), dt, scale2.data_ptr(), shift2.data_ptr(), mean2.data_ptr(),
+                      rstd2.data_ptr(), sums2r.data_ptr(), NS, P, C, GG, 1, nrep, S())
+    close(host(sums2r).sum(axis=0), host(sums2), 1e-5 if dt == F32 else 1e-4, kind + " replicated sums2")
+    dx2 = torch.empty(B, H, W, C, dtype=tdt(dt)).cuda()
+    dgamma2 = torch.zeros(C, dtype=torch.float32).cuda()
+    dbeta2 = torch.zeros(C, dtype=torch.float32).cuda()
+    L.norm_bwd_apply_fused(dAd.data_ptr(), dt, xd.data_ptr(), dt, scale2.data_ptr(), shift2.data_ptr(), mean2.data_ptr(),
+                           rstd2.data_ptr(), gd.data_ptr(), sums2r.data_ptr(), dx2.data_ptr(), dt, dgamma2.data_ptr(),
+                           dbeta2.data_ptr(), NS, P, C, GG, 1, nrep, S())
+    close(host(dx2), xr.grad.numpy(), 5e-5 if dt == F32 else 8e-3, kind + " fused dx")
+    close(host(dgamma2), gr.grad.numpy(), 5e-5 if dt == F32 else 2e-3, kind + " fused dgamma")
+    close(host(dbeta2), br.grad.numpy(), 5e-5 if dt == F32 else 2e-3, kind + " fused dbeta")
 
 
 def test_bn_infer_scale_shift(L):
