@@ -1059,9 +1059,10 @@ static int wgrad_plan(int B, int H, int W, int Cin, int Cout, MTile* g, int* tci
     *tco = Cout % 64 == 0 ? 64 : 32;
     *wk = 4 / ((*tci / 32) * (*tco / 32));
     const int cblocks = (Cin / *tci) * (Cout / *tco);
-    // measured on MI355X (tools/bench_wgrad.py): 512 blocks for big maps; fewer when there are few pixel tiles, because every
-    // block writes (and k_wgrad_reduce re-reads) a full 9*TCI*TCO partial filter
-    int target_blocks = (*tci == 32 && *tco == 32) ? 256 : 512;
+    // measured on MI355X (tools/bench_wgrad.py, LDS-DMA kernels, two blocks per CU): ~384 blocks; 512 when few channel
+    // blocks share the pixel tiles; fewer when there are few pixel tiles, because every block writes (and k_wgrad_reduce
+    // re-reads) a full 9*TCI*TCO partial filter
+    int target_blocks = cblocks <= 4 && *tci == 64 && *tco == 64 ? 512 : 384;
     if (ntiles <= 256 && target_blocks > 256) target_blocks = 256;
     if (const char* e = getenv("PHX_WGRAD_BLOCKS")) target_blocks = atoi(e);      // tuning hook
     int split = (target_blocks + cblocks - 1) / cblocks;

@@ -2,6 +2,7 @@
 // y_lvl (nlabels channels) -- posteriors.py:125-127, priors.py:117-119, likelihoods.py:220.  They are pure streaming
 // passes over the feature map (C = 32..192 channels in, NOUT <= 8 out), so a thread owns one 8-channel vector
 // (16 bytes of bf16) of a pixel, the NOUT x 8 filter slice lives in registers, and the kernels run at HBM speed.
+#include <stdlib.h>
 #include "phx_common.h"
 
 template <typename T, int V> struct HVec;
@@ -231,7 +232,10 @@ int phx_head1x1_wgrad(const void* x, int x_dt, const float* dy, float* dw, float
         PHX_REQUIRE(head_geo(C, V, &PL, &threads) == 0, PHX_E_SHAPE, "head1x1: C too large");
         int chunk = PL * 32;
         size_t grid = (npix + chunk - 1) / chunk;
-        if (grid > 1024) { chunk = (int)((npix + 1023) / 1024); grid = (npix + chunk - 1) / chunk; }
+        // every block ends in C * nout same-address atomics (~45 ns each, serialised): few, long blocks
+        static int cap = 0;
+        if (!cap) { const char* e = getenv("PHX_HEADW_BLOCKS"); cap = e ? atoi(e) : 1024; }
+        if (grid > (size_t)cap) { chunk = (int)((npix + cap - 1) / cap); grid = (npix + chunk - 1) / chunk; }
         size_t sh = (size_t)PL * C * N * sizeof(float);
         if (sh < (size_t)PL * N * sizeof(float)) sh = (size_t)PL * N * sizeof(float);
         hipLaunchKernelGGL((k_head1x1_wgrad<TX, V, N>), dim3((unsigned)grid), dim3(threads), sh, (hipStream_t)stream,

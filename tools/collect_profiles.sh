@@ -1,0 +1,23 @@
+#!/bin/bash
+# GPU box: the evidence behind bench.py's numbers -> gpurun_out/final/ (copy the summaries into profiles/ afterwards)
+#   1. bench.py (default flags) JSON line + per-layer conv table
+#   2. rocprofv3 --kernel-trace --stats of the same command (rocpd database -> tools/prof_summary.py)
+#   3. rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, kernel trace only (-> tools/pmc_summary.py)
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/final
+mkdir -p $O
+cd $R
+python bench.py --steps 20 --warmup 5 --profile-table > $O/bench.json 2> $O/bench_table.txt
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $O/stats -- python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-roofline > $O/stats.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc/$c -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-roofline > $O/pmc_$c.log 2>&1
+  f=$(find $O/pmc/$c -name "*counter_collection.csv" | head -1)
+  cp "$f" $O/pmc/$c/p_counter_collection.csv
+done
+cd $R
+db=$(find $O/stats -name "*results.db" | head -1)
+python tools/prof_summary.py $db 11 > $O/kernel_stats.txt
+python tools/pmc_summary.py $O/pmc 4 $O/pmc_hbm_traffic.txt $O/pmc_hbm_traffic.json > /dev/null
+rm -rf $O/stats $O/pmc/*/runc $O/pmc/*/*/ 2>/dev/null
+head -5 $O/kernel_stats.txt; tail -1 $O/pmc_hbm_traffic.txt; tail -c 400 $O/bench.json
