@@ -82,6 +82,12 @@ int phx_pack_conv3x3_bf16_multi(const void* descs_dev, int n, void* stream);
 int phx_pad_channels_bf16(const void* x, int dt, int C, void* out, int Cpad, size_t npix, void* stream);
 int phx_unpad_channels_bf16(const void* src, void* dst, int dst_dt, int C, int Cpad, size_t npix, void* stream);
 int phx_unpad_filter_grad_accumulate(const float* dw_pad, float* dw_hwio, int Cin, int Cin_pad, int Cout, void* stream);
+/* Split-K variant for small maps (few pixel tiles): with a workspace of phx_conv3x3_mfma_ws_bytes (0: not used for this
+ * shape) and stats_partial == NULL, the K / 32 chunks are spread over several blocks per tile and a second kernel sums the
+ * fp32 slices and applies bias / activation.  Otherwise identical to phx_conv3x3_mfma_bf16. */
+size_t phx_conv3x3_mfma_ws_bytes(int B, int H, int W, int K, int N);
+int phx_conv3x3_mfma_bf16_ws(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
+                             void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream);
 /* number of pixel tiles (= rows of stats_partial) phx_conv3x3_mfma_bf16 uses for this shape */
 int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W, int K, int N);
 /* debug: device buffer of >= 16 uint64 that receives shader-clock phase timestamps of block 0 (NULL disables) */

@@ -168,12 +168,15 @@ __device__ unsigned long long* g_phx_blocklog = nullptr;   // debug: per-block {
 // NW = waves per block (4: 256-pixel tiles, two blocks per CU; 8: 512-pixel 16 x 32 tiles, one block per CU -- the
 // filter slab, 64 % of the staged bytes of a 256 x 64 tile, is then shared by twice the pixels: the kernel is bound
 // by the L2 -> LDS path (~12 B/clk/CU), so bytes staged per FLOP set its speed).
-template <int BN, int NA, bool FAST16, bool BIASACT, int NW>
+// SPLITK (small maps: a handful of pixel tiles cannot fill 256 CUs and each block would walk all K / 32 chunks serially,
+// ~2 us apiece): gridDim.z blocks share a tile, each takes a run of chunks and stores its fp32 accumulators to
+// ws[z][pixel][N]; k_splitk_finish sums the slices, adds bias / activation and writes the bf16 tensor.
+template <int BN, int NA, bool FAST16, bool BIASACT, int NW, bool SPLITK>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const unsigned short* __restrict__ x,
                                                          const unsigned short* __restrict__ wpk,
                                                          unsigned short* __restrict__ y, const float* __restrict__ bias,
                                                          int act, float* __restrict__ stats_partial, int B, int H, int W,
-                                                         int K, int N, MTile g) {
+                                                         int K, int N, MTile g, float* __restrict__ ws) {
     constexpr int NJ = BN / 32;
     constexpr int NT = NW * 64;                            // threads; the tile has NT pixels
     constexpr int NB = (9 * BN * 4 + NT - 1) / NT;        // filter-slab pieces per thread
@@ -254,11 +257,18 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
         else if constexpr (idx < NA + NB)
             rb[idx - NA] = __builtin_amdgcn_raw_buffer_load_b128(rsw, idx - NA == NB - 1 ? gbl : gb0, c0 * 2 + (idx - NA) * gbs, 0);
     };
+    // this block's run of 32-channel chunks [cbeg, cend)
+    int cbeg = 0, cend = K;
+    if constexpr (SPLITK) {
+        const int per = (K / KC + gridDim.z - 1) / gridDim.z;
+        cbeg = blockIdx.z * per * KC;
+        cend = min(K, cbeg + per * KC);
+    }
     {
         auto all = [&](auto self, auto idxc) {
             constexpr int idx = decltype(idxc)::value;
             if constexpr (idx < NA + NB) {
-                prefetch_piece(idxc, 0);
+                prefetch_piece(idxc, cbeg);
                 self(self, std::integral_constant<int, idx + 1>());
             }
         };
@@ -337,8 +347,27 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
     {
         const int cx0 = tx0, cy0 = ty0, cb0 = b0;
         const bool tr0 = true;
-        for (int c0 = 0; c0 + KC < K; c0 += KC) chunk(c0 + KC, std::true_type(), c0 == KC);
+        for (int c0 = cbeg; c0 + KC < cend; c0 += KC) chunk(c0 + KC, std::true_type(), c0 == KC);
         chunk(0, std::false_type(), K == 2 * KC);
+        if constexpr (SPLITK) {
+            // fp32 partial tile -> ws[z][pixel][N]; C layout: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+            float* wz = ws + (size_t)blockIdx.z * B * H * W * N;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
+                    const int ox = cx0 + lx, oy = cy0 + ly, ob = cb0 + lb;
+                    if (ox < W && oy < H && ob < B) {
+                        float* wr = wz + (((size_t)ob * H + oy) * W + ox) * N + n0 + l31;
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) wr[j * 32] = acc[i][j][r];
+                    }
+                }
+            PHX_BLOCKLOG_END();
+            return;
+        }
 
         // epilogue: C layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel).  The tile is transposed
         // through LDS ([pixel][BN] bf16, 16-byte padded rows) so that global stores are 16 bytes per lane, 128 contiguous
@@ -936,6 +965,25 @@ __global__ void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__
         atomicAdd(&dw[i], red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
 
+// y[pix][n] = bf16(act(sum_z ws[z][pix][n] + bias[n])), four channels per thread
+__global__ void k_splitk_finish(const float* __restrict__ ws, int nz, size_t total, int N, const float* __restrict__ bias,
+                                int act, unsigned short* __restrict__ y) {
+    for (size_t i4 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i4 * 4 < total; i4 += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = i4 * 4;
+        f32x4 a = *reinterpret_cast<const f32x4*>(ws + i);
+        for (int z = 1; z < nz; ++z) a += *reinterpret_cast<const f32x4*>(ws + (size_t)z * total + i);
+        if (bias != nullptr || act != PHX_ACT_ID) {
+            const int n = (int)(i % N);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = act_fwd(a[q] + (bias ? bias[n + q] : 0.f), act);
+        }
+        uint2 o;
+        o.x = f2bf_pk(a[0], a[1]);
+        o.y = f2bf_pk(a[2], a[3]);
+        *reinterpret_cast<uint2*>(y + i) = o;
+    }
+}
+
 extern "C" {
 
 int phx_pack_conv3x3_bf16(const float* w_hwio, void* wpk_fwd, void* wpk_dgrad, int Cin, int Cout, void* stream) {
@@ -1001,10 +1049,44 @@ int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W, int K, int N) {
     return g.tiles_x * g.tiles_y * g.tiles_b;
 }
 
+// split-K factor for the forward / data-gradient kernel: > 1 only for the 256-pixel-tile kernels on maps whose tiles x
+// channel blocks leave most CUs idle (H <= 16 at batch 64); aims at ~256 blocks
+static int fwd_ksplit(int B, int H, int W, int K, int N) {
+    const char* e = getenv("PHX_FWD_SPLITK");
+    if (e && atoi(e) == 0) return 1;
+    if (fwd_big_tiles(B, H, W, K, N)) return 1;
+    MTile g = make_mtile(B, H, W);
+    const int blocks = g.tiles_x * g.tiles_y * g.tiles_b * (N / (N % 64 == 0 ? 64 : 32));
+    const int nck = K / KC;
+    static int tgt = 0;
+    if (!tgt) { const char* t = getenv("PHX_FWD_SPLITK_BLOCKS"); tgt = t ? atoi(t) : 128; }    // tuning hook
+    if (blocks * 2 > tgt || nck < 2) return 1;
+    int ks = (tgt + blocks - 1) / blocks;
+    if (ks > nck) ks = nck;
+    const int per = (nck + ks - 1) / ks;
+    return (nck + per - 1) / per;                    // no empty slices
+}
+
+size_t phx_conv3x3_mfma_ws_bytes(int B, int H, int W, int K, int N) {
+    const int ks = fwd_ksplit(B, H, W, K, N);
+    return ks > 1 ? (size_t)ks * B * H * W * N * sizeof(float) : 0;
+}
+
 int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
                           int B, int H, int W, int K, int N, void* stream) {
+    return phx_conv3x3_mfma_bf16_ws(x, wpk, y, bias, act, stats_partial, nullptr, 0, B, H, W, K, N, stream);
+}
+
+int phx_conv3x3_mfma_bf16_ws(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
+                             void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream) {
     PHX_REQUIRE(K % KC == 0 && N % 32 == 0, PHX_E_SHAPE, "conv3x3_mfma: K % 32 == 0 and N % 32 == 0 required");
     PHX_REQUIRE((((uintptr_t)x | (uintptr_t)wpk | (uintptr_t)y) & 15) == 0, PHX_E_ALIGN, "conv3x3_mfma: 16-byte alignment");
+    int ksplit = 1;
+    if (workspace && !stats_partial) {
+        ksplit = fwd_ksplit(B, H, W, K, N);
+        PHX_REQUIRE(workspace_bytes >= (size_t)(ksplit > 1 ? ksplit : 0) * B * H * W * N * sizeof(float), PHX_E_INVAL,
+                    "conv3x3_mfma: workspace too small");
+    }
     MTile g = make_mtile_fwd(B, H, W, K, N);
     const bool big = fwd_big_tiles(B, H, W, K, N);
     const int tw = 1 << g.tws, th = 1 << g.ths;
@@ -1012,13 +1094,15 @@ int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* 
     const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
     PHX_REQUIRE((double)B * H * W * (K > N ? K : N) < 2147483648.0, PHX_E_SHAPE, "conv3x3_mfma: tensor exceeds 2^31 elements");
     static bool attr_set = false;
-#define CM_ATTR1(BNv, NAv, Fv, Av, NWv)                                                                              \
-    PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_mfma<BNv, NAv, Fv, Av, NWv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-#define CM_ATTR(BNv, NAv, Fv, NWv) CM_ATTR1(BNv, NAv, Fv, false, NWv); CM_ATTR1(BNv, NAv, Fv, true, NWv)
+#define CM_ATTR1(BNv, NAv, Fv, Av, NWv, Sv)                                                                          \
+    PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_mfma<BNv, NAv, Fv, Av, NWv, Sv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+#define CM_ATTR(BNv, NAv, Fv, NWv) CM_ATTR1(BNv, NAv, Fv, false, NWv, false); CM_ATTR1(BNv, NAv, Fv, true, NWv, false)
     if (!attr_set) {
         CM_ATTR(64, 8, false, 4); CM_ATTR(32, 8, false, 4); CM_ATTR(64, 16, false, 4); CM_ATTR(32, 16, false, 4);
         CM_ATTR(64, 8, true, 4); CM_ATTR(32, 8, true, 4);
         CM_ATTR(128, 5, true, 8); CM_ATTR(64, 5, true, 8); CM_ATTR(32, 5, true, 8);
+        CM_ATTR1(64, 8, false, false, 4, true); CM_ATTR1(32, 8, false, false, 4, true); CM_ATTR1(64, 16, false, false, 4, true);
+        CM_ATTR1(32, 16, false, false, 4, true); CM_ATTR1(64, 8, true, false, 4, true); CM_ATTR1(32, 8, true, false, 4, true);
         attr_set = true;
     }
 #undef CM_ATTR
@@ -1027,17 +1111,27 @@ int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* 
     PHX_REQUIRE(na <= 16, PHX_E_SHAPE, "conv3x3_mfma: unexpected tile geometry");
     const bool biasact = bias != nullptr || act != PHX_ACT_ID;
     // (the OROW-pitched epilogue tile also has to fit: NT * (2 BN + 16) bytes)
-#define CM_LAUNCH1(BNv, NAv, Fv, Av, NWv)                                                                            \
+#define CM_LAUNCH1(BNv, NAv, Fv, Av, NWv, Sv)                                                                          \
     do {                                                                                                             \
         size_t sh = (size_t)npatch * ROWB + 9 * BNv * ROWB;                                                          \
         const size_t she = (size_t)NWv * 64 * (BNv * 2 + 16);                                                        \
         if (she > sh) sh = she;                                                                                      \
-        hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, Av, NWv>), dim3(ntiles, N / BNv), dim3(NWv * 64), sh,       \
-                           (hipStream_t)stream, (const unsigned short*)x, (const unsigned short*)wpk,                \
-                           (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, g);                          \
+        if (Sv)                                                                                                      \
+            hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, false, NWv, Sv>), dim3(ntiles, N / BNv, ksplit),        \
+                               dim3(NWv * 64), sh, (hipStream_t)stream, (const unsigned short*)x,                    \
+                               (const unsigned short*)wpk, (unsigned short*)y, nullptr, 0, nullptr, B, H, W, K, N, g,\
+                               (float*)workspace);                                                                   \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, Av, NWv, false>), dim3(ntiles, N / BNv), dim3(NWv * 64),\
+                               sh, (hipStream_t)stream, (const unsigned short*)x, (const unsigned short*)wpk,        \
+                               (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, g, nullptr);             \
     } while (0)
 #define CM_LAUNCH(BNv, NAv, Fv, NWv)                                                                                 \
-    do { if (biasact) CM_LAUNCH1(BNv, NAv, Fv, true, NWv); else CM_LAUNCH1(BNv, NAv, Fv, false, NWv); } while (0)
+    do {                                                                                                             \
+        if (NWv == 4 && ksplit > 1) CM_LAUNCH1(BNv, NAv, Fv, false, NWv, (NWv == 4));                                \
+        else if (biasact) CM_LAUNCH1(BNv, NAv, Fv, true, NWv, false);                                                \
+        else CM_LAUNCH1(BNv, NAv, Fv, false, NWv, false);                                                            \
+    } while (0)
     const bool fast16 = g.tws == 4 && g.ths == 4 && g.tb == 1;
     if (big) {
         if (N % 128 == 0) CM_LAUNCH(128, 5, true, 8); else if (N % 64 == 0) CM_LAUNCH(64, 5, true, 8); else CM_LAUNCH(32, 5, true, 8);
@@ -1049,6 +1143,12 @@ int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* 
 #undef CM_LAUNCH
 #undef CM_LAUNCH1
     PHX_CHECK_LAUNCH();
+    if (ksplit > 1) {
+        const size_t total = (size_t)B * H * W * N;
+        hipLaunchKernelGGL(k_splitk_finish, dim3(phx_grid_for(total / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)workspace, ksplit, total, N, bias, act, (unsigned short*)y);
+        PHX_CHECK_LAUNCH();
+    }
     return PHX_OK;
 }
 

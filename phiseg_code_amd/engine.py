@@ -445,8 +445,11 @@ class Plan:
             if head1x1:
                 self._emit(Lb.head1x1_fwd, x.ptr, x.dt, wptr, bptr, y.ptr, B * H * Wd, cin, cout, act_code, S)
             elif mfma:
-                self._emit(Lb.conv3x3_mfma_bf16, x.ptr, wf.ptr, y.ptr, bptr, act_code,
-                           stats_part.ptr if stats_part is not None else None, B, H, Wd, cin_eff, cout, S,
+                wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cin_eff, cout)) if stats_part is None else 0
+                ws = self._alloc((wsb // 4,), F32) if wsb else None          # split-K slices (small maps)
+                self._emit(Lb.conv3x3_mfma_bf16_ws, x.ptr, wf.ptr, y.ptr, bptr, act_code,
+                           stats_part.ptr if stats_part is not None else None, ws.ptr if ws else None, wsb,
+                           B, H, Wd, cin_eff, cout, S,
                            tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
             else:
                 self._emit(Lb.conv2d_direct, x.ptr, x.dt, wptr, bptr, y.ptr, y.dt, B, H, Wd, cin, cout, k, act_code,
@@ -791,9 +794,13 @@ class Plan:
                 self._add_grad(xin, write_fn=wr)
             elif sv["mfma"]:
                 _, wd = self._packed(W)
-                self._add_grad(xin, write_fn=lambda g: self._emit(
-                    Lb.conv3x3_mfma_bf16, dY.ptr, wd.ptr, g.ptr, None, 0, None, B, H, Wd, cout, cin, S,
-                    tag="conv3x3_mfma_dgrad", flops=18.0 * cin * cout * B * H * Wd))
+
+                def wr_mfma(g):
+                    wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cout, cin))
+                    ws = self._alloc((wsb // 4,), F32) if wsb else None      # split-K slices (small maps)
+                    self._emit(Lb.conv3x3_mfma_bf16_ws, dY.ptr, wd.ptr, g.ptr, None, 0, None, ws.ptr if ws else None, wsb,
+                               B, H, Wd, cout, cin, S, tag="conv3x3_mfma_dgrad", flops=18.0 * cin * cout * B * H * Wd)
+                self._add_grad(xin, write_fn=wr_mfma)
             else:
                 self._add_grad(xin, write_fn=lambda g: self._emit(
                     Lb.conv2d_direct, dY.ptr, dY.dt, self.store.ptr(W), None, g.ptr, g.dt, B, H, Wd, cin, cout, k, 0,

@@ -185,6 +185,15 @@ def _mfma_case(L, case):
     L.conv3x3_mfma_bf16(xd.data_ptr(), wf.data_ptr(), y.data_ptr(), None, 0, None, B, H, W, K, N, S())
     pre = T.conv2d_same(xr, wr)
     close(host(y), pre.detach().numpy(), 6e-3, "mfma fwd id")
+    # split-K variant (used when the shape has few pixel tiles; same result, with and without bias / activation)
+    wsb = int(L.conv3x3_mfma_ws_bytes(B, H, W, K, N))
+    wsk = torch.empty(max(wsb // 4, 1), dtype=torch.float32).cuda()
+    y2 = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
+    L.conv3x3_mfma_bf16_ws(xd.data_ptr(), wf.data_ptr(), y2.data_ptr(), None, 0, None, wsk.data_ptr(), wsb, B, H, W, K, N, S())
+    close(host(y2), pre.detach().numpy(), 6e-3, "mfma fwd id (split-K path)")
+    L.conv3x3_mfma_bf16_ws(xd.data_ptr(), wf.data_ptr(), y2.data_ptr(), bd.data_ptr(), 1, None, wsk.data_ptr(), wsb, B, H, W, K, N,
+                           S())
+    close(host(y2), yr.detach().numpy(), 6e-3, "mfma fwd bias relu (split-K path)")
     dy = RNG.standard_normal((B, H, W, N))
     dyr = rounded(dy, BF16)
     (pre * dyr).sum().backward()

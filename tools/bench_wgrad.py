@@ -17,11 +17,14 @@ for (B, H, W, K, N) in shapes:
     wsp = ws.data_ptr() if wsb else None
     wf = torch.randn(9 * K * N, device="cuda").to(torch.bfloat16)
     y = torch.empty(B, H, W, N, device="cuda", dtype=torch.bfloat16)
+    fwsb = int(L.conv3x3_mfma_ws_bytes(B, H, W, K, N)) if os.environ.get("PHX_FWD_WS", "1") == "1" else 0
+    fws = torch.empty(max(fwsb // 4, 1), device="cuda")
     def run():
         if which == "wgrad":
             L.conv3x3_wgrad_mfma_bf16(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), wsp, wsb, B, H, W, K, N, st)
         else:
-            L.conv3x3_mfma_bf16(x.data_ptr(), wf.data_ptr(), y.data_ptr(), None, 0, None, B, H, W, K, N, st)
+            L.conv3x3_mfma_bf16_ws(x.data_ptr(), wf.data_ptr(), y.data_ptr(), None, 0, None, fws.data_ptr() if fwsb else None, fwsb,
+                                   B, H, W, K, N, st)
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
