@@ -4,7 +4,6 @@
 // One thread = one output pixel x COT output channels; input patch and filter slab staged in LDS.
 #include "phx_common.h"
 
-#define CI_T 8
 
 struct TileGeo {
     int tws, ths, tb;       // tile = tb images x (1<<ths) rows x (1<<tws) cols = 256 pixels
@@ -26,7 +25,8 @@ static TileGeo make_geo(int B, int H, int W) {
     return g;
 }
 
-template <typename TI, typename TO, int COT, int KS>
+// CIT = input channels per LDS stage (8; 32 for wide inputs with <= 4 output channels: a quarter of the serial stages)
+template <typename TI, typename TO, int COT, int KS, int CIT>
 __global__ __launch_bounds__(256) void k_conv_direct(const TI* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, TO* __restrict__ y,
                                                      float* __restrict__ stats, int B, int H, int W, int Cx, int Cy,
@@ -36,8 +36,8 @@ __global__ __launch_bounds__(256) void k_conv_direct(const TI* __restrict__ x, c
     const int pw = tw + KS - 1, ph = th + KS - 1;
     const int npatch = g.tb * ph * pw;
     extern __shared__ float smem[];
-    float* sx = smem;                         // [CI_T][npatch]
-    float* sw = smem + CI_T * npatch;         // [KS*KS][CI_T][COT]
+    float* sx = smem;                         // [CIT][npatch]
+    float* sw = smem + CIT * npatch;         // [KS*KS][CIT][COT]
 
     int t = blockIdx.x;
     const int tx0 = (t % g.tiles_x) << g.tws; t /= g.tiles_x;
@@ -55,11 +55,11 @@ __global__ __launch_bounds__(256) void k_conv_direct(const TI* __restrict__ x, c
 #pragma unroll
     for (int j = 0; j < COT; ++j) acc[j] = 0.f;
 
-    for (int c0 = 0; c0 < Cx; c0 += CI_T) {
+    for (int c0 = 0; c0 < Cx; c0 += CIT) {
         __syncthreads();
         // stage the input patch (zero padded), channel fastest in the global read
-        for (int i = threadIdx.x; i < npatch * CI_T; i += 256) {
-            const int ci = i % CI_T, pp = i / CI_T;
+        for (int i = threadIdx.x; i < npatch * CIT; i += 256) {
+            const int ci = i % CIT, pp = i / CIT;
             const int px = pp % pw, py = (pp / pw) % ph, pb = pp / (pw * ph);
             const int gx = tx0 + px - PAD, gy = ty0 + py - PAD, gb = b0 + pb;
             float v = 0.f;
@@ -68,8 +68,8 @@ __global__ __launch_bounds__(256) void k_conv_direct(const TI* __restrict__ x, c
             sx[ci * npatch + pp] = v;
         }
         // stage the filter slab
-        for (int i = threadIdx.x; i < KS * KS * CI_T * COT; i += 256) {
-            const int j = i % COT, ci = (i / COT) % CI_T, tap = i / (COT * CI_T);
+        for (int i = threadIdx.x; i < KS * KS * CIT * COT; i += 256) {
+            const int j = i % COT, ci = (i / COT) % CIT, tap = i / (COT * CIT);
             const int inc = c0 + ci, outc = co0 + j;
             float v = 0.f;
             if (inc < Cx && outc < Cy) {
@@ -84,9 +84,9 @@ __global__ __launch_bounds__(256) void k_conv_direct(const TI* __restrict__ x, c
 #pragma unroll
             for (int kw = 0; kw < KS; ++kw) {
                 const int poff = pbase + kh * pw + kw;
-                const float* wt = sw + (kh * KS + kw) * CI_T * COT;
+                const float* wt = sw + (kh * KS + kw) * CIT * COT;
 #pragma unroll
-                for (int ci = 0; ci < CI_T; ++ci) {
+                for (int ci = 0; ci < CIT; ++ci) {
                     const float xv = sx[ci * npatch + poff];
 #pragma unroll
                     for (int j = 0; j < COT; ++j) acc[j] = fmaf(xv, wt[ci * COT + j], acc[j]);
@@ -199,16 +199,17 @@ int phx_conv2d_direct(const void* x, int x_dt, const float* w_hwio, const float*
     const int tw = 1 << g.tws, th = 1 << g.ths;
     const int npatch = g.tb * (th + ksize - 1) * (tw + ksize - 1);
     const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
-#define CD_LAUNCH(COT, KS)                                                                                           \
+#define CD_LAUNCH(COT, KS, CIT)                                                                                      \
     do {                                                                                                             \
-        const size_t sh = (size_t)(CI_T * npatch + KS * KS * CI_T * COT) * sizeof(float);                            \
-        hipLaunchKernelGGL((k_conv_direct<TI, TO, COT, KS>), dim3(ntiles, (Cy + COT - 1) / COT), dim3(256), sh,      \
+        const size_t sh = (size_t)(CIT * npatch + KS * KS * CIT * COT) * sizeof(float);                              \
+        hipLaunchKernelGGL((k_conv_direct<TI, TO, COT, KS, CIT>), dim3(ntiles, (Cy + COT - 1) / COT), dim3(256), sh, \
                            (hipStream_t)stream, (const TI*)x, w_hwio, bias, (TO*)y, stats, B, H, W, Cx, Cy, Cin, Cout, \
                            act, transpose_flip, g);                                                                  \
     } while (0)
     PHX_DT_SWITCH(x_dt, TI, PHX_DT_SWITCH(y_dt, TO, {
-        if (Cy <= 4) { if (ksize == 3) CD_LAUNCH(4, 3); else CD_LAUNCH(4, 1); }
-        else { if (ksize == 3) CD_LAUNCH(16, 3); else CD_LAUNCH(16, 1); }
+        if (Cy <= 4 && Cx >= 64) { if (ksize == 3) CD_LAUNCH(4, 3, 32); else CD_LAUNCH(4, 1, 32); }
+        else if (Cy <= 4) { if (ksize == 3) CD_LAUNCH(4, 3, 8); else CD_LAUNCH(4, 1, 8); }
+        else { if (ksize == 3) CD_LAUNCH(16, 3, 8); else CD_LAUNCH(16, 1, 8); }
     }));
 #undef CD_LAUNCH
     PHX_CHECK_LAUNCH();
