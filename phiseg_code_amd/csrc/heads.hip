@@ -129,7 +129,26 @@ __global__ void k_head1x1_wgrad(const TX* __restrict__ x, const float* __restric
     const size_t p0 = (size_t)blockIdx.x * chunk;
     const size_t p1 = p0 + chunk < npix ? p0 + chunk : npix;
     if (pl < PL) {
-        for (size_t p = p0 + pl; p < p1; p += PL) {
+        size_t p = p0 + pl;
+        for (; p + 3 * (size_t)PL < p1; p += 4 * (size_t)PL) {    // four pixels per trip, loads first (latency-bound otherwise)
+            float xv[4][V], d[4][NOUT];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                HVec<TX, V>::load(x, (p + (size_t)u * PL) * C + (size_t)cv * V, xv[u]);
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) d[u][o] = dy[(p + (size_t)u * PL) * NOUT + o];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) accb[o] += d[u][o];
+#pragma unroll
+                for (int j = 0; j < V; ++j)
+#pragma unroll
+                    for (int o = 0; o < NOUT; ++o) acc[j][o] = fmaf(xv[u][j], d[u][o], acc[j][o]);
+            }
+        }
+        for (; p < p1; p += PL) {
             float xv[V], d[NOUT];
             HVec<TX, V>::load(x, p * C + (size_t)cv * V, xv);
 #pragma unroll
