@@ -942,27 +942,40 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_dma(const unsigned sho
     PHX_BLOCKLOG_END();
 }
 
-// dw[k][ci][co] += sum over the nslice partial tiles written by k_conv3x3_wgrad.  Block = 64 filter entries x 4 slice
-// groups; gridDim.y further splits the slices (one atomic per entry per y-block).
+// dw[k][ci][co] += sum over the nslice partial tiles written by the filter-gradient kernels.  A thread owns four
+// consecutive co entries (16-byte loads); block = 64 such quads x 4 slice groups; gridDim.y further splits the slices
+// (one atomic per entry per y-block); four slices are in flight per thread.
 __global__ void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw, int nslice, int Cin, int Cout,
                                int tci, int tco) {
     const int tile_elems = 9 * tci * tco;
     const int ntile_ci = Cin / tci;
     const size_t total = (size_t)9 * Cin * Cout;
-    const size_t i = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const size_t i = ((size_t)blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     const int sg = threadIdx.x >> 6;
-    float a = 0.f;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
     if (i < total) {
         const int co = (int)(i % Cout), ci = (int)((i / Cout) % Cin), k = (int)(i / ((size_t)Cout * Cin));
         const int cb = (co / tco) * ntile_ci + (ci / tci);
         const float* p = ws + (size_t)cb * nslice * tile_elems + (k * tci + ci % tci) * tco + co % tco;
-        for (int sidx = blockIdx.y * 4 + sg; sidx < nslice; sidx += gridDim.y * 4) a += p[(size_t)sidx * tile_elems];
+        const int step = gridDim.y * 4;
+        int sidx = blockIdx.y * 4 + sg;
+        for (; sidx + 3 * step < nslice; sidx += 4 * step) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)sidx * tile_elems);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(sidx + step) * tile_elems);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (size_t)(sidx + 2 * step) * tile_elems);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (size_t)(sidx + 3 * step) * tile_elems);
+            a += (v0 + v1) + (v2 + v3);
+        }
+        for (; sidx < nslice; sidx += step) a += *reinterpret_cast<const f32x4*>(p + (size_t)sidx * tile_elems);
     }
-    __shared__ float red[256];
+    __shared__ f32x4 red[256];
     red[threadIdx.x] = a;
     __syncthreads();
-    if (sg == 0 && i < total)
-        atomicAdd(&dw[i], red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+    if (sg == 0 && i < total) {
+        const f32x4 r = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) atomicAdd(&dw[i + q], r[q]);
+    }
 }
 
 // y[pix][n] = bf16(act(sum_z ws[z][pix][n] + bias[n])), four channels per thread
@@ -1244,7 +1257,7 @@ int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, v
         int gy = nslice / 16;
         if (gy < 1) gy = 1;
         if (gy > 16) gy = 16;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 63) / 64), gy), dim3(256), 0, (hipStream_t)stream, ws,
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total / 4 + 63) / 64), gy), dim3(256), 0, (hipStream_t)stream, ws,
                            dw_hwio, nslice, Cin, Cout, tci, tco);
         PHX_CHECK_LAUNCH();
     }
