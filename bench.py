@@ -76,7 +76,7 @@ def main():
     from phiseg_code_amd.data import synthetic
     from phiseg_code_amd.phiseg import phiseg_model
 
-    ctx = distributed.DistContext()
+    ctx = distributed.DistContext(force=os.environ.get("PHX_FORCE_DIST") == "1")   # dev: exercise the split path on one GPU
     assert ctx.world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     cfg = make_config(args.batch, args.dtype)
     model = phiseg_model.phiseg(cfg, dist=ctx if ctx.active else None)

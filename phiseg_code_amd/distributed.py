@@ -34,12 +34,22 @@ class DistContext:
 
     def allreduce_sum(self, tensor, plan=None, bucket_elems=8 << 20):
         """Sum `tensor` (the flat gradient arena) over ranks, in ~32 MB buckets so RCCL pipelines them over
-        the xGMI links.  `plan`: the engine plan whose stream produced the gradients (synchronised first)."""
+        the xGMI links.  `plan`: the engine plan whose stream produced the gradients and will consume the sums.
+        On the GPU nothing blocks the host: the collectives are enqueued against the plan's own HIP stream (wrapped
+        as a torch ExternalStream), so RCCL waits for the backward graph and the optimizer graph waits for RCCL."""
         if not self.active:
+            return
+        flat = tensor.view(-1)
+        if self.cuda and plan is not None:
+            ext = torch.cuda.ExternalStream(int(plan.stream_handle()))
+            with torch.cuda.stream(ext):
+                works = [dist.all_reduce(flat[i:i + bucket_elems], op=dist.ReduceOp.SUM, async_op=True)
+                         for i in range(0, flat.numel(), bucket_elems)]
+                for w in works:
+                    w.wait()                  # stream-side wait: the plan's stream waits for RCCL
             return
         if plan is not None:
             plan.sync()
-        flat = tensor.view(-1)
         works = [dist.all_reduce(flat[i:i + bucket_elems], op=dist.ReduceOp.SUM, async_op=True)
                  for i in range(0, flat.numel(), bucket_elems)]
         for w in works:

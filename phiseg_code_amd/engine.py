@@ -877,6 +877,10 @@ class Plan:
     def sync(self):
         self.L.stream_sync(self.stream)
 
+    def stream_handle(self):
+        """hipStream_t (as int) of the origin lane: graph launches are enqueued on it and every lane joins into it."""
+        return int(self._lanes[0].value or 0)
+
     def time_tagged_kernels(self, repeats=3):
         """Per tagged launch (the bf16 MFMA convolutions): average GPU duration over `repeats` back-to-back
         re-launches, bracketed by HIP events on THIS plan's stream.  -> list of (tag, flops, ms, args-shape)."""
