@@ -45,7 +45,27 @@ static bool fwd_big_tiles(int B, int H, int W, int K, int N) {
     if (en == 2) return true;                                  // dev: force
     return (N % 128 == 0 || (N == 32 && K >= 128)) && (long)B * (H / 32) * (W / 16) >= 512;
 }
-static MTile make_mtile_fwd(int B, int H, int W, int K, int N) {
+// 32 x 16-tile LDS-DMA kernel (k_conv3x3_fwd_dma): 0 = not used, else the channel-block width
+static int fwd_dma_bn(int B, int H, int W, int K, int N) {
+    // Measured (tools/bench_wgrad.py, tools/blocklog.py): 776 vs 826 TFLOP/s against the register-staged 8-wave kernel on
+    // the 128->128 @ 128x128 layer.  16-channel stages fetch 32 contiguous bytes per pixel / filter row, half a 64-byte
+    // sector, so the staging path moves twice the bytes it delivers (7.7 K cycles per stage against 4.6 K of MFMA work), and
+    // one block per CU pays ~6 K cycles of dispatch gap per tile.  Kept as a tested experimental path: off by default.
+    const char* e = getenv("PHX_FWD_DMA");                     // default 0: never; 1: policy; 2: whenever eligible (tests)
+    const int en = e ? atoi(e) : 0;
+    if (!en || H % 16 != 0 || W % 32 != 0 || K % 16 != 0 || N % 64 != 0) return 0;
+    const int bn = N % 128 == 0 ? 128 : 64;
+    if (en == 2) return bn;
+    if (en == 3) return 64;                                    // tuning: 64-wide blocks everywhere
+    return (N % 128 == 0 && (long)B * (H / 16) * (W / 32) >= 512) ? 128 : 0;
+}
+static MTile make_mtile_fwd(int B, int H, int W, int K, int N, bool allow_dma = true) {
+    if (allow_dma && fwd_dma_bn(B, H, W, K, N)) {
+        MTile g;
+        g.tws = 5; g.ths = 4; g.tb = 1;
+        g.tiles_x = W / 32; g.tiles_y = H / 16; g.tiles_b = B;
+        return g;
+    }
     if (!fwd_big_tiles(B, H, W, K, N)) return make_mtile(B, H, W);
     MTile g;
     g.tws = 4; g.ths = 5; g.tb = 1;
@@ -483,6 +503,200 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
         }
     }
     PHX_BLOCKLOG_END();
+}
+
+// ---- forward / data-gradient, 32x16-pixel tiles, LDS-DMA staging -----------------------------------------------------
+// The kernels above are bound by the global -> LDS path, i.e. by staged bytes per FLOP.  This one stages 16-channel
+// slices of a 512-pixel (32 x 16) patch and of a BN-wide filter slab with buffer_load ... lds (no staging registers, no
+// ds_write pass) into a DOUBLE-BUFFERED LDS image: the DMA of stage s+2 is issued right after the MFMAs of stage s and
+// lands under those of stage s+1 (counted vmcnt, raw s_barrier).  8 waves: wave = (pixel group pg of 4 tile rows) x
+// (channel half cg); 4 x NJ accumulators of 32 px x 32 ch per wave.
+// LDS rows are 32 bytes (16 channels), two 16-byte slots; slot = k-half ^ bit 3 of (patch column | channel), applied on
+// the DMA source side (the destination is lane-linear): a ds_read_b128 lane group then covers all 16 slots of the
+// 256-byte bank row exactly once, and every read address is a per-lane base plus an immediate.
+template <int BN, bool BIASACT>
+__global__ __launch_bounds__(512, 1) void k_conv3x3_fwd_dma(const unsigned short* __restrict__ x,
+                                                            const unsigned short* __restrict__ wpk,
+                                                            unsigned short* __restrict__ y, const float* __restrict__ bias,
+                                                            int act, float* __restrict__ stats_partial,
+                                                            int B, int H, int W, int K, int N, int tiles_x, int tiles_y) {
+    constexpr int NJ = BN / 64;                       // 32-channel accumulator tiles per wave
+    constexpr int AI = 20, BI = 9 * BN * 32 / 1024;   // 1 KiB DMA instructions per stage: patch (612 rows -> 20), slab
+    constexpr int NPW = (AI + BI + 7) / 8;            // per wave (7 for BN = 128; 5 with two dummies for BN = 64)
+    constexpr int STAGE = NPW * 8 * 1024;
+    constexpr int A_BYTES = AI * 1024;
+    constexpr int OROW = BN * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int t = blockIdx.x;
+    const int tx0 = (t % tiles_x) << 5; t /= tiles_x;
+    const int ty0 = (t % tiles_y) << 4; t /= tiles_y;
+    const int b0 = t;
+    const int n0 = blockIdx.y * BN;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int pg = wave & 3, cg = wave >> 2;
+
+    // DMA plan: instruction j = wave + 8 n fills LDS bytes [j KiB, (j+1) KiB) of the stage; this lane's slot e = 64 j + lane
+    unsigned voff[NPW];
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+        const int j = wave + 8 * n;
+        voff[n] = 0xffffffffu;
+        if (j < AI) {
+            const int e = j * 64 + lane, pp = e >> 1, slot = e & 1;
+            const int py = pp / 34, px = pp - py * 34;
+            const int h = slot ^ ((px >> 3) & 1);
+            const int gx = tx0 + px - 1, gy = ty0 + py - 1;
+            if (pp < 612 && gx >= 0 && gx < W && gy >= 0 && gy < H) voff[n] = (unsigned)((((b0 * H + gy) * W + gx) * K) * 2 + h * 16);
+        } else if (j < AI + BI) {
+            const int e = (j - AI) * 64 + lane, rb = e >> 1, slot = e & 1;
+            const int tap = rb / BN, nn = rb - tap * BN;
+            const int h = slot ^ ((nn >> 3) & 1);
+            voff[n] = (unsigned)((((tap * N + n0 + nn) * K)) * 2 + h * 16);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, (int)(9u * N * K * 2u), 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    // all NPW DMA instructions of one stage (channels 16 stage ..) into buffer buf
+#define FWD_DMA_ISSUE(stage, buf)                                                                                      \
+    _Pragma("unroll") for (int n_ = 0; n_ < NPW; ++n_) {                                                               \
+        const int j_ = wave + 8 * n_;                                                                                  \
+        if (j_ < AI)                                                                                                   \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + (buf) * STAGE + j_ * 1024), 16, (int)voff[n_],\
+                                                     (stage) * 32, 0, 0);                                              \
+        else                                                                                                           \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(smem + (buf) * STAGE + j_ * 1024), 16, (int)voff[n_],\
+                                                     (stage) * 32, 0, 0);                                              \
+    }
+
+    // per-lane read bases (stage 0); tap / row-tile / channel-tile terms are immediates
+    unsigned aK[3], bK;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+        aK[kw] = (unsigned)((pg * 4 * 34 + l31 + kw) * 32 + (((khalf ^ ((l31 + kw) >> 3)) & 1) << 4));
+    bK = (unsigned)(A_BYTES + (cg * (BN / 2) + l31) * 32 + (((khalf ^ (l31 >> 3)) & 1) << 4));
+
+    f32x16 acc[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    PHX_BLOCKLOG_BEGIN();
+    const int nst = K / 16;
+    FWD_DMA_ISSUE(0, 0)
+    if (nst > 1) { FWD_DMA_ISSUE(1, 1) }
+    for (int s = 0; s < nst; ++s) {
+        // stage s has landed once at most the NPW instructions of stage s+1 are still outstanding
+        if (s + 1 < nst) {
+            if constexpr (NPW == 7) asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        const unsigned sb = (unsigned)((s & 1) * STAGE);
+        // nine taps: fragments of tap t+1 are read before the MFMAs of tap t (double-buffered, order pinned)
+        bf16x8 fa[2][4], fb[2][NJ];
+        auto read_frags = [&](auto tc) {
+            constexpr int tp = decltype(tc)::value;
+            constexpr int kh = tp / 3, kw = tp % 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                fa[tp & 1][i] = *reinterpret_cast<const bf16x8*>(smem + sb + aK[kw] + (i + kh) * 34 * 32);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                fb[tp & 1][j] = *reinterpret_cast<const bf16x8*>(smem + sb + bK + (tp * BN + j * 32) * 32);
+        };
+        read_frags(std::integral_constant<int, 0>());
+        auto taps = [&](auto self, auto tc) {
+            constexpr int tp = decltype(tc)::value;
+            if constexpr (tp < 9) {
+                if constexpr (tp < 8) read_frags(std::integral_constant<int, tp + 1>());
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tp & 1][i], fb[tp & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                self(self, std::integral_constant<int, tp + 1>());
+            }
+        };
+        taps(taps, std::integral_constant<int, 0>());
+        if (s + 2 < nst) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done reading this buffer
+            FWD_DMA_ISSUE(s + 2, s & 1)
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // operand reads done: LDS becomes the output tile
+
+    // epilogue (interior tiles only): pack pairs of rows, statistics, transpose through LDS, 16-byte stores
+    if constexpr (BIASACT) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float bv = bias ? bias[n0 + cg * (BN / 2) + j * 32 + l31] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r] + bv, act);
+        }
+    }
+    const int odd = lane & 1;
+    float s1[NJ], s2[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) s1[j] = s2[j] = 0.f;
+    unsigned char* lw = smem + (pg * 128 + 4 * khalf + odd) * OROW + (cg * (BN / 2) + (l31 & ~1)) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int r0 = 2 * rp;
+                const unsigned w2 = f2bf_pk(acc[i][j][r0], acc[i][j][r0 + 1]);
+                const float ra_ = __uint_as_float(w2 << 16), rb_ = __uint_as_float(w2 & 0xffff0000u);
+                s1[j] += ra_ + rb_;
+                s2[j] += ra_ * ra_ + rb_ * rb_;
+                const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)w2, 0xB1, 0xf, 0xf, true);
+                const unsigned word = odd ? ((nb >> 16) | (w2 & 0xffff0000u)) : ((w2 & 0xffffu) | (nb << 16));
+                *reinterpret_cast<unsigned*>(lw + (i * 32 + (r0 & 3) + 8 * (r0 >> 2)) * OROW + j * 64) = word;
+            }
+    __syncthreads();
+    {
+        constexpr int PPP = BN / 8;                   // 16-byte pieces per pixel
+        constexpr int PSTEP = 512 / PPP;              // pixels between a thread's pieces: 32 (one tile row) or 64
+        const int mt = threadIdx.x / PPP, q = threadIdx.x % PPP;
+        const unsigned char* lr = smem + mt * OROW + q * 16;
+        unsigned short* yp = y + (((size_t)b0 * H + ty0 + (mt >> 5)) * W + tx0 + (mt & 31)) * N + n0 + q * 8;
+        const size_t ystep = (size_t)(PSTEP / 32) * W * N;
+#pragma unroll
+        for (int it = 0; it < PPP; ++it)
+            *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * PSTEP * OROW);
+    }
+    if (stats_partial) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);      // [4 pixel groups][2][BN]
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float a = s1[j] + __shfl_xor(s1[j], 32, 64);
+            const float bq = s2[j] + __shfl_xor(s2[j], 32, 64);
+            if (khalf == 0) {
+                red[(pg * 2 + 0) * BN + cg * (BN / 2) + j * 32 + l31] = a;
+                red[(pg * 2 + 1) * BN + cg * (BN / 2) + j * 32 + l31] = bq;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * BN) {
+            const int which = threadIdx.x / BN, n = threadIdx.x % BN;
+            const float v = (red[(0 * 2 + which) * BN + n] + red[(1 * 2 + which) * BN + n]) +
+                            (red[(2 * 2 + which) * BN + n] + red[(3 * 2 + which) * BN + n]);
+            stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + n] = v;
+        }
+    }
+    PHX_BLOCKLOG_END();
+#undef FWD_DMA_ISSUE
 }
 
 // ---- filter gradient --------------------------------------------------------------------------------------
@@ -1100,7 +1314,26 @@ int phx_conv3x3_mfma_bf16_ws(const void* x, const void* wpk, void* y, const floa
         PHX_REQUIRE(workspace_bytes >= (size_t)(ksplit > 1 ? ksplit : 0) * B * H * W * N * sizeof(float), PHX_E_INVAL,
                     "conv3x3_mfma: workspace too small");
     }
-    MTile g = make_mtile_fwd(B, H, W, K, N);
+    if (const int dbn = fwd_dma_bn(B, H, W, K, N)) {
+        const bool ba = bias != nullptr || act != PHX_ACT_ID;
+        static bool dattr = false;
+#define FD_ATTR(BNv, Av) PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_dma<BNv, Av>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+        if (!dattr) { FD_ATTR(128, false); FD_ATTR(128, true); FD_ATTR(64, false); FD_ATTR(64, true); dattr = true; }
+#undef FD_ATTR
+        PHX_REQUIRE((double)B * H * W * (K > N ? K : N) < 2147483648.0, PHX_E_SHAPE, "conv3x3_mfma: tensor exceeds 2^31 elements");
+        const int ntl = B * (H / 16) * (W / 32);
+        // LDS: two stages (7 resp. 5 KiB-instructions per wave each) or the 512-pixel output tile, whichever is larger
+#define FD_LAUNCH(BNv, Av, SHv)                                                                                       \
+    hipLaunchKernelGGL((k_conv3x3_fwd_dma<BNv, Av>), dim3(ntl, N / BNv), dim3(512), SHv, (hipStream_t)stream,          \
+                       (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B,  \
+                       H, W, K, N, W / 32, H / 16)
+        if (dbn == 128) { if (ba) FD_LAUNCH(128, true, 512 * (128 * 2 + 16)); else FD_LAUNCH(128, false, 512 * (128 * 2 + 16)); }
+        else { if (ba) FD_LAUNCH(64, true, 2 * 5 * 8 * 1024); else FD_LAUNCH(64, false, 2 * 5 * 8 * 1024); }
+#undef FD_LAUNCH
+        PHX_CHECK_LAUNCH();
+        return PHX_OK;
+    }
+    MTile g = make_mtile_fwd(B, H, W, K, N, false);
     const bool big = fwd_big_tiles(B, H, W, K, N);
     const int tw = 1 << g.tws, th = 1 << g.ths;
     const int npatch = g.tb * (th + 2) * (tw + 2);

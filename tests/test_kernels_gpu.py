@@ -158,6 +158,13 @@ def test_conv3x3_mfma_big_tiles(L, case, monkeypatch):
     _mfma_case(L, case)
 
 
+# the 32 x 16-tile LDS-DMA forward kernels (policy: large maps with 128-wide channel blocks), forced on small shapes
+@pytest.mark.parametrize("case", [(2, 16, 32, 32, 128), (1, 32, 64, 96, 64), (3, 16, 32, 32, 192), (1, 48, 32, 64, 256)])
+def test_conv3x3_mfma_dma_tiles(L, case, monkeypatch):
+    monkeypatch.setenv("PHX_FWD_DMA", "2")
+    _mfma_case(L, case)
+
+
 def _mfma_case(L, case):
     B, H, W, K, N = case
     x = RNG.standard_normal((B, H, W, K))
