@@ -63,7 +63,8 @@ int phx_conv2d_direct_wgrad(const void* x, int x_dt, const void* dy, int dy_dt, 
                             int B, int H, int W, int Cin, int Cout, int ksize, void* stream);
 
 /* bf16 MFMA path (v_mfma_f32_32x32x16_bf16), 3x3 only, Cin % 32 == 0, Cout % 32 == 0.
- * wpk is the packed filter [9][N][K] (bf16, K contiguous) written by phx_pack_conv3x3_bf16:
+ * wpk is the packed bf16 filter [K / 32][9][N][32] (element (tap t, row n, channel k) at (((k / 32) * 9 + t) * N + n) * 32
+ * + k % 32: the slab of one 32-channel chunk is contiguous) written by phx_pack_conv3x3_bf16:
  *   forward:  N = Cout, K = Cin, tap t = kh*3+kw          (wpk_fwd)
  *   dgrad:    N = Cin,  K = Cout, tap t = (2-kh)*3+(2-kw) (wpk_dgrad); call with x := dy, K := Cout, N := Cin.
  * Optional epilogue: + bias[N], act, and per-channel {sum, sumsq} of the bf16-rounded output into

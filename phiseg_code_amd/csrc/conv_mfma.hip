@@ -74,7 +74,13 @@ static MTile make_mtile_fwd(int B, int H, int W, int K, int N, bool allow_dma = 
 }
 
 // ---- filter packing ---------------------------------------------------------------------------------
-// wpk_fwd[t][co][ci] = w[t][ci][co];  wpk_dgrad[t][ci][co] = w[8-t][ci][co]
+// Packed bf16 filter for an (N rows) x (K reduction channels) convolution: [K / 32][9 taps][N][32], i.e. the 9 x N x 64 B
+// slab a block stages per 32-channel chunk is CONTIGUOUS (full 128-byte lines; with [9][N][K] every row contributed a
+// 64-byte half line and the staging path, which bounds these kernels, moved twice the requests).
+__host__ __device__ __forceinline__ size_t pk_idx(int t, int n, int k, int N) {
+    return ((((size_t)(k >> 5) * 9 + t) * N + n) << 5) + (k & 31);
+}
+// wpk_fwd(t, co, ci) = w[t][ci][co];  wpk_dgrad(8 - t, ci, co) = w[t][ci][co]   (element addressing: pk_idx)
 __global__ void k_pack_conv3x3(const float* __restrict__ w, unsigned short* __restrict__ wf,
                                unsigned short* __restrict__ wd, int Cin, int Cout) {
     const size_t n = (size_t)9 * Cin * Cout;
@@ -83,14 +89,14 @@ __global__ void k_pack_conv3x3(const float* __restrict__ w, unsigned short* __re
         const int ci = (int)((i / Cout) % Cin);
         const int t = (int)(i / ((size_t)Cout * Cin));
         const unsigned short v = f2bf(w[i]);
-        if (wf) wf[((size_t)t * Cout + co) * Cin + ci] = v;
-        if (wd) wd[((size_t)(8 - t) * Cin + ci) * Cout + co] = v;
+        if (wf) wf[pk_idx(t, co, ci, Cout)] = v;
+        if (wd) wd[pk_idx(8 - t, ci, co, Cin)] = v;
     }
 }
 
 // Cin < 32 (image-input convolutions, Cin = 1 or 3): zero-pad the channel axis to 32 so the layer runs on the MFMA
-// kernels.  wpk[t][co][ci_pad] = ci < Cin ? w[t][ci][co] : 0
-// and (optional) wpk_dgrad[t][ci_pad][co] = ci < Cin ? w[8-t][ci][co] : 0
+// kernels.  wpk(t, co, ci_pad) = ci < Cin ? w[t][ci][co] : 0
+// and (optional) wpk_dgrad(8 - t, ci_pad, co) = the same value   (element addressing: pk_idx)
 __global__ void k_pack_conv3x3_pad(const float* __restrict__ w, unsigned short* __restrict__ wf,
                                    unsigned short* __restrict__ wd, int Cin, int Cpad, int Cout) {
     const size_t n = (size_t)9 * Cout * Cpad;
@@ -99,15 +105,15 @@ __global__ void k_pack_conv3x3_pad(const float* __restrict__ w, unsigned short* 
         const int co = (int)((i / Cpad) % Cout);
         const int t = (int)(i / ((size_t)Cpad * Cout));
         const unsigned short v = ci < Cin ? f2bf(w[((size_t)t * Cin + ci) * Cout + co]) : (unsigned short)0;
-        wf[i] = v;
-        if (wd) wd[((size_t)(8 - t) * Cpad + ci) * Cout + co] = v;
+        wf[pk_idx(t, co, ci, Cout)] = v;
+        if (wd) wd[pk_idx(8 - t, ci, co, Cpad)] = v;
     }
 }
 // all filters of a plan in ONE launch: descriptor table in device memory, blockIdx.y = filter
 struct PackDesc {
     const float* w;
-    unsigned short* wf;       // [9][Cout][Cpad]
-    unsigned short* wd;       // [9][Cpad][Cout] taps flipped (nullable)
+    unsigned short* wf;       // pk_idx(t, co, ci, Cout)
+    unsigned short* wd;       // pk_idx(8 - t, ci, co, Cpad): taps flipped (nullable)
     int cin, cpad, cout, _pad;
 };
 __global__ void k_pack_conv3x3_multi(const PackDesc* __restrict__ descs) {
@@ -126,13 +132,13 @@ __global__ void k_pack_conv3x3_multi(const PackDesc* __restrict__ descs) {
             const int ci = cit * 32 + ty * 4 + r, co = cot * 32 + tx;
             const float v = ci < d.cin ? d.w[((size_t)t * d.cin + ci) * d.cout + co] : 0.f;
             tile[ty * 4 + r][tx] = v;
-            if (d.wd) d.wd[((size_t)(8 - t) * d.cpad + ci) * d.cout + co] = f2bf(v);
+            if (d.wd) d.wd[pk_idx(8 - t, ci, co, d.cpad)] = f2bf(v);
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = cot * 32 + ty * 4 + r, ci = cit * 32 + tx;
-            d.wf[((size_t)t * d.cout + co) * d.cpad + ci] = f2bf(tile[tx][ty * 4 + r]);
+            d.wf[pk_idx(t, co, ci, d.cout)] = f2bf(tile[tx][ty * 4 + r]);
         }
     }
 }
@@ -248,12 +254,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
     {
         const int q = threadIdx.x & 3, row = threadIdx.x >> 2;
         const int tap = row / BN, n = row - tap * BN;
-        gb0 = (unsigned)(((tap * N + n0 + n) * K + q * 8) * 2);
+        gb0 = (unsigned)(((tap * N + n0 + n) * 32 + q * 8) * 2);          // chunk 0; chunk c adds c * 9 * N * 64 bytes
         gbl = (threadIdx.x + (NB - 1) * NT < 9 * BN * 4) ? gb0 : 0xffffffffu;
     }
     // a thread's consecutive slab pieces are NT / 4 slab rows = NT / 4 / BN taps apart (BN <= NT / 4)
     static_assert(NT / 4 % BN == 0, "slab piece stride must be whole taps");
-    const int gbs = (NT / 4 / BN) * N * K * 2;
+    const int gbs = (NT / 4 / BN) * N * 64;
+    const int gcs = 9 * N * 64;                   // bytes per 32-channel chunk of the packed filter
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K * 2u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, (int)(9u * N * K * 2u), 0x00020000);
 
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
         if constexpr (PHX_ABLATE & 1) return;
         if constexpr (idx < NA) ra[idx] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ga[idx], c0 * 2, 0);
         else if constexpr (idx < NA + NB)
-            rb[idx - NA] = __builtin_amdgcn_raw_buffer_load_b128(rsw, idx - NA == NB - 1 ? gbl : gb0, c0 * 2 + (idx - NA) * gbs, 0);
+            rb[idx - NA] = __builtin_amdgcn_raw_buffer_load_b128(rsw, idx - NA == NB - 1 ? gbl : gb0, (c0 >> 5) * gcs + (idx - NA) * gbs, 0);
     };
     // this block's run of 32-channel chunks [cbeg, cend)
     int cbeg = 0, cend = K;
@@ -552,7 +559,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_fwd_dma(const unsigned short
             const int e = (j - AI) * 64 + lane, rb = e >> 1, slot = e & 1;
             const int tap = rb / BN, nn = rb - tap * BN;
             const int h = slot ^ ((nn >> 3) & 1);
-            voff[n] = (unsigned)((((tap * N + n0 + nn) * K)) * 2 + h * 16);
+            voff[n] = (unsigned)(((tap * N + n0 + nn) * 32) * 2 + h * 16);
         }
     }
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K * 2u), 0x00020000);
@@ -567,7 +574,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_fwd_dma(const unsigned short
                                                      (stage) * 32, 0, 0);                                              \
         else                                                                                                           \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(smem + (buf) * STAGE + j_ * 1024), 16, (int)voff[n_],\
-                                                     (stage) * 32, 0, 0);                                              \
+                                                     ((stage) >> 1) * 9 * N * 64 + ((stage) & 1) * 32, 0, 0);          \
     }
 
     // per-lane read bases (stage 0); tap / row-tile / channel-tile terms are immediates
