@@ -213,11 +213,28 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
     unsigned char* sA = smem;                    // [npatch][ROWB]
     unsigned char* sB = smem + npatch * ROWB;    // [9][BN][ROWB]
 
-    int t = blockIdx.x;
+    // Linear block id -> (pixel tile, channel block).  Work-groups go round-robin over the 8 XCDs (id % 8), each with its
+    // own L2: the N / BN channel blocks of a tile get ids 8 apart -- same XCD, dispatched back to back -- so the input
+    // patch they all read comes from HBM once.  (Placement only affects speed, never results.)
+    int tile_id, cob;
+    {
+        const int ncob = N / BN, ntl = g.tiles_x * g.tiles_y * g.tiles_b;
+        const int id = blockIdx.x, full = (ntl >> 3) * 8 * ncob;
+        if (id < full) {
+            const int grp = id / (8 * ncob), r = id - grp * 8 * ncob;
+            tile_id = grp * 8 + (r & 7);
+            cob = r >> 3;
+        } else {
+            const int rem = ntl & 7, r = id - full;
+            tile_id = (ntl & ~7) + r % rem;
+            cob = r / rem;
+        }
+    }
+    int t = tile_id;
     const int tx0 = (t % g.tiles_x) << g.tws; t /= g.tiles_x;
     const int ty0 = (t % g.tiles_y) << g.ths; t /= g.tiles_y;
     const int b0 = t * g.tb;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = cob * BN;
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int l31 = lane & 31, khalf = lane >> 5;
@@ -505,7 +522,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
                 float v = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) v += red[(w * 2 + which) * BN + n];
-                stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + n] = v;
+                stats_partial[((size_t)tile_id * 2 + which) * N + n0 + n] = v;
             }
         }
     }
@@ -1370,12 +1387,12 @@ int phx_conv3x3_mfma_bf16_ws(const void* x, const void* wpk, void* y, const floa
         const size_t she = (size_t)NWv * 64 * (BNv * 2 + 16);                                                        \
         if (she > sh) sh = she;                                                                                      \
         if (Sv)                                                                                                      \
-            hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, false, NWv, Sv>), dim3(ntiles, N / BNv, ksplit),        \
+            hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, false, NWv, Sv>), dim3(ntiles * (N / BNv), 1, ksplit),  \
                                dim3(NWv * 64), sh, (hipStream_t)stream, (const unsigned short*)x,                    \
                                (const unsigned short*)wpk, (unsigned short*)y, nullptr, 0, nullptr, B, H, W, K, N, g,\
                                (float*)workspace);                                                                   \
         else                                                                                                         \
-            hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, Av, NWv, false>), dim3(ntiles, N / BNv), dim3(NWv * 64),\
+            hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, Av, NWv, false>), dim3(ntiles * (N / BNv)), dim3(NWv * 64),\
                                sh, (hipStream_t)stream, (const unsigned short*)x, (const unsigned short*)wpk,        \
                                (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, g, nullptr);             \
     } while (0)
