@@ -7,7 +7,14 @@ Layout (mirrors the reference's top-level packages so it is a drop-in for that p
   graph.py engine.py runtime.py distributed.py    symbolic graph -> HIP launch plan -> hipGraph
   csrc/        hand-written HIP kernels + the C ABI (include/phx.h) -> libphx.so
 """
+import os
 import sys
+
+# The plan replays one hipGraph whose branches ("lanes", engine.Plan) run on up to 6 streams next to torch's own; the HIP
+# runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read once when the runtime starts.
+# Measured on MI355X (bench.py, 6 lanes): 8 queues 16.4-16.7 ms/step, 4 queues 16.9-17.0.  Only a default: the user's
+# setting wins, and it has no effect if HIP was initialised before this package was imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def install_dropin_aliases():
