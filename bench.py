@@ -146,11 +146,10 @@ def main():
             a[2] += 1
         if args.profile_table:
             for tag, fl, ms, shp in sorted(rows, key=lambda r: -r[2]):
-                print("# %-20s %8.3f ms %8.1f TFLOP/s  %s" % (tag, ms, fl / ms / 1e9, shp), file=sys.stderr)
+                print("# %-20s %8.3f ms %8.1f TFLOP/s  %s" % (tag, ms, fl / ms / 1e9, shp[-5:]), file=sys.stderr)
             byh = {}
             for tag, fl, ms, shp in rows:
-                h = [v for v in shp if v in (2, 4, 8, 16, 32, 64, 128)]
-                key = (tag, shp[1] if tag.endswith("wgrad") else shp[2])
+                key = (tag, shp[-4])                      # launch arguments end (..., B, H, W, Cin|K, Cout|N)
                 a = byh.setdefault(key, [0.0, 0.0, 0])
                 a[0] += fl; a[1] += ms; a[2] += 1
             for key in sorted(byh):
@@ -173,7 +172,7 @@ def main():
         alg_bytes = 0.0
         for tag, flp, ms_, shp in rows:
             if tag != "conv3x3_mfma_wgrad":
-                _, Bq, Hq, Wq, Kq, Nq = shp[:6]
+                Bq, Hq, Wq, Kq, Nq = shp[-5:]
                 alg_bytes += 2.0 * Bq * Hq * Wq * (Kq + Nq) + 18.0 * Kq * Nq
         out["roofline"] = {
             "bound": "mfma", "kernel": "k_conv3x3_mfma<BN> (forward + data-gradient launches of one step)",
