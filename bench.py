@@ -27,11 +27,14 @@ F_TRAIN_GFLOP_PER_IMAGE = 75.08       # fwd 25.026 + dgr
 PEAK_BF16_TFLOPS = 2500.0             # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def make_config(batch, compute_dtype):
-    base = importlib.import_module("phiseg_code_amd.phiseg.experiments.phiseg_7_5")
+def make_config(batch, compute_dtype, exp="phiseg_7_5", image_size=128, nlabels=None):
+    base = importlib.import_module("phiseg_code_amd.phiseg.experiments." + exp)
     cfg = types.SimpleNamespace(**{k: getattr(base, k) for k in dir(base) if not k.startswith("_")})
     cfg.batch_size = batch
     cfg.compute_dtype = compute_dtype
+    cfg.image_size = (image_size, image_size, 1)
+    if nlabels:
+        cfg.nlabels = nlabels
     return cfg
 
 
@@ -68,6 +71,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--profile-table", action="store_true", help="print the per-layer kernel timing table")
+    # the other BASELINE.json configurations (the default run is config 2, the headline metric):
+    ap.add_argument("--exp", default="phiseg_7_5", help="experiment config (phiseg/experiments/*.py), e.g. probunet")
+    ap.add_argument("--workload", default="train", choices=["train", "generate"],
+                    help="generate: Monte-Carlo sampling passes (prior sample + likelihood decode + softmax), config 5")
+    ap.add_argument("--image-size", type=int, default=128)
+    ap.add_argument("--nlabels", type=int, default=0, help="0: the experiment's own")
     args = ap.parse_args()
 
     import numpy as np
@@ -78,21 +87,29 @@ def main():
 
     ctx = distributed.DistContext(force=os.environ.get("PHX_FORCE_DIST") == "1")   # dev: exercise the split path on one GPU
     assert ctx.world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    cfg = make_config(args.batch, args.dtype)
+    cfg = make_config(args.batch, args.dtype, args.exp, args.image_size, args.nlabels)
     model = phiseg_model.phiseg(cfg, dist=ctx if ctx.active else None)
     sess = model.sess
-    plan = sess.plan_for([model.loss_tot], True, args.batch, True)
+    generate = args.workload == "generate"
+    if generate:
+        plan = sess.plan_for([model.s_out_eval_sm], False, args.batch, False)
+    else:
+        plan = sess.plan_for([model.loss_tot], True, args.batch, True)
     rng = np.random.default_rng(1234 + ctx.rank)
-    x, s = synthetic.make_batch(args.batch, 128, cfg.nlabels, rng)
+    x, s = synthetic.make_batch(args.batch, args.image_size, cfg.nlabels, rng)
     plan.set_input("x_input", x)          # resident in HBM for the whole run
-    plan.set_input("s_input", s)
+    if not generate:
+        plan.set_input("s_input", s)
     sess.store.set_lr(1e-3)
     if ctx.active:                        # identical replicas
         ctx.broadcast_(sess.store.params)
         ctx.broadcast_(sess.store.state)
 
     def step():
-        if ctx.active:
+        if generate:                      # one sampling pass over the batch; fresh noise for the next one (on the plan's stream)
+            plan.run()
+            plan.L.step_increment(sess.store.noise_step.data_ptr(), plan.stream_handle())
+        elif ctx.active:
             plan.run_main()
             ctx.allreduce_sum(sess.store.grads, plan)
             plan.run_opt()
@@ -111,20 +128,27 @@ def main():
     torch.cuda.synchronize()
     ctx.barrier()
     dt = ctx.max_float(time.perf_counter() - t0)
-    loss = float(plan.fetch(model.loss_tot))
+    loss = None if generate else float(plan.fetch(model.loss_tot))
     images = args.batch * ctx.world * args.steps
     out = {
-        "metric": "training images/sec (ELBO step) phiseg_7_5 128x128 LIDC", "value": images / dt,
+        "metric": ("segmentation samples/sec (prior sample + likelihood decode) %s %dx%d" % (args.exp, args.image_size, args.image_size))
+                  if generate else "training images/sec (ELBO step) %s %dx%d LIDC" % (args.exp, args.image_size, args.image_size),
+        "value": images / dt,
         "unit": "images/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "phiseg_7_5 LIDC 128x128x1, 2 classes, %s, batch %d per GPU, full ELBO training step "
-                               "(fwd + 5 CE + 5 KL + bwd + Adam%s)" % (args.dtype, args.batch,
-                                                                       " + RCCL grad all-reduce" if ctx.world > 1 else ""),
+        "config": {"workload": ("%s %dx%dx1, %d classes, %s, batch %d per GPU, one sampling pass per step (prior sample + "
+                                "likelihood decode + softmax)" % (args.exp, args.image_size, args.image_size, cfg.nlabels,
+                                                                  args.dtype, args.batch)) if generate else
+                               "%s LIDC %dx%dx1, %d classes, %s, batch %d per GPU, full ELBO training step "
+                               "(fwd + CE + KL + bwd + Adam%s)" % (args.exp, args.image_size, args.image_size, cfg.nlabels,
+                                                                   args.dtype, args.batch,
+                                                                   " + RCCL grad all-reduce" if ctx.world > 1 else ""),
                    "global_batch": args.batch * ctx.world, "parallelism": "dp%d" % ctx.world,
                    "launches_per_step": len(plan.launches) + len(plan.opt_launches), "final_loss": loss},
-        "step_tflops": images / dt * F_TRAIN_GFLOP_PER_IMAGE / 1e3,
     }
+    if not generate and args.exp == "phiseg_7_5" and args.image_size == 128:
+        out["step_tflops"] = images / dt * F_TRAIN_GFLOP_PER_IMAGE / 1e3
     if ctx.rank == 0 and not args.no_roofline and args.dtype == "bf16":
         rows_all = plan.time_tagged_kernels(repeats=3)
         rows = [r for r in rows_all if r[0].startswith("conv")]
@@ -184,7 +208,8 @@ def main():
             "families": {k: {"tflops": v[0] / v[1] / 1e9, "ms_per_step": v[1], "launches": v[2]} for k, v in fam.items()},
             "conv_ms_per_step": sum(v[1] for v in fam.values()),
         }
-    if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
+    if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline and not generate and args.exp == "phiseg_7_5" \
+            and args.image_size == 128:
         out["cpu_baseline"] = cpu_baseline()
     if ctx.rank == 0:
         out["config"]["hbm_peak_allocated_gb"] = torch.cuda.max_memory_allocated() / 2 ** 30
