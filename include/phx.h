@@ -78,11 +78,14 @@ int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* 
 int phx_pack_conv3x3_bf16_pad(const float* w_hwio, void* wpk_fwd, void* wpk_dgrad /* nullable */, int Cin, int Cin_pad,
                               int Cout, void* stream);
 /* every filter of a step in one launch: descs_dev = device array of n records
- * { const float* w_hwio; void* wpk_fwd; void* wpk_dgrad (nullable); int32 Cin, Cin_pad, Cout, 0 }  (40 bytes each) */
+ * { const float* w_hwio; void* wpk_fwd; void* wpk_dgrad (nullable); int32 Cin, Cin_pad, Cout, k1 }  (40 bytes each) */
 int phx_pack_conv3x3_bf16_multi(const void* descs_dev, int n, void* stream);
 int phx_pad_channels_bf16(const void* x, int dt, int C, void* out, int Cpad, size_t npix, void* stream);
 int phx_unpad_channels_bf16(const void* src, void* dst, int dst_dt, int C, int Cpad, size_t npix, void* stream);
 int phx_unpad_filter_grad_accumulate(const float* dw_pad, float* dw_hwio, int Cin, int Cin_pad, int Cout, void* stream);
+/* 1x1 convolutions run as the centre tap of a 3x3 (descriptor field k1 of phx_pack_conv3x3_bf16_multi):
+ * dw_1x1[ci][co] += dw_pad[tap 4][ci][co] */
+int phx_unpad_filter_grad_center(const float* dw_pad, float* dw_1x1, int Cin, int Cin_pad, int Cout, void* stream);
 /* Split-K variant for small maps (few pixel tiles): with a workspace of phx_conv3x3_mfma_ws_bytes (0: not used for this
  * shape) and stats_partial == NULL, the K / 32 chunks are spread over several blocks per tile and a second kernel sums the
  * fp32 slices and applies bias / activation.  Otherwise identical to phx_conv3x3_mfma_bf16. */

@@ -114,7 +114,7 @@ struct PackDesc {
     const float* w;
     unsigned short* wf;       // pk_idx(t, co, ci, Cout)
     unsigned short* wd;       // pk_idx(8 - t, ci, co, Cpad): taps flipped (nullable)
-    int cin, cpad, cout, _pad;
+    int cin, cpad, cout, k1;  // k1 != 0: w is a 1x1 filter [Cin][Cout], packed as the centre tap of a 3x3 (other taps zero)
 };
 __global__ void k_pack_conv3x3_multi(const PackDesc* __restrict__ descs) {
     // 32 (ci) x 32 (co) tiles transposed through LDS so that the fp32 read, the [t][co][ci] write and the flipped
@@ -130,7 +130,11 @@ __global__ void k_pack_conv3x3_multi(const PackDesc* __restrict__ descs) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ci = cit * 32 + ty * 4 + r, co = cot * 32 + tx;
-            const float v = ci < d.cin ? d.w[((size_t)t * d.cin + ci) * d.cout + co] : 0.f;
+            float v = 0.f;
+            if (ci < d.cin) {
+                if (!d.k1) v = d.w[((size_t)t * d.cin + ci) * d.cout + co];
+                else if (t == 4) v = d.w[(size_t)ci * d.cout + co];
+            }
             tile[ty * 4 + r][tx] = v;
             if (d.wd) d.wd[pk_idx(8 - t, ci, co, d.cpad)] = f2bf(v);
         }
@@ -160,10 +164,11 @@ __global__ void k_pad_channels(const T* __restrict__ x, unsigned short* __restri
         out[i] = c < C ? f2bf(ldf<T>(x, p * C + c)) : (unsigned short)0;
     }
 }
-__global__ void k_unpad_rows_acc(const float* __restrict__ dwp, float* __restrict__ dw, int Cin, int Cpad, int Cout) {
-    const int n = 9 * Cin * Cout;
+// ntap = 9: all taps; ntap = 1: only the centre tap (a 1x1 filter run as the centre tap of a 3x3)
+__global__ void k_unpad_rows_acc(const float* __restrict__ dwp, float* __restrict__ dw, int Cin, int Cpad, int Cout, int ntap) {
+    const int n = ntap * Cin * Cout;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int co = i % Cout, ci = (i / Cout) % Cin, t = i / (Cout * Cin);
+        const int co = i % Cout, ci = (i / Cout) % Cin, t = ntap == 1 ? 4 : i / (Cout * Cin);
         dw[i] += dwp[((size_t)t * Cpad + ci) * Cout + co];
     }
 }
@@ -1278,7 +1283,13 @@ int phx_unpad_channels_bf16(const void* src, void* dst, int dst_dt, int C, int C
 }
 int phx_unpad_filter_grad_accumulate(const float* dw_pad, float* dw_hwio, int Cin, int Cin_pad, int Cout, void* stream) {
     hipLaunchKernelGGL(k_unpad_rows_acc, dim3(phx_grid_for((size_t)9 * Cin * Cout, 256)), dim3(256), 0,
-                       (hipStream_t)stream, dw_pad, dw_hwio, Cin, Cin_pad, Cout);
+                       (hipStream_t)stream, dw_pad, dw_hwio, Cin, Cin_pad, Cout, 9);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+int phx_unpad_filter_grad_center(const float* dw_pad, float* dw_1x1, int Cin, int Cin_pad, int Cout, void* stream) {
+    hipLaunchKernelGGL(k_unpad_rows_acc, dim3(phx_grid_for((size_t)Cin * Cout, 256)), dim3(256), 0,
+                       (hipStream_t)stream, dw_pad, dw_1x1, Cin, Cin_pad, Cout, 1);
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }

@@ -336,7 +336,7 @@ class Plan:
             rec = np.zeros(len(self._pack_jobs), dtype=[("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("cin", "<i4"),
                                                          ("cpad", "<i4"), ("cout", "<i4"), ("pad", "<i4")])
             for i, j in enumerate(self._pack_jobs):
-                rec[i] = (j[0], j[1], j[2], j[3], j[4], j[5], 0)
+                rec[i] = (j[0], j[1], j[2], j[3], j[4], j[5], j[6] if len(j) > 6 else 0)
             self._pack_desc = torch.from_numpy(rec.view(np.uint8).copy()).to(_device())
             self._keep.append(self._pack_desc)
             self.launches[1] = (self.L.pack_conv3x3_bf16_multi, (self._pack_desc.data_ptr(), len(self._pack_jobs), self.stream))
@@ -420,21 +420,28 @@ class Plan:
                 and cout % 32 == 0)
         S, Lb = self.stream, self.L
         cin_eff = cin
-        # narrow-input convolutions (image Cin = 1 / 3, latent Cin = 2): zero-pad channels to 32 -> MFMA kernels
-        padded = self.act_dt == BF16 and out.dt == BF16 and k == 3 and cin < 32 and cout % 32 == 0
+        # Convolutions the 3x3 MFMA kernels do not take as they are: input channels not a multiple of 32 (image Cin = 1 / 3,
+        # latent Cin = 2, prob_unet2D's feature + z concat) are zero-padded, and 1x1 filters (prob_unet2D's recombination
+        # layers, likelihoods.py) run as the centre tap of a 3x3 -- 9x the FLOPs on the matrix cores still beats the fp32
+        # direct kernel by 30x.  Both get their own packed filter copies ("padded" path).
+        k1 = k == 1 and cout % 32 == 0
+        padded = (self.act_dt == BF16 and out.dt == BF16 and cout % 32 == 0 and
+                  ((k == 3 and (cin % 32 != 0 or x.dt != BF16)) or k1))
         if padded:
-            cin_eff = 32
-            xp = self._alloc((B, H, Wd, cin_eff), BF16)
-            self._emit(Lb.pad_channels_bf16, x.ptr, x.dt, cin, xp.ptr, cin_eff, B * H * Wd, S)
-            x, mfma = xp, True
-        st = dict(x=x, out=out, mfma=mfma, norm=a["norm"], padded=padded, cin_eff=cin_eff)
+            cin_eff = (cin + 31) // 32 * 32
+            if cin_eff != cin or x.dt != BF16:        # (with cin_eff == cin the pad kernel is just the cast to bf16)
+                xp = self._alloc((B, H, Wd, cin_eff), BF16)
+                self._emit(Lb.pad_channels_bf16, x.ptr, x.dt, cin, xp.ptr, cin_eff, B * H * Wd, S)
+                x = xp
+            mfma = True
+        st = dict(x=x, out=out, mfma=mfma, norm=a["norm"], padded=padded, cin_eff=cin_eff, k1=bool(padded and k1))
         wptr, bptr = self.store.ptr(W), (self.store.ptr(b) if b is not None else None)
         if padded:
             wf = self._alloc((9 * cin_eff * cout,), BF16)
             need_dgrad = bw and self.req.get(op.inputs[0], False)
             wdp = self._alloc((9 * cin_eff * cout,), BF16) if need_dgrad else None
             st["wd_pad"] = wdp
-            self._pack_jobs.append((wptr, wf.ptr, wdp.ptr if wdp else 0, cin, cin_eff, cout))
+            self._pack_jobs.append((wptr, wf.ptr, wdp.ptr if wdp else 0, cin, cin_eff, cout, 1 if k1 else 0))
         elif mfma:
             wf, _ = self._packed(W)
 
@@ -766,7 +773,8 @@ class Plan:
             wsp = self._alloc((wsb // 4,), F32)
             self._emit(Lb.conv3x3_wgrad_mfma_bf16, x.ptr, dY.ptr, dwp.ptr, wsp.ptr, wsb, B, H, Wd, ce, cout, S,
                        tag="conv3x3_mfma_wgrad", flops=18.0 * cin * cout * B * H * Wd)
-            self._emit(Lb.unpad_filter_grad_accumulate, dwp.ptr, dw, cin, ce, cout, S)
+            self._emit(Lb.unpad_filter_grad_center if sv.get("k1") else Lb.unpad_filter_grad_accumulate, dwp.ptr, dw, cin, ce,
+                       cout, S)
             if db is not None:
                 self._emit(Lb.channel_sum_accumulate, dY.ptr, dY.dt, db, B * H * Wd, cout, S)
         elif sv["mfma"]:
@@ -791,7 +799,12 @@ class Plan:
                     self._emit(Lb.conv3x3_mfma_bf16, dY.ptr, wdp.ptr, gp.ptr, None, 0, None, B, H, Wd, cout, ce, S,
                                tag="conv3x3_mfma_dgrad", flops=18.0 * cin * cout * B * H * Wd)
                     self._emit(Lb.unpad_channels_bf16, gp.ptr, g.ptr, g.dt, cin, ce, B * H * Wd, S)
-                self._add_grad(xin, write_fn=wr)
+                if ce == cin and self.val[xin].dt == BF16:      # nothing to strip / cast: the data gradient is written in place
+                    self._add_grad(xin, write_fn=lambda g: self._emit(
+                        Lb.conv3x3_mfma_bf16, dY.ptr, wdp.ptr, g.ptr, None, 0, None, B, H, Wd, cout, ce, S,
+                        tag="conv3x3_mfma_dgrad", flops=18.0 * cin * cout * B * H * Wd))
+                else:
+                    self._add_grad(xin, write_fn=wr)
             elif sv["mfma"]:
                 _, wd = self._packed(W)
 

@@ -165,6 +165,46 @@ def test_conv3x3_mfma_dma_tiles(L, case, monkeypatch):
     _mfma_case(L, case)
 
 
+@pytest.mark.parametrize("case", [(2, 16, 16, 38, 32), (1, 32, 32, 64, 64)])
+def test_conv1x1_as_centre_tap(L, case):
+    """1x1 filters (prob_unet2D's recombination layers, model_zoo/likelihoods.py) run on the 3x3 MFMA kernels as the centre
+    tap, input channels zero-padded to a multiple of 32: forward, data gradient and filter gradient vs the 1x1 oracle."""
+    B, H, W, C, N = case
+    Cp = (C + 31) // 32 * 32
+    x = RNG.standard_normal((B, H, W, C))
+    w = RNG.standard_normal((1, 1, C, N)) / np.sqrt(C)
+    xr = rounded(x, BF16).requires_grad_(True)
+    wr = rounded(w, BF16).requires_grad_(True)
+    xd, wd = dev(x, BF16), dev(w)
+    xp = torch.empty(B, H, W, Cp, dtype=torch.bfloat16).cuda()
+    L.pad_channels_bf16(xd.data_ptr(), BF16, C, xp.data_ptr(), Cp, B * H * W, S())
+    wf = torch.empty(9 * N * Cp, dtype=torch.bfloat16).cuda()
+    wg = torch.empty(9 * N * Cp, dtype=torch.bfloat16).cuda()
+    desc = np.zeros(1, dtype=[("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("cin", "<i4"), ("cpad", "<i4"), ("cout", "<i4"),
+                              ("k1", "<i4")])
+    desc[0] = (wd.data_ptr(), wf.data_ptr(), wg.data_ptr(), C, Cp, N, 1)
+    dd = torch.from_numpy(desc.view(np.uint8).copy()).cuda()
+    L.pack_conv3x3_bf16_multi(dd.data_ptr(), 1, S())
+    y = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
+    L.conv3x3_mfma_bf16(xp.data_ptr(), wf.data_ptr(), y.data_ptr(), None, 0, None, B, H, W, Cp, N, S())
+    yr = torch.einsum("bhwc,cn->bhwn", xr, wr[0, 0])
+    close(host(y), yr.detach().numpy(), 6e-3, "1x1 fwd")
+    dy = RNG.standard_normal((B, H, W, N))
+    dyr = rounded(dy, BF16)
+    (yr * dyr).sum().backward()
+    dyd = dev(dy, BF16)
+    dxp = torch.empty(B, H, W, Cp, dtype=torch.bfloat16).cuda()
+    L.conv3x3_mfma_bf16(dyd.data_ptr(), wg.data_ptr(), dxp.data_ptr(), None, 0, None, B, H, W, N, Cp, S())
+    close(host(dxp)[..., :C], xr.grad.numpy(), 6e-3, "1x1 dgrad")
+    if Cp > C:
+        assert np.abs(host(dxp)[..., C:]).max() == 0.0
+    dwp = torch.zeros(9 * Cp * N, dtype=torch.float32).cuda()
+    L.conv3x3_wgrad_mfma_bf16(xp.data_ptr(), dyd.data_ptr(), dwp.data_ptr(), None, 0, B, H, W, Cp, N, S())
+    dw = torch.zeros(C, N, dtype=torch.float32).cuda()
+    L.unpad_filter_grad_center(dwp.data_ptr(), dw.data_ptr(), C, Cp, N, S())
+    close(host(dw), wr.grad.numpy()[0, 0], 1e-4, "1x1 wgrad")
+
+
 def _mfma_case(L, case):
     B, H, W, K, N = case
     x = RNG.standard_normal((B, H, W, K))
