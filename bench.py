@@ -104,6 +104,7 @@ def main():
     if ctx.active:                        # identical replicas
         ctx.broadcast_(sess.store.params)
         ctx.broadcast_(sess.store.state)
+        torch.cuda.synchronize()          # the plan replays on its own HIP streams: finish the broadcasts first
 
     def step():
         if generate:                      # one sampling pass over the batch; fresh noise for the next one (on the plan's stream)
