@@ -219,6 +219,19 @@ int phx_sum_scalars(const float* in, int n, float* out, void* stream);
  * (loss_tot of phiseg_model.py:118-130) */
 int phx_weighted_sum(const float* const* ptrs, const float* weights, int n, float* out, void* stream);
 
+/* ---- validation metrics on the device ---------------------------------------------------
+ * What phiseg_model._do_validation computes per validation image (phiseg_model.py:586-613 calling
+ * utils.generalised_energy_distance utils.py:270-322, utils.variance_ncc_dist utils.py:326-370 and the Dice loop), for I
+ * images at once:
+ *   sm   [I][N][P][C] f32 soft-max of the N Monte-Carlo samples (P = X * Y pixels, 2 <= C <= 8)
+ *   gt   [I][M][P] u8 annotations (M <= 8), sref [I][P] u8 the annotation the Dice is taken against
+ *   out  [I][2 + 8] f32: GED over labels label0 .. C-1 (the reference passes label_range = 1 .. nlabels-1), NCC,
+ *        Dice of arg-max(mean soft-max) vs sref for labels 0 .. C-1 (remaining slots unused)
+ *   work scratch of phx_validation_metrics_ws_bytes bytes */
+size_t phx_validation_metrics_ws_bytes(int I, int N, int M, int P, int C);
+int phx_validation_metrics(const float* sm, const unsigned char* gt, const unsigned char* sref, void* work, size_t work_bytes,
+                           int I, int N, int M, int P, int C, int label0, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

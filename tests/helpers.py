@@ -37,3 +37,41 @@ def check_tensor(g, key, arr, rtol, atol=0.0, what=""):
                                    err_msg=what + key)
         np.testing.assert_allclose(np.abs(arr).sum(), float(g[key + "@abssum"]), rtol=max(rtol, 1e-9) * 10,
                                    err_msg=what + key + "@abssum")
+
+
+# ---- validation metrics -----------------------------------------------------------------------
+METRICS_CASES = [(11, 6, 4, 32, 32, 2, "plain"), (12, 16, 4, 48, 40, 4, "plain"), (13, 5, 3, 24, 24, 3, "empty_fg"),
+                 (14, 4, 2, 16, 16, 2, "identical"), (15, 8, 1, 32, 32, 2, "plain")]
+
+
+def metrics_case(seed, N, M, X, Y, C, mode):
+    """Seeded inputs of the metrics fixtures (tools/make_goldens_metrics.py stores only the expected outputs): N blobby
+    soft-max samples [N, X, Y, C] and M annotations [M, X, Y]; "empty_fg": some maps without foreground; "identical":
+    all samples and annotations are the same map."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:X, 0:Y]
+
+    def blob_logits(shift):
+        lg = np.zeros((X, Y, C))
+        for c in range(1, C):
+            cx, cy, r = rng.uniform(0.25, 0.75) * X + shift, rng.uniform(0.25, 0.75) * Y, rng.uniform(0.1, 0.3) * X
+            lg[..., c] = 3.0 - ((xx - cx) ** 2 + (yy - cy) ** 2) / (r * r) * 3.0
+        return lg
+    base = blob_logits(0.0)
+    sm = np.zeros((N, X, Y, C))
+    for i in range(N):
+        lg = base + 0.8 * blob_logits(rng.normal() * 2.0) + rng.normal(size=(X, Y, C)) * 0.3
+        if mode == "empty_fg" and i % 2 == 0:
+            lg[..., 1:] -= 20.0
+        e = np.exp(lg - lg.max(axis=-1, keepdims=True))
+        sm[i] = e / e.sum(axis=-1, keepdims=True)
+    gts = np.zeros((M, X, Y), dtype=np.uint8)
+    for j in range(M):
+        g = (base + 0.8 * blob_logits(rng.normal() * 2.0)).argmax(axis=-1)
+        if mode == "empty_fg" and j == 0:
+            g[:] = 0
+        gts[j] = g
+    if mode == "identical":
+        sm[:] = sm[0]
+        gts[:] = sm[0].argmax(axis=-1)
+    return sm.astype(np.float32), gts

@@ -8,6 +8,6 @@ for n in "$@"; do
 done
 wait
 for n in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build_runtime.o build_elementwise.o build_losses_opt.o build_conv_direct.o /tmp/ab_conv_$n.o build_heads.o -o ../libphx_ab$n.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build_runtime.o build_elementwise.o build_losses_opt.o build_conv_direct.o /tmp/ab_conv_$n.o build_heads.o build_metrics.o -o ../libphx_ab$n.so
   echo built libphx_ab$n.so
 done
