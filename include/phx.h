@@ -92,6 +92,16 @@ int phx_unpad_filter_grad_center(const float* dw_pad, float* dw_1x1, int Cin, in
 size_t phx_conv3x3_mfma_ws_bytes(int B, int H, int W, int K, int N);
 int phx_conv3x3_mfma_bf16_ws(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
                              void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream);
+/* Data-gradient launch with the batch-norm backward statistics of the PRODUCER layer fused into its epilogue: dA (the
+ * gradient w.r.t. a = act(bn(y_prod)), [B,H,W,N] bf16) is written as by phx_conv3x3_mfma_bf16(dy, wpk_dgrad, dA, ...), and
+ * stats2_partial[tiles][2][N] receives per pixel tile {sum g, sum g * xhat}, g = dA * act'(y_prod * scale + shift),
+ * xhat = (y_prod - mean) * rstd (scale/shift/mean/rstd: the producer's [N] vectors, batch norm only) -- the sums
+ * phx_norm_bwd_reduce computes in a pass of its own; reduce the rows with phx_norm_reduce_partials.  Only for shapes where
+ * phx_conv3x3_mfma_bwdstats_supported(B,H,W,K,N) != 0 (16-wide tiles, every tile interior, no split-K). */
+int phx_conv3x3_mfma_bwdstats_supported(int B, int H, int W, int K, int N);
+int phx_conv3x3_mfma_bf16_bwdstats(const void* dy, const void* wpk_dgrad, void* dA, const void* y_prod, const float* scale,
+                                   const float* shift, const float* mean, const float* rstd, int act_prod,
+                                   float* stats2_partial, int B, int H, int W, int K, int N, void* stream);
 /* number of pixel tiles (= rows of stats_partial) phx_conv3x3_mfma_bf16 uses for this shape */
 int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W, int K, int N);
 /* debug: device buffer of >= 16 uint64 that receives shader-clock phase timestamps of block 0 (NULL disables) */

@@ -194,6 +194,17 @@ __device__ unsigned long long* g_phx_blocklog = nullptr;   // debug: per-block {
             g_phx_trace[slot] = __builtin_readcyclecounter();                                            \
     } while (0)
 
+// Fused batch-norm backward statistics (data-gradient launches): the tensor this launch writes is dA, the gradient w.r.t. the
+// OUTPUT a = act(bn(y)) of the producer layer; with y and the producer's per-channel scale / shift / mean / rstd the
+// epilogue also emits part[tile][2][N] = {sum g, sum g * xhat}, g = dA * act'(y * scale + shift), xhat = (y - mean) * rstd --
+// what k_norm_bwd_reduce would compute in a pass of its own over dA and y (4 B/element and a launch per layer).
+struct BwdStats {
+    const unsigned short* y;
+    const float *scale, *shift, *mean, *rstd;
+    float* part;
+    int act, _pad;
+};
+
 // NA = compile-time bound on the 16-byte input-patch pieces a thread stages per 32-channel chunk
 // (ceil(npatch * 4 / 256): 6 for 16x16 tiles, 7 for 8x8x4, 9 for 4x4x16, 16 for 2x2x64).
 // NW = waves per block (4: 256-pixel tiles, two blocks per CU; 8: 512-pixel 16 x 32 tiles, one block per CU -- the
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
                                                          const unsigned short* __restrict__ wpk,
                                                          unsigned short* __restrict__ y, const float* __restrict__ bias,
                                                          int act, float* __restrict__ stats_partial, int B, int H, int W,
-                                                         int K, int N, MTile g, float* __restrict__ ws) {
+                                                         int K, int N, MTile g, float* __restrict__ ws, BwdStats bws) {
     constexpr int NJ = BN / 32;
     constexpr int NT = NW * 64;                            // threads; the tile has NT pixels
     constexpr int NB = (9 * BN * 4 + NT - 1) / NT;        // filter-slab pieces per thread
@@ -469,10 +480,51 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
             const unsigned char* lr = smem + mt * OROW + q * 16;
             unsigned short* yp = y + (((size_t)cb0 * H + cy0 + (mt >> 4)) * W + cx0 + (mt & 15)) * N + n0 + q * 8;
             const size_t ystep = (size_t)(NT / PPP / 16) * W * N;
+            if (bws.part == nullptr) {
 #pragma unroll
-            for (int it = 0; it < PPP; ++it)
-                if (!(PHX_ABLATE & 8) || cx0 < 0)
-                    *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * (NT / PPP) * OROW);
+                for (int it = 0; it < PPP; ++it)
+                    if (!(PHX_ABLATE & 8) || cx0 < 0)
+                        *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * (NT / PPP) * OROW);
+            } else {
+                // fused BN-backward statistics: this thread's pieces all belong to channels n0 + 8 q .. + 7
+                float sc[8], sh[8], mu[8], rs[8], t1[8], t2[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = n0 + q * 8 + e;
+                    sc[e] = bws.scale[c]; sh[e] = bws.shift[c]; mu[e] = bws.mean[c]; rs[e] = bws.rstd[c];
+                    t1[e] = t2[e] = 0.f;
+                }
+                const unsigned short* yq = bws.y + (yp - y);
+#pragma unroll
+                for (int it = 0; it < PPP; ++it) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(lr + it * (NT / PPP) * OROW);
+                    const uint4 yv = *reinterpret_cast<const uint4*>(yq + it * ystep);
+                    *reinterpret_cast<uint4*>(yp + it * ystep) = v;
+                    const unsigned vw[4] = {v.x, v.y, v.z, v.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float da = __uint_as_float((e & 1) ? (vw[e >> 1] & 0xffff0000u) : (vw[e >> 1] << 16));
+                        const float yy = __uint_as_float((e & 1) ? (yw[e >> 1] & 0xffff0000u) : (yw[e >> 1] << 16));
+                        const float gq = da * act_grad_pre(yy * sc[e] + sh[e], bws.act);
+                        t1[e] += gq;
+                        t2[e] += gq * (yy - mu[e]) * rs[e];
+                    }
+                }
+                __syncthreads();                             // the output tile has been read: LDS becomes reduction scratch
+                float* scr = reinterpret_cast<float*>(smem);  // [NT][16]
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    scr[threadIdx.x * 16 + e] = t1[e];
+                    scr[threadIdx.x * 16 + 8 + e] = t2[e];
+                }
+                __syncthreads();
+                if (threadIdx.x < 2 * BN) {
+                    const int which = threadIdx.x / BN, n = threadIdx.x % BN;
+                    float a = 0.f;
+                    for (int m2 = 0; m2 < NT / PPP; ++m2) a += scr[(m2 * PPP + (n >> 3)) * 16 + which * 8 + (n & 7)];
+                    bws.part[((size_t)tile_id * 2 + which) * N + n0 + n] = a;
+                }
+            }
         } else {
             // edge tiles and the small-map tile shapes: per-row masks and addresses
             const int tid_o = threadIdx.x;
@@ -1339,8 +1391,37 @@ int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* 
     return phx_conv3x3_mfma_bf16_ws(x, wpk, y, bias, act, stats_partial, nullptr, 0, B, H, W, K, N, stream);
 }
 
+// the fused-statistics epilogue lives in the full-tile path of the 16-wide-tile kernels: every tile must be interior
+static bool fwd_bws_ok(int B, int H, int W, int K, int N) {
+    if (fwd_dma_bn(B, H, W, K, N) || fwd_ksplit(B, H, W, K, N) > 1) return false;
+    if (fwd_big_tiles(B, H, W, K, N)) return true;                       // H % 32 == 0, W % 16 == 0
+    return H % 16 == 0 && W % 16 == 0;
+}
+int phx_conv3x3_mfma_bwdstats_supported(int B, int H, int W, int K, int N) { return fwd_bws_ok(B, H, W, K, N) ? 1 : 0; }
+
+static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
+                             void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, BwdStats bws,
+                             void* stream);
+
 int phx_conv3x3_mfma_bf16_ws(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
                              void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream) {
+    return conv3x3_mfma_impl(x, wpk, y, bias, act, stats_partial, workspace, workspace_bytes, B, H, W, K, N, BwdStats{}, stream);
+}
+
+int phx_conv3x3_mfma_bf16_bwdstats(const void* dy, const void* wpk_dgrad, void* dA, const void* y_prod, const float* scale,
+                                   const float* shift, const float* mean, const float* rstd, int act_prod,
+                                   float* stats2_partial, int B, int H, int W, int K, int N, void* stream) {
+    PHX_REQUIRE(fwd_bws_ok(B, H, W, K, N), PHX_E_SHAPE, "conv3x3_mfma_bwdstats: shape not supported (see ..._supported)");
+    PHX_REQUIRE(y_prod && scale && shift && mean && rstd && stats2_partial, PHX_E_INVAL, "conv3x3_mfma_bwdstats: null argument");
+    BwdStats b;
+    b.y = (const unsigned short*)y_prod; b.scale = scale; b.shift = shift; b.mean = mean; b.rstd = rstd;
+    b.part = stats2_partial; b.act = act_prod; b._pad = 0;
+    return conv3x3_mfma_impl(dy, wpk_dgrad, dA, nullptr, PHX_ACT_ID, nullptr, nullptr, 0, B, H, W, K, N, b, stream);
+}
+
+static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
+                             void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, BwdStats bws,
+                             void* stream) {
     PHX_REQUIRE(K % KC == 0 && N % 32 == 0, PHX_E_SHAPE, "conv3x3_mfma: K % 32 == 0 and N % 32 == 0 required");
     PHX_REQUIRE((((uintptr_t)x | (uintptr_t)wpk | (uintptr_t)y) & 15) == 0, PHX_E_ALIGN, "conv3x3_mfma: 16-byte alignment");
     int ksplit = 1;
@@ -1401,11 +1482,11 @@ int phx_conv3x3_mfma_bf16_ws(const void* x, const void* wpk, void* y, const floa
             hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, false, NWv, Sv>), dim3(ntiles * (N / BNv), 1, ksplit),  \
                                dim3(NWv * 64), sh, (hipStream_t)stream, (const unsigned short*)x,                    \
                                (const unsigned short*)wpk, (unsigned short*)y, nullptr, 0, nullptr, B, H, W, K, N, g,\
-                               (float*)workspace);                                                                   \
+                               (float*)workspace, BwdStats{});                                                       \
         else                                                                                                         \
             hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, Av, NWv, false>), dim3(ntiles * (N / BNv)), dim3(NWv * 64),\
                                sh, (hipStream_t)stream, (const unsigned short*)x, (const unsigned short*)wpk,        \
-                               (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, g, nullptr);             \
+                               (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, g, nullptr, bws);        \
     } while (0)
 #define CM_LAUNCH(BNv, NAv, Fv, NWv)                                                                                 \
     do {                                                                                                             \

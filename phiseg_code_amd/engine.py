@@ -14,6 +14,7 @@ torch is used for device memory and, in ``distributed.py``, for torch.distribute
 arithmetic operation is a libphx kernel and a missing library is a hard error.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -298,6 +299,8 @@ class Plan:
         nl = len(self._lanes)
         self.op_lane = {op: self._lane_of(op) for op in ops}
         opset = set(ops)
+        self._opset = opset
+        self._bws = {}                # producer conv op -> (partials, tiles): BN-backward sums fused into the consumer's dgrad
         fork = self._record(0) if nl > 1 else None          # lanes 1.. join the capture / wait for the memsets
         for ln in range(1, nl):
             self._lane = ln
@@ -747,12 +750,18 @@ class Plan:
             nv = a["norm_vars"]
             y, NS, P, Gn = sv["y"], sv["NS"], sv["P"], sv["G"]
             nrep = 8 if P >= 4096 else 1           # replicated accumulators: see k_norm_bwd_reduce
+            fused = self._bws.pop(op, None)        # the consumer's data-gradient launch already produced the sums
+            if fused is not None:
+                nrep = 1
             sums2 = self._alloc_zeroed(nrep * NS * cout * 2)
             Sg = self._alloc((NS * Gn * 2,), F32)
             dY = self._alloc(y.shape, y.dt)
-            self._emit(Lb.norm_bwd_reduce, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
-                       sv["mean"].ptr, sv["rstd"].ptr, sums2.ptr, NS, P, cout, Gn, act, nrep, S,
-                       tag="bytes_norm_bwd_reduce", flops=float(dA.nbytes + y.nbytes))
+            if fused is not None:
+                self._emit(Lb.norm_reduce_partials, fused[0].ptr, fused[1], cout, sums2.ptr, S)
+            else:
+                self._emit(Lb.norm_bwd_reduce, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
+                           sv["mean"].ptr, sv["rstd"].ptr, sums2.ptr, NS, P, cout, Gn, act, nrep, S,
+                           tag="bytes_norm_bwd_reduce", flops=float(dA.nbytes + y.nbytes))
             self._emit(Lb.norm_bwd_apply_fused, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
                        sv["mean"].ptr, sv["rstd"].ptr, self.store.ptr(nv["gamma"]), sums2.ptr, dY.ptr, dY.dt,
                        self.store.grad_ptr(nv["gamma"]), self.store.grad_ptr(nv["beta"]), NS, P, cout, Gn, act, nrep, S,
@@ -808,7 +817,31 @@ class Plan:
             elif sv["mfma"]:
                 _, wd = self._packed(W)
 
+                # Optional fusion (PHX_FUSE_BWS=1, off by default): when the ONLY consumer of a = relu(bn(y)) of a batch-norm
+                # producer is this convolution, the data-gradient epilogue can also emit the producer's batch-norm backward
+                # sums (phx_conv3x3_mfma_bf16_bwdstats) and the producer skips its phx_norm_bwd_reduce pass.  Measured on
+                # MI355X: 25 of the 106 layers qualify; the data-gradient launches get 0.65 ms/step slower (the extra y-tile
+                # loads hit the staging path that already bounds them) while the dropped reduce passes, which stream at
+                # 4.6 TB/s, only saved 0.51 ms -- a net loss of 1.3 %.
+                prod = xin.op
+                psv = self.saved.get(prod) if prod is not None else None
+                fuse = (psv is not None and prod.type == "conv_unit" and psv.get("norm") == "batch" and "y" in psv
+                        and "mean" in psv and psv.get("NS") == 1 and psv.get("G") == cin and xin is prod.outputs[0]
+                        and self.val[xin].dt == BF16 and psv["y"].dt == BF16
+                        and len(self._real_consumers(xin, self._opset)) == 1
+                        and os.environ.get("PHX_FUSE_BWS", "0") == "1"
+                        and bool(Lb.conv3x3_mfma_bwdstats_supported(B, H, Wd, cout, cin)))
+
                 def wr_mfma(g):
+                    if fuse:
+                        ntile = Lb.conv3x3_mfma_bf16_tiles(B, H, Wd, cout, cin)
+                        part2 = self._alloc((ntile * 2 * cin,), F32)
+                        self._emit(Lb.conv3x3_mfma_bf16_bwdstats, dY.ptr, wd.ptr, g.ptr, psv["y"].ptr, psv["scale"].ptr,
+                                   psv["shift"].ptr, psv["mean"].ptr, psv["rstd"].ptr, rt.ACT_CODES[prod.attrs["act"]],
+                                   part2.ptr, B, H, Wd, cout, cin, S,
+                                   tag="conv3x3_mfma_dgrad", flops=18.0 * cin * cout * B * H * Wd)
+                        self._bws[prod] = (part2, ntile)
+                        return
                     wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cout, cin))
                     ws = self._alloc((wsb // 4,), F32) if wsb else None      # split-K slices (small maps)
                     self._emit(Lb.conv3x3_mfma_bf16_ws, dY.ptr, wd.ptr, g.ptr, None, 0, None, ws.ptr if ws else None, wsb,

@@ -205,6 +205,39 @@ def test_conv1x1_as_centre_tap(L, case):
     close(host(dw), wr.grad.numpy()[0, 0], 1e-4, "1x1 wgrad")
 
 
+@pytest.mark.parametrize("case", [(2, 32, 32, 64, 64), (1, 16, 48, 32, 192), (3, 64, 32, 128, 128), (40, 16, 16, 64, 96)])
+def test_dgrad_with_fused_bn_backward_statistics(L, case, monkeypatch):
+    """Data-gradient launch that also emits the producer layer's batch-norm backward sums: same dA as the plain launch,
+    and its reduced partials equal phx_norm_bwd_reduce run on that dA."""
+    B, H, W, K, N = case                       # K = channels of dy (consumer's Cout), N = channels of dA / y_prod
+    if case[1] % 32 == 0:
+        monkeypatch.setenv("PHX_FWD_BIG", "2")  # exercise the 16 x 32-tile kernels too
+    assert L.conv3x3_mfma_bwdstats_supported(B, H, W, K, N)
+    w = RNG.standard_normal((3, 3, N, K)) / np.sqrt(9 * N)
+    wd_ = dev(w)
+    wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    wg = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    L.pack_conv3x3_bf16(wd_.data_ptr(), wf.data_ptr(), wg.data_ptr(), N, K, S())
+    dy = dev(RNG.standard_normal((B, H, W, K)), BF16)
+    yp = dev(RNG.standard_normal((B, H, W, N)) * 1.3 + 0.2, BF16)
+    scale, shift = dev(1.0 + 0.2 * RNG.standard_normal(N)), dev(0.3 * RNG.standard_normal(N))
+    mean, rstd = dev(0.2 * RNG.standard_normal(N)), dev(0.8 + 0.3 * RNG.random(N))
+    dA1 = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
+    L.conv3x3_mfma_bf16(dy.data_ptr(), wg.data_ptr(), dA1.data_ptr(), None, 0, None, B, H, W, K, N, S())
+    sums_ref = torch.zeros(N, 2, dtype=torch.float32).cuda()
+    L.norm_bwd_reduce(dA1.data_ptr(), BF16, yp.data_ptr(), BF16, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                      rstd.data_ptr(), sums_ref.data_ptr(), 1, B * H * W, N, N, 1, 1, S())
+    ntile = L.conv3x3_mfma_bf16_tiles(B, H, W, K, N)
+    part = torch.zeros(ntile, 2, N, dtype=torch.float32).cuda()
+    dA2 = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
+    L.conv3x3_mfma_bf16_bwdstats(dy.data_ptr(), wg.data_ptr(), dA2.data_ptr(), yp.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                 mean.data_ptr(), rstd.data_ptr(), 1, part.data_ptr(), B, H, W, K, N, S())
+    assert torch.equal(dA1, dA2)
+    sums = torch.zeros(N, 2, dtype=torch.float32).cuda()
+    L.norm_reduce_partials(part.data_ptr(), ntile, N, sums.data_ptr(), S())
+    close(host(sums), host(sums_ref), 2e-5, "fused bn-backward sums")
+
+
 def _mfma_case(L, case):
     B, H, W, K, N = case
     x = RNG.standard_normal((B, H, W, K))
