@@ -29,6 +29,10 @@ _NP_DT = {F32: np.float32, U8: np.uint8}
 _ESIZE = {F32: 4, BF16: 2, U8: 1}
 
 
+def _noop():
+    pass
+
+
 def _device():
     if not torch.cuda.is_available():
         raise rt.PhxError("no GPU visible: the PHiSeg engine has no CPU fallback")
@@ -213,14 +217,17 @@ class Plan:
             self._cur.append((self.L.stream_wait_event, (self.stream, evl[0])))
             self._lane_seq[self._lane] = self._lane_seq.get(self._lane, 0) + 1
 
-    def _side_lane(self):
-        """Lane for leaf work (filter gradients) of the op being differentiated, or None.  Only ops of lane 0 qualify: a
-        cross-lane edge must have the capture's origin stream on one side (see _lane_of)."""
-        n = len(self._lanes)
-        if n < 3 or self._lane != 0 or os.environ.get("PHX_WGRAD_LANES", "0") != "1":
-            return None
-        self._side_rr = (getattr(self, "_side_rr", -1) + 1) % (n - 2)
-        return 2 + self._side_rr
+    def _prune_dead_event_records(self):
+        """Every gradient contribution records an event in case another lane folds it in; most are consumed on the lane
+        that produced them and nobody waits.  An unwaited record is still a node of the captured graph (214 records against
+        60 waits in the PHiSeg training plan): replace those by no-ops -- the launch list keeps its indices."""
+        if os.environ.get("PHX_PRUNE_EVENTS", "1") == "0":
+            return
+        for lst in (self.launches, self.opt_launches):
+            waited = {a[1].value for f, a in lst if f is self.L.stream_wait_event}
+            for i, (f, a) in enumerate(lst):
+                if f is self.L.event_record and a[0].value not in waited:
+                    lst[i] = (_noop, ())
 
     def _lane_of(self, op):
         """Lane plan.  Lane 0 (the capture's origin stream): posterior, the likelihood's top-down fusion path, losses.
@@ -343,6 +350,7 @@ class Plan:
             for evl in tails:
                 self._wait(evl)
         self._lane = 0
+        self._prune_dead_event_records()
         self.launches[0] = (self.L.memset, (self._zarena.data_ptr(), 0, max(self._zused, 1) * 4, self.stream))
         if self._pack_jobs:           # slot 1 was reserved before the fork: refresh every packed bf16 filter in one launch
             rec = np.zeros(len(self._pack_jobs), dtype=[("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("cin", "<i4"),
@@ -782,16 +790,8 @@ class Plan:
             dY = dA
         dw = self.store.grad_ptr(W)
         db = self.store.grad_ptr(b) if b is not None else None
-        # The filter gradient is a leaf of the backward graph (only the optimizer reads it) while the data gradient below is
-        # on the critical path.  Optional (PHX_WGRAD_LANES=1, off by default): the filter-gradient launches of lane-0 ops go
-        # to the per-level likelihood lanes and run beside the chain.  Measured: 19.3 vs 16.7 ms/step -- every cross-lane
-        # edge of a captured hipGraph costs more on ROCm 7.2 than the overlap wins.
-        home, side = self._lane, self._side_lane()
-        if side is not None:
-            ev = self._record(home)
-            self._lane = side
-            self._wait(ev)
-            S = self.stream
+        # (The filter gradient is a leaf of the backward graph; moving these launches to another lane, beside the data-
+        # gradient chain, was measured 20 % SLOWER: each cross-lane edge of a captured hipGraph costs ~30 us on ROCm 7.2.)
         if sv.get("head1x1"):
             self._emit(Lb.head1x1_wgrad, x.ptr, x.dt, dY.ptr, dw, db, B * H * Wd, cin, cout, S)
         elif sv.get("padded"):
@@ -814,9 +814,6 @@ class Plan:
                 self._emit(Lb.channel_sum_accumulate, dY.ptr, dY.dt, db, B * H * Wd, cout, S)
         else:
             self._emit(Lb.conv2d_direct_wgrad, x.ptr, x.dt, dY.ptr, dY.dt, dw, db, B, H, Wd, cin, cout, k, S)
-        if side is not None:
-            self._lane = home
-            S = self.stream
         xin = op.inputs[0]
         if self.req.get(xin, False):
             if sv.get("head1x1"):
