@@ -173,6 +173,7 @@ class Plan:
         self._lane = 0
         self._events = []
         self._last_rec, self._lane_seq = {}, {}
+        self._ev_order, self._waited = {}, {}
         self.launches, self.opt_launches = [], []
         self._cur = self.launches
         self.val, self.grad, self.saved = {}, {}, {}
@@ -209,11 +210,19 @@ class Plan:
         ev = self._new_event()
         self._cur.append((self.L.event_record, (ev, self._lanes[lane])))
         self._last_rec[lane] = (ev, self._lane_seq.get(lane, 0), self._cur)
+        self._ev_order[ev.value] = (id(self._cur), len(self._cur))      # position in the launch list = order on its lane
         return (ev, lane)
 
     def _wait(self, evl):
         """Make the current lane wait for an (event, lane) pair recorded elsewhere."""
         if evl is not None and evl[1] != self._lane:
+            # events of one lane are ordered: a wait for an event recorded BEFORE one this lane already waited for adds
+            # nothing but a graph edge (~3 us each in the replayed hipGraph)
+            lst, pos = self._ev_order.get(evl[0].value, (None, -1))
+            key = (self._lane, evl[1], lst)
+            if pos >= 0 and self._waited.get(key, -1) >= pos and os.environ.get("PHX_DEDUP_WAITS", "1") == "1":
+                return
+            self._waited[key] = pos
             self._cur.append((self.L.stream_wait_event, (self.stream, evl[0])))
             self._lane_seq[self._lane] = self._lane_seq.get(self._lane, 0) + 1
 
@@ -791,7 +800,8 @@ class Plan:
         dw = self.store.grad_ptr(W)
         db = self.store.grad_ptr(b) if b is not None else None
         # (The filter gradient is a leaf of the backward graph; moving these launches to another lane, beside the data-
-        # gradient chain, was measured 20 % SLOWER: each cross-lane edge of a captured hipGraph costs ~30 us on ROCm 7.2.)
+        # gradient chain, was measured 20 % SLOWER: both are bound by the same global->LDS path, so the kernel on the
+        # critical path just gets half of it.)
         if sv.get("head1x1"):
             self._emit(Lb.head1x1_wgrad, x.ptr, x.dt, dY.ptr, dw, db, B * H * Wd, cin, cout, S)
         elif sv.get("padded"):
