@@ -59,8 +59,18 @@ static int fwd_dma_bn(int B, int H, int W, int K, int N) {
     if (en == 3) return 64;                                    // tuning: 64-wide blocks everywhere
     return (N % 128 == 0 && (long)B * (H / 16) * (W / 32) >= 512) ? 128 : 0;
 }
+// register-staged 32 x 16-tile kernel (k_conv3x3_fwd_rs): 0 = not used, else the channel-block width
+static int fwd_rs_bn(int B, int H, int W, int K, int N) {
+    const char* e = getenv("PHX_FWD_RS");                      // 0: never; 1: policy; 2: whenever eligible (tests); 3: 64-wide everywhere
+    const int en = e ? atoi(e) : 0;
+    if (!en || H % 16 != 0 || W % 32 != 0 || N % 64 != 0) return 0;
+    const int bn = N % 128 == 0 ? 128 : 64;
+    if (en == 2) return bn;
+    if (en == 3) return 64;
+    return (N % 128 == 0 && (long)B * (H / 16) * (W / 32) >= 512) ? 128 : 0;
+}
 static MTile make_mtile_fwd(int B, int H, int W, int K, int N, bool allow_dma = true) {
-    if (allow_dma && fwd_dma_bn(B, H, W, K, N)) {
+    if (allow_dma && (fwd_dma_bn(B, H, W, K, N) || fwd_rs_bn(B, H, W, K, N))) {
         MTile g;
         g.tws = 5; g.ths = 4; g.tb = 1;
         g.tiles_x = W / 32; g.tiles_y = H / 16; g.tiles_b = B;
@@ -779,6 +789,206 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_fwd_dma(const unsigned short
     PHX_BLOCKLOG_END();
 #undef FWD_DMA_ISSUE
 }
+// ---- forward / data-gradient, 32x16-pixel tiles, register staging into double-buffered 16-channel LDS halves ----------
+// Tile geometry, LDS image (32-byte rows, source/slot swizzle), operand reads and epilogue of k_conv3x3_fwd_dma; the
+// staging differs: 64-byte global rows (full sectors, unlike that kernel's 32-byte DMA pieces) into registers, split into
+// the two 16-channel halves on the way into LDS.
+template <int BN, bool BIASACT>
+__global__ __launch_bounds__(512, 1) void k_conv3x3_fwd_rs(const unsigned short* __restrict__ x,
+                                                            const unsigned short* __restrict__ wpk,
+                                                            unsigned short* __restrict__ y, const float* __restrict__ bias,
+                                                            int act, float* __restrict__ stats_partial,
+                                                            int B, int H, int W, int K, int N, int tiles_x, int tiles_y) {
+    constexpr int NJ = BN / 64;                       // 32-channel accumulator tiles per wave
+    constexpr int NA = 5;                             // 612 patch rows x four 16-byte pieces / 512 threads
+    constexpr int NB = (9 * BN * 4 + 511) / 512;      // slab pieces per thread (9 for BN = 128, 4.5 -> 5 for BN = 64)
+    constexpr int A_BYTES = 640 * 32;                 // patch region of one 16-channel stage (612 rows used)
+    constexpr int STAGE = A_BYTES + 9 * BN * 32;
+    constexpr int OROW = BN * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int t = blockIdx.x;
+    const int tx0 = (t % tiles_x) << 5; t /= tiles_x;
+    const int ty0 = (t % tiles_y) << 4; t /= tiles_y;
+    const int b0 = t;
+    const int n0 = blockIdx.y * BN;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int pg = wave & 3, cg = wave >> 2;
+
+    // Staging plan.  Piece i = tid + 512 it is the 16-byte quarter q = tid & 3 of row (tid >> 2) + 128 it: global loads
+    // fetch whole 64-byte (32-channel) rows -- full sectors -- while the LDS image holds 16-channel HALVES: quarters 0, 1
+    // ("lo" lanes) belong to the stage buffer of channels 0..15 of the chunk, quarters 2, 3 ("hi" lanes) to 16..31.
+    const int q = threadIdx.x & 3, rowt = threadIdx.x >> 2;
+    const bool hi = q >= 2;
+    unsigned gA[NA];
+    int lA[NA];
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+        const int pp = rowt + it * 128;
+        const int py = pp / 34, px = pp - py * 34;
+        const int gx = tx0 + px - 1, gy = ty0 + py - 1;
+        gA[it] = 0xffffffffu;
+        lA[it] = pp < 612 ? pp * 32 + ((((q & 1) ^ (px >> 3)) & 1) << 4) : -1;
+        if (pp < 612 && gx >= 0 && gx < W && gy >= 0 && gy < H) gA[it] = (unsigned)((((b0 * H + gy) * W + gx) * K) * 2 + q * 16);
+    }
+    // slab rows advance 128 per piece: whole taps (BN = 128: one, BN = 64: two) -> scalar strides
+    const int rb0 = rowt, tap0 = rb0 / BN, nn0 = rb0 - tap0 * BN;
+    const unsigned gB0 = (unsigned)(((tap0 * N + n0 + nn0) * 32 + q * 8) * 2);
+    const int lB0 = A_BYTES + rb0 * 32 + ((((q & 1) ^ (nn0 >> 3)) & 1) << 4);
+    const int gBs = (128 / BN) * N * 64;              // global bytes between a thread's consecutive slab pieces
+    const bool lastB = threadIdx.x + (NB - 1) * 512 < 9 * BN * 4;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, (int)(9u * N * K * 2u), 0x00020000);
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 rA[NA], rB[NB];
+    auto load_chunk = [&](int c) {                    // 32-channel chunk c -> registers (zeros outside the image)
+#pragma unroll
+        for (int it = 0; it < NA; ++it) rA[it] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (PHX_ABLATE & 128) ? -1 : (int)gA[it], c * 64, 0);
+#pragma unroll
+        for (int it = 0; it < NB; ++it)
+            rB[it] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)(((PHX_ABLATE & 128) || (it == NB - 1 && !lastB)) ? 0xffffffffu : gB0),
+                                                           c * 9 * N * 64 + it * gBs, 0);
+    };
+    auto write_half = [&]() {                         // this lane's pieces -> its half's stage buffer
+        unsigned char* base = smem + (hi ? STAGE : 0);
+#pragma unroll
+        for (int it = 0; it < NA; ++it)
+            if (lA[it] >= 0) *reinterpret_cast<u32x4*>(base + lA[it]) = rA[it];
+#pragma unroll
+        for (int it = 0; it < NB; ++it)
+            if (it < NB - 1 || lastB) *reinterpret_cast<u32x4*>(base + lB0 + it * 4096) = rB[it];
+    };
+
+    // per-lane read bases (stage 0); tap / row-tile / channel-tile terms are immediates
+    unsigned aK[3], bK;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+        aK[kw] = (unsigned)((pg * 4 * 34 + l31 + kw) * 32 + (((khalf ^ ((l31 + kw) >> 3)) & 1) << 4));
+    bK = (unsigned)(A_BYTES + (cg * (BN / 2) + l31) * 32 + (((khalf ^ (l31 >> 3)) & 1) << 4));
+
+    f32x16 acc[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    PHX_BLOCKLOG_BEGIN();
+    // Pipeline over 16-channel stages s (chunk s >> 1, half s & 1), buffer s & 1.  Both buffers are free at the start, so
+    // chunk 0 goes in whole; afterwards the "lo" lanes refill buffer 0 during the odd stages (which read buffer 1) and the
+    // "hi" lanes buffer 1 during the even ones, each lane reloading its registers with the next chunk right after its own
+    // write -- two stages ahead of use.  One barrier per stage, no phase without MFMAs.
+    const int nst = K / 16, nch = K / 32;
+    load_chunk(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    write_half();
+    if (nch > 1) load_chunk(1);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int s = 0; s < nst; ++s) {
+        const int cw = (s + 1) >> 1;                   // chunk whose half gets written during this stage
+        if (s >= 1 && cw < nch && hi == ((s & 1) == 0)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            write_half();
+            if (cw + 1 < nch) load_chunk(cw + 1);
+        }
+        const unsigned sb = (unsigned)((s & 1) * STAGE);
+        bf16x8 fa[2][4], fb[2][NJ];
+        auto read_frags = [&](auto tc) {
+            constexpr int tp = decltype(tc)::value;
+            constexpr int kh = tp / 3, kw = tp % 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                fa[tp & 1][i] = *reinterpret_cast<const bf16x8*>(smem + sb + aK[kw] + (i + kh) * 34 * 32);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                fb[tp & 1][j] = *reinterpret_cast<const bf16x8*>(smem + sb + bK + (tp * BN + j * 32) * 32);
+        };
+        read_frags(std::integral_constant<int, 0>());
+        auto taps = [&](auto self, auto tc) {
+            constexpr int tp = decltype(tc)::value;
+            if constexpr (tp < 9) {
+                if constexpr (tp < 8) read_frags(std::integral_constant<int, tp + 1>());
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        if constexpr (PHX_ABLATE & 64) acc[i][j][(tp + i + j) & 15] += (float)fa[tp & 1][i][0] * (float)fb[tp & 1][j][0];
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tp & 1][i], fb[tp & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                self(self, std::integral_constant<int, tp + 1>());
+            }
+        };
+        taps(taps, std::integral_constant<int, 0>());
+        if (s + 1 < nst) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // operand reads done: LDS becomes the output tile
+
+    // epilogue (interior tiles only): pack pairs of rows, statistics, transpose through LDS, 16-byte stores
+    if constexpr (BIASACT) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float bv = bias ? bias[n0 + cg * (BN / 2) + j * 32 + l31] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r] + bv, act);
+        }
+    }
+    const int odd = lane & 1;
+    float s1[NJ], s2[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) s1[j] = s2[j] = 0.f;
+    unsigned char* lw = smem + (pg * 128 + 4 * khalf + odd) * OROW + (cg * (BN / 2) + (l31 & ~1)) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rp = 0; rp < 8; ++rp)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int r0 = 2 * rp;
+                const unsigned w2 = f2bf_pk(acc[i][j][r0], acc[i][j][r0 + 1]);
+                const float ra_ = __uint_as_float(w2 << 16), rb_ = __uint_as_float(w2 & 0xffff0000u);
+                s1[j] += ra_ + rb_;
+                s2[j] += ra_ * ra_ + rb_ * rb_;
+                const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)w2, 0xB1, 0xf, 0xf, true);
+                const unsigned word = odd ? ((nb >> 16) | (w2 & 0xffff0000u)) : ((w2 & 0xffffu) | (nb << 16));
+                *reinterpret_cast<unsigned*>(lw + (i * 32 + (r0 & 3) + 8 * (r0 >> 2)) * OROW + j * 64) = word;
+            }
+    __syncthreads();
+    {
+        constexpr int PPP = BN / 8;                   // 16-byte pieces per pixel
+        constexpr int PSTEP = 512 / PPP;              // pixels between a thread's pieces: 32 (one tile row) or 64
+        const int mt = threadIdx.x / PPP, q = threadIdx.x % PPP;
+        const unsigned char* lr = smem + mt * OROW + q * 16;
+        unsigned short* yp = y + (((size_t)b0 * H + ty0 + (mt >> 5)) * W + tx0 + (mt & 31)) * N + n0 + q * 8;
+        const size_t ystep = (size_t)(PSTEP / 32) * W * N;
+#pragma unroll
+        for (int it = 0; it < PPP; ++it)
+            *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * PSTEP * OROW);
+    }
+    if (stats_partial) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);      // [4 pixel groups][2][BN]
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float a = s1[j] + __shfl_xor(s1[j], 32, 64);
+            const float bq = s2[j] + __shfl_xor(s2[j], 32, 64);
+            if (khalf == 0) {
+                red[(pg * 2 + 0) * BN + cg * (BN / 2) + j * 32 + l31] = a;
+                red[(pg * 2 + 1) * BN + cg * (BN / 2) + j * 32 + l31] = bq;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * BN) {
+            const int which = threadIdx.x / BN, n = threadIdx.x % BN;
+            const float v = (red[(0 * 2 + which) * BN + n] + red[(1 * 2 + which) * BN + n]) +
+                            (red[(2 * 2 + which) * BN + n] + red[(3 * 2 + which) * BN + n]);
+            stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + n] = v;
+        }
+    }
+    PHX_BLOCKLOG_END();
+}
 
 // ---- filter gradient --------------------------------------------------------------------------------------
 // Block tile: TCI input channels x TCO output channels (32 or 64 each) x all 9 taps.  The 4 waves split the tile
@@ -1393,7 +1603,7 @@ int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* 
 
 // the fused-statistics epilogue lives in the full-tile path of the 16-wide-tile kernels: every tile must be interior
 static bool fwd_bws_ok(int B, int H, int W, int K, int N) {
-    if (fwd_dma_bn(B, H, W, K, N) || fwd_ksplit(B, H, W, K, N) > 1) return false;
+    if (fwd_dma_bn(B, H, W, K, N) || fwd_rs_bn(B, H, W, K, N) || fwd_ksplit(B, H, W, K, N) > 1) return false;
     if (fwd_big_tiles(B, H, W, K, N)) return true;                       // H % 32 == 0, W % 16 == 0
     return H % 16 == 0 && W % 16 == 0;
 }
@@ -1429,6 +1639,25 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
         ksplit = fwd_ksplit(B, H, W, K, N);
         PHX_REQUIRE(workspace_bytes >= (size_t)(ksplit > 1 ? ksplit : 0) * B * H * W * N * sizeof(float), PHX_E_INVAL,
                     "conv3x3_mfma: workspace too small");
+    }
+    if (const int rbn = fwd_rs_bn(B, H, W, K, N)) {
+        const bool ba = bias != nullptr || act != PHX_ACT_ID;
+        static bool rattr = false;
+#define FR_ATTR(BNv, Av) PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_rs<BNv, Av>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+        if (!rattr) { FR_ATTR(128, false); FR_ATTR(128, true); FR_ATTR(64, false); FR_ATTR(64, true); rattr = true; }
+#undef FR_ATTR
+        PHX_REQUIRE((double)B * H * W * (K > N ? K : N) < 2147483648.0, PHX_E_SHAPE, "conv3x3_mfma: tensor exceeds 2^31 elements");
+        const int ntl = B * (H / 16) * (W / 32);
+#define FR_LAUNCH(BNv, Av, SHv)                                                                                       \
+    hipLaunchKernelGGL((k_conv3x3_fwd_rs<BNv, Av>), dim3(ntl, N / BNv), dim3(512), SHv, (hipStream_t)stream,           \
+                       (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B,  \
+                       H, W, K, N, W / 32, H / 16)
+        // LDS: two stages or the 512-pixel output tile, whichever is larger
+        if (rbn == 128) { if (ba) FR_LAUNCH(128, true, 512 * (128 * 2 + 16)); else FR_LAUNCH(128, false, 512 * (128 * 2 + 16)); }
+        else { if (ba) FR_LAUNCH(64, true, 2 * (640 * 32 + 9 * 64 * 32)); else FR_LAUNCH(64, false, 2 * (640 * 32 + 9 * 64 * 32)); }
+#undef FR_LAUNCH
+        PHX_CHECK_LAUNCH();
+        return PHX_OK;
     }
     if (const int dbn = fwd_dma_bn(B, H, W, K, N)) {
         const bool ba = bias != nullptr || act != PHX_ACT_ID;

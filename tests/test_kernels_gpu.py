@@ -165,6 +165,14 @@ def test_conv3x3_mfma_dma_tiles(L, case, monkeypatch):
     _mfma_case(L, case)
 
 
+# same tile geometry, register staging into double-buffered 16-channel LDS halves (k_conv3x3_fwd_rs)
+@pytest.mark.parametrize("case", [(2, 16, 32, 32, 128), (1, 32, 64, 96, 64), (3, 16, 32, 32, 192), (1, 48, 32, 64, 256),
+                                  (1, 16, 64, 160, 128)])
+def test_conv3x3_mfma_rs_tiles(L, case, monkeypatch):
+    monkeypatch.setenv("PHX_FWD_RS", "2")
+    _mfma_case(L, case)
+
+
 @pytest.mark.parametrize("case", [(2, 16, 16, 38, 32), (1, 32, 32, 64, 64)])
 def test_conv1x1_as_centre_tap(L, case):
     """1x1 filters (prob_unet2D's recombination layers, model_zoo/likelihoods.py) run on the 3x3 MFMA kernels as the centre
