@@ -31,9 +31,25 @@ class _Split:
         return make_batch(batch_size, self.size, self.nlabels, self.rng)
 
 
+class _ValidationSplit(_Split):
+    """``.images`` [n, X, Y, 1] and ``.labels`` [n, X, Y, annotators] as phiseg_model._do_validation reads them
+    (data/batch_provider.py keeps the validation set as arrays): every image with `annotators` differing masks."""
+
+    def __init__(self, size, nlabels, seed, n_images=8, annotators=4):
+        super().__init__(size, nlabels, seed)
+        xs, ls = [], []
+        for _ in range(n_images):
+            x, _ = make_batch(1, size, nlabels, self.rng)
+            _, s = make_batch(annotators, size, nlabels, self.rng)
+            xs.append(x[0])
+            ls.append(np.transpose(s, (1, 2, 0)))
+        self.images, self.labels = np.stack(xs), np.stack(ls)
+
+
 class SyntheticLIDC:
     """Object with the ``.train`` / ``.validation`` surface of the reference's ``lidc_data`` (data/lidc_data.py)."""
 
-    def __init__(self, exp_config, seed=1234):
+    def __init__(self, exp_config, seed=1234, n_validation=8):
         self.train = _Split(exp_config.image_size[0], exp_config.nlabels, seed)
-        self.validation = _Split(exp_config.image_size[0], exp_config.nlabels, seed + 1)
+        self.validation = _ValidationSplit(exp_config.image_size[0], exp_config.nlabels, seed + 1, n_validation,
+                                           getattr(exp_config, "num_labels_per_subject", 4))

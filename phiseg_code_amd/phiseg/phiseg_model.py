@@ -203,6 +203,42 @@ class phiseg():
                 self.save_weights(os.path.join(log_dir, 'model.ckpt-%d.npz' % step))
         return losses
 
+    # ---- validation (phiseg_model.py:530-660): N Monte-Carlo samples per image, metrics on the device ---------------
+    def _do_validation(self, data):
+        """For every validation image: `validation_samples` segmentation samples + the ELBO against one randomly chosen
+        annotation (phiseg_model.py:570-586), then GED over the foreground labels, variance-NCC and the Dice of the mean
+        prediction (586-613).  The reference scores these in Python loops on the host (N*M + N^2 + M^2 IoU evaluations per
+        image); here they are one libphx call per image (utils.validation_metrics -> phx_validation_metrics).
+        -> dict(loss, dice, per_structure_dice, ged, ncc), the averages the reference logs (615-634)."""
+        cfg = self.exp_config
+        imgs, labs = data.validation.images, data.validation.labels
+        n_img = imgs.shape[0] if cfg.num_validation_images == 'all' else min(cfg.num_validation_images, imgs.shape[0])
+        ns = cfg.validation_samples
+        dice_list, elbo_list, ged_list, ncc_list = [], [], [], []
+        for ii in range(n_img):
+            x = imgs[ii, ...].reshape([1] + list(cfg.image_size))
+            s_gt_arr = labs[ii, ...]                                   # [X, Y, num annotators]
+            s = s_gt_arr[:, :, np.random.choice(cfg.annotator_range)]
+            x_b, s_b = np.tile(x, [ns, 1, 1, 1]), np.tile(s, [ns, 1, 1])
+            fd = {self.training_pl: False, self.x_inp: x_b, self.s_inp: s_b}
+            sm_arr, elbo = self.sess.run([self.s_out_eval_sm, self.loss_tot], feed_dict=fd)
+            self._advance_noise()
+            gts = np.ascontiguousarray(s_gt_arr.transpose((2, 0, 1)))  # num annotators x X x Y
+            ged, ncc, dice = utils.validation_metrics(sm_arr[None], gts[None], s[None], cfg.nlabels)
+            dice_list.append(dice[0])
+            elbo_list.append(float(elbo))
+            ged_list.append(float(ged[0]))
+            ncc_list.append(float(ncc[0]))
+        dice_arr = np.asarray(dice_list)
+        out = dict(loss=utils.list_mean(elbo_list), dice=float(np.mean(dice_arr)), per_structure_dice=dice_arr.mean(axis=0),
+                   ged=utils.list_mean(ged_list), ncc=utils.list_mean(ncc_list))
+        logging.info('FULL VALIDATION (%d images):' % n_img)
+        logging.info(' - Mean foreground dice: %.4f' % np.mean(out['per_structure_dice']))
+        logging.info(' - Mean (neg.) ELBO: %.4f' % out['loss'])
+        logging.info(' - Mean GED: %.4f' % out['ged'])
+        logging.info(' - Mean NCC: %.4f' % out['ncc'])
+        return out
+
     # ---- checkpoints (npz keyed by the TF variable names of SURVEY.md Appendix B) -------------------
     def save_weights(self, path):
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
