@@ -1,7 +1,8 @@
 // Validation metrics on the device: generalised energy distance, variance-NCC and per-label
 // Dice exactly as phiseg_model._do_validation scores one image (phiseg_model.py:586-613 calling utils.py:270-370), for a
 // batch of images in three launches.  The reference evaluates N*M + N^2 + M^2 pairwise IoU distances per image in Python
-// loops on the host; here every (mask, mask) pair is one block.
+// loops on the host; here the label maps become bit planes (one ballot per 64 pixels and label) and every (mask, mask) pair
+// is one wave of popcounts.
 #include "phx_common.h"
 
 #define MT_MAXC 8
@@ -9,34 +10,62 @@
 
 // ---- A: per pixel -- arg-max label maps, mean soft-max arg-max, cross-entropy maps and their moments ------------------
 // acc[i][0] = sum a, [1] = sum a^2, [2 + 3 j ..] = sum v_j, sum v_j^2, sum a v_j   (a = E_ss map, v_j = E_sy[j] map)
+// planes[img][mask][c][word] : bit p % 64 of word p / 64 = (mask label at pixel p == c); masks 0..N-1 samples, N mean arg-max,
+// N+1..N+M annotations, N+M+1 sref -- the pair kernel works on these (1 bit per pixel and label instead of a byte per pixel)
 __global__ void k_metrics_pixel(const float* __restrict__ sm, const unsigned char* __restrict__ gt,
-                                unsigned char* __restrict__ lab, double* __restrict__ acc, int N, int M, int P, int C) {
+                                const unsigned char* __restrict__ sref, unsigned long long* __restrict__ planes,
+                                double* __restrict__ acc, int N, int M, int P, int C) {
     const int img = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int NMK = N + M + 2, W64 = (P + 63) / 64, word = p >> 6;
+    unsigned long long* pl = planes + (size_t)img * NMK * MT_MAXC * W64;
+    auto put_planes = [&](int mask, int label) {         // whole wave: one ballot per label (label < 0: pixel beyond P)
+#pragma unroll
+        for (int c = 0; c < MT_MAXC; ++c)
+            if (c < C) {
+                const unsigned long long bits = __ballot(label == c);
+                if ((threadIdx.x & 63) == 0 && (blockIdx.x * blockDim.x + (threadIdx.x & ~63)) < P)
+                    pl[((size_t)mask * MT_MAXC + c) * W64 + word] = bits;
+            }
+    };
     float vals[2 + 3 * MT_MAXM];
 #pragma unroll
     for (int k = 0; k < 2 + 3 * MT_MAXM; ++k) vals[k] = 0.f;
-    if (p < P) {
-        float mean[MT_MAXC], slog[MT_MAXC];
+    const bool in = p < P;
+    float mean[MT_MAXC], slog[MT_MAXC];
 #pragma unroll
-        for (int c = 0; c < MT_MAXC; ++c) mean[c] = slog[c] = 0.f;
-        for (int n = 0; n < N; ++n) {
-            const float* q = sm + (((size_t)img * N + n) * P + p) * C;
-            int best = 0;
-            float bv = q[0];
+    for (int c = 0; c < MT_MAXC; ++c) mean[c] = slog[c] = 0.f;
+    // four samples per trip, loads first (a thread's trips are serially dependent: the loads in flight set the speed)
+    for (int n0 = 0; n0 < N; n0 += 4) {
+        float v[4][MT_MAXC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int c = 0; c < MT_MAXC; ++c)
-                if (c < C) {
-                    const float v = q[c];
-                    mean[c] += v;
-                    slog[c] += logf(v + 1e-8f);
-                    if (v > bv) { bv = v; best = c; }           // first maximum wins, like np.argmax
-                }
-            lab[((size_t)img * (N + 1) + n) * P + p] = (unsigned char)best;
+                v[u][c] = (in && n0 + u < N && c < C) ? sm[(((size_t)img * N + n0 + u) * P + p) * C + c] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (n0 + u >= N) break;                      // uniform
+            int best = -1;
+            if (in) {
+                best = 0;
+                float bv = v[u][0];
+#pragma unroll
+                for (int c = 0; c < MT_MAXC; ++c)
+                    if (c < C) {
+                        mean[c] += v[u][c];
+                        slog[c] += logf(v[u][c] + 1e-8f);
+                        if (v[u][c] > bv) { bv = v[u][c]; best = c; }   // first maximum wins, like np.argmax
+                    }
+            }
+            put_planes(n0 + u, best);
         }
+    }
+    int bmi = -1;
+    if (in) {
         const float invn = 1.f / (float)N;
         float ess = 0.f, bm = -1.f;
-        int bmi = 0;
+        bmi = 0;
 #pragma unroll
         for (int c = 0; c < MT_MAXC; ++c)
             if (c < C) {
@@ -45,7 +74,6 @@ __global__ void k_metrics_pixel(const float* __restrict__ sm, const unsigned cha
                 if (mc > bm) { bm = mc; bmi = c; }
             }
         ess *= invn;
-        lab[((size_t)img * (N + 1) + N) * P + p] = (unsigned char)bmi;
         vals[0] = ess;
         vals[1] = ess * ess;
 #pragma unroll
@@ -61,6 +89,9 @@ __global__ void k_metrics_pixel(const float* __restrict__ sm, const unsigned cha
                 vals[4 + 3 * j] = ess * v;
             }
     }
+    put_planes(N, bmi);
+    for (int j = 0; j < M; ++j) put_planes(N + 1 + j, in ? (int)gt[((size_t)img * M + j) * P + p] : -1);
+    put_planes(N + M + 1, in ? (int)sref[(size_t)img * P + p] : -1);
     __shared__ double red[4][2 + 3 * MT_MAXM];
     const int nv = 2 + 3 * M;
     for (int k = 0; k < nv; ++k) {
@@ -77,53 +108,45 @@ __global__ void k_metrics_pixel(const float* __restrict__ sm, const unsigned cha
     }
 }
 
-// ---- B: one block per (mask a, mask b) pair -- per-label counts and intersections -----------------------------------------
-// masks 0..N-1: sample label maps, N..N+M-1: annotations; pair index npairs: (arg-max of the mean soft-max, sref) for Dice
+// ---- B: one wave per (mask a, mask b) pair -- per-label counts and intersections by popcount over the bit planes ---------
+// pair p < npairs: masks a < b among {N samples, M annotations}; pair npairs: (arg-max of the mean soft-max, sref) for the Dice
 // stats[i][pair][c][3] = {|a == c|, |b == c|, |a == c and b == c|}
-__global__ void k_metrics_pairs(const unsigned char* __restrict__ lab, const unsigned char* __restrict__ gt,
-                                const unsigned char* __restrict__ sref, int* __restrict__ stats, int N, int M, int P, int C) {
-    const int img = blockIdx.y, K = N + M, npairs = K * (K - 1) / 2;
-    int idx = blockIdx.x, a = 0, b = 0;
-    const unsigned char *ma, *mb;
-    if (idx < npairs) {
+__global__ void k_metrics_pairs(const unsigned long long* __restrict__ planes, int* __restrict__ stats, int N, int M, int P,
+                                int C, int label0) {
+    const int img = blockIdx.y, K = N + M, npairs = K * (K - 1) / 2, NMK = N + M + 2, W64 = (P + 63) / 64;
+    const int pair = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pair > npairs) return;
+    int ia, ib;
+    if (pair < npairs) {
+        int idx = pair, a = 0;
         while (idx >= K - 1 - a) { idx -= K - 1 - a; ++a; }
-        b = a + 1 + idx;
-        ma = a < N ? lab + ((size_t)img * (N + 1) + a) * P : gt + ((size_t)img * M + (a - N)) * P;
-        mb = b < N ? lab + ((size_t)img * (N + 1) + b) * P : gt + ((size_t)img * M + (b - N)) * P;
+        const int b = a + 1 + idx;
+        ia = a < N ? a : a + 1;                       // plane index: annotations sit behind the mean-arg-max plane
+        ib = b < N ? b : b + 1;
     } else {
-        ma = lab + ((size_t)img * (N + 1) + N) * P;
-        mb = sref + (size_t)img * P;
+        ia = N;
+        ib = N + M + 1;
     }
-    int ca[MT_MAXC], cb[MT_MAXC], ci[MT_MAXC];
-#pragma unroll
-    for (int c = 0; c < MT_MAXC; ++c) ca[c] = cb[c] = ci[c] = 0;
-    for (int p = threadIdx.x; p < P; p += blockDim.x) {
-        const int la = ma[p], lb = mb[p];
-#pragma unroll
-        for (int c = 0; c < MT_MAXC; ++c) {
-            ca[c] += (la == c);
-            cb[c] += (lb == c);
-            ci[c] += (la == c) & (lb == c);
+    const unsigned long long* pa = planes + ((size_t)img * NMK + ia) * MT_MAXC * W64;
+    const unsigned long long* pb = planes + ((size_t)img * NMK + ib) * MT_MAXC * W64;
+    for (int c = (pair < npairs ? label0 : 0); c < C; ++c) {   // the GED only looks at labels label0 .. C-1
+        int x = 0, y = 0, z = 0;
+        for (int w = lane; w < W64; w += 64) {
+            const unsigned long long ua = pa[(size_t)c * W64 + w], ub = pb[(size_t)c * W64 + w];
+            x += __popcll(ua);
+            y += __popcll(ub);
+            z += __popcll(ua & ub);
         }
-    }
-    __shared__ int red[4][MT_MAXC][3];
-#pragma unroll
-    for (int c = 0; c < MT_MAXC; ++c) {
-        int x = ca[c], y = cb[c], z = ci[c];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             x += __shfl_xor(x, o, 64);
             y += __shfl_xor(y, o, 64);
             z += __shfl_xor(z, o, 64);
         }
-        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][c][0] = x; red[threadIdx.x >> 6][c][1] = y; red[threadIdx.x >> 6][c][2] = z; }
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < C * 3) {
-        const int c = threadIdx.x / 3, w = threadIdx.x % 3;
-        int v = 0;
-        for (int q = 0; q < (int)(blockDim.x >> 6); ++q) v += red[q][c][w];
-        stats[(((size_t)img * (npairs + 1) + blockIdx.x) * MT_MAXC + c) * 3 + w] = v;
+        if (lane == 0) {
+            int* st = stats + (((size_t)img * (npairs + 1) + pair) * MT_MAXC + c) * 3;
+            st[0] = x; st[1] = y; st[2] = z;
+        }
     }
 }
 
@@ -179,7 +202,7 @@ extern "C" {
 size_t phx_validation_metrics_ws_bytes(int I, int N, int M, int P, int C) {
     (void)C;
     const size_t K = (size_t)N + M, npairs = K * (K - 1) / 2;
-    return mt_align((size_t)I * (N + 1) * P) + mt_align((size_t)I * (2 + 3 * MT_MAXM) * sizeof(double)) +
+    return mt_align((size_t)I * (N + M + 2) * MT_MAXC * ((P + 63) / 64) * 8) + mt_align((size_t)I * (2 + 3 * MT_MAXM) * sizeof(double)) +
            mt_align((size_t)I * (npairs + 1) * MT_MAXC * 3 * sizeof(int));
 }
 
@@ -190,14 +213,15 @@ int phx_validation_metrics(const float* sm, const unsigned char* gt, const unsig
                 "validation_metrics: 2 <= C <= 8, M <= 8, 0 <= label0 < C");
     PHX_REQUIRE(work_bytes >= phx_validation_metrics_ws_bytes(I, N, M, P, C), PHX_E_INVAL, "validation_metrics: workspace too small");
     const size_t K = (size_t)N + M, npairs = K * (K - 1) / 2;
-    unsigned char* lab = (unsigned char*)work;
-    double* acc = (double*)((char*)work + mt_align((size_t)I * (N + 1) * P));
+    unsigned long long* planes = (unsigned long long*)work;
+    double* acc = (double*)((char*)work + mt_align((size_t)I * (N + M + 2) * MT_MAXC * ((P + 63) / 64) * 8));
     int* stats = (int*)((char*)acc + mt_align((size_t)I * (2 + 3 * MT_MAXM) * sizeof(double)));
     PHX_CHECK_HIP(hipMemsetAsync(acc, 0, (size_t)I * (2 + 3 * MT_MAXM) * sizeof(double), (hipStream_t)stream));
-    hipLaunchKernelGGL(k_metrics_pixel, dim3((P + 255) / 256, I), dim3(256), 0, (hipStream_t)stream, sm, gt, lab, acc, N, M, P, C);
-    PHX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_metrics_pairs, dim3((unsigned)npairs + 1, I), dim3(256), 0, (hipStream_t)stream, lab, gt, sref, stats, N,
+    hipLaunchKernelGGL(k_metrics_pixel, dim3((P + 255) / 256, I), dim3(256), 0, (hipStream_t)stream, sm, gt, sref, planes, acc, N,
                        M, P, C);
+    PHX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_metrics_pairs, dim3((unsigned)(npairs + 1 + 3) / 4, I), dim3(256), 0, (hipStream_t)stream, planes, stats,
+                       N, M, P, C, label0);
     PHX_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_metrics_final, dim3(I), dim3(64), 0, (hipStream_t)stream, stats, acc, N, M, P, C, label0, out);
     PHX_CHECK_LAUNCH();
