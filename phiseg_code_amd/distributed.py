@@ -26,7 +26,8 @@ class DistContext:
         if self.active and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            backend = backend or ("nccl" if self.cuda else "gloo")
+            # PHX_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL refuses duplicate devices) -- protocol tests only
+            backend = backend or os.environ.get("PHX_DIST_BACKEND") or ("nccl" if self.cuda else "gloo")
             kw = {}
             if backend == "nccl":
                 kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
