@@ -16,6 +16,9 @@
 #ifndef PHX_ABLATE      // dev only (tools/build_ablate.sh): fwd 1 no global loads, 2 no LDS staging stores, 4 no MFMAs, 8 no output stores; wgrad 16 no global loads, 32 no MFMAs
 #define PHX_ABLATE 0
 #endif
+#ifndef PHX_FRAG_DEPTH  // operand-fragment prefetch distance (in 4-MFMA groups) of the 256-pixel kernels
+#define PHX_FRAG_DEPTH 2
+#endif
 #define KC 32            // input channels per LDS stage (two MFMA k-steps)
 #define ROWB 80          // bytes per pixel / filter row in LDS: 32 bf16 + 16 B pad -> conflict-free ds_read_b128
 
@@ -69,8 +72,16 @@ static int fwd_rs_bn(int B, int H, int W, int K, int N) {
     if (en == 3) return 64;
     return (N % 128 == 0 && (long)B * (H / 16) * (W / 32) >= 512) ? 128 : 0;
 }
+// wave-specialised 32 x 16-tile x 64-channel kernel (k_conv3x3_fwd_ws64)
+static bool fwd_ws64(int B, int H, int W, int K, int N) {
+    const char* e = getenv("PHX_FWD_WS");                      // 0: never; 1: policy; 2: whenever eligible (tests / tuning)
+    const int en = e ? atoi(e) : 0;
+    if (!en || H % 16 != 0 || W % 32 != 0 || N % 64 != 0 || K % 32 != 0) return false;
+    if (en == 2) return true;
+    return (long)B * (H / 16) * (W / 32) * (N / 64) >= 512;
+}
 static MTile make_mtile_fwd(int B, int H, int W, int K, int N, bool allow_dma = true) {
-    if (allow_dma && (fwd_dma_bn(B, H, W, K, N) || fwd_rs_bn(B, H, W, K, N))) {
+    if (allow_dma && (fwd_ws64(B, H, W, K, N) || fwd_dma_bn(B, H, W, K, N) || fwd_rs_bn(B, H, W, K, N))) {
         MTile g;
         g.tws = 5; g.ths = 4; g.tb = 1;
         g.tiles_x = W / 32; g.tiles_y = H / 16; g.tiles_b = B;
@@ -370,7 +381,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
         // issued before the MFMAs of group gi (fragment registers double-buffered by group parity)
         // (NJ = 4 keeps a single fragment set -- 128 accumulator registers leave no room for two; its 8 MFMAs per group
         // cover the LDS latency of the next group's reads, which are issued right behind them)
-        constexpr int FB = NJ <= 2 ? 2 : 1;
+        constexpr int FB = NJ <= 2 ? (PHX_FRAG_DEPTH + 1) : 1;      // fragment sets: reads run PHX_FRAG_DEPTH groups ahead
         bf16x8 fa[FB][2], fb[FB][NJ];
         auto read_frags = [&](auto gc) {
             constexpr int gi = decltype(gc)::value;
@@ -384,10 +395,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
                 fb[gi % FB][j] = *reinterpret_cast<const bf16x8*>(sB + (tap * BN + j * 32) * ROWB + boff + ks * 32);
         };
         read_frags(std::integral_constant<int, 0>());
+        if constexpr (FB >= 3) read_frags(std::integral_constant<int, 1>());
         auto group = [&](auto self, auto gc) {
             constexpr int gi = decltype(gc)::value;
             if constexpr (gi < 18) {
-                if constexpr (FB == 2 && gi < 17) read_frags(std::integral_constant<int, gi + 1>());
+                if constexpr (FB >= 2 && gi + FB - 1 < 18) read_frags(std::integral_constant<int, gi + FB - 1>());
                 if constexpr (PF) {
                     auto pieces = [&](auto self2, auto pc) {
                         constexpr int pi = decltype(pc)::value;
@@ -402,7 +414,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        if constexpr (PHX_ABLATE & 4) acc[i][j][(gi + i + j) & 15] += (float)fa[gi % FB][i][0] * (float)fb[gi % FB][j][0];
+                        if constexpr (PHX_ABLATE & 4) acc[i][j][0] += (float)fa[gi % FB][i][0] * (float)fb[gi % FB][j][0];   // (static index: keeps the operand reads alive)
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[gi % FB][i], fb[gi % FB][j], acc[i][j], 0, 0, 0);
                 if constexpr (FB == 1 && gi < 17) read_frags(std::integral_constant<int, gi + 1>());
                 __builtin_amdgcn_sched_barrier(0);
@@ -913,7 +925,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_fwd_rs(const unsigned short*
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        if constexpr (PHX_ABLATE & 64) acc[i][j][(tp + i + j) & 15] += (float)fa[tp & 1][i][0] * (float)fb[tp & 1][j][0];
+                        if constexpr (PHX_ABLATE & 64) acc[i][j][0] += (float)fa[tp & 1][i][0] * (float)fb[tp & 1][j][0];
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tp & 1][i], fb[tp & 1][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 self(self, std::integral_constant<int, tp + 1>());
@@ -984,6 +996,197 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_fwd_rs(const unsigned short*
             const int which = threadIdx.x / BN, n = threadIdx.x % BN;
             const float v = (red[(0 * 2 + which) * BN + n] + red[(1 * 2 + which) * BN + n]) +
                             (red[(2 * 2 + which) * BN + n] + red[(3 * 2 + which) * BN + n]);
+            stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + n] = v;
+        }
+    }
+    PHX_BLOCKLOG_END();
+}
+
+// ---- forward / data-gradient, 32x16-pixel tiles x 64 channels, wave-specialised: 8 MFMA waves + 2 loader waves ----------
+// Ablation of the kernels above (tools/build_ablate.sh) shows their load and MFMA costs ADD: a wave that is issuing global
+// loads cannot issue MFMAs, interleaved or not.  Here the staging is taken out of the MFMA waves altogether: waves 8 and 9
+// only issue buffer_load ... lds DMA for the NEXT 32-channel chunk (whole 64-byte rows -> full sectors; double-buffered
+// 75 KiB stages) and wait for it to land, waves 0-7 only read operands and issue MFMAs (64 pixels x 64 channels each);
+// one s_barrier per chunk hands the buffers over.  512 pixels per slab fetch: 248 FLOP per staged byte (164 with 256).
+// LDS rows are 64 bytes, four 16-byte slots, slot ^= bits 2-3 of the patch column / channel (source-side for the DMA).
+template <bool BIASACT>
+__global__ __launch_bounds__(640, 1) void k_conv3x3_fwd_ws64(const unsigned short* __restrict__ x,
+                                                            const unsigned short* __restrict__ wpk,
+                                                            unsigned short* __restrict__ y, const float* __restrict__ bias,
+                                                            int act, float* __restrict__ stats_partial,
+                                                            int B, int H, int W, int K, int N, int tiles_x, int tiles_y) {
+    constexpr int BN = 64;
+    constexpr int AI = 39, BI = 36;                   // 1 KiB DMA instructions per chunk: 612 patch rows x 64 B, 576 slab rows
+    constexpr int NI = AI + BI, NPL = (NI + 1) / 2;   // per loader wave
+    constexpr int A_BYTES = AI * 1024, STAGE = NI * 1024;
+    constexpr int OROW = BN * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int t = blockIdx.x;
+    const int tx0 = (t % tiles_x) << 5; t /= tiles_x;
+    const int ty0 = (t % tiles_y) << 4; t /= tiles_y;
+    const int b0 = t;
+    const int n0 = blockIdx.y * BN;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const bool loader = wave >= 8;
+    const int nch = K / 32;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    PHX_BLOCKLOG_BEGIN();
+
+    if (loader) {
+        // ---- loader waves: instruction j = (wave - 8) + 2 n fills LDS bytes [j KiB, (j + 1) KiB) of the stage
+        const int lw = wave - 8;
+        unsigned voff[NPL];
+#pragma unroll
+        for (int n = 0; n < NPL; ++n) {
+            const int j = lw + 2 * n;
+            voff[n] = 0xffffffffu;
+            if (j < AI) {
+                const int e = j * 64 + lane, pp = e >> 2, slot = e & 3;
+                const int py = pp / 34, px = pp - py * 34;
+                const int piece = slot ^ ((px >> 2) & 3);
+                const int gx = tx0 + px - 1, gy = ty0 + py - 1;
+                if (pp < 612 && gx >= 0 && gx < W && gy >= 0 && gy < H) voff[n] = (unsigned)((((b0 * H + gy) * W + gx) * K) * 2 + piece * 16);
+            } else if (j < NI) {
+                const int e = (j - AI) * 64 + lane, rb = e >> 2, slot = e & 3;
+                const int tap = rb >> 6, nn = rb & 63;
+                const int piece = slot ^ ((nn >> 2) & 3);
+                voff[n] = (unsigned)(((tap * N + n0 + nn) * 32 + piece * 8) * 2);
+            }
+        }
+        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K * 2u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, (int)(9u * N * K * 2u), 0x00020000);
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        for (int c = -1; c < nch; ++c) {               // c = -1: prologue (chunk 0); chunk c: stage chunk c + 1
+            if (c + 1 < nch) {
+                const int cn = c + 1, buf = cn & 1;
+#pragma unroll
+                for (int n = 0; n < NPL; ++n) {
+                    const int j = lw + 2 * n;
+                    if (j < AI)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + buf * STAGE + j * 1024), 16, (int)voff[n],
+                                                                 cn * 64, 0, 0);
+                    else if (j < NI)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(smem + buf * STAGE + j * 1024), 16, (int)voff[n],
+                                                                 cn * 9 * N * 64, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_barrier" ::: "memory");    // hands chunk c + 1 over / learns that chunk c's buffer is free
+        }
+    } else {
+        // ---- MFMA waves: wave w owns tile rows 2 w, 2 w + 1 (32 pixels each) x 64 channels
+        unsigned aK[3][2], bK[2];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                aK[kw][ks] = (unsigned)((wave * 2 * 34 + l31 + kw) * 64 + (((ks * 2 + khalf) ^ (((l31 + kw) >> 2) & 3)) << 4));
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) bK[ks] = (unsigned)(A_BYTES + l31 * 64 + (((ks * 2 + khalf) ^ ((l31 >> 2) & 3)) << 4));
+        asm volatile("s_barrier" ::: "memory");        // chunk 0 has landed
+        for (int c = 0; c < nch; ++c) {
+            const unsigned sb = (unsigned)((c & 1) * STAGE);
+            bf16x8 fa[2][2], fb[2][2];
+            auto read_frags = [&](auto gc) {
+                constexpr int gi = decltype(gc)::value;
+                constexpr int tap = gi / 2, ks = gi % 2, kh = tap / 3, kw = tap % 3;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    fa[gi & 1][i] = *reinterpret_cast<const bf16x8*>(smem + sb + aK[kw][ks] + (i + kh) * 34 * 64);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    fb[gi & 1][j] = *reinterpret_cast<const bf16x8*>(smem + sb + bK[ks] + (tap * 64 + j * 32) * 64);
+            };
+            read_frags(std::integral_constant<int, 0>());
+            auto groups = [&](auto self, auto gc) {
+                constexpr int gi = decltype(gc)::value;
+                if constexpr (gi < 18) {
+                    if constexpr (gi < 17) read_frags(std::integral_constant<int, gi + 1>());
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[gi & 1][i], fb[gi & 1][j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    self(self, std::integral_constant<int, gi + 1>());
+                }
+            };
+            groups(groups, std::integral_constant<int, 0>());
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // done reading this buffer; next chunk has landed
+        }
+    }
+
+    // epilogue (interior tiles only): pack pairs of rows, statistics, transpose through LDS, 16-byte stores
+    const int odd = lane & 1;
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    if (!loader) {
+        if constexpr (BIASACT) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float bv = bias ? bias[n0 + j * 32 + l31] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r] + bv, act);
+            }
+        }
+        unsigned char* lwp = smem + (wave * 64 + 4 * khalf + odd) * OROW + (l31 & ~1) * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rp = 0; rp < 8; ++rp)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int r0 = 2 * rp;
+                    const unsigned w2 = f2bf_pk(acc[i][j][r0], acc[i][j][r0 + 1]);
+                    const float ra_ = __uint_as_float(w2 << 16), rb_ = __uint_as_float(w2 & 0xffff0000u);
+                    s1[j] += ra_ + rb_;
+                    s2[j] += ra_ * ra_ + rb_ * rb_;
+                    const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)w2, 0xB1, 0xf, 0xf, true);
+                    const unsigned word = odd ? ((nb >> 16) | (w2 & 0xffff0000u)) : ((w2 & 0xffffu) | (nb << 16));
+                    *reinterpret_cast<unsigned*>(lwp + (i * 32 + (r0 & 3) + 8 * (r0 >> 2)) * OROW + j * 64) = word;
+                }
+    }
+    __syncthreads();
+    if (!loader) {
+        constexpr int PPP = BN / 8;                   // 16-byte pieces per pixel
+        constexpr int PSTEP = 512 / PPP;              // 64 pixels = two tile rows between a thread's pieces
+        const int mt = threadIdx.x / PPP, q = threadIdx.x % PPP;
+        const unsigned char* lr = smem + mt * OROW + q * 16;
+        unsigned short* yp = y + (((size_t)b0 * H + ty0 + (mt >> 5)) * W + tx0 + (mt & 31)) * N + n0 + q * 8;
+        const size_t ystep = (size_t)(PSTEP / 32) * W * N;
+#pragma unroll
+        for (int it = 0; it < PPP; ++it)
+            *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * PSTEP * OROW);
+    }
+    if (stats_partial) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);      // [8 waves][2][BN]
+        if (!loader) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float a = s1[j] + __shfl_xor(s1[j], 32, 64);
+                const float bq = s2[j] + __shfl_xor(s2[j], 32, 64);
+                if (khalf == 0) {
+                    red[(wave * 2 + 0) * BN + j * 32 + l31] = a;
+                    red[(wave * 2 + 1) * BN + j * 32 + l31] = bq;
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * BN) {
+            const int which = threadIdx.x / BN, n = threadIdx.x % BN;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += red[(w * 2 + which) * BN + n];
             stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + n] = v;
         }
     }
@@ -1603,7 +1806,7 @@ int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* 
 
 // the fused-statistics epilogue lives in the full-tile path of the 16-wide-tile kernels: every tile must be interior
 static bool fwd_bws_ok(int B, int H, int W, int K, int N) {
-    if (fwd_dma_bn(B, H, W, K, N) || fwd_rs_bn(B, H, W, K, N) || fwd_ksplit(B, H, W, K, N) > 1) return false;
+    if (fwd_ws64(B, H, W, K, N) || fwd_dma_bn(B, H, W, K, N) || fwd_rs_bn(B, H, W, K, N) || fwd_ksplit(B, H, W, K, N) > 1) return false;
     if (fwd_big_tiles(B, H, W, K, N)) return true;                       // H % 32 == 0, W % 16 == 0
     return H % 16 == 0 && W % 16 == 0;
 }
@@ -1639,6 +1842,28 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
         ksplit = fwd_ksplit(B, H, W, K, N);
         PHX_REQUIRE(workspace_bytes >= (size_t)(ksplit > 1 ? ksplit : 0) * B * H * W * N * sizeof(float), PHX_E_INVAL,
                     "conv3x3_mfma: workspace too small");
+    }
+    if (fwd_ws64(B, H, W, K, N)) {
+        const bool ba = bias != nullptr || act != PHX_ACT_ID;
+        static bool wattr = false;
+        if (!wattr) {
+            PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_ws64<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_ws64<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            wattr = true;
+        }
+        PHX_REQUIRE((double)B * H * W * (K > N ? K : N) < 2147483648.0, PHX_E_SHAPE, "conv3x3_mfma: tensor exceeds 2^31 elements");
+        const int ntl = B * (H / 16) * (W / 32);
+        const size_t sh = 2 * 75 * 1024;              // two 75 KiB stages (the 72 KiB output tile reuses them)
+        if (ba)
+            hipLaunchKernelGGL((k_conv3x3_fwd_ws64<true>), dim3(ntl, N / 64), dim3(640), sh, (hipStream_t)stream,
+                               (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B,
+                               H, W, K, N, W / 32, H / 16);
+        else
+            hipLaunchKernelGGL((k_conv3x3_fwd_ws64<false>), dim3(ntl, N / 64), dim3(640), sh, (hipStream_t)stream,
+                               (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B,
+                               H, W, K, N, W / 32, H / 16);
+        PHX_CHECK_LAUNCH();
+        return PHX_OK;
     }
     if (const int rbn = fwd_rs_bn(B, H, W, K, N)) {
         const bool ba = bias != nullptr || act != PHX_ACT_ID;

@@ -246,6 +246,14 @@ def test_dgrad_with_fused_bn_backward_statistics(L, case, monkeypatch):
     close(host(sums), host(sums_ref), 2e-5, "fused bn-backward sums")
 
 
+# wave-specialised variant: 8 MFMA waves + 2 DMA loader waves, 512 pixels x 64 channels per block (k_conv3x3_fwd_ws64)
+@pytest.mark.parametrize("case", [(2, 16, 32, 32, 128), (1, 32, 64, 96, 64), (3, 16, 32, 32, 192), (1, 48, 32, 64, 256),
+                                  (1, 16, 64, 160, 128)])
+def test_conv3x3_mfma_wave_specialised(L, case, monkeypatch):
+    monkeypatch.setenv("PHX_FWD_WS", "2")
+    _mfma_case(L, case)
+
+
 def _mfma_case(L, case):
     B, H, W, K, N = case
     x = RNG.standard_normal((B, H, W, K))
