@@ -21,6 +21,11 @@
 #endif
 #define KC 32            // input channels per LDS stage (two MFMA k-steps)
 #define ROWB 80          // bytes per pixel / filter row in LDS: 32 bf16 + 16 B pad -> conflict-free ds_read_b128
+// Pitch of one 18-pixel patch row of the 16-wide tiles.  A ds_read_b128 is served in 16-lane groups {0-3, 12-15, 20-27}, ...:
+// twelve pixels of one tile row and four of the next.  With 80-byte pixels the 16-byte slot (mod 256 B) of pixel p is 5p
+// mod 16, a permutation of a row's 16 pixels; the second row's pixels fill exactly the first row's gaps when the row pitch
+// is a multiple of 256 B.  18 * 80 = 1440 is not (two 2-way conflicts per group: measured 40 % of the LDS cycles); 1536 is.
+#define PITCH16 1536
 
 struct MTile {
     int tws, ths, tb, tiles_x, tiles_y, tiles_b;
@@ -248,7 +253,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
     const int npatch = FAST16 ? 18 * (NT / 16 + 2) : g.tb * ph * pw;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                    // [npatch][ROWB]
-    unsigned char* sB = smem + npatch * ROWB;    // [9][BN][ROWB]
+    // (the 512-pixel x 32-channel variant measured 12 % slower with the padded pitch -- it keeps the dense one)
+    constexpr int P16 = (NW == 8 && BN == 32) ? 18 * ROWB : PITCH16;
+    const int pitch = FAST16 ? P16 : pw * ROWB;
+    unsigned char* sB = smem + (FAST16 ? (NT / 16 + 2) * P16 : npatch * ROWB);    // [9][BN][ROWB]
 
     // Linear block id -> (pixel tile, channel block).  Work-groups go round-robin over the 8 XCDs (id % 8), each with its
     // own L2: the N / BN channel blocks of a tile get ids 8 apart -- same XCD, dispatched back to back -- so the input
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
     for (int i = 0; i < 2; ++i) {
         const int m = wave * 64 + i * 32 + l31;
         const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
-        aoff[i] = ((lb * ph + ly) * pw + lx) * ROWB + khalf * 16;
+        aoff[i] = (lb * ph + ly) * pitch + lx * ROWB + khalf * 16;
     }
     const int boff = l31 * ROWB + khalf * 16;
 
@@ -368,7 +376,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
 #pragma unroll
         for (int it = 0; it < NA; ++it) {
             const int i = threadIdx.x + it * NT;
-            if (!(PHX_ABLATE & 2) && (i >> 2) < npatch) *reinterpret_cast<u32x4*>(sA + (i >> 2) * ROWB + (i & 3) * 16) = ra[it];
+            const int pp = i >> 2;
+            const int so = FAST16 ? (pp / 18) * (P16 - 18 * ROWB) + pp * ROWB : pp * ROWB;
+            if (!(PHX_ABLATE & 2) && pp < npatch) *reinterpret_cast<u32x4*>(sA + so + (i & 3) * 16) = ra[it];
         }
 #pragma unroll
         for (int it = 0; it < NB; ++it) {
@@ -386,7 +396,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
         auto read_frags = [&](auto gc) {
             constexpr int gi = decltype(gc)::value;
             constexpr int tap = gi / 2, ks = gi % 2, kh = tap / 3, kw = tap % 3;
-            const int tapoff = (kh * pw + kw) * ROWB;
+            const int tapoff = kh * pitch + kw * ROWB;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 fa[gi % FB][i] = *reinterpret_cast<const bf16x8*>(sA + aoff[i] + tapoff + ks * 32);
@@ -1929,7 +1939,8 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
     // (the OROW-pitched epilogue tile also has to fit: NT * (2 BN + 16) bytes)
 #define CM_LAUNCH1(BNv, NAv, Fv, Av, NWv, Sv)                                                                          \
     do {                                                                                                             \
-        size_t sh = (size_t)npatch * ROWB + 9 * BNv * ROWB;                                                          \
+        size_t sh = (Fv ? (size_t)(NWv * 4 + 2) * ((NWv == 8 && BNv == 32) ? 18 * ROWB : PITCH16)                    \
+                        : (size_t)npatch * ROWB) + 9 * BNv * ROWB;                                                   \
         const size_t she = (size_t)NWv * 64 * (BNv * 2 + 16);                                                        \
         if (she > sh) sh = she;                                                                                      \
         if (Sv)                                                                                                      \
