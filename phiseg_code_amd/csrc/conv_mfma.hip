@@ -29,7 +29,21 @@
 
 struct MTile {
     int tws, ths, tb, tiles_x, tiles_y, tiles_b;
+    unsigned mpw, mpp;      // ceil(2^20 / (tw + 2)), ceil(2^20 / ((tw + 2) (th + 2))): exact quotients for dividends < 4096
 };
+// halo-patch index -> (x, y, batch) by multiply-shift: a runtime integer division costs ~40 instructions, and the staging
+// plans of the small-map tiles do three per 16-byte piece (48 per thread -- microseconds of a launch that has 1 us of MFMAs)
+static void mtile_magic(MTile* g) {
+    const unsigned pw = (1u << g->tws) + 2, ph = (1u << g->ths) + 2;
+    g->mpw = ((1u << 20) + pw - 1) / pw;
+    g->mpp = ((1u << 20) + pw * ph - 1) / (pw * ph);
+}
+__device__ __forceinline__ void patch_coords(const MTile& g, int pp, int pw, int ph, int* px, int* py, int* pb) {
+    const int b = (int)(((unsigned)pp * g.mpp) >> 20);
+    const int rem = pp - b * pw * ph;
+    const int y = (int)(((unsigned)rem * g.mpw) >> 20);
+    *pb = b; *py = y; *px = rem - y * pw;
+}
 static MTile make_mtile(int B, int H, int W) {
     MTile g;
     int tw = 1, th = 1;
@@ -40,6 +54,7 @@ static MTile make_mtile(int B, int H, int W) {
     g.tiles_x = (W + tw - 1) / tw;
     g.tiles_y = (H + th - 1) / th;
     g.tiles_b = (B + g.tb - 1) / g.tb;
+    mtile_magic(&g);
     return g;
 }
 
@@ -90,12 +105,14 @@ static MTile make_mtile_fwd(int B, int H, int W, int K, int N, bool allow_dma = 
         MTile g;
         g.tws = 5; g.ths = 4; g.tb = 1;
         g.tiles_x = W / 32; g.tiles_y = H / 16; g.tiles_b = B;
+        mtile_magic(&g);
         return g;
     }
     if (!fwd_big_tiles(B, H, W, K, N)) return make_mtile(B, H, W);
     MTile g;
     g.tws = 4; g.ths = 5; g.tb = 1;
     g.tiles_x = W / 16; g.tiles_y = H / 32; g.tiles_b = B;
+    mtile_magic(&g);
     return g;
 }
 
@@ -303,9 +320,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
         ga[it] = 0xffffffffu;
         if (pp < npatch) {
             // 16-wide tiles: the patch is 18 wide -> compile-time divisors (runtime division costs ~40 instructions)
-            const int px = FAST16 ? pp % 18 : pp % pw;
-            const int py = FAST16 ? pp / 18 : (pp / pw) % ph;
-            const int pb = FAST16 ? 0 : pp / (pw * ph);
+            int px, py, pb;
+            if constexpr (FAST16) { px = pp % 18; py = pp / 18; pb = 0; }
+            else patch_coords(g, pp, pw, ph, &px, &py, &pb);
             const int gx = tx0 + px - 1, gy = ty0 + py - 1, gbi = b0 + pb;
             if (gx >= 0 && gx < W && gy >= 0 && gy < H && gbi < B) ga[it] = (unsigned)((((gbi * H + gy) * W + gx) * K + q * 8) * 2);
         }
@@ -1267,8 +1284,14 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* 
         const int i = threadIdx.x + it * 256;
         const int pp = i / QX;
         planx[it] = -1;
-        if (pp < npatch)
-            planx[it] = FAST16 ? ((pp % 18) | ((pp / 18) << 8)) : ((pp % pw) | (((pp / pw) % ph) << 8) | ((pp / (pw * ph)) << 16));
+        if (pp < npatch) {
+            if constexpr (FAST16) planx[it] = (pp % 18) | ((pp / 18) << 8);
+            else {
+                int px, py, pb;
+                patch_coords(g, pp, pw, ph, &px, &py, &pb);
+                planx[it] = px | (py << 8) | (pb << 16);
+            }
+        }
     }
 #pragma unroll
     for (int it = 0; it < QD; ++it) {
@@ -1960,9 +1983,14 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
         else CM_LAUNCH1(BNv, NAv, Fv, false, NWv, false);                                                            \
     } while (0)
     const bool fast16 = g.tws == 4 && g.ths == 4 && g.tb == 1;
+    // fewer 64-channel blocks than CUs: every block runs alone on its CU and the launch is one block's latency chain --
+    // 32-channel blocks double the block count (two per CU) and halve each block's chain
+    static int n32thr = -1;
+    if (n32thr < 0) { const char* e = getenv("PHX_BN32_MAXBLOCKS"); n32thr = e ? atoi(e) : 256; }
+    const bool narrow32 = N % 64 == 0 && !big && ksplit == 1 && ntiles * (N / 64) <= n32thr;
     if (big) {
         if (N % 128 == 0) CM_LAUNCH(128, 5, true, 8); else if (N % 64 == 0) CM_LAUNCH(64, 5, true, 8); else CM_LAUNCH(32, 5, true, 8);
-    } else if (N % 64 == 0) {
+    } else if (N % 64 == 0 && !narrow32) {
         if (fast16) CM_LAUNCH(64, 8, true, 4); else if (na <= 8) CM_LAUNCH(64, 8, false, 4); else CM_LAUNCH(64, 16, false, 4);
     } else {
         if (fast16) CM_LAUNCH(32, 8, true, 4); else if (na <= 8) CM_LAUNCH(32, 8, false, 4); else CM_LAUNCH(32, 16, false, 4);
