@@ -39,10 +39,11 @@ static void mtile_magic(MTile* g) {
     g->mpp = ((1u << 20) + pw * ph - 1) / (pw * ph);
 }
 __device__ __forceinline__ void patch_coords(const MTile& g, int pp, int pw, int ph, int* px, int* py, int* pb) {
-    const int b = (int)(((unsigned)pp * g.mpp) >> 20);
-    const int rem = pp - b * pw * ph;
-    const int y = (int)(((unsigned)rem * g.mpw) >> 20);
-    *pb = b; *py = y; *px = rem - y * pw;
+    // (24-bit multiplies: full rate, v_mul_lo_u32 is quarter rate; every operand here is < 2^21)
+    const int b = (int)(__umul24((unsigned)pp, g.mpp) >> 20);
+    const int rem = pp - (int)__umul24((unsigned)b, (unsigned)(pw * ph));
+    const int y = (int)(__umul24((unsigned)rem, g.mpw) >> 20);
+    *pb = b; *py = y; *px = rem - (int)__umul24((unsigned)y, (unsigned)pw);
 }
 static MTile make_mtile(int B, int H, int W) {
     MTile g;
@@ -324,7 +325,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
             if constexpr (FAST16) { px = pp % 18; py = pp / 18; pb = 0; }
             else patch_coords(g, pp, pw, ph, &px, &py, &pb);
             const int gx = tx0 + px - 1, gy = ty0 + py - 1, gbi = b0 + pb;
-            if (gx >= 0 && gx < W && gy >= 0 && gy < H && gbi < B) ga[it] = (unsigned)((((gbi * H + gy) * W + gx) * K + q * 8) * 2);
+            const bool in = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && gbi < B;
+            unsigned off;
+            if constexpr (FAST16) off = (unsigned)((((gbi * H + gy) * W + gx) * K + q * 8) * 2);
+            else {                                             // small maps: B * H * W < 2^24 (checked by the launcher)
+                const unsigned pix = __umul24(__umul24((unsigned)gbi, (unsigned)H) + gy, (unsigned)W) + gx;
+                off = (__umul24(pix, (unsigned)K) + q * 8) * 2;
+            }
+            ga[it] = in ? off : 0xffffffffu;
         }
     }
     // filter-slab pieces: piece `it` of a thread lies it * 64 slab rows further on, i.e. a fixed byte stride -> one VGPR
@@ -1983,6 +1991,7 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
         else CM_LAUNCH1(BNv, NAv, Fv, false, NWv, false);                                                            \
     } while (0)
     const bool fast16 = g.tws == 4 && g.ths == 4 && g.tb == 1;
+    PHX_REQUIRE(fast16 || big || (double)B * H * W < 16777216.0, PHX_E_SHAPE, "conv3x3_mfma: small-map tiles need B*H*W < 2^24");
     // fewer 64-channel blocks than CUs: every block runs alone on its CU and the launch is one block's latency chain --
     // 32-channel blocks double the block count (two per CU) and halve each block's chain
     static int n32thr = -1;
