@@ -155,6 +155,19 @@ int phx_norm_bwd_apply_fused(const void* dA, int da_dt, const void* x, int x_dt,
                              const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx,
                              int dx_dt, float* dgamma, float* dbeta, int NS, int P, int C, int G, int act, int nrep,
                              void* stream);
+/* Small-map batch norm, training mode, bf16 NHWC (tfwrapper/normalisation.py:16-45 batch_norm -> tf.layers.
+ * batch_normalization(training=True), fused with the activation of layers.py:134-135): the whole layer in ONE launch when
+ * P = B*H*W <= 4096 and C % 16 == 0 (a block owns 16 channels of all pixels; two-pass variance; no atomics).
+ * fwd: y = act(gamma * (x - mean) * rstd + beta); publishes mean / rstd / scale / shift [C] and, if momentum > 0, the
+ * moving-average update (moving -= (moving - batch) * momentum, unbiased variance).
+ * bwd: dx from dA, the saved x and statistics; dgamma / dbeta are accumulated (+=). */
+int phx_bn_small_supported(int P, int C, int dt);
+int phx_bn_small_fwd(const void* x, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd,
+                     float* scale, float* shift, float* moving_mean, float* moving_var, float momentum, int P, int C,
+                     int act, void* stream);
+int phx_bn_small_bwd(const void* dA, const void* x, const float* scale, const float* shift, const float* mean,
+                     const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, int P, int C, int act,
+                     void* stream);
 /* backward of y = act(norm(x)):  g = dA * act'(.);  sums2[nrep][NS][C][2] += {sum g, sum g*xhat}: block b adds into
  * replica b % nrep (same-address atomics serialise at ~45 ns each); phx_norm_bwd_apply_fused sums the replicas, the other
  * consumers take nrep = 1 */

@@ -99,6 +99,206 @@ __global__ void k_norm_stats(const T* __restrict__ x, float* __restrict__ sums, 
     }
 }
 
+// =================================================================================================
+// Small-map batch norm (P = B*H*W <= 4096 pixels: the H <= 8 levels).  There the three-launch forward (statistics,
+// finalisation + apply) and two-launch backward (reduction, apply) are a chain of 5-10 us latency-bound launches for a
+// tensor of at most 1.5 MB.  Here ONE launch does the whole layer: a block owns 16 channels (a 32-byte slice of every
+// pixel row) for ALL pixels, keeps its slice in registers (NIT x 16 B per thread), and reduces over pixels inside the
+// block -- no atomics, no second launch, exact two-pass variance.  1024 threads = 512 pixel lanes x 2 channel vectors.
+__device__ __forceinline__ void bf16x8_unpack(const uint4& r, float o[8]) {
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        o[2 * k] = __uint_as_float(w[k] << 16);
+        o[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+    }
+}
+// sum of s[0..NV) over the 512 pixel lanes that share this thread's channel vector (threadIdx.x & 1); red: [17][2][NV]
+template <int NV>
+__device__ __forceinline__ void small_block_sum(float s[NV], float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int m = 2; m < 64; m <<= 1)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) s[j] += __shfl_xor(s[j], m);
+    __syncthreads();                                   // red may still be read from the previous call
+    if (lane < 2)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) red[(wave * 2 + lane) * NV + j] = s[j];
+    __syncthreads();
+    float* tot = red + 16 * 2 * NV;                    // [2][NV]
+    if (threadIdx.x < 2 * NV) {
+        const int vv = threadIdx.x / NV, j = threadIdx.x % NV;
+        float a = 0.f;
+        for (int w = 0; w < 16; ++w) a += red[(w * 2 + vv) * NV + j];
+        tot[vv * NV + j] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NV; ++j) s[j] = tot[(threadIdx.x & 1) * NV + j];
+}
+
+template <int NIT>
+__global__ __launch_bounds__(1024) void k_bn_small_fwd(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, bf16_t* __restrict__ y,
+                                                       float* mean_out, float* rstd_out, float* scale_out,
+                                                       float* shift_out, float* moving_mean, float* moving_var,
+                                                       float momentum, int P, int C, int act) {
+    __shared__ float red[17 * 2 * 8];
+    const int v = threadIdx.x & 1, pl = threadIdx.x >> 1;
+    const int c0 = blockIdx.x * 16 + v * 8;
+    uint4 r[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int p = pl + it * 512;
+        r[it] = make_uint4(0, 0, 0, 0);
+        if (p < P) r[it] = *reinterpret_cast<const uint4*>(x + (size_t)p * C + c0);
+    }
+    float s[8], mu[8], gm[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; gm[j] = gamma[c0 + j]; be[j] = beta[c0 + j]; }   // (loaded ahead of the reductions)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {                  // (pixels past P hold zeros)
+        float f[8];
+        bf16x8_unpack(r[it], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += f[j];
+    }
+    small_block_sum<8>(s, red);
+    const float invP = 1.f / (float)P;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mu[j] = s[j] * invP; s[j] = 0.f; }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        if (pl + it * 512 < P) {
+            float f[8];
+            bf16x8_unpack(r[it], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = f[j] - mu[j]; s[j] = fmaf(d, d, s[j]); }
+        }
+    }
+    small_block_sum<8>(s, red);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j;
+        const float var = s[j] * invP, rs = rsqrtf(var + eps);
+        sc[j] = gm[j] * rs;
+        sh[j] = be[j] - mu[j] * sc[j];
+        if (pl == 0) {
+            mean_out[c] = mu[j];
+            rstd_out[c] = rs;
+            scale_out[c] = sc[j];
+            shift_out[c] = sh[j];
+            if (momentum > 0.f && moving_mean) {          // TF1 fused-batch-norm moving update (unbiased variance)
+                const float m = (float)P;
+                moving_mean[c] -= (moving_mean[c] - mu[j]) * momentum;
+                moving_var[c] -= (moving_var[c] - var * (m / fmaxf(m - 1.f, 1.f))) * momentum;
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int p = pl + it * 512;
+        if (p < P) {
+            float f[8];
+            bf16x8_unpack(r[it], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = act_fwd(fmaf(f[j], sc[j], sh[j]), act);
+            VecIO<bf16_t, 8>::store(y, (size_t)p * C + c0, f);
+        }
+    }
+}
+
+template <int NIT>
+__global__ __launch_bounds__(1024) void k_bn_small_bwd(const bf16_t* __restrict__ dA, const bf16_t* __restrict__ x,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, bf16_t* __restrict__ dx,
+                                                       float* dgamma, float* dbeta, int P, int C, int act) {
+    __shared__ float red[17 * 2 * 16];
+    const int v = threadIdx.x & 1, pl = threadIdx.x >> 1;
+    const int c0 = blockIdx.x * 16 + v * 8;
+    // the slice stays in registers between the two passes when that is <= 4 x 16 B per thread; larger slices are read
+    // again (from L2) -- 2 x 8 x 16 B per thread on top of the unpacked working set does not fit 128 registers
+    constexpr bool KEEP = NIT <= 2;
+    constexpr int NB = KEEP ? NIT : 2;                 // register buffers (reads go two pixels at a time when not kept)
+    uint4 rx[NB], rd[NB];
+    auto fetch = [&](int it) {
+        const int p = pl + it * 512;
+        rx[it % NB] = rd[it % NB] = make_uint4(0, 0, 0, 0);
+        if (p < P) {
+            rx[it % NB] = *reinterpret_cast<const uint4*>(x + (size_t)p * C + c0);
+            rd[it % NB] = *reinterpret_cast<const uint4*>(dA + (size_t)p * C + c0);
+        }
+    };
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) fetch(it);
+    }
+    float sc[8], sh[8], mu[8], rs[8], gmv[8], s[16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j;
+        sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; rs[j] = rstd[c]; gmv[j] = gamma[c];
+        s[j] = s[8 + j] = 0.f;
+    }
+    auto accumulate = [&](int it) {                     // (pixels past P: dA = 0 -> g = 0)
+        float xf[8], df[8];
+        bf16x8_unpack(rx[it % NB], xf);
+        bf16x8_unpack(rd[it % NB], df);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float g = df[j] * act_grad_pre(fmaf(xf[j], sc[j], sh[j]), act);
+            s[j] += g;
+            s[8 + j] = fmaf(g * (xf[j] - mu[j]), rs[j], s[8 + j]);
+        }
+    };
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) accumulate(it);
+    } else {
+#pragma unroll 1
+        for (int it = 0; it < NIT; it += 2) { fetch(it); fetch(it + 1); accumulate(it); accumulate(it + 1); }
+    }
+    small_block_sum<16>(s, red);
+    const float inv_m = 1.f / (float)P;
+    float ca[8], cb[8], cc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j;
+        const float gm = gmv[j];
+        ca[j] = rs[j] * gm;
+        cc[j] = -rs[j] * rs[j] * gm * s[8 + j] * inv_m;
+        cb[j] = -rs[j] * gm * s[j] * inv_m - cc[j] * mu[j];
+        if (pl == 0) {                                  // (accumulate: a variable may be used by several layers)
+            atomicAdd(&dbeta[c], s[j]);
+            atomicAdd(&dgamma[c], s[8 + j]);
+        }
+    }
+    auto apply = [&](int it) {
+        const int p = pl + it * 512;
+        if (p < P) {
+            float xf[8], df[8], o[8];
+            bf16x8_unpack(rx[it % NB], xf);
+            bf16x8_unpack(rd[it % NB], df);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float gq = df[j] * act_grad_pre(fmaf(xf[j], sc[j], sh[j]), act);
+                o[j] = fmaf(ca[j], gq, fmaf(cc[j], xf[j], cb[j]));
+            }
+            VecIO<bf16_t, 8>::store(dx, (size_t)p * C + c0, o);
+        }
+    };
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) apply(it);
+    } else {
+#pragma unroll 1
+        for (int it = 0; it < NIT; it += 2) { fetch(it); fetch(it + 1); apply(it); apply(it + 1); }
+    }
+}
+
 static int norm_geometry(int P, int C, int V, int* PL, int* threads, int* chunk, int* nchunks, int NS, int nrep = 1) {
     int CV = C / V;
     if (CV > 256) return -1;
@@ -901,6 +1101,34 @@ int phx_norm_bwd_reduce(const void* dA, int da_dt, const void* x, int x_dt, cons
                            (size_t)PL * C * 2 * sizeof(float), (hipStream_t)stream, (const TD*)dA, (const TX*)x, scale,
                            shift, mean, rstd, sums2, P, C, G, PL, chunk, act, nrep);
     })));
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_bn_small_supported(int P, int C, int dt) { return dt == PHX_BF16 && P >= 1 && P <= 4096 && C % 16 == 0; }
+
+int phx_bn_small_fwd(const void* x, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd,
+                     float* scale, float* shift, float* moving_mean, float* moving_var, float momentum, int P, int C,
+                     int act, void* stream) {
+    PHX_REQUIRE(phx_bn_small_supported(P, C, PHX_BF16), PHX_E_SHAPE, "bn_small_fwd: needs bf16, P <= 4096, C % 16 == 0");
+#define BNS_F(NITv)                                                                                                   \
+    hipLaunchKernelGGL((k_bn_small_fwd<NITv>), dim3(C / 16), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)x,    \
+                       gamma, beta, eps, (bf16_t*)y, mean, rstd, scale, shift, moving_mean, moving_var, momentum, P, C, act)
+    if (P <= 512) BNS_F(1); else if (P <= 1024) BNS_F(2); else if (P <= 2048) BNS_F(4); else BNS_F(8);
+#undef BNS_F
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_bn_small_bwd(const void* dA, const void* x, const float* scale, const float* shift, const float* mean,
+                     const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, int P, int C, int act,
+                     void* stream) {
+    PHX_REQUIRE(phx_bn_small_supported(P, C, PHX_BF16), PHX_E_SHAPE, "bn_small_bwd: needs bf16, P <= 4096, C % 16 == 0");
+#define BNS_B(NITv)                                                                                                   \
+    hipLaunchKernelGGL((k_bn_small_bwd<NITv>), dim3(C / 16), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)dA,   \
+                       (const bf16_t*)x, scale, shift, mean, rstd, gamma, (bf16_t*)dx, dgamma, dbeta, P, C, act)
+    if (P <= 512) BNS_B(1); else if (P <= 1024) BNS_B(2); else if (P <= 2048) BNS_B(4); else BNS_B(8);
+#undef BNS_B
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }

@@ -27,6 +27,7 @@ F32, BF16, U8 = rt.F32, rt.BF16, 2
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, U8: torch.uint8}
 _NP_DT = {F32: np.float32, U8: np.uint8}
 _ESIZE = {F32: 4, BF16: 2, U8: 1}
+_BN_SMALL = int(os.environ.get("PHX_BN_SMALL", "1024"))     # one-launch batch norm up to this many pixels (0: off)
 
 
 def _noop():
@@ -513,6 +514,21 @@ class Plan:
             conv_into(y, 0)
             self._emit(Lb.affine_act, y.ptr, y.dt, scale.ptr, shift.ptr, out.ptr, out.dt, NS, P, cout, act, S)
         else:
+            # H <= 8 levels: the whole batch-norm layer in one launch (phx_bn_small_fwd / _bwd; csrc/elementwise.hip)
+            # (policy P <= 1024, the H <= 4 levels: at P = 4096 the single launch measured no faster than the chain)
+            bn_small = (norm == "batch" and y.dt == BF16 and out.dt == BF16 and P <= _BN_SMALL
+                        and Lb.bn_small_supported(P, cout, BF16))
+            if bn_small:
+                upd = training and self.loss is not None
+                conv_into(y, 0)
+                self._emit(Lb.bn_small_fwd, y.ptr, gptr, beptr, eps, out.ptr, mean.ptr, rstd.ptr, scale.ptr, shift.ptr,
+                           self.store.ptr(nv["moving_mean"]) if upd else None,
+                           self.store.ptr(nv["moving_variance"]) if upd else None,
+                           (1.0 - tfnorm.BN_DECAY) if upd else 0.0, P, cout, act, S,
+                           tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
+                st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn, bn_small=True)
+                self.saved[op] = st
+                return
             sums = self._alloc_zeroed(NS * cout * 2)
             pivot = None
             # shifted (pivot) sums in a stand-alone pass: always on the fp32 parity path, and on the bf16 path when
@@ -775,23 +791,30 @@ class Plan:
                 raise NotImplementedError("backward through inference-mode batch norm is not on the hot path")
             nv = a["norm_vars"]
             y, NS, P, Gn = sv["y"], sv["NS"], sv["P"], sv["G"]
-            nrep = 8 if P >= 4096 else 1           # replicated accumulators: see k_norm_bwd_reduce
-            fused = self._bws.pop(op, None)        # the consumer's data-gradient launch already produced the sums
-            if fused is not None:
-                nrep = 1
-            sums2 = self._alloc_zeroed(nrep * NS * cout * 2)
-            Sg = self._alloc((NS * Gn * 2,), F32)
-            dY = self._alloc(y.shape, y.dt)
-            if fused is not None:
-                self._emit(Lb.norm_reduce_partials, fused[0].ptr, fused[1], cout, sums2.ptr, S)
+            if sv.get("bn_small") and dA.dt == BF16:
+                dY = self._alloc(y.shape, y.dt)
+                self._emit(Lb.bn_small_bwd, dA.ptr, y.ptr, sv["scale"].ptr, sv["shift"].ptr, sv["mean"].ptr, sv["rstd"].ptr,
+                           self.store.ptr(nv["gamma"]), dY.ptr, self.store.grad_ptr(nv["gamma"]),
+                           self.store.grad_ptr(nv["beta"]), P, cout, act, S,
+                           tag="bytes_norm_bwd_apply", flops=float(dA.nbytes + y.nbytes + dY.nbytes))
             else:
-                self._emit(Lb.norm_bwd_reduce, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
-                           sv["mean"].ptr, sv["rstd"].ptr, sums2.ptr, NS, P, cout, Gn, act, nrep, S,
-                           tag="bytes_norm_bwd_reduce", flops=float(dA.nbytes + y.nbytes))
-            self._emit(Lb.norm_bwd_apply_fused, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
-                       sv["mean"].ptr, sv["rstd"].ptr, self.store.ptr(nv["gamma"]), sums2.ptr, dY.ptr, dY.dt,
-                       self.store.grad_ptr(nv["gamma"]), self.store.grad_ptr(nv["beta"]), NS, P, cout, Gn, act, nrep, S,
-                       tag="bytes_norm_bwd_apply", flops=float(dA.nbytes + y.nbytes + dY.nbytes))
+                nrep = 8 if P >= 4096 else 1           # replicated accumulators: see k_norm_bwd_reduce
+                fused = self._bws.pop(op, None)        # the consumer's data-gradient launch already produced the sums
+                if fused is not None:
+                    nrep = 1
+                sums2 = self._alloc_zeroed(nrep * NS * cout * 2)
+                Sg = self._alloc((NS * Gn * 2,), F32)
+                dY = self._alloc(y.shape, y.dt)
+                if fused is not None:
+                    self._emit(Lb.norm_reduce_partials, fused[0].ptr, fused[1], cout, sums2.ptr, S)
+                else:
+                    self._emit(Lb.norm_bwd_reduce, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
+                               sv["mean"].ptr, sv["rstd"].ptr, sums2.ptr, NS, P, cout, Gn, act, nrep, S,
+                               tag="bytes_norm_bwd_reduce", flops=float(dA.nbytes + y.nbytes))
+                self._emit(Lb.norm_bwd_apply_fused, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
+                           sv["mean"].ptr, sv["rstd"].ptr, self.store.ptr(nv["gamma"]), sums2.ptr, dY.ptr, dY.dt,
+                           self.store.grad_ptr(nv["gamma"]), self.store.grad_ptr(nv["beta"]), NS, P, cout, Gn, act, nrep, S,
+                           tag="bytes_norm_bwd_apply", flops=float(dA.nbytes + y.nbytes + dY.nbytes))
         elif act != rt.ACT_ID:
             dY = self._alloc(out.shape, dA.dt)
             self._emit(Lb.act_bwd, dA.ptr, dA.dt, out.ptr, out.dt, dY.ptr, dY.dt, dA.n, act, S)

@@ -401,6 +401,63 @@ def test_norm_fwd_bwd(L, case):
     close(host(dbeta2), br.grad.numpy(), 5e-5 if dt == F32 else 2e-3, kind + " fused dbeta")
 
 
+@pytest.mark.parametrize("case", [(64, 2, 2, 192, 1), (64, 4, 4, 192, 1), (37, 3, 3, 48, 1), (64, 8, 8, 192, 1), (50, 8, 8, 16, 0),
+                                  (1, 1, 2, 32, 1), (23, 6, 6, 128, 1)])
+def test_bn_small_one_launch_layer(L, case):
+    """phx_bn_small_fwd / _bwd (the H <= 8 levels: whole batch-norm layer in one launch) against the oracle's batch norm
+    + ReLU and its autograd, bf16 activations; P from 2 to 4096 covers every slice depth (NIT 1, 2, 4, 8) and ragged tails."""
+    B, H, W, C, act = case
+    P = B * H * W
+    assert L.bn_small_supported(P, C, BF16) == 1 and L.bn_small_supported(4097, C, BF16) == 0 and L.bn_small_supported(P, 24, BF16) == 0
+    x = RNG.standard_normal((B, H, W, C)) * 1.5 + 0.3
+    gamma = 1.0 + 0.2 * RNG.standard_normal(C)
+    beta = 0.1 * RNG.standard_normal(C)
+    xr = rounded(x, BF16).requires_grad_(True)
+    gr = torch.as_tensor(gamma, dtype=torch.float32).double().requires_grad_(True)
+    br = torch.as_tensor(beta, dtype=torch.float32).double().requires_grad_(True)
+    yr, mean_r, varu_r = T.batch_norm_train(xr, gr, br)
+    ar = T.relu(yr) if act else yr
+    xd, gd, bd = dev(x, BF16), dev(gamma), dev(beta)
+    mean, rstd, scale, shift = (torch.empty(C, dtype=torch.float32).cuda() for _ in range(4))
+    mm = dev(0.1 * RNG.standard_normal(C))
+    mv = dev(1.0 + 0.3 * RNG.random(C))
+    mm0, mv0 = host(mm).copy(), host(mv).copy()
+    a = torch.empty(B, H, W, C, dtype=torch.bfloat16).cuda()
+    L.bn_small_fwd(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-3, a.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                   scale.data_ptr(), shift.data_ptr(), mm.data_ptr(), mv.data_ptr(), 0.01, P, C, act, S())
+    close(host(a), ar.detach().numpy(), 6e-3, "bn_small fwd")
+    close(host(mean), mean_r.detach().numpy(), 1e-5, "bn_small mean")
+    if P > 1:
+        close(host(mm), mm0 - (mm0 - mean_r.detach().numpy()) * 0.01, 1e-5, "bn_small moving_mean")
+        close(host(mv), mv0 - (mv0 - varu_r.detach().numpy()) * 0.01, 1e-5, "bn_small moving_var")
+    var_b = xr.detach().reshape(P, C).var(0, unbiased=False).numpy()
+    close(host(rstd), 1.0 / np.sqrt(var_b + 1e-3), 1e-5, "bn_small rstd")
+    close(host(scale), gamma.astype(np.float32) * host(rstd), 1e-6, "bn_small scale")
+    # the three-launch path the engine uses on larger maps publishes the same statistics
+    sums = torch.zeros(1, C, 2, dtype=torch.float32).cuda()
+    pivot = torch.zeros(1, C, dtype=torch.float32).cuda()
+    L.norm_stats(xd.data_ptr(), BF16, sums.data_ptr(), pivot.data_ptr(), 1, P, C, S())
+    a3 = torch.empty_like(a)
+    mean3, rstd3, scale3, shift3 = (torch.empty_like(t) for t in (mean, rstd, scale, shift))
+    L.norm_apply_fused(xd.data_ptr(), BF16, sums.data_ptr(), pivot.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-3, a3.data_ptr(),
+                       BF16, mean3.data_ptr(), rstd3.data_ptr(), scale3.data_ptr(), shift3.data_ptr(), None, None, 0.0, 1, P, C, C,
+                       act, S())
+    close(host(scale), host(scale3), 2e-5, "bn_small vs three-launch scale")
+    close(host(shift), host(shift3), 2e-5, "bn_small vs three-launch shift")
+    dA = RNG.standard_normal((B, H, W, C))
+    dAr = rounded(dA, BF16)
+    (ar * dAr).sum().backward()
+    dAd = dev(dA, BF16)
+    dx = torch.empty(B, H, W, C, dtype=torch.bfloat16).cuda()
+    dgamma = torch.full((C,), 0.5, dtype=torch.float32).cuda()        # accumulated (+=), not overwritten
+    dbeta = torch.full((C,), -0.25, dtype=torch.float32).cuda()
+    L.bn_small_bwd(dAd.data_ptr(), xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                   gd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), P, C, act, S())
+    close(host(dx), xr.grad.numpy(), 8e-3, "bn_small dx")
+    close(host(dgamma) - 0.5, gr.grad.numpy(), 2e-3, "bn_small dgamma")
+    close(host(dbeta) + 0.25, br.grad.numpy(), 2e-3, "bn_small dbeta")
+
+
 def test_bn_infer_scale_shift(L):
     C = 24
     g, b, mm, mv = RNG.random(C) + 0.5, RNG.standard_normal(C), RNG.standard_normal(C), RNG.random(C) + 0.5
