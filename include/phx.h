@@ -237,6 +237,10 @@ int phx_kl_diag_gauss(const float* mu0, const float* s0, const float* mu1, const
 int phx_adam_tf1(float* p, const float* g, float* m, float* v, size_t n, const float* lr_dev, float beta1,
                  float beta2, float eps, const int32_t* step_dev, void* stream);
 int phx_step_increment(int32_t* step_dev, void* stream);
+/* diagnostic: *dst_u64 = the device's constant-rate (100 MHz) wall clock when the stream reaches this point; the engine
+ * (PHX_STAMPS=1) brackets every operator with these to draw the per-lane timeline of a replayed plan without a profiler
+ * (rocprofv3's kernel trace serialises the lanes).  No reference counterpart. */
+int phx_stamp(void* dst_u64, void* stream);
 int phx_sum_scalars(const float* in, int n, float* out, void* stream);
 /* out = sum_i weights[i] * (*ptrs[i]), n <= 16; ptrs / weights are HOST arrays of device pointers / floats
  * (loss_tot of phiseg_model.py:118-130) */

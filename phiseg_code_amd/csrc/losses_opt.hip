@@ -216,6 +216,7 @@ __global__ void k_adam_tf1(float* __restrict__ p, const float* __restrict__ g, f
 }
 
 __global__ void k_step_increment(int32_t* s) { *s += 1; }
+__global__ void k_stamp(unsigned long long* dst) { *dst = wall_clock64(); }      // constant 100 MHz counter
 __global__ void k_sum_scalars(const float* in, int n, float* out) {
     float a = 0.f;
     for (int i = 0; i < n; ++i) a += in[i];
@@ -324,6 +325,12 @@ int phx_adam_tf1(float* p, const float* g, float* m, float* v, size_t n, const f
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }
+int phx_stamp(void* dst_u64, void* stream) {
+    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)dst_u64);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
 int phx_step_increment(int32_t* step_dev, void* stream) {
     hipLaunchKernelGGL(k_step_increment, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
     PHX_CHECK_LAUNCH();

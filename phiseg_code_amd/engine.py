@@ -27,6 +27,7 @@ F32, BF16, U8 = rt.F32, rt.BF16, 2
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, U8: torch.uint8}
 _NP_DT = {F32: np.float32, U8: np.uint8}
 _ESIZE = {F32: 4, BF16: 2, U8: 1}
+_STAMPS = os.environ.get("PHX_STAMPS", "0") == "1"
 _BN_SMALL = int(os.environ.get("PHX_BN_SMALL", "1024"))     # one-launch batch norm up to this many pixels (0: off)
 
 
@@ -155,13 +156,12 @@ class Plan:
         self.loss = loss
         self.optimize = bool(optimize and loss is not None)
         self.split_optimizer = split_optimizer      # data-parallel: [fwd+bwd] | all-reduce | [adam]
-        self.use_hip_graph = use_hip_graph
+        self.use_hip_graph = use_hip_graph and os.environ.get("PHX_HIP_GRAPH", "1") == "1"     # 0: replay the launch list on the lane streams
         # Lanes: independent sub-graphs (posterior / prior encoders, the per-level likelihood chains) are enqueued on
         # separate HIP streams so the many small-map kernels overlap; cross-lane dependencies are HIP events.  The
         # whole multi-stream launch sequence is captured into ONE hipGraph (fork from / join into lane 0).
         self._lanes = []
         if n_lanes is None:
-            import os
             n_lanes = int(os.environ.get("PHX_LANES", "6"))
         if stream is None:
             for _ in range(max(1, int(n_lanes))):
@@ -226,6 +226,23 @@ class Plan:
             self._waited[key] = pos
             self._cur.append((self.L.stream_wait_event, (self.stream, evl[0])))
             self._lane_seq[self._lane] = self._lane_seq.get(self._lane, 0) + 1
+
+    # ---- PHX_STAMPS=1: device wall-clock stamps around every operator (tools/lane_timeline.py) ----
+    def _stamp_begin(self):
+        if _STAMPS:
+            if not hasattr(self, "_stamp_buf"):
+                self._stamp_buf = torch.zeros(16384, dtype=torch.int64, device=_device())
+                self.stamps = []                  # (phase, op name, lane, index of the begin stamp)
+            self._stamp_i = len(self.stamps) * 2
+            self._emit(self.L.stamp, self._stamp_buf.data_ptr() + 8 * self._stamp_i, self.stream)
+
+    def _stamp_end(self, phase, op, n0):
+        if _STAMPS:
+            if len(self._cur) == n0 + 1:          # the operator launched nothing: drop its begin stamp
+                self._cur.pop()
+                return
+            self._emit(self.L.stamp, self._stamp_buf.data_ptr() + 8 * (self._stamp_i + 1), self.stream)
+            self.stamps.append((phase, op.name, self._lane, self._stamp_i))
 
     def _prune_dead_event_records(self):
         """Every gradient contribution records an event in case another lane folds it in; most are consumed on the lane
@@ -337,7 +354,9 @@ class Plan:
             for t in op.inputs:                               # forward dependencies produced on other lanes
                 self._wait(self.fw_event.get(self._real_producer(t)))
             n0 = len(self._cur)
+            self._stamp_begin()
             getattr(self, "_fw_" + op.type)(op, with_bw)
+            self._stamp_end("fw", op, n0)
             if nl > 1 and len(self._cur) > n0:
                 cross = any(self.op_lane.get(c, ln) != ln for o in op.outputs for c in self._real_consumers(o, opset))
                 if cross or op.type in ("residual_ce", "kl", "weighted_sum"):
@@ -350,9 +369,12 @@ class Plan:
                     self._lane = self.op_lane[op]
                     self._cur_bw_op = op
                     self._wait(self.fw_event.get(op))        # forward of this op may live on another lane's past
+                    n0 = len(self._cur)
+                    self._stamp_begin()
                     for o in op.outputs:
                         self._finalize_grad(o)
                     getattr(self, "_bw_" + op.type)(op)
+                    self._stamp_end("bw", op, n0)
             self.n_launch_bwd = len(self.launches) - self.n_launch_fwd
         if nl > 1:                                            # join: lane 0 waits for every other lane
             tails = [self._record(ln) for ln in range(1, nl)]
