@@ -2054,6 +2054,11 @@ int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, v
     if (workspace) {
         PHX_REQUIRE(workspace_bytes >= phx_conv3x3_wgrad_ws_bytes(B, H, W, Cin, Cout), PHX_E_INVAL, "conv3x3_wgrad_mfma: workspace too small");
         ws = (float*)workspace;
+        // a handful of pixel tiles (H <= 4 at batch 64): the partial filters are few, so adding them straight into dw with
+        // atomics beats the extra k_wgrad_reduce launch on the latency-bound small-map chains (26 -> 20 us at 4 x 4)
+        static int atl = -1;
+        if (atl < 0) { const char* e = getenv("PHX_WGRAD_ATOMIC_TILES"); atl = e ? atoi(e) : 4; }
+        if (ntiles <= atl) ws = nullptr;
     }
     static bool attr_set = false;
     if (!attr_set) {

@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 from phiseg_code_amd import runtime as rt
 L = rt.lib()
 st = torch.cuda.current_stream().cuda_stream
-shapes = [(64, 128, 128, 32, 32), (64, 16, 16, 192, 192), (64, 16, 16, 384, 192), (64, 32, 32, 192, 64), (64, 128, 128, 128, 128), (64, 128, 128, 192, 32), (64, 64, 64, 192, 192),
+shapes = [(64, 2, 2, 192, 192), (64, 4, 4, 192, 192), (64, 8, 8, 192, 192), (64, 16, 16, 192, 192), (64, 128, 128, 32, 32), (64, 128, 128, 128, 128), (64, 128, 128, 192, 32), (64, 64, 64, 192, 192),
           (64, 32, 32, 128, 128), (64, 32, 32, 192, 192), (64, 16, 16, 192, 192), (64, 8, 8, 192, 192), (64, 4, 4, 192, 192)]
 which = sys.argv[1] if len(sys.argv) > 1 else "wgrad"
 for (B, H, W, K, N) in shapes:
