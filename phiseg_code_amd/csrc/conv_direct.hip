@@ -188,6 +188,116 @@ __global__ __launch_bounds__(256) void k_conv_direct_wgrad(const TX* __restrict_
     if (dbias && blockIdx.y == 0 && ci_l == 0 && co < Cout) atomicAdd(&dbias[co], accb);
 }
 
+// ---- small maps (B*H*W <= 4096 pixels) with a handful of channels on one side: the top-level 3x3 mu convolution (192 -> 2
+// at 2x2) and its backward.  k_conv_direct gives every output pixel to ONE thread (1728 x COT serial FMAs, six staged
+// 32-channel chunks: 60 us for 1.7 MFLOP, on the critical chain of both directions).  Here the reduction is spread out:
+// one wave per output pixel, lanes over the wide channel axis, everything a thread needs fetched in one latency round.
+template <int KS>
+__device__ __forceinline__ size_t tiny_widx(int tap, int ci, int co, int wCin, int wCout, int tflip) {
+    // forward: w[tap][ci][co];  data gradient: input channel ci of this convolution is the filter's OUTPUT channel
+    return tflip ? ((size_t)(KS * KS - 1 - tap) * wCin + co) * wCout + ci : ((size_t)tap * wCin + ci) * wCout + co;
+}
+// few output channels (Cy <= 4), many input channels: lanes split the input channels, wave-sum at the end
+template <typename TI, typename TO, int KS>
+__global__ __launch_bounds__(256) void k_conv_tiny_narrow_out(const TI* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, TO* __restrict__ y, int B,
+                                                              int H, int W, int Cx, int Cy, int wCin, int wCout, int act,
+                                                              int tflip) {
+    constexpr int PAD = KS / 2;
+    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pix >= B * H * W) return;
+    const int ox = pix % W, oy = (pix / W) % H, b = pix / (W * H);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+            const int iy = oy + kh - PAD, ix = ox + kw - PAD;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                const size_t xo = (((size_t)b * H + iy) * W + ix) * Cx;
+                for (int c = lane; c < Cx; c += 64) {
+                    const float xv = ldf<TI>(x, xo + c);
+#pragma unroll
+                    for (int o = 0; o < 4; ++o)
+                        if (o < Cy) acc[o] = fmaf(xv, w[tiny_widx<KS>(kh * KS + kw, c, o, wCin, wCout, tflip)], acc[o]);
+                }
+            }
+        }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) acc[o] = wave_sum(acc[o]);
+    if (lane == 0)
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (o < Cy) stf<TO>(y, (size_t)pix * Cy + o, act_fwd(acc[o] + (bias ? bias[o] : 0.f), act));
+}
+// few input channels (Cx <= 4), many output channels: lanes over the output channels, no reduction across lanes
+template <typename TI, typename TO, int KS>
+__global__ __launch_bounds__(256) void k_conv_tiny_wide_out(const TI* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, TO* __restrict__ y, int B,
+                                                            int H, int W, int Cx, int Cy, int wCin, int wCout, int act,
+                                                            int tflip) {
+    constexpr int PAD = KS / 2;
+    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pix >= B * H * W) return;
+    const int ox = pix % W, oy = (pix / W) % H, b = pix / (W * H);
+    for (int o = lane; o < Cy; o += 64) {
+        float acc = bias ? bias[o] : 0.f;
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw) {
+                const int iy = oy + kh - PAD, ix = ox + kw - PAD;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                    const size_t xo = (((size_t)b * H + iy) * W + ix) * Cx;
+                    for (int c = 0; c < Cx; ++c)
+                        acc = fmaf(ldf<TI>(x, xo + c), w[tiny_widx<KS>(kh * KS + kw, c, o, wCin, wCout, tflip)], acc);
+                }
+            }
+        stf<TO>(y, (size_t)pix * Cy + o, act_fwd(acc, act));
+    }
+}
+// filter gradient, Cout <= 4: thread = (tap, input channel), block.y = chunk of 16 output pixels; dw / dbias by atomics
+template <typename TX, typename TD, int KS>
+__global__ __launch_bounds__(256) void k_conv_tiny_wgrad(const TX* __restrict__ x, const TD* __restrict__ dy,
+                                                         float* __restrict__ dw, float* __restrict__ dbias, int B, int H,
+                                                         int W, int Cin, int Cout) {
+    constexpr int PAD = KS / 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // tap * Cin + ci
+    const int P = B * H * W, p0 = blockIdx.y * 16;
+    if (idx < KS * KS * Cin) {
+        const int tap = idx / Cin, ci = idx - tap * Cin, kh = tap / KS, kw = tap % KS;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int p = p0 + q;
+            if (p < P) {
+                const int ox = p % W, oy = (p / W) % H, b = p / (W * H);
+                const int iy = oy + kh - PAD, ix = ox + kw - PAD;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                    const float xv = ldf<TX>(x, (((size_t)b * H + iy) * W + ix) * Cin + ci);
+#pragma unroll
+                    for (int o = 0; o < 4; ++o)
+                        if (o < Cout) acc[o] = fmaf(xv, ldf<TD>(dy, (size_t)p * Cout + o), acc[o]);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (o < Cout) atomicAdd(&dw[(size_t)idx * Cout + o], acc[o]);
+    }
+    if (dbias && blockIdx.x == 0 && threadIdx.x < Cout) {
+        float a = 0.f;
+        for (int q = 0; q < 16; ++q)
+            if (p0 + q < P) a += ldf<TD>(dy, (size_t)(p0 + q) * Cout + threadIdx.x);
+        atomicAdd(&dbias[threadIdx.x], a);
+    }
+}
+static bool tiny_map(int B, int H, int W) {
+    static int en = -1;
+    if (en < 0) { const char* e = getenv("PHX_TINY_CONV"); en = e ? atoi(e) : 1; }     // 0: always the tiled kernels (A/B, tests)
+    return en && (long)B * H * W <= 4096;
+}
+
 extern "C" {
 
 int phx_conv2d_direct(const void* x, int x_dt, const float* w_hwio, const float* bias, void* y, int y_dt, int B, int H,
@@ -206,6 +316,19 @@ int phx_conv2d_direct(const void* x, int x_dt, const float* w_hwio, const float*
                            (hipStream_t)stream, (const TI*)x, w_hwio, bias, (TO*)y, stats, B, H, W, Cx, Cy, Cin, Cout, \
                            act, transpose_flip, g);                                                                  \
     } while (0)
+    if (tiny_map(B, H, W) && !stats && (Cy <= 4 || Cx <= 4)) {
+        const int P = B * H * W;
+#define CT_LAUNCH(KERN, KS)                                                                                          \
+    hipLaunchKernelGGL((KERN<TI, TO, KS>), dim3((P + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const TI*)x, w_hwio, \
+                       bias, (TO*)y, B, H, W, Cx, Cy, Cin, Cout, act, transpose_flip)
+        PHX_DT_SWITCH(x_dt, TI, PHX_DT_SWITCH(y_dt, TO, {
+            if (Cy <= 4) { if (ksize == 3) CT_LAUNCH(k_conv_tiny_narrow_out, 3); else CT_LAUNCH(k_conv_tiny_narrow_out, 1); }
+            else { if (ksize == 3) CT_LAUNCH(k_conv_tiny_wide_out, 3); else CT_LAUNCH(k_conv_tiny_wide_out, 1); }
+        }));
+#undef CT_LAUNCH
+        PHX_CHECK_LAUNCH();
+        return PHX_OK;
+    }
     PHX_DT_SWITCH(x_dt, TI, PHX_DT_SWITCH(y_dt, TO, {
         if (Cy <= 4 && Cx >= 64) { if (ksize == 3) CD_LAUNCH(4, 3, 32); else CD_LAUNCH(4, 1, 32); }
         else if (Cy <= 4) { if (ksize == 3) CD_LAUNCH(4, 3, 8); else CD_LAUNCH(4, 1, 8); }
@@ -219,6 +342,16 @@ int phx_conv2d_direct(const void* x, int x_dt, const float* w_hwio, const float*
 int phx_conv2d_direct_wgrad(const void* x, int x_dt, const void* dy, int dy_dt, float* dw_hwio, float* dbias, int B,
                             int H, int W, int Cin, int Cout, int ksize, void* stream) {
     PHX_REQUIRE(ksize == 1 || ksize == 3, PHX_E_SHAPE, "conv2d_direct_wgrad: ksize must be 1 or 3");
+    if (tiny_map(B, H, W) && Cout <= 4) {
+        const int P = B * H * W;
+#define CTW_LAUNCH(KS)                                                                                               \
+    hipLaunchKernelGGL((k_conv_tiny_wgrad<TX, TD, KS>), dim3((KS * KS * Cin + 255) / 256, (P + 15) / 16), dim3(256), 0, \
+                       (hipStream_t)stream, (const TX*)x, (const TD*)dy, dw_hwio, dbias, B, H, W, Cin, Cout)
+        PHX_DT_SWITCH(x_dt, TX, PHX_DT_SWITCH(dy_dt, TD, { if (ksize == 3) CTW_LAUNCH(3); else CTW_LAUNCH(1); }));
+#undef CTW_LAUNCH
+        PHX_CHECK_LAUNCH();
+        return PHX_OK;
+    }
     TileGeo g = make_geo(B, H, W);
     const int tw = 1 << g.tws, th = 1 << g.ths;
     const int npatch = g.tb * (th + ksize - 1) * (tw + ksize - 1);

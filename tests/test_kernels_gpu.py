@@ -81,6 +81,10 @@ CONV_DIRECT_CASES = [
     (1, 6, 6, 38, 32, 1, "relu", False, BF16, BF16),
     (2, 3, 3, 20, 17, 3, "identity", True, F32, F32),
     (1, 128, 128, 32, 32, 3, "identity", False, F32, F32),
+    # small maps with a narrow side: the wave-per-pixel kernels (top-level 3x3 mu convolution, 192 -> 2 at 2x2, and its backward)
+    (64, 2, 2, 192, 2, 3, "identity", True, BF16, F32),
+    (7, 3, 5, 70, 3, 3, "softplus", True, BF16, F32),
+    (9, 4, 4, 2, 130, 3, "relu", True, F32, BF16),
 ]
 ACT = {"identity": 0, "relu": 1, "softplus": 2}
 
@@ -112,6 +116,10 @@ def test_conv2d_direct_fwd_dgrad_wgrad(L, case):
     yst = host(y)
     close(host(stats)[0::2], yst.sum(axis=(0, 1, 2)), 1e-4 if ydt == F32 else 1e-3, "stats sum")
     close(host(stats)[1::2], (yst ** 2).sum(axis=(0, 1, 2)), 1e-4 if ydt == F32 else 1e-3, "stats sumsq")
+    y2 = torch.empty_like(y)                    # without statistics (how the heads are launched; small maps take their own kernels)
+    L.conv2d_direct(xd.data_ptr(), xdt, wd.data_ptr(), bd.data_ptr() if use_bias else None, y2.data_ptr(), ydt,
+                    B, H, W, Cin, Cout, k, ACT[act], 0, None, S())
+    close(host(y2), yr.detach().numpy(), tol, "fwd (no stats)")
     # gradients of sum(conv(x, w) * dy) (pre-activation): dgrad via transpose_flip, wgrad kernel
     dy = RNG.standard_normal((B, H, W, Cout))
     dyr = rounded(dy, ydt)
