@@ -90,6 +90,10 @@ int phx_unpad_filter_grad_center(const float* dw_pad, float* dw_1x1, int Cin, in
  * shape) and stats_partial == NULL, the K / 32 chunks are spread over several blocks per tile and a second kernel sums the
  * fp32 slices and applies bias / activation.  Otherwise identical to phx_conv3x3_mfma_bf16. */
 size_t phx_conv3x3_mfma_ws_bytes(int B, int H, int W, int K, int N);
+/* number of fp32 slices that launch leaves (1: no split).  With y == NULL (and no bias / activation) the finishing pass is
+ * skipped and the slices ws[z][B*H*W][N] stay in the workspace for a consumer that sums them itself
+ * (phx_bn_small_fwd_splitk). */
+int phx_conv3x3_mfma_ksplit(int B, int H, int W, int K, int N);
 int phx_conv3x3_mfma_bf16_ws(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
                              void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream);
 /* Data-gradient launch with the batch-norm backward statistics of the PRODUCER layer fused into its epilogue: dA (the
@@ -165,6 +169,11 @@ int phx_bn_small_supported(int P, int C, int dt);
 int phx_bn_small_fwd(const void* x, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd,
                      float* scale, float* shift, float* moving_mean, float* moving_var, float momentum, int P, int C,
                      int act, void* stream);
+/* the same layer fed by a split-K convolution that skipped its finishing pass (phx_conv3x3_mfma_bf16_ws with y == NULL):
+ * sums the nz fp32 slices ws[z][P][C], writes the bf16 pre-normalisation tensor x_out and normalises it */
+int phx_bn_small_fwd_splitk(const float* ws, int nz, void* x_out, const float* gamma, const float* beta, float eps, void* y,
+                            float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,
+                            float momentum, int P, int C, int act, void* stream);
 int phx_bn_small_bwd(const void* dA, const void* x, const float* scale, const float* shift, const float* mean,
                      const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, int P, int C, int act,
                      void* stream);

@@ -1835,6 +1835,8 @@ static int fwd_ksplit(int B, int H, int W, int K, int N) {
     return (nck + per - 1) / per;                    // no empty slices
 }
 
+int phx_conv3x3_mfma_ksplit(int B, int H, int W, int K, int N) { return fwd_ksplit(B, H, W, K, N); }
+
 size_t phx_conv3x3_mfma_ws_bytes(int B, int H, int W, int K, int N) {
     const int ks = fwd_ksplit(B, H, W, K, N);
     return ks > 1 ? (size_t)ks * B * H * W * N * sizeof(float) : 0;
@@ -1884,6 +1886,8 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
         PHX_REQUIRE(workspace_bytes >= (size_t)(ksplit > 1 ? ksplit : 0) * B * H * W * N * sizeof(float), PHX_E_INVAL,
                     "conv3x3_mfma: workspace too small");
     }
+    PHX_REQUIRE(y != nullptr || (ksplit > 1 && !bias && act == PHX_ACT_ID), PHX_E_INVAL,
+                "conv3x3_mfma: y == NULL only for a split-K launch without bias / activation (slices left in the workspace)");
     if (fwd_ws64(B, H, W, K, N)) {
         const bool ba = bias != nullptr || act != PHX_ACT_ID;
         static bool wattr = false;
@@ -2007,7 +2011,7 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
 #undef CM_LAUNCH
 #undef CM_LAUNCH1
     PHX_CHECK_LAUNCH();
-    if (ksplit > 1) {
+    if (ksplit > 1 && y != nullptr) {                // (y == NULL: the caller consumes the fp32 slices itself)
         const size_t total = (size_t)B * H * W * N;
         hipLaunchKernelGGL(k_splitk_finish, dim3(phx_grid_for(total / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)workspace, ksplit, total, N, bias, act, (unsigned short*)y);

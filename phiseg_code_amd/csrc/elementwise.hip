@@ -138,8 +138,12 @@ __device__ __forceinline__ void small_block_sum(float s[NV], float* red) {
     for (int j = 0; j < NV; ++j) s[j] = tot[(threadIdx.x & 1) * NV + j];
 }
 
-template <int NIT>
-__global__ __launch_bounds__(1024) void k_bn_small_fwd(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+// SLICES: x is not there yet -- the convolution ran split-K and left nz fp32 partial tensors ws[z][P][C]; this kernel sums
+// them, writes the bf16 pre-normalisation tensor x (the backward pass reads it) and normalises the ROUNDED values, i.e. it
+// also replaces k_splitk_finish.
+template <int NIT, bool SLICES>
+__global__ __launch_bounds__(1024) void k_bn_small_fwd(const bf16_t* __restrict__ x, const float* __restrict__ ws, int nz,
+                                                       bf16_t* __restrict__ xout, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, bf16_t* __restrict__ y,
                                                        float* mean_out, float* rstd_out, float* scale_out,
                                                        float* shift_out, float* moving_mean, float* moving_var,
@@ -152,7 +156,21 @@ __global__ __launch_bounds__(1024) void k_bn_small_fwd(const bf16_t* __restrict_
     for (int it = 0; it < NIT; ++it) {
         const int p = pl + it * 512;
         r[it] = make_uint4(0, 0, 0, 0);
-        if (p < P) r[it] = *reinterpret_cast<const uint4*>(x + (size_t)p * C + c0);
+        if (p < P) {
+            if constexpr (SLICES) {
+                typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+                const float* q = ws + (size_t)p * C + c0;
+                f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(q), a1 = *reinterpret_cast<const f32x4_t*>(q + 4);
+                for (int z = 1; z < nz; ++z) {
+                    a0 += *reinterpret_cast<const f32x4_t*>(q + (size_t)z * P * C);
+                    a1 += *reinterpret_cast<const f32x4_t*>(q + (size_t)z * P * C + 4);
+                }
+                r[it] = make_uint4(f2bf_pk(a0[0], a0[1]), f2bf_pk(a0[2], a0[3]), f2bf_pk(a1[0], a1[1]), f2bf_pk(a1[2], a1[3]));
+                *reinterpret_cast<uint4*>(xout + (size_t)p * C + c0) = r[it];
+            } else {
+                r[it] = *reinterpret_cast<const uint4*>(x + (size_t)p * C + c0);
+            }
+        }
     }
     float s[8], mu[8], gm[8], be[8];
 #pragma unroll
@@ -1112,8 +1130,23 @@ int phx_bn_small_fwd(const void* x, const float* gamma, const float* beta, float
                      int act, void* stream) {
     PHX_REQUIRE(phx_bn_small_supported(P, C, PHX_BF16), PHX_E_SHAPE, "bn_small_fwd: needs bf16, P <= 4096, C % 16 == 0");
 #define BNS_F(NITv)                                                                                                   \
-    hipLaunchKernelGGL((k_bn_small_fwd<NITv>), dim3(C / 16), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)x,    \
-                       gamma, beta, eps, (bf16_t*)y, mean, rstd, scale, shift, moving_mean, moving_var, momentum, P, C, act)
+    hipLaunchKernelGGL((k_bn_small_fwd<NITv, false>), dim3(C / 16), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)x, \
+                       nullptr, 0, nullptr, gamma, beta, eps, (bf16_t*)y, mean, rstd, scale, shift, moving_mean,      \
+                       moving_var, momentum, P, C, act)
+    if (P <= 512) BNS_F(1); else if (P <= 1024) BNS_F(2); else if (P <= 2048) BNS_F(4); else BNS_F(8);
+#undef BNS_F
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_bn_small_fwd_splitk(const float* ws, int nz, void* x_out, const float* gamma, const float* beta, float eps, void* y,
+                            float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,
+                            float momentum, int P, int C, int act, void* stream) {
+    PHX_REQUIRE(phx_bn_small_supported(P, C, PHX_BF16) && nz >= 1, PHX_E_SHAPE, "bn_small_fwd_splitk: needs P <= 4096, C % 16 == 0");
+#define BNS_F(NITv)                                                                                                   \
+    hipLaunchKernelGGL((k_bn_small_fwd<NITv, true>), dim3(C / 16), dim3(1024), 0, (hipStream_t)stream, nullptr, ws, nz, \
+                       (bf16_t*)x_out, gamma, beta, eps, (bf16_t*)y, mean, rstd, scale, shift, moving_mean, moving_var, \
+                       momentum, P, C, act)
     if (P <= 512) BNS_F(1); else if (P <= 1024) BNS_F(2); else if (P <= 2048) BNS_F(4); else BNS_F(8);
 #undef BNS_F
     PHX_CHECK_LAUNCH();

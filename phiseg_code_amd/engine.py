@@ -28,6 +28,7 @@ _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, U8: torch.uint8}
 _NP_DT = {F32: np.float32, U8: np.uint8}
 _ESIZE = {F32: 4, BF16: 2, U8: 1}
 _STAMPS = os.environ.get("PHX_STAMPS", "0") == "1"
+_BN_SPLITK = os.environ.get("PHX_BN_SPLITK", "0") == "1"   # small batch norm consumes the split-K slices of its convolution (measured 0.5 % slower: off)
 _BN_SMALL = int(os.environ.get("PHX_BN_SMALL", "1024"))     # one-launch batch norm up to this many pixels (0: off)
 
 
@@ -542,12 +543,23 @@ class Plan:
                         and Lb.bn_small_supported(P, cout, BF16))
             if bn_small:
                 upd = training and self.loss is not None
-                conv_into(y, 0)
-                self._emit(Lb.bn_small_fwd, y.ptr, gptr, beptr, eps, out.ptr, mean.ptr, rstd.ptr, scale.ptr, shift.ptr,
-                           self.store.ptr(nv["moving_mean"]) if upd else None,
-                           self.store.ptr(nv["moving_variance"]) if upd else None,
-                           (1.0 - tfnorm.BN_DECAY) if upd else 0.0, P, cout, act, S,
-                           tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
+                mm = self.store.ptr(nv["moving_mean"]) if upd else None
+                mv = self.store.ptr(nv["moving_variance"]) if upd else None
+                mom = (1.0 - tfnorm.BN_DECAY) if upd else 0.0
+                ks = int(Lb.conv3x3_mfma_ksplit(B, H, Wd, cin_eff, cout)) if (mfma and not head1x1 and _BN_SPLITK) else 1
+                if ks > 1:        # split-K convolution: its fp32 slices go straight into the norm kernel (no finishing launch)
+                    wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cin_eff, cout))
+                    ws = self._alloc((wsb // 4,), F32)
+                    self._emit(Lb.conv3x3_mfma_bf16_ws, x.ptr, wf.ptr, None, None, 0, None, ws.ptr, wsb, B, H, Wd, cin_eff,
+                               cout, S, tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
+                    self._emit(Lb.bn_small_fwd_splitk, ws.ptr, ks, y.ptr, gptr, beptr, eps, out.ptr, mean.ptr, rstd.ptr,
+                               scale.ptr, shift.ptr, mm, mv, mom, P, cout, act, S,
+                               tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
+                else:
+                    conv_into(y, 0)
+                    self._emit(Lb.bn_small_fwd, y.ptr, gptr, beptr, eps, out.ptr, mean.ptr, rstd.ptr, scale.ptr, shift.ptr,
+                               mm, mv, mom, P, cout, act, S,
+                               tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
                 st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn, bn_small=True)
                 self.saved[op] = st
                 return

@@ -452,6 +452,19 @@ def test_bn_small_one_launch_layer(L, case):
                        act, S())
     close(host(scale), host(scale3), 2e-5, "bn_small vs three-launch scale")
     close(host(shift), host(shift3), 2e-5, "bn_small vs three-launch shift")
+    # fed by split-K slices (the convolution skipped its finishing pass): same layer, plus the bf16 copy of the summed input
+    nz = 3
+    parts = RNG.standard_normal((nz, B, H, W, C)).astype(np.float32)
+    parts[nz - 1] = x.astype(np.float32) - parts[:nz - 1].sum(axis=0)
+    pd = torch.as_tensor(parts).cuda()
+    xs = torch.as_tensor(parts).cuda().sum(0)                    # what the kernel rounds to bf16
+    xsr = xs.to(torch.bfloat16).double().cpu()
+    ys, _, _ = T.batch_norm_train(xsr, gr.detach(), br.detach())
+    a4, x4 = torch.empty_like(a), torch.empty_like(a)
+    L.bn_small_fwd_splitk(pd.data_ptr(), nz, x4.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-3, a4.data_ptr(), mean3.data_ptr(),
+                          rstd3.data_ptr(), scale3.data_ptr(), shift3.data_ptr(), None, None, 0.0, P, C, act, S())
+    close(host(x4), xsr.numpy(), 4e-3, "bn_small split-K summed input")      # (summation order may flip a bf16 rounding)
+    close(host(a4), (T.relu(ys) if act else ys).numpy(), 8e-3, "bn_small split-K fwd")
     dA = RNG.standard_normal((B, H, W, C))
     dAr = rounded(dA, BF16)
     (ar * dAr).sum().backward()
