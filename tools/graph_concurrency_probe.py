@@ -43,6 +43,10 @@ def forked(token):
         L.event_record(ej, s1); L.stream_wait_event(s0, ej)
     return body
 def one(): chain(A, s0, N)
+_tb = torch.zeros(8, dtype=torch.int64, device="cuda")
+def stamps():
+    for _ in range(N): L.stamp(_tb.data_ptr(), s0)
+print("chain of %d 1-thread launches:    %8.1f us  (pure per-node cost)" % (N, timeit(capture(stamps))))
 print("one chain of %d launches:        %8.1f us" % (N, timeit(capture(one))))
 print("two chains, one stream:          %8.1f us" % timeit(capture(serial)))
 print("two chains, two streams:         %8.1f us" % timeit(capture(forked(False))))
