@@ -1308,35 +1308,34 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* 
     }
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     u32x4 rx[NXI], rd[QD];
-    auto prefetch = [&](int t) {                 // global -> registers for tile t (zero fill outside the image / batch)
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * Cin * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * H * W * Cout * 2u), 0x00020000);
+    const int qxb = (threadIdx.x % QX) * 16, qdb = (threadIdx.x % QD) * 16;      // 256 % QX == 0: the same for every piece
+    // global -> registers for tile t.  Branch-free: a piece outside the image / batch gets buffer offset 0xffffffff and
+    // reads zeros.  (With `if (inside) load` the compiler drained the load queue at every branch join: 40 pieces x ~350
+    // cycles = 6.8 us of prologue on the small-map tiles, a third of the launch.)
+    auto prefetch = [&](int t) {
         const int tx0 = (t % g.tiles_x) << g.tws; t /= g.tiles_x;
         const int ty0 = (t % g.tiles_y) << g.ths; t /= g.tiles_y;
         const int b0 = t * g.tb;
 #pragma unroll
         for (int it = 0; it < NXI; ++it) {
-            rx[it] = u32x4{0, 0, 0, 0};
-            if (planx[it] >= 0) {
-                const int gx = tx0 + (planx[it] & 255) - 1, gy = ty0 + ((planx[it] >> 8) & 255) - 1, gb = b0 + (planx[it] >> 16);
-                if (gx >= 0 && gx < W && gy >= 0 && gy < H && gb < B)
-                    rx[it] = *reinterpret_cast<const u32x4*>(x + (((size_t)gb * H + gy) * W + gx) * Cin + ci0 +
-                                                             ((threadIdx.x + it * 256) % QX) * 8);
-            }
+            const int gx = tx0 + (planx[it] & 255) - 1, gy = ty0 + ((planx[it] >> 8) & 255) - 1, gb = b0 + (planx[it] >> 16);
+            const bool ok = planx[it] >= 0 && (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && gb < B;
+            const unsigned vo = ok ? (unsigned)(((gb * H + gy) * W + gx) * Cin * 2 + qxb) : 0xffffffffu;
+            rx[it] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)vo, ci0 * 2, 0);
         }
 #pragma unroll
         for (int it = 0; it < QD; ++it) {
             const int ox = tx0 + (pland[it] & 255), oy = ty0 + ((pland[it] >> 8) & 255), ob = b0 + (pland[it] >> 16);
-            rd[it] = u32x4{0, 0, 0, 0};
-            if (ox < W && oy < H && ob < B)
-                rd[it] = *reinterpret_cast<const u32x4*>(dy + (((size_t)ob * H + oy) * W + ox) * Cout + co0 +
-                                                         ((threadIdx.x + it * 256) % QD) * 8);
+            const bool ok = ox < W && oy < H && ob < B;
+            const unsigned vo = ok ? (unsigned)(((ob * H + oy) * W + ox) * Cout * 2 + qdb) : 0xffffffffu;
+            rd[it] = __builtin_amdgcn_raw_buffer_load_b128(rsd, (int)vo, co0 * 2, 0);
         }
     };
     // FAST16 kernels stage with raw buffer loads instead: a piece outside the image gets offset 0xffffffff, which the buffer
     // range check turns into zeros -- no branches, so single pieces can be issued between the MFMAs of the k-steps and the
     // global-load path (~12 B/clk/CU, the scarce resource of this kernel) works underneath the matrix pipe.
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * Cin * 2u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * H * W * Cout * 2u), 0x00020000);
-    const int qxb = (threadIdx.x % QX) * 16, qdb = (threadIdx.x % QD) * 16;      // 256 % QX == 0: the same for every piece
     int ptx0 = 0, pty0 = 0, pb0 = 0;             // tile being prefetched
     auto decode = [&](int t) {
         ptx0 = (t % g.tiles_x) << g.tws; t /= g.tiles_x;
