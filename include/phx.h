@@ -116,6 +116,15 @@ int phx_debug_set_blocklog(void* dev_buf);
  * the per-block partial filters are stored with plain writes and summed by a second kernel; workspace == NULL falls back
  * to fp32 atomics straight into dw_hwio (a CU issues those at ~1 lane/clock: 46 us per block on MI355X). */
 size_t phx_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout);
+/* Deferred reduction: ..._partial launches the filter-gradient kernels only and leaves the partial filters in the workspace;
+ * phx_conv3x3_wgrad_reduce_plan tells (host side) whether that launch uses the workspace at all (plan6[0]; maps of a few tiles
+ * add straight into dw_hwio) and the slice / tile geometry; phx_wgrad_reduce_multi then sums the workspaces of many layers in
+ * ONE launch.  jobs_dev: device array of {const float* ws; float* dw; int nslice, Cin, Cout, tci, tco, gx, gy, blk0;} with
+ * gx, gy = plan6[4], plan6[5], blk0 = running sum of gx * gy (ascending), total_blocks = its final value. */
+int phx_conv3x3_wgrad_reduce_plan(int B, int H, int W, int Cin, int Cout, int* plan6);
+int phx_conv3x3_wgrad_mfma_bf16_partial(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes,
+                                        int B, int H, int W, int Cin, int Cout, void* stream);
+int phx_wgrad_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, void* stream);
 int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes,
                                 int B, int H, int W, int Cin, int Cout, void* stream);
 

@@ -1693,20 +1693,20 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_dma(const unsigned sho
 // dw[k][ci][co] += sum over the nslice partial tiles written by the filter-gradient kernels.  A thread owns four
 // consecutive co entries (16-byte loads); block = 64 such quads x 4 slice groups; gridDim.y further splits the slices
 // (one atomic per entry per y-block); four slices are in flight per thread.
-__global__ void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw, int nslice, int Cin, int Cout,
-                               int tci, int tco) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ ws, float* __restrict__ dw, int nslice, int Cin,
+                                                  int Cout, int tci, int tco, int bx, int by, int ny) {
     const int tile_elems = 9 * tci * tco;
     const int ntile_ci = Cin / tci;
     const size_t total = (size_t)9 * Cin * Cout;
-    const size_t i = ((size_t)blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const size_t i = ((size_t)bx * 64 + (threadIdx.x & 63)) * 4;
     const int sg = threadIdx.x >> 6;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     if (i < total) {
         const int co = (int)(i % Cout), ci = (int)((i / Cout) % Cin), k = (int)(i / ((size_t)Cout * Cin));
         const int cb = (co / tco) * ntile_ci + (ci / tci);
         const float* p = ws + (size_t)cb * nslice * tile_elems + (k * tci + ci % tci) * tco + co % tco;
-        const int step = gridDim.y * 4;
-        int sidx = blockIdx.y * 4 + sg;
+        const int step = ny * 4;
+        int sidx = by * 4 + sg;
         for (; sidx + 3 * step < nslice; sidx += 4 * step) {
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)sidx * tile_elems);
             const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(sidx + step) * tile_elems);
@@ -1724,6 +1724,27 @@ __global__ void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__
 #pragma unroll
         for (int q = 0; q < 4; ++q) atomicAdd(&dw[i + q], r[q]);
     }
+}
+__global__ void k_wgrad_reduce(const float* __restrict__ ws, float* __restrict__ dw, int nslice, int Cin, int Cout,
+                               int tci, int tco) {
+    wgrad_reduce_body(ws, dw, nslice, Cin, Cout, tci, tco, blockIdx.x, blockIdx.y, gridDim.y);
+}
+// The reductions are leaves of the backward graph: instead of one small launch behind every filter-gradient kernel (81 per
+// step, ~10 us each on the latency-bound small-map chains) ONE launch at the end of the backward pass sums the partial
+// filters of all layers.  jobs[j].blk0 = first block of job j in the flat grid (ascending).
+struct WgrJob {
+    const float* ws; float* dw;
+    int nslice, Cin, Cout, tci, tco, gx, gy, blk0;
+};
+__global__ void k_wgrad_reduce_multi(const WgrJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {                                         // last job with blk0 <= blockIdx.x (uniform per block)
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const WgrJob j = jobs[lo];
+    const int local = blockIdx.x - j.blk0;
+    wgrad_reduce_body(j.ws, j.dw, j.nslice, j.Cin, j.Cout, j.tci, j.tco, local % j.gx, local / j.gx, j.gy);
 }
 
 // y[pix][n] = bf16(act(sum_z ws[z][pix][n] + bias[n])), four channels per thread
@@ -2046,8 +2067,47 @@ size_t phx_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout) {
     return (size_t)(Cin / tci) * (Cout / tco) * gx * wk * 9 * tci * tco * sizeof(float);
 }
 
+static int wgrad_atomic_tiles() {
+    static int atl = -1;
+    if (atl < 0) { const char* e = getenv("PHX_WGRAD_ATOMIC_TILES"); atl = e ? atoi(e) : 4; }
+    return atl;
+}
+static void wgrad_reduce_geometry(int Cin, int Cout, int nslice, int* rgx, int* rgy) {
+    const size_t total = (size_t)9 * Cin * Cout;
+    int gy = nslice / 16;
+    if (gy < 1) gy = 1;
+    if (gy > 16) gy = 16;
+    *rgx = (int)((total / 4 + 63) / 64);
+    *rgy = gy;
+}
+/* plan6 = {uses_workspace, nslice, tci, tco, reduce grid x, reduce grid y} of the launch phx_conv3x3_wgrad_mfma_bf16 makes */
+int phx_conv3x3_wgrad_reduce_plan(int B, int H, int W, int Cin, int Cout, int* plan6) {
+    MTile g; int tci, tco, gx, tpb, wk;
+    const int ntiles = wgrad_plan(B, H, W, Cin, Cout, &g, &tci, &tco, &gx, &tpb, &wk);
+    plan6[0] = ntiles > wgrad_atomic_tiles();
+    plan6[1] = gx * wk; plan6[2] = tci; plan6[3] = tco;
+    wgrad_reduce_geometry(Cin, Cout, gx * wk, &plan6[4], &plan6[5]);
+    return PHX_OK;
+}
+int phx_wgrad_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, void* stream) {
+    PHX_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, PHX_E_INVAL, "wgrad_reduce_multi: empty job list");
+    hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const WgrJob*)jobs_dev, njobs);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+static int wgrad_impl(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes, int B, int H,
+                      int W, int Cin, int Cout, bool reduce, void* stream);
 int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes,
                                 int B, int H, int W, int Cin, int Cout, void* stream) {
+    return wgrad_impl(x, dy, dw_hwio, workspace, workspace_bytes, B, H, W, Cin, Cout, true, stream);
+}
+int phx_conv3x3_wgrad_mfma_bf16_partial(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes,
+                                        int B, int H, int W, int Cin, int Cout, void* stream) {
+    return wgrad_impl(x, dy, dw_hwio, workspace, workspace_bytes, B, H, W, Cin, Cout, false, stream);
+}
+static int wgrad_impl(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes, int B, int H,
+                      int W, int Cin, int Cout, bool reduce, void* stream) {
     PHX_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, PHX_E_SHAPE, "conv3x3_wgrad_mfma: Cin % 32 == 0 and Cout % 32 == 0 required");
     MTile g; int tci, tco, gx, tpb, wk;
     const int ntiles = wgrad_plan(B, H, W, Cin, Cout, &g, &tci, &tco, &gx, &tpb, &wk);
@@ -2059,9 +2119,7 @@ int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, v
         ws = (float*)workspace;
         // a handful of pixel tiles (H <= 4 at batch 64): the partial filters are few, so adding them straight into dw with
         // atomics beats the extra k_wgrad_reduce launch on the latency-bound small-map chains (26 -> 20 us at 4 x 4)
-        static int atl = -1;
-        if (atl < 0) { const char* e = getenv("PHX_WGRAD_ATOMIC_TILES"); atl = e ? atoi(e) : 4; }
-        if (ntiles <= atl) ws = nullptr;
+        if (ntiles <= wgrad_atomic_tiles()) ws = nullptr;
     }
     static bool attr_set = false;
     if (!attr_set) {
@@ -2110,14 +2168,12 @@ int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, v
 #undef WG_LAUNCH
     PHX_CHECK_LAUNCH();
     }
-    if (ws) {
-        const size_t total = (size_t)9 * Cin * Cout;
+    if (ws && reduce) {
         const int nslice = gx * wk;
-        int gy = nslice / 16;
-        if (gy < 1) gy = 1;
-        if (gy > 16) gy = 16;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total / 4 + 63) / 64), gy), dim3(256), 0, (hipStream_t)stream, ws,
-                           dw_hwio, nslice, Cin, Cout, tci, tco);
+        int rgx, rgy;
+        wgrad_reduce_geometry(Cin, Cout, nslice, &rgx, &rgy);
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)rgx, rgy), dim3(256), 0, (hipStream_t)stream, ws, dw_hwio, nslice,
+                           Cin, Cout, tci, tco);
         PHX_CHECK_LAUNCH();
     }
     return PHX_OK;

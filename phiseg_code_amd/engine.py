@@ -27,6 +27,7 @@ F32, BF16, U8 = rt.F32, rt.BF16, 2
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, U8: torch.uint8}
 _NP_DT = {F32: np.float32, U8: np.uint8}
 _ESIZE = {F32: 4, BF16: 2, U8: 1}
+_WGRAD_MULTI = os.environ.get("PHX_WGRAD_MULTI", "1") == "1"   # one reduction launch for all layers' partial filter gradients
 _EARLY_TOUCH = os.environ.get("PHX_EARLY_TOUCH", "1") == "1"
 _STAMPS = os.environ.get("PHX_STAMPS", "0") == "1"
 _BN_SPLITK = os.environ.get("PHX_BN_SPLITK", "0") == "1"   # small batch norm consumes the split-K slices of its convolution (measured 0.5 % slower: off)
@@ -184,6 +185,7 @@ class Plan:
         self.feeds = {}
         self._keep = []
         self._wpk = {}
+        self._wgr_jobs = []           # deferred filter-gradient reductions: (ws, dw, nslice, Cin, Cout, tci, tco, gx, gy)
         self._pack_jobs = []          # (w, wpk_fwd, wpk_dgrad, Cin, Cin_pad, Cout): ONE multi-filter pack launch per run
         self._zarena = torch.zeros(8 << 20, dtype=torch.float32, device=_device())     # 32 MB of per-step accumulators
         self._zused = 0
@@ -400,6 +402,16 @@ class Plan:
             for evl in tails:
                 self._wait(evl)
         self._lane = 0
+        if self._wgr_jobs:
+            rec = np.zeros(len(self._wgr_jobs), dtype=[("ws", "<u8"), ("dw", "<u8"), ("nslice", "<i4"), ("cin", "<i4"), ("cout", "<i4"),
+                                                       ("tci", "<i4"), ("tco", "<i4"), ("gx", "<i4"), ("gy", "<i4"), ("blk0", "<i4")])
+            blk = 0
+            for i, j in enumerate(self._wgr_jobs):
+                rec[i] = tuple(j) + (blk,)
+                blk += j[7] * j[8]
+            self._wgr_desc = torch.from_numpy(rec.view(np.uint8).copy()).to(_device())
+            self._keep.append(self._wgr_desc)
+            self._emit(self.L.wgrad_reduce_multi, self._wgr_desc.data_ptr(), len(self._wgr_jobs), blk, self.stream)
         self._prune_dead_event_records()
         self.launches[0] = (self.L.memset, (self._zarena.data_ptr(), 0, max(self._zused, 1) * 4, self.stream))
         if self._pack_jobs:           # slot 1 was reserved before the fork: refresh every packed bf16 filter in one launch
@@ -892,8 +904,17 @@ class Plan:
         elif sv["mfma"]:
             wsb = int(Lb.conv3x3_wgrad_ws_bytes(B, H, Wd, cin, cout))
             wsp = self._alloc((wsb // 4,), F32)      # per-layer workspace of partial filters (no cross-lane sharing)
-            self._emit(Lb.conv3x3_wgrad_mfma_bf16, x.ptr, dY.ptr, dw, wsp.ptr, wsb, B, H, Wd, cin, cout, S,
-                       tag="conv3x3_mfma_wgrad", flops=18.0 * cin * cout * B * H * Wd)
+            plan6 = (ctypes.c_int * 6)()
+            Lb.conv3x3_wgrad_reduce_plan(B, H, Wd, cin, cout, plan6)
+            if _WGRAD_MULTI and plan6[0]:
+                # the sum over the partial filters is a leaf of the backward graph: deferred to ONE launch for all layers
+                # (phx_wgrad_reduce_multi, emitted after the lanes have joined)
+                self._emit(Lb.conv3x3_wgrad_mfma_bf16_partial, x.ptr, dY.ptr, dw, wsp.ptr, wsb, B, H, Wd, cin, cout, S,
+                           tag="conv3x3_mfma_wgrad", flops=18.0 * cin * cout * B * H * Wd)
+                self._wgr_jobs.append((wsp.ptr, dw, plan6[1], cin, cout, plan6[2], plan6[3], plan6[4], plan6[5]))
+            else:
+                self._emit(Lb.conv3x3_wgrad_mfma_bf16, x.ptr, dY.ptr, dw, wsp.ptr, wsb, B, H, Wd, cin, cout, S,
+                           tag="conv3x3_mfma_wgrad", flops=18.0 * cin * cout * B * H * Wd)
             if db is not None:
                 self._emit(Lb.channel_sum_accumulate, dY.ptr, dY.dt, db, B * H * Wd, cout, S)
         else:

@@ -315,6 +315,39 @@ def _mfma_case(L, case):
     close(host(dw2), wr.grad.numpy(), 1e-4, "mfma wgrad (workspace)")
 
 
+def test_wgrad_deferred_multi_layer_reduction(L):
+    """phx_conv3x3_wgrad_mfma_bf16_partial + ONE phx_wgrad_reduce_multi over several layers == the per-layer launches."""
+    import ctypes
+    shapes = [(3, 16, 16, 64, 64), (2, 32, 32, 32, 96), (5, 8, 8, 96, 32), (2, 16, 48, 128, 64), (64, 2, 2, 64, 64)]
+    keep, jobs, want, blk = [], [], [], 0
+    for (B, H, W, K, N) in shapes:
+        x, dy = dev(RNG.standard_normal((B, H, W, K)), BF16), dev(RNG.standard_normal((B, H, W, N)), BF16)
+        wsb = int(L.conv3x3_wgrad_ws_bytes(B, H, W, K, N))
+        ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32).cuda()
+        ref = torch.full((3, 3, K, N), 0.25, dtype=torch.float32).cuda()          # accumulate semantics: start from non-zero
+        L.conv3x3_wgrad_mfma_bf16(x.data_ptr(), dy.data_ptr(), ref.data_ptr(), ws.data_ptr(), wsb, B, H, W, K, N, S())
+        torch.cuda.synchronize()
+        ws2 = torch.empty_like(ws)
+        dw = torch.full((3, 3, K, N), 0.25, dtype=torch.float32).cuda()
+        plan = (ctypes.c_int * 6)()
+        L.conv3x3_wgrad_reduce_plan(B, H, W, K, N, plan)
+        L.conv3x3_wgrad_mfma_bf16_partial(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws2.data_ptr(), wsb, B, H, W, K, N, S())
+        if plan[0]:
+            jobs.append((ws2.data_ptr(), dw.data_ptr(), plan[1], K, N, plan[2], plan[3], plan[4], plan[5], blk))
+            blk += plan[4] * plan[5]
+        keep.append((x, dy, ws, ws2)); want.append((ref, dw, plan[0]))
+    assert any(w[2] for w in want) and not all(w[2] for w in want)                 # both the workspace and the atomics path
+    rec = np.zeros(len(jobs), dtype=[("ws", "<u8"), ("dw", "<u8"), ("nslice", "<i4"), ("cin", "<i4"), ("cout", "<i4"), ("tci", "<i4"),
+                                     ("tco", "<i4"), ("gx", "<i4"), ("gy", "<i4"), ("blk0", "<i4")])
+    for i, j in enumerate(jobs):
+        rec[i] = j
+    desc = torch.from_numpy(rec.view(np.uint8).copy()).cuda()
+    L.wgrad_reduce_multi(desc.data_ptr(), len(jobs), blk, S())
+    torch.cuda.synchronize()
+    for k, (ref, dw, _) in enumerate(want):
+        close(host(dw), host(ref), 2e-6, "deferred reduction, layer %d" % k)
+
+
 NORM_CASES = [
     # kind, B, H, W, C, G, dt
     ("batch", 3, 8, 8, 32, None, F32),
