@@ -136,6 +136,13 @@ int phx_head1x1_fwd(const void* x, int x_dt, const float* w, const float* bias, 
 int phx_head1x1_dgrad(const float* dy, const float* w, void* dx, int dx_dt, size_t npix, int C, int nout, void* stream);
 int phx_head1x1_wgrad(const void* x, int x_dt, const float* dy, float* dw, float* db, size_t npix, int C, int nout,
                       void* stream);
+/* Deferred form: the head filter gradients are leaves of the backward graph, so all heads of a plan can share ONE launch.
+ * phx_head1x1_wgrad_plan (host) gives plan4 = {PL, chunk, grid, dynamic LDS bytes} for C % 8 == 0; jobs_dev is a device array
+ * of {const void* x; const float* dy; float* dw; float* db; uint64 npix; int C, PL, chunk, blk0;} with blk0 = running sum
+ * of the grids (ascending), all jobs with the same x dtype and nout; lds_bytes = max of the jobs' plan4[3]. */
+int phx_head1x1_wgrad_plan(size_t npix, int C, int nout, int* plan4);
+int phx_head1x1_wgrad_multi(const void* jobs_dev, int njobs, int total_blocks, int x_dt, int nout, size_t lds_bytes,
+                            void* stream);
 
 /* ---- normalisation (tfwrapper/normalisation.py:3-36,145-163) --------------------------------------- */
 /* One implementation for batch / group / instance norm.  A statistic is taken over P pixels x (C/G) channels

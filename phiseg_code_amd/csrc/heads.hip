@@ -114,8 +114,9 @@ __global__ void k_head1x1_dgrad(const float* __restrict__ dy, const float* __res
 
 // dw[c][o] += sum_p x[p][c] * dy[p][o];  db[o] += sum_p dy[p][o]
 template <typename TX, int V, int NOUT>
-__global__ void k_head1x1_wgrad(const TX* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
-                                float* __restrict__ db, size_t npix, int C, int PL, int chunk) {
+__device__ __forceinline__ void head1x1_wgrad_body(const TX* __restrict__ x, const float* __restrict__ dy,
+                                                   float* __restrict__ dw, float* __restrict__ db, size_t npix, int C, int PL,
+                                                   int chunk, int bx) {
     const int CV = C / V;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
     extern __shared__ float red[];                  // [PL][C][NOUT]
@@ -126,7 +127,7 @@ __global__ void k_head1x1_wgrad(const TX* __restrict__ x, const float* __restric
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[j][o] = 0.f;
     }
-    const size_t p0 = (size_t)blockIdx.x * chunk;
+    const size_t p0 = (size_t)bx * chunk;
     const size_t p1 = p0 + chunk < npix ? p0 + chunk : npix;
     if (pl < PL) {
         size_t p = p0 + pl;
@@ -186,6 +187,29 @@ __global__ void k_head1x1_wgrad(const TX* __restrict__ x, const float* __restric
         }
     }
 }
+template <typename TX, int V, int NOUT>
+__global__ void k_head1x1_wgrad(const TX* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
+                                float* __restrict__ db, size_t npix, int C, int PL, int chunk) {
+    head1x1_wgrad_body<TX, V, NOUT>(x, dy, dw, db, npix, C, PL, chunk, blockIdx.x);
+}
+// The head filter gradients are leaves of the backward graph (only Adam reads them): one launch for all heads of a plan,
+// after the lanes have joined, instead of 23 latency-bound launches inside the posterior / prior / likelihood chains.
+struct HeadWJob {
+    const void* x; const float* dy; float* dw; float* db;
+    unsigned long long npix;
+    int C, PL, chunk, blk0;
+};
+template <typename TX, int NOUT>
+__global__ __launch_bounds__(256) void k_head1x1_wgrad_multi(const HeadWJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {                                         // last job with blk0 <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const HeadWJob j = jobs[lo];
+    // (256-thread blocks; C = 192 uses 240 of them -- the others have pl >= PL and only take part in the barriers)
+    head1x1_wgrad_body<TX, 8, NOUT>((const TX*)j.x, j.dy, j.dw, j.db, (size_t)j.npix, j.C, j.PL, j.chunk, (int)blockIdx.x - j.blk0);
+}
 
 static int head_geo(int C, int V, int* PL, int* threads) {
     const int CV = C / V;
@@ -243,18 +267,48 @@ int phx_head1x1_dgrad(const float* dy, const float* w, void* dx, int dx_dt, size
     return PHX_OK;
 }
 
+static void head_wgrad_geometry(size_t npix, int PL, int* chunk, int* grid) {
+    int ch = PL * 32;
+    size_t g = (npix + ch - 1) / ch;
+    // every block ends in C * nout same-address atomics (~45 ns each, serialised): few, long blocks
+    static int cap = 0;
+    if (!cap) { const char* e = getenv("PHX_HEADW_BLOCKS"); cap = e ? atoi(e) : 1024; }
+    if (g > (size_t)cap) { ch = (int)((npix + cap - 1) / cap); g = (npix + ch - 1) / ch; }
+    *chunk = ch; *grid = (int)g;
+}
+/* plan4 = {PL, chunk, grid, dynamic LDS bytes} of the launch phx_head1x1_wgrad makes for C % 8 == 0 */
+int phx_head1x1_wgrad_plan(size_t npix, int C, int nout, int* plan4) {
+    PHX_REQUIRE(C % 8 == 0 && C / 8 <= 256, PHX_E_SHAPE, "head1x1_wgrad_plan: C % 8 == 0 required");
+    int PL, threads;
+    head_geo(C, 8, &PL, &threads);
+    const int N = nout <= 2 ? 2 : nout <= 4 ? 4 : nout <= 6 ? 6 : 8;
+    plan4[0] = PL;
+    head_wgrad_geometry(npix, PL, &plan4[1], &plan4[2]);
+    plan4[3] = (int)((size_t)PL * C * N * sizeof(float));
+    return PHX_OK;
+}
+/* jobs_dev: device array of {const void* x; const float* dy; float* dw; float* db; uint64 npix; int C, PL, chunk, blk0;}
+ * (PL, chunk from phx_head1x1_wgrad_plan, blk0 = running sum of the grids), all with the same x dtype and nout, C % 8 == 0 */
+int phx_head1x1_wgrad_multi(const void* jobs_dev, int njobs, int total_blocks, int x_dt, int nout, size_t lds_bytes,
+                            void* stream) {
+    PHX_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, PHX_E_INVAL, "head1x1_wgrad_multi: empty job list");
+    PHX_REQUIRE(nout == 2 || nout == 4 || nout == 6 || nout == 8, PHX_E_SHAPE, "head1x1: nout in {2,4,6,8}");
+    PHX_DT_SWITCH(x_dt, TX, HEAD_NOUT_SWITCH(nout, N, {
+        hipLaunchKernelGGL((k_head1x1_wgrad_multi<TX, N>), dim3((unsigned)total_blocks), dim3(256), lds_bytes,
+                           (hipStream_t)stream, (const HeadWJob*)jobs_dev, njobs);
+    }));
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
 int phx_head1x1_wgrad(const void* x, int x_dt, const float* dy, float* dw, float* db, size_t npix, int C, int nout,
                       void* stream) {
     PHX_REQUIRE(nout == 2 || nout == 4 || nout == 6 || nout == 8, PHX_E_SHAPE, "head1x1: nout in {2,4,6,8}");
     PHX_DT_SWITCH(x_dt, TX, HEAD_VEC_SWITCH(C, V, HEAD_NOUT_SWITCH(nout, N, {
         int PL, threads;
         PHX_REQUIRE(head_geo(C, V, &PL, &threads) == 0, PHX_E_SHAPE, "head1x1: C too large");
-        int chunk = PL * 32;
-        size_t grid = (npix + chunk - 1) / chunk;
-        // every block ends in C * nout same-address atomics (~45 ns each, serialised): few, long blocks
-        static int cap = 0;
-        if (!cap) { const char* e = getenv("PHX_HEADW_BLOCKS"); cap = e ? atoi(e) : 1024; }
-        if (grid > (size_t)cap) { chunk = (int)((npix + cap - 1) / cap); grid = (npix + chunk - 1) / chunk; }
+        int chunk, grid;
+        head_wgrad_geometry(npix, PL, &chunk, &grid);
         size_t sh = (size_t)PL * C * N * sizeof(float);
         if (sh < (size_t)PL * N * sizeof(float)) sh = (size_t)PL * N * sizeof(float);
         hipLaunchKernelGGL((k_head1x1_wgrad<TX, V, N>), dim3((unsigned)grid), dim3(threads), sh, (hipStream_t)stream,

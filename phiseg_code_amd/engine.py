@@ -185,6 +185,7 @@ class Plan:
         self.feeds = {}
         self._keep = []
         self._wpk = {}
+        self._headw_jobs = {}         # deferred 1x1-head filter gradients by (x dtype, nout): (x, dy, dw, db, npix, C, PL, chunk, grid, lds)
         self._wgr_jobs = []           # deferred filter-gradient reductions: (ws, dw, nslice, Cin, Cout, tci, tco, gx, gy)
         self._pack_jobs = []          # (w, wpk_fwd, wpk_dgrad, Cin, Cin_pad, Cout): ONE multi-filter pack launch per run
         self._zarena = torch.zeros(8 << 20, dtype=torch.float32, device=_device())     # 32 MB of per-step accumulators
@@ -412,6 +413,17 @@ class Plan:
             self._wgr_desc = torch.from_numpy(rec.view(np.uint8).copy()).to(_device())
             self._keep.append(self._wgr_desc)
             self._emit(self.L.wgrad_reduce_multi, self._wgr_desc.data_ptr(), len(self._wgr_jobs), blk, self.stream)
+        for (xdt, nout), jobs in self._headw_jobs.items():
+            rec = np.zeros(len(jobs), dtype=[("x", "<u8"), ("dy", "<u8"), ("dw", "<u8"), ("db", "<u8"), ("npix", "<u8"), ("C", "<i4"),
+                                             ("PL", "<i4"), ("chunk", "<i4"), ("blk0", "<i4")])
+            blk = lds = 0
+            for i, j in enumerate(jobs):
+                rec[i] = (j[0], j[1], j[2], j[3], j[4], j[5], j[6], j[7], blk)
+                blk += j[8]
+                lds = max(lds, j[9])
+            desc = torch.from_numpy(rec.view(np.uint8).copy()).to(_device())
+            self._keep.append(desc)
+            self._emit(self.L.head1x1_wgrad_multi, desc.data_ptr(), len(jobs), blk, xdt, nout, lds, self.stream)
         self._prune_dead_event_records()
         self.launches[0] = (self.L.memset, (self._zarena.data_ptr(), 0, max(self._zused, 1) * 4, self.stream))
         if self._pack_jobs:           # slot 1 was reserved before the fork: refresh every packed bf16 filter in one launch
@@ -888,7 +900,13 @@ class Plan:
         # (The filter gradient is a leaf of the backward graph; moving these launches to another lane, beside the data-
         # gradient chain, was measured 20 % SLOWER: both are bound by the same global->LDS path, so the kernel on the
         # critical path just gets half of it.)
-        if sv.get("head1x1"):
+        if sv.get("head1x1") and _WGRAD_MULTI and cin % 8 == 0 and db is not None:
+            # a leaf of the backward graph: all heads share one launch after the lanes have joined (phx_head1x1_wgrad_multi)
+            plan4 = (ctypes.c_int * 4)()
+            Lb.head1x1_wgrad_plan(B * H * Wd, cin, cout, plan4)
+            self._headw_jobs.setdefault((x.dt, cout), []).append((x.ptr, dY.ptr, dw, db, B * H * Wd, cin, plan4[0], plan4[1],
+                                                                   plan4[2], plan4[3]))
+        elif sv.get("head1x1"):
             self._emit(Lb.head1x1_wgrad, x.ptr, x.dt, dY.ptr, dw, db, B * H * Wd, cin, cout, S)
         elif sv.get("padded"):
             ce = sv["cin_eff"]

@@ -722,3 +722,35 @@ def test_head1x1_kernels(L, case):
     L.head1x1_wgrad(xd.data_ptr(), xdt, dyd.data_ptr(), dw.data_ptr(), db.data_ptr(), npix, C, NO, S())
     close(host(dw), wr.grad.numpy().reshape(C, NO), 3e-5, "head wgrad")
     close(host(db), br.grad.numpy(), 3e-5, "head dbias")
+
+
+@pytest.mark.parametrize("nout", [2, 4])
+def test_head1x1_wgrad_multi_matches_per_head_launches(L, nout):
+    """One phx_head1x1_wgrad_multi launch over heads of different widths / map sizes == the per-head launches (accumulating)."""
+    import ctypes
+    heads = [(64, 2, 2, 192), (64, 16, 16, 192), (3, 32, 32, 128), (2, 64, 64, 64), (1, 128, 128, 32), (5, 7, 3, 40)]
+    keep, rows, want, blk, lds = [], [], [], 0, 0
+    for (B, H, W, C) in heads:
+        npix = B * H * W
+        x, dy = dev(RNG.standard_normal((npix, C)), BF16), dev(RNG.standard_normal((npix, nout)))
+        dw_ref = torch.full((C, nout), 0.5, dtype=torch.float32).cuda()
+        db_ref = torch.full((nout,), -1.0, dtype=torch.float32).cuda()
+        L.head1x1_wgrad(x.data_ptr(), BF16, dy.data_ptr(), dw_ref.data_ptr(), db_ref.data_ptr(), npix, C, nout, S())
+        dw = torch.full((C, nout), 0.5, dtype=torch.float32).cuda()
+        db = torch.full((nout,), -1.0, dtype=torch.float32).cuda()
+        plan = (ctypes.c_int * 4)()
+        L.head1x1_wgrad_plan(npix, C, nout, plan)
+        rows.append((x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), npix, C, plan[0], plan[1], blk))
+        blk += plan[2]
+        lds = max(lds, plan[3])
+        keep.append((x, dy)); want.append((dw_ref, db_ref, dw, db))
+    rec = np.zeros(len(rows), dtype=[("x", "<u8"), ("dy", "<u8"), ("dw", "<u8"), ("db", "<u8"), ("npix", "<u8"), ("C", "<i4"), ("PL", "<i4"),
+                                     ("chunk", "<i4"), ("blk0", "<i4")])
+    for i, r in enumerate(rows):
+        rec[i] = r
+    desc = torch.from_numpy(rec.view(np.uint8).copy()).cuda()
+    L.head1x1_wgrad_multi(desc.data_ptr(), len(rows), blk, BF16, nout, lds, S())
+    torch.cuda.synchronize()
+    for k, (dw_ref, db_ref, dw, db) in enumerate(want):
+        close(host(dw), host(dw_ref), 1e-5, "multi head wgrad, head %d" % k)
+        close(host(db), host(db_ref), 1e-5, "multi head dbias, head %d" % k)
