@@ -125,6 +125,15 @@ int phx_conv3x3_wgrad_reduce_plan(int B, int H, int W, int Cin, int Cout, int* p
 int phx_conv3x3_wgrad_mfma_bf16_partial(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes,
                                         int B, int H, int W, int Cin, int Cout, void* stream);
 int phx_wgrad_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, void* stream);
+/* Deferred small-map filter gradients (maps narrower than 16 pixels: a few tiles, 9-36 blocks, latency-bound, and leaves of
+ * the backward graph): phx_conv3x3_wgrad_multi_job fills ONE job record of phx_conv3x3_wgrad_multi_job_bytes() bytes in HOST
+ * memory for the launch phx_conv3x3_wgrad_mfma_bf16_partial would make; info4 = {variant (0: 16x16-tile shape, cannot be
+ * deferred), blocks, dynamic LDS bytes, uses_workspace}.  The caller concatenates the records of one variant (blk0 = running
+ * sum of blocks), copies them to the device and calls phx_conv3x3_wgrad_multi once (lds_bytes = max over the jobs). */
+int phx_conv3x3_wgrad_multi_job_bytes(void);
+int phx_conv3x3_wgrad_multi_job(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes, int B,
+                                int H, int W, int Cin, int Cout, int blk0, void* job_out, int* info4);
+int phx_conv3x3_wgrad_multi(const void* jobs_dev, int njobs, int total_blocks, int variant, size_t lds_bytes, void* stream);
 int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes,
                                 int B, int H, int W, int Cin, int Cout, void* stream);
 

@@ -12,6 +12,7 @@
 #include <type_traits>
 
 #include "phx_common.h"
+#include <cstring>
 
 #ifndef PHX_ABLATE      // dev only (tools/build_ablate.sh): fwd 1 no global loads, 2 no LDS staging stores, 4 no MFMAs, 8 no output stores; wgrad 16 no global loads, 32 no MFMAs
 #define PHX_ABLATE 0
@@ -1241,12 +1242,12 @@ __device__ __forceinline__ int wswz(int pix, int byte_in_row) {
 }
 
 // BIGP selects the bound on the per-thread staging pieces: false -> 16x16 / 8x8x4 tiles, true -> 4x4x16 / 2x2x64 tiles
+// (body shared by the one-layer kernel and the multi-layer one below: bx / by / bz / gdx / gdy stand in for blockIdx, gridDim)
 template <int TCI, int TCO, bool BIGP, bool FAST16>
-__global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* __restrict__ x,
-                                                          const unsigned short* __restrict__ dy,
-                                                          float* __restrict__ dw, float* __restrict__ ws, int B, int H,
-                                                          int W, int Cin, int Cout, MTile g, int ntiles,
-                                                          int tiles_per_block) {
+__device__ __forceinline__ void conv3x3_wgrad_body(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
+                                                   float* __restrict__ dw, float* __restrict__ ws, int B, int H, int W, int Cin,
+                                                   int Cout, MTile g, int ntiles, int tiles_per_block, const int bx,
+                                                   const int by, const int bz, const int gdx, const int gdy) {
     constexpr int WI = TCI / 32, WJ = TCO / 32, WK = 4 / (WI * WJ);
     constexpr int RBX = TCI * 2, RBD = TCO * 2;
     constexpr int QX = TCI / 8, QD = TCO / 8;                        // 16-byte pieces per pixel
@@ -1257,7 +1258,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sX = smem;                    // [npatch][RBX]
     unsigned char* sD = smem + npatch * RBX;     // [256][RBD]
-    const int ci0 = blockIdx.y * TCI, co0 = blockIdx.z * TCO;
+    const int ci0 = by * TCI, co0 = bz * TCO;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wi = wave % WI, wj = (wave / WI) % WJ, wk = wave / (WI * WJ);
     const int c16 = lane & 15, cb16 = (lane >> 4) & 1, khalf = lane >> 5;
@@ -1365,7 +1366,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* 
             self(self, std::integral_constant<int, l + 1>(), hi);
         }
     };
-    const int t_begin = blockIdx.x * tiles_per_block;
+    const int t_begin = bx * tiles_per_block;
     const int t_end = min(ntiles, t_begin + tiles_per_block);
     PHX_BLOCKLOG_BEGIN();
     PHX_TRACE(0);
@@ -1501,10 +1502,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* 
     PHX_TRACE(5);
     if (ws) {
         // A CU issues fp32 atomics at ~1 lane/clock (measured: 36.8 K lane-atomics = 46 us per block), so the partial
-        // tile goes to a workspace with plain coalesced stores: ws[(cblock * gridDim.x + blockIdx.x)][wk][9][TCI][TCO];
+        // tile goes to a workspace with plain coalesced stores: ws[(cblock * gdx + bx)][wk][9][TCI][TCO];
         // k_wgrad_reduce sums the slices into dw.
-        const size_t cb = (size_t)blockIdx.z * gridDim.y + blockIdx.y;
-        float* wp = ws + ((cb * gridDim.x + blockIdx.x) * WK + wk) * (size_t)(9 * TCI * TCO);
+        const size_t cb = (size_t)bz * gdy + by;
+        float* wp = ws + ((cb * gdx + bx) * WK + wk) * (size_t)(9 * TCI * TCO);
 #pragma unroll
         for (int k = 0; k < 9; ++k)
 #pragma unroll
@@ -1524,6 +1525,37 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* 
     }
     PHX_TRACE(6);
     PHX_BLOCKLOG_END();
+}
+
+template <int TCI, int TCO, bool BIGP, bool FAST16>
+__global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* __restrict__ x,
+                                                          const unsigned short* __restrict__ dy,
+                                                          float* __restrict__ dw, float* __restrict__ ws, int B, int H,
+                                                          int W, int Cin, int Cout, MTile g, int ntiles,
+                                                          int tiles_per_block) {
+    conv3x3_wgrad_body<TCI, TCO, BIGP, FAST16>(x, dy, dw, ws, B, H, W, Cin, Cout, g, ntiles, tiles_per_block, blockIdx.x,
+                                               blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+}
+// Small-map filter gradients are leaves of the backward graph and latency-bound (a few tiles, 9-36 blocks, ~20 us each, in
+// the middle of the posterior / prior / likelihood chains).  The engine defers them: ONE launch per kernel variant runs the
+// jobs of all such layers side by side after the lanes have joined.  jobs[j].blk0 = first block of job j (ascending).
+struct WgMJob {
+    const unsigned short* x; const unsigned short* dy; float* dw; float* ws;
+    int B, H, W, Cin, Cout;
+    MTile g;
+    int ntiles, tpb, gdx, gdy, gdz, blk0;
+};
+template <int TCI, int TCO, bool BIGP>
+__global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_multi(const WgMJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {                                         // last job with blk0 <= blockIdx.x (uniform per block)
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const WgMJob j = jobs[lo];
+    const int local = blockIdx.x - j.blk0;
+    conv3x3_wgrad_body<TCI, TCO, BIGP, false>(j.x, j.dy, j.dw, j.ws, j.B, j.H, j.W, j.Cin, j.Cout, j.g, j.ntiles, j.tpb,
+                                              local % j.gdx, (local / j.gdx) % j.gdy, local / (j.gdx * j.gdy), j.gdx, j.gdy);
 }
 
 // ---- filter gradient, 16x16 tiles, LDS-DMA staging ---------------------------------------------------------------
@@ -2098,6 +2130,61 @@ int phx_wgrad_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, vo
 }
 static int wgrad_impl(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes, int B, int H,
                       int W, int Cin, int Cout, bool reduce, void* stream);
+/* Deferred small-map filter gradients (see k_conv3x3_wgrad_multi).  phx_conv3x3_wgrad_multi_job fills ONE job record of
+ * phx_conv3x3_wgrad_multi_job_bytes() bytes in HOST memory for the launch phx_conv3x3_wgrad_mfma_bf16_partial would make;
+ * info4 = {variant (0: this shape runs on the 16x16-tile kernels and cannot be deferred), blocks, dynamic LDS bytes,
+ * uses_workspace}.  The caller concatenates the records of one variant (blk0 = running sum of blocks), copies them to the
+ * device and calls phx_conv3x3_wgrad_multi once. */
+int phx_conv3x3_wgrad_multi_job_bytes(void) { return (int)sizeof(WgMJob); }
+int phx_conv3x3_wgrad_multi_job(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes, int B,
+                                int H, int W, int Cin, int Cout, int blk0, void* job_out, int* info4) {
+    PHX_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, PHX_E_SHAPE, "conv3x3_wgrad_multi_job: Cin % 32 == 0 and Cout % 32 == 0 required");
+    MTile g; int tci, tco, gx, tpb, wk;
+    const int ntiles = wgrad_plan(B, H, W, Cin, Cout, &g, &tci, &tco, &gx, &tpb, &wk);
+    info4[0] = info4[1] = info4[2] = info4[3] = 0;
+    if (g.tws == 4 && g.ths == 4 && g.tb == 1) return PHX_OK;                 // 16x16 tiles: LDS-DMA / FAST16 kernels
+    const int npatch = g.tb * ((1 << g.ths) + 2) * ((1 << g.tws) + 2);
+    const bool use_ws = workspace != nullptr && ntiles > wgrad_atomic_tiles();
+    if (use_ws)
+        PHX_REQUIRE(workspace_bytes >= phx_conv3x3_wgrad_ws_bytes(B, H, W, Cin, Cout), PHX_E_INVAL, "conv3x3_wgrad_multi_job: workspace too small");
+    WgMJob j;
+    j.x = (const unsigned short*)x; j.dy = (const unsigned short*)dy; j.dw = dw_hwio; j.ws = use_ws ? (float*)workspace : nullptr;
+    j.B = B; j.H = H; j.W = W; j.Cin = Cin; j.Cout = Cout; j.g = g; j.ntiles = ntiles; j.tpb = tpb;
+    j.gdx = gx; j.gdy = Cin / tci; j.gdz = Cout / tco; j.blk0 = blk0;
+    memcpy(job_out, &j, sizeof(j));
+    info4[0] = 1 + (tco == 64 ? 1 : 0) + (tci == 64 ? 2 : 0) + (npatch > 400 ? 4 : 0);
+    info4[1] = j.gdx * j.gdy * j.gdz;
+    info4[2] = npatch * tci * 2 + 256 * tco * 2;
+    info4[3] = use_ws;
+    return PHX_OK;
+}
+int phx_conv3x3_wgrad_multi(const void* jobs_dev, int njobs, int total_blocks, int variant, size_t lds_bytes, void* stream) {
+    PHX_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0 && variant >= 1 && variant <= 8, PHX_E_INVAL, "conv3x3_wgrad_multi: bad arguments");
+    static bool attr_set = false;
+#define WM_ATTR(A, Bq, C) PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_multi<A, Bq, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+    if (!attr_set) {
+        WM_ATTR(32, 32, false); WM_ATTR(32, 64, false); WM_ATTR(64, 32, false); WM_ATTR(64, 64, false);
+        WM_ATTR(32, 32, true); WM_ATTR(32, 64, true); WM_ATTR(64, 32, true); WM_ATTR(64, 64, true);
+        attr_set = true;
+    }
+#undef WM_ATTR
+#define WM_LAUNCH(A, Bq, C)                                                                                           \
+    hipLaunchKernelGGL((k_conv3x3_wgrad_multi<A, Bq, C>), dim3((unsigned)total_blocks), dim3(256), lds_bytes,          \
+                       (hipStream_t)stream, (const WgMJob*)jobs_dev, njobs)
+    switch (variant - 1) {
+        case 0: WM_LAUNCH(32, 32, false); break;
+        case 1: WM_LAUNCH(32, 64, false); break;
+        case 2: WM_LAUNCH(64, 32, false); break;
+        case 3: WM_LAUNCH(64, 64, false); break;
+        case 4: WM_LAUNCH(32, 32, true); break;
+        case 5: WM_LAUNCH(32, 64, true); break;
+        case 6: WM_LAUNCH(64, 32, true); break;
+        default: WM_LAUNCH(64, 64, true); break;
+    }
+#undef WM_LAUNCH
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
 int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes,
                                 int B, int H, int W, int Cin, int Cout, void* stream) {
     return wgrad_impl(x, dy, dw_hwio, workspace, workspace_bytes, B, H, W, Cin, Cout, true, stream);

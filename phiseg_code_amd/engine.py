@@ -27,6 +27,7 @@ F32, BF16, U8 = rt.F32, rt.BF16, 2
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, U8: torch.uint8}
 _NP_DT = {F32: np.float32, U8: np.uint8}
 _ESIZE = {F32: 4, BF16: 2, U8: 1}
+_WGRAD_DEFER_SMALL = os.environ.get("PHX_WGRAD_DEFER_SMALL", "1") == "1"   # small-map filter-gradient launches deferred too
 _WGRAD_MULTI = os.environ.get("PHX_WGRAD_MULTI", "1") == "1"   # one reduction launch for all layers' partial filter gradients
 _EARLY_TOUCH = os.environ.get("PHX_EARLY_TOUCH", "1") == "1"
 _STAMPS = os.environ.get("PHX_STAMPS", "0") == "1"
@@ -185,6 +186,7 @@ class Plan:
         self.feeds = {}
         self._keep = []
         self._wpk = {}
+        self._wgm_jobs = {}           # deferred small-map filter gradients by kernel variant: records, total blocks, LDS bytes
         self._headw_jobs = {}         # deferred 1x1-head filter gradients by (x dtype, nout): (x, dy, dw, db, npix, C, PL, chunk, grid, lds)
         self._wgr_jobs = []           # deferred filter-gradient reductions: (ws, dw, nslice, Cin, Cout, tci, tco, gx, gy)
         self._pack_jobs = []          # (w, wpk_fwd, wpk_dgrad, Cin, Cin_pad, Cout): ONE multi-filter pack launch per run
@@ -403,6 +405,11 @@ class Plan:
             for evl in tails:
                 self._wait(evl)
         self._lane = 0
+        for variant, grp in sorted(self._wgm_jobs.items()):
+            desc = torch.frombuffer(bytearray(b"".join(grp["recs"])), dtype=torch.uint8).to(_device())
+            self._keep.append(desc)
+            self._emit(self.L.conv3x3_wgrad_multi, desc.data_ptr(), len(grp["recs"]), grp["blocks"], variant, grp["lds"],
+                       self.stream)
         if self._wgr_jobs:
             rec = np.zeros(len(self._wgr_jobs), dtype=[("ws", "<u8"), ("dw", "<u8"), ("nslice", "<i4"), ("cin", "<i4"), ("cout", "<i4"),
                                                        ("tci", "<i4"), ("tco", "<i4"), ("gx", "<i4"), ("gy", "<i4"), ("blk0", "<i4")])
@@ -924,7 +931,25 @@ class Plan:
             wsp = self._alloc((wsb // 4,), F32)      # per-layer workspace of partial filters (no cross-lane sharing)
             plan6 = (ctypes.c_int * 6)()
             Lb.conv3x3_wgrad_reduce_plan(B, H, Wd, cin, cout, plan6)
-            if _WGRAD_MULTI and plan6[0]:
+            deferred = False
+            if _WGRAD_MULTI and _WGRAD_DEFER_SMALL:
+                # small maps (tiles narrower than 16 pixels): the filter-gradient launch itself is deferred -- one launch per
+                # kernel variant runs all such layers side by side after the lanes have joined (phx_conv3x3_wgrad_multi)
+                nb = int(Lb.conv3x3_wgrad_multi_job_bytes())
+                jb, info = ctypes.create_string_buffer(nb), (ctypes.c_int * 4)()
+                Lb.conv3x3_wgrad_multi_job(x.ptr, dY.ptr, dw, wsp.ptr, wsb, B, H, Wd, cin, cout, 0, jb, info)
+                if info[0]:
+                    grp = self._wgm_jobs.setdefault(int(info[0]), dict(recs=[], blocks=0, lds=0))
+                    Lb.conv3x3_wgrad_multi_job(x.ptr, dY.ptr, dw, wsp.ptr, wsb, B, H, Wd, cin, cout, grp["blocks"], jb, info)
+                    grp["recs"].append(jb.raw)
+                    grp["blocks"] += int(info[1])
+                    grp["lds"] = max(grp["lds"], int(info[2]))
+                    if info[3]:
+                        self._wgr_jobs.append((wsp.ptr, dw, plan6[1], cin, cout, plan6[2], plan6[3], plan6[4], plan6[5]))
+                    deferred = True
+            if deferred:
+                pass
+            elif _WGRAD_MULTI and plan6[0]:
                 # the sum over the partial filters is a leaf of the backward graph: deferred to ONE launch for all layers
                 # (phx_wgrad_reduce_multi, emitted after the lanes have joined)
                 self._emit(Lb.conv3x3_wgrad_mfma_bf16_partial, x.ptr, dY.ptr, dw, wsp.ptr, wsb, B, H, Wd, cin, cout, S,

@@ -754,3 +754,50 @@ def test_head1x1_wgrad_multi_matches_per_head_launches(L, nout):
     for k, (dw_ref, db_ref, dw, db) in enumerate(want):
         close(host(dw), host(dw_ref), 1e-5, "multi head wgrad, head %d" % k)
         close(host(db), host(db_ref), 1e-5, "multi head dbias, head %d" % k)
+
+
+def test_wgrad_deferred_small_map_launches(L):
+    """phx_conv3x3_wgrad_multi: the small-map filter gradients of several layers in one launch per kernel variant (+ the
+    deferred reduction for those that use a workspace) == the per-layer phx_conv3x3_wgrad_mfma_bf16 launches."""
+    import ctypes
+    shapes = [(64, 2, 2, 64, 64), (64, 4, 4, 64, 64), (16, 8, 8, 64, 64), (64, 8, 8, 64, 64), (9, 4, 4, 32, 96), (64, 2, 2, 96, 32),
+              (3, 8, 8, 32, 32), (2, 16, 16, 64, 64)]
+    nb = int(L.conv3x3_wgrad_multi_job_bytes())
+    groups, rjobs, keep, want = {}, [], [], []
+    for (B, H, W, K, N) in shapes:
+        x, dy = dev(RNG.standard_normal((B, H, W, K)), BF16), dev(RNG.standard_normal((B, H, W, N)), BF16)
+        wsb = int(L.conv3x3_wgrad_ws_bytes(B, H, W, K, N))
+        ws, ws2 = (torch.empty(max(wsb // 4, 1), dtype=torch.float32).cuda() for _ in range(2))
+        ref = torch.full((3, 3, K, N), 0.25, dtype=torch.float32).cuda()
+        L.conv3x3_wgrad_mfma_bf16(x.data_ptr(), dy.data_ptr(), ref.data_ptr(), ws.data_ptr(), wsb, B, H, W, K, N, S())
+        dw = torch.full((3, 3, K, N), 0.25, dtype=torch.float32).cuda()
+        jb, info = ctypes.create_string_buffer(nb), (ctypes.c_int * 4)()
+        L.conv3x3_wgrad_multi_job(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws2.data_ptr(), wsb, B, H, W, K, N, 0, jb, info)
+        keep.append((x, dy, ws, ws2))
+        if not info[0]:                                       # 16x16-tile shape: not deferrable, stays a per-layer launch
+            assert (H, W) == (16, 16)
+            continue
+        g = groups.setdefault(int(info[0]), dict(recs=[], blocks=0, lds=0))
+        L.conv3x3_wgrad_multi_job(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws2.data_ptr(), wsb, B, H, W, K, N, g["blocks"], jb, info)
+        g["recs"].append(jb.raw); g["blocks"] += info[1]; g["lds"] = max(g["lds"], info[2])
+        if info[3]:
+            plan = (ctypes.c_int * 6)()
+            L.conv3x3_wgrad_reduce_plan(B, H, W, K, N, plan)
+            rjobs.append((ws2.data_ptr(), dw.data_ptr(), plan[1], K, N, plan[2], plan[3], plan[4], plan[5]))
+        want.append((ref, dw))
+    assert len(groups) >= 3 and rjobs
+    for variant, g in groups.items():
+        desc = torch.frombuffer(bytearray(b"".join(g["recs"])), dtype=torch.uint8).cuda()
+        L.conv3x3_wgrad_multi(desc.data_ptr(), len(g["recs"]), g["blocks"], variant, g["lds"], S())
+        keep.append(desc)
+    rec = np.zeros(len(rjobs), dtype=[("ws", "<u8"), ("dw", "<u8"), ("nslice", "<i4"), ("cin", "<i4"), ("cout", "<i4"), ("tci", "<i4"),
+                                      ("tco", "<i4"), ("gx", "<i4"), ("gy", "<i4"), ("blk0", "<i4")])
+    blk = 0
+    for i, j in enumerate(rjobs):
+        rec[i] = j + (blk,)
+        blk += j[7] * j[8]
+    desc = torch.from_numpy(rec.view(np.uint8).copy()).cuda()
+    L.wgrad_reduce_multi(desc.data_ptr(), len(rjobs), blk, S())
+    torch.cuda.synchronize()
+    for k, (ref, dw) in enumerate(want):
+        close(host(dw), host(ref), 3e-6, "deferred small-map filter gradient, layer %d" % k)
