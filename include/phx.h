@@ -127,8 +127,9 @@ int phx_conv3x3_wgrad_mfma_bf16_partial(const void* x, const void* dy, float* dw
 int phx_wgrad_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, void* stream);
 /* Deferred small-map filter gradients (maps narrower than 16 pixels: a few tiles, 9-36 blocks, latency-bound, and leaves of
  * the backward graph): phx_conv3x3_wgrad_multi_job fills ONE job record of phx_conv3x3_wgrad_multi_job_bytes() bytes in HOST
- * memory for the launch phx_conv3x3_wgrad_mfma_bf16_partial would make; info4 = {variant (0: 16x16-tile shape, cannot be
- * deferred), blocks, dynamic LDS bytes, uses_workspace}.  The caller concatenates the records of one variant (blk0 = running
+ * memory for the launch phx_conv3x3_wgrad_mfma_bf16_partial would make; info4 = {variant (1-8 register-staged small-map
+ * kernels, 9-12 LDS-DMA kernels on 16x16 tiles with at most PHX_WGRAD_DEFER_TILES = 1024 tiles; 0: not deferred -- use the
+ * per-layer launch), blocks, dynamic LDS bytes, uses_workspace}.  The caller concatenates the records of one variant (blk0 = running
  * sum of blocks), copies them to the device and calls phx_conv3x3_wgrad_multi once (lds_bytes = max over the jobs). */
 int phx_conv3x3_wgrad_multi_job_bytes(void);
 int phx_conv3x3_wgrad_multi_job(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes, int B,

@@ -1566,10 +1566,10 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_multi(const WgMJob* __
 // 128-byte rows is applied on the SOURCE side (each lane fetches the piece that belongs in its slot); pieces outside the
 // image carry offset 0xffffffff and the buffer range check writes zeros for them.  Partial filters go to the workspace.
 template <int TCI, int TCO>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_dma(const unsigned short* __restrict__ x,
-                                                              const unsigned short* __restrict__ dy, float* __restrict__ ws,
-                                                              int B, int H, int W, int Cin, int Cout, MTile g, int ntiles,
-                                                              int tiles_per_block) {
+__device__ __forceinline__ void conv3x3_wgrad_dma_body(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
+                                                       float* __restrict__ ws, int B, int H, int W, int Cin, int Cout, MTile g,
+                                                       int ntiles, int tiles_per_block, const int bx, const int by, const int bz,
+                                                       const int gdx, const int gdy) {
     constexpr int WI = TCI / 32, WJ = TCO / 32, WK = 4 / (WI * WJ);
     constexpr int RBX = TCI * 2, RBD = TCO * 2;
     constexpr int QX = TCI / 8, QD = TCO / 8;                        // 16-byte pieces per pixel
@@ -1578,7 +1578,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_dma(const unsigned sho
     constexpr int XN = (XI + 3) / 4, DN = DI / 4;                    // per wave
     constexpr int SD_OFF = XI * 1024;                                // dy tile starts on the next 1 KiB boundary
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int ci0 = blockIdx.y * TCI, co0 = blockIdx.z * TCO;
+    const int ci0 = by * TCI, co0 = bz * TCO;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wi = wave % WI, wj = (wave / WI) % WJ, wk = wave / (WI * WJ);
     const int c16 = lane & 15, cb16 = (lane >> 4) & 1, khalf = lane >> 5;
@@ -1630,7 +1630,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_dma(const unsigned sho
     const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * H * W * Cout * 2u), 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-    const int t_begin = blockIdx.x * tiles_per_block;
+    const int t_begin = bx * tiles_per_block;
     const int t_end = min(ntiles, t_begin + tiles_per_block);
     PHX_BLOCKLOG_BEGIN();
     for (int t = t_begin; t < t_end; ++t) {
@@ -1710,8 +1710,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_dma(const unsigned sho
         steps(steps, std::integral_constant<int, 0>());
     }
     // partial tile -> workspace (see k_conv3x3_wgrad); C layout: col = lane&31 -> co, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> ci
-    const size_t cb = (size_t)blockIdx.z * gridDim.y + blockIdx.y;
-    float* wp = ws + ((cb * gridDim.x + blockIdx.x) * WK + wk) * (size_t)(9 * TCI * TCO);
+    const size_t cb = (size_t)bz * gdy + by;
+    float* wp = ws + ((cb * gdx + bx) * WK + wk) * (size_t)(9 * TCI * TCO);
 #pragma unroll
     for (int k = 0; k < 9; ++k)
 #pragma unroll
@@ -1720,6 +1720,28 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_dma(const unsigned sho
             wp[(k * TCI + cil) * TCO + wj * 32 + (lane & 31)] = acc[k][r];
         }
     PHX_BLOCKLOG_END();
+}
+
+template <int TCI, int TCO>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_dma(const unsigned short* __restrict__ x,
+                                                              const unsigned short* __restrict__ dy, float* __restrict__ ws,
+                                                              int B, int H, int W, int Cin, int Cout, MTile g, int ntiles,
+                                                              int tiles_per_block) {
+    conv3x3_wgrad_dma_body<TCI, TCO>(x, dy, ws, B, H, W, Cin, Cout, g, ntiles, tiles_per_block, blockIdx.x, blockIdx.y, blockIdx.z,
+                                     gridDim.x, gridDim.y);
+}
+// multi-layer form (see k_conv3x3_wgrad_multi): the 16x16-tile layers with few tiles (H = 16 at batch 64)
+template <int TCI, int TCO>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_dma_multi(const WgMJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const WgMJob j = jobs[lo];
+    const int local = blockIdx.x - j.blk0;
+    conv3x3_wgrad_dma_body<TCI, TCO>(j.x, j.dy, j.ws, j.B, j.H, j.W, j.Cin, j.Cout, j.g, j.ntiles, j.tpb, local % j.gdx,
+                                     (local / j.gdx) % j.gdy, local / (j.gdx * j.gdy), j.gdx, j.gdy);
 }
 
 // dw[k][ci][co] += sum over the nslice partial tiles written by the filter-gradient kernels.  A thread owns four
@@ -2142,7 +2164,15 @@ int phx_conv3x3_wgrad_multi_job(const void* x, const void* dy, float* dw_hwio, v
     MTile g; int tci, tco, gx, tpb, wk;
     const int ntiles = wgrad_plan(B, H, W, Cin, Cout, &g, &tci, &tco, &gx, &tpb, &wk);
     info4[0] = info4[1] = info4[2] = info4[3] = 0;
-    if (g.tws == 4 && g.ths == 4 && g.tb == 1) return PHX_OK;                 // 16x16 tiles: LDS-DMA / FAST16 kernels
+    const bool fast16 = g.tws == 4 && g.ths == 4 && g.tb == 1;
+    if (fast16) {
+        // 16x16 tiles: the LDS-DMA kernel with a workspace; measured: deferring up to 1024 tiles (H <= 64 at batch 64) helps,
+        // the 128x128 layers are as fast inline (their inputs are still in the Infinity Cache right after the backward
+        // normalisation pass)
+        static int dtl = -1;
+        if (dtl < 0) { const char* e = getenv("PHX_WGRAD_DEFER_TILES"); dtl = e ? atoi(e) : 1024; }
+        if (!workspace || ntiles > dtl || ntiles <= wgrad_atomic_tiles()) return PHX_OK;
+    }
     const int npatch = g.tb * ((1 << g.ths) + 2) * ((1 << g.tws) + 2);
     const bool use_ws = workspace != nullptr && ntiles > wgrad_atomic_tiles();
     if (use_ws)
@@ -2152,19 +2182,22 @@ int phx_conv3x3_wgrad_multi_job(const void* x, const void* dy, float* dw_hwio, v
     j.B = B; j.H = H; j.W = W; j.Cin = Cin; j.Cout = Cout; j.g = g; j.ntiles = ntiles; j.tpb = tpb;
     j.gdx = gx; j.gdy = Cin / tci; j.gdz = Cout / tco; j.blk0 = blk0;
     memcpy(job_out, &j, sizeof(j));
-    info4[0] = 1 + (tco == 64 ? 1 : 0) + (tci == 64 ? 2 : 0) + (npatch > 400 ? 4 : 0);
+    info4[0] = 1 + (tco == 64 ? 1 : 0) + (tci == 64 ? 2 : 0) + (fast16 ? 8 : npatch > 400 ? 4 : 0);     // 9..12: LDS-DMA kernels
     info4[1] = j.gdx * j.gdy * j.gdz;
-    info4[2] = npatch * tci * 2 + 256 * tco * 2;
+    info4[2] = fast16 ? ((324 * (tci / 8) + 63) / 64) * 1024 + 256 * tco * 2 : npatch * tci * 2 + 256 * tco * 2;
     info4[3] = use_ws;
     return PHX_OK;
 }
 int phx_conv3x3_wgrad_multi(const void* jobs_dev, int njobs, int total_blocks, int variant, size_t lds_bytes, void* stream) {
-    PHX_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0 && variant >= 1 && variant <= 8, PHX_E_INVAL, "conv3x3_wgrad_multi: bad arguments");
+    PHX_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0 && variant >= 1 && variant <= 12, PHX_E_INVAL, "conv3x3_wgrad_multi: bad arguments");
     static bool attr_set = false;
 #define WM_ATTR(A, Bq, C) PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_multi<A, Bq, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
     if (!attr_set) {
         WM_ATTR(32, 32, false); WM_ATTR(32, 64, false); WM_ATTR(64, 32, false); WM_ATTR(64, 64, false);
         WM_ATTR(32, 32, true); WM_ATTR(32, 64, true); WM_ATTR(64, 32, true); WM_ATTR(64, 64, true);
+#define WMD_ATTR(A, Bq) PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_dma_multi<A, Bq>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+        WMD_ATTR(32, 32); WMD_ATTR(32, 64); WMD_ATTR(64, 32); WMD_ATTR(64, 64);
+#undef WMD_ATTR
         attr_set = true;
     }
 #undef WM_ATTR
@@ -2179,7 +2212,15 @@ int phx_conv3x3_wgrad_multi(const void* jobs_dev, int njobs, int total_blocks, i
         case 4: WM_LAUNCH(32, 32, true); break;
         case 5: WM_LAUNCH(32, 64, true); break;
         case 6: WM_LAUNCH(64, 32, true); break;
-        default: WM_LAUNCH(64, 64, true); break;
+        case 7: WM_LAUNCH(64, 64, true); break;
+#define WMD_LAUNCH(A, Bq)                                                                                             \
+    hipLaunchKernelGGL((k_conv3x3_wgrad_dma_multi<A, Bq>), dim3((unsigned)total_blocks), dim3(256), lds_bytes,         \
+                       (hipStream_t)stream, (const WgMJob*)jobs_dev, njobs)
+        case 8: WMD_LAUNCH(32, 32); break;
+        case 9: WMD_LAUNCH(32, 64); break;
+        case 10: WMD_LAUNCH(64, 32); break;
+        default: WMD_LAUNCH(64, 64); break;
+#undef WMD_LAUNCH
     }
 #undef WM_LAUNCH
     PHX_CHECK_LAUNCH();

@@ -761,7 +761,7 @@ def test_wgrad_deferred_small_map_launches(L):
     deferred reduction for those that use a workspace) == the per-layer phx_conv3x3_wgrad_mfma_bf16 launches."""
     import ctypes
     shapes = [(64, 2, 2, 64, 64), (64, 4, 4, 64, 64), (16, 8, 8, 64, 64), (64, 8, 8, 64, 64), (9, 4, 4, 32, 96), (64, 2, 2, 96, 32),
-              (3, 8, 8, 32, 32), (2, 16, 16, 64, 64)]
+              (3, 8, 8, 32, 32), (2, 16, 16, 64, 64), (16, 16, 16, 64, 64), (40, 16, 16, 96, 64), (7, 16, 32, 32, 32)]
     nb = int(L.conv3x3_wgrad_multi_job_bytes())
     groups, rjobs, keep, want = {}, [], [], []
     for (B, H, W, K, N) in shapes:
@@ -774,8 +774,8 @@ def test_wgrad_deferred_small_map_launches(L):
         jb, info = ctypes.create_string_buffer(nb), (ctypes.c_int * 4)()
         L.conv3x3_wgrad_multi_job(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws2.data_ptr(), wsb, B, H, W, K, N, 0, jb, info)
         keep.append((x, dy, ws, ws2))
-        if not info[0]:                                       # 16x16-tile shape: not deferrable, stays a per-layer launch
-            assert (H, W) == (16, 16)
+        if not info[0]:                                       # a 16x16-tile shape with <= 4 tiles adds straight into dw: per-layer launch
+            assert (B, H, W) == (2, 16, 16)
             continue
         g = groups.setdefault(int(info[0]), dict(recs=[], blocks=0, lds=0))
         L.conv3x3_wgrad_multi_job(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws2.data_ptr(), wsb, B, H, W, K, N, g["blocks"], jb, info)
@@ -785,7 +785,7 @@ def test_wgrad_deferred_small_map_launches(L):
             L.conv3x3_wgrad_reduce_plan(B, H, W, K, N, plan)
             rjobs.append((ws2.data_ptr(), dw.data_ptr(), plan[1], K, N, plan[2], plan[3], plan[4], plan[5]))
         want.append((ref, dw))
-    assert len(groups) >= 3 and rjobs
+    assert len(groups) >= 5 and any(v > 8 for v in groups) and rjobs         # register-staged and LDS-DMA variants
     for variant, g in groups.items():
         desc = torch.frombuffer(bytearray(b"".join(g["recs"])), dtype=torch.uint8).cuda()
         L.conv3x3_wgrad_multi(desc.data_ptr(), len(g["recs"]), g["blocks"], variant, g["lds"], S())
