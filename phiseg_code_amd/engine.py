@@ -186,6 +186,7 @@ class Plan:
         self.feeds = {}
         self._keep = []
         self._wpk = {}
+        self._tail_jobs = []          # launches that follow the deferred ones on lane 0 (padded-filter folds)
         self._wgm_jobs = {}           # deferred small-map filter gradients by kernel variant: records, total blocks, LDS bytes
         self._headw_jobs = {}         # deferred 1x1-head filter gradients by (x dtype, nout): (x, dy, dw, db, npix, C, PL, chunk, grid, lds)
         self._wgr_jobs = []           # deferred filter-gradient reductions: (ws, dw, nslice, Cin, Cout, tci, tco, gx, gy)
@@ -420,6 +421,8 @@ class Plan:
             self._wgr_desc = torch.from_numpy(rec.view(np.uint8).copy()).to(_device())
             self._keep.append(self._wgr_desc)
             self._emit(self.L.wgrad_reduce_multi, self._wgr_desc.data_ptr(), len(self._wgr_jobs), blk, self.stream)
+        for fn, args in self._tail_jobs:
+            self._emit(fn, *args, self.stream)
         for (xdt, nout), jobs in self._headw_jobs.items():
             rec = np.zeros(len(jobs), dtype=[("x", "<u8"), ("dy", "<u8"), ("dw", "<u8"), ("db", "<u8"), ("npix", "<u8"), ("C", "<i4"),
                                              ("PL", "<i4"), ("chunk", "<i4"), ("blk0", "<i4")])
@@ -915,49 +918,52 @@ class Plan:
                                                                    plan4[2], plan4[3]))
         elif sv.get("head1x1"):
             self._emit(Lb.head1x1_wgrad, x.ptr, x.dt, dY.ptr, dw, db, B * H * Wd, cin, cout, S)
-        elif sv.get("padded"):
-            ce = sv["cin_eff"]
-            dwp = self._alloc_zeroed(9 * ce * cout)
+        elif sv.get("padded") or sv["mfma"]:
+            # padded layers (zero-padded input channels / 1x1 as centre tap): the gradient goes to a padded filter buffer
+            # first and a small kernel folds it into dw afterwards
+            padded = bool(sv.get("padded"))
+            ce = sv["cin_eff"] if padded else cin
+            tgt = self._alloc_zeroed(9 * ce * cout).ptr if padded else dw
             wsb = int(Lb.conv3x3_wgrad_ws_bytes(B, H, Wd, ce, cout))
-            wsp = self._alloc((wsb // 4,), F32)
-            self._emit(Lb.conv3x3_wgrad_mfma_bf16, x.ptr, dY.ptr, dwp.ptr, wsp.ptr, wsb, B, H, Wd, ce, cout, S,
-                       tag="conv3x3_mfma_wgrad", flops=18.0 * cin * cout * B * H * Wd)
-            self._emit(Lb.unpad_filter_grad_center if sv.get("k1") else Lb.unpad_filter_grad_accumulate, dwp.ptr, dw, cin, ce,
-                       cout, S)
-            if db is not None:
-                self._emit(Lb.channel_sum_accumulate, dY.ptr, dY.dt, db, B * H * Wd, cout, S)
-        elif sv["mfma"]:
-            wsb = int(Lb.conv3x3_wgrad_ws_bytes(B, H, Wd, cin, cout))
             wsp = self._alloc((wsb // 4,), F32)      # per-layer workspace of partial filters (no cross-lane sharing)
             plan6 = (ctypes.c_int * 6)()
-            Lb.conv3x3_wgrad_reduce_plan(B, H, Wd, cin, cout, plan6)
+            Lb.conv3x3_wgrad_reduce_plan(B, H, Wd, ce, cout, plan6)
+            rjob = (wsp.ptr, tgt, plan6[1], ce, cout, plan6[2], plan6[3], plan6[4], plan6[5])
+            wargs = (x.ptr, dY.ptr, tgt, wsp.ptr, wsb, B, H, Wd, ce, cout)
+            wflops = 18.0 * cin * cout * B * H * Wd
             deferred = False
             if _WGRAD_MULTI and _WGRAD_DEFER_SMALL:
-                # small maps (tiles narrower than 16 pixels): the filter-gradient launch itself is deferred -- one launch per
-                # kernel variant runs all such layers side by side after the lanes have joined (phx_conv3x3_wgrad_multi)
+                # The filter gradients are leaves of the backward graph.  Small and mid-size maps: the launch itself is
+                # deferred -- one launch per kernel variant runs all such layers side by side after the lanes have joined
+                # (phx_conv3x3_wgrad_multi); their latency leaves the posterior / prior / likelihood chains.
                 nb = int(Lb.conv3x3_wgrad_multi_job_bytes())
                 jb, info = ctypes.create_string_buffer(nb), (ctypes.c_int * 4)()
-                Lb.conv3x3_wgrad_multi_job(x.ptr, dY.ptr, dw, wsp.ptr, wsb, B, H, Wd, cin, cout, 0, jb, info)
+                Lb.conv3x3_wgrad_multi_job(*wargs, 0, jb, info)
                 if info[0]:
                     grp = self._wgm_jobs.setdefault(int(info[0]), dict(recs=[], blocks=0, lds=0))
-                    Lb.conv3x3_wgrad_multi_job(x.ptr, dY.ptr, dw, wsp.ptr, wsb, B, H, Wd, cin, cout, grp["blocks"], jb, info)
+                    Lb.conv3x3_wgrad_multi_job(*wargs, grp["blocks"], jb, info)
                     grp["recs"].append(jb.raw)
                     grp["blocks"] += int(info[1])
                     grp["lds"] = max(grp["lds"], int(info[2]))
                     if info[3]:
-                        self._wgr_jobs.append((wsp.ptr, dw, plan6[1], cin, cout, plan6[2], plan6[3], plan6[4], plan6[5]))
+                        self._wgr_jobs.append(rjob)
                     deferred = True
             if deferred:
                 pass
             elif _WGRAD_MULTI and plan6[0]:
-                # the sum over the partial filters is a leaf of the backward graph: deferred to ONE launch for all layers
-                # (phx_wgrad_reduce_multi, emitted after the lanes have joined)
-                self._emit(Lb.conv3x3_wgrad_mfma_bf16_partial, x.ptr, dY.ptr, dw, wsp.ptr, wsb, B, H, Wd, cin, cout, S,
-                           tag="conv3x3_mfma_wgrad", flops=18.0 * cin * cout * B * H * Wd)
-                self._wgr_jobs.append((wsp.ptr, dw, plan6[1], cin, cout, plan6[2], plan6[3], plan6[4], plan6[5]))
+                # large maps: the launch stays here, only the sum over its partial filters is deferred to ONE launch for all
+                # layers (phx_wgrad_reduce_multi)
+                self._emit(Lb.conv3x3_wgrad_mfma_bf16_partial, *wargs, S, tag="conv3x3_mfma_wgrad", flops=wflops)
+                self._wgr_jobs.append(rjob)
+                deferred = True
             else:
-                self._emit(Lb.conv3x3_wgrad_mfma_bf16, x.ptr, dY.ptr, dw, wsp.ptr, wsb, B, H, Wd, cin, cout, S,
-                           tag="conv3x3_mfma_wgrad", flops=18.0 * cin * cout * B * H * Wd)
+                self._emit(Lb.conv3x3_wgrad_mfma_bf16, *wargs, S, tag="conv3x3_mfma_wgrad", flops=wflops)
+            if padded:
+                unpad = (Lb.unpad_filter_grad_center if sv.get("k1") else Lb.unpad_filter_grad_accumulate, (tgt, dw, cin, ce, cout))
+                if deferred:
+                    self._tail_jobs.append(unpad)             # after the deferred launches, on lane 0
+                else:
+                    self._emit(unpad[0], *unpad[1], S)
             if db is not None:
                 self._emit(Lb.channel_sum_accumulate, dY.ptr, dY.dt, db, B * H * Wd, cout, S)
         else:
