@@ -42,6 +42,28 @@ def forked(token):
         chain(A, s0, N); chain(B_, s1, N - (1 if token else 0))
         L.event_record(ej, s1); L.stream_wait_event(s0, ej)
     return body
+def late_dep():
+    # second chain: first half independent, second half waits for the END of the first chain (the prior's latent levels
+    # wait for the posterior's samples); ideal: N launches + N/2, serialised: 2N
+    ef, em, ej = new_event(), new_event(), new_event()
+    L.event_record(ef, s0); L.stream_wait_event(s1, ef)
+    chain(A, s0, N); chain(B_, s1, N // 2)
+    L.event_record(em, s0); L.stream_wait_event(s1, em)
+    chain(B_, s1, N - N // 2)
+    L.event_record(ej, s1); L.stream_wait_event(s0, ej)
+def mid_dep():          # event recorded in the MIDDLE of the origin chain; both streams have work before and after
+    ef, em, ej = new_event(), new_event(), new_event()
+    L.event_record(ef, s0); L.stream_wait_event(s1, ef)
+    chain(A, s0, N // 2); chain(B_, s1, N // 2)
+    L.event_record(em, s0); L.stream_wait_event(s1, em)
+    chain(A, s0, N - N // 2); chain(B_, s1, N - N // 2)
+    L.event_record(ej, s1); L.stream_wait_event(s0, ej)
+def serial_two_streams():   # the second stream only starts after the first chain: nothing can overlap
+    ef, ej = new_event(), new_event()
+    chain(A, s0, N)
+    L.event_record(ef, s0); L.stream_wait_event(s1, ef)
+    chain(B_, s1, N)
+    L.event_record(ej, s1); L.stream_wait_event(s0, ej)
 def one(): chain(A, s0, N)
 _tb = torch.zeros(8, dtype=torch.int64, device="cuda")
 def stamps():
@@ -50,4 +72,7 @@ print("chain of %d 1-thread launches:    %8.1f us  (pure per-node cost)" % (N, t
 print("one chain of %d launches:        %8.1f us" % (N, timeit(capture(one))))
 print("two chains, one stream:          %8.1f us" % timeit(capture(serial)))
 print("two chains, two streams:         %8.1f us" % timeit(capture(forked(False))))
+print("two streams, 2nd waits mid-way:  %8.1f us  (ideal 1.5 chains)" % timeit(capture(late_dep)))
+print("two streams, event mid-chain:    %8.1f us  (ideal 1 chain)" % timeit(capture(mid_dep)))
+print("second stream after the first:   %8.1f us  (ideal 2 chains)" % timeit(capture(serial_two_streams)))
 print("two chains, two streams + token: %8.1f us" % timeit(capture(forked(True))))
