@@ -27,6 +27,7 @@ F32, BF16, U8 = rt.F32, rt.BF16, 2
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, U8: torch.uint8}
 _NP_DT = {F32: np.float32, U8: np.uint8}
 _ESIZE = {F32: 4, BF16: 2, U8: 1}
+_LIK_SIDE = os.environ.get("PHX_LIK_SIDE", "1") == "1"        # two lanes: the likelihood's per-level chains share the prior's lane
 _WGRAD_DEFER_SMALL = os.environ.get("PHX_WGRAD_DEFER_SMALL", "1") == "1"   # small-map filter-gradient launches deferred too
 _WGRAD_MULTI = os.environ.get("PHX_WGRAD_MULTI", "1") == "1"   # one reduction launch for all layers' partial filter gradients
 _EARLY_TOUCH = os.environ.get("PHX_EARLY_TOUCH", "1") == "1"
@@ -308,11 +309,11 @@ class Plan:
         name = op.name
         if name.startswith("prior/"):
             return 1
-        if n >= 3 and name.startswith("likelihood/"):
+        if (n >= 3 or _LIK_SIDE) and name.startswith("likelihood/"):
             import re
             m = re.match(r"likelihood/(?:z(\d+)_post_|preups_(\d+)/)", name)
             if m:
-                return 2 + int(m.group(1) or m.group(2)) % (n - 2)
+                return 1 if n == 2 else 2 + int(m.group(1) or m.group(2)) % (n - 2)
         return 0
 
     # ---------------------------------------------------------------------------------------------
