@@ -1901,7 +1901,7 @@ static int fwd_ksplit(int B, int H, int W, int K, int N) {
     const int blocks = g.tiles_x * g.tiles_y * g.tiles_b * (N / (N % 64 == 0 ? 64 : 32));
     const int nck = K / KC;
     static int tgt = 0;
-    if (!tgt) { const char* t = getenv("PHX_FWD_SPLITK_BLOCKS"); tgt = t ? atoi(t) : 128; }    // tuning hook
+    if (!tgt) { const char* t = getenv("PHX_FWD_SPLITK_BLOCKS"); tgt = t ? atoi(t) : 64; }     // tuning hook (re-measured under the two-lane schedule: 32-96 equal, 128+ 0.6 % slower)
     if (blocks * 2 > tgt || nck < 2) return 1;
     int ks = (tgt + blocks - 1) / blocks;
     if (ks > nck) ks = nck;
