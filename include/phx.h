@@ -127,13 +127,15 @@ int phx_conv3x3_wgrad_mfma_bf16_partial(const void* x, const void* dy, float* dw
 int phx_wgrad_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, void* stream);
 /* Deferred small-map filter gradients (maps narrower than 16 pixels: a few tiles, 9-36 blocks, latency-bound, and leaves of
  * the backward graph): phx_conv3x3_wgrad_multi_job fills ONE job record of phx_conv3x3_wgrad_multi_job_bytes() bytes in HOST
- * memory for the launch phx_conv3x3_wgrad_mfma_bf16_partial would make; info4 = {variant (1-8 register-staged small-map
+ * memory for the launch phx_conv3x3_wgrad_mfma_bf16_partial would make; info9 = {variant (1-8 register-staged small-map
  * kernels, 9-12 LDS-DMA kernels on 16x16 tiles with at most PHX_WGRAD_DEFER_TILES = 1024 tiles; 0: not deferred -- use the
- * per-layer launch), blocks, dynamic LDS bytes, uses_workspace}.  The caller concatenates the records of one variant (blk0 = running
+ * per-layer launch), blocks, dynamic LDS bytes, uses_workspace, nslice, tci, tco, reduce grid x, reduce grid y} (9 ints;
+ * the last five describe this launch's phx_wgrad_reduce_multi job).  blocks_target > 0 overrides the pixel-tile split of this job:
+ * inside a multi-layer launch a layer needs far fewer partial filters than alone.  The caller concatenates the records of one variant (blk0 = running
  * sum of blocks), copies them to the device and calls phx_conv3x3_wgrad_multi once (lds_bytes = max over the jobs). */
 int phx_conv3x3_wgrad_multi_job_bytes(void);
 int phx_conv3x3_wgrad_multi_job(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes, int B,
-                                int H, int W, int Cin, int Cout, int blk0, void* job_out, int* info4);
+                                int H, int W, int Cin, int Cout, int blocks_target, int blk0, void* job_out, int* info9);
 int phx_conv3x3_wgrad_multi(const void* jobs_dev, int njobs, int total_blocks, int variant, size_t lds_bytes, void* stream);
 int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes,
                                 int B, int H, int W, int Cin, int Cout, void* stream);

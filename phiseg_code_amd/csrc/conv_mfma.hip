@@ -2094,7 +2094,8 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
     return PHX_OK;
 }
 
-static int wgrad_plan(int B, int H, int W, int Cin, int Cout, MTile* g, int* tci, int* tco, int* gx, int* tpb, int* wk) {
+static int wgrad_plan(int B, int H, int W, int Cin, int Cout, MTile* g, int* tci, int* tco, int* gx, int* tpb, int* wk,
+                      int target_override = 0) {
     *g = make_mtile(B, H, W);
     const int ntiles = g->tiles_x * g->tiles_y * g->tiles_b;
     *tci = Cin % 64 == 0 ? 64 : 32;
@@ -2107,6 +2108,7 @@ static int wgrad_plan(int B, int H, int W, int Cin, int Cout, MTile* g, int* tci
     int target_blocks = cblocks <= 4 && *tci == 64 && *tco == 64 ? 512 : 384;
     if (ntiles <= 256 && target_blocks > 256) target_blocks = 256;
     if (const char* e = getenv("PHX_WGRAD_BLOCKS")) target_blocks = atoi(e);      // tuning hook
+    if (target_override > 0) target_blocks = target_override;                     // deferred multi-layer launches (see below)
     int split = (target_blocks + cblocks - 1) / cblocks;
     if (split > ntiles) split = ntiles;
     if (split < 1) split = 1;
@@ -2154,16 +2156,17 @@ static int wgrad_impl(const void* x, const void* dy, float* dw_hwio, void* works
                       int W, int Cin, int Cout, bool reduce, void* stream);
 /* Deferred small-map filter gradients (see k_conv3x3_wgrad_multi).  phx_conv3x3_wgrad_multi_job fills ONE job record of
  * phx_conv3x3_wgrad_multi_job_bytes() bytes in HOST memory for the launch phx_conv3x3_wgrad_mfma_bf16_partial would make;
- * info4 = {variant (0: this shape runs on the 16x16-tile kernels and cannot be deferred), blocks, dynamic LDS bytes,
- * uses_workspace}.  The caller concatenates the records of one variant (blk0 = running sum of blocks), copies them to the
+ * info = {variant (0: not deferred), blocks, dynamic LDS bytes, uses_workspace, nslice, tci, tco, reduce grid x, y} (9 ints).  The caller concatenates the records of one variant (blk0 = running sum of blocks), copies them to the
  * device and calls phx_conv3x3_wgrad_multi once. */
 int phx_conv3x3_wgrad_multi_job_bytes(void) { return (int)sizeof(WgMJob); }
 int phx_conv3x3_wgrad_multi_job(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes, int B,
-                                int H, int W, int Cin, int Cout, int blk0, void* job_out, int* info4) {
+                                int H, int W, int Cin, int Cout, int blocks_target, int blk0, void* job_out, int* info4) {
     PHX_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, PHX_E_SHAPE, "conv3x3_wgrad_multi_job: Cin % 32 == 0 and Cout % 32 == 0 required");
     MTile g; int tci, tco, gx, tpb, wk;
-    const int ntiles = wgrad_plan(B, H, W, Cin, Cout, &g, &tci, &tco, &gx, &tpb, &wk);
-    info4[0] = info4[1] = info4[2] = info4[3] = 0;
+    // blocks_target > 0: pixel-tile split of THIS job (a multi-layer launch has thousands of blocks in all, so a layer needs far
+    // fewer partial filters than when it runs alone -- less workspace traffic for the launch and for the reduction)
+    const int ntiles = wgrad_plan(B, H, W, Cin, Cout, &g, &tci, &tco, &gx, &tpb, &wk, blocks_target);
+    for (int i = 0; i < 9; ++i) info4[i] = 0;
     const bool fast16 = g.tws == 4 && g.ths == 4 && g.tb == 1;
     if (fast16) {
         // 16x16 tiles: the LDS-DMA kernel with a workspace; measured: deferring up to 1024 tiles (H <= 64 at batch 64) helps,
@@ -2186,6 +2189,8 @@ int phx_conv3x3_wgrad_multi_job(const void* x, const void* dy, float* dw_hwio, v
     info4[1] = j.gdx * j.gdy * j.gdz;
     info4[2] = fast16 ? ((324 * (tci / 8) + 63) / 64) * 1024 + 256 * tco * 2 : npatch * tci * 2 + 256 * tco * 2;
     info4[3] = use_ws;
+    info4[4] = gx * wk; info4[5] = tci; info4[6] = tco;                       // reduction job of this launch (phx_wgrad_reduce_multi)
+    wgrad_reduce_geometry(Cin, Cout, gx * wk, &info4[7], &info4[8]);
     return PHX_OK;
 }
 int phx_conv3x3_wgrad_multi(const void* jobs_dev, int njobs, int total_blocks, int variant, size_t lds_bytes, void* stream) {

@@ -28,6 +28,7 @@ _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, U8: torch.uint8}
 _NP_DT = {F32: np.float32, U8: np.uint8}
 _ESIZE = {F32: 4, BF16: 2, U8: 1}
 _LIK_SIDE = os.environ.get("PHX_LIK_SIDE", "1") == "1"        # two lanes: the likelihood's per-level chains share the prior's lane
+_WGRAD_DEFER_BLOCKS = int(os.environ.get("PHX_WGRAD_DEFER_BLOCKS", "96"))  # pixel-tile split target of a deferred layer (0: as when it runs alone; measured 48..128)
 _WGRAD_DEFER_SMALL = os.environ.get("PHX_WGRAD_DEFER_SMALL", "1") == "1"   # small-map filter-gradient launches deferred too
 _WGRAD_MULTI = os.environ.get("PHX_WGRAD_MULTI", "1") == "1"   # one reduction launch for all layers' partial filter gradients
 _EARLY_TOUCH = os.environ.get("PHX_EARLY_TOUCH", "1") == "1"
@@ -946,16 +947,16 @@ class Plan:
                 # deferred -- one launch per kernel variant runs all such layers side by side after the lanes have joined
                 # (phx_conv3x3_wgrad_multi); their latency leaves the posterior / prior / likelihood chains.
                 nb = int(Lb.conv3x3_wgrad_multi_job_bytes())
-                jb, info = ctypes.create_string_buffer(nb), (ctypes.c_int * 4)()
-                Lb.conv3x3_wgrad_multi_job(*wargs, 0, jb, info)
+                jb, info = ctypes.create_string_buffer(nb), (ctypes.c_int * 9)()
+                Lb.conv3x3_wgrad_multi_job(*wargs, _WGRAD_DEFER_BLOCKS, 0, jb, info)
                 if info[0]:
                     grp = self._wgm_jobs.setdefault(int(info[0]), dict(recs=[], blocks=0, lds=0))
-                    Lb.conv3x3_wgrad_multi_job(*wargs, grp["blocks"], jb, info)
+                    Lb.conv3x3_wgrad_multi_job(*wargs, _WGRAD_DEFER_BLOCKS, grp["blocks"], jb, info)
                     grp["recs"].append(jb.raw)
                     grp["blocks"] += int(info[1])
                     grp["lds"] = max(grp["lds"], int(info[2]))
                     if info[3]:
-                        self._wgr_jobs.append(rjob)
+                        self._wgr_jobs.append((wsp.ptr, tgt, info[4], ce, cout, info[5], info[6], info[7], info[8]))
                     deferred = True
             if deferred:
                 pass

@@ -771,19 +771,18 @@ def test_wgrad_deferred_small_map_launches(L):
         ref = torch.full((3, 3, K, N), 0.25, dtype=torch.float32).cuda()
         L.conv3x3_wgrad_mfma_bf16(x.data_ptr(), dy.data_ptr(), ref.data_ptr(), ws.data_ptr(), wsb, B, H, W, K, N, S())
         dw = torch.full((3, 3, K, N), 0.25, dtype=torch.float32).cuda()
-        jb, info = ctypes.create_string_buffer(nb), (ctypes.c_int * 4)()
-        L.conv3x3_wgrad_multi_job(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws2.data_ptr(), wsb, B, H, W, K, N, 0, jb, info)
+        jb, info = ctypes.create_string_buffer(nb), (ctypes.c_int * 9)()
+        tgt = (0, 24, 96)[len(keep) % 3]                     # this job's own pixel-tile split (0: the stand-alone plan)
+        L.conv3x3_wgrad_multi_job(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws2.data_ptr(), wsb, B, H, W, K, N, tgt, 0, jb, info)
         keep.append((x, dy, ws, ws2))
         if not info[0]:                                       # a 16x16-tile shape with <= 4 tiles adds straight into dw: per-layer launch
             assert (B, H, W) == (2, 16, 16)
             continue
         g = groups.setdefault(int(info[0]), dict(recs=[], blocks=0, lds=0))
-        L.conv3x3_wgrad_multi_job(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws2.data_ptr(), wsb, B, H, W, K, N, g["blocks"], jb, info)
+        L.conv3x3_wgrad_multi_job(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws2.data_ptr(), wsb, B, H, W, K, N, tgt, g["blocks"], jb, info)
         g["recs"].append(jb.raw); g["blocks"] += info[1]; g["lds"] = max(g["lds"], info[2])
         if info[3]:
-            plan = (ctypes.c_int * 6)()
-            L.conv3x3_wgrad_reduce_plan(B, H, W, K, N, plan)
-            rjobs.append((ws2.data_ptr(), dw.data_ptr(), plan[1], K, N, plan[2], plan[3], plan[4], plan[5]))
+            rjobs.append((ws2.data_ptr(), dw.data_ptr(), info[4], K, N, info[5], info[6], info[7], info[8]))
         want.append((ref, dw))
     assert len(groups) >= 5 and any(v > 8 for v in groups) and rjobs         # register-staged and LDS-DMA variants
     for variant, g in groups.items():
