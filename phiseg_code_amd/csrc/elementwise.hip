@@ -323,7 +323,9 @@ static int norm_geometry(int P, int C, int V, int* PL, int* threads, int* chunk,
     *PL = 256 / CV;
     *threads = CV * (*PL);
     int rows = (P + *PL - 1) / (*PL);
-    int want = (rows + 15) / 16;                              // 16 pixels per thread on big maps, >= ~512 blocks on small ones
+    static int ppt_n = 0;
+    if (!ppt_n) { const char* e = getenv("PHX_NORM_PPT"); ppt_n = e ? atoi(e) : 8; }     // tuning hook: pixels per thread
+    int want = (rows + ppt_n - 1) / ppt_n;                    // 8 pixels per thread on big maps (re-measured under the two-lane schedule)
     static int fl = 0;
     if (!fl) { const char* e = getenv("PHX_NORM_FLOOR"); fl = e ? atoi(e) : 128; }      // tuning hook (measured: tools/bench_norm.py)
     int floor_blocks = rows < fl ? rows : fl;
@@ -347,7 +349,9 @@ static int stream_geometry(int P, int C, int V, int* PL, int* threads, int* chun
     // 16 pixels per thread on big maps; on small maps fewer, so that >= ~1024 blocks exist (the kernels are latency-bound
     // there: a thread's iterations are serially dependent loads)
     int rows = (P + *PL - 1) / (*PL);
-    int want = (rows + 15) / 16;
+    static int ppt_s = 0;
+    if (!ppt_s) { const char* e = getenv("PHX_STREAM_PPT"); ppt_s = e ? atoi(e) : 32; }  // tuning hook: pixels per thread
+    int want = (rows + ppt_s - 1) / ppt_s;
     static int fl = 0;
     if (!fl) { const char* e = getenv("PHX_STREAM_FLOOR"); fl = e ? atoi(e) : 256; }    // tuning hook (measured: tools/bench_norm.py)
     int floor_blocks = rows < fl ? rows : fl;
