@@ -331,7 +331,7 @@ static int norm_geometry(int P, int C, int V, int* PL, int* threads, int* chunk,
     int floor_blocks = rows < fl ? rows : fl;
     if (want < floor_blocks) want = floor_blocks;
     static int capv = 0;
-    if (!capv) { const char* e = getenv("PHX_NORM_CAP"); capv = e ? atoi(e) : 2048; }    // tuning hook
+    if (!capv) { const char* e = getenv("PHX_NORM_CAP"); capv = e ? atoi(e) : 1024; }    // tuning hook
     int cap = (nrep > 1 ? capv : 2048) / (NS > 0 ? NS : 1);   // every block ends in 2C same-address atomics (see k_norm_bwd_reduce)
     if (cap < 1) cap = 1;
     if (want > cap) want = cap;
