@@ -214,9 +214,18 @@ def main():
         out["cpu_baseline"] = cpu_baseline()
     if ctx.rank == 0:
         out["config"]["hbm_peak_allocated_gb"] = torch.cuda.max_memory_allocated() / 2 ** 30
-        print(json.dumps(out))
     ctx.barrier()              # the other ranks wait for rank 0's extra measurements before tearing RCCL down
     ctx.shutdown()
+    if ctx.rank == 0:
+        # RCCL writes its version banner through C stdio; when stdout is a pipe it sits in libc's buffer until exit and would
+        # land AFTER the result.  Flush it first so that the JSON line is the last line of rank 0's stdout.
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
