@@ -800,3 +800,30 @@ def test_wgrad_deferred_small_map_launches(L):
     torch.cuda.synchronize()
     for k, (ref, dw) in enumerate(want):
         close(host(dw), host(ref), 3e-6, "deferred small-map filter gradient, layer %d" % k)
+
+
+def test_abi_rejects_bad_arguments_loudly(L):
+    """Invalid shapes / arguments come back as PhxError with the library's message -- nothing is launched, nothing falls back."""
+    from phiseg_code_amd.runtime import PhxError
+    x = torch.zeros(2 * 16 * 16 * 64, dtype=torch.bfloat16).cuda()
+    y = torch.zeros(2 * 16 * 16 * 64, dtype=torch.bfloat16).cuda()
+    w = torch.zeros(9 * 64 * 64, dtype=torch.bfloat16).cuda()
+    f = torch.zeros(9 * 64 * 64, dtype=torch.float32).cuda()
+    with pytest.raises(PhxError, match="K % 32"):
+        L.conv3x3_mfma_bf16(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, 0, None, 2, 16, 16, 48, 64, S())
+    with pytest.raises(PhxError, match="y == NULL"):
+        L.conv3x3_mfma_bf16(x.data_ptr(), w.data_ptr(), None, None, 0, None, 2, 16, 16, 64, 64, S())
+    with pytest.raises(PhxError, match="workspace too small"):
+        L.conv3x3_wgrad_mfma_bf16(x.data_ptr(), y.data_ptr(), f.data_ptr(), f.data_ptr(), 16, 2, 16, 16, 64, 64, S())
+    with pytest.raises(PhxError, match="ksize"):
+        L.conv2d_direct(x.data_ptr(), BF16, f.data_ptr(), None, y.data_ptr(), BF16, 2, 16, 16, 64, 64, 2, 0, 0, None, S())
+    with pytest.raises(PhxError, match="bad shape"):
+        L.conv2d_direct(x.data_ptr(), BF16, f.data_ptr(), None, y.data_ptr(), BF16, 0, 16, 16, 64, 64, 3, 0, 0, None, S())
+    with pytest.raises(PhxError, match="nout"):
+        L.head1x1_wgrad(x.data_ptr(), BF16, f.data_ptr(), f.data_ptr(), f.data_ptr(), 512, 64, 3, S())
+    with pytest.raises(PhxError, match="P <= 4096"):
+        L.bn_small_fwd(x.data_ptr(), f.data_ptr(), f.data_ptr(), 1e-3, y.data_ptr(), f.data_ptr(), f.data_ptr(), f.data_ptr(), f.data_ptr(),
+                       None, None, 0.0, 5000, 64, 1, S())
+    with pytest.raises(PhxError, match="empty job list"):
+        L.wgrad_reduce_multi(None, 0, 0, S())
+    torch.cuda.synchronize()
