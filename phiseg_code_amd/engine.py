@@ -29,6 +29,8 @@ _NP_DT = {F32: np.float32, U8: np.uint8}
 _ESIZE = {F32: 4, BF16: 2, U8: 1}
 _LIK_SIDE = os.environ.get("PHX_LIK_SIDE", "1") == "1"        # two lanes: the likelihood's per-level chains share the prior's lane
 _WGRAD_DEFER_BLOCKS = int(os.environ.get("PHX_WGRAD_DEFER_BLOCKS", "96"))  # pixel-tile split target of a deferred layer (0: as when it runs alone; measured 48..128)
+_NREP = int(os.environ.get("PHX_NREP", "8"))
+_NREP_MINP = int(os.environ.get("PHX_NREP_MINP", "4096"))
 _WGRAD_DEFER_SMALL = os.environ.get("PHX_WGRAD_DEFER_SMALL", "1") == "1"   # small-map filter-gradient launches deferred too
 _WGRAD_MULTI = os.environ.get("PHX_WGRAD_MULTI", "1") == "1"   # one reduction launch for all layers' partial filter gradients
 _EARLY_TOUCH = os.environ.get("PHX_EARLY_TOUCH", "1") == "1"
@@ -893,7 +895,7 @@ class Plan:
                            self.store.grad_ptr(nv["beta"]), P, cout, act, S,
                            tag="bytes_norm_bwd_apply", flops=float(dA.nbytes + y.nbytes + dY.nbytes))
             else:
-                nrep = 8 if P >= 4096 else 1           # replicated accumulators: see k_norm_bwd_reduce
+                nrep = _NREP if P >= _NREP_MINP else 1   # replicated accumulators: see k_norm_bwd_reduce
                 fused = self._bws.pop(op, None)        # the consumer's data-gradient launch already produced the sums
                 if fused is not None:
                     nrep = 1
