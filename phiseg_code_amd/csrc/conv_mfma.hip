@@ -94,12 +94,19 @@ static int fwd_rs_bn(int B, int H, int W, int K, int N) {
     if (en == 3) return 64;
     return (N % 128 == 0 && (long)B * (H / 16) * (W / 32) >= 512) ? 128 : 0;
 }
-// wave-specialised 32 x 16-tile x 64-channel kernel (k_conv3x3_fwd_ws64)
+// 32 x 16-pixel tiles x 64 channels, LDS-DMA staged (PHX_FWD_WS selects the kernel):
+//   unset / 1: policy -- k_conv3x3_fwd_dma128 (128-pixel wave tiles, one 75 KiB stage per block, two blocks per CU) when the map
+//              has at least 512 such blocks (the 128x128 and 64x64 levels at batch 64): measured 1.1-1.3x the 256-pixel kernels
+//              there, equal on 32x32 maps
+//   0: never;  5: dma128 whenever the shape is eligible (tests);  2 / 3 / 4: the wave-specialised experiments (ws64, ws128)
+static int fwd_ws_mode() {
+    const char* e = getenv("PHX_FWD_WS");
+    return e ? atoi(e) : 1;
+}
 static bool fwd_ws64(int B, int H, int W, int K, int N) {
-    const char* e = getenv("PHX_FWD_WS");                      // 0: never; 1: policy; 2: whenever eligible (tests / tuning)
-    const int en = e ? atoi(e) : 0;
+    const int en = fwd_ws_mode();
     if (!en || H % 16 != 0 || W % 32 != 0 || N % 64 != 0 || K % 32 != 0) return false;
-    if (en == 2) return true;
+    if (en >= 2) return true;
     return (long)B * (H / 16) * (W / 32) * (N / 64) >= 512;
 }
 static MTile make_mtile_fwd(int B, int H, int W, int K, int N, bool allow_dma = true) {
@@ -217,6 +224,12 @@ __global__ void k_unpad_rows_acc(const float* __restrict__ dwp, float* __restric
         dw[i] += dwp[((size_t)t * Cpad + ci) * Cout + co];
     }
 }
+
+// ping-pong persistent kernel for large maps (conv_pp.hip)
+bool phx_pp_eligible(int B, int H, int W, int K, int N);
+int phx_pp_partial_rows(int B, int H, int W);
+int phx_pp_launch(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial, int B, int H,
+                  int W, int K, int N, void* stream);
 
 // ---- forward / dgrad ----------------------------------------------------------------------------------
 __device__ unsigned long long* g_phx_trace = nullptr;      // debug: phase timestamps of block (0,0,0), thread 0
@@ -1229,6 +1242,434 @@ __global__ __launch_bounds__(640, 1) void k_conv3x3_fwd_ws64(const unsigned shor
     PHX_BLOCKLOG_END();
 }
 
+// ---- forward / data-gradient, 32x16-pixel tiles x 64 channels, wave-specialised, 128-pixel wave tiles --------------------
+// Same staging engine as k_conv3x3_fwd_ws64 (two loader waves, LDS-DMA, two 75 KiB stages), but FOUR MFMA waves that own
+// four tile rows (4 x 32 pixels) x 64 channels each.  An MFMA's 32 pixels are one tile row, so the A fragment of (row r,
+// tap row kh) is the patch row r + kh: a wave's four rows need only six patch rows per (kw, k-step) instead of twelve
+// fragment reads, and every filter fragment feeds four MFMAs instead of two -- 12 ds_read_b128 per 24 MFMAs (0.5 KiB of LDS
+// reads per MFMA against 1 KiB in the 64-pixel wave tiles, whose LDS traffic is what their MFMA rate is bounded by).
+template <bool BIASACT, int NLW>
+__global__ __launch_bounds__(256 + 64 * NLW, 1) void k_conv3x3_fwd_ws128(const unsigned short* __restrict__ x,
+                                                             const unsigned short* __restrict__ wpk,
+                                                             unsigned short* __restrict__ y, const float* __restrict__ bias,
+                                                             int act, float* __restrict__ stats_partial,
+                                                             int B, int H, int W, int K, int N, int tiles_x, int tiles_y) {
+    constexpr int BN = 64;
+    constexpr int AI = 39, BI = 36;                   // 1 KiB DMA instructions per chunk: 612 patch rows x 64 B, 576 slab rows
+    constexpr int NI = AI + BI, NPL = (NI + NLW - 1) / NLW;   // per loader wave
+    constexpr int A_BYTES = AI * 1024, STAGE = NI * 1024;
+    constexpr int OROW = BN * 2 + 16;
+    constexpr int PROW = 34 * 64;                     // bytes per patch row
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // linear block id -> (pixel tile, channel block): the N / 64 channel blocks of a tile get ids 8 apart (same XCD, dispatched
+    // back to back), so the patch they share comes from HBM once (as in k_conv3x3_mfma)
+    int tile_id, cob;
+    {
+        const int ncob = N / BN, ntl = tiles_x * tiles_y * B;
+        const int id = blockIdx.x, full = (ntl >> 3) * 8 * ncob;
+        if (id < full) {
+            const int grp = id / (8 * ncob), r = id - grp * 8 * ncob;
+            tile_id = grp * 8 + (r & 7);
+            cob = r >> 3;
+        } else {
+            const int rem = ntl & 7, r = id - full;
+            tile_id = (ntl & ~7) + r % rem;
+            cob = r / rem;
+        }
+    }
+    int t = tile_id;
+    const int tx0 = (t % tiles_x) << 5; t /= tiles_x;
+    const int ty0 = (t % tiles_y) << 4; t /= tiles_y;
+    const int b0 = t;
+    const int n0 = cob * BN;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const bool loader = wave >= 4;
+    const int nch = K / 32;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    PHX_BLOCKLOG_BEGIN();
+
+    if (loader) {
+        const int lw = wave - 4;
+        unsigned voff[NPL];
+#pragma unroll
+        for (int n = 0; n < NPL; ++n) {
+            const int j = lw + NLW * n;
+            voff[n] = 0xffffffffu;
+            if (j < AI) {
+                const int e = j * 64 + lane, pp = e >> 2, slot = e & 3;
+                const int py = pp / 34, px = pp - py * 34;
+                const int piece = slot ^ ((px >> 2) & 3);
+                const int gx = tx0 + px - 1, gy = ty0 + py - 1;
+                if (pp < 612 && gx >= 0 && gx < W && gy >= 0 && gy < H) voff[n] = (unsigned)((((b0 * H + gy) * W + gx) * K) * 2 + piece * 16);
+            } else if (j < NI) {
+                const int e = (j - AI) * 64 + lane, rb = e >> 2, slot = e & 3;
+                const int tap = rb >> 6, nn = rb & 63;
+                const int piece = slot ^ ((nn >> 2) & 3);
+                voff[n] = (unsigned)(((tap * N + n0 + nn) * 32 + piece * 8) * 2);
+            }
+        }
+        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K * 2u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, (int)(9u * N * K * 2u), 0x00020000);
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        for (int c = -1; c < nch; ++c) {               // c = -1: prologue (chunk 0); chunk c: stage chunk c + 1
+            if (c + 1 < nch) {
+                const int cn = c + 1, buf = cn & 1;
+#pragma unroll
+                for (int n = 0; n < NPL; ++n) {
+                    const int j = lw + NLW * n;
+                    if (j < AI)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + buf * STAGE + j * 1024), 16, (int)voff[n],
+                                                                 cn * 64, 0, 0);
+                    else if (j < NI)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(smem + buf * STAGE + j * 1024), 16, (int)voff[n],
+                                                                 cn * 9 * N * 64, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_barrier" ::: "memory");    // hands chunk c + 1 over / learns that chunk c's buffer is free
+        }
+    } else {
+        // ---- MFMA waves: wave w owns tile rows 4 w .. 4 w + 3 (32 pixels each) x 64 channels
+        unsigned aK[3][2], bK[2];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                aK[kw][ks] = (unsigned)((wave * 4 * 34 + l31 + kw) * 64 + (((ks * 2 + khalf) ^ (((l31 + kw) >> 2) & 3)) << 4));
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) bK[ks] = (unsigned)(A_BYTES + l31 * 64 + (((ks * 2 + khalf) ^ ((l31 >> 2) & 3)) << 4));
+        asm volatile("s_barrier" ::: "memory");        // chunk 0 has landed
+        for (int c = 0; c < nch; ++c) {
+            const unsigned sb = (unsigned)((c & 1) * STAGE);
+            bf16x8 fa[2][6], fb[2][3][2];
+            auto read_frags = [&](auto gc) {           // group g = (k-step ks, tap column kw): six patch rows, three tap rows
+                constexpr int g = decltype(gc)::value;
+                constexpr int ks = g / 3, kw = g % 3;
+#pragma unroll
+                for (int rr = 0; rr < 6; ++rr)
+                    fa[g & 1][rr] = *reinterpret_cast<const bf16x8*>(smem + sb + aK[kw][ks] + rr * PROW);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        fb[g & 1][kh][j] = *reinterpret_cast<const bf16x8*>(smem + sb + bK[ks] + ((kh * 3 + kw) * 64 + j * 32) * 64);
+            };
+            read_frags(std::integral_constant<int, 0>());
+            auto groups = [&](auto self, auto gc) {
+                constexpr int g = decltype(gc)::value;
+                if constexpr (g < 6) {
+                    if constexpr (g < 5) read_frags(std::integral_constant<int, g + 1>());
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g & 1][i + kh], fb[g & 1][kh][j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    self(self, std::integral_constant<int, g + 1>());
+                }
+            };
+            groups(groups, std::integral_constant<int, 0>());
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // done reading this buffer; next chunk has landed
+        }
+    }
+
+    // epilogue (interior tiles only): pack pairs of rows, statistics, transpose through LDS, 16-byte stores
+    const int odd = lane & 1;
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    if (!loader) {
+        if constexpr (BIASACT) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float bv = bias ? bias[n0 + j * 32 + l31] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r] + bv, act);
+            }
+        }
+        unsigned char* lwp = smem + (wave * 128 + 4 * khalf + odd) * OROW + (l31 & ~1) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int rp = 0; rp < 8; ++rp)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int r0 = 2 * rp;
+                    const unsigned w2 = f2bf_pk(acc[i][j][r0], acc[i][j][r0 + 1]);
+                    const float ra_ = __uint_as_float(w2 << 16), rb_ = __uint_as_float(w2 & 0xffff0000u);
+                    s1[j] += ra_ + rb_;
+                    s2[j] += ra_ * ra_ + rb_ * rb_;
+                    const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)w2, 0xB1, 0xf, 0xf, true);
+                    const unsigned word = odd ? ((nb >> 16) | (w2 & 0xffff0000u)) : ((w2 & 0xffffu) | (nb << 16));
+                    *reinterpret_cast<unsigned*>(lwp + (i * 32 + (r0 & 3) + 8 * (r0 >> 2)) * OROW + j * 64) = word;
+                }
+    }
+    __syncthreads();
+    if (!loader) {
+        constexpr int PPP = BN / 8;                   // 16-byte pieces per pixel
+        const int mt = threadIdx.x / PPP, q = threadIdx.x % PPP;        // 256 threads: tile column mt, piece q; one tile row per step
+        const unsigned char* lr = smem + mt * OROW + q * 16;
+        unsigned short* yp = y + (((size_t)b0 * H + ty0) * W + tx0 + mt) * N + n0 + q * 8;
+        const size_t ystep = (size_t)W * N;
+#pragma unroll
+        for (int it = 0; it < 16; ++it)
+            *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * 32 * OROW);
+    }
+    if (stats_partial) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);      // [4 waves][2][BN]
+        if (!loader) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float a = s1[j] + __shfl_xor(s1[j], 32, 64);
+                const float bq = s2[j] + __shfl_xor(s2[j], 32, 64);
+                if (khalf == 0) {
+                    red[(wave * 2 + 0) * BN + j * 32 + l31] = a;
+                    red[(wave * 2 + 1) * BN + j * 32 + l31] = bq;
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * BN) {
+            const int which = threadIdx.x / BN, n = threadIdx.x % BN;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red[(w * 2 + which) * BN + n];
+            stats_partial[((size_t)tile_id * 2 + which) * N + n0 + n] = v;
+        }
+    }
+    PHX_BLOCKLOG_END();
+}
+
+// ---- the same 128-pixel wave tiles without loader waves: one 75 KiB stage per block, TWO blocks per CU -----------------
+__device__ unsigned g_phx_cu_arrivals[4096];
+template <bool BIASACT, int DBG>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned short* __restrict__ x,
+                                                             const unsigned short* __restrict__ wpk,
+                                                             unsigned short* __restrict__ y, const float* __restrict__ bias,
+                                                             int act, float* __restrict__ stats_partial,
+                                                             int B, int H, int W, int K, int N, int tiles_x, int tiles_y, int dephase) {
+    constexpr int BN = 64;
+    constexpr int AI = 39, BI = 36;                   // 1 KiB DMA instructions per chunk: 612 patch rows x 64 B, 576 slab rows
+    constexpr int NLW = 4;
+    constexpr int NI = AI + BI, NPL = (NI + NLW - 1) / NLW;   // DMA instructions per wave
+    constexpr int A_BYTES = AI * 1024, STAGE = NI * 1024;
+    constexpr int OROW = BN * 2 + 16;
+    constexpr int PROW = 34 * 64;                     // bytes per patch row
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // linear block id -> (pixel tile, channel block): the N / 64 channel blocks of a tile get ids 8 apart (same XCD, dispatched
+    // back to back), so the patch they share comes from HBM once (as in k_conv3x3_mfma)
+    int tile_id, cob;
+    {
+        const int ncob = N / BN, ntl = tiles_x * tiles_y * B;
+        const int id = blockIdx.x, full = (ntl >> 3) * 8 * ncob;
+        if (id < full) {
+            const int grp = id / (8 * ncob), r = id - grp * 8 * ncob;
+            tile_id = grp * 8 + (r & 7);
+            cob = r >> 3;
+        } else {
+            const int rem = ntl & 7, r = id - full;
+            tile_id = (ntl & ~7) + r % rem;
+            cob = r / rem;
+        }
+    }
+    int t = tile_id;
+    const int tx0 = (t % tiles_x) << 5; t /= tiles_x;
+    const int ty0 = (t % tiles_y) << 4; t /= tiles_y;
+    const int b0 = t;
+    const int n0 = cob * BN;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    constexpr bool loader = false;
+    const int nch = K / 32;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    PHX_BLOCKLOG_BEGIN();
+
+    // every wave stages its share of the chunk (LDS-DMA), then computes: ONE stage per block, two blocks per CU -- one block's
+    // DMA latency, prologue and epilogue run under the other block's MFMAs
+    const int lw = wave;
+    unsigned voff[NPL];
+#pragma unroll
+    for (int n = 0; n < NPL; ++n) {
+        const int j = lw + NLW * n;
+        voff[n] = 0xffffffffu;
+        if (j < AI) {
+            const int e = j * 64 + lane, pp = e >> 2, slot = e & 3;
+            const int py = pp / 34, px = pp - py * 34;
+            const int piece = slot ^ ((px >> 2) & 3);
+            const int gx = tx0 + px - 1, gy = ty0 + py - 1;
+            if (pp < 612 && gx >= 0 && gx < W && gy >= 0 && gy < H && !(DBG & 1)) voff[n] = (unsigned)((((b0 * H + gy) * W + gx) * K) * 2 + piece * 16);
+        } else if (j < NI) {
+            const int e = (j - AI) * 64 + lane, rb = e >> 2, slot = e & 3;
+            const int tap = rb >> 6, nn = rb & 63;
+            const int piece = slot ^ ((nn >> 2) & 3);
+            if (!(DBG & 2)) voff[n] = (unsigned)(((tap * N + n0 + nn) * 32 + piece * 8) * 2);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, (int)(9u * N * K * 2u), 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    unsigned aK[3][2], bK[2];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            aK[kw][ks] = (unsigned)((wave * 4 * 34 + l31 + kw) * 64 + (((ks * 2 + khalf) ^ (((l31 + kw) >> 2) & 3)) << 4));
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) bK[ks] = (unsigned)(A_BYTES + l31 * 64 + (((ks * 2 + khalf) ^ ((l31 >> 2) & 3)) << 4));
+    if (dephase > 0) {
+        // De-phasing experiment: two blocks share a CU and run identical load -> compute cycles; started together they stay in
+        // lock-step (both load, then both compute on half the matrix pipe each).  Every second block that arrives on a CU
+        // sleeps for `dephase` x 64 cycles first, so that one block's loads fall under the other's MFMAs.
+        volatile unsigned* s_old = reinterpret_cast<volatile unsigned*>(smem + STAGE);
+        if (threadIdx.x == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508) & 0xf;
+            *s_old = atomicAdd(&g_phx_cu_arrivals[(xcc << 8) | ((hw >> 8) & 0xff)], 1u);
+        }
+        __syncthreads();
+        if (*s_old & 1)
+            for (int q = 0; q < dephase; ++q) __builtin_amdgcn_s_sleep(1);
+    }
+    for (int c = 0; c < nch; ++c) {
+        if (c) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done reading the previous chunk
+#pragma unroll
+        for (int n = 0; n < NPL; ++n) {
+            const int j = lw + NLW * n;
+            if (j < AI)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + j * 1024), 16, (int)voff[n], c * 64, 0, 0);
+            else if (j < NI)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(smem + j * 1024), 16, (int)voff[n], c * 9 * N * 64, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        // 12 half-steps per chunk: step t = (group g = t / 2 = (k-step ks, tap column kw), channel half j = t % 2).  The six patch
+        // rows of a group are read once (fa, double-buffered by group parity), the three tap-row filter fragments per half-step
+        // (fb, by step parity); the next half-step's reads are pinned AHEAD of this one's 12 MFMAs (left alone, the compiler
+        // sinks them to their first use and every group pays the LDS latency).
+        bf16x8 fa[2][6], fb[2][3];
+        auto read_a = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int ks = g / 3, kw = g % 3;
+#pragma unroll
+            for (int rr = 0; rr < 6; ++rr)
+                fa[g & 1][rr] = *reinterpret_cast<const bf16x8*>(smem + aK[kw][ks] + rr * PROW);
+        };
+        auto read_b = [&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int g = t / 2, j = t % 2, ks = g / 3, kw = g % 3;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+                fb[t & 1][kh] = *reinterpret_cast<const bf16x8*>(smem + bK[ks] + ((kh * 3 + kw) * 64 + j * 32) * 64);
+        };
+        read_a(std::integral_constant<int, 0>());
+        read_b(std::integral_constant<int, 0>());
+        auto steps = [&](auto self, auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (t < 12) {
+                constexpr int g = t / 2, j = t % 2;
+                if constexpr (t + 1 < 12) {
+                    if constexpr (j == 1) read_a(std::integral_constant<int, g + 1>());
+                    read_b(std::integral_constant<int, t + 1>());
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!(DBG & 4))
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g & 1][i + kh], fb[t & 1][kh], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                self(self, std::integral_constant<int, t + 1>());
+            }
+        };
+        steps(steps, std::integral_constant<int, 0>());
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // epilogue (interior tiles only): pack pairs of rows, statistics, transpose through LDS, 16-byte stores
+    const int odd = lane & 1;
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    if (!loader) {
+        if constexpr (BIASACT) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float bv = bias ? bias[n0 + j * 32 + l31] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r] + bv, act);
+            }
+        }
+        unsigned char* lwp = smem + (wave * 128 + 4 * khalf + odd) * OROW + (l31 & ~1) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int rp = 0; rp < 8; ++rp)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int r0 = 2 * rp;
+                    const unsigned w2 = f2bf_pk(acc[i][j][r0], acc[i][j][r0 + 1]);
+                    const float ra_ = __uint_as_float(w2 << 16), rb_ = __uint_as_float(w2 & 0xffff0000u);
+                    s1[j] += ra_ + rb_;
+                    s2[j] += ra_ * ra_ + rb_ * rb_;
+                    const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)w2, 0xB1, 0xf, 0xf, true);
+                    const unsigned word = odd ? ((nb >> 16) | (w2 & 0xffff0000u)) : ((w2 & 0xffffu) | (nb << 16));
+                    *reinterpret_cast<unsigned*>(lwp + (i * 32 + (r0 & 3) + 8 * (r0 >> 2)) * OROW + j * 64) = word;
+                }
+    }
+    __syncthreads();
+    if (!loader) {
+        constexpr int PPP = BN / 8;                   // 16-byte pieces per pixel
+        const int mt = threadIdx.x / PPP, q = threadIdx.x % PPP;        // 256 threads: tile column mt, piece q; one tile row per step
+        const unsigned char* lr = smem + mt * OROW + q * 16;
+        unsigned short* yp = y + (((size_t)b0 * H + ty0) * W + tx0 + mt) * N + n0 + q * 8;
+        const size_t ystep = (size_t)W * N;
+#pragma unroll
+        for (int it = 0; it < 16; ++it)
+            *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * 32 * OROW);
+    }
+    if (stats_partial) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);      // [4 waves][2][BN]
+        if (!loader) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float a = s1[j] + __shfl_xor(s1[j], 32, 64);
+                const float bq = s2[j] + __shfl_xor(s2[j], 32, 64);
+                if (khalf == 0) {
+                    red[(wave * 2 + 0) * BN + j * 32 + l31] = a;
+                    red[(wave * 2 + 1) * BN + j * 32 + l31] = bq;
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * BN) {
+            const int which = threadIdx.x / BN, n = threadIdx.x % BN;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red[(w * 2 + which) * BN + n];
+            stats_partial[((size_t)tile_id * 2 + which) * N + n0 + n] = v;
+        }
+    }
+    PHX_BLOCKLOG_END();
+}
+
 // ---- filter gradient --------------------------------------------------------------------------------------
 // Block tile: TCI input channels x TCO output channels (32 or 64 each) x all 9 taps.  The 4 waves split the tile
 // into 32x32 sub-tiles (WI x WJ) and, when the tile has fewer than four sub-tiles, the pixel (k) steps WK ways;
@@ -1887,6 +2328,7 @@ int phx_debug_set_blocklog(void* dev_buf) {
 }
 
 int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W, int K, int N) {
+    if (phx_pp_eligible(B, H, W, K, N)) return phx_pp_partial_rows(B, H, W);     // one row of partial sums per (tile, wave)
     MTile g = make_mtile_fwd(B, H, W, K, N);
     return g.tiles_x * g.tiles_y * g.tiles_b;
 }
@@ -1923,6 +2365,7 @@ int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* 
 
 // the fused-statistics epilogue lives in the full-tile path of the 16-wide-tile kernels: every tile must be interior
 static bool fwd_bws_ok(int B, int H, int W, int K, int N) {
+    if (phx_pp_eligible(B, H, W, K, N)) return false;
     if (fwd_ws64(B, H, W, K, N) || fwd_dma_bn(B, H, W, K, N) || fwd_rs_bn(B, H, W, K, N) || fwd_ksplit(B, H, W, K, N) > 1) return false;
     if (fwd_big_tiles(B, H, W, K, N)) return true;                       // H % 32 == 0, W % 16 == 0
     return H % 16 == 0 && W % 16 == 0;
@@ -1962,6 +2405,8 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
     }
     PHX_REQUIRE(y != nullptr || (ksplit > 1 && !bias && act == PHX_ACT_ID), PHX_E_INVAL,
                 "conv3x3_mfma: y == NULL only for a split-K launch without bias / activation (slices left in the workspace)");
+    if (bws.part == nullptr && ksplit == 1 && phx_pp_eligible(B, H, W, K, N))
+        return phx_pp_launch(x, wpk, y, bias, act, stats_partial, B, H, W, K, N, stream);
     if (fwd_ws64(B, H, W, K, N)) {
         const bool ba = bias != nullptr || act != PHX_ACT_ID;
         static bool wattr = false;
@@ -1973,6 +2418,48 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
         PHX_REQUIRE((double)B * H * W * (K > N ? K : N) < 2147483648.0, PHX_E_SHAPE, "conv3x3_mfma: tensor exceeds 2^31 elements");
         const int ntl = B * (H / 16) * (W / 32);
         const size_t sh = 2 * 75 * 1024;              // two 75 KiB stages (the 72 KiB output tile reuses them)
+        const int wsm = fwd_ws_mode();
+        if (wsm == 5 || wsm == 1) {                  // k_conv3x3_fwd_dma128: one stage per block, two blocks per CU
+            const char* dbe = getenv("PHX_DBG_ABLATE");   // dev: bit 1 no patch loads, 2 no slab loads, 4 no MFMAs
+            const int dbg = dbe ? atoi(dbe) : 0;
+#define D128_LAUNCH(Av, Dv)                                                                                                     \
+    do {                                                                                                                        \
+        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_dma128<Av, Dv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((k_conv3x3_fwd_dma128<Av, Dv>), dim3(ntl * (N / 64)), dim3(256), 75 * 1024 + 16, (hipStream_t)stream,      \
+                           (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, \
+                           H, W, K, N, W / 32, H / 16, dephase);                                                                \
+    } while (0)
+            const char* dpe = getenv("PHX_DEPHASE");
+            const int dephase = dpe ? atoi(dpe) : 0;
+            if (ba) D128_LAUNCH(true, 0);
+            else switch (dbg) {
+                case 1: D128_LAUNCH(false, 1); break; case 2: D128_LAUNCH(false, 2); break; case 3: D128_LAUNCH(false, 3); break;
+                case 4: D128_LAUNCH(false, 4); break; case 5: D128_LAUNCH(false, 5); break; case 6: D128_LAUNCH(false, 6); break;
+                case 7: D128_LAUNCH(false, 7); break; default: D128_LAUNCH(false, 0);
+            }
+#undef D128_LAUNCH
+            PHX_CHECK_LAUNCH();
+            return PHX_OK;
+        }
+        if (wsm >= 3) {                  // 128-pixel wave tiles (k_conv3x3_fwd_ws128); 3: two loader waves, 4: four
+            static bool wattr2 = false;
+            if (!wattr2) {
+                PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_ws128<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_ws128<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_ws128<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_ws128<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                wattr2 = true;
+            }
+#define WS128_LAUNCH(Av, NLWv)                                                                                                   \
+    hipLaunchKernelGGL((k_conv3x3_fwd_ws128<Av, NLWv>), dim3(ntl * (N / 64)), dim3(256 + 64 * NLWv), sh, (hipStream_t)stream,    \
+                       (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, H, \
+                       W, K, N, W / 32, H / 16)
+            if (wsm == 3) { if (ba) WS128_LAUNCH(true, 2); else WS128_LAUNCH(false, 2); }
+            else { if (ba) WS128_LAUNCH(true, 4); else WS128_LAUNCH(false, 4); }
+#undef WS128_LAUNCH
+            PHX_CHECK_LAUNCH();
+            return PHX_OK;
+        }
         if (ba)
             hipLaunchKernelGGL((k_conv3x3_fwd_ws64<true>), dim3(ntl, N / 64), dim3(640), sh, (hipStream_t)stream,
                                (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B,

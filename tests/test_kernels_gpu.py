@@ -262,6 +262,24 @@ def test_conv3x3_mfma_wave_specialised(L, case, monkeypatch):
     _mfma_case(L, case)
 
 
+# 128-pixel wave tiles with shared patch rows: 4 MFMA waves + 2 DMA loader waves (k_conv3x3_fwd_ws128)
+@pytest.mark.parametrize("case", [(2, 16, 32, 32, 128), (1, 32, 64, 96, 64), (3, 16, 32, 32, 192), (1, 48, 32, 64, 256),
+                                  (1, 16, 64, 160, 128)])
+def test_conv3x3_mfma_wave_specialised_128(L, case, monkeypatch):
+    monkeypatch.setenv("PHX_FWD_WS", "5")
+    _mfma_case(L, case)
+
+
+# ping-pong persistent kernel (conv_pp.hip): forced on small shapes; PHX_PP_GRID = 3 makes every block walk several items
+@pytest.mark.parametrize("case", [(2, 16, 32, 32, 128), (1, 32, 64, 96, 64), (4, 16, 32, 32, 192), (2, 48, 32, 64, 256),
+                                  (1, 16, 64, 160, 128), (6, 32, 32, 64, 64)])
+@pytest.mark.parametrize("grid", [0, 3])
+def test_conv3x3_mfma_ping_pong(L, case, grid, monkeypatch):
+    monkeypatch.setenv("PHX_FWD_PP", "2")
+    monkeypatch.setenv("PHX_PP_GRID", str(grid))
+    _mfma_case(L, case)
+
+
 def _mfma_case(L, case):
     B, H, W, K, N = case
     x = RNG.standard_normal((B, H, W, K))
