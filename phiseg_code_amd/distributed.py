@@ -69,6 +69,13 @@ class DistContext:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def sum_float(self, v):
+        if not self.active:
+            return float(v)
+        t = torch.tensor([float(v)], dtype=torch.float64, device="cuda" if self.cuda else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
     def broadcast_(self, tensor, src=0):
         if self.active:
             dist.broadcast(tensor, src=src)

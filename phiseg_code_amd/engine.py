@@ -49,6 +49,12 @@ def _device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def device_sync():
+    """Order work enqueued through torch (parameter loads, lr / step updates, broadcasts) before plan replays, which run on
+    the plans' own non-blocking HIP streams."""
+    torch.cuda.synchronize()
+
+
 class Buf:
     """A device buffer: torch owns the memory, libphx sees the raw pointer."""
 
@@ -141,9 +147,39 @@ class ParamStore:
 
     def set_lr(self, lr):
         self.lr.fill_(float(lr))
+        device_sync()
 
     def set_step(self, step):
         self.step.fill_(int(step))
+        device_sync()
+
+    def export_adam(self):
+        """-> {variable name: (m, v)} for the trainable variables (TF's '<var>/Adam', '<var>/Adam_1' slots)."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, v in self.graph.variables.items():
+            if v.trainable:
+                off = self.offset[name]
+                out[name] = (self.adam_m[off:off + v.size].cpu().numpy().reshape(v.shape),
+                             self.adam_v[off:off + v.size].cpu().numpy().reshape(v.shape))
+        return out
+
+    def load_adam(self, slots):
+        for name, (m, vv) in slots.items():
+            v = self.graph.variables.get(name)
+            if v is None or not v.trainable:
+                continue
+            off = self.offset[name]
+            for arena, val in ((self.adam_m, m), (self.adam_v, vv)):
+                a = torch.as_tensor(np.asarray(val, dtype=np.float32).reshape(-1))
+                assert a.numel() == v.size, "shape mismatch for the Adam slot of %s" % name
+                arena[off:off + v.size] = a.to(arena.device)
+        torch.cuda.synchronize()
+
+    def reset_optimizer(self):
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        self.set_step(0)
 
 
 class Plan:

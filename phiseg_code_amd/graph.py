@@ -74,7 +74,10 @@ class Variable:
         return int(np.prod(self.shape))
 
     def initial_value(self, seed=0):
-        rng = np.random.default_rng([seed, zlib.crc32(self.name.encode())])
+        """Value at initialisation: a function of (seed, variable name, shape) only -- the Philox stream contract of
+        phiseg_code_amd/philox_host.py -- so every replica, every run and the CPU oracle start from identical weights."""
+        from phiseg_code_amd import philox_host
+        rng = philox_host.VariableStream(seed, self.name)
         return np.asarray(self.initializer(self.shape, rng), dtype=np.float32).reshape(self.shape)
 
     def __bool__(self):

@@ -54,10 +54,17 @@ class Session:
         self.dist = dist
         self.store = None
         self.plans = {}
+        self._lr = None
 
     def _ensure_store(self):
         if self.store is None:
             self.store = engine.ParamStore(self.model.graph, seed=self.model.init_seed)
+            if self.dist is not None and self.dist.active:
+                # identical replicas (the Philox initialiser already gives every rank the same values; this also covers
+                # weights loaded on one rank only)
+                self.dist.broadcast_(self.store.params)
+                self.dist.broadcast_(self.store.state)
+                engine.device_sync()
         return self.store
 
     def plan_for(self, fetch_tensors, train, batch, training):
@@ -96,15 +103,23 @@ class Session:
             if m.s_inp not in feed_dict:
                 raise ValueError("these fetches need s_inp")
             plan.set_input("s_input", feed_dict[m.s_inp])
-        if m.lr_pl in feed_dict:
-            self.store.set_lr(feed_dict[m.lr_pl])
-        if train and self.dist is not None and self.dist.active:
+        if m.lr_pl in feed_dict and float(feed_dict[m.lr_pl]) != self._lr:
+            self._lr = float(feed_dict[m.lr_pl])
+            self.store.set_lr(self._lr)               # (synchronises: the plans replay on their own HIP streams)
+        dp = self.dist is not None and self.dist.active
+        if train and dp:
             plan.run_main()
             self.dist.allreduce_sum(self.store.grads, plan)
             plan.run_opt()
         else:
             plan.run()
         vals = [plan.fetch(f) if isinstance(f, G.Tensor) else None for f in flat]
+        if dp and "s_input" in plan.feeds:
+            # the loss kernels scale every term by 1 / (B_local * world): a rank's scalar is its SHARE of the global-batch mean
+            # (phiseg_model.py:221,236 take the mean over the whole batch) -- sum the shares
+            for i, f in enumerate(flat):
+                if isinstance(f, G.Tensor) and f.shape == () and vals[i] is not None:
+                    vals[i] = np.float32(self.dist.sum_float(float(vals[i])))
 
         def build(s):
             return [build(x) for x in s] if isinstance(s, list) else vals[s]
@@ -182,12 +197,51 @@ class phiseg():
         pass
 
     # ---- training loop (phiseg_model.py:166-207) -------------------------------------------------
+    def _is_writer(self):
+        return self.dist is None or not self.dist.active or self.dist.rank == 0
+
+    def _setup_log_dir_and_continue_mode(self, log_dir=None):
+        """phiseg_model.py:821-845: log dir = <log_root>/<log_dir_name>/<experiment_name>; when it already holds a
+        model.ckpt-N checkpoint the run continues from the highest N and logs into <log_dir>_cont."""
+        from phiseg_code_amd.config import system as sys_config
+        from phiseg_code_amd.tfwrapper import utils as tfutils
+        cfg = self.exp_config
+        self.log_dir = log_dir or os.path.join(sys_config.log_root, cfg.log_dir_name, cfg.experiment_name)
+        self.init_checkpoint_path = None
+        self.continue_run = False
+        self.init_step = 0
+        if os.path.isdir(self.log_dir):
+            ckpt = tfutils.get_latest_model_checkpoint_path(self.log_dir, 'model.ckpt')
+            if ckpt is not False:
+                self.init_checkpoint_path = ckpt
+                self.continue_run = True
+                self.init_step = int(os.path.basename(ckpt).split('-')[-1])
+                self.log_dir += '_cont'
+                logging.info('--------------------------- Continuing previous run --------------------------------')
+                logging.info('Checkpoint path: %s' % self.init_checkpoint_path)
+                logging.info('Latest step was: %d' % self.init_step)
+        if self._is_writer():
+            os.makedirs(self.log_dir, exist_ok=True)
+
     def train(self, data, num_iter=None, log_every=100, log_dir=None):
+        """The reference's train(data) (phiseg_model.py:166-207): continue mode, lr schedule, one ELBO step per iteration,
+        `_do_validation` (checkpoint + metrics + best-of checkpoints) every `validation_frequency` steps.  TensorBoard
+        summaries (199-203) are out of scope.  `log_dir=None` keeps everything in memory (no checkpoints, no validation)
+        unless the config's log root exists; pass a directory to get the reference's on-disk behaviour.
+        Data-parallel: `data` should draw rank-dependent batches (SyntheticLIDC(cfg, seed=1234 + rank)); the returned /
+        logged loss is the global-batch mean; only rank 0 writes files."""
         cfg = self.exp_config
         num_iter = cfg.num_iter if num_iter is None else num_iter
+        on_disk = log_dir is not None
+        self.init_step, self.continue_run = 0, False
+        if on_disk:
+            self._setup_log_dir_and_continue_mode(log_dir)
+            if self.continue_run:
+                self.load_weights(self.init_checkpoint_path)
+        self.best_dice, self.best_loss, self.best_ged, self.best_ncc = -1, np.inf, np.inf, -1
         losses = []
         t0 = time.time()
-        for step in range(num_iter):
+        for step in range(self.init_step, num_iter):
             lr_key, _ = utils.find_floor_in_list(cfg.lr_schedule_dict.keys(), step)
             lr = cfg.lr_schedule_dict[lr_key]
             x_b, s_b = data.train.next_batch(cfg.batch_size)
@@ -196,11 +250,12 @@ class phiseg():
                                                         self.lr_pl: lr})
             losses.append(float(loss_tot_eval))
             if log_every and step % log_every == 0:
+                world = self.dist.world if (self.dist is not None and self.dist.active) else 1
                 logging.info('step %d  loss %.4f  (%.1f img/s)', step, losses[-1],
-                             (step + 1) * cfg.batch_size / max(time.time() - t0, 1e-9))
+                             (step - self.init_step + 1) * cfg.batch_size * world / max(time.time() - t0, 1e-9))
             vf = getattr(cfg, 'validation_frequency', None)
-            if log_dir and vf and step % vf == 0:
-                self.save_weights(os.path.join(log_dir, 'model.ckpt-%d.npz' % step))
+            if on_disk and vf and step % vf == 0:
+                self._do_validation(data)
         return losses
 
     # ---- validation (phiseg_model.py:530-660): N Monte-Carlo samples per image, metrics on the device ---------------
@@ -211,6 +266,23 @@ class phiseg():
         image); here they are one libphx call per image (utils.validation_metrics -> phx_validation_metrics).
         -> dict(loss, dice, per_structure_dice, ged, ncc), the averages the reference logs (615-634)."""
         cfg = self.exp_config
+        store = self.sess._ensure_store()
+        global_step = int(store.step.cpu().item()) - 1               # tf global_step - 1 (phiseg_model.py:532)
+        save = getattr(self, 'log_dir', None) is not None and os.path.isdir(getattr(self, 'log_dir', '') or '')
+        if save:
+            self.save_weights(os.path.join(self.log_dir, 'model.ckpt-%d' % global_step))
+        if hasattr(data.validation, 'next_batch'):                   # BATCH VALIDATION of every loss term (537-556)
+            names = list(self.loss_dict.keys())
+            val_x, val_s = data.validation.next_batch(cfg.batch_size)
+            val_out = self.sess.run(list(self.loss_dict.values()),
+                                    feed_dict={self.x_inp: val_x, self.s_inp: val_s, self.training_pl: False})
+            train_x, train_s = data.train.next_batch(cfg.batch_size)
+            train_out = self.sess.run(list(self.loss_dict.values()),
+                                      feed_dict={self.x_inp: train_x, self.s_inp: train_s, self.training_pl: False})
+            logging.info('----- Step: %d ------' % global_step)
+            logging.info('BATCH VALIDATION:')
+            for ii, loss_name in enumerate(names):
+                logging.info('%s | training: %f | validation: %f' % (loss_name, train_out[ii], val_out[ii]))
         imgs, labs = data.validation.images, data.validation.labels
         n_img = imgs.shape[0] if cfg.num_validation_images == 'all' else min(cfg.num_validation_images, imgs.shape[0])
         ns = cfg.validation_samples
@@ -237,31 +309,85 @@ class phiseg():
         logging.info(' - Mean (neg.) ELBO: %.4f' % out['loss'])
         logging.info(' - Mean GED: %.4f' % out['ged'])
         logging.info(' - Mean NCC: %.4f' % out['ncc'])
+        # best-of checkpoints (phiseg_model.py:638-660)
+        if not hasattr(self, 'best_dice'):
+            self.best_dice, self.best_loss, self.best_ged, self.best_ncc = -1, np.inf, np.inf, -1
+        mean_dice = float(np.mean(out['per_structure_dice']))
+        for key, value, better, fmt in (('dice', mean_dice, mean_dice >= self.best_dice, 'New best validation Dice! (%.3f)'),
+                                        ('loss', out['loss'], out['loss'] <= self.best_loss, 'New best validation loss! (%.3f)'),
+                                        ('ged', out['ged'], out['ged'] <= self.best_ged, 'New best GED score! (%.3f)'),
+                                        ('ncc', out['ncc'], out['ncc'] >= self.best_ncc, 'New best NCC score! (%.3f)')):
+            if better:
+                setattr(self, 'best_' + key, value)
+                logging.info(fmt % value)
+                if save:
+                    self.save_weights(os.path.join(self.log_dir, 'model_best_%s.ckpt-%d' % (key, global_step)))
         return out
 
     # ---- checkpoints (npz keyed by the TF variable names of SURVEY.md Appendix B) -------------------
     def save_weights(self, path):
-        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        """What tf.train.Saver writes for this graph (phiseg_model.py:144-148, 534-535): every variable, the Adam slots under
+        TF's names '<var>/Adam' (m) and '<var>/Adam_1' (v), and the step (TF keeps beta1_power / beta2_power and global_step;
+        one integer carries the same information).  File: <path>.npz.  Data-parallel: batch-norm moving statistics are
+        averaged over the replicas first (per-replica statistics); rank 0 writes."""
         store = self.sess._ensure_store()
-        np.savez(path, __step__=store.step.cpu().numpy(), **store.export())
+        dp = self.dist is not None and self.dist.active
+        if dp and store.n_state:
+            avg = store.state.clone()
+            self.dist.allreduce_sum(avg)
+            avg /= self.dist.world
+            store.state.copy_(avg)
+            engine.device_sync()
+        if not self._is_writer():
+            return
+        if not path.endswith('.npz'):
+            path += '.npz'
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        blob = dict(store.export())
+        for name, (m, v) in store.export_adam().items():
+            blob[name + '/Adam'] = m
+            blob[name + '/Adam_1'] = v
+        tmp = path + '.tmp.npz'
+        np.savez(tmp, __step__=store.step.cpu().numpy(), **blob)
+        os.replace(tmp, path)
 
     def load_weights(self, log_dir=None, type='latest', **kwargs):
+        """phiseg_model.py:505-525 (+ 'best_ncc', which the reference writes but cannot load -- SURVEY.md Q9).  `log_dir` may
+        also be a checkpoint file / prefix.  Restores variables, Adam slots and the step; a checkpoint without Adam slots
+        (weights only) resets the optimiser state and the step."""
+        from phiseg_code_amd.tfwrapper import utils as tfutils
+        if not log_dir:
+            log_dir = getattr(self, 'log_dir', None)
         path = log_dir
         if os.path.isdir(log_dir):
             names = {'latest': 'model.ckpt', 'best_dice': 'model_best_dice.ckpt', 'best_loss': 'model_best_loss.ckpt',
                      'best_ged': 'model_best_ged.ckpt', 'best_ncc': 'model_best_ncc.ckpt'}
-            if type not in names:
-                raise ValueError('Argument type=%s is unknown.' % type)
-            cands = sorted((f for f in os.listdir(log_dir) if f.startswith(names[type]) and f.endswith('.npz')),
-                           key=lambda f: int(''.join(c for c in f if c.isdigit()) or 0))
-            if not cands:
-                raise FileNotFoundError('no %s checkpoint in %s' % (type, log_dir))
-            path = os.path.join(log_dir, cands[-1])
+            if type == 'iter':
+                assert 'iteration' in kwargs, "argument 'iteration' must be provided for type='iter'"
+                path = os.path.join(log_dir, 'model.ckpt-%d' % kwargs['iteration'])
+            elif type in names:
+                path = tfutils.get_latest_model_checkpoint_path(log_dir, names[type])
+                if path is False:
+                    raise FileNotFoundError('no %s checkpoint in %s' % (type, log_dir))
+            else:
+                raise ValueError('Argument type=%s is unknown. type can be latest/iter.' % type)
+        if not os.path.exists(path) and os.path.exists(path + '.npz'):
+            path += '.npz'
         ck = np.load(path)
         store = self.sess._ensure_store()
-        store.load({k: ck[k] for k in ck.files if k != '__step__'})
-        if '__step__' in ck.files:
-            store.set_step(int(ck['__step__'][0]))
+        names = set(self.graph.variables)
+        store.load({k: ck[k] for k in ck.files if k in names})
+        slots = {k[:-len('/Adam')]: (ck[k], ck[k + '_1']) for k in ck.files if k.endswith('/Adam') and k + '_1' in ck.files}
+        if slots:
+            store.load_adam(slots)
+            store.set_step(int(ck['__step__'][0]) if '__step__' in ck.files else 0)
+        else:
+            store.reset_optimizer()
+        self.sess._lr = None
+        if self.dist is not None and self.dist.active:
+            for t in (store.params, store.state, store.adam_m, store.adam_v):
+                self.dist.broadcast_(t)
+            engine.device_sync()
 
     def set_weights(self, values):
         self.sess._ensure_store().load(values)
@@ -304,3 +430,4 @@ class phiseg():
         """Every sampling call must see fresh noise (TF's stateful RNG): bump the Philox step word."""
         store = self.sess._ensure_store()
         store.noise_step += 1
+        engine.device_sync()          # torch's stream -> the plans' own HIP streams

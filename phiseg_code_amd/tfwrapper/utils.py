@@ -2,7 +2,10 @@
 
 ``get_weight_variable`` / ``get_bias_variable`` keep the reference's signatures.  he_normal follows TF 1.12's
 ``variance_scaling_initializer(factor=2.0, mode='FAN_IN', uniform=False)``: a truncated normal (resampled
-beyond two standard deviations) with stddev sqrt(1.3 * 2 / fan_in), fan_in = kh*kw*Cin."""
+beyond two standard deviations) with stddev sqrt(1.3 * 2 / fan_in), fan_in = kh*kw*Cin.
+
+Random draws come from the build's Philox stream contract (``phiseg_code_amd/philox_host.py``: TensorFlow itself is never
+seeded by the reference): a variable's value depends on (seed, TF variable name, shape) only."""
 import math
 
 import numpy as np
@@ -11,12 +14,8 @@ from phiseg_code_amd import graph as G
 
 
 def _truncated_normal(shape, std, rng):
-    out = rng.standard_normal(shape)
-    bad = np.abs(out) > 2.0
-    while bad.any():
-        out[bad] = rng.standard_normal(int(bad.sum()))
-        bad = np.abs(out) > 2.0
-    return out * std
+    """TF's truncated_normal: draws beyond two standard deviations are re-drawn (rng: philox_host.VariableStream)."""
+    return rng.truncated_normal(shape) * std
 
 
 def _fans(shape):
@@ -25,19 +24,33 @@ def _fans(shape):
 
 
 def _initializer(type_, **kwargs):
+    """tfwrapper/utils.py:221-244 of the reference.  he_normal / xavier_normal = TF 1.12's variance_scaling_initializer
+    (truncated normal, stddev sqrt(1.3 * factor / fan)); the *_uniform variants draw U(-limit, limit)."""
     if type_ == "he_normal":
         return lambda shape, rng: _truncated_normal(shape, math.sqrt(1.3 * 2.0 / _fans(shape)[0]), rng)
     if type_ == "he_uniform":
-        return lambda shape, rng: rng.uniform(-1, 1, shape) * math.sqrt(3.0 * 2.0 / _fans(shape)[0])
+        return lambda shape, rng: rng.uniform(-1.0, 1.0, shape) * math.sqrt(3.0 * 2.0 / _fans(shape)[0])
     if type_ == "caffe_uniform":
-        return lambda shape, rng: rng.uniform(-1, 1, shape) * math.sqrt(3.0 * 1.0 / _fans(shape)[0])
+        return lambda shape, rng: rng.uniform(-1.0, 1.0, shape) * math.sqrt(3.0 * 1.0 / _fans(shape)[0])
     if type_ == "xavier_uniform":
-        return lambda shape, rng: rng.uniform(-1, 1, shape) * math.sqrt(6.0 / sum(_fans(shape)))
+        return lambda shape, rng: rng.uniform(-1.0, 1.0, shape) * math.sqrt(6.0 / sum(_fans(shape)))
     if type_ == "xavier_normal":
         return lambda shape, rng: _truncated_normal(shape, math.sqrt(1.3 * 2.0 / sum(_fans(shape))), rng)
     if type_ == "simple":
         std = kwargs.get("stddev", 0.02)
         return lambda shape, rng: _truncated_normal(shape, std, rng)
+    if type_ == "bilinear":
+        # tfwrapper/utils.py:275-307: 2-D bilinear interpolation kernel on the diagonal of a transposed-convolution filter
+        def bil(shape, rng):
+            kh, kw, co, ci = shape
+            f = math.ceil(kw / 2.0)
+            c = (2 * f - 1 - f % 2) / (2.0 * f)
+            k2 = np.array([[(1 - abs(xx / f - c)) * (1 - abs(yy / f - c)) for yy in range(kh)] for xx in range(kw)])
+            w = np.zeros(shape, dtype=np.float32)
+            for i in range(min(co, ci)):
+                w[:, :, i, i] = k2
+            return w
+        return bil
     raise ValueError("Unknown initialisation requested: %s" % type_)
 
 
@@ -65,6 +78,21 @@ def get_bias_variable(shape, name=None, init_value=0.0, **kwargs):
     else:
         init = lambda shape, rng: np.full(shape, init_value, dtype=np.float32)
     return G.get_default_graph().get_variable(name, shape, init)
+
+
+def get_latest_model_checkpoint_path(folder, name):
+    """tfwrapper/utils.py:189-210 of the reference: the checkpoint `name`-<iteration> with the highest iteration in
+    `folder` (False when there is none).  TF marks a checkpoint by its .meta file; ours is one file <name>-<it>.npz."""
+    import glob
+    import os
+    its = []
+    for f in glob.glob(os.path.join(folder, '%s-*.npz' % name)):
+        tail = os.path.basename(f)[len(name) + 1:-len('.npz')]
+        if tail.isdigit():
+            its.append(int(tail))
+    if not its:
+        return False
+    return os.path.join(folder, name + '-' + str(max(its)))
 
 
 def get_rhs_dim(tensor):

@@ -1,0 +1,125 @@
+"""(f)3 checkpoint / resume / validation inside train() -- reference phiseg_model.py:144-148, 166-207, 505-535, 638-660,
+821-845 and tfwrapper/utils.py:189-210."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import load_golden
+from tests.test_graph_cpu import make_config
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg():
+    g, cfg, _ = load_golden("tiny_phiseg_bn")
+    c = make_config(cfg, "f32")
+    c.batch_size = 2
+    c.validation_frequency = 2
+    c.validation_samples = 4
+    c.num_validation_images = 2
+    c.annotator_range = range(4)
+    c.lr_schedule_dict = {0: 1e-3}
+    return c
+
+
+def _data(cfg, seed=1234):
+    from phiseg_code_amd.data import synthetic
+    return synthetic.SyntheticLIDC(cfg, seed=seed, n_validation=3)
+
+
+def test_train_writes_checkpoints_and_best_of(tmp_path):
+    from phiseg_code_amd.phiseg import phiseg_model
+    from phiseg_code_amd.tfwrapper import utils as tfutils
+    cfg = _cfg()
+    model = phiseg_model.phiseg(cfg)
+    log_dir = str(tmp_path / "run")
+    losses = model.train(_data(cfg), num_iter=5, log_every=0, log_dir=log_dir)
+    assert len(losses) == 5 and np.all(np.isfinite(losses))
+    files = sorted(os.listdir(log_dir))
+    # validation at steps 0, 2, 4: model.ckpt-<step> each time, best-of files for the four criteria
+    for st in (0, 2, 4):
+        assert "model.ckpt-%d.npz" % st in files
+    for crit in ("dice", "loss", "ged", "ncc"):
+        assert any(f.startswith("model_best_%s.ckpt-" % crit) for f in files), files
+    assert tfutils.get_latest_model_checkpoint_path(log_dir, "model.ckpt") == os.path.join(log_dir, "model.ckpt-4")
+    assert tfutils.get_latest_model_checkpoint_path(str(tmp_path), "model.ckpt") is False
+    ck = np.load(os.path.join(log_dir, "model.ckpt-4.npz"))
+    names = set(model.graph.variables)
+    assert names <= set(ck.files)
+    w = [n for n in names if n.endswith("/W")][0]
+    assert w + "/Adam" in ck.files and w + "/Adam_1" in ck.files and int(ck["__step__"][0]) == 5
+    assert max(np.abs(ck[n + "/Adam_1"]).max() for n in names if n.endswith("/W")) > 0     # second moments of live filters
+    # every type the reference's load_weights knows (+ best_ncc), and type='iter'
+    m2 = phiseg_model.phiseg(cfg)
+    for t in ("latest", "best_dice", "best_loss", "best_ged", "best_ncc"):
+        m2.load_weights(log_dir, type=t)
+    m2.load_weights(log_dir, type="iter", iteration=2)
+    assert int(m2.sess.store.step.cpu().item()) == 3
+    with pytest.raises(ValueError):
+        m2.load_weights(log_dir, type="nonsense")
+
+
+def test_resume_continues_the_same_trajectory(tmp_path):
+    """2 steps + checkpoint + fresh process state + 2 more steps == 4 steps straight: weights, Adam slots, the step (Adam's
+    bias correction and the Philox noise key) and the batch-norm moving statistics all survive the round trip."""
+    from phiseg_code_amd.phiseg import phiseg_model
+    cfg = _cfg()
+    data = _data(cfg)
+    batches = [data.train.next_batch(cfg.batch_size) for _ in range(4)]
+
+    def steps(model, idx):
+        out = []
+        for i in idx:
+            x, s = batches[i]
+            _, l = model.sess.run([model.train_step, model.loss_tot],
+                                  {model.x_inp: x, model.s_inp: s, model.training_pl: True, model.lr_pl: 1e-5})
+            out.append(float(l))
+        return out
+
+    a = phiseg_model.phiseg(cfg)
+    la = steps(a, range(4))
+    b = phiseg_model.phiseg(cfg)
+    lb = steps(b, range(2))
+    b.save_weights(str(tmp_path / "mid.ckpt-1"))
+    c = phiseg_model.phiseg(cfg, init_seed=99)                  # different initial weights: everything must come from the file
+    c.load_weights(str(tmp_path / "mid.ckpt-1"))
+    lc = steps(c, range(2, 4))
+    np.testing.assert_allclose(lb + lc, la, rtol=2e-3)      # (fp32 atomics reorder sums run to run: 6e-4 on this freshly initialised net)
+    pa, pc, pmid = a.sess.store.export(), c.sess.store.export(), b.sess.store.export()
+    checked = 0
+    for k in pa:
+        # (Adam moves a weight by ~lr per step whatever the gradient's size: an element whose tiny gradient changes sign with
+        # the summation order may differ by 2 lr between two identical runs)
+        np.testing.assert_allclose(pc[k], pa[k], rtol=0, atol=4e-5 + 1e-5 * np.abs(pa[k]).max(), err_msg=k)
+        # the UPDATE of the two resumed steps equals the straight run's (a reset optimiser would move every weight by
+        # lr * sign(g) instead of lr * m_hat / sqrt(v_hat): relative error ~1)
+        da, dc = (pa[k] - pmid[k]).ravel().astype(np.float64), (pc[k] - pmid[k]).ravel().astype(np.float64)
+        if k.endswith("/W") and np.abs(da).max() > 1e-6:
+            assert np.linalg.norm(dc - da) <= 0.1 * np.linalg.norm(da), k
+            checked += 1
+    assert checked > 50
+    # a weights-only file resets the optimiser (no silent 3x-lr first steps with stale bias correction)
+    blob = {k: v for k, v in np.load(str(tmp_path / "mid.ckpt-1.npz")).items() if not k.endswith(("/Adam", "/Adam_1"))}
+    np.savez(str(tmp_path / "weights_only.npz"), **blob)
+    d = phiseg_model.phiseg(cfg)
+    steps(d, range(1))
+    d.load_weights(str(tmp_path / "weights_only.npz"))
+    assert int(d.sess.store.step.cpu().item()) == 0 and float(d.sess.store.adam_v.abs().max().cpu()) == 0.0
+
+
+def test_continue_mode_picks_latest_and_logs_into_cont(tmp_path):
+    from phiseg_code_amd.phiseg import phiseg_model
+    cfg = _cfg()
+    log_dir = str(tmp_path / "exp")
+    m = phiseg_model.phiseg(cfg)
+    m.train(_data(cfg), num_iter=3, log_every=0, log_dir=log_dir)
+    assert os.path.exists(os.path.join(log_dir, "model.ckpt-2.npz"))
+    m2 = phiseg_model.phiseg(cfg)
+    losses = m2.train(_data(cfg), num_iter=5, log_every=0, log_dir=log_dir)
+    assert m2.continue_run and m2.init_step == 2 and m2.log_dir == log_dir + "_cont"
+    assert len(losses) == 3                                       # steps 2, 3, 4 (the reference re-runs the checkpointed index)
+    # checkpoints are numbered by the optimiser's global step - 1 (phiseg_model.py:532), which ran one ahead of the loop index
+    # after the re-run of step 2 -- the reference's own numbering drift on continued runs
+    assert os.path.exists(os.path.join(log_dir + "_cont", "model.ckpt-5.npz"))
+    assert int(m2.sess.store.step.cpu().item()) == 6
