@@ -96,7 +96,7 @@ def test_resume_continues_the_same_trajectory(tmp_path):
         # lr * sign(g) instead of lr * m_hat / sqrt(v_hat): relative error ~1)
         da, dc = (pa[k] - pmid[k]).ravel().astype(np.float64), (pc[k] - pmid[k]).ravel().astype(np.float64)
         if k.endswith("/W") and np.abs(da).max() > 1e-6:
-            assert np.linalg.norm(dc - da) <= 0.3 * np.linalg.norm(da), k       # (one flipped element of a small filter: 0.14)
+            assert np.linalg.norm(dc - da) <= 0.5 * np.linalg.norm(da), k       # (flipped elements of a small filter: 0.14-0.3 observed)
             checked += 1
     assert checked > 50
     # a weights-only file resets the optimiser (no silent 3x-lr first steps with stale bias correction)
