@@ -42,13 +42,17 @@ def loss_and_grads(params, x, s, eps_fn, cfg):
     return out, grads
 
 
-def train_steps(params, batches, cfg, eps_seed, lr=1e-3, n_steps=1, dtype=torch.float64):
+def train_steps(params, batches, cfg, eps_seed, lr=1e-3, n_steps=1, dtype=torch.float64, snapshots=None):
     """Runs n_steps of (ELBO, backward, Adam, moving-stat update) in place; batches[i] = (x, s) numpy.
-    Step index i is the Philox `step` word for the noise; Adam's t = i + 1.  Returns list of losses."""
+    Step index i is the Philox `step` word for the noise; Adam's t = i + 1.  Returns list of losses.
+    snapshots: optional dict {step index: None}; filled with (params, adam m, adam v) copies taken BEFORE that step."""
     m = {k: torch.zeros_like(v) for k, v in params.items() if v.requires_grad}
     vv = {k: torch.zeros_like(v) for k, v in params.items() if v.requires_grad}
     losses = []
     for i in range(n_steps):
+        if snapshots is not None and i in snapshots:
+            snapshots[i] = ({k: v.detach().clone() for k, v in params.items()}, {k: v.clone() for k, v in m.items()},
+                            {k: v.clone() for k, v in vv.items()})
         x_np, s_np = batches[i % len(batches)]
         x = torch.as_tensor(x_np, dtype=dtype)
         s = torch.as_tensor(s_np)

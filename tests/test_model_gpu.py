@@ -345,3 +345,173 @@ def test_full_size_bench_configuration_properties_bf16():
     _, tot3 = model.sess.run([model.train_step, model.loss_tot], fd)
     tot4 = float(model.sess.run(model.loss_tot, fd))
     assert np.isfinite(tot4) and abs(tot4 - float(tot3)) > 1e-6 * abs(float(tot3))
+
+
+# ---- training parity at the benchmark's network size (n0 = 32, 128 x 128): gradients and a 12-step trajectory -----------------
+def _lidc_setup(compute_dtype, perturbed):
+    from oracle import init as oinit
+    from phiseg_code_amd.phiseg import phiseg_model
+    g, cfg, var_order = load_golden("lidc_phiseg_bn")
+    model = phiseg_model.phiseg(make_config(cfg, compute_dtype), rng_seed=cfg["eps_seed"])
+    params = otrain.make_params(var_order, cfg["weight_seed"], torch.float32, perturbed=perturbed)
+    x_np, s_np = oinit.synthetic_batch(cfg["B"], cfg["H"], cfg["nlabels"], cfg["data_seed"])
+    model.set_weights({k: v.detach().numpy() for k, v in params.items()})
+    return cfg, model, params, x_np, s_np
+
+
+def test_bf16_gradients_n0_32_vs_simulated_bf16_oracle():
+    """Every variable's gradient of the bf16 training plan at the benchmark's network size (n0 = 32, 128 x 128, batch 2;
+    3x3 MFMA forward / data-gradient / filter-gradient kernels, the deferred multi-layer filter-gradient launches and their
+    reductions, the 1x1 head filter gradients) against torch autograd of the oracle -- exact (fp32) and with the engine's
+    bf16 storage policy simulated (oracle.nets.Ctx.bf16_sim).  Bound per variable: the relative L2 error against the exact
+    gradient may be at most 2x the simulated policy's own deviation (two bf16 evaluations decorrelate through rounding
+    flips; independent errors add in quadrature -> 1.4x expected), with a floor of 3 % for variables the policy happens
+    to leave almost untouched."""
+    from oracle import nets
+    cfg, model, params, x_np, s_np = _lidc_setup("bf16", perturbed=True)
+    xt, st = torch.as_tensor(x_np, dtype=torch.float32), torch.as_tensor(s_np)
+
+    def oracle_grads(sim):
+        for v in params.values():
+            v.grad = None
+        eps = otrain.torch_eps_fn(cfg["eps_seed"], 0, cfg["B"], torch.float32)
+        out = nets.elbo(params, xt, st, eps, cfg, training=True, bf16_sim=sim)
+        out["loss_tot"].backward()
+        return float(out["loss_tot"]), {k: v.grad.detach().double().numpy().copy() for k, v in params.items()
+                                        if v.requires_grad and v.grad is not None}
+    l_exact, g_exact = oracle_grads(False)
+    l_sim, g_sim = oracle_grads(True)
+    plan = model.sess.plan_for([model.loss_tot], True, cfg["B"], True)
+    plan.set_input("x_input", x_np)
+    plan.set_input("s_input", s_np)
+    plan.optimize = False
+    model.sess.store.set_lr(0.0)                      # the step applies Adam with lr = 0: parameters stay put
+    plan.run()
+    plan.sync()
+    loss = float(plan.fetch(model.loss_tot))
+    got = model.sess.store.export(grads=True)
+    assert abs(loss - l_exact) <= max(0.05, 3 * abs(l_sim - l_exact) / abs(l_exact)) * abs(l_exact)
+    worst, n_checked, tot_e, tot_inh = (0.0, None), 0, 0.0, 0.0
+    for name, ge in g_exact.items():
+        nrm = np.linalg.norm(ge)
+        if nrm < 1e-8 * max(1.0, np.sqrt(ge.size)):
+            continue                                  # never-consumed branches (SURVEY.md Q1): zero gradient
+        gh = got[name].astype(np.float64).reshape(ge.shape)
+        inh = np.linalg.norm(g_sim[name] - ge) / nrm
+        e = np.linalg.norm(gh - ge) / nrm
+        e_s = np.linalg.norm(gh - g_sim[name]) / nrm
+        bound = 2.0 * max(inh, 0.03)
+        assert e <= bound and e_s <= bound, (name, e, e_s, inh)
+        if e / bound > worst[0]:
+            worst = (e / bound, name, e, inh)
+        tot_e += e; tot_inh += inh; n_checked += 1
+    print("bf16 gradients: %d variables, mean rel. L2 error %.4f (simulated policy itself %.4f), worst %s" %
+          (n_checked, tot_e / n_checked, tot_inh / n_checked, worst))
+    assert n_checked >= 360                           # 368 live trainable tensors (SURVEY.md section 2.1)
+
+
+NSTEP = 12
+
+
+@pytest.fixture(scope="module")
+def lidc_trajectory():
+    """The oracle's 12-step trajectory at n0 = 32, 128 x 128, batch 2 (fp32 torch-CPU, ~3.5 s per step), snapshots of (weights,
+    Adam slots) before steps 5 and 11, and the SAME trajectory from an input perturbed by 1e-6 relative: TF1 Adam moves every weight
+    by ~lr * sign-like(m / sqrt(v)), so weights whose gradient is round-off-sized change direction with the summation
+    order and two exact implementations drift apart -- the perturbed run measures that drift (the chaos band)."""
+    from oracle import init as oinit
+    g, cfg, var_order = load_golden("lidc_phiseg_bn")
+    lr = 2e-5
+    x_np, s_np = oinit.synthetic_batch(cfg["B"], cfg["H"], cfg["nlabels"], cfg["data_seed"])
+    params = otrain.make_params(var_order, cfg["weight_seed"], torch.float32, perturbed=True)
+    p0 = {k: v.detach().clone().numpy() for k, v in params.items()}
+    snaps = {5: None, 11: None}
+    ref = [l["total_loss"] for l in otrain.train_steps(params, [(x_np, s_np)], cfg, cfg["eps_seed"], lr=lr, n_steps=NSTEP,
+                                                        dtype=torch.float32, snapshots=snaps)]
+    params2 = otrain.make_params(var_order, cfg["weight_seed"], torch.float32, perturbed=True)
+    ref2 = [l["total_loss"] for l in otrain.train_steps(params2, [(x_np * np.float32(1.000001), s_np)], cfg, cfg["eps_seed"],
+                                                         lr=lr, n_steps=NSTEP, dtype=torch.float32)]
+    chaos = np.abs(np.array(ref2) - np.array(ref)) / np.abs(ref)
+    return dict(cfg=cfg, lr=lr, x=x_np, s=s_np, p0=p0, ref=ref, chaos=chaos, snaps=snaps)
+
+
+@pytest.mark.parametrize("compute_dtype", ["f32", "bf16"])
+def test_loss_curve_n0_32(compute_dtype, lidc_trajectory):
+    """12 free-running training steps (ELBO, backward, TF1 Adam, batch-norm moving statistics; eager, hipGraph capture,
+    then replay) at n0 = 32, 128 x 128, batch 2 against the oracle's trajectory on identical weights / batch / Philox noise.
+    Step 0 must agree to 1e-4 (fp32) -- after that the comparison is bounded by the drift the oracle shows against ITSELF
+    under a 1e-6 input perturbation (3x its maximum, floor 1e-3): 1e-3 per step is below that drift at this size (the
+    oracle's self-drift reaches ~1e-2 within ten steps).
+    bf16: additionally the band between exact and simulated-bf16 oracle evaluation of the first step (x3, floor 2 %).
+    The per-step exactness of the step function along the trajectory is checked separately, from the oracle's own
+    snapshots (test_single_steps_from_oracle_snapshots_n0_32)."""
+    from oracle import nets
+    from phiseg_code_amd.phiseg import phiseg_model
+    t = lidc_trajectory
+    cfg, lr, x_np, s_np, ref = t["cfg"], t["lr"], t["x"], t["s"], t["ref"]
+    model = phiseg_model.phiseg(make_config(cfg, compute_dtype), rng_seed=cfg["eps_seed"])
+    model.set_weights(t["p0"])
+    band0 = 1e-4
+    extra = 0.0
+    if compute_dtype == "bf16":
+        params = {k: torch.as_tensor(v) for k, v in t["p0"].items()}
+        xt, st = torch.as_tensor(x_np, dtype=torch.float32), torch.as_tensor(s_np)
+        eps = otrain.torch_eps_fn(cfg["eps_seed"], 0, cfg["B"], torch.float32)
+        with torch.no_grad():
+            ex = float(nets.elbo(params, xt, st, eps, cfg, training=True)["loss_tot"])
+            sm_ = float(nets.elbo(params, xt, st, eps, cfg, training=True, bf16_sim=True)["loss_tot"])
+        extra = max(0.02, 3 * abs(sm_ - ex) / abs(ex))
+        band0 = extra
+    losses = []
+    for _ in range(NSTEP):
+        _, lt = model.sess.run([model.train_step, model.loss_tot],
+                               {model.x_inp: x_np, model.s_inp: s_np, model.training_pl: True, model.lr_pl: lr})
+        losses.append(float(lt))
+    rel = np.abs(np.array(losses) - np.array(ref)) / np.abs(ref)
+    band = max(1e-3, 3 * float(t["chaos"].max())) + extra
+    print("%s 12-step curve: %.1f -> %.1f (oracle %.1f -> %.1f); rel. deviation step 0 %.1e, max %.2e; oracle self-drift max %.2e" %
+          (compute_dtype, losses[0], losses[-1], ref[0], ref[-1], rel[0], rel.max(), t["chaos"].max()))
+    assert ref[-1] < ref[0] and losses[-1] < losses[0]    # both trajectories descend
+    assert rel[0] <= band0, rel[0]
+    if compute_dtype == "f32":
+        assert (rel[1:] <= band).all(), (rel, band)
+    else:
+        # stated bf16 band: every step within 15 %, the mean deviation over the curve within 5 % (each step draws fresh noise and
+        # the level-0 KL term alone moves by several per cent under bf16 rounding flips; measured: max 11 %, mean 4 %)
+        assert rel.max() <= 0.15 and rel.mean() <= 0.05, (rel, band)
+
+
+def test_single_steps_from_oracle_snapshots_n0_32(lidc_trajectory):
+    """The step function along the trajectory, without drift: weights, Adam slots and the step counter of the ORACLE before
+    its steps 5 and 11 are loaded into the engine, ONE HIP step (fp32) is taken and compared with the oracle's own step:
+    loss to 1e-4; every weight moves like the oracle's (Adam: ~lr per step; bound 10 % of the update's L2 norm per filter)."""
+    from phiseg_code_amd.phiseg import phiseg_model
+    t = lidc_trajectory
+    cfg, lr, x_np, s_np = t["cfg"], t["lr"], t["x"], t["s"]
+    model = phiseg_model.phiseg(make_config(cfg, "f32"), rng_seed=cfg["eps_seed"])
+    for step, (params, m, v) in sorted(t["snaps"].items()):
+        before = {k: p.numpy() for k, p in params.items()}
+        model.set_weights(before)
+        model.sess.store.load_adam({k: (m[k].numpy(), v[k].numpy()) for k in m})
+        model.sess.store.set_step(step)
+        _, lt = model.sess.run([model.train_step, model.loss_tot],
+                               {model.x_inp: x_np, model.s_inp: s_np, model.training_pl: True, model.lr_pl: lr})
+        np.testing.assert_allclose(float(lt), t["ref"][step], rtol=1e-4)
+        # the oracle's own update from the same state
+        p2 = {k: p.clone().requires_grad_(p.requires_grad) for k, p in params.items()}
+        out, grads = otrain.loss_and_grads(p2, torch.as_tensor(x_np), torch.as_tensor(s_np),
+                                           otrain.torch_eps_fn(cfg["eps_seed"], step, cfg["B"], torch.float32), cfg)
+        from oracle import tf1_ops as T
+        got = model.sess.store.export()
+        n_bad = n_all = 0
+        for k, gk in grads.items():
+            if gk is None or not k.endswith("/W"):
+                continue
+            pn, _, _ = T.adam_tf1_step(params[k], gk, m[k], v[k], step + 1, lr)
+            dref = (pn - params[k]).numpy().ravel().astype(np.float64)
+            dgot = (got[k] - before[k]).ravel().astype(np.float64)
+            if np.linalg.norm(dref) < 1e-9:
+                continue
+            n_all += 1
+            n_bad += int(np.linalg.norm(dgot - dref) > 0.1 * np.linalg.norm(dref))
+        assert n_all > 100 and n_bad <= 0.02 * n_all, (step, n_bad, n_all)
