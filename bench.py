@@ -112,7 +112,7 @@ def main():
             plan.L.step_increment(sess.store.noise_step.data_ptr(), plan.stream_handle())
         elif ctx.active:
             plan.run_main()
-            ctx.allreduce_sum(sess.store.grads, plan)
+            ctx.allreduce_sum(sess.store.grads[:sess.store.n_live], plan)
             plan.run_opt()
         else:
             plan.run()

@@ -24,7 +24,7 @@ extern "C" {
 
 enum { PHX_F32 = 0, PHX_BF16 = 1 };
 enum { PHX_ACT_ID = 0, PHX_ACT_RELU = 1, PHX_ACT_SOFTPLUS = 2 };
-enum { PHX_OK = 0, PHX_E_INVAL = -1, PHX_E_SHAPE = -2, PHX_E_ALIGN = -3, PHX_E_LAUNCH = -4, PHX_E_RUNTIME = -5 };
+enum { PHX_OK = 0, PHX_E_INVAL = -1, PHX_E_SHAPE = -2, PHX_E_ALIGN = -3, PHX_E_LAUNCH = -4, PHX_E_RUNTIME = -5, PHX_E_COMM = -6 };
 
 /* ---- runtime plumbing ------------------------------------------------------------------------------ */
 int phx_abi_version(void);
@@ -295,6 +295,21 @@ int phx_weighted_sum(const float* const* ptrs, const float* weights, int n, floa
 size_t phx_validation_metrics_ws_bytes(int I, int N, int M, int P, int C);
 int phx_validation_metrics(const float* sm, const unsigned char* gt, const unsigned char* sref, void* work, size_t work_bytes,
                            int I, int N, int M, int P, int C, int label0, float* out, void* stream);
+
+/* ---- data-parallel gradient exchange over RCCL / xGMI ------------------------------------------------
+ * The reference is single-process, single-device (phiseg_model.py:151-157); the data-parallel design shards the batch over
+ * ranks (one process per GPU) and exchanges ONE sum of the flat fp32 gradient arena per step.  RCCL is dlopen'ed on first use.
+ *   phx_comm_unique_id : rank 0 creates the 128-byte rendezvous id and hands it to the other ranks out of band
+ *                        (phiseg_code_amd/distributed.py broadcasts it through torch.distributed's store)
+ *   phx_comm_init      : every rank, with its HIP device current; world == 1 is valid (the all-reduce is the identity)
+ *   phx_comm_allreduce_sum_f32 : in-place sum of buf[0..n) over the ranks, split into bucket_elems-sized pieces (0: one piece)
+ *                        inside one RCCL group, ENQUEUED on `stream` (ordered after / before the work around it on that stream;
+ *                        nothing blocks the host)
+ * Errors: PHX_E_COMM with the RCCL error text in phx_last_error. */
+int phx_comm_unique_id(void* id128);
+int phx_comm_init(void** comm, int world, int rank, const void* id128);
+int phx_comm_allreduce_sum_f32(void* comm, float* buf, size_t n, size_t bucket_elems, void* stream);
+int phx_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

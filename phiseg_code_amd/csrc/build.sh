@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libphx.so
-SRCS="runtime.hip elementwise.hip losses_opt.hip conv_direct.hip conv_mfma.hip conv_pp.hip heads.hip metrics.hip"
+SRCS="runtime.hip elementwise.hip losses_opt.hip conv_direct.hip conv_mfma.hip conv_pp.hip heads.hip metrics.hip comm.hip"
 OBJS=""
 for s in $SRCS; do
   o="build_${s%.hip}.o"
@@ -13,5 +13,5 @@ for s in $SRCS; do
   OBJS="$OBJS $o"
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -ldl -o $OUT
 echo "built $(realpath $OUT)"

@@ -7,6 +7,7 @@ loss kernels already scale by 1/(B_local * world), so the sum IS the global-batc
 noise is keyed by the global sample index (rank * B_local + b), so results do not depend on the sharding.
 Batch-norm statistics stay per replica (standard DP semantics); group / instance norm are exactly
 sharding-invariant."""
+import ctypes
 import os
 
 import torch
@@ -23,6 +24,7 @@ class DistContext:
         if self.cuda:
             torch.cuda.set_device(self.local_rank % torch.cuda.device_count())
         self.active = self.world > 1 or force
+        self._comm = None
         if self.active and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
@@ -33,14 +35,51 @@ class DistContext:
                 kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, **kw)
 
+    def _native(self):
+        """The library's own RCCL communicator (phx_comm_*): rank 0 creates the rendezvous id, torch.distributed -- already up
+        for process bootstrap -- carries it to the other ranks.  Used on the GPU with the nccl backend (PHX_COMM=torch keeps
+        torch.distributed's collectives; gloo = several ranks on one GPU, where RCCL refuses duplicate devices)."""
+        if self._comm is None:
+            self._comm = False
+            if (self.active and self.cuda and dist.get_backend() == "nccl"
+                    and os.environ.get("PHX_COMM", "native") == "native"):
+                from phiseg_code_amd import runtime as rt
+                L = rt.lib()
+                idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if self.rank == 0:
+                    buf = ctypes.create_string_buffer(128)
+                    L.comm_unique_id(buf)
+                    idt.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+                dist.broadcast(idt, src=0)
+                raw = bytes(idt.cpu().numpy().tobytes())
+                comm = ctypes.c_void_p()
+                L.comm_init(ctypes.byref(comm), self.world, self.rank, raw)
+                self._comm = (L, comm)
+        return self._comm
+
     def allreduce_sum(self, tensor, plan=None, bucket_elems=8 << 20):
-        """Sum `tensor` (the flat gradient arena) over ranks, in ~32 MB buckets so RCCL pipelines them over
+        """Sum `tensor` (the live part of the flat gradient arena) over ranks, in ~32 MB buckets so RCCL pipelines them over
         the xGMI links.  `plan`: the engine plan whose stream produced the gradients and will consume the sums.
-        On the GPU nothing blocks the host: the collectives are enqueued against the plan's own HIP stream (wrapped
-        as a torch ExternalStream), so RCCL waits for the backward graph and the optimizer graph waits for RCCL."""
+        On the GPU nothing blocks the host: the collective is enqueued ON the plan's own HIP stream (phx_comm_allreduce_sum_f32),
+        so RCCL runs after the backward graph and the optimizer graph after RCCL."""
         if not self.active:
             return
         flat = tensor.view(-1)
+        native = self._native() if (self.cuda and plan is not None and flat.dtype == torch.float32) else False
+        if native:
+            L, comm = native
+            L.comm_allreduce_sum_f32(comm, flat.data_ptr(), flat.numel(), bucket_elems, plan.stream_handle())
+            return
+        if dist.get_backend() == "gloo" and flat.is_cuda:
+            # protocol tests (several ranks on one GPU): stage through the host
+            if plan is not None:
+                plan.sync()
+            torch.cuda.synchronize()
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+            torch.cuda.synchronize()
+            return
         if self.cuda and plan is not None:
             ext = torch.cuda.ExternalStream(int(plan.stream_handle()))
             with torch.cuda.stream(ext):
@@ -65,21 +104,35 @@ class DistContext:
     def max_float(self, v):
         if not self.active:
             return float(v)
-        t = torch.tensor([float(v)], dtype=torch.float64, device="cuda" if self.cuda else "cpu")
+        t = torch.tensor([float(v)], dtype=torch.float64, device=self._scalar_device())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def sum_float(self, v):
         if not self.active:
             return float(v)
-        t = torch.tensor([float(v)], dtype=torch.float64, device="cuda" if self.cuda else "cpu")
+        t = torch.tensor([float(v)], dtype=torch.float64, device=self._scalar_device())
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
+    def _scalar_device(self):
+        return "cuda" if (self.cuda and dist.get_backend() == "nccl") else "cpu"
+
     def broadcast_(self, tensor, src=0):
-        if self.active:
-            dist.broadcast(tensor, src=src)
+        if not self.active:
+            return
+        if dist.get_backend() == "gloo" and tensor.is_cuda:
+            host = tensor.cpu()
+            dist.broadcast(host, src=src)
+            tensor.copy_(host)
+            torch.cuda.synchronize()
+            return
+        dist.broadcast(tensor, src=src)
 
     def shutdown(self):
+        if self._comm:
+            L, comm = self._comm
+            L.comm_destroy(comm)
+            self._comm = None
         if self.active and dist.is_initialized():
             dist.destroy_process_group()

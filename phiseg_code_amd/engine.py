@@ -49,6 +49,25 @@ def _device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def live_variables(loss):
+    """Names of the variables the scalar `loss` depends on (TF: the variables optimizer.minimize gets a gradient for)."""
+    seen, live, stack = set(), set(), [loss.op]
+    while stack:
+        op = stack.pop()
+        if op in seen:
+            continue
+        seen.add(op)
+        if op.type == "conv_unit":
+            a = op.attrs
+            for v in (a["W"], a["b"]):
+                if v is not None:
+                    live.add(v.name)
+            for v in (a.get("norm_vars") or {}).values():
+                live.add(v.name)
+        stack.extend(i.op for i in op.inputs)
+    return live
+
+
 def device_sync():
     """Order work enqueued through torch (parameter loads, lr / step updates, broadcasts) before plan replays, which run on
     the plans' own non-blocking HIP streams."""
@@ -83,18 +102,30 @@ class Buf:
 class ParamStore:
     """Flat arenas for every variable of a graph (created once, shared by all plans of a model)."""
 
-    def __init__(self, graph, seed=0):
+    def __init__(self, graph, seed=0, live=None):
+        """live: names of the trainable variables the loss depends on (live_variables()).  They are laid out FIRST, so the
+        data-parallel exchange sums grads[:n_live] only -- the never-consumed up-sampling branches of the reference's zoo
+        (887 808 parameters) get no gradient and need no reduction."""
         self.graph = graph
         self.offset, self.state_offset = {}, {}
         off = soff = 0
-        for name, v in graph.variables.items():
+        names = list(graph.variables)
+        if live is not None:
+            names = [n for n in names if n in live] + [n for n in names if n not in live]
+        self.n_live = None
+        for name in names:
+            v = graph.variables[name]
             if v.trainable:
+                if live is not None and name not in live and self.n_live is None:
+                    self.n_live = off
                 self.offset[name] = off
                 off += (v.size + 3) // 4 * 4
             else:
                 self.state_offset[name] = soff
                 soff += (v.size + 3) // 4 * 4
         self.n_train, self.n_state = off, soff
+        if self.n_live is None:
+            self.n_live = off
         dev = _device()
         self.params = torch.zeros(max(off, 4), dtype=torch.float32, device=dev)
         self.grads = torch.zeros_like(self.params)

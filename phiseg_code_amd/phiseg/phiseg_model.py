@@ -58,7 +58,8 @@ class Session:
 
     def _ensure_store(self):
         if self.store is None:
-            self.store = engine.ParamStore(self.model.graph, seed=self.model.init_seed)
+            self.store = engine.ParamStore(self.model.graph, seed=self.model.init_seed,
+                                           live=engine.live_variables(self.model.loss_tot))
             if self.dist is not None and self.dist.active:
                 # identical replicas (the Philox initialiser already gives every rank the same values; this also covers
                 # weights loaded on one rank only)
@@ -109,7 +110,7 @@ class Session:
         dp = self.dist is not None and self.dist.active
         if train and dp:
             plan.run_main()
-            self.dist.allreduce_sum(self.store.grads, plan)
+            self.dist.allreduce_sum(self.store.grads[:self.store.n_live], plan)
             plan.run_opt()
         else:
             plan.run()

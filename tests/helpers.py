@@ -12,7 +12,11 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def load_golden(name):
-    g = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    alt = os.environ.get("PHX_TEST_GOLDEN_DIR")          # derived fixtures written by a test (e.g. a doubled batch)
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    if alt and os.path.exists(os.path.join(alt, name + ".npz")):
+        path = os.path.join(alt, name + ".npz")
+    g = np.load(path)
     cfg = json.loads(str(g["meta/cfg_json"]))
     cfg["image_size"] = (cfg["H"], cfg["H"], 1)
     var_order = [(n, tuple(s)) for n, s in json.loads(str(g["meta/var_order_json"]))]

@@ -845,3 +845,25 @@ def test_abi_rejects_bad_arguments_loudly(L):
     with pytest.raises(PhxError, match="empty job list"):
         L.wgrad_reduce_multi(None, 0, 0, S())
     torch.cuda.synchronize()
+
+
+def test_comm_abi_single_rank_rccl(L):
+    """phx_comm_* on RCCL with a world of one (the only world a 1-GPU box offers): rendezvous id, communicator, a bucketed
+    in-place all-reduce enqueued on a HIP stream (identity for one rank), teardown; bad arguments are rejected."""
+    import ctypes
+    from phiseg_code_amd import runtime as rt
+    idbuf = ctypes.create_string_buffer(128)
+    L.comm_unique_id(idbuf)
+    assert any(idbuf.raw)
+    comm = ctypes.c_void_p()
+    L.comm_init(ctypes.byref(comm), 1, 0, idbuf.raw)
+    x = torch.randn(1 << 20, device="cuda")
+    ref = x.clone()
+    L.comm_allreduce_sum_f32(comm, x.data_ptr(), x.numel(), 1 << 18, S())
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    with pytest.raises(rt.PhxError):
+        L.comm_allreduce_sum_f32(None, x.data_ptr(), x.numel(), 0, S())
+    with pytest.raises(rt.PhxError):
+        L.comm_init(ctypes.byref(ctypes.c_void_p()), 2, 5, idbuf.raw)
+    L.comm_destroy(comm)
