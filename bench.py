@@ -27,7 +27,7 @@ F_TRAIN_GFLOP_PER_IMAGE = 75.08       # fwd 25.026 + dgr
 PEAK_BF16_TFLOPS = 2500.0             # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def make_config(batch, compute_dtype, exp="phiseg_7_5", image_size=128, nlabels=None):
+def make_config(batch, compute_dtype, exp="phiseg_7_5", image_size=128, nlabels=None, norm="batch"):
     base = importlib.import_module("phiseg_code_amd.phiseg.experiments." + exp)
     cfg = types.SimpleNamespace(**{k: getattr(base, k) for k in dir(base) if not k.startswith("_")})
     cfg.batch_size = batch
@@ -35,12 +35,20 @@ def make_config(batch, compute_dtype, exp="phiseg_7_5", image_size=128, nlabels=
     cfg.image_size = (image_size, image_size, 1)
     if nlabels:
         cfg.nlabels = nlabels
+    if norm != "batch":            # north_star names group / instance norm; every shipped experiment selects batch_norm
+        from phiseg_code_amd.tfwrapper import normalisation as tfnorm
+        cfg.layer_norm = {"group": tfnorm.group_norm2D, "instance": tfnorm.instance_norm2D}[norm]
     return cfg
 
 
 def cpu_baseline(batch=12, steps=2):
-    """The oracle (oracle/: port of the reference's TF 1.12 graph to torch-CPU, fp32) running the SAME training
-    step on the host cores: `steps` timed steps at batch 12 (the reference's own batch size) after one warm-up."""
+    """The oracle (oracle/: port of the reference's TF 1.12 graph to torch-CPU, fp32) running the SAME training step on the
+    host cores, from the SAME initial weights (seed 0, Philox stream contract) and the SAME synthetic images (seed 1234) as
+    the GPU leg: `steps` timed steps at batch 12 -- the reference's own batch size (phiseg_7_5.py:40) -- after one warm-up.
+    Two steps, not ten: a step takes ~14.5 s on the 128 host threads, so this is already a ~30 s sample (the bound asked of
+    a default bench run); the per-step time varies by < 2 % between steps (round 1: 0.82 / 0.89 images/s on two boxes).
+    Smaller batches are NOT a cheaper stand-in: at batch 2 the same port reaches only 0.32 images/s (the host threads
+    starve), which would understate the CPU path."""
     import numpy as np
     import torch
     from oracle import init as oinit
@@ -52,13 +60,27 @@ def cpu_baseline(batch=12, steps=2):
     var_specs = [(n, v.shape) for n, v in model.graph.variables.items()]
     params = otrain.make_params(var_specs, 0, torch.float32, perturbed=False)
     x, s = oinit.synthetic_batch(batch, 128, 2, 1234)
-    otrain.train_steps(params, [(x, s)], cfg, 42, lr=1e-3, n_steps=1, dtype=torch.float32)      # warm-up
+    first = otrain.train_steps(params, [(x, s)], cfg, 42, lr=1e-3, n_steps=1, dtype=torch.float32)      # warm-up (= step 0)
     t0 = time.time()
     otrain.train_steps(params, [(x, s)], cfg, 42, lr=1e-3, n_steps=steps, dtype=torch.float32)
     dt = time.time() - t0
     return {"value": batch * steps / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "first_step_loss": first[0]["total_loss"],
             "sample": "%d training steps (fwd+ELBO+autograd+Adam) of phiseg_7_5 128x128 at batch %d, torch-CPU fp32 "
-                      "oracle, %.1f s" % (steps, batch, dt)}
+                      "oracle, %.1f s; same initial weights and images as the GPU leg" % (steps, batch, dt)}
+
+
+def gpu_first_step_loss(args, batch=12):
+    """The GPU engine's ELBO of training step 0 on the CPU baseline's twelve images, initial weights and Philox noise (bf16):
+    the number to put next to cpu_baseline.first_step_loss."""
+    from phiseg_code_amd.data import synthetic
+    from phiseg_code_amd.phiseg import phiseg_model
+    cfg = make_config(batch, args.dtype)
+    model = phiseg_model.phiseg(cfg)
+    x, s = synthetic.philox_batch(batch, 128, cfg.nlabels, seed=1234)
+    _, loss = model.sess.run([model.train_step, model.loss_tot],
+                             {model.x_inp: x, model.s_inp: s, model.training_pl: True, model.lr_pl: 1e-3})
+    return float(loss)
 
 
 def main():
@@ -77,6 +99,11 @@ def main():
                     help="generate: Monte-Carlo sampling passes (prior sample + likelihood decode + softmax), config 5")
     ap.add_argument("--image-size", type=int, default=128)
     ap.add_argument("--nlabels", type=int, default=0, help="0: the experiment's own")
+    ap.add_argument("--norm", default="batch", choices=["batch", "group", "instance"],
+                    help="layer_norm of the experiment (every shipped experiment: batch; north_star also names group / instance)")
+    ap.add_argument("--samples-per-image", type=int, default=16,
+                    help="generate: Monte-Carlo samples drawn per image in one pass (the prior's x-only encoder is shared); "
+                         "0: one sample per image and pass, the reference's call pattern")
     args = ap.parse_args()
 
     import numpy as np
@@ -87,16 +114,22 @@ def main():
 
     ctx = distributed.DistContext(force=os.environ.get("PHX_FORCE_DIST") == "1")   # dev: exercise the split path on one GPU
     assert ctx.world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    cfg = make_config(args.batch, args.dtype, args.exp, args.image_size, args.nlabels)
+    generate = args.workload == "generate"
+    spi = args.samples_per_image if generate else 0
+    if generate and spi and args.exp.startswith("phiseg") and args.batch == 64:
+        args.batch = 1                    # BASELINE config 5: one image, 16 Monte-Carlo samples per pass
+    cfg = make_config(args.batch, args.dtype, args.exp, args.image_size, args.nlabels, args.norm)
     model = phiseg_model.phiseg(cfg, dist=ctx if ctx.active else None)
     sess = model.sess
-    generate = args.workload == "generate"
-    if generate:
+    if generate and spi and args.exp.startswith("phiseg"):
+        plan = sess.plan_for([model.sampling_graph(spi)[1]], False, args.batch, False)
+    elif generate:
+        spi = 0
         plan = sess.plan_for([model.s_out_eval_sm], False, args.batch, False)
     else:
         plan = sess.plan_for([model.loss_tot], True, args.batch, True)
-    rng = np.random.default_rng(1234 + ctx.rank)
-    x, s = synthetic.make_batch(args.batch, args.image_size, cfg.nlabels, rng)
+    # seeded Philox inputs: rank r draws samples [r * batch, (r + 1) * batch) of the global batch (seed 1234)
+    x, s = synthetic.philox_batch(args.batch, args.image_size, cfg.nlabels, seed=1234, sample_offset=ctx.rank * args.batch)
     plan.set_input("x_input", x)          # resident in HBM for the whole run
     if not generate:
         plan.set_input("s_input", s)
@@ -130,7 +163,7 @@ def main():
     ctx.barrier()
     dt = ctx.max_float(time.perf_counter() - t0)
     loss = None if generate else float(plan.fetch(model.loss_tot))
-    images = args.batch * ctx.world * args.steps
+    images = args.batch * max(spi, 1) * ctx.world * args.steps
     out = {
         "metric": ("segmentation samples/sec (prior sample + likelihood decode) %s %dx%d" % (args.exp, args.image_size, args.image_size))
                   if generate else "training images/sec (ELBO step) %s %dx%d LIDC" % (args.exp, args.image_size, args.image_size),
@@ -138,12 +171,13 @@ def main():
         "unit": "images/s", "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": ("%s %dx%dx1, %d classes, %s, batch %d per GPU, one sampling pass per step (prior sample + "
-                                "likelihood decode + softmax)" % (args.exp, args.image_size, args.image_size, cfg.nlabels,
-                                                                  args.dtype, args.batch)) if generate else
-                               "%s LIDC %dx%dx1, %d classes, %s, batch %d per GPU, full ELBO training step "
+        "config": {"workload": ("%s %dx%dx1, %d classes, %s, %d image(s) per GPU and pass, %s (prior sample + likelihood decode + "
+                                "softmax)" % (args.exp, args.image_size, args.image_size, cfg.nlabels, args.dtype, args.batch,
+                                              ("%d Monte-Carlo samples per image in one pass, the prior's x-only encoder shared" % spi)
+                                              if spi else "one sample per image")) if generate else
+                               "%s LIDC %dx%dx1, %d classes, %s, %s norm, batch %d per GPU, full ELBO training step "
                                "(fwd + CE + KL + bwd + Adam%s)" % (args.exp, args.image_size, args.image_size, cfg.nlabels,
-                                                                   args.dtype, args.batch,
+                                                                   args.dtype, args.norm, args.batch,
                                                                    " + RCCL grad all-reduce" if ctx.world > 1 else ""),
                    "global_batch": args.batch * ctx.world, "parallelism": "dp%d" % ctx.world,
                    "launches_per_step": len(plan.launches) + len(plan.opt_launches), "final_loss": loss},
@@ -188,8 +222,8 @@ def main():
         # corrected as MI355X_MICROARCH.md prescribes; see profiles/r01_pmc_hbm_traffic_final.txt): bytes per launch
         traffic = None
         try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_final.json")))
-            ks = [v for k, v in pj.items() if k.startswith("void k_conv3x3_mfma<")]
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")) else "r01_pmc_hbm_traffic_final.json")))
+            ks = [v for k, v in pj.items() if k.startswith("void k_conv3x3_mfma<") or k.startswith("void k_conv3x3_fwd_dma128<")]
             calls = sum(v["calls_per_step"] for v in ks)
             traffic = 1e6 * sum(v["fetch_x2_MB_per_step"] + v["write_MB_per_step"] for v in ks) / calls
         except Exception:
@@ -200,9 +234,9 @@ def main():
                 Bq, Hq, Wq, Kq, Nq = shp[-5:]
                 alg_bytes += 2.0 * Bq * Hq * Wq * (Kq + Nq) + 18.0 * Kq * Nq
         out["roofline"] = {
-            "bound": "mfma", "kernel": "k_conv3x3_mfma<BN> (forward + data-gradient launches of one step)",
+            "bound": "mfma", "kernel": "k_conv3x3_mfma<BN> / k_conv3x3_fwd_dma128 (forward + data-gradient launches of one step)",
             "achieved": fl / ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS,
-            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, separate passes; profiles/r01_pmc_hbm_traffic_final.txt)",
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 passes; profiles/r0x_pmc_hbm_traffic*.txt)",
             "algorithmic_bytes_per_launch_avg": alg_bytes / max(nl, 1),
             "launches": nl, "avg_launch_ms": ms / max(nl, 1),
             "algorithmic_gflop_per_launch_avg": fl / max(nl, 1) / 1e9,
@@ -210,8 +244,9 @@ def main():
             "conv_ms_per_step": sum(v[1] for v in fam.values()),
         }
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline and not generate and args.exp == "phiseg_7_5" \
-            and args.image_size == 128:
+            and args.image_size == 128 and args.norm == "batch":
         out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"]["gpu_first_step_loss_same_inputs"] = gpu_first_step_loss(args)
     if ctx.rank == 0:
         out["config"]["hbm_peak_allocated_gb"] = torch.cuda.max_memory_allocated() / 2 ** 30
     ctx.barrier()              # the other ranks wait for rank 0's extra measurements before tearing RCCL down

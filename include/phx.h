@@ -96,6 +96,12 @@ size_t phx_conv3x3_mfma_ws_bytes(int B, int H, int W, int K, int N);
 int phx_conv3x3_mfma_ksplit(int B, int H, int W, int K, int N);
 int phx_conv3x3_mfma_bf16_ws(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
                              void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream);
+/* Convolution with an AFFINE epilogue: y = act(conv(x) * scale[n] + shift[n]) -- inference-mode batch norm
+ * (normalisation.py:145-163 with is_training = False: y = gamma (x - moving_mean) / sqrt(moving_var + eps) + beta) and its
+ * activation folded into the convolution that feeds it: one launch where the reference runs conv2d, batch_norm and relu.
+ * scale / shift: phx_bn_infer_scale_shift(_multi).  workspace as for phx_conv3x3_mfma_bf16_ws (may be NULL / 0). */
+int phx_conv3x3_mfma_bf16_affine(const void* x, const void* wpk, void* y, const float* scale, const float* shift, int act,
+                                 void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream);
 /* Data-gradient launch with the batch-norm backward statistics of the PRODUCER layer fused into its epilogue: dA (the
  * gradient w.r.t. a = act(bn(y_prod)), [B,H,W,N] bf16) is written as by phx_conv3x3_mfma_bf16(dy, wpk_dgrad, dA, ...), and
  * stats2_partial[tiles][2][N] receives per pixel tile {sum g, sum g * xhat}, g = dA * act'(y_prod * scale + shift),
@@ -174,6 +180,13 @@ int phx_norm_finalize(const float* sums, const float* pivot, const float* gamma,
 /* inference-mode batch norm: scale/shift from the moving statistics */
 int phx_bn_infer_scale_shift(const float* gamma, const float* beta, const float* moving_mean,
                              const float* moving_var, float eps, int C, float* scale, float* shift, void* stream);
+/* all inference-mode batch-norm layers of a plan in ONE launch: descs_dev = n records {const float* gamma, beta, moving_mean,
+ * moving_var; float* scale, shift; int C; float eps} (48 bytes, device memory) */
+/* out[b * n + k] = x[b] (k < n): a feature map repeated for the n Monte-Carlo samples drawn per image -- lets the sampling path
+ * run the x-only part of the prior (priors.py:80-95, 6.2 of 49.2 GFLOP per sample at 192 x 192) ONCE per image where the
+ * reference's np.tile(x, [n,1,1,1]) (phiseg_model.py:577-585) recomputes it n times */
+int phx_repeat_batch(const void* x, void* out, int B, size_t bytes_per_sample, int n, void* stream);
+int phx_bn_infer_scale_shift_multi(const void* descs_dev, int n, void* stream);
 int phx_affine_act(const void* x, int x_dt, const float* scale, const float* shift, void* y, int y_dt,
                    int NS, int P, int C, int act, void* stream);
 /* fused forms used by the engine: finalize + affine_act in one launch (every thread re-derives the statistics of its

@@ -261,6 +261,7 @@ struct BwdStats {
     const float *scale, *shift, *mean, *rstd;
     float* part;
     int act, _pad;
+    const float* oscale;      // per-output-channel scale of the bias / activation epilogue (inference-mode batch norm folded in)
 };
 
 // NA = compile-time bound on the 16-byte input-patch pieces a thread stages per 32-channel chunk
@@ -513,10 +514,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
 #pragma unroll                                       // code costs the common kernels neither registers nor issue slots
             for (int j = 0; j < NJ; ++j) {
                 const float bv = bias ? bias[n0 + j * 32 + l31] : 0.f;
+                const float sv = bws.oscale ? bws.oscale[n0 + j * 32 + l31] : 1.f;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r] + bv, act);
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(fmaf(acc[i][j][r], sv, bv), act);
             }
         }
         // Lane pairs (channels n, n+1) trade one of two rows so that each lane writes ONE 32-bit word {ch n, ch n+1} per
@@ -1458,7 +1460,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
                                                              const unsigned short* __restrict__ wpk,
                                                              unsigned short* __restrict__ y, const float* __restrict__ bias,
                                                              int act, float* __restrict__ stats_partial,
-                                                             int B, int H, int W, int K, int N, int tiles_x, int tiles_y, int dephase) {
+                                                             int B, int H, int W, int K, int N, int tiles_x, int tiles_y, int dephase, const float* __restrict__ oscale) {
     constexpr int BN = 64;
     constexpr int AI = 39, BI = 36;                   // 1 KiB DMA instructions per chunk: 612 patch rows x 64 B, 576 slab rows
     constexpr int NLW = 4;
@@ -1610,10 +1612,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float bv = bias ? bias[n0 + j * 32 + l31] : 0.f;
+                const float sv = oscale ? oscale[n0 + j * 32 + l31] : 1.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r] + bv, act);
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(fmaf(acc[i][j][r], sv, bv), act);
             }
         }
         unsigned char* lwp = smem + (wave * 128 + 4 * khalf + odd) * OROW + (l31 & ~1) * 2;
@@ -2244,15 +2247,15 @@ __global__ void k_wgrad_reduce_multi(const WgrJob* __restrict__ jobs, int njobs)
 
 // y[pix][n] = bf16(act(sum_z ws[z][pix][n] + bias[n])), four channels per thread
 __global__ void k_splitk_finish(const float* __restrict__ ws, int nz, size_t total, int N, const float* __restrict__ bias,
-                                int act, unsigned short* __restrict__ y) {
+                                int act, unsigned short* __restrict__ y, const float* __restrict__ oscale) {
     for (size_t i4 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i4 * 4 < total; i4 += (size_t)gridDim.x * blockDim.x) {
         const size_t i = i4 * 4;
         f32x4 a = *reinterpret_cast<const f32x4*>(ws + i);
         for (int z = 1; z < nz; ++z) a += *reinterpret_cast<const f32x4*>(ws + (size_t)z * total + i);
-        if (bias != nullptr || act != PHX_ACT_ID) {
+        if (bias != nullptr || act != PHX_ACT_ID || oscale != nullptr) {
             const int n = (int)(i % N);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = act_fwd(a[q] + (bias ? bias[n + q] : 0.f), act);
+            for (int q = 0; q < 4; ++q) a[q] = act_fwd(fmaf(a[q], oscale ? oscale[n + q] : 1.f, bias ? bias[n + q] : 0.f), act);
         }
         uint2 o;
         o.x = f2bf_pk(a[0], a[1]);
@@ -2381,12 +2384,22 @@ int phx_conv3x3_mfma_bf16_ws(const void* x, const void* wpk, void* y, const floa
     return conv3x3_mfma_impl(x, wpk, y, bias, act, stats_partial, workspace, workspace_bytes, B, H, W, K, N, BwdStats{}, stream);
 }
 
+int phx_conv3x3_mfma_bf16_affine(const void* x, const void* wpk, void* y, const float* scale, const float* shift, int act,
+                                 void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream) {
+    PHX_REQUIRE(scale != nullptr && shift != nullptr, PHX_E_INVAL, "conv3x3_mfma_affine: scale and shift are required");
+    PHX_REQUIRE(!fwd_rs_bn(B, H, W, K, N) && !fwd_dma_bn(B, H, W, K, N), PHX_E_INVAL,
+                "conv3x3_mfma_affine: not implemented in the experimental rs / dma forward kernels");
+    BwdStats b{};
+    b.oscale = scale;
+    return conv3x3_mfma_impl(x, wpk, y, shift, act, nullptr, workspace, workspace_bytes, B, H, W, K, N, b, stream);
+}
+
 int phx_conv3x3_mfma_bf16_bwdstats(const void* dy, const void* wpk_dgrad, void* dA, const void* y_prod, const float* scale,
                                    const float* shift, const float* mean, const float* rstd, int act_prod,
                                    float* stats2_partial, int B, int H, int W, int K, int N, void* stream) {
     PHX_REQUIRE(fwd_bws_ok(B, H, W, K, N), PHX_E_SHAPE, "conv3x3_mfma_bwdstats: shape not supported (see ..._supported)");
     PHX_REQUIRE(y_prod && scale && shift && mean && rstd && stats2_partial, PHX_E_INVAL, "conv3x3_mfma_bwdstats: null argument");
-    BwdStats b;
+    BwdStats b{};
     b.y = (const unsigned short*)y_prod; b.scale = scale; b.shift = shift; b.mean = mean; b.rstd = rstd;
     b.part = stats2_partial; b.act = act_prod; b._pad = 0;
     return conv3x3_mfma_impl(dy, wpk_dgrad, dA, nullptr, PHX_ACT_ID, nullptr, nullptr, 0, B, H, W, K, N, b, stream);
@@ -2405,10 +2418,12 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
     }
     PHX_REQUIRE(y != nullptr || (ksplit > 1 && !bias && act == PHX_ACT_ID), PHX_E_INVAL,
                 "conv3x3_mfma: y == NULL only for a split-K launch without bias / activation (slices left in the workspace)");
-    if (bws.part == nullptr && ksplit == 1 && phx_pp_eligible(B, H, W, K, N))
+    if (bws.part == nullptr && bws.oscale == nullptr && ksplit == 1 && phx_pp_eligible(B, H, W, K, N))
         return phx_pp_launch(x, wpk, y, bias, act, stats_partial, B, H, W, K, N, stream);
     if (fwd_ws64(B, H, W, K, N)) {
-        const bool ba = bias != nullptr || act != PHX_ACT_ID;
+        const bool ba = bias != nullptr || act != PHX_ACT_ID || bws.oscale != nullptr;
+        const int wsm0 = fwd_ws_mode();
+        PHX_REQUIRE(bws.oscale == nullptr || wsm0 == 1 || wsm0 == 5, PHX_E_INVAL, "conv3x3_mfma: the affine epilogue is not implemented in the experimental ws64 / ws128 kernels");
         static bool wattr = false;
         if (!wattr) {
             PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_ws64<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2427,7 +2442,7 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
         PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_dma128<Av, Dv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((k_conv3x3_fwd_dma128<Av, Dv>), dim3(ntl * (N / 64)), dim3(256), 75 * 1024 + 16, (hipStream_t)stream,      \
                            (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, \
-                           H, W, K, N, W / 32, H / 16, dephase);                                                                \
+                           H, W, K, N, W / 32, H / 16, dephase, bws.oscale);                                                    \
     } while (0)
             const char* dpe = getenv("PHX_DEPHASE");
             const int dephase = dpe ? atoi(dpe) : 0;
@@ -2531,7 +2546,7 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
 #undef CM_ATTR1
     const int na = (npatch * 4 + 255) / 256;
     PHX_REQUIRE(na <= 16, PHX_E_SHAPE, "conv3x3_mfma: unexpected tile geometry");
-    const bool biasact = bias != nullptr || act != PHX_ACT_ID;
+    const bool biasact = bias != nullptr || act != PHX_ACT_ID || bws.oscale != nullptr;
     // (the OROW-pitched epilogue tile also has to fit: NT * (2 BN + 16) bytes)
 #define CM_LAUNCH1(BNv, NAv, Fv, Av, NWv, Sv)                                                                          \
     do {                                                                                                             \
@@ -2575,7 +2590,7 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
     if (ksplit > 1 && y != nullptr) {                // (y == NULL: the caller consumes the fp32 slices itself)
         const size_t total = (size_t)B * H * W * N;
         hipLaunchKernelGGL(k_splitk_finish, dim3(phx_grid_for(total / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)workspace, ksplit, total, N, bias, act, (unsigned short*)y);
+                           (const float*)workspace, ksplit, total, N, bias, act, (unsigned short*)y, bws.oscale);
         PHX_CHECK_LAUNCH();
     }
     return PHX_OK;

@@ -328,7 +328,10 @@ static int norm_geometry(int P, int C, int V, int* PL, int* threads, int* chunk,
     int want = (rows + ppt_n - 1) / ppt_n;                    // 8 pixels per thread on big maps (re-measured under the two-lane schedule)
     static int fl = 0;
     if (!fl) { const char* e = getenv("PHX_NORM_FLOOR"); fl = e ? atoi(e) : 128; }      // tuning hook (measured: tools/bench_norm.py)
-    int floor_blocks = rows < fl ? rows : fl;
+    // (the floor counts blocks of the whole launch: with per-sample statistics, NS > 1, every sample gets its share -- a
+    // floor per SAMPLE cut the 128 x 128 group-norm layers into thousands of blocks of two pixels per thread: 62 us vs 19)
+    const int fl_ns = (fl + (NS > 0 ? NS : 1) - 1) / (NS > 0 ? NS : 1);
+    int floor_blocks = rows < fl_ns ? rows : fl_ns;
     if (want < floor_blocks) want = floor_blocks;
     static int capv = 0;
     if (!capv) { const char* e = getenv("PHX_NORM_CAP"); capv = e ? atoi(e) : 1024; }    // tuning hook
@@ -354,7 +357,10 @@ static int stream_geometry(int P, int C, int V, int* PL, int* threads, int* chun
     int want = (rows + ppt_s - 1) / ppt_s;
     static int fl = 0;
     if (!fl) { const char* e = getenv("PHX_STREAM_FLOOR"); fl = e ? atoi(e) : 256; }    // tuning hook (measured: tools/bench_norm.py)
-    int floor_blocks = rows < fl ? rows : fl;
+    // (the floor counts blocks of the whole launch: with per-sample statistics, NS > 1, every sample gets its share -- a
+    // floor per SAMPLE cut the 128 x 128 group-norm layers into thousands of blocks of two pixels per thread: 62 us vs 19)
+    const int fl_ns = (fl + (NS > 0 ? NS : 1) - 1) / (NS > 0 ? NS : 1);
+    int floor_blocks = rows < fl_ns ? rows : fl_ns;
     if (want < floor_blocks) want = floor_blocks;
     int cap = 8192 / (NS > 0 ? NS : 1);
     if (cap < 1) cap = 1;
@@ -429,6 +435,21 @@ __global__ void k_bn_infer_scale_shift(const float* gamma, const float* beta, co
     const float sc = gamma[c] * rsqrtf(mv[c] + eps);
     scale[c] = sc;
     shift[c] = beta[c] - mm[c] * sc;
+}
+
+struct BnInferDesc {
+    const float *gamma, *beta, *mm, *mv;
+    float *scale, *shift;
+    int C;
+    float eps;
+};
+__global__ void k_bn_infer_scale_shift_multi(const BnInferDesc* __restrict__ descs) {
+    const BnInferDesc d = descs[blockIdx.y];
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < d.C; c += gridDim.x * blockDim.x) {
+        const float sc = d.gamma[c] * rsqrtf(d.mv[c] + d.eps);
+        d.scale[c] = sc;
+        d.shift[c] = d.beta[c] - d.mm[c] * sc;
+    }
 }
 
 // y = act(x*scale[ns][c] + shift[ns][c]).  A thread owns one channel vector (cv) and walks over pixels, so the
@@ -968,6 +989,43 @@ __global__ void k_channel_sum(const T* __restrict__ x, float* __restrict__ out, 
     __syncthreads();
     if (prow == 0 && c < C) atomicAdd(&out[c], sh[threadIdx.x] + sh[threadIdx.x + 64] + sh[threadIdx.x + 128] + sh[threadIdx.x + 192]);
 }
+// the same sum, 16-byte loads: block = (C / 8 channel vectors) x PL pixel lanes, a chunk of pixels per block
+template <typename T>
+__global__ void k_channel_sum_v8(const T* __restrict__ x, float* __restrict__ out, size_t npix, int C, int PL, size_t chunk) {
+    const int CV = C / 8;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    extern __shared__ float red[];   // [PL][C]
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    const size_t p0 = blockIdx.x * chunk, p1 = min(npix, p0 + chunk);
+    if (pl < PL) {
+        size_t p = p0 + pl;
+        for (; p + 3 * (size_t)PL < p1; p += 4 * (size_t)PL) {
+            float v[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) VecIO<T, 8>::load(x, (p + (size_t)u * PL) * C + (size_t)cv * 8, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] += v[u][j];
+        }
+        for (; p < p1; p += PL) {
+            float v[8];
+            VecIO<T, 8>::load(x, p * C + (size_t)cv * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[pl * C + cv * 8 + j] = a[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+        float t = 0.f;
+        for (int q = 0; q < PL; ++q) t += red[q * C + i];
+        atomicAdd(&out[i], t);
+    }
+}
 template <typename TI, typename TO>
 __global__ void k_cast(const TI* __restrict__ src, TO* __restrict__ dst, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -1062,6 +1120,14 @@ int phx_bn_infer_scale_shift(const float* gamma, const float* beta, const float*
                              float eps, int C, float* scale, float* shift, void* stream) {
     hipLaunchKernelGGL(k_bn_infer_scale_shift, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, gamma, beta,
                        moving_mean, moving_var, eps, C, scale, shift);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_bn_infer_scale_shift_multi(const void* descs_dev, int n, void* stream) {
+    if (n <= 0) return PHX_OK;
+    PHX_REQUIRE(descs_dev != nullptr, PHX_E_INVAL, "bn_infer_scale_shift_multi: null descriptor table");
+    hipLaunchKernelGGL(k_bn_infer_scale_shift_multi, dim3(2, n), dim3(128), 0, (hipStream_t)stream, (const BnInferDesc*)descs_dev);
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }
@@ -1266,6 +1332,21 @@ int phx_add_inplace(void* dst, const void* src, size_t n, int dt, void* stream) 
     return PHX_OK;
 }
 int phx_channel_sum_accumulate(const void* x, int dt, float* out, size_t npix, int C, void* stream) {
+    if (C % 8 == 0 && C / 8 <= 256 && npix >= 64) {
+        const int CV = C / 8, PL = 256 / CV, threads = CV * PL;
+        size_t rows = (npix + PL - 1) / PL;
+        size_t want = (rows + 31) / 32;                   // ~32 pixels per thread, at least 64 and at most 1024 blocks
+        if (want < 64) want = rows < 64 ? rows : 64;
+        if (want > 1024) want = 1024;
+        const size_t chunk = (npix + want - 1) / want;
+        const int nchunks = (int)((npix + chunk - 1) / chunk);
+        PHX_DT_SWITCH(dt, T, {
+            hipLaunchKernelGGL((k_channel_sum_v8<T>), dim3(nchunks), dim3(threads), (size_t)PL * C * sizeof(float), (hipStream_t)stream,
+                               (const T*)x, out, npix, C, PL, chunk);
+        });
+        PHX_CHECK_LAUNCH();
+        return PHX_OK;
+    }
     int gx = (int)((npix + 63) / 64);
     if (gx > 256) gx = 256;
     if (gx < 1) gx = 1;
@@ -1300,6 +1381,22 @@ int phx_global_avgpool_fwd(const float* x, float* y, int B, int P, int C, void* 
 int phx_global_avgpool_bwd(const float* dy, float* dx, int B, int P, int C, void* stream) {
     const size_t n = (size_t)B * P * C;
     hipLaunchKernelGGL(k_gap_bwd, dim3(phx_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, dx, P, C, n);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+// out[b * n + k][:] = x[b][:] for k < n: every image's feature map repeated for its n Monte-Carlo samples (16-byte pieces)
+__global__ void k_repeat_rows16(const uint4* __restrict__ x, uint4* __restrict__ out, size_t per16, int n, size_t total16) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total16; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / per16, e = i - row * per16;
+        out[i] = x[(row / n) * per16 + e];
+    }
+}
+int phx_repeat_batch(const void* x, void* out, int B, size_t bytes_per_sample, int n, void* stream) {
+    PHX_REQUIRE(bytes_per_sample % 16 == 0 && n >= 1, PHX_E_SHAPE, "repeat_batch: sample size must be a multiple of 16 bytes");
+    PHX_REQUIRE((((uintptr_t)x | (uintptr_t)out) & 15) == 0, PHX_E_ALIGN, "repeat_batch: 16-byte alignment");
+    const size_t per16 = bytes_per_sample / 16, total16 = per16 * B * n;
+    hipLaunchKernelGGL(k_repeat_rows16, dim3(phx_grid_for(total16, 256)), dim3(256), 0, (hipStream_t)stream, (const uint4*)x,
+                       (uint4*)out, per16, n, total16);
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }

@@ -22,6 +22,29 @@ def make_batch(batch, size, nlabels, rng):
     return x, s
 
 
+def philox_batch(batch, size, nlabels, seed=1234, step=0, sample_offset=0):
+    """The same kind of batch from the build's Philox streams (philox_host): sample g = sample_offset + b of (seed, step)
+    depends on nothing else, so every rank of a data-parallel job -- and the CPU baseline -- can draw exactly its shard.
+    x [B,H,W,1] ~ U(-0.5, 0.5); s: nested filled ellipses (label k inside the k-th), 25 % empty masks."""
+    from phiseg_code_amd import philox_host
+    h = w = size
+    yy, xx = np.mgrid[0:h, 0:w]
+    xs, ss = [], []
+    for b in range(batch):
+        u = philox_host.uniforms(seed, step, 1000 + b + sample_offset, h * w + 8)
+        xs.append((u[:h * w] - 0.5).astype(np.float32).reshape(h, w, 1))
+        p = u[h * w:]
+        s = np.zeros((h, w), dtype=np.uint8)
+        if p[0] >= 0.25:
+            cy, cx = (0.3125 + 0.375 * p[1]) * h, (0.3125 + 0.375 * p[2]) * w
+            ry, rx = (3 + 17 * p[3]) * h / 128.0, (3 + 17 * p[4]) * w / 128.0
+            for k in range(1, nlabels):
+                f = 1.0 - (k - 1) / float(nlabels - 1) if nlabels > 2 else 1.0
+                s[((yy - cy) / (ry * f)) ** 2 + ((xx - cx) / (rx * f)) ** 2 <= 1.0] = k
+        ss.append(s)
+    return np.stack(xs), np.stack(ss)
+
+
 class _Split:
     def __init__(self, size, nlabels, seed):
         self.size, self.nlabels = size, nlabels

@@ -262,6 +262,7 @@ class Plan:
         self._headw_jobs = {}         # deferred 1x1-head filter gradients by (x dtype, nout): (x, dy, dw, db, npix, C, PL, chunk, grid, lds)
         self._wgr_jobs = []           # deferred filter-gradient reductions: (ws, dw, nslice, Cin, Cout, tci, tco, gx, gy)
         self._pack_jobs = []          # (w, wpk_fwd, wpk_dgrad, Cin, Cin_pad, Cout): ONE multi-filter pack launch per run
+        self._bninfer_jobs = []       # (gamma, beta, moving_mean, moving_var, scale, shift, C, eps): ONE launch per run
         self._zarena = torch.zeros(8 << 20, dtype=torch.float32, device=_device())     # 32 MB of per-step accumulators
         self._zused = 0
         self.fetches = list(fetches)
@@ -411,7 +412,7 @@ class Plan:
         return {G.KIND_ACT: self.act_dt, G.KIND_F32: F32, G.KIND_U8: U8}[t.kind]
 
     def _cshape(self, t):
-        return tuple(self.B if s is None else s for s in t.shape)
+        return tuple(self.B * getattr(t, "bmul", 1) if s is None else s for s in t.shape)
 
     def _alloc_like(self, t, zero=False):
         return self._alloc(self._cshape(t), self._dt_of(t), zero=zero)
@@ -449,6 +450,7 @@ class Plan:
         self._lane = 0
         self._emit(self.L.memset, self._zarena.data_ptr(), 0, 4, self.stream)       # size patched below
         self._emit(self.L.memset, self._zarena.data_ptr(), 0, 4, self.stream)       # slot 1: multi-filter pack, patched below
+        self._emit(_noop)                                                            # slot 2: inference-mode batch-norm scale / shift of all layers
         if with_bw:
             self._emit(self.L.memset, self.store.grads.data_ptr(), 0, self.store.grads.numel() * 4, self.stream)
         nl = len(self._lanes)
@@ -523,6 +525,14 @@ class Plan:
             self._pack_desc = torch.from_numpy(rec.view(np.uint8).copy()).to(_device())
             self._keep.append(self._pack_desc)
             self.launches[1] = (self.L.pack_conv3x3_bf16_multi, (self._pack_desc.data_ptr(), len(self._pack_jobs), self.stream))
+        if self._bninfer_jobs:        # slot 2: scale / shift of every inference-mode batch-norm layer in one launch
+            rec = np.zeros(len(self._bninfer_jobs), dtype=[("gamma", "<u8"), ("beta", "<u8"), ("mm", "<u8"), ("mv", "<u8"),
+                                                            ("scale", "<u8"), ("shift", "<u8"), ("C", "<i4"), ("eps", "<f4")])
+            for i, j in enumerate(self._bninfer_jobs):
+                rec[i] = j
+            self._bninfer_desc = torch.from_numpy(rec.view(np.uint8).copy()).to(_device())
+            self._keep.append(self._bninfer_desc)
+            self.launches[2] = (self.L.bn_infer_scale_shift_multi, (self._bninfer_desc.data_ptr(), len(self._bninfer_jobs), self.stream))
         if self.optimize:
             if self.split_optimizer:
                 self._cur = self.opt_launches
@@ -661,6 +671,19 @@ class Plan:
         scale, shift = self._alloc((NS * cout,), F32), self._alloc((NS * cout,), F32)
         mean, rstd = self._alloc((NS * Gn,), F32), self._alloc((NS * Gn,), F32)
         eps = tfnorm.EPS[norm]
+        if norm == "batch" and not training and mfma and not head1x1 and not bw and os.environ.get("PHX_BN_FOLD", "1") == "1":
+            # inference-mode batch norm + activation folded into the convolution's epilogue (phx_conv3x3_mfma_bf16_affine):
+            # one launch where the reference runs conv2d, batch_norm and relu; the scale / shift vectors of all layers come
+            # from one launch at the head of the run
+            self._bninfer_jobs.append((gptr, beptr, self.store.ptr(nv["moving_mean"]), self.store.ptr(nv["moving_variance"]),
+                                       scale.ptr, shift.ptr, cout, eps))
+            wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cin_eff, cout))
+            ws = self._alloc((wsb // 4,), F32) if wsb else None
+            self._emit(Lb.conv3x3_mfma_bf16_affine, x.ptr, wf.ptr, out.ptr, scale.ptr, shift.ptr, act, ws.ptr if ws else None, wsb,
+                       B, H, Wd, cin_eff, cout, S, tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
+            st.update(scale=scale, shift=shift, NS=NS, P=P, G=Gn)
+            self.saved[op] = st
+            return
         if norm == "batch" and not training:
             self._emit(Lb.bn_infer_scale_shift, gptr, beptr, self.store.ptr(nv["moving_mean"]),
                        self.store.ptr(nv["moving_variance"]), eps, cout, scale.ptr, shift.ptr, S)
@@ -746,6 +769,17 @@ class Plan:
         self._emit(self.L.reparam_fwd, mu.ptr, sigma.ptr, z.ptr, mu.shape[0], per, self.rng_seed,
                    self._noise_step_ptr(), stream_id, self.sample_offset, self.stream)
         self.saved[op] = dict(mu_t=mu_t, sigma_t=sigma_t, per=per, stream_id=stream_id)
+
+    def _fw_tile_batch(self, op, bw):
+        x = self.val[op.inputs[0]]
+        out = self._alloc(self._cshape(op.outputs[0]), x.dt)
+        self.val[op.outputs[0]] = out
+        n = op.attrs["tile"]
+        assert out.shape[0] == x.shape[0] * n
+        self._emit(self.L.repeat_batch, x.ptr, out.ptr, x.shape[0], (x.n // x.shape[0]) * _ESIZE[x.dt], n, self.stream)
+
+    def _bw_tile_batch(self, op):
+        raise NotImplementedError("tile_batch is part of the sampling path only")
 
     def _fw_global_avgpool(self, op, bw):
         x = self._as_dt(self.val[op.inputs[0]], F32)

@@ -29,6 +29,7 @@ class Tensor:
         self.kind = kind
         self.name = name or (op.name if op is not None else "t")
         self.consumers = []
+        self.bmul = 1                   # rows per fed image: > 1 behind tile_batch (n Monte-Carlo samples per image)
 
     def get_shape(self):
         return _Shape(self.shape)
@@ -148,6 +149,12 @@ class Graph:
         op = Op(type_, inputs, attrs, self.unique_name((self.scope_name() + "/" if self._scope else "") + (name or type_)))
         for i, (shape, kind) in enumerate(out_specs):
             op.outputs.append(Tensor(op, shape, kind, op.name + (":%d" % i if len(out_specs) > 1 else "")))
+        bm = {t.bmul for t in inputs if t.shape and t.shape[0] is None}
+        if len(bm) > 1:
+            raise ValueError("op %s mixes tensors with %s rows per image (tile_batch the smaller one first)" % (op.name, sorted(bm)))
+        rows = (max(bm) if bm else 1) * (int(attrs.get("tile", 1)) if type_ == "tile_batch" else 1)
+        for o in op.outputs:
+            o.bmul = rows
         for t in inputs:
             t.consumers.append(op)
         self.ops.append(op)
@@ -159,6 +166,13 @@ _default = Graph()
 
 def get_default_graph():
     return _default
+
+
+def set_default_graph(g):
+    """Make `g` the graph new ops are added to (a model adding a graph instance after construction)."""
+    global _default
+    _default = g
+    return g
 
 
 def reset_default_graph():
@@ -228,6 +242,13 @@ def resize_nearest(x, out_hw):
         raise ValueError("nearest resize: integer power-of-two factor <= 16 required (%s -> %s)" % ((h, w), out_hw))
     return get_default_graph().add_op("nn_resize", [x], dict(shift=f.bit_length() - 1),
                                       [((n, out_hw[0], out_hw[1], c), KIND_F32)])[0]
+
+
+def tile_batch(x, n):
+    """[B, ...] -> [B * n, ...], row b * n + k = x[b]: every image's feature map repeated for its n Monte-Carlo samples."""
+    if n == 1:
+        return x
+    return get_default_graph().add_op("tile_batch", [x], dict(tile=int(n)), [(x.shape, x.kind)], name="tile_batch")[0]
 
 
 def global_average_pool(x, name=None):

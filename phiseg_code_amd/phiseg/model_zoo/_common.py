@@ -45,6 +45,11 @@ def hierarchical_ladder(scope_name, rng_net, inputs, teacher, zdim_0, training, 
         if scope_reuse:
             scope.reuse_variables()
         pre_z = encoder(inputs, 'z%d_pre_%d', widths, resolution_levels, norm, training)
+        # sampling path only: n Monte-Carlo samples per image share the encoder (it depends on x alone, priors.py:80-95);
+        # its feature maps are repeated n times and everything below runs at batch B * n
+        tile = int(kwargs.get('tile_samples', 1))
+        if tile > 1:
+            pre_z = [G.tile_batch(f, tile) if (i >= gap) else f for i, f in enumerate(pre_z)]
         mu, sigma, z = [None] * latent_levels, [None] * latent_levels, [None] * latent_levels
         # sent[a][b]: latent of level a brought to the resolution of level b (reference z_ups_mat[b][a])
         sent = [[None] * latent_levels for _ in range(latent_levels)]

@@ -191,6 +191,7 @@ class phiseg():
         self.loss_dict['total_loss'] = self.loss_tot
         self.train_step = TrainStep(self.loss_tot)
 
+        self._multi = {}
         self.sess = Session(self, getattr(exp_config, 'compute_dtype', 'f32'), rng_seed=rng_seed, dist=dist)
         self.dist = dist
 
@@ -401,8 +402,34 @@ class phiseg():
             return z, mu, sg
         return self.sess.run(self.prior_z_list_gen, fd)
 
+    def sampling_graph(self, num_samples):
+        """(s_out_eval, s_out_eval_sm) of a graph instance that draws `num_samples` segmentations PER fed image in one pass:
+        the prior's encoder -- a function of x alone -- runs once per image, its features are repeated num_samples times
+        (graph.tile_batch) and the latent path + likelihood run at batch B * num_samples.  Same variables (scope reuse) and
+        the same Philox stream as s_out_eval_sm; output rows b * num_samples + k = sample k of image b."""
+        if num_samples not in self._multi:
+            cfg = self.exp_config
+            net_kw = dict(n0=cfg.n0, resolution_levels=cfg.resolution_levels, latent_levels=cfg.latent_levels, norm=cfg.layer_norm)
+            G.set_default_graph(self.graph)
+            z_gen, _, _ = cfg.prior(self.z_list, self.x_inp, zdim_0=cfg.zdim0, n_classes=cfg.nlabels, training=self.training_pl,
+                                    generation_mode=True, scope_reuse=True, tile_samples=num_samples, **net_kw)
+            s_list = cfg.likelihood(z_gen, self.training_pl, scope_reuse=True, n_classes=cfg.nlabels, image_size=cfg.image_size,
+                                    x=self.x_inp, **net_kw)
+            self._multi[num_samples] = G.aggregate_logits(s_list)
+        return self._multi[num_samples]
+
     def predict(self, x_in, num_samples=50, return_softmax=False):
+        """phiseg_model.py:337-354: mean soft-max over num_samples prior samples, arg-max.  One pass per call when the prior
+        has an x-only encoder to share (sampling_graph); prob_unet2D draws z per image, so it keeps the reference's loop."""
         fd = {self.training_pl: False, self.x_inp: x_in}
+        if num_samples > 1 and getattr(self.exp_config.prior, '__name__', '') == 'phiseg':
+            _, sm = self.sampling_graph(num_samples)
+            sm_all = self.sess.run(sm, feed_dict=fd)                          # [B * n, X, Y, C]
+            self._advance_noise()
+            cumsum_sm = sm_all.reshape((-1, num_samples) + sm_all.shape[1:]).sum(axis=1)
+            if return_softmax:
+                return np.argmax(cumsum_sm, axis=-1), cumsum_sm / num_samples
+            return np.argmax(cumsum_sm, axis=-1)
         cumsum_sm = self.sess.run(self.s_out_eval_sm, feed_dict=fd)
         for _ in range(num_samples - 1):
             self._advance_noise()

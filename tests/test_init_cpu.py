@@ -90,3 +90,14 @@ def test_init_is_independent_of_creation_order_and_rank():
     name = [n for n in a if n.endswith("/W")][7]
     assert np.array_equal(a[name].initial_value(5), b[name].initial_value(5))
     assert not np.array_equal(a[name].initial_value(5), a[name].initial_value(6))
+
+
+def test_philox_synthetic_batch_matches_oracle_and_shards():
+    """The product's seeded synthetic batch equals the oracle's (bench.py feeds the GPU leg and the CPU baseline from it),
+    and a rank's shard is a slice of the global batch."""
+    from phiseg_code_amd.data import synthetic
+    x, s = synthetic.philox_batch(5, 32, 4, seed=1234)
+    xo, so = oinit.synthetic_batch(5, 32, 4, 1234)
+    assert np.array_equal(x, xo) and np.array_equal(s, so)
+    x2, s2 = synthetic.philox_batch(2, 32, 4, seed=1234, sample_offset=3)
+    assert np.array_equal(x2, x[3:5]) and np.array_equal(s2, s[3:5])

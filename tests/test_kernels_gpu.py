@@ -5,6 +5,7 @@ Tolerances: fp32 kernels 1e-5 relative-to-max (fp32 accumulation order); bf16 st
 with an oracle evaluated on the SAME bf16-rounded inputs, so the only differences are fp32 accumulation
 order and the final bf16 rounding of the output (2^-8 relative)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -593,6 +594,12 @@ def test_concat_split_add_cast_misc(L):
         cs = torch.zeros(Ca, dtype=torch.float32).cuda()
         L.channel_sum_accumulate(ad.data_ptr(), dt, cs.data_ptr(), 32, Ca, S())
         close(host(cs), host(ad).sum(axis=(0, 1, 2)), 1e-5, "channel_sum")
+    for (npix, C, dt) in [(64, 32, BF16), (1000, 192, BF16), (5000, 64, F32), (70000, 32, BF16), (333, 8, F32)]:
+        a = RNG.standard_normal((npix, C))           # the 16-byte-load kernel (bias gradients of the group / instance norm nets)
+        ad = dev(a, dt)
+        cs = torch.full((C,), 0.5, dtype=torch.float32).cuda()
+        L.channel_sum_accumulate(ad.data_ptr(), dt, cs.data_ptr(), npix, C, S())
+        close(host(cs), 0.5 + host(ad).astype(np.float64).sum(axis=0), 2e-5, "channel_sum v8 %s" % ((npix, C, dt),))
     x = RNG.standard_normal((2, 8, 8, 1)).astype(np.float32)
     s = RNG.integers(0, 4, (2, 8, 8)).astype(np.uint8)
     out = torch.empty(2, 8, 8, 5).cuda()
@@ -867,3 +874,52 @@ def test_comm_abi_single_rank_rccl(L):
     with pytest.raises(rt.PhxError):
         L.comm_init(ctypes.byref(ctypes.c_void_p()), 2, 5, idbuf.raw)
     L.comm_destroy(comm)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 32, 64), (3, 4, 4, 192, 64), (1, 32, 64, 96, 128), (2, 12, 12, 32, 32), (40, 2, 2, 64, 96)])
+@pytest.mark.parametrize("act", ["relu", "identity"])
+def test_conv3x3_mfma_affine_epilogue(L, case, act):
+    """Inference-mode batch norm + activation folded into the convolution (reference: conv2d -> batch_norm(is_training=False)
+    -> relu, tfwrapper/layers.py:123-135, normalisation.py:145-163): y = act(conv(x) * scale + shift) in one launch, on the
+    256-pixel tiles, the split-K small-map path and (forced) the 32 x 16-tile LDS-DMA kernel."""
+    B, H, W, K, N = case
+    x = RNG.standard_normal((B, H, W, K))
+    w = RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K)
+    gamma, beta = 1.0 + 0.2 * RNG.standard_normal(N), 0.1 * RNG.standard_normal(N)
+    mm, mv = 0.1 * RNG.standard_normal(N), 1.0 + 0.3 * RNG.random(N)
+    eps = 1e-3
+    xr, wr = rounded(x, BF16), rounded(w, BF16)
+    pre = T.conv2d_same(xr, wr)
+    sc = gamma / np.sqrt(mv + eps)
+    ref = pre * torch.as_tensor(sc) + torch.as_tensor(beta - mm * sc)
+    if act == "relu":
+        ref = T.relu(ref)
+    xd, wd = dev(x, BF16), dev(w)
+    wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    wg = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    L.pack_conv3x3_bf16(wd.data_ptr(), wf.data_ptr(), wg.data_ptr(), K, N, S())
+    vec = [dev(v) for v in (gamma, beta, mm, mv)]
+    scale, shift = torch.empty(N, dtype=torch.float32).cuda(), torch.empty(N, dtype=torch.float32).cuda()
+    desc = np.zeros(1, dtype=[("gamma", "<u8"), ("beta", "<u8"), ("mm", "<u8"), ("mv", "<u8"), ("scale", "<u8"), ("shift", "<u8"),
+                              ("C", "<i4"), ("eps", "<f4")])
+    desc[0] = (vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), scale.data_ptr(), shift.data_ptr(), N, eps)
+    dd = torch.from_numpy(desc.view(np.uint8).copy()).cuda()
+    L.bn_infer_scale_shift_multi(dd.data_ptr(), 1, S())
+    close(host(scale), sc, 1e-6, "scale")
+    wsb = int(L.conv3x3_mfma_ws_bytes(B, H, W, K, N))
+    ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32).cuda()
+    y = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
+    for env in ({}, {"PHX_FWD_WS": "5"}, {"PHX_FWD_WS": "0"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            y.zero_()
+            L.conv3x3_mfma_bf16_affine(xd.data_ptr(), wf.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), ACT[act],
+                                       ws.data_ptr() if wsb else None, wsb, B, H, W, K, N, S())
+            close(host(y), ref.numpy(), 6e-3, "affine epilogue %s" % (env,))
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v

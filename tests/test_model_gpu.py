@@ -528,3 +528,23 @@ def test_single_steps_from_oracle_snapshots_n0_32(lidc_trajectory):
             n_all += 1
             n_bad += int(np.linalg.norm(dgot - dref) > 0.1 * np.linalg.norm(dref))
         assert n_all > 100 and n_bad <= 0.02 * n_all, (step, n_bad, n_all)
+
+
+def test_shared_encoder_sampling_equals_tiled_batch_fp32():
+    """predict()'s one-pass graph (prior encoder once per image, features repeated for the n samples: graph.tile_batch) gives
+    the samples the reference's own batching gives -- np.tile(x, [n,1,1,1]) through the full graph (phiseg_model.py:577-585):
+    same Philox noise per (image, sample) row, so the soft-max maps agree to fp32 round-off; and predict() returns their mean."""
+    g, cfg, var_order, model, params, x_np, s_np = build("tiny_phiseg_bn")
+    n = 4
+    x2 = x_np[:2]
+    _, sm_multi = model.sampling_graph(n)
+    fd = {model.training_pl: False, model.x_inp: x2}
+    a = model.sess.run(sm_multi, fd)                                       # rows b * n + k
+    xt = np.repeat(x2, n, axis=0)                                          # the reference's tiling: rows b * n + k as well
+    b = model.sess.run(model.s_out_eval_sm, {model.training_pl: False, model.x_inp: xt})
+    assert a.shape == b.shape == (2 * n,) + x2.shape[1:3] + (cfg["nlabels"],)
+    np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)
+    assert np.abs(a[0] - a[1]).max() > 1e-4                                # the n samples of an image differ
+    seg, sm = model.predict(x2, num_samples=n, return_softmax=True)
+    np.testing.assert_allclose(sm, a.reshape(2, n, *a.shape[1:]).mean(axis=1), rtol=0, atol=2e-6)
+    assert seg.shape == x2.shape[:3] and (seg == sm.argmax(-1)).all()
