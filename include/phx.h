@@ -309,6 +309,17 @@ size_t phx_validation_metrics_ws_bytes(int I, int N, int M, int P, int C);
 int phx_validation_metrics(const float* sm, const unsigned char* gt, const unsigned char* sref, void* work, size_t work_bytes,
                            int I, int N, int M, int P, int C, int label0, float* out, void* stream);
 
+/* ---- mini-batch producer on the device ---------------------------------------------------
+ * Replaces data/batch_provider.py:43-67 (next_batch), 131-137 (_select_random_label) and 140-272 (_augmentation_function with
+ * the cv2 helpers of utils.py:18-38) for a data set resident in HBM: images [N][X][Y] f32, labels [N][X][Y][A] u8 (A annotators).
+ * params_dev: B records of phx_augment_param_bytes() bytes in device memory,
+ *   { int src, annot, flags (1 rotate | 2 crop-scale | 4 fliplr | 8 flipud), r_y, p_x, p_y; double iM[6] }
+ * iM = inverse of cv2.getRotationMatrix2D((Y/2, X/2), angle, 1).  Output x_out [B][X][Y] f32, s_out [B][X][Y] u8 -- the plan's
+ * x_input / s_input buffers can be written directly.  nlabels <= 4 (labels are interpolated as one-hot planes and arg-maxed). */
+int phx_augment_param_bytes(void);
+int phx_augment_batch(const float* images, const unsigned char* labels, const void* params_dev, float* x_out,
+                      unsigned char* s_out, int B, int X, int Y, int A, int nlabels, void* stream);
+
 /* ---- data-parallel gradient exchange over RCCL / xGMI ------------------------------------------------
  * The reference is single-process, single-device (phiseg_model.py:151-157); the data-parallel design shards the batch over
  * ranks (one process per GPU) and exchanges ONE sum of the flat fp32 gradient arena per step.  RCCL is dlopen'ed on first use.
