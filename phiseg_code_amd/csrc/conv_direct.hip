@@ -342,7 +342,7 @@ int phx_conv2d_direct(const void* x, int x_dt, const float* w_hwio, const float*
 int phx_conv2d_direct_wgrad(const void* x, int x_dt, const void* dy, int dy_dt, float* dw_hwio, float* dbias, int B,
                             int H, int W, int Cin, int Cout, int ksize, void* stream) {
     PHX_REQUIRE(ksize == 1 || ksize == 3, PHX_E_SHAPE, "conv2d_direct_wgrad: ksize must be 1 or 3");
-    if (tiny_map(B, H, W) && Cout <= 4) {
+    if (tiny_map(B, H, W) && Cout <= 4 && !phx_deterministic()) {       // (its pixel groups meet in atomics)
         const int P = B * H * W;
 #define CTW_LAUNCH(KS)                                                                                               \
     hipLaunchKernelGGL((k_conv_tiny_wgrad<TX, TD, KS>), dim3((KS * KS * Cin + 255) / 256, (P + 15) / 16), dim3(256), 0, \
@@ -358,6 +358,7 @@ int phx_conv2d_direct_wgrad(const void* x, int x_dt, const void* dy, int dy_dt, 
     const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
     int tpb = (ntiles + 255) / 256;          // <= 256 blocks along the pixel axis -> bounded atomic traffic
     if (tpb < 1) tpb = 1;
+    if (phx_deterministic()) tpb = ntiles;   // one block walks every pixel tile: a single add per filter element
     const int gx = (ntiles + tpb - 1) / tpb;
     const size_t sh = (size_t)(WG_CI * npatch + 256 * WG_CO) * sizeof(float);
     PHX_DT_SWITCH(x_dt, TX, PHX_DT_SWITCH(dy_dt, TD, {

@@ -2628,12 +2628,12 @@ size_t phx_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout) {
 static int wgrad_atomic_tiles() {
     static int atl = -1;
     if (atl < 0) { const char* e = getenv("PHX_WGRAD_ATOMIC_TILES"); atl = e ? atoi(e) : 4; }
-    return atl;
+    return phx_deterministic() ? 0 : atl;        // deterministic mode: always partial filters + ordered reduction
 }
 static void wgrad_reduce_geometry(int Cin, int Cout, int nslice, int* rgx, int* rgy) {
     const size_t total = (size_t)9 * Cin * Cout;
     int gy = nslice / 16;
-    if (gy < 1) gy = 1;
+    if (gy < 1 || phx_deterministic()) gy = 1;     // (gy > 1: several blocks add into one filter element)
     if (gy > 16) gy = 16;
     *rgx = (int)((total / 4 + 63) / 64);
     *rgy = gy;

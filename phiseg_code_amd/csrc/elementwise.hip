@@ -1090,6 +1090,7 @@ int phx_norm_stats(const void* x, int dt, float* sums, float* pivot, int NS, int
     PHX_DT_SWITCH(dt, T, PHX_VEC_SWITCH(C, V, {
         int PL, threads, chunk, nchunks;
         PHX_REQUIRE(norm_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_stats: C too large");
+        if (phx_deterministic()) { chunk = P; nchunks = 1; }       // one block per sample group: no cross-block atomics
         hipLaunchKernelGGL((k_norm_stats<T, V>), dim3(nchunks, NS), dim3(threads), (size_t)PL * C * 2 * sizeof(float),
                            (hipStream_t)stream, (const T*)x, sums, pivot, P, C, PL, chunk);
     }));
@@ -1185,6 +1186,10 @@ int phx_norm_bwd_reduce(const void* dA, int da_dt, const void* x, int x_dt, cons
     PHX_DT_SWITCH(da_dt, TD, PHX_DT_SWITCH(x_dt, TX, PHX_VEC_SWITCH(C, V, {
         int PL, threads, chunk, nchunks;
         PHX_REQUIRE(norm_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS, nrep) == 0, PHX_E_SHAPE, "norm_bwd_reduce: C too large");
+        if (phx_deterministic() && nchunks > nrep) {               // block b owns replica b: one add per accumulator, the consumer
+            chunk = (P + nrep - 1) / nrep;                         // sums the replicas in a fixed order
+            nchunks = (P + chunk - 1) / chunk;
+        }
         hipLaunchKernelGGL((k_norm_bwd_reduce<TD, TX, V>), dim3(nchunks, NS), dim3(threads),
                            (size_t)PL * C * 2 * sizeof(float), (hipStream_t)stream, (const TD*)dA, (const TX*)x, scale,
                            shift, mean, rstd, sums2, P, C, G, PL, chunk, act, nrep);
@@ -1338,6 +1343,7 @@ int phx_channel_sum_accumulate(const void* x, int dt, float* out, size_t npix, i
         size_t want = (rows + 31) / 32;                   // ~32 pixels per thread, at least 64 and at most 1024 blocks
         if (want < 64) want = rows < 64 ? rows : 64;
         if (want > 1024) want = 1024;
+        if (phx_deterministic()) want = 1;
         const size_t chunk = (npix + want - 1) / want;
         const int nchunks = (int)((npix + chunk - 1) / chunk);
         PHX_DT_SWITCH(dt, T, {
@@ -1349,7 +1355,7 @@ int phx_channel_sum_accumulate(const void* x, int dt, float* out, size_t npix, i
     }
     int gx = (int)((npix + 63) / 64);
     if (gx > 256) gx = 256;
-    if (gx < 1) gx = 1;
+    if (gx < 1 || phx_deterministic()) gx = 1;
     PHX_DT_SWITCH(dt, T, {
         hipLaunchKernelGGL((k_channel_sum<T>), dim3(gx, (C + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const T*)x, out,
                            npix, C);

@@ -274,6 +274,7 @@ static void head_wgrad_geometry(size_t npix, int PL, int* chunk, int* grid) {
     static int cap = 0;
     if (!cap) { const char* e = getenv("PHX_HEADW_BLOCKS"); cap = e ? atoi(e) : 1024; }
     if (g > (size_t)cap) { ch = (int)((npix + cap - 1) / cap); g = (npix + ch - 1) / ch; }
+    if (phx_deterministic()) { ch = (int)npix; g = 1; }     // one block per head: fixed summation order
     *chunk = ch; *grid = (int)g;
 }
 /* plan4 = {PL, chunk, grid, dynamic LDS bytes} of the launch phx_head1x1_wgrad makes for C % 8 == 0 */

@@ -59,7 +59,7 @@ struct CEArgs {
 template <int C>
 __global__ void k_residual_ce(CEArgs a, int L, const uint8_t* __restrict__ labels, int B, int H, int W, float gscale,
                               float inv_batch, float* __restrict__ loss_part, float* __restrict__ s_out,
-                              float* __restrict__ sm_out) {
+                              float* __restrict__ sm_out, int det) {
     const int tiles_x = (W + 15) >> 4, tiles_y = (H + 15) >> 4;
     const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -120,7 +120,13 @@ __global__ void k_residual_ce(CEArgs a, int L, const uint8_t* __restrict__ label
         for (int l = 0; l < CE_MAXL; ++l) {
             if (l >= L) continue;
             const float t = wave_sum(ce[l]);
-            if (lane == 0) atomicAdd(&loss_part[((blockIdx.x * 4 + wave) & 63) * CE_MAXL + l], t * inv_batch);
+            if (lane == 0) {
+                if (det)      // deterministic mode: 32 slots of 2^-20 fixed point (integer adds commute), k_reduce_loss_parts converts
+                    atomicAdd(reinterpret_cast<unsigned long long*>(loss_part) + ((blockIdx.x * 4 + wave) & 31) * CE_MAXL + l,
+                              (unsigned long long)(long long)llrintf(t * inv_batch * 1048576.f));
+                else
+                    atomicAdd(&loss_part[((blockIdx.x * 4 + wave) & 63) * CE_MAXL + l], t * inv_batch);
+            }
         }
     }
     // gradients: d/ds_k = sum_{l<=k} G_l (prefix over levels, finest first), then f x f block sum
@@ -146,7 +152,16 @@ __global__ void k_residual_ce(CEArgs a, int L, const uint8_t* __restrict__ label
                 }
                 const int m = (1 << rb) - 1;
                 const bool leader = ((lane & 7) & m) == 0 && ((lane >> 3) & m) == 0;
-                if (leader && valid) {
+                if (sh == 4) {
+                    // the 16 x 16 block IS this work-group's tile: its four wave sums meet in LDS and are added in a fixed
+                    // order (four atomics on one address otherwise: the only unordered sum of this kernel's gradients)
+                    __shared__ float wsum[4][C];
+                    if (lane == 0) wsum[wave][c] = v;
+                    __syncthreads();
+                    if (threadIdx.x == 0 && valid)
+                        a.ds[k][(((size_t)b * hh + (py >> 4)) * ww + (px >> 4)) * C + c] = (wsum[0][c] + wsum[1][c]) + (wsum[2][c] + wsum[3][c]);
+                    __syncthreads();
+                } else if (leader && valid) {
                     float* dp = a.ds[k] + (((size_t)b * hh + (py >> sh)) * ww + (px >> sh)) * C + c;
                     if (sh == 0) *dp = v; else atomicAdd(dp, v);
                 }
@@ -155,9 +170,15 @@ __global__ void k_residual_ce(CEArgs a, int L, const uint8_t* __restrict__ label
     }
 }
 
-__global__ void k_reduce_loss_parts(const float* __restrict__ part, int L, float* __restrict__ losses) {
+__global__ void k_reduce_loss_parts(const float* __restrict__ part, int L, float* __restrict__ losses, int det) {
     const int l = threadIdx.x;
     if (l >= L) return;
+    if (det) {
+        long long a = 0;
+        for (int j = 0; j < 32; ++j) a += reinterpret_cast<const long long*>(part)[j * CE_MAXL + l];
+        losses[l] = (float)((double)a * (1.0 / 1048576.0));
+        return;
+    }
     float a = 0.f;
     for (int j = 0; j < 64; ++j) a += part[j * CE_MAXL + l];
     losses[l] = a;
@@ -283,9 +304,10 @@ int phx_residual_ce(const float* const* s, float* const* ds, const int* shift, i
     if (part) PHX_CHECK_HIP(hipMemsetAsync(part, 0, 64 * CE_MAXL * sizeof(float), (hipStream_t)stream));
     const int tiles = ((W + 15) / 16) * ((H + 15) / 16);
     const float gscale = weight * inv_batch;
+    const int det = phx_deterministic() ? 1 : 0;
 #define CE_LAUNCH(CC)                                                                                            \
     hipLaunchKernelGGL((k_residual_ce<CC>), dim3(tiles* B), dim3(256), 0, (hipStream_t)stream, a, L, labels, B, H, W, \
-                       gscale, inv_batch, part, s_out, sm_out)
+                       gscale, inv_batch, part, s_out, sm_out, det)
     switch (C) {
         case 2: CE_LAUNCH(2); break;
         case 3: CE_LAUNCH(3); break;
@@ -298,7 +320,7 @@ int phx_residual_ce(const float* const* s, float* const* ds, const int* shift, i
 #undef CE_LAUNCH
     PHX_CHECK_LAUNCH();
     if (part) {
-        hipLaunchKernelGGL(k_reduce_loss_parts, dim3(1), dim3(64), 0, (hipStream_t)stream, part, L, losses);
+        hipLaunchKernelGGL(k_reduce_loss_parts, dim3(1), dim3(64), 0, (hipStream_t)stream, part, L, losses, det);
         PHX_CHECK_LAUNCH();
     }
     return PHX_OK;
@@ -308,7 +330,7 @@ int phx_kl_diag_gauss(const float* mu0, const float* s0, const float* mu1, const
                       float inv_batch, float grad_scale, float* loss, float* dmu0, float* ds0, float* dmu1, float* ds1,
                       void* stream) {
     PHX_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream));
-    hipLaunchKernelGGL(k_kl, dim3(phx_grid_for(n, 256, 64)), dim3(256), 0, (hipStream_t)stream, mu0, s0, mu1, s1, n,
+    hipLaunchKernelGGL(k_kl, dim3(phx_deterministic() ? 1 : phx_grid_for(n, 256, 64)), dim3(256), 0, (hipStream_t)stream, mu0, s0, mu1, s1, n,
                        level_w, inv_batch, grad_scale, loss, dmu0, ds0, dmu1, ds1);
     PHX_CHECK_LAUNCH();
     return PHX_OK;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/phx.h"
@@ -92,6 +93,15 @@ void phx_set_error(const char* fmt, ...);
             return code;                                          \
         }                                                         \
     } while (0)
+
+// PHX_DETERMINISTIC=1 (read once): every cross-block floating-point reduction takes a fixed summation order -- single-block or
+// one-slot-per-block launches, ordered second stages, integer fixed-point for the loss partials -- so that two runs of the same
+// step are bit-identical.  Slower (fewer blocks on the reduction kernels); see DESIGN.md section 4.
+static inline bool phx_deterministic() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PHX_DETERMINISTIC"); v = (e && atoi(e) != 0) ? 1 : 0; }
+    return v == 1;
+}
 
 // dispatch on a storage dtype code
 #define PHX_DT_SWITCH(dt, T, ...)                                      \

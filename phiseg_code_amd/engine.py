@@ -36,6 +36,7 @@ _WGRAD_MULTI = os.environ.get("PHX_WGRAD_MULTI", "1") == "1"   # one reduction l
 _EARLY_TOUCH = os.environ.get("PHX_EARLY_TOUCH", "1") == "1"
 _STAMPS = os.environ.get("PHX_STAMPS", "0") == "1"
 _BN_SPLITK = os.environ.get("PHX_BN_SPLITK", "0") == "1"   # small batch norm consumes the split-K slices of its convolution (measured 0.5 % slower: off)
+_DETERMINISTIC = os.environ.get("PHX_DETERMINISTIC", "0") not in ("0", "")   # fixed summation orders everywhere (libphx reads the same variable)
 _BN_SMALL = int(os.environ.get("PHX_BN_SMALL", "1024"))     # one-launch batch norm up to this many pixels (0: off)
 
 
@@ -726,8 +727,8 @@ class Plan:
                 part = self._alloc((ntile * 2 * cout,), F32)
                 conv_into(y, 0, stats_part=part)
                 self._emit(Lb.norm_reduce_partials, part.ptr, ntile, cout, sums.ptr, S)
-            elif norm == "batch" and not small:
-                conv_into(y, 0, stats_direct=sums)
+            elif norm == "batch" and not small and not _DETERMINISTIC:
+                conv_into(y, 0, stats_direct=sums)        # (direct kernels add their tiles' sums atomically)
             else:
                 pivot = self._alloc((NS * cout,), F32)
                 conv_into(y, 0)
@@ -997,6 +998,8 @@ class Plan:
                            tag="bytes_norm_bwd_apply", flops=float(dA.nbytes + y.nbytes + dY.nbytes))
             else:
                 nrep = _NREP if P >= _NREP_MINP else 1   # replicated accumulators: see k_norm_bwd_reduce
+                if _DETERMINISTIC and P >= _NREP_MINP:
+                    nrep = 64                             # one block per replica there: more replicas = more blocks
                 fused = self._bws.pop(op, None)        # the consumer's data-gradient launch already produced the sums
                 if fused is not None:
                     nrep = 1
