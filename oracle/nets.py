@@ -193,9 +193,7 @@ def prior_probunet(ctx, z_list, x, generation_mode, eps_fn, n0=32, resolution_le
     return _probunet_head(ctx, "prior", enc[-1], eps_fn, "prior_gen" if generation_mode else "prior")
 
 
-def likelihood_probunet(ctx, z_list, image_size, n_classes, x, n0=32, resolution_levels=7, **_):
-    nc = num_channels(n0)
-    z = z_list[0]
+def _unet_on_x(ctx, x, n0, resolution_levels):
     enc = _probunet_encoder(ctx, "likelihood/encoder", x, n0, resolution_levels)
     h = enc[-1]
     for jj in range(resolution_levels - 1):
@@ -203,6 +201,32 @@ def likelihood_probunet(ctx, z_list, image_size, n_classes, x, n0=32, resolution
         h = torch.cat([ctx.up2(h), enc[ii - 1]], dim=3)      # crop_and_concat: equal sizes here
         for t in (1, 2, 3):
             h = ctx.conv(h, "likelihood/decoder/conv_%d_%d" % (jj, t))
+    return h
+
+
+def posterior_dummy(ctx, x, s_oh, eps_fn, latent_levels=5, **_):
+    """posteriors.py:135-138 / priors.py:130-133: constant placeholders, never consumed."""
+    zero = [torch.zeros((), dtype=x.dtype)] * latent_levels
+    return zero, zero, zero
+
+
+def prior_dummy(ctx, z_list, x, generation_mode, eps_fn, latent_levels=5, **_):
+    zero = [torch.zeros((), dtype=x.dtype)] * latent_levels
+    return zero, zero, zero
+
+
+def likelihood_detunet(ctx, z_list, image_size, n_classes, x, n0=32, resolution_levels=7, **_):
+    """likelihoods.py:10-79: the deterministic U-Net (z_list ignored)."""
+    h = _unet_on_x(ctx, x, n0, resolution_levels)
+    for t in range(3):
+        h = ctx.conv(h, "likelihood/recomb_%d" % t)
+    return [ctx.conv(h, "likelihood/prediction", act="identity", normalise=False)]
+
+
+def likelihood_probunet(ctx, z_list, image_size, n_classes, x, n0=32, resolution_levels=7, **_):
+    nc = num_channels(n0)
+    z = z_list[0]
+    h = _unet_on_x(ctx, x, n0, resolution_levels)
     bs, zdim = z.shape
     bz = z.reshape(bs, 1, 1, zdim).expand(bs, image_size[0], image_size[1], zdim)
     h = torch.cat([h, bz], dim=-1)
@@ -214,6 +238,7 @@ def likelihood_probunet(ctx, z_list, image_size, n_classes, x, n0=32, resolution
 ZOO = {
     "phiseg": (posterior_phiseg, prior_phiseg, likelihood_phiseg),
     "prob_unet2D": (posterior_probunet, prior_probunet, likelihood_probunet),
+    "det_unet2D": (posterior_dummy, prior_dummy, likelihood_detunet),
 }
 
 

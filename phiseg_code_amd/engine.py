@@ -551,6 +551,12 @@ class Plan:
         self.val[t] = b
         self.feeds[op.name.rsplit("/", 1)[-1]] = b
 
+    def _fw_constant(self, op, bw):
+        b = self._alloc((), F32, zero=True)
+        if op.attrs["value"] != 0.0:
+            b.t.fill_(op.attrs["value"])
+        self.val[op.outputs[0]] = b
+
     def _fw_one_hot(self, op, bw):
         pass            # virtual: consumed by the fused posterior-input kernel / the loss kernel
 
@@ -913,7 +919,7 @@ class Plan:
     def _bw_placeholder(self, op):
         pass
 
-    _bw_one_hot = _bw_sub_const = _bw_random_normal = _bw_mul = _bw_weighted_sum = _bw_aggregate = _bw_placeholder
+    _bw_one_hot = _bw_sub_const = _bw_random_normal = _bw_mul = _bw_weighted_sum = _bw_aggregate = _bw_constant = _bw_placeholder
 
     def _bw_nn_resize(self, op):
         raise NotImplementedError("nearest-resized logits only feed the fused loss kernel")

@@ -191,6 +191,11 @@ def placeholder(kind, shape, name):
     return get_default_graph().add_op("placeholder", [], dict(), [(tuple(shape), kind)], name=name)[0]
 
 
+def constant(value):
+    """tf.constant(scalar): only ever a placeholder value (the dummy posterior / prior of the deterministic baseline)."""
+    return get_default_graph().add_op("constant", [], dict(value=float(value)), [((), KIND_F32)], name="const")[0]
+
+
 def one_hot(s, depth):
     """tf.one_hot (phiseg_model.py:29): [.., H, W] u8 -> [.., H, W, depth]."""
     return get_default_graph().add_op("one_hot", [s], dict(depth=int(depth)), [(s.shape + (int(depth),), KIND_ACT)])[0]

@@ -6,8 +6,38 @@ from phiseg_code_amd.tfwrapper import layers
 from phiseg_code_amd.tfwrapper import normalisation as tfnorm
 
 
+def _unet_on_x(x, widths, resolution_levels, norm, training, add_bias):
+    """The U-Net both prob_unet2D and det_unet2D run on the image: encoder (likelihoods.py:28-44 / 106-120) and decoder with
+    bilinear up-sampling + skip connections (46-68 / 124-145) -> feature map at full resolution."""
+    g = G.get_default_graph()
+    cu = dict(training=training, normalisation=norm, add_bias=add_bias)
+    with g.variable_scope('encoder'):
+        enc = _common.encoder(x, 'conv_%d_%d', widths, resolution_levels, norm, training, extra=dict(add_bias=add_bias))
+    with g.variable_scope('decoder'):
+        net = enc[-1]
+        for jj in range(resolution_levels - 1):
+            ii = resolution_levels - jj - 1
+            net = layers.bilinear_upsample2D(net, 'upsample', 2)
+            net = layers.crop_and_concat([net, enc[ii - 1]], axis=3)
+            for t in (1, 2, 3):
+                net = layers.conv2D(net, 'conv_%d_%d' % (jj, t), num_filters=widths[ii], **cu)
+    return net, cu
+
+
 def det_unet2D(z_list, training, image_size, n_classes, scope_reuse=False, norm=tfnorm.batch_norm, **kwargs):
-    raise NotImplementedError("det_unet2D is the deterministic baseline (no latent path; out of scope)")
+    """likelihoods.py:10-79: the deterministic U-Net baseline -- the same U-Net on x, no latent input (z_list is ignored),
+    three 1x1 recombination convolutions and the 1x1 prediction head."""
+    x = kwargs.get('x')
+    resolution_levels = kwargs.get('resolution_levels', 7)
+    widths = _common.channel_plan(kwargs.get('n0', 32))
+    g = G.get_default_graph()
+    with g.variable_scope('likelihood') as scope:
+        if scope_reuse:
+            scope.reuse_variables()
+        net, cu = _unet_on_x(x, widths, resolution_levels, norm, training, norm is not tfnorm.batch_norm)
+        for t in range(3):
+            net = layers.conv2D(net, 'recomb_%d' % t, num_filters=widths[0], kernel_size=(1, 1), **cu)
+        return [layers.conv2D(net, 'prediction', num_filters=n_classes, kernel_size=(1, 1), activation=act.identity)]
 
 
 def prob_unet2D(z_list, training, image_size, n_classes, scope_reuse=False, norm=tfnorm.batch_norm, **kwargs):
@@ -20,19 +50,7 @@ def prob_unet2D(z_list, training, image_size, n_classes, scope_reuse=False, norm
     with g.variable_scope('likelihood') as scope:
         if scope_reuse:
             scope.reuse_variables()
-        add_bias = norm is not tfnorm.batch_norm
-        cu = dict(training=training, normalisation=norm, add_bias=add_bias)
-        with g.variable_scope('encoder'):
-            enc = _common.encoder(x, 'conv_%d_%d', widths, resolution_levels, norm, training,
-                                  extra=dict(add_bias=add_bias))
-        with g.variable_scope('decoder'):
-            net = enc[-1]
-            for jj in range(resolution_levels - 1):
-                ii = resolution_levels - jj - 1
-                net = layers.bilinear_upsample2D(net, 'upsample', 2)
-                net = layers.crop_and_concat([net, enc[ii - 1]], axis=3)
-                for t in (1, 2, 3):
-                    net = layers.conv2D(net, 'conv_%d_%d' % (jj, t), num_filters=widths[ii], **cu)
+        net, cu = _unet_on_x(x, widths, resolution_levels, norm, training, norm is not tfnorm.batch_norm)
         net = G.concat([net, G.tile_pixels(z, image_size[0], image_size[1])], axis=-1)
         for t in range(3):
             net = layers.conv2D(net, 'recomb_%d' % t, num_filters=widths[0], kernel_size=(1, 1), **cu)

@@ -19,4 +19,8 @@ def phiseg(x, s_oh, zdim_0, training, scope_reuse=False, norm=tfnorm.batch_norm,
 
 
 def dummy(x, s_oh, zdim_0, training, scope_reuse=False, norm=tfnorm.batch_norm, **kwargs):
-    raise NotImplementedError("posteriors.dummy belongs to the deterministic U-Net baseline (out of scope)")
+    """posteriors.py:135-138: placeholder latents of the deterministic U-Net baseline (experiments/detunet.py) -- three lists of
+    tf.constant(0), never consumed (det_unet2D ignores z_list, the KL term is switched off)."""
+    latent_levels = kwargs.get('latent_levels', 5)
+    zero = [G.constant(0.0)] * latent_levels
+    return [zero, zero, zero]

@@ -1,4 +1,5 @@
 """Priors p(z | x) -- same callables as the reference's phiseg/model_zoo/priors.py."""
+from phiseg_code_amd import graph as G
 from phiseg_code_amd.phiseg.model_zoo import _common
 from phiseg_code_amd.tfwrapper import normalisation as tfnorm
 
@@ -19,4 +20,8 @@ def phiseg(z_list, x, zdim_0, n_classes, generation_mode, training, scope_reuse=
 
 def dummy(z_list, x, zdim_0, n_classes, generation_mode, training, scope_reuse=False, norm=tfnorm.batch_norm,
           **kwargs):
-    raise NotImplementedError("priors.dummy belongs to the deterministic U-Net baseline (out of scope)")
+    """priors.py:130-133: placeholder latents of the deterministic U-Net baseline (experiments/detunet.py) -- three lists of
+    tf.constant(0), never consumed (det_unet2D ignores z_list, the KL term is switched off)."""
+    latent_levels = kwargs.get('latent_levels', 5)
+    zero = [G.constant(0.0)] * latent_levels
+    return [zero, zero, zero]

@@ -21,18 +21,23 @@ def make_config(cfg, compute_dtype="f32"):
     base = importlib.import_module("phiseg_code_amd.phiseg.experiments.phiseg_7_5")
     c = types.SimpleNamespace(**{k: getattr(base, k) for k in dir(base) if not k.startswith("_")})
     arch = cfg["arch"]
-    c.posterior, c.prior, c.likelihood = getattr(posteriors, arch), getattr(priors, arch), getattr(likelihoods, arch)
+    if arch == "det_unet2D":              # the deterministic baseline: dummy latent nets (experiments/detunet.py)
+        c.posterior, c.prior, c.likelihood = posteriors.dummy, priors.dummy, likelihoods.det_unet2D
+    else:
+        c.posterior, c.prior, c.likelihood = getattr(posteriors, arch), getattr(priors, arch), getattr(likelihoods, arch)
     c.layer_norm = NORMS[cfg["norm"]]
     c.latent_levels, c.resolution_levels = cfg["latent_levels"], cfg["resolution_levels"]
     c.n0, c.zdim0, c.nlabels = cfg["n0"], cfg["zdim0"], cfg["nlabels"]
     c.image_size = (cfg["H"], cfg["H"], 1)
     c.batch_size = cfg["B"]
+    if cfg.get("KL_weight", 1.0) is None:
+        c.KL_divergence_loss_weight = None
     c.compute_dtype = compute_dtype
     return c
 
 
 @pytest.mark.parametrize("case", ["tiny_phiseg_bn", "tiny_phiseg_gn4", "tiny_phiseg_in", "tiny_probunet_bn",
-                                  "tiny_phiseg71_bn", "tiny_phiseg_bn_192", "lidc_phiseg_bn"])
+                                  "tiny_phiseg71_bn", "tiny_phiseg_bn_192", "lidc_phiseg_bn", "tiny_detunet_bn"])
 def test_variables_match_reference_trace(case):
     g, cfg, var_order = load_golden(case)
     model = phiseg_model.phiseg(make_config(cfg))
@@ -41,7 +46,7 @@ def test_variables_match_reference_trace(case):
     # 11 loss_dict entries for 5 latent levels, same keys as the reference (phiseg_model.py:253,279,130)
     L = cfg["latent_levels"]
     want = {"total_loss"} | {"residual_multinoulli_loss_lvl%d" % i for i in range(L)} | \
-           {"KL_divergence_loss_lvl%d" % i for i in range(L)}
+           ({"KL_divergence_loss_lvl%d" % i for i in range(L)} if cfg.get("KL_weight", 1.0) is not None else set())
     assert set(model.loss_dict) == want
 
 
@@ -62,12 +67,14 @@ def test_experiment_config_surface():
             "batch_size", "num_iter", "annotator_range", "KL_divergence_loss_weight", "exponential_weighting",
             "residual_multinoulli_loss_weight", "do_image_summaries", "rescale_RGB", "validation_frequency",
             "validation_samples", "num_validation_images", "tensorboard_update_frequency"]
-    for name in ["phiseg_7_5", "phiseg_7_1", "phiseg_7_5_1annot", "phiseg_7_1_1annot", "probunet", "probunet_1annot"]:
+    for name in ["phiseg_7_5", "phiseg_7_1", "phiseg_7_5_1annot", "phiseg_7_1_1annot", "probunet", "probunet_1annot", "detunet"]:
         m = importlib.import_module("phiseg_code_amd.phiseg.experiments." + name)
         for k in want:
             assert hasattr(m, k), (name, k)
     pu = importlib.import_module("phiseg_code_amd.phiseg.experiments.probunet")
     assert pu.zdim0 == 6 and pu.latent_levels == 1 and pu.posterior is posteriors.prob_unet2D
+    du = importlib.import_module("phiseg_code_amd.phiseg.experiments.detunet")
+    assert du.likelihood is likelihoods.det_unet2D and du.posterior is posteriors.dummy and du.KL_divergence_loss_weight is None
 
 
 def test_c_abi_exports_every_declared_symbol():

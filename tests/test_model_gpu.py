@@ -548,3 +548,28 @@ def test_shared_encoder_sampling_equals_tiled_batch_fp32():
     seg, sm = model.predict(x2, num_samples=n, return_softmax=True)
     np.testing.assert_allclose(sm, a.reshape(2, n, *a.shape[1:]).mean(axis=1), rtol=0, atol=2e-6)
     assert seg.shape == x2.shape[:3] and (seg == sm.argmax(-1)).all()
+
+
+def test_deterministic_unet_baseline_matches_reference_goldens_fp32():
+    """experiments/detunet.py (reference likelihoods.py:10-79 with posteriors.dummy / priors.dummy, no KL term): logits, the
+    cross-entropy ELBO, the evaluation instance and three Adam steps against the golden produced by executing the reference's
+    det_unet2D, and against the oracle."""
+    case = "tiny_detunet_bn"
+    g, cfg, var_order, model, params, x_np, s_np = build(case)
+    assert set(model.loss_dict) == {"total_loss", "residual_multinoulli_loss_lvl0"}
+    s_list, losses = model.sess.run([model.s_out_list, [model.loss_dict[k] for k in sorted(model.loss_dict)]],
+                                    {model.x_inp: x_np, model.s_inp: s_np, model.training_pl: True})
+    check_tensor(g, "train/s_0", s_list[0], fwd_tol(case, "s"))
+    for k, v in zip(sorted(model.loss_dict), losses):
+        np.testing.assert_allclose(float(v), float(g["train/loss/" + k]), rtol=fwd_tol(case, "loss"), err_msg=k)
+    s_eval, s_out = model.sess.run([model.s_out_eval_list, model.s_out_eval], {model.x_inp: x_np, model.training_pl: False})
+    check_tensor(g, "infer/s_eval_0", s_eval[0], fwd_tol(case, "s"))
+    check_tensor(g, "infer/s_out_eval", s_out, fwd_tol(case, "s"))
+    lr = 1e-5
+    ref_losses = otrain.train_steps(params, [(x_np, s_np)], cfg, cfg["eps_seed"], lr=lr, n_steps=3)
+    got = []
+    for _ in range(3):
+        _, lt = model.sess.run([model.train_step, model.loss_tot],
+                               {model.x_inp: x_np, model.s_inp: s_np, model.training_pl: True, model.lr_pl: lr})
+        got.append(float(lt))
+    np.testing.assert_allclose(got, [l["total_loss"] for l in ref_losses], rtol=1e-3)

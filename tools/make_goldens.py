@@ -40,7 +40,8 @@ from phiseg import phiseg_model as ref_model  # noqa: E402          (reference f
 NORMS = {"batch_norm": tfnorm.batch_norm, "group_norm": tfnorm.group_norm2D,
          "instance_norm": tfnorm.instance_norm2D}
 ZOO = {"phiseg": (posteriors.phiseg, priors.phiseg, likelihoods.phiseg),
-       "prob_unet2D": (posteriors.prob_unet2D, priors.prob_unet2D, likelihoods.prob_unet2D)}
+       "prob_unet2D": (posteriors.prob_unet2D, priors.prob_unet2D, likelihoods.prob_unet2D),
+       "det_unet2D": (posteriors.dummy, priors.dummy, likelihoods.det_unet2D)}
 
 CASES = {
     # name: cfg.  H must be a multiple of 2^(resolution_levels-1) = 64.  The "tiny" cases keep the LIDC geometry
@@ -57,6 +58,9 @@ CASES = {
     "tiny_phiseg_bn_192": dict(arch="phiseg", norm="batch_norm", n0=4, zdim0=2, H=192, B=2, nlabels=4),
     "lidc_phiseg_bn": dict(arch="phiseg", norm="batch_norm", n0=32, zdim0=2, H=128, B=2, nlabels=2,
                            full=False),
+    # the deterministic U-Net baseline (experiments/detunet.py): dummy posterior / prior, no KL term
+    "tiny_detunet_bn": dict(arch="det_unet2D", norm="batch_norm", n0=4, zdim0=6, H=128, B=3, nlabels=2, latent_levels=1,
+                            KL_weight=None),
 }
 
 
@@ -65,7 +69,8 @@ def full_cfg(c):
     c.setdefault("latent_levels", 5)
     c.setdefault("resolution_levels", 7)
     c.setdefault("full", True)
-    c.update(image_size=(c["H"], c["H"], 1), KL_weight=1.0, CE_weight=1.0, exponential_weighting=True,
+    c.setdefault("KL_weight", 1.0)
+    c.update(image_size=(c["H"], c["H"], 1), CE_weight=1.0, exponential_weighting=True,
              weight_seed=0, eps_seed=42, data_seed=1234)
     return c
 
@@ -117,7 +122,8 @@ def run_reference(cfg, training):
     stub.prior_mu_list, stub.prior_sigma_list = pmu, psig
     stub.loss_dict, stub.loss_tot = {}, 0
     stub.add_residual_multinoulli_loss()
-    stub.add_hierarchical_KL_div_loss()
+    if cfg["KL_weight"] is not None:                      # phiseg_model.py:122: hasattr / not None guard
+        stub.add_hierarchical_KL_div_loss()
     s_out_eval = stub._aggregate_output_list(list(s_eval), use_softmax=False)
     return dict(x=x_np, s=s_np, z=z, mu=mu, sigma=sigma, prior_mu=pmu, prior_sigma=psig,
                 prior_z_gen=pzg, prior_mu_gen=pmug, prior_sigma_gen=psigg, s_list=s_list,
@@ -154,7 +160,7 @@ def main():
         r = run_reference(cfg, training=True)
         L = cfg["latent_levels"]
         for key in ("z", "mu", "sigma", "prior_mu", "prior_sigma"):
-            for l in range(L):
+            for l in range(L if cfg["arch"] != "det_unet2D" else 0):
                 summarise("train/%s_%d" % (key, l), t2n(r[key][l]), out, cfg["full"])
         for l in range(L):
             summarise("train/s_%d" % l, t2n(r["s_list"][l]), out, cfg["full"])
@@ -181,7 +187,8 @@ def main():
         # ---- inference-mode pass (sampling path, phiseg_model.py:356-364) ---------------------
         r = run_reference(cfg, training=False)
         for l in range(L):
-            summarise("infer/prior_z_gen_%d" % l, t2n(r["prior_z_gen"][l]), out, cfg["full"])
+            if cfg["arch"] != "det_unet2D":
+                summarise("infer/prior_z_gen_%d" % l, t2n(r["prior_z_gen"][l]), out, cfg["full"])
             summarise("infer/s_eval_%d" % l, t2n(r["s_eval"][l]), out, cfg["full"])
         summarise("infer/s_out_eval", t2n(r["s_out_eval"]), out, cfg["full"])
         meta = {k: v for k, v in cfg.items() if k not in ("image_size",)}
