@@ -309,6 +309,17 @@ size_t phx_validation_metrics_ws_bytes(int I, int N, int M, int P, int C);
 int phx_validation_metrics(const float* sm, const unsigned char* gt, const unsigned char* sref, void* work, size_t work_bytes,
                            int I, int N, int M, int P, int C, int label0, float* out, void* stream);
 
+/* ---- transposed convolution (tfwrapper/layers.py:197-258, tf.nn.conv2d_transpose) --------------
+ * x [B,H,W,Cin] -> y [B, H*sh, W*sw, Cout], filter w_hwoi [kh][kw][Cout][Cin] fp32 (TF's layout), SAME padding, optional bias and
+ * activation.  dgrad: dy [B, H*sh, W*sw, Cout] -> dx [B,H,W,Cin].  wgrad ACCUMULATES into dw_hwoi.  Direct (untuned) kernels: no
+ * shipped experiment calls this layer. */
+int phx_tconv2d_fwd(const void* x, int x_dt, const float* w_hwoi, const float* bias, void* y, int y_dt, int B, int H, int W,
+                    int Cin, int Cout, int kh, int kw, int sh, int sw, int act, void* stream);
+int phx_tconv2d_dgrad(const void* dy, int dy_dt, const float* w_hwoi, void* dx, int dx_dt, int B, int H, int W, int Cin, int Cout,
+                      int kh, int kw, int sh, int sw, void* stream);
+int phx_tconv2d_wgrad(const void* x, int x_dt, const void* dy, int dy_dt, float* dw_hwoi, int B, int H, int W, int Cin, int Cout,
+                      int kh, int kw, int sh, int sw, void* stream);
+
 /* ---- mini-batch producer on the device ---------------------------------------------------
  * Replaces data/batch_provider.py:43-67 (next_batch), 131-137 (_select_random_label) and 140-272 (_augmentation_function with
  * the cv2 helpers of utils.py:18-38) for a data set resident in HBM: images [N][X][Y] f32, labels [N][X][Y][A] u8 (A annotators).

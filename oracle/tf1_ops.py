@@ -181,3 +181,19 @@ def he_normal_truncated(shape, seed, stream):
     keep = raw[np.abs(raw) <= 2.0]
     assert keep.size >= n
     return (keep[:n] * std).reshape(shape)
+
+
+def conv2d_transpose_same(x, w_hwoi, stride):
+    """[TF1.12] tf.nn.conv2d_transpose(x, filter [kh, kw, Cout, Cin], output [B, H*s, W*s, Cout], strides s, 'SAME')
+    (tfwrapper/layers.py:225-229): the gradient of the stride-s SAME conv2d with respect to its input -- torch's
+    conv_transpose2d gives the un-cropped result of size (H - 1) s + k, of which rows / columns [pad_before, pad_before + H s)
+    are kept, pad_before = max((H - 1) s + k - H s, 0) // 2 (TF's SAME rule for the forward convolution)."""
+    kh, kw, cout, cin = w_hwoi.shape
+    sh, sw = stride
+    B, H, W, _ = x.shape
+    full = F.conv_transpose2d(x.permute(0, 3, 1, 2), w_hwoi.permute(3, 2, 0, 1), stride=(sh, sw))
+    Ho, Wo = H * sh, W * sw
+    th, tw = max((H - 1) * sh + kh - Ho, 0), max((W - 1) * sw + kw - Wo, 0)
+    pt, pl = th // 2, tw // 2
+    full = F.pad(full, (0, max(0, pl + Wo - full.shape[3]), 0, max(0, pt + Ho - full.shape[2])))
+    return full[:, :, pt:pt + Ho, pl:pl + Wo].permute(0, 2, 3, 1)

@@ -606,8 +606,61 @@ class Plan:
             self._pack_jobs.append((self.store.ptr(W), wf.ptr, wd.ptr, cin, cin, cout))
         return self._wpk[W.name]
 
+    def _fw_tconv_unit(self, op, bw):
+        """tf.nn.conv2d_transpose -> [bias] -> [norm] -> act (tfwrapper/layers.py:197-258) on the direct kernels of tconv.hip;
+        the normalisation runs as statistics pass + fused apply on the up-sampled tensor."""
+        a = op.attrs
+        x = self.val[op.inputs[0]]
+        W, b = a["W"], a["b"]
+        kh, kw, sh, sw = a["transposed"]
+        cout, cin = W.shape[2], W.shape[3]
+        B, H, Wd = x.shape[0], x.shape[1], x.shape[2]
+        out = self._alloc_like(op.outputs[0])
+        self.val[op.outputs[0]] = out
+        Ho, Wo = out.shape[1], out.shape[2]
+        act = rt.ACT_CODES[a["act"]]
+        norm = a["norm"]
+        training = a["training"] if isinstance(a["training"], bool) else self.training
+        S, Lb = self.stream, self.L
+        wptr, bptr = self.store.ptr(W), (self.store.ptr(b) if b is not None else None)
+        st = dict(x=x, out=out, mfma=False, norm=norm, padded=False, cin_eff=cin, k1=False, head1x1=False, transposed=a["transposed"])
+        geo = (B, H, Wd, cin, cout, kh, kw, sh, sw)
+        if norm is None:
+            self._emit(Lb.tconv2d_fwd, x.ptr, x.dt, wptr, bptr, out.ptr, out.dt, *geo, act, S)
+            self.saved[op] = st
+            return
+        nv = a["norm_vars"]
+        gptr, beptr = self.store.ptr(nv["gamma"]), self.store.ptr(nv["beta"])
+        y = self._alloc(out.shape, out.dt)
+        self._emit(Lb.tconv2d_fwd, x.ptr, x.dt, wptr, bptr, y.ptr, y.dt, *geo, 0, S)
+        if norm == "batch":
+            NS, P, Gn = 1, B * Ho * Wo, cout
+        else:
+            Gn = cout if norm == "instance" else (a["num_groups"] or max(2, cout // 16))
+            NS, P = B, Ho * Wo
+        scale, shift = self._alloc((NS * cout,), F32), self._alloc((NS * cout,), F32)
+        mean, rstd = self._alloc((NS * Gn,), F32), self._alloc((NS * Gn,), F32)
+        eps = tfnorm.EPS[norm]
+        if norm == "batch" and not training:
+            self._emit(Lb.bn_infer_scale_shift, gptr, beptr, self.store.ptr(nv["moving_mean"]),
+                       self.store.ptr(nv["moving_variance"]), eps, cout, scale.ptr, shift.ptr, S)
+            self._emit(Lb.affine_act, y.ptr, y.dt, scale.ptr, shift.ptr, out.ptr, out.dt, NS, P, cout, act, S)
+        else:
+            sums = self._alloc_zeroed(NS * cout * 2)
+            pivot = self._alloc((NS * cout,), F32)
+            self._emit(Lb.norm_stats, y.ptr, y.dt, sums.ptr, pivot.ptr, NS, P, cout, S)
+            upd = norm == "batch" and training and self.loss is not None
+            self._emit(Lb.norm_apply_fused, y.ptr, y.dt, sums.ptr, pivot.ptr, gptr, beptr, eps, out.ptr, out.dt, mean.ptr, rstd.ptr,
+                       scale.ptr, shift.ptr, self.store.ptr(nv["moving_mean"]) if upd else None,
+                       self.store.ptr(nv["moving_variance"]) if upd else None, (1.0 - tfnorm.BN_DECAY) if upd else 0.0,
+                       NS, P, cout, Gn, act, S)
+        st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn)
+        self.saved[op] = st
+
     def _fw_conv_unit(self, op, bw):
         a = op.attrs
+        if a.get("transposed") is not None:
+            return self._fw_tconv_unit(op, bw)
         x = self.val[op.inputs[0]]
         W, b = a["W"], a["b"]
         k, (_, _, cin, cout) = a["ksize"], W.shape
@@ -988,6 +1041,8 @@ class Plan:
         x, out = sv["x"], sv["out"]
         W, b = a["W"], a["b"]
         k, (_, _, cin, cout) = a["ksize"], W.shape
+        if sv.get("transposed") is not None:
+            cout, cin = W.shape[2], W.shape[3]
         B, H, Wd = x.shape[0], x.shape[1], x.shape[2]
         act = rt.ACT_CODES[a["act"]]
         S, Lb = self.stream, self.L
@@ -1029,6 +1084,17 @@ class Plan:
             dY = dA
         dw = self.store.grad_ptr(W)
         db = self.store.grad_ptr(b) if b is not None else None
+        if sv.get("transposed") is not None:
+            kh, kw, sh, sw = sv["transposed"]
+            geo = (B, H, Wd, cin, cout, kh, kw, sh, sw)
+            self._emit(Lb.tconv2d_wgrad, x.ptr, x.dt, dY.ptr, dY.dt, dw, *geo, S)
+            if db is not None:
+                self._emit(Lb.channel_sum_accumulate, dY.ptr, dY.dt, db, dY.n // cout, cout, S)
+            xin = op.inputs[0]
+            if self.req.get(xin, False):
+                self._add_grad(xin, write_fn=lambda g: self._emit(Lb.tconv2d_dgrad, dY.ptr, dY.dt, self.store.ptr(W), g.ptr, g.dt,
+                                                                   *geo, S))
+            return
         # (The filter gradient is a leaf of the backward graph; moving these launches to another lane, beside the data-
         # gradient chain, was measured 20 % SLOWER: both are bound by the same global->LDS path, so the kernel on the
         # critical path just gets half of it.)

@@ -219,13 +219,19 @@ def random_normal(like, stream):
     return get_default_graph().add_op("random_normal", [like], dict(stream=int(stream)), [(like.shape, KIND_F32)])[0]
 
 
-def conv_unit(x, W, b, ksize, norm, norm_vars, act, training, num_groups=None, head=False, name="conv"):
-    """conv (SAME, stride 1) -> [+bias] -> [norm] -> act as ONE node (tfwrapper/layers.py:122-135)."""
-    cout = W.shape[3]
+def conv_unit(x, W, b, ksize, norm, norm_vars, act, training, num_groups=None, head=False, name="conv", transposed=None):
+    """conv (SAME, stride 1) -> [+bias] -> [norm] -> act as ONE node (tfwrapper/layers.py:122-135).
+    transposed = (kh, kw, sh, sw): tf.nn.conv2d_transpose instead (layers.py:197-258), W is [kh, kw, Cout, Cin] and the output
+    is sh x sw times larger."""
     kind = KIND_F32 if head else KIND_ACT
     attrs = dict(W=W, b=b, ksize=int(ksize), norm=norm, norm_vars=norm_vars, act=act, training=training,
-                 num_groups=num_groups, head=head)
-    return get_default_graph().add_op("conv_unit", [x], attrs, [(x.shape[:3] + (cout,), kind)], name=name)[0]
+                 num_groups=num_groups, head=head, transposed=transposed)
+    if transposed is not None:
+        kh, kw, sh, sw = transposed
+        shape = (x.shape[0], x.shape[1] * sh, x.shape[2] * sw, W.shape[2])
+    else:
+        shape = x.shape[:3] + (W.shape[3],)
+    return get_default_graph().add_op("conv_unit", [x], attrs, [(shape, kind)], name=name)[0]
 
 
 def avg_pool2x2(x):

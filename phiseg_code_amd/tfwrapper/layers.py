@@ -4,7 +4,8 @@ Hot-path layers (surface B1): ``conv2D`` (layers.py:94-1
 ``bilinear_upsample2D`` (336-345), ``global_averagepool2D`` (70-78), ``crop_and_concat`` (586-622),
 ``nearest_neighbour_upsample2D`` (326-333).  Every call adds nodes to ``phiseg_code_amd.graph``; the arithmetic
 runs in hand-written HIP kernels (libphx.so).  Layers that no PHiSeg configuration calls (3-D variants,
-residual units, dense, dilated / transposed conv) keep their names and raise NotImplementedError.
+residual units, dense, dilated conv) keep their names and raise NotImplementedError; transposed_conv2D (named by the
+north star) is implemented on direct kernels.
 """
 import logging
 
@@ -78,6 +79,46 @@ def conv2D(x,
                            training, num_groups=kwargs.get('num_groups'), head=head, name='conv')
 
 
+def transposed_conv2D(bottom,
+                      name,
+                      kernel_size=(4, 4),
+                      num_filters=32,
+                      strides=(2, 2),
+                      output_shape=None,
+                      activation=STANDARD_NONLINEARITY,
+                      normalisation=tfnorm.identity,
+                      normalise_post_activation=False,
+                      dropout_p=None,
+                      padding="SAME",
+                      weight_init='he_normal',
+                      add_bias=True,
+                      **kwargs):
+    """Standard 2-D transposed convolution (tfwrapper/layers.py:197-258): tf.nn.conv2d_transpose with a [kh, kw, num_filters,
+    bottom channels] filter, default behaviour up-samples by a factor of 2; -> [bias] -> normalisation -> activation.  Unlike
+    conv2D the reference keeps the bias here even in front of batch_norm (layers.py:231-234)."""
+    if padding != "SAME":
+        raise NotImplementedError("transposed_conv2D: SAME padding (the reference's default) only")
+    if normalise_post_activation or dropout_p is not None:
+        raise NotImplementedError("normalise_post_activation / dropout are never set by the PHiSeg configs")
+    if normalisation not in tfnorm.KIND:
+        raise ValueError("Unknown normalisation callable %r" % (normalisation,))
+    if activation not in activations.ACT_NAME:
+        raise ValueError("Unknown activation callable %r" % (activation,))
+    shp = bottom.get_shape().as_list()
+    if output_shape is not None and tuple(output_shape[1:3]) != (shp[1] * strides[0], shp[2] * strides[1]):
+        raise NotImplementedError("transposed_conv2D: output_shape other than input * strides")
+    weight_shape = [kernel_size[0], kernel_size[1], num_filters, shp[3]]
+    g = G.get_default_graph()
+    with g.variable_scope(name):
+        weights = utils.get_weight_variable(weight_shape, name='W', type=weight_init, regularize=True)
+        biases = utils.get_bias_variable([num_filters], name='b') if add_bias else None
+        kind = tfnorm.KIND[normalisation]
+        norm_vars = tfnorm.make_variables(kind, num_filters)
+        return G.conv_unit(bottom, weights, biases, kernel_size[0], kind, norm_vars, activations.ACT_NAME[activation],
+                           kwargs.get('training', True), num_groups=kwargs.get('num_groups'), head=False, name='deconv',
+                           transposed=(int(kernel_size[0]), int(kernel_size[1]), int(strides[0]), int(strides[1])))
+
+
 def nearest_neighbour_upsample2D(x, factor):
     shp = x.get_shape().as_list()
     return G.resize_nearest(x, (shp[1] * factor, shp[2] * factor))
@@ -117,7 +158,6 @@ maxpool2D = _not_on_hot_path("maxpool2D")
 maxpool3D = _not_on_hot_path("maxpool3D")
 reshape_pool2D_layer = _not_on_hot_path("reshape_pool2D_layer")
 conv3D = _not_on_hot_path("conv3D")
-transposed_conv2D = _not_on_hot_path("transposed_conv2D")
 transposed_conv3D = _not_on_hot_path("transposed_conv3D")
 bilinear_upsample3D = _not_on_hot_path("bilinear_upsample3D")
 dilated_conv2D = _not_on_hot_path("dilated_conv2D")
