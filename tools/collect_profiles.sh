@@ -19,5 +19,11 @@ cd $R
 db=$(find $O/stats -name "*results.db" | head -1)
 python tools/prof_summary.py $db 11 > $O/kernel_stats.txt
 python tools/pmc_summary.py $O/pmc 4 $O/pmc_hbm_traffic.txt $O/pmc_hbm_traffic.json > /dev/null
+# MFMA / LDS utilisation of the convolution kernels (one more PMC pass, kernel trace only)
+cd /tmp
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc/MFMA -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-roofline > $O/pmc_MFMA.log 2>&1
+cd $R
+f=$(find $O/pmc/MFMA -name "*counter_collection.csv" | head -1)
+python tools/pmc_mfma_summary.py "$f" 4 $O/pmc_mfma_lds_util.txt > /dev/null 2>&1 || true
 rm -rf $O/stats $O/pmc/*/runc $O/pmc/*/*/ 2>/dev/null
 head -5 $O/kernel_stats.txt; tail -1 $O/pmc_hbm_traffic.txt; tail -c 400 $O/bench.json
