@@ -400,7 +400,8 @@ def test_bf16_gradients_n0_32_vs_simulated_bf16_oracle():
         inh = np.linalg.norm(g_sim[name] - ge) / nrm
         e = np.linalg.norm(gh - ge) / nrm
         e_s = np.linalg.norm(gh - g_sim[name]) / nrm
-        bound = 2.0 * max(inh, 0.03)
+        # (the relative L2 error of a 2-element bias is itself a noisy statistic: a handful of elements get 3x)
+        bound = (2.0 if ge.size >= 64 else 3.0) * max(inh, 0.03)
         assert e <= bound and e_s <= bound, (name, e, e_s, inh)
         if e / bound > worst[0]:
             worst = (e / bound, name, e, inh)
@@ -408,6 +409,7 @@ def test_bf16_gradients_n0_32_vs_simulated_bf16_oracle():
     print("bf16 gradients: %d variables, mean rel. L2 error %.4f (simulated policy itself %.4f), worst %s" %
           (n_checked, tot_e / n_checked, tot_inh / n_checked, worst))
     assert n_checked >= 360                           # 368 live trainable tensors
+    assert tot_e <= 1.3 * tot_inh + 0.03 * n_checked  # on average the HIP path deviates no more than the simulated policy itself
 
 
 NSTEP = 12
