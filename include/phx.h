@@ -296,6 +296,11 @@ int phx_sum_scalars(const float* in, int n, float* out, void* stream);
  * (loss_tot of phiseg_model.py:118-130) */
 int phx_weighted_sum(const float* const* ptrs, const float* weights, int n, float* out, void* stream);
 
+/* weight decay (phiseg_model.py:290-299): out = scale * sum_i mask[i] p[i]^2 / 2 over the flat parameter arena (mask = 1 on the members of
+ * the 'weight_variables' collection; work256: 256 floats of scratch), and its gradient g += alpha * mask * p */
+int phx_l2_masked(const float* p, const float* mask, size_t n, float scale, float* work256, float* out, void* stream);
+int phx_axpy_masked(float* g, const float* p, const float* mask, size_t n, float alpha, void* stream);
+
 /* ---- validation metrics on the device ---------------------------------------------------
  * What phiseg_model._do_validation computes per validation image (phiseg_model.py:586-613 calling
  * utils.generalised_energy_distance utils.py:270-322, utils.variance_ncc_dist utils.py:326-370 and the Dice loop), for I

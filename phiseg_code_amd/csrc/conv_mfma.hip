@@ -2680,8 +2680,9 @@ int phx_conv3x3_wgrad_multi_job(const void* x, const void* dy, float* dw_hwio, v
     }
     const int npatch = g.tb * ((1 << g.ths) + 2) * ((1 << g.tws) + 2);
     const bool use_ws = workspace != nullptr && ntiles > wgrad_atomic_tiles();
-    if (use_ws)
-        PHX_REQUIRE(workspace_bytes >= phx_conv3x3_wgrad_ws_bytes(B, H, W, Cin, Cout), PHX_E_INVAL, "conv3x3_wgrad_multi_job: workspace too small");
+    if (use_ws)      // the partial filters of THIS plan (blocks_target may split the pixel tiles finer than the stand-alone launch)
+        PHX_REQUIRE(workspace_bytes >= (size_t)(Cin / tci) * (Cout / tco) * gx * wk * 9 * tci * tco * sizeof(float), PHX_E_INVAL,
+                    "conv3x3_wgrad_multi_job: workspace too small for this blocks_target");
     WgMJob j;
     j.x = (const unsigned short*)x; j.dy = (const unsigned short*)dy; j.dw = dw_hwio; j.ws = use_ws ? (float*)workspace : nullptr;
     j.B = B; j.H = H; j.W = W; j.Cin = Cin; j.Cout = Cout; j.g = g; j.ntiles = ntiles; j.tpb = tpb;

@@ -207,6 +207,30 @@ __global__ void k_kl(const float* __restrict__ mu0, const float* __restrict__ s0
     if (threadIdx.x == 0) atomicAdd(loss, (sh[0] + sh[1] + sh[2] + sh[3]) * lw * inv_batch);
 }
 
+// ---- weight decay (phiseg_model.py:290-299): weight * sum over the 'weight_variables' collection of tf.nn.l2_loss(W) = sum w^2 / 2.
+// The variables live in one flat arena; `mask` (1 for the elements of collection members, 0 elsewhere) selects them, so the
+// term is one pass over the arena whatever the number of variables.  Two stages, fixed order: deterministic.
+__global__ void k_l2_masked_partial(const float* __restrict__ p, const float* __restrict__ mask, size_t n, float* __restrict__ part) {
+    float a = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a += mask[i] * p[i] * p[i];
+    __shared__ float sh[4];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ void k_l2_masked_finish(const float* __restrict__ part, int nb, float scale, float* __restrict__ out) {
+    float a = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 64) a += part[i];
+    a = wave_sum(a);
+    if (threadIdx.x == 0) *out = 0.5f * scale * a;
+}
+// g += alpha * mask * p   (the gradient of alpha * l2 term)
+__global__ void k_axpy_masked(float* __restrict__ g, const float* __restrict__ p, const float* __restrict__ mask, size_t n, float alpha) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        g[i] = fmaf(alpha * mask[i], p[i], g[i]);
+}
+
 // ---- Adam, TF 1.12 form ----------------------------------------------------------------------------
 __global__ void k_adam_tf1(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                            float* __restrict__ v, size_t n4, size_t n, const float* __restrict__ lr_dev, float b1,
@@ -332,6 +356,21 @@ int phx_kl_diag_gauss(const float* mu0, const float* s0, const float* mu1, const
     PHX_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream));
     hipLaunchKernelGGL(k_kl, dim3(phx_deterministic() ? 1 : phx_grid_for(n, 256, 64)), dim3(256), 0, (hipStream_t)stream, mu0, s0, mu1, s1, n,
                        level_w, inv_batch, grad_scale, loss, dmu0, ds0, dmu1, ds1);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+/* out = scale * sum_i mask[i] p[i]^2 / 2; work: 256 floats of scratch */
+int phx_l2_masked(const float* p, const float* mask, size_t n, float scale, float* work256, float* out, void* stream) {
+    PHX_REQUIRE(p && mask && work256 && out, PHX_E_INVAL, "l2_masked: null argument");
+    hipLaunchKernelGGL(k_l2_masked_partial, dim3(256), dim3(256), 0, (hipStream_t)stream, p, mask, n, work256);
+    hipLaunchKernelGGL(k_l2_masked_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)work256, 256, scale, out);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+int phx_axpy_masked(float* g, const float* p, const float* mask, size_t n, float alpha, void* stream) {
+    PHX_REQUIRE(g && p && mask, PHX_E_INVAL, "axpy_masked: null argument");
+    hipLaunchKernelGGL(k_axpy_masked, dim3(phx_grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, g, p, mask, n, alpha);
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }

@@ -58,6 +58,8 @@ def live_variables(loss):
         if op in seen:
             continue
         seen.add(op)
+        if op.type == "l2_weights":            # weight decay reaches every member of the collection (never-consumed branches too)
+            live.update(v.name for v in op.attrs["vars"])
         if op.type == "conv_unit":
             a = op.attrs
             for v in (a["W"], a["b"]):
@@ -498,7 +500,7 @@ class Plan:
             # (Launching what the likelihood and the prior have deferred on the prior's lane as soon as their backward is
             # done, beside the posterior's backward chain, was measured 7 % slower than one batch after the join.)
             for op in reversed(ops):
-                if any(o in self.grad for o in op.outputs) or op.type in ("residual_ce", "kl"):
+                if any(o in self.grad for o in op.outputs) or op.type in ("residual_ce", "kl", "l2_weights"):
                     self._lane = self.op_lane[op]
                     self._cur_bw_op = op
                     self._wait(self.fw_event.get(op))        # forward of this op may live on another lane's past
@@ -556,6 +558,27 @@ class Plan:
         if op.attrs["value"] != 0.0:
             b.t.fill_(op.attrs["value"])
         self.val[op.outputs[0]] = b
+
+    def _fw_l2_weights(self, op, bw):
+        st = self.store
+        if not hasattr(st, "decay_mask"):
+            m = torch.zeros_like(st.params)
+            for v in op.attrs["vars"]:
+                off = st.offset[v.name]
+                m[off:off + v.size] = 1.0
+            st.decay_mask = m
+            device_sync()
+        out = self._alloc((), F32)
+        work = self._alloc((256,), F32)
+        self.val[op.outputs[0]] = out
+        self._emit(self.L.l2_masked, st.params.data_ptr(), st.decay_mask.data_ptr(), st.n_train, op.attrs["scale"], work.ptr, out.ptr, self.stream)
+        if bw:
+            self._l2_weight = self.loss_weight.get(op.outputs[0], 0.0) * op.attrs["scale"]
+
+    def _bw_l2_weights(self, op):
+        st = self.store
+        self._emit(self.L.axpy_masked, st.grads.data_ptr(), st.params.data_ptr(), st.decay_mask.data_ptr(), st.n_train,
+                   float(self._l2_weight), self.stream)
 
     def _fw_one_hot(self, op, bw):
         pass            # virtual: consumed by the fused posterior-input kernel / the loss kernel

@@ -289,6 +289,13 @@ def kl_two_gauss(mu0, sigma0, mu1, sigma1, level_weight, loss_weight):
                                       [((), KIND_F32)], name="KL")[0]
 
 
+def l2_of_collection(scale=1.0, name="weight_variables"):
+    """scale * sum of tf.nn.l2_loss over a variable collection (phiseg_model.py:290-299, add_weight_decay)."""
+    g = get_default_graph()
+    return g.add_op("l2_weights", [], dict(vars=list(g.get_collection(name)), scale=float(scale)), [((), KIND_F32)],
+                    name="weights_norm")[0]
+
+
 def aggregate_logits(s_list):
     """_aggregate_output_list(use_softmax=False) + tf.nn.softmax (phiseg_model.py:106-109, 304-311)
     -> (sum of levels, softmax of the sum)."""

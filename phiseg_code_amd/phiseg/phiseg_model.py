@@ -98,6 +98,8 @@ class Session:
             raise ValueError("feed_dict must provide x_inp")
         x = np.asarray(x)
         training = bool(feed_dict.get(m.training_pl, False))
+        if train and training and m.bn_double_update:
+            tensors = tensors + [m.s_out_eval]         # Q4: the second graph instances run (and update moving statistics) too
         plan = self.plan_for(tensors, train, x.shape[0], training)
         plan.set_input("x_input", x)
         if "s_input" in plan.feeds:
@@ -130,8 +132,13 @@ class Session:
 
 class phiseg():
 
-    def __init__(self, exp_config, dist=None, init_seed=0, rng_seed=42):
+    def __init__(self, exp_config, dist=None, init_seed=0, rng_seed=42, bn_double_update=None):
+        """bn_double_update (default: $PHX_BN_DOUBLE_UPDATE == 1): reproduce the TF graph's UPDATE_OPS behaviour (SURVEY.md Q4,
+        phiseg_model.py:135-141): every training step also runs the generation-mode prior and the evaluation likelihood in
+        training mode, so the batch-norm moving statistics of the layers they share with the training instances are updated
+        TWICE per step.  Off by default: only the live graph runs (1.9x less forward work)."""
         self.exp_config = exp_config
+        self.bn_double_update = (os.environ.get("PHX_BN_DOUBLE_UPDATE", "0") == "1") if bn_double_update is None else bool(bn_double_update)
         self.init_seed = init_seed
         self.checks()
         self.graph = G.reset_default_graph()
@@ -186,7 +193,11 @@ class phiseg():
                 terms.append(kl)
                 weights.append(w)
         if getattr(exp_config, 'weight_decay_weight', None) is not None:
-            raise NotImplementedError("weight decay is off in every PHiSeg experiment (phiseg_model.py:126)")
+            logging.info(' - Adding weight decay')                      # add_weight_decay (phiseg_model.py:126-128, 290-299)
+            wd = G.l2_of_collection(float(exp_config.weight_decay_weight), 'weight_variables')
+            self.loss_dict['weight_decay'] = wd
+            terms.append(wd)
+            weights.append(1.0)
         self.loss_tot = G.weighted_sum(terms, weights)
         self.loss_dict['total_loss'] = self.loss_tot
         self.train_step = TrainStep(self.loss_tot)

@@ -575,3 +575,72 @@ def test_deterministic_unet_baseline_matches_reference_goldens_fp32():
                                {model.x_inp: x_np, model.s_inp: s_np, model.training_pl: True, model.lr_pl: lr})
         got.append(float(lt))
     np.testing.assert_allclose(got, [l["total_loss"] for l in ref_losses], rtol=1e-3)
+
+
+def test_weight_decay_term_fp32():
+    """add_weight_decay (phiseg_model.py:126-128, 290-299): loss_dict['weight_decay'] = weight * sum of tf.nn.l2_loss over the
+    'weight_variables' collection -- EVERY conv filter, also those of the never-consumed branches -- and its gradient weight * W."""
+    import types
+    g, cfg, var_order = load_golden("tiny_phiseg_bn")
+    from phiseg_code_amd.phiseg import phiseg_model
+    c = make_config(cfg, "f32")
+    c.weight_decay_weight = 0.37
+    model = phiseg_model.phiseg(c, rng_seed=cfg["eps_seed"])
+    params, x_np, s_np = golden_inputs(cfg, var_order, dtype=torch.float64)
+    model.set_weights({k: v.detach().numpy() for k, v in params.items()})
+    keys = sorted(model.loss_dict)
+    out = model.sess.run([model.loss_dict[k] for k in keys], {model.x_inp: x_np, model.s_inp: s_np, model.training_pl: True})
+    vals = dict(zip(keys, [float(v) for v in out]))
+    wsum = sum(float((v.detach() ** 2).sum()) / 2 for k, v in params.items() if k.endswith("/W"))
+    np.testing.assert_allclose(vals["weight_decay"], 0.37 * wsum, rtol=2e-6)
+    np.testing.assert_allclose(vals["total_loss"], float(g["train/loss/total_loss"]) + 0.37 * wsum, rtol=5e-4)
+    # gradient: the ELBO gradient + 0.37 * W (dead-branch filters get 0.37 * W alone)
+    base = phiseg_model.phiseg(make_config(cfg, "f32"), rng_seed=cfg["eps_seed"])
+    base.set_weights({k: v.detach().numpy() for k, v in params.items()})
+    g0 = _hip_grads(base, cfg, x_np, s_np)
+    g1 = _hip_grads(model, cfg, x_np, s_np)
+    n_dead = 0
+    for k, v in params.items():
+        if not k.endswith("/W"):
+            continue
+        want = g0[k] + 0.37 * v.detach().numpy()
+        if np.abs(g0[k]).max() == 0:                 # never-consumed branch: the decay term is the whole gradient, exact
+            np.testing.assert_allclose(g1[k], want, rtol=1e-6, atol=1e-9, err_msg=k)
+            n_dead += 1
+        else:                                        # live filter: ELBO gradient (fp32 conditioning bound, GRAD_RTOL) + decay
+            np.testing.assert_allclose(g1[k], want, rtol=0, atol=GRAD_RTOL * max(np.abs(want).max(), 1e-3), err_msg=k)
+    assert n_dead > 0
+
+
+def test_bn_double_update_switch_reproduces_update_ops_fp32():
+    """SURVEY.md Q4 / phiseg_model.py:135-141: with control_dependencies(UPDATE_OPS) TF also runs the generation-mode prior and the
+    evaluation likelihood every training step, so the moving statistics of the prior / likelihood layers are updated twice (the
+    posterior's once).  bn_double_update=True reproduces that; checked against the oracle applying the two updates in turn."""
+    from oracle import nets
+    from phiseg_code_amd.phiseg import phiseg_model
+    g, cfg, var_order = load_golden("tiny_phiseg_bn")
+    model = phiseg_model.phiseg(make_config(cfg, "f32"), rng_seed=cfg["eps_seed"], bn_double_update=True)
+    params, x_np, s_np = golden_inputs(cfg, var_order, dtype=torch.float64)
+    model.set_weights({k: v.detach().numpy() for k, v in params.items()})
+    model.sess.run([model.train_step, model.loss_tot], {model.x_inp: x_np, model.s_inp: s_np, model.training_pl: True, model.lr_pl: 0.0})
+    got = model.sess.store.export()
+    xt, st = torch.as_tensor(x_np, dtype=torch.float64), torch.as_tensor(s_np)
+    eps = otrain.torch_eps_fn(cfg["eps_seed"], 0, cfg["B"])
+    with torch.no_grad():
+        first = nets.elbo(params, xt, st, eps, cfg, training=True)["moving_updates"]
+        p2 = dict(params)
+        p2.update(first)
+        ctx = nets.Ctx(p2, cfg["norm"], True)
+        kw = dict(n0=cfg["n0"], resolution_levels=cfg["resolution_levels"], latent_levels=cfg["latent_levels"])
+        pz, _, _ = nets.prior_phiseg(ctx, None, xt, True, eps, zdim_0=cfg["zdim0"], **kw)
+        nets.likelihood_phiseg(ctx, pz, cfg["image_size"], cfg["nlabels"], **kw)
+        second = ctx.moving_updates
+    n2 = 0
+    for k, v in first.items():
+        want = second.get(k, v)
+        n2 += int(k in second)
+        r = want.numpy()
+        np.testing.assert_allclose(got[k], r, rtol=0, atol=1e-4 * max(np.abs(r).max(), 1.0), err_msg=k)
+        if k in second and k.endswith("moving_mean"):
+            assert np.abs(second[k].numpy() - v.numpy()).max() > 0       # the second update really moved it
+    assert n2 > 50 and any(k.startswith("posterior/") and k not in second for k in first)
