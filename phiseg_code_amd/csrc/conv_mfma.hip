@@ -105,9 +105,15 @@ static int fwd_ws_mode() {
 }
 static bool fwd_ws64(int B, int H, int W, int K, int N) {
     const int en = fwd_ws_mode();
-    if (!en || H % 16 != 0 || W % 32 != 0 || N % 64 != 0 || K % 32 != 0) return false;
+    const bool dma128 = en == 1 || en == 5;                    // (the 32-channel-block variant exists for dma128 only)
+    if (!en || H % 16 != 0 || W % 32 != 0 || N % (dma128 ? 32 : 64) != 0 || K % 32 != 0) return false;
     if (en >= 2) return true;
-    return (long)B * (H / 16) * (W / 32) * (N / 64) >= 512;
+    // 32-channel blocks: 13 % faster than the 64-pixel-tile kernel at K = 32 (39 vs 45 us on 64 x 128 x 128), 8 % at K = 64,
+    // 5 % SLOWER at K = 192 (the patch is staged once per 32 output channels)
+    static int n32 = -1;
+    if (n32 < 0) { const char* t = getenv("PHX_FWD_N32"); n32 = t ? atoi(t) : 1; }                 // A/B hook
+    if (N % 64 != 0 && (K > 64 || !n32)) return false;
+    return (long)B * (H / 16) * (W / 32) * (N / (N % 64 == 0 ? 64 : 32)) >= 512;
 }
 static MTile make_mtile_fwd(int B, int H, int W, int K, int N, bool allow_dma = true) {
     if (allow_dma && (fwd_ws64(B, H, W, K, N) || fwd_dma_bn(B, H, W, K, N) || fwd_rs_bn(B, H, W, K, N))) {
@@ -1455,14 +1461,14 @@ __global__ __launch_bounds__(256 + 64 * NLW, 1) void k_conv3x3_fwd_ws128(const u
 
 // ---- the same 128-pixel wave tiles without loader waves: one 75 KiB stage per block, TWO blocks per CU -----------------
 __device__ unsigned g_phx_cu_arrivals[4096];
-template <bool BIASACT, int DBG>
+template <bool BIASACT, int DBG, int BN>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned short* __restrict__ x,
                                                              const unsigned short* __restrict__ wpk,
                                                              unsigned short* __restrict__ y, const float* __restrict__ bias,
                                                              int act, float* __restrict__ stats_partial,
                                                              int B, int H, int W, int K, int N, int tiles_x, int tiles_y, int dephase, const float* __restrict__ oscale) {
-    constexpr int BN = 64;
-    constexpr int AI = 39, BI = 36;                   // 1 KiB DMA instructions per chunk: 612 patch rows x 64 B, 576 slab rows
+    constexpr int NJ = BN / 32;                       // BN = 64 (two 32-channel MFMA columns per wave) or 32 (one)
+    constexpr int AI = 39, BI = 9 * BN * 64 / 1024;   // 1 KiB DMA instructions per chunk: 612 patch rows x 64 B, 9 * BN slab rows
     constexpr int NLW = 4;
     constexpr int NI = AI + BI, NPL = (NI + NLW - 1) / NLW;   // DMA instructions per wave
     constexpr int A_BYTES = AI * 1024, STAGE = NI * 1024;
@@ -1495,11 +1501,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
     constexpr bool loader = false;
     const int nch = K / 32;
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     PHX_BLOCKLOG_BEGIN();
@@ -1520,7 +1526,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
             if (pp < 612 && gx >= 0 && gx < W && gy >= 0 && gy < H && !(DBG & 1)) voff[n] = (unsigned)((((b0 * H + gy) * W + gx) * K) * 2 + piece * 16);
         } else if (j < NI) {
             const int e = (j - AI) * 64 + lane, rb = e >> 2, slot = e & 3;
-            const int tap = rb >> 6, nn = rb & 63;
+            const int tap = rb / BN, nn = rb % BN;
             const int piece = slot ^ ((nn >> 2) & 3);
             if (!(DBG & 2)) voff[n] = (unsigned)(((tap * N + n0 + nn) * 32 + piece * 8) * 2);
         }
@@ -1574,19 +1580,19 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
         };
         auto read_b = [&](auto tc) {
             constexpr int t = decltype(tc)::value;
-            constexpr int g = t / 2, j = t % 2, ks = g / 3, kw = g % 3;
+            constexpr int g = t / NJ, j = t % NJ, ks = g / 3, kw = g % 3;
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
-                fb[t & 1][kh] = *reinterpret_cast<const bf16x8*>(smem + bK[ks] + ((kh * 3 + kw) * 64 + j * 32) * 64);
+                fb[t & 1][kh] = *reinterpret_cast<const bf16x8*>(smem + bK[ks] + ((kh * 3 + kw) * BN + j * 32) * 64);
         };
         read_a(std::integral_constant<int, 0>());
         read_b(std::integral_constant<int, 0>());
         auto steps = [&](auto self, auto tc) {
             constexpr int t = decltype(tc)::value;
-            if constexpr (t < 12) {
-                constexpr int g = t / 2, j = t % 2;
-                if constexpr (t + 1 < 12) {
-                    if constexpr (j == 1) read_a(std::integral_constant<int, g + 1>());
+            if constexpr (t < 6 * NJ) {
+                constexpr int g = t / NJ, j = t % NJ;
+                if constexpr (t + 1 < 6 * NJ) {
+                    if constexpr (j == NJ - 1) read_a(std::integral_constant<int, g + 1>());
                     read_b(std::integral_constant<int, t + 1>());
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1606,11 +1612,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
 
     // epilogue (interior tiles only): pack pairs of rows, statistics, transpose through LDS, 16-byte stores
     const int odd = lane & 1;
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    float s1[NJ], s2[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) s1[j] = s2[j] = 0.f;
     if (!loader) {
         if constexpr (BIASACT) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const float bv = bias ? bias[n0 + j * 32 + l31] : 0.f;
                 const float sv = oscale ? oscale[n0 + j * 32 + l31] : 1.f;
 #pragma unroll
@@ -1625,7 +1633,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
 #pragma unroll
             for (int rp = 0; rp < 8; ++rp)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     const int r0 = 2 * rp;
                     const unsigned w2 = f2bf_pk(acc[i][j][r0], acc[i][j][r0 + 1]);
                     const float ra_ = __uint_as_float(w2 << 16), rb_ = __uint_as_float(w2 & 0xffff0000u);
@@ -1639,20 +1647,21 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
     __syncthreads();
     if (!loader) {
         constexpr int PPP = BN / 8;                   // 16-byte pieces per pixel
-        const int mt = threadIdx.x / PPP, q = threadIdx.x % PPP;        // 256 threads: tile column mt, piece q; one tile row per step
+        constexpr int PSTEP = 256 / PPP;              // pixels per step of the 256 storing threads (32: one tile row; 64: two)
+        const int mt = threadIdx.x / PPP, q = threadIdx.x % PPP;
         const unsigned char* lr = smem + mt * OROW + q * 16;
-        unsigned short* yp = y + (((size_t)b0 * H + ty0) * W + tx0 + mt) * N + n0 + q * 8;
-        const size_t ystep = (size_t)W * N;
+        unsigned short* yp = y + (((size_t)b0 * H + ty0 + (mt >> 5)) * W + tx0 + (mt & 31)) * N + n0 + q * 8;
+        const size_t ystep = (size_t)(PSTEP / 32) * W * N;
 #pragma unroll
-        for (int it = 0; it < 16; ++it)
-            *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * 32 * OROW);
+        for (int it = 0; it < 512 / PSTEP; ++it)
+            *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * PSTEP * OROW);
     }
     if (stats_partial) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);      // [4 waves][2][BN]
         if (!loader) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const float a = s1[j] + __shfl_xor(s1[j], 32, 64);
                 const float bq = s2[j] + __shfl_xor(s2[j], 32, 64);
                 if (khalf == 0) {
@@ -2437,13 +2446,15 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
         if (wsm == 5 || wsm == 1) {                  // k_conv3x3_fwd_dma128: one stage per block, two blocks per CU
             const char* dbe = getenv("PHX_DBG_ABLATE");   // dev: bit 1 no patch loads, 2 no slab loads, 4 no MFMAs
             const int dbg = dbe ? atoi(dbe) : 0;
-#define D128_LAUNCH(Av, Dv)                                                                                                     \
+#define D128_LAUNCH1(Av, Dv, BNv)                                                                                               \
     do {                                                                                                                        \
-        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_dma128<Av, Dv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        hipLaunchKernelGGL((k_conv3x3_fwd_dma128<Av, Dv>), dim3(ntl * (N / 64)), dim3(256), 75 * 1024 + 16, (hipStream_t)stream,      \
+        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_dma128<Av, Dv, BNv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((k_conv3x3_fwd_dma128<Av, Dv, BNv>), dim3(ntl * (N / BNv)), dim3(256), 75 * 1024 + 16, (hipStream_t)stream, \
                            (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, \
                            H, W, K, N, W / 32, H / 16, dephase, bws.oscale);                                                    \
     } while (0)
+#define D128_LAUNCH(Av, Dv)                                                                                                     \
+    do { if (N % 64 == 0) D128_LAUNCH1(Av, Dv, 64); else D128_LAUNCH1(Av, 0, 32); } while (0)
             const char* dpe = getenv("PHX_DEPHASE");
             const int dephase = dpe ? atoi(dpe) : 0;
             if (ba) D128_LAUNCH(true, 0);
@@ -2452,6 +2463,7 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
                 case 4: D128_LAUNCH(false, 4); break; case 5: D128_LAUNCH(false, 5); break; case 6: D128_LAUNCH(false, 6); break;
                 case 7: D128_LAUNCH(false, 7); break; default: D128_LAUNCH(false, 0);
             }
+#undef D128_LAUNCH1
 #undef D128_LAUNCH
             PHX_CHECK_LAUNCH();
             return PHX_OK;

@@ -265,7 +265,7 @@ def test_conv3x3_mfma_wave_specialised(L, case, monkeypatch):
 
 # 128-pixel wave tiles with shared patch rows: 4 MFMA waves + 2 DMA loader waves (k_conv3x3_fwd_ws128)
 @pytest.mark.parametrize("case", [(2, 16, 32, 32, 128), (1, 32, 64, 96, 64), (3, 16, 32, 32, 192), (1, 48, 32, 64, 256),
-                                  (1, 16, 64, 160, 128)])
+                                  (1, 16, 64, 160, 128), (2, 32, 32, 32, 32), (1, 16, 64, 192, 32), (2, 16, 32, 64, 96)])
 def test_conv3x3_mfma_wave_specialised_128(L, case, monkeypatch):
     monkeypatch.setenv("PHX_FWD_WS", "5")
     _mfma_case(L, case)

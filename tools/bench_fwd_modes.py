@@ -10,6 +10,8 @@ shapes = [(64, 128, 128, 128, 128), (64, 128, 128, 64, 128), (64, 128, 128, 128,
           (64, 64, 64, 64, 64), (64, 64, 64, 128, 192), (64, 64, 64, 192, 64), (64, 32, 32, 128, 128), (64, 32, 32, 192, 192),
           (64, 32, 32, 64, 64), (64, 32, 32, 256, 192)]
 modes = sys.argv[1:] or ["0", "2", "3"]
+if os.environ.get("BENCH_SHAPES") == "n32":
+    shapes = [(64, 128, 128, 32, 32), (64, 128, 128, 192, 32), (64, 128, 128, 64, 32), (64, 64, 64, 32, 32), (64, 128, 128, 32, 64)]
 if os.environ.get("BENCH_SHAPES") == "short":
     shapes = [(64, 128, 128, 128, 128), (64, 64, 64, 192, 192), (64, 128, 128, 32, 192), (64, 64, 64, 64, 64)]
 for (B, H, W, K, N) in shapes:
