@@ -200,6 +200,14 @@ int phx_norm_bwd_apply_fused(const void* dA, int da_dt, const void* x, int x_dt,
                              const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx,
                              int dx_dt, float* dgamma, float* dbeta, int NS, int P, int C, int G, int act, int nrep,
                              void* stream);
+/* the same with the gradient of the convolution bias that precedes the normalisation (group / instance norm layers keep their
+ * bias, tfwrapper/layers.py:126-132): dbias[c] += sum over (ns, p) of dx, in closed form from the per-channel sums of the
+ * backward reduction (sums2) and of the forward statistics pass (fwd_sums / fwd_pivot as given to phx_norm_apply_fused) --
+ * no pass over dx.  dbias == NULL: identical to phx_norm_bwd_apply_fused. */
+int phx_norm_bwd_apply_fused_bias(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
+                                  const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx,
+                                  int dx_dt, float* dgamma, float* dbeta, const float* fwd_sums, const float* fwd_pivot,
+                                  float* dbias, int NS, int P, int C, int G, int act, int nrep, void* stream);
 /* Small-map batch norm, training mode, bf16 NHWC (tfwrapper/normalisation.py:16-45 batch_norm -> tf.layers.
  * batch_normalization(training=True), fused with the activation of layers.py:134-135): the whole layer in ONE launch when
  * P = B*H*W <= 4096 and C % 16 == 0 (a block owns 16 channels of all pixels; two-pass variance; no atomics).

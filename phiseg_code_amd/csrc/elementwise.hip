@@ -589,7 +589,9 @@ __global__ void k_norm_bwd_apply_fused(const TD* __restrict__ dA, const TX* __re
                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                        const float* __restrict__ gamma, const float* __restrict__ sums2,
                                        TO* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int P,
-                                       int C, int G, int PL, int chunk, int act, int nrep) {
+                                       int C, int G, int PL, int chunk, int act, int nrep,
+                                       const float* __restrict__ fsums, const float* __restrict__ fpivot,
+                                       float* __restrict__ dbias) {
     const int CV = C / V, cg = C / G;
     const int ns = blockIdx.y;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
@@ -643,6 +645,13 @@ __global__ void k_norm_bwd_apply_fused(const TD* __restrict__ dA, const TX* __re
         if (publish) {
             atomicAdd(&dbeta[c], t0);
             atomicAdd(&dgamma[c], t1);
+            if (dbias) {
+                // gradient of the bias the producing convolution adds BEFORE the normalisation (group / instance norm keep it,
+                // layers.py:126-132): sum_p dx[ns, p, c] = a * sum g + P * b + c * sum x, in closed form from the per-channel
+                // sums of both passes -- no pass over dx.  (sum x - P * mean from the shifted forward sums: no cancellation.)
+                const float dsum = fsums[((size_t)ns * C + c) * 2] + (float)P * ((fpivot ? fpivot[(size_t)ns * C + c] : 0.f) - mu);
+                atomicAdd(&dbias[c], fmaf(ca[j], t0, fmaf(cc[j], dsum, -(float)P * rs * S0 * inv_m)));
+            }
         }
     }
     const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
@@ -1166,14 +1175,23 @@ int phx_norm_bwd_apply_fused(const void* dA, int da_dt, const void* x, int x_dt,
                              const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx,
                              int dx_dt, float* dgamma, float* dbeta, int NS, int P, int C, int G, int act, int nrep,
                              void* stream) {
+    return phx_norm_bwd_apply_fused_bias(dA, da_dt, x, x_dt, scale, shift, mean, rstd, gamma, sums2, dx, dx_dt, dgamma, dbeta,
+                                         nullptr, nullptr, nullptr, NS, P, C, G, act, nrep, stream);
+}
+
+int phx_norm_bwd_apply_fused_bias(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
+                                  const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx,
+                                  int dx_dt, float* dgamma, float* dbeta, const float* fwd_sums, const float* fwd_pivot,
+                                  float* dbias, int NS, int P, int C, int G, int act, int nrep, void* stream) {
     PHX_REQUIRE(da_dt == dx_dt, PHX_E_INVAL, "norm_bwd_apply_fused: dA and dx dtypes must match");
+    PHX_REQUIRE(dbias == nullptr || fwd_sums != nullptr, PHX_E_INVAL, "norm_bwd_apply_fused_bias: dbias needs the forward sums");
     PHX_REQUIRE(nrep >= 1, PHX_E_INVAL, "norm_bwd_apply_fused: nrep >= 1");
     PHX_DT_SWITCH(da_dt, TD, PHX_DT_SWITCH(x_dt, TX, PHX_VEC_SWITCH(C, V, {
         int PL, threads, chunk, nchunks;
         PHX_REQUIRE(stream_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_bwd_apply_fused: C too large");
         hipLaunchKernelGGL((k_norm_bwd_apply_fused<TD, TX, TD, V>), dim3(nchunks, NS), dim3(threads),
                            (size_t)2 * C * sizeof(float), (hipStream_t)stream, (const TD*)dA, (const TX*)x, scale, shift, mean, rstd, gamma, sums2,
-                           (TD*)dx, dgamma, dbeta, P, C, G, PL, chunk, act, nrep);
+                           (TD*)dx, dgamma, dbeta, P, C, G, PL, chunk, act, nrep, fwd_sums, fwd_pivot, dbias);
     })));
     PHX_CHECK_LAUNCH();
     return PHX_OK;

@@ -30,6 +30,7 @@ _ESIZE = {F32: 4, BF16: 2, U8: 1}
 _LIK_SIDE = os.environ.get("PHX_LIK_SIDE", "1") == "1"        # two lanes: the likelihood's per-level chains share the prior's lane
 _WGRAD_DEFER_BLOCKS = int(os.environ.get("PHX_WGRAD_DEFER_BLOCKS", "96"))  # pixel-tile split target of a deferred layer (0: as when it runs alone; measured 48..128)
 _NREP = int(os.environ.get("PHX_NREP", "8"))
+_BIAS_GRAD_FUSED = os.environ.get("PHX_BIAS_GRAD_FUSED", "1") == "1"   # group / instance norm: conv-bias gradient in closed form (A/B hook)
 _NREP_MINP = int(os.environ.get("PHX_NREP_MINP", "4096"))
 _WGRAD_DEFER_SMALL = os.environ.get("PHX_WGRAD_DEFER_SMALL", "1") == "1"   # small-map filter-gradient launches deferred too
 _WGRAD_MULTI = os.environ.get("PHX_WGRAD_MULTI", "1") == "1"   # one reduction launch for all layers' partial filter gradients
@@ -823,6 +824,8 @@ class Plan:
                        (1.0 - tfnorm.BN_DECAY) if upd else 0.0, NS, P, cout, Gn, act, S,
                        tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
         st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn)
+        if norm != "batch":
+            st.update(fsums=sums, fpivot=pivot)          # forward per-channel sums: the bias gradient is closed-form from them
         self.saved[op] = st
 
     def _fw_avgpool(self, op, bw):
@@ -1069,6 +1072,7 @@ class Plan:
         B, H, Wd = x.shape[0], x.shape[1], x.shape[2]
         act = rt.ACT_CODES[a["act"]]
         S, Lb = self.stream, self.L
+        db_done = False
         if sv["norm"] is not None:
             if "y" not in sv or "mean" not in sv or (sv["norm"] == "batch" and not self.training):
                 raise NotImplementedError("backward through inference-mode batch norm is not on the hot path")
@@ -1096,9 +1100,17 @@ class Plan:
                     self._emit(Lb.norm_bwd_reduce, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
                                sv["mean"].ptr, sv["rstd"].ptr, sums2.ptr, NS, P, cout, Gn, act, nrep, S,
                                tag="bytes_norm_bwd_reduce", flops=float(dA.nbytes + y.nbytes))
-                self._emit(Lb.norm_bwd_apply_fused, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
+                # group / instance norm keep the convolution bias: its gradient (the per-channel sum of dY) comes out of this
+                # launch in closed form instead of a pass over dY (phx_norm_bwd_apply_fused_bias)
+                fs = sv.get("fsums") if (b is not None and _BIAS_GRAD_FUSED) else None
+                if fs is not None:
+                    db_done = True
+                self._emit(Lb.norm_bwd_apply_fused_bias, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
                            sv["mean"].ptr, sv["rstd"].ptr, self.store.ptr(nv["gamma"]), sums2.ptr, dY.ptr, dY.dt,
-                           self.store.grad_ptr(nv["gamma"]), self.store.grad_ptr(nv["beta"]), NS, P, cout, Gn, act, nrep, S,
+                           self.store.grad_ptr(nv["gamma"]), self.store.grad_ptr(nv["beta"]),
+                           fs.ptr if fs is not None else None,
+                           sv["fpivot"].ptr if (fs is not None and sv.get("fpivot") is not None) else None,
+                           self.store.grad_ptr(b) if fs is not None else None, NS, P, cout, Gn, act, nrep, S,
                            tag="bytes_norm_bwd_apply", flops=float(dA.nbytes + y.nbytes + dY.nbytes))
         elif act != rt.ACT_ID:
             dY = self._alloc(out.shape, dA.dt)
@@ -1106,7 +1118,7 @@ class Plan:
         else:
             dY = dA
         dw = self.store.grad_ptr(W)
-        db = self.store.grad_ptr(b) if b is not None else None
+        db = self.store.grad_ptr(b) if (b is not None and not db_done) else None
         if sv.get("transposed") is not None:
             kh, kw, sh, sw = sv["transposed"]
             geo = (B, H, Wd, cin, cout, kh, kw, sh, sw)

@@ -459,6 +459,24 @@ def test_norm_fwd_bwd(L, case):
     close(host(dx2), xr.grad.numpy(), 5e-5 if dt == F32 else 8e-3, kind + " fused dx")
     close(host(dgamma2), gr.grad.numpy(), 5e-5 if dt == F32 else 2e-3, kind + " fused dgamma")
     close(host(dbeta2), br.grad.numpy(), 5e-5 if dt == F32 else 2e-3, kind + " fused dbeta")
+    # ... and with the gradient of a convolution bias in front of the normalisation (group / instance norm layers): the
+    # per-channel sum of dx in closed form from the sums of both passes (phx_norm_bwd_apply_fused_bias), with and without pivot
+    ref_db = xr.grad.numpy().sum(axis=(0, 1, 2))
+    for pv in (pivot, None):
+        fs = sums
+        if pv is None:                                   # unshifted forward sums {sum x, sum x^2}
+            fs = torch.zeros(NS, C, 2, dtype=torch.float32).cuda()
+            L.norm_stats(xd.data_ptr(), dt, fs.data_ptr(), None, NS, P, C, S())
+        dx3 = torch.empty(B, H, W, C, dtype=tdt(dt)).cuda()
+        dg3, dbe3, dbias = (torch.zeros(C, dtype=torch.float32).cuda() for _ in range(3))
+        L.norm_bwd_apply_fused_bias(dAd.data_ptr(), dt, xd.data_ptr(), dt, scale2.data_ptr(), shift2.data_ptr(), mean2.data_ptr(),
+                                    rstd2.data_ptr(), gd.data_ptr(), sums2r.data_ptr(), dx3.data_ptr(), dt, dg3.data_ptr(),
+                                    dbe3.data_ptr(), fs.data_ptr(), pv.data_ptr() if pv is not None else None, dbias.data_ptr(),
+                                    NS, P, C, GG, 1, nrep, S())
+        assert torch.equal(dx3, dx2)
+        scale_db = max(1.0, float(np.abs(xr.grad.numpy()).sum(axis=(0, 1, 2)).max()))
+        err = float(np.abs(host(dbias) - ref_db).max()) / scale_db
+        assert err < (2e-5 if dt == F32 else 2e-3), (kind, "bias gradient", err)
 
 
 @pytest.mark.parametrize("case", [(64, 2, 2, 192, 1), (64, 4, 4, 192, 1), (37, 3, 3, 48, 1), (64, 8, 8, 192, 1), (50, 8, 8, 16, 0),
