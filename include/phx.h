@@ -226,6 +226,23 @@ int phx_bn_small_fwd_splitk(const float* ws, int nz, void* x_out, const float* g
 int phx_bn_small_bwd(const void* dA, const void* x, const float* scale, const float* shift, const float* mean,
                      const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, int P, int C, int act,
                      void* stream);
+/* Group / instance norm (tfwrapper/normalisation.py:3-36), bf16 NHWC, the whole layer in ONE launch when a sample has
+ * P = H*W <= 256 pixels (maps up to 16 x 16) and the statistic is per channel (G == C: instance norm) or per 16-channel
+ * group (G * 16 == C: group_norm2D's default groups for C >= 32): a wave owns (sample, 16-channel slice) pairs, keeps the
+ * slice in registers, two-pass variance, wave shuffles only; no atomics in the forward pass, one add per channel and block in
+ * the backward pass.
+ *   fwd: ws == NULL: x is the input.  ws != NULL: the convolution ran split-K (phx_conv3x3_mfma_bf16_ws with y == NULL): the
+ *        nz fp32 slices ws[z][NS*P][C] are summed, `bias` (the convolution bias, may be NULL) added, the bf16 result written
+ *        to x and normalised.  mean / rstd: [NS][G]; scale / shift: [NS][C].
+ *   bwd: dx, dgamma += , dbeta += , and (dbias != NULL) the gradient of the convolution bias in front of the layer,
+ *        dbias[c] += sum over samples and pixels of dx -- closed form, no extra pass. */
+int phx_norm_small_supported(int NS, int P, int C, int G, int dt);
+int phx_norm_small_fwd(void* x, const float* ws, int nz, const float* bias, const float* gamma, const float* beta, float eps,
+                       void* y, float* mean, float* rstd, float* scale, float* shift, int NS, int P, int C, int G, int act,
+                       void* stream);
+int phx_norm_small_bwd(const void* dA, const void* x, const float* scale, const float* shift, const float* mean,
+                       const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, float* dbias, int NS, int P,
+                       int C, int G, int act, void* stream);
 /* backward of y = act(norm(x)):  g = dA * act'(.);  sums2[nrep][NS][C][2] += {sum g, sum g*xhat}: block b adds into
  * replica b % nrep (same-address atomics serialise at ~45 ns each); phx_norm_bwd_apply_fused sums the replicas, the other
  * consumers take nrep = 1 */

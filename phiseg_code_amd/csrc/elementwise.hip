@@ -317,6 +317,263 @@ __global__ __launch_bounds__(1024) void k_bn_small_bwd(const bf16_t* __restrict_
     }
 }
 
+// =================================================================================================
+// Group / instance norm on small maps (a sample has P = H*W <= 256 pixels: the H <= 16 levels), bf16 NHWC: the whole layer
+// in one launch, like k_bn_small_* -- but the statistics are per SAMPLE, so nothing is reduced across waves: a wave owns
+// (sample, 16-channel slice) pairs, lane = (sample slot, pixel lane, channel vector); LPS pixel lanes per sample (4, 16 or
+// 32 -> 8, 2 or 1 samples per wave pass), NIT pixels per lane, reductions by wave shuffles only, no barrier in the forward
+// pass.  MODE 0: one statistic per channel (instance norm); MODE 1: one per 16-channel group = the whole slice (group_norm2D's
+// default groups for C >= 32).  A block (4 waves) walks a run of samples; the backward pass keeps dgamma / dbeta / dbias of
+// its run in registers and adds them once per block.
+template <int LPS> struct NormWaveMap {
+    static constexpr int SPW = 32 / LPS;               // samples per wave pass
+    int v, q, ss;
+    __device__ __forceinline__ NormWaveMap() {
+        const int l = threadIdx.x & 63;
+        v = l & 1;
+        q = (l >> 1) & (LPS - 1);
+        ss = l / (2 * LPS);
+    }
+};
+template <int LPS, int NV>
+__device__ __forceinline__ void wave_pixel_sum(float s[NV]) {     // over the LPS pixel lanes of a sample slot (lane bits 1..)
+#pragma unroll
+    for (int m = 2; m <= LPS; m <<= 1)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) s[j] += __shfl_xor(s[j], m);
+}
+__device__ __forceinline__ float slice16_total(const float t[8]) {   // sum over the 16 channels of the slice (both channel vectors)
+    float g = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    return g + __shfl_xor(g, 1);
+}
+
+template <int LPS, int NIT, int MODE, bool SLICES>
+__global__ __launch_bounds__(256) void k_norm_wave_fwd(bf16_t* __restrict__ x, const float* __restrict__ ws, int nz,
+                                                      const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps, bf16_t* __restrict__ y,
+                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                      float* __restrict__ scale_out, float* __restrict__ shift_out, int NS,
+                                                      int P, int C, int passes, int act) {
+    const NormWaveMap<LPS> m;
+    constexpr int SPW = NormWaveMap<LPS>::SPW;
+    const int wave = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 16 + m.v * 8;
+    const int G = gridDim.x;
+    float gm[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gm[j] = gamma[c0 + j]; be[j] = beta[c0 + j]; }
+    const float inv_m = 1.f / ((float)P * (MODE == 1 ? 16.f : 1.f));
+    for (int i = 0; i < passes; ++i) {
+        const int ns = ((blockIdx.y * passes + i) * 4 + wave) * SPW + m.ss;
+        const bool live = ns < NS;
+        const size_t base = (size_t)ns * P * C + c0;
+        uint4 r[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int p = m.q + it * LPS;
+            r[it] = make_uint4(0, 0, 0, 0);
+            if (live && p < P) {
+                if constexpr (SLICES) {
+                    typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+                    const size_t zs = (size_t)NS * P * C;
+                    const float* qp = ws + base + (size_t)p * C;
+                    f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(qp), a1 = *reinterpret_cast<const f32x4_t*>(qp + 4);
+                    for (int z = 1; z < nz; ++z) {
+                        a0 += *reinterpret_cast<const f32x4_t*>(qp + (size_t)z * zs);
+                        a1 += *reinterpret_cast<const f32x4_t*>(qp + (size_t)z * zs + 4);
+                    }
+                    if (bias) {
+                        a0 += *reinterpret_cast<const f32x4_t*>(bias + c0);
+                        a1 += *reinterpret_cast<const f32x4_t*>(bias + c0 + 4);
+                    }
+                    r[it] = make_uint4(f2bf_pk(a0[0], a0[1]), f2bf_pk(a0[2], a0[3]), f2bf_pk(a1[0], a1[1]), f2bf_pk(a1[2], a1[3]));
+                    *reinterpret_cast<uint4*>(x + base + (size_t)p * C) = r[it];
+                } else {
+                    r[it] = *reinterpret_cast<const uint4*>(x + base + (size_t)p * C);
+                }
+            }
+        }
+        float s[8], mu[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {                  // (pixels past P hold zeros)
+            float f[8];
+            bf16x8_unpack(r[it], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += f[j];
+        }
+        wave_pixel_sum<LPS, 8>(s);
+        if constexpr (MODE == 1) {
+            const float g = slice16_total(s);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] = g;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { mu[j] = s[j] * inv_m; s[j] = 0.f; }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (m.q + it * LPS < P) {
+                float f[8];
+                bf16x8_unpack(r[it], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = f[j] - mu[j]; s[j] = fmaf(d, d, s[j]); }
+            }
+        }
+        wave_pixel_sum<LPS, 8>(s);
+        if constexpr (MODE == 1) {
+            const float g = slice16_total(s);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] = g;
+        }
+        float sc[8], sh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j;
+            const float rs = rsqrtf(s[j] * inv_m + eps);
+            sc[j] = gm[j] * rs;
+            sh[j] = be[j] - mu[j] * sc[j];
+            if (live && m.q == 0) {
+                if constexpr (MODE == 1) {
+                    if (m.v == 0 && j == 0) {
+                        mean_out[(size_t)ns * G + blockIdx.x] = mu[j];
+                        rstd_out[(size_t)ns * G + blockIdx.x] = rs;
+                    }
+                } else {
+                    mean_out[(size_t)ns * C + c] = mu[j];
+                    rstd_out[(size_t)ns * C + c] = rs;
+                }
+                scale_out[(size_t)ns * C + c] = sc[j];
+                shift_out[(size_t)ns * C + c] = sh[j];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int p = m.q + it * LPS;
+            if (live && p < P) {
+                float f[8];
+                bf16x8_unpack(r[it], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = act_fwd(fmaf(f[j], sc[j], sh[j]), act);
+                VecIO<bf16_t, 8>::store(y, base + (size_t)p * C, f);
+            }
+        }
+    }
+}
+
+// dbias: the gradient of a convolution bias in front of the normalisation, sum over samples and pixels of dx, in closed form
+// per sample (a * sum g + c * sum (x - mean) - P * rstd * S0 / m; identically zero in MODE 0, not computed there)
+template <int LPS, int NIT, int MODE>
+__global__ __launch_bounds__(256) void k_norm_wave_bwd(const bf16_t* __restrict__ dA, const bf16_t* __restrict__ x,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ gamma, bf16_t* __restrict__ dx,
+                                                      float* dgamma, float* dbeta, float* dbias, int NS, int P, int C,
+                                                      int passes, int act) {
+    constexpr int NA = MODE == 1 ? 24 : 16;
+    const NormWaveMap<LPS> m;
+    constexpr int SPW = NormWaveMap<LPS>::SPW;
+    __shared__ float red[4 * SPW * 2 * NA];
+    const int wave = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 16 + m.v * 8;
+    const int G = gridDim.x;
+    float gmv[8], acc[NA];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gmv[j] = gamma[c0 + j];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) acc[j] = 0.f;
+    const float inv_m = 1.f / ((float)P * (MODE == 1 ? 16.f : 1.f));
+    for (int i = 0; i < passes; ++i) {
+        const int ns = ((blockIdx.y * passes + i) * 4 + wave) * SPW + m.ss;
+        const bool live = ns < NS;
+        const size_t base = (size_t)ns * P * C + c0;
+        uint4 rx[NIT], rd[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int p = m.q + it * LPS;
+            rx[it] = rd[it] = make_uint4(0, 0, 0, 0);
+            if (live && p < P) {
+                rx[it] = *reinterpret_cast<const uint4*>(x + base + (size_t)p * C);
+                rd[it] = *reinterpret_cast<const uint4*>(dA + base + (size_t)p * C);
+            }
+        }
+        float sc[8], sh[8], mu[8], rs[8], s[NA];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j;
+            const size_t si = MODE == 1 ? (size_t)ns * G + blockIdx.x : (size_t)ns * C + c;
+            sc[j] = live ? scale[(size_t)ns * C + c] : 0.f;
+            sh[j] = live ? shift[(size_t)ns * C + c] : 0.f;
+            mu[j] = live ? mean[si] : 0.f;
+            rs[j] = live ? rstd[si] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) s[j] = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {              // (pixels past P: dA = 0 -> g = 0)
+            float xf[8], df[8];
+            bf16x8_unpack(rx[it], xf);
+            bf16x8_unpack(rd[it], df);
+            const bool in = live && m.q + it * LPS < P;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float g = df[j] * act_grad_pre(fmaf(xf[j], sc[j], sh[j]), act);
+                s[j] += g;
+                s[8 + j] = fmaf(g * (xf[j] - mu[j]), rs[j], s[8 + j]);
+                if constexpr (MODE == 1) s[16 + j] += in ? xf[j] - mu[j] : 0.f;
+            }
+        }
+        wave_pixel_sum<LPS, NA>(s);
+        float S0[8], S1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { S0[j] = gmv[j] * s[j]; S1[j] = gmv[j] * s[8 + j]; }
+        if constexpr (MODE == 1) {                      // S = sum over the group's 16 channels of gamma_c * {sum g, sum g xhat}
+            const float a = slice16_total(S0), bq = slice16_total(S1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { S0[j] = a; S1[j] = bq; }
+        }
+        float ca[8], cb[8], cc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ca[j] = rs[j] * gmv[j];
+            cc[j] = -rs[j] * rs[j] * S1[j] * inv_m;
+            cb[j] = -rs[j] * S0[j] * inv_m - cc[j] * mu[j];
+            acc[j] += s[j];
+            acc[8 + j] += s[8 + j];
+            if constexpr (MODE == 1) acc[16 + j] += fmaf(ca[j], s[j], fmaf(cc[j], s[16 + j], -(float)P * rs[j] * S0[j] * inv_m));
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int p = m.q + it * LPS;
+            if (live && p < P) {
+                float xf[8], df[8], o[8];
+                bf16x8_unpack(rx[it], xf);
+                bf16x8_unpack(rd[it], df);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float gq = df[j] * act_grad_pre(fmaf(xf[j], sc[j], sh[j]), act);
+                    o[j] = fmaf(ca[j], gq, fmaf(cc[j], xf[j], cb[j]));
+                }
+                VecIO<bf16_t, 8>::store(dx, base + (size_t)p * C, o);
+            }
+        }
+    }
+    // the block's run of samples: one add per channel (every pixel lane of a slot holds the slot's totals; lane q == 0 speaks)
+    if (m.q == 0)
+#pragma unroll
+        for (int j = 0; j < NA; ++j) red[((wave * SPW + m.ss) * 2 + m.v) * NA + j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < 2 * NA) {
+        const int vv = threadIdx.x / NA, j = threadIdx.x % NA;
+        float a = 0.f;
+        for (int w = 0; w < 4 * SPW; ++w) a += red[(w * 2 + vv) * NA + j];
+        const int c = blockIdx.x * 16 + vv * 8 + (j & 7);
+        if (j < 8) atomicAdd(&dbeta[c], a);
+        else if (j < 16) atomicAdd(&dgamma[c], a);
+        else if (dbias) atomicAdd(&dbias[c], a);
+    }
+}
+
 static int norm_geometry(int P, int C, int V, int* PL, int* threads, int* chunk, int* nchunks, int NS, int nrep = 1) {
     int CV = C / V;
     if (CV > 256) return -1;
@@ -1255,6 +1512,71 @@ int phx_bn_small_bwd(const void* dA, const void* x, const float* scale, const fl
                        (const bf16_t*)x, scale, shift, mean, rstd, gamma, (bf16_t*)dx, dgamma, dbeta, P, C, act)
     if (P <= 512) BNS_B(1); else if (P <= 1024) BNS_B(2); else if (P <= 2048) BNS_B(4); else BNS_B(8);
 #undef BNS_B
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+// ---- group / instance norm, one launch per layer on maps of up to 256 pixels (k_norm_wave_*) ----
+int phx_norm_small_supported(int NS, int P, int C, int G, int dt) {
+    return dt == PHX_BF16 && NS >= 1 && P >= 1 && P <= 256 && C % 16 == 0 && (G == C || G * 16 == C);
+}
+// pixel lanes per sample (4, 16, 32), samples per block pass, block passes and sample blocks for the (C / 16, nsb) grid
+static void norm_wave_plan(int NS, int P, int C, int* lps, int* passes, int* nsb) {
+    *lps = P <= 4 ? 4 : P <= 16 ? 16 : 32;
+    const int spb = 4 * (32 / *lps);                           // samples per block pass (4 waves)
+    const int need = (NS + spb - 1) / spb;                     // block passes in all
+    int want = 512 / (C / 16);                                 // sample blocks for ~512 blocks
+    if (want < 1) want = 1;
+    if (phx_deterministic()) want = 1;                         // one block per slice: a fixed order for dgamma / dbeta / dbias
+    *nsb = need < want ? need : want;
+    *passes = (need + *nsb - 1) / *nsb;
+    *nsb = (need + *passes - 1) / *passes;
+}
+#define PHX_NW_SWITCH(P, ...)                                                                                        \
+    do {                                                                                                             \
+        if ((P) <= 4) { constexpr int LPSv = 4, NITv = 1; __VA_ARGS__; }                                             \
+        else if ((P) <= 16) { constexpr int LPSv = 16, NITv = 1; __VA_ARGS__; }                                      \
+        else if ((P) <= 32) { constexpr int LPSv = 32, NITv = 1; __VA_ARGS__; }                                      \
+        else if ((P) <= 64) { constexpr int LPSv = 32, NITv = 2; __VA_ARGS__; }                                      \
+        else if ((P) <= 128) { constexpr int LPSv = 32, NITv = 4; __VA_ARGS__; }                                     \
+        else { constexpr int LPSv = 32, NITv = 8; __VA_ARGS__; }                                                     \
+    } while (0)
+
+int phx_norm_small_fwd(void* x, const float* ws, int nz, const float* bias, const float* gamma, const float* beta, float eps,
+                       void* y, float* mean, float* rstd, float* scale, float* shift, int NS, int P, int C, int G, int act,
+                       void* stream) {
+    PHX_REQUIRE(phx_norm_small_supported(NS, P, C, G, PHX_BF16), PHX_E_SHAPE,
+                "norm_small_fwd: needs bf16, P <= 256, C % 16 == 0, per-channel statistics or 16-channel groups");
+    PHX_REQUIRE(x != nullptr && (ws == nullptr || nz >= 1), PHX_E_INVAL, "norm_small_fwd: x (and nz >= 1 with ws)");
+    PHX_REQUIRE(ws != nullptr || bias == nullptr, PHX_E_INVAL, "norm_small_fwd: bias only with split-K slices");
+    int lps, passes, nsb;
+    norm_wave_plan(NS, P, C, &lps, &passes, &nsb);
+    PHX_REQUIRE(passes < 65536 && nsb < 65536, PHX_E_SHAPE, "norm_small_fwd: too many samples");
+    const dim3 grid(C / 16, nsb);
+#define NW_F(SLv, Mv)                                                                                                           \
+    PHX_NW_SWITCH(P, hipLaunchKernelGGL((k_norm_wave_fwd<LPSv, NITv, Mv, SLv>), grid, dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ws, \
+                                        nz, bias, gamma, beta, eps, (bf16_t*)y, mean, rstd, scale, shift, NS, P, C, passes, act))
+    if (ws) { if (G == C) NW_F(true, 0); else NW_F(true, 1); }
+    else { if (G == C) NW_F(false, 0); else NW_F(false, 1); }
+#undef NW_F
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_norm_small_bwd(const void* dA, const void* x, const float* scale, const float* shift, const float* mean,
+                       const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, float* dbias, int NS, int P,
+                       int C, int G, int act, void* stream) {
+    PHX_REQUIRE(phx_norm_small_supported(NS, P, C, G, PHX_BF16), PHX_E_SHAPE,
+                "norm_small_bwd: needs bf16, P <= 256, C % 16 == 0, per-channel statistics or 16-channel groups");
+    int lps, passes, nsb;
+    norm_wave_plan(NS, P, C, &lps, &passes, &nsb);
+    PHX_REQUIRE(passes < 65536 && nsb < 65536, PHX_E_SHAPE, "norm_small_bwd: too many samples");
+    const dim3 grid(C / 16, nsb);
+#define NW_B(Mv)                                                                                                                \
+    PHX_NW_SWITCH(P, hipLaunchKernelGGL((k_norm_wave_bwd<LPSv, NITv, Mv>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dA,   \
+                                        (const bf16_t*)x, scale, shift, mean, rstd, gamma, (bf16_t*)dx, dgamma, dbeta, dbias, NS, P, C, passes, act))
+    if (G == C) NW_B(0); else NW_B(1);                  // (per-channel statistics: the bias gradient is identically zero)
+#undef NW_B
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }

@@ -30,6 +30,7 @@ _ESIZE = {F32: 4, BF16: 2, U8: 1}
 _LIK_SIDE = os.environ.get("PHX_LIK_SIDE", "1") == "1"        # two lanes: the likelihood's per-level chains share the prior's lane
 _WGRAD_DEFER_BLOCKS = int(os.environ.get("PHX_WGRAD_DEFER_BLOCKS", "96"))  # pixel-tile split target of a deferred layer (0: as when it runs alone; measured 48..128)
 _NREP = int(os.environ.get("PHX_NREP", "8"))
+_NORM_SMALL = os.environ.get("PHX_NORM_SMALL", "1") == "1"             # one-launch group / instance norm layers on maps <= 16 x 16 (A/B hook)
 _BIAS_GRAD_FUSED = os.environ.get("PHX_BIAS_GRAD_FUSED", "1") == "1"   # group / instance norm: conv-bias gradient in closed form (A/B hook)
 _NREP_MINP = int(os.environ.get("PHX_NREP_MINP", "4096"))
 _WGRAD_DEFER_SMALL = os.environ.get("PHX_WGRAD_DEFER_SMALL", "1") == "1"   # small-map filter-gradient launches deferred too
@@ -800,6 +801,27 @@ class Plan:
                 st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn, bn_small=True)
                 self.saved[op] = st
                 return
+            # group / instance norm on maps of up to 256 pixels: the whole layer in one launch as well (phx_norm_small_fwd / _bwd: a
+            # wave per (sample, 16-channel slice)); a split-K convolution hands over its slices and its bias
+            if (norm != "batch" and _NORM_SMALL and y.dt == BF16 and out.dt == BF16
+                    and Lb.norm_small_supported(NS, P, cout, Gn, BF16)):
+                ks = int(Lb.conv3x3_mfma_ksplit(B, H, Wd, cin_eff, cout)) if (mfma and not head1x1 and _BN_SPLITK) else 1
+                if ks > 1:
+                    wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cin_eff, cout))
+                    ws = self._alloc((wsb // 4,), F32)
+                    self._emit(Lb.conv3x3_mfma_bf16_ws, x.ptr, wf.ptr, None, None, 0, None, ws.ptr, wsb, B, H, Wd, cin_eff,
+                               cout, S, tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
+                    self._emit(Lb.norm_small_fwd, y.ptr, ws.ptr, ks, bptr, gptr, beptr, eps, out.ptr, mean.ptr, rstd.ptr,
+                               scale.ptr, shift.ptr, NS, P, cout, Gn, act, S,
+                               tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
+                else:
+                    conv_into(y, 0)
+                    self._emit(Lb.norm_small_fwd, y.ptr, None, 0, None, gptr, beptr, eps, out.ptr, mean.ptr, rstd.ptr,
+                               scale.ptr, shift.ptr, NS, P, cout, Gn, act, S,
+                               tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
+                st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn, norm_small=True)
+                self.saved[op] = st
+                return
             sums = self._alloc_zeroed(NS * cout * 2)
             pivot = None
             # shifted (pivot) sums in a stand-alone pass: always on the fp32 parity path, and on the bf16 path when
@@ -1084,6 +1106,14 @@ class Plan:
                            self.store.ptr(nv["gamma"]), dY.ptr, self.store.grad_ptr(nv["gamma"]),
                            self.store.grad_ptr(nv["beta"]), P, cout, act, S,
                            tag="bytes_norm_bwd_apply", flops=float(dA.nbytes + y.nbytes + dY.nbytes))
+            elif sv.get("norm_small") and dA.dt == BF16:
+                dY = self._alloc(y.shape, y.dt)
+                self._emit(Lb.norm_small_bwd, dA.ptr, y.ptr, sv["scale"].ptr, sv["shift"].ptr, sv["mean"].ptr, sv["rstd"].ptr,
+                           self.store.ptr(nv["gamma"]), dY.ptr, self.store.grad_ptr(nv["gamma"]),
+                           self.store.grad_ptr(nv["beta"]), self.store.grad_ptr(b) if b is not None else None,
+                           NS, P, cout, Gn, act, S,
+                           tag="bytes_norm_bwd_apply", flops=float(dA.nbytes + y.nbytes + dY.nbytes))
+                db_done = True
             else:
                 nrep = _NREP if P >= _NREP_MINP else 1   # replicated accumulators: see k_norm_bwd_reduce
                 if _DETERMINISTIC and P >= _NREP_MINP:

@@ -549,6 +549,92 @@ def test_bn_small_one_launch_layer(L, case):
     close(host(dbeta) + 0.25, br.grad.numpy(), 2e-3, "bn_small dbeta")
 
 
+@pytest.mark.parametrize("case", [("group", 3, 8, 8, 32, 2, 1), ("group", 2, 4, 4, 192, 12, 1), ("group", 64, 2, 2, 192, 12, 1),
+                                  ("group", 5, 16, 16, 64, 4, 1), ("group", 70, 4, 4, 32, 2, 0), ("group", 3, 12, 12, 48, 3, 1),
+                                  ("group", 131, 2, 2, 32, 2, 1), ("group", 9, 5, 6, 32, 2, 1), ("group", 2, 11, 13, 32, 2, 1),
+                                  ("instance", 3, 8, 8, 48, 48, 1), ("instance", 37, 3, 3, 16, 16, 1), ("instance", 2, 16, 16, 16, 16, 1)])
+def test_norm_small_one_launch_layer(L, case):
+    """phx_norm_small_fwd / _bwd (group norm with 16-channel groups / instance norm, maps of up to 256 pixels: the whole layer in one
+    launch, a wave per (sample, 16-channel slice)) against the oracle's group_norm / instance_norm + ReLU and its autograd; also fed by split-K
+    slices plus the convolution bias, and the closed-form bias gradient against the per-channel sum of the oracle's dx."""
+    kind, B, H, W, C, G, act = case
+    P = H * W
+    assert L.norm_small_supported(B, P, C, G, BF16) == 1
+    assert L.norm_small_supported(B, 257, C, G, BF16) == 0 and L.norm_small_supported(B, P, 64, 8, BF16) == 0
+    x = RNG.standard_normal((B, H, W, C)) * 1.5 + 0.3
+    gamma = 1.0 + 0.2 * RNG.standard_normal(C)
+    beta = 0.1 * RNG.standard_normal(C)
+    xr = rounded(x, BF16).requires_grad_(True)
+    gr = torch.as_tensor(gamma, dtype=torch.float32).double().requires_grad_(True)
+    br = torch.as_tensor(beta, dtype=torch.float32).double().requires_grad_(True)
+    fn = (lambda t: T.group_norm(t, gr, br, G)) if kind == "group" else (lambda t: T.instance_norm(t, gr, br))
+    yr = fn(xr)
+    ar = T.relu(yr) if act else yr
+    xd, gd, bd = dev(x, BF16), dev(gamma), dev(beta)
+    mean = torch.empty(B * G, dtype=torch.float32).cuda()
+    rstd = torch.empty_like(mean)
+    scale = torch.empty(B * C, dtype=torch.float32).cuda()
+    shift = torch.empty_like(scale)
+    a = torch.empty(B, H, W, C, dtype=torch.bfloat16).cuda()
+    L.norm_small_fwd(xd.data_ptr(), None, 0, None, gd.data_ptr(), bd.data_ptr(), 1e-5, a.data_ptr(), mean.data_ptr(),
+                     rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), B, P, C, G, act, S())
+    close(host(a), ar.detach().numpy(), 6e-3, "norm_small fwd")
+    xg = xr.detach().reshape(B, P, G, C // G).permute(0, 2, 1, 3).reshape(B, G, -1)
+    close(host(mean).reshape(B, G), xg.mean(-1).numpy(), 1e-5, "norm_small mean")
+    close(host(rstd).reshape(B, G), 1.0 / np.sqrt(xg.var(-1, unbiased=False).numpy() + 1e-5), 2e-5, "norm_small rstd")
+    # the three-launch path used on larger maps publishes the same statistics
+    sums = torch.zeros(B, C, 2, dtype=torch.float32).cuda()
+    pivot = torch.zeros(B, C, dtype=torch.float32).cuda()
+    L.norm_stats(xd.data_ptr(), BF16, sums.data_ptr(), pivot.data_ptr(), B, P, C, S())
+    a3 = torch.empty_like(a)
+    mean3, rstd3, scale3, shift3 = (torch.empty_like(t) for t in (mean, rstd, scale, shift))
+    L.norm_apply_fused(xd.data_ptr(), BF16, sums.data_ptr(), pivot.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-5, a3.data_ptr(),
+                       BF16, mean3.data_ptr(), rstd3.data_ptr(), scale3.data_ptr(), shift3.data_ptr(), None, None, 0.0, B, P, C, G,
+                       act, S())
+    close(host(scale), host(scale3), 5e-5, "norm_small vs three-launch scale")
+    close(host(shift), host(shift3), 5e-5, "norm_small vs three-launch shift")
+    # fed by split-K slices + the convolution bias
+    nz = 3
+    cb = RNG.standard_normal(C).astype(np.float32) * 0.3
+    parts = RNG.standard_normal((nz, B, H, W, C)).astype(np.float32)
+    parts[nz - 1] = x.astype(np.float32) - cb - parts[:nz - 1].sum(axis=0)
+    pd, cbd = torch.as_tensor(parts).cuda(), torch.as_tensor(cb).cuda()
+    xs = pd.sum(0) + cbd
+    xsr = xs.to(torch.bfloat16).double().cpu()
+    ys = (lambda t: T.group_norm(t, gr.detach(), br.detach(), G) if kind == "group" else T.instance_norm(t, gr.detach(), br.detach()))(xsr)
+    a4, x4 = torch.empty_like(a), torch.empty_like(a)
+    L.norm_small_fwd(x4.data_ptr(), pd.data_ptr(), nz, cbd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-5, a4.data_ptr(),
+                     mean3.data_ptr(), rstd3.data_ptr(), scale3.data_ptr(), shift3.data_ptr(), B, P, C, G, act, S())
+    close(host(x4), xsr.numpy(), 4e-3, "norm_small split-K summed input")
+    close(host(a4), (T.relu(ys) if act else ys).numpy(), 8e-3, "norm_small split-K fwd")
+    dA = RNG.standard_normal((B, H, W, C))
+    dAr = rounded(dA, BF16)
+    (ar * dAr).sum().backward()
+    dAd = dev(dA, BF16)
+    dx = torch.empty(B, H, W, C, dtype=torch.bfloat16).cuda()
+    dgamma = torch.full((C,), 0.5, dtype=torch.float32).cuda()        # accumulated (+=), not overwritten
+    dbeta = torch.full((C,), -0.25, dtype=torch.float32).cuda()
+    dbias = torch.full((C,), 2.0, dtype=torch.float32).cuda()
+    L.norm_small_bwd(dAd.data_ptr(), xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                     gd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dbias.data_ptr(), B, P, C, G, act, S())
+    close(host(dx), xr.grad.numpy(), 8e-3, "norm_small dx")
+    close(host(dgamma) - 0.5, gr.grad.numpy(), 2e-3, "norm_small dgamma")
+    close(host(dbeta) + 0.25, br.grad.numpy(), 2e-3, "norm_small dbeta")
+    ref_db = xr.grad.numpy().sum(axis=(0, 1, 2))
+    scale_db = max(1.0, float(np.abs(xr.grad.numpy()).sum(axis=(0, 1, 2)).max()))
+    got = host(dbias) - 2.0
+    if kind == "instance":
+        assert np.all(got == 0.0)                      # per-channel statistics: identically zero, not computed
+        assert float(np.abs(ref_db).max()) / scale_db < 1e-6
+    else:
+        assert float(np.abs(got - ref_db).max()) / scale_db < 2e-3, ("norm_small bias gradient", got[:4], ref_db[:4])
+    # dbias == NULL: same dx
+    dx2 = torch.empty_like(dx)
+    L.norm_small_bwd(dAd.data_ptr(), xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                     gd.data_ptr(), dx2.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), None, B, P, C, G, act, S())
+    assert torch.equal(dx, dx2)
+
+
 def test_bn_infer_scale_shift(L):
     C = 24
     g, b, mm, mv = RNG.random(C) + 0.5, RNG.standard_normal(C), RNG.standard_normal(C), RNG.random(C) + 0.5
