@@ -980,7 +980,8 @@ def test_comm_abi_single_rank_rccl(L):
     L.comm_destroy(comm)
 
 
-@pytest.mark.parametrize("case", [(2, 16, 16, 32, 64), (3, 4, 4, 192, 64), (1, 32, 64, 96, 128), (2, 12, 12, 32, 32), (40, 2, 2, 64, 96)])
+@pytest.mark.parametrize("case", [(2, 16, 16, 32, 64), (3, 4, 4, 192, 64), (1, 32, 64, 96, 128), (2, 12, 12, 32, 32), (40, 2, 2, 64, 96),
+                                  (1, 16, 64, 32, 32), (2, 16, 32, 64, 96)])
 @pytest.mark.parametrize("act", ["relu", "identity"])
 def test_conv3x3_mfma_affine_epilogue(L, case, act):
     """Inference-mode batch norm + activation folded into the convolution (reference: conv2d -> batch_norm(is_training=False)
