@@ -29,6 +29,9 @@ enum { PHX_OK = 0, PHX_E_INVAL = -1, PHX_E_SHAPE = -2, PHX_E_ALIGN = -3, PHX_E_L
 /* ---- runtime plumbing ------------------------------------------------------------------------------ */
 int phx_abi_version(void);
 int phx_last_error(char* buf, size_t n);
+/* CRC-32C (Castagnoli) of a HOST buffer; *crc holds the running value (start with 0).  Host-side helper of the TensorFlow
+ * checkpoint reader / writer (tfwrapper/tf_checkpoint.py: what tf.train.Saver's tensor bundles carry per block and tensor). */
+int phx_crc32c(const void* data, size_t n, unsigned* crc);
 int phx_device_info(int* cu_count, int* clock_khz, size_t* hbm_bytes, char* name, size_t name_n);
 int phx_stream_create(void** stream);
 int phx_stream_destroy(void* stream);

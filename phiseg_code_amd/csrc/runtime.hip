@@ -1,5 +1,7 @@
 // libphx runtime plumbing: errors, streams, events, hipGraph capture/replay, copies.
 // Replaces what tf.Session owns in the reference (phiseg/phiseg_model.py:151-157, 194).
+#include <cstring>
+#include <cstdint>
 #include <stdarg.h>
 #include <stdlib.h>
 
@@ -119,6 +121,38 @@ int phx_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
 }
 int phx_memset(void* dst, int value, size_t bytes, void* stream) {
     PHX_CHECK_HIP(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+    return PHX_OK;
+}
+
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) of a HOST buffer, slicing-by-8: the checksum TensorFlow's tensor-bundle
+// checkpoints carry per block and per tensor (tfwrapper/tf_checkpoint.py); *crc is the running value (0 to start).
+int phx_crc32c(const void* data, size_t n, unsigned* crc) {
+    PHX_REQUIRE(crc != nullptr && (data != nullptr || n == 0), PHX_E_INVAL, "crc32c: null argument");
+    static unsigned tab[8][256];
+    static bool init = false;
+    if (!init) {
+        for (unsigned i = 0; i < 256; ++i) {
+            unsigned c = i;
+            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
+            tab[0][i] = c;
+        }
+        for (unsigned i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) tab[t][i] = (tab[t - 1][i] >> 8) ^ tab[0][tab[t - 1][i] & 0xff];
+        init = true;
+    }
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    unsigned c = ~*crc;
+    while (n && (reinterpret_cast<uintptr_t>(p) & 7)) { c = (c >> 8) ^ tab[0][(c ^ *p++) & 0xff]; --n; }
+    while (n >= 8) {
+        unsigned long long w;
+        memcpy(&w, p, 8);
+        w ^= c;
+        c = tab[7][w & 0xff] ^ tab[6][(w >> 8) & 0xff] ^ tab[5][(w >> 16) & 0xff] ^ tab[4][(w >> 24) & 0xff] ^
+            tab[3][(w >> 32) & 0xff] ^ tab[2][(w >> 40) & 0xff] ^ tab[1][(w >> 48) & 0xff] ^ tab[0][(w >> 56) & 0xff];
+        p += 8; n -= 8;
+    }
+    while (n--) c = (c >> 8) ^ tab[0][(c ^ *p++) & 0xff];
+    *crc = ~c;
     return PHX_OK;
 }
 

@@ -283,7 +283,7 @@ class phiseg():
         global_step = int(store.step.cpu().item()) - 1               # tf global_step - 1 (phiseg_model.py:532)
         save = getattr(self, 'log_dir', None) is not None and os.path.isdir(getattr(self, 'log_dir', '') or '')
         if save:
-            self.save_weights(os.path.join(self.log_dir, 'model.ckpt-%d' % global_step))
+            self.save_weights(os.path.join(self.log_dir, 'model.ckpt-%d' % global_step), format=self._ckpt_format())
         if hasattr(data.validation, 'next_batch'):                   # BATCH VALIDATION of every loss term (537-556)
             names = list(self.loss_dict.keys())
             val_x, val_s = data.validation.next_batch(cfg.batch_size)
@@ -334,15 +334,21 @@ class phiseg():
                 setattr(self, 'best_' + key, value)
                 logging.info(fmt % value)
                 if save:
-                    self.save_weights(os.path.join(self.log_dir, 'model_best_%s.ckpt-%d' % (key, global_step)))
+                    self.save_weights(os.path.join(self.log_dir, 'model_best_%s.ckpt-%d' % (key, global_step)), format=self._ckpt_format())
         return out
 
     # ---- checkpoints (npz keyed by the TF variable names of SURVEY.md Appendix B) -------------------
-    def save_weights(self, path):
+    def _ckpt_format(self):
+        """exp_config.checkpoint_format: 'npz' (default) or 'tf' (TensorFlow tensor bundles, as the reference's Saver writes)"""
+        return getattr(self.exp_config, 'checkpoint_format', 'npz')
+
+    def save_weights(self, path, format='npz'):
         """What tf.train.Saver writes for this graph (phiseg_model.py:144-148, 534-535): every variable, the Adam slots under
         TF's names '<var>/Adam' (m) and '<var>/Adam_1' (v), and the step (TF keeps beta1_power / beta2_power and global_step;
-        one integer carries the same information).  File: <path>.npz.  Data-parallel: batch-norm moving statistics are
-        averaged over the replicas first (per-replica statistics); rank 0 writes."""
+        one integer carries the same information).  File: <path>.npz, or with format='tf' a TensorFlow tensor-bundle checkpoint
+        <path>.index + <path>.data-00000-of-00001 (tfwrapper/tf_checkpoint.py) that tf.train.Saver.restore of the reference
+        graph accepts: same variable names, beta1_power / beta2_power / global_step included.  Data-parallel: batch-norm
+        moving statistics are averaged over the replicas first (per-replica statistics); rank 0 writes."""
         store = self.sess._ensure_store()
         dp = self.dist is not None and self.dist.active
         if dp and store.n_state:
@@ -353,21 +359,40 @@ class phiseg():
             engine.device_sync()
         if not self._is_writer():
             return
-        if not path.endswith('.npz'):
-            path += '.npz'
-        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         blob = dict(store.export())
         for name, (m, v) in store.export_adam().items():
             blob[name + '/Adam'] = m
             blob[name + '/Adam_1'] = v
+        step = int(store.step.cpu().numpy()[0])
+        if format == 'tf':
+            from phiseg_code_amd import optimizers
+            from phiseg_code_amd.tfwrapper import tf_checkpoint
+            if path.endswith('.npz'):
+                path = path[:-4]
+            # TF 1.x AdamOptimizer's non-slot variables: beta_power = beta^(t + 1) after t updates; minimize() counts global_step
+            b1, b2 = optimizers.AdamOptimizer.beta1, optimizers.AdamOptimizer.beta2
+            blob['beta1_power'] = np.asarray(b1 ** (step + 1), dtype=np.float32)
+            blob['beta2_power'] = np.asarray(b2 ** (step + 1), dtype=np.float32)
+            blob['global_step'] = np.asarray(step, dtype=np.int64)
+            tf_checkpoint.write(path, blob)
+            tf_checkpoint.update_checkpoint_state(os.path.dirname(os.path.abspath(path)), os.path.basename(path))
+            return
+        if format != 'npz':
+            raise ValueError("save_weights: format is 'npz' or 'tf'")
+        if not path.endswith('.npz'):
+            path += '.npz'
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         tmp = path + '.tmp.npz'
-        np.savez(tmp, __step__=store.step.cpu().numpy(), **blob)
+        np.savez(tmp, __step__=np.asarray([step], dtype=np.int32), **blob)
         os.replace(tmp, path)
 
     def load_weights(self, log_dir=None, type='latest', **kwargs):
         """phiseg_model.py:505-525 (+ 'best_ncc', which the reference writes but cannot load -- SURVEY.md Q9).  `log_dir` may
         also be a checkpoint file / prefix.  Restores variables, Adam slots and the step; a checkpoint without Adam slots
-        (weights only) resets the optimiser state and the step."""
+        (weights only) resets the optimiser state and the step.  A prefix with a `.index` file next to it is a TensorFlow
+        tensor-bundle checkpoint -- one written by the reference's tf.train.Saver or by save_weights(format='tf') -- and is
+        read directly (tfwrapper/tf_checkpoint.py); variables the checkpoint lacks keep their values, as Saver.restore of a
+        sub-graph would."""
         from phiseg_code_amd.tfwrapper import utils as tfutils
         if not log_dir:
             log_dir = getattr(self, 'log_dir', None)
@@ -384,16 +409,30 @@ class phiseg():
                     raise FileNotFoundError('no %s checkpoint in %s' % (type, log_dir))
             else:
                 raise ValueError('Argument type=%s is unknown. type can be latest/iter.' % type)
-        if not os.path.exists(path) and os.path.exists(path + '.npz'):
-            path += '.npz'
-        ck = np.load(path)
         store = self.sess._ensure_store()
         names = set(self.graph.variables)
-        store.load({k: ck[k] for k in ck.files if k in names})
-        slots = {k[:-len('/Adam')]: (ck[k], ck[k + '_1']) for k in ck.files if k.endswith('/Adam') and k + '_1' in ck.files}
+        if os.path.exists(path + '.index') and not os.path.exists(path + '.npz'):
+            from phiseg_code_amd import optimizers
+            from phiseg_code_amd.tfwrapper import tf_checkpoint
+            ck = tf_checkpoint.read(path)
+            files = list(ck)
+            if 'global_step' in ck:
+                step = int(ck['global_step'])
+            elif 'beta1_power' in ck:            # beta1^(t + 1) after t updates
+                step = max(0, int(round(np.log(float(ck['beta1_power'])) / np.log(optimizers.AdamOptimizer.beta1))) - 1)
+            else:
+                step = 0
+        else:
+            if not os.path.exists(path) and os.path.exists(path + '.npz'):
+                path += '.npz'
+            ck = np.load(path)
+            files = ck.files
+            step = int(ck['__step__'][0]) if '__step__' in files else 0
+        store.load({k: ck[k] for k in files if k in names})
+        slots = {k[:-len('/Adam')]: (ck[k], ck[k + '_1']) for k in files if k.endswith('/Adam') and k + '_1' in files}
         if slots:
             store.load_adam(slots)
-            store.set_step(int(ck['__step__'][0]) if '__step__' in ck.files else 0)
+            store.set_step(step)
         else:
             store.reset_optimizer()
         self.sess._lr = None

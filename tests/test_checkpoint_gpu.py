@@ -123,3 +123,56 @@ def test_continue_mode_picks_latest_and_logs_into_cont(tmp_path):
     # after the re-run of step 2 -- the reference's own numbering drift on continued runs
     assert os.path.exists(os.path.join(log_dir + "_cont", "model.ckpt-5.npz"))
     assert int(m2.sess.store.step.cpu().item()) == 6
+
+
+def test_tensorflow_bundle_checkpoints_round_trip(tmp_path):
+    """checkpoint_format = 'tf': train() writes TensorFlow tensor bundles (tfwrapper/tf_checkpoint.py: <prefix>.index +
+    .data-00000-of-00001, TF's variable / slot names, beta1_power, beta2_power, global_step, the `checkpoint` state file);
+    load_weights reads them back -- weights, Adam slots and step bit-exact, so the continued trajectory equals the npz one --
+    and a bundle holding only weights (a reference checkpoint stripped of its optimiser) resets the optimiser."""
+    from phiseg_code_amd.phiseg import phiseg_model
+    from phiseg_code_amd.tfwrapper import tf_checkpoint as tfc
+    from phiseg_code_amd.tfwrapper import utils as tfutils
+    cfg = _cfg()
+    cfg.checkpoint_format = "tf"
+    model = phiseg_model.phiseg(cfg)
+    log_dir = str(tmp_path / "run")
+    model.train(_data(cfg), num_iter=3, log_every=0, log_dir=log_dir)
+    files = sorted(os.listdir(log_dir))
+    assert "model.ckpt-2.index" in files and "model.ckpt-2.data-00000-of-00001" in files and "checkpoint" in files
+    prefix = tfutils.get_latest_model_checkpoint_path(log_dir, "model.ckpt")
+    assert prefix == os.path.join(log_dir, "model.ckpt-2")
+    listed = tfc.list_variables(prefix)
+    names = set(model.graph.variables)
+    assert names <= set(listed) and {"beta1_power", "beta2_power", "global_step"} <= set(listed)
+    for n, v in model.graph.variables.items():
+        assert listed[n] == (np.dtype(np.float32), tuple(v.shape))
+    ck = tfc.read(prefix)
+    assert int(ck["global_step"]) == 3 and abs(float(ck["beta1_power"]) - 0.9 ** 4) < 1e-7
+    # the state at the time of the checkpoint = the state now (the checkpoint of step 2 is written after its update)
+    store = model.sess.store
+    now, adam = store.export(), store.export_adam()
+    m2 = phiseg_model.phiseg(cfg)
+    m2.load_weights(log_dir, type="latest")
+    got, gadam = m2.sess.store.export(), m2.sess.store.export_adam()
+    for n in names:
+        np.testing.assert_array_equal(got[n], now[n])
+    for n, (m_, v_) in adam.items():
+        np.testing.assert_array_equal(gadam[n][0], m_)
+        np.testing.assert_array_equal(gadam[n][1], v_)
+    assert int(m2.sess.store.step.cpu().item()) == 3
+    # weights-only bundle: optimiser state and step reset
+    wonly = str(tmp_path / "weights_only" / "model.ckpt-9")
+    tfc.write(wonly, {n: now[n] for n in names})
+    m2.load_weights(wonly)
+    assert int(m2.sess.store.step.cpu().item()) == 0
+    assert all(float(np.abs(m_).max()) == 0.0 for m_, _ in m2.sess.store.export_adam().values())
+    # explicit format argument, same content as the npz writer
+    model.save_weights(str(tmp_path / "a" / "w"), format="tf")
+    model.save_weights(str(tmp_path / "a" / "w2"))
+    a, b = tfc.read(str(tmp_path / "a" / "w")), np.load(str(tmp_path / "a" / "w2.npz"))
+    for k in b.files:
+        if k != "__step__":
+            np.testing.assert_array_equal(a[k], b[k])
+    with pytest.raises(ValueError):
+        model.save_weights(str(tmp_path / "a" / "w3"), format="hdf5")
