@@ -161,7 +161,7 @@ class lidc_data:
     """data/lidc_data.py: .train (augmented, random annotator), .validation, .test providers built from the arrays the
     reference keeps in HDF5 (lidc_data_loader.py:92-104: <split>/images [N,128,128] float, <split>/labels [N,128,128,4] uint8).
     `source`: a dict {'train': {'images':..., 'labels':...}, 'val': ..., 'test': ...} of arrays, the path of an .npz with keys
-    'train_images', 'train_labels', ..., or -- when h5py is importable -- the reference's HDF5 file."""
+    'train_images', 'train_labels', ..., or the reference's HDF5 file data_lidc.hdf5 (h5py when importable, else data/mini_hdf5.py)."""
 
     def __init__(self, exp_config, source, seed=1234):
         data = self._load(source)
@@ -182,9 +182,8 @@ class lidc_data:
             return {sp: dict(images=z[sp + "_images"], labels=z[sp + "_labels"]) for sp in ("train", "val", "test")
                     if sp + "_images" in z.files}
         try:
-            import h5py
-        except ImportError as e:
-            raise ImportError("reading the reference's HDF5 file needs h5py, which is not installed here; convert it to .npz "
-                              "(keys train_images, train_labels, val_images, ...) or pass the arrays") from e
-        with h5py.File(source, "r") as f:
+            import h5py as h5
+        except ImportError:                  # not installed here: the package's own reader of the loader's HDF5 layout
+            from phiseg_code_amd.data import mini_hdf5 as h5
+        with h5.File(source, "r") as f:
             return {sp: dict(images=f[sp]["images"][()], labels=f[sp]["labels"][()]) for sp in ("train", "val", "test") if sp in f}

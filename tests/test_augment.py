@@ -98,3 +98,27 @@ def test_provider_feeds_the_training_plan_directly():
     prov.next_batch_device(4, xb.data_ptr(), sb.data_ptr())
     torch.cuda.synchronize()
     assert float(xb.abs().sum()) > 0
+
+
+@pytest.mark.gpu
+def test_lidc_data_from_the_loaders_hdf5_file():
+    """data/lidc_data.py: the three providers built straight from the HDF5 file the reference's loader writes (read by
+    data/mini_hdf5.py: tests/golden/lidc_like.hdf5 was written by libhdf5 as lidc_data_loader.py:92-104 does); un-augmented
+    batches are rows of the file (float64 images cast to the fp32 feed), augmented training batches keep their shape and range."""
+    import os
+    import types
+    from phiseg_code_amd.data import augment as pa
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    exp = np.load(os.path.join(gold, "lidc_like_expected.npz"))
+    cfg = types.SimpleNamespace(num_labels_per_subject=4, annotator_range=range(4), nlabels=2,
+                                augmentation_options={'do_flip_lr': True, 'do_flip_ud': True, 'do_rotations': True,
+                                                      'do_scaleaug': True, 'nlabels': 2})
+    data = pa.lidc_data(cfg, os.path.join(gold, "lidc_like.hdf5"), seed=3)
+    x, s = data.validation.next_batch(2)
+    for j, (src, an) in enumerate(zip(data.validation.last_indices, data.validation.last_annotators)):
+        np.testing.assert_array_equal(x[j, ..., 0], exp["val_images"][src].astype(np.float32))
+        np.testing.assert_array_equal(s[j], exp["val_labels"][src, ..., an])
+    xt, st = data.train.next_batch(5)
+    assert xt.shape == (5, 24, 24, 1) and st.shape == (5, 24, 24) and xt.dtype == np.float32 and st.dtype == np.uint8
+    assert float(np.abs(xt).max()) <= 0.5 + 1e-6 and set(np.unique(st)) <= {0, 1}
+    assert data.test is not None and data.test.next_batch(3)[0].shape == (3, 24, 24, 1)
