@@ -19,9 +19,12 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 def install_dropin_aliases():
     """Make ``import tfwrapper.layers`` / ``from phiseg.model_zoo import posteriors`` / ``import config.system``
-    resolve to this package, the way scripts written against the reference import them."""
+    / ``from data.data_switch import data_switch`` / ``import utils`` resolve to this package, the way scripts written against the
+    reference import them."""
     import importlib
-    for top in ("tfwrapper", "phiseg", "config"):
+    for sub in ("data_switch", "lidc_data", "batch_provider", "lidc_data_loader"):      # (from data.data_switch import data_switch)
+        importlib.import_module("phiseg_code_amd.data." + sub)
+    for top in ("tfwrapper", "phiseg", "config", "data", "utils"):
         mod = importlib.import_module("phiseg_code_amd." + top)
         sys.modules.setdefault(top, mod)
         for name, m in list(sys.modules.items()):

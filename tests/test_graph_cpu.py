@@ -91,3 +91,9 @@ def test_dropin_aliases():
     import tfwrapper.layers as L2
     from phiseg_code_amd.tfwrapper import layers as L1
     assert L1 is L2
+    # phiseg_train.py:7 `from data.data_switch import data_switch`, :11 `import utils`
+    from data.data_switch import data_switch
+    from phiseg_code_amd.data import data_switch as ds
+    assert data_switch is ds.data_switch
+    import utils
+    assert hasattr(utils, "generalised_energy_distance") and hasattr(utils, "variance_ncc_dist")
