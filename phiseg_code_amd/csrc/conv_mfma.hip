@@ -2162,16 +2162,48 @@ __device__ __forceinline__ void conv3x3_wgrad_dma_body(const unsigned short* __r
         };
         steps(steps, std::integral_constant<int, 0>());
     }
-    // partial tile -> workspace (see k_conv3x3_wgrad); C layout: col = lane&31 -> co, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> ci
-    const size_t cb = (size_t)bz * gdy + by;
-    float* wp = ws + ((cb * gdx + bx) * WK + wk) * (size_t)(9 * TCI * TCO);
+    // The WK wave groups of a block hold partial sums of the SAME filter tile (they split the tile's pixels): summed here through
+    // LDS (the staging buffers are free now) in log2(WK) rounds -- wave groups with bit `half` set hand their 36 KiB of
+    // accumulators to the group below -- so a block writes ONE partial filter instead of WK (the 32 x 32 layers at 128 x 128 wrote
+    // 52 MB of partials per launch, a quarter of the kernel's time, and the reduction read them back).
+    if constexpr (WK > 1) {
+        typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+        f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+        for (int half = 1; half < WK; half <<= 1) {
+            const int sel = wk & (2 * half - 1);
+            f32x4_t* p = red + (size_t)(wi + WI * (wj + WJ * (wk / (2 * half)))) * (9 * 4 * 64) + lane;
+            __syncthreads();                     // staging tile / previous round consumed
+            if (sel == half)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int cil = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            wp[(k * TCI + cil) * TCO + wj * 32 + (lane & 31)] = acc[k][r];
+                for (int k = 0; k < 9; ++k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        p[(k * 4 + q) * 64] = f32x4_t{acc[k][4 * q], acc[k][4 * q + 1], acc[k][4 * q + 2], acc[k][4 * q + 3]};
+            __syncthreads();
+            if (sel == 0)
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4_t v = p[(k * 4 + q) * 64];
+                        acc[k][4 * q] += v[0]; acc[k][4 * q + 1] += v[1]; acc[k][4 * q + 2] += v[2]; acc[k][4 * q + 3] += v[3];
+                    }
         }
+    }
+    // partial tile -> workspace (see k_conv3x3_wgrad): ws[(cblock * gdx + bx)][9][TCI][TCO]; C layout: col = lane&31 -> co,
+    // row = (r&3) + 8*(r>>2) + 4*(lane>>5) -> ci
+    if (WK == 1 || wk == 0) {
+        const size_t cb = (size_t)bz * gdy + by;
+        float* wp = ws + (cb * gdx + bx) * (size_t)(9 * TCI * TCO);
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cil = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                wp[(k * TCI + cil) * TCO + wj * 32 + (lane & 31)] = acc[k][r];
+            }
+    }
     PHX_BLOCKLOG_END();
 }
 
@@ -2608,6 +2640,17 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
     return PHX_OK;
 }
 
+static bool wgrad_dma_enabled() {
+    static int dma_en = -1;
+    if (dma_en < 0) { const char* e = getenv("PHX_WGRAD_DMA"); dma_en = e ? atoi(e) : 1; }
+    return dma_en != 0;
+}
+// dynamic LDS of the LDS-DMA filter-gradient kernels: the staged tile, or the 2 x 36 KiB of the wave-group reduction
+static size_t wgrad_dma_lds(int tci, int tco) {
+    const size_t stage = (size_t)((324 * (tci / 8) + 63) / 64) * 1024 + (size_t)256 * tco * 2;
+    const size_t red = (tci == 64 && tco == 64) ? 0 : (size_t)2 * 9 * 16 * 64 * sizeof(float);
+    return stage > red ? stage : red;
+}
 static int wgrad_plan(int B, int H, int W, int Cin, int Cout, MTile* g, int* tci, int* tco, int* gx, int* tpb, int* wk,
                       int target_override = 0) {
     *g = make_mtile(B, H, W);
@@ -2615,6 +2658,7 @@ static int wgrad_plan(int B, int H, int W, int Cin, int Cout, MTile* g, int* tci
     *tci = Cin % 64 == 0 ? 64 : 32;
     *tco = Cout % 64 == 0 ? 64 : 32;
     *wk = 4 / ((*tci / 32) * (*tco / 32));
+    if (wgrad_dma_enabled() && g->tws == 4 && g->ths == 4 && g->tb == 1) *wk = 1;   // the LDS-DMA kernel sums its wave groups in LDS
     const int cblocks = (Cin / *tci) * (Cout / *tco);
     // measured on MI355X (tools/bench_wgrad.py, LDS-DMA kernels, two blocks per CU): ~384 blocks; 512 when few channel
     // blocks share the pixel tiles; fewer when there are few pixel tiles, because every block writes (and k_wgrad_reduce
@@ -2688,7 +2732,7 @@ int phx_conv3x3_wgrad_multi_job(const void* x, const void* dy, float* dw_hwio, v
         // normalisation pass)
         static int dtl = -1;
         if (dtl < 0) { const char* e = getenv("PHX_WGRAD_DEFER_TILES"); dtl = e ? atoi(e) : 1024; }
-        if (!workspace || ntiles > dtl || ntiles <= wgrad_atomic_tiles()) return PHX_OK;
+        if (!workspace || ntiles > dtl || ntiles <= wgrad_atomic_tiles() || !wgrad_dma_enabled()) return PHX_OK;
     }
     const int npatch = g.tb * ((1 << g.ths) + 2) * ((1 << g.tws) + 2);
     const bool use_ws = workspace != nullptr && ntiles > wgrad_atomic_tiles();
@@ -2702,7 +2746,7 @@ int phx_conv3x3_wgrad_multi_job(const void* x, const void* dy, float* dw_hwio, v
     memcpy(job_out, &j, sizeof(j));
     info4[0] = 1 + (tco == 64 ? 1 : 0) + (tci == 64 ? 2 : 0) + (fast16 ? 8 : npatch > 400 ? 4 : 0);     // 9..12: LDS-DMA kernels
     info4[1] = j.gdx * j.gdy * j.gdz;
-    info4[2] = fast16 ? ((324 * (tci / 8) + 63) / 64) * 1024 + 256 * tco * 2 : npatch * tci * 2 + 256 * tco * 2;
+    info4[2] = fast16 ? (int)wgrad_dma_lds(tci, tco) : npatch * tci * 2 + 256 * tco * 2;
     info4[3] = use_ws;
     info4[4] = gx * wk; info4[5] = tci; info4[6] = tco;                       // reduction job of this launch (phx_wgrad_reduce_multi)
     wgrad_reduce_geometry(Cin, Cout, gx * wk, &info4[7], &info4[8]);
@@ -2780,16 +2824,14 @@ static int wgrad_impl(const void* x, const void* dy, float* dw_hwio, void* works
         attr_set = true;
     }
     // 16x16 tiles with a workspace: the LDS-DMA kernel (two blocks per CU)
-    static int dma_en = -1;
-    if (dma_en < 0) { const char* e = getenv("PHX_WGRAD_DMA"); dma_en = e ? atoi(e) : 1; }
-    if (dma_en && ws && g.tws == 4 && g.ths == 4 && g.tb == 1) {
+    if (wgrad_dma_enabled() && ws && g.tws == 4 && g.ths == 4 && g.tb == 1) {
         static bool dattr = false;
 #define WD_ATTR(A, Bq) PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_dma<A, Bq>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
         if (!dattr) { WD_ATTR(64, 64); WD_ATTR(64, 32); WD_ATTR(32, 64); WD_ATTR(32, 32); dattr = true; }
 #undef WD_ATTR
 #define WD_LAUNCH(A, Bq)                                                                                              \
     hipLaunchKernelGGL((k_conv3x3_wgrad_dma<A, Bq>), dim3(gx, Cin / A, Cout / Bq), dim3(256),                         \
-                       (size_t)((324 * (A / 8) + 63) / 64) * 1024 + (size_t)256 * Bq * 2, (hipStream_t)stream,        \
+                       wgrad_dma_lds(A, Bq), (hipStream_t)stream,                                                     \
                        (const unsigned short*)x, (const unsigned short*)dy, ws, B, H, W, Cin, Cout, g, ntiles, tpb)
         if (tci == 64 && tco == 64) WD_LAUNCH(64, 64);
         else if (tci == 64) WD_LAUNCH(64, 32);

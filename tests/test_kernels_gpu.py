@@ -905,7 +905,8 @@ def test_wgrad_deferred_small_map_launches(L):
         L.conv3x3_wgrad_multi_job(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws2.data_ptr(), wsb, B, H, W, K, N, tgt, 0, jb, info)
         keep.append((x, dy, ws, ws2))
         if not info[0]:                                       # a 16x16-tile shape with <= 4 tiles adds straight into dw: per-layer launch
-            assert (B, H, W) == (2, 16, 16)
+            # (with the LDS-DMA kernels switched off -- PHX_WGRAD_DMA=0, a debug hook -- no 16x16-tile layer is deferred)
+            assert (B, H, W) == (2, 16, 16) or os.environ.get("PHX_WGRAD_DMA") == "0"
             continue
         g = groups.setdefault(int(info[0]), dict(recs=[], blocks=0, lds=0))
         L.conv3x3_wgrad_multi_job(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws2.data_ptr(), wsb, B, H, W, K, N, tgt, g["blocks"], jb, info)
