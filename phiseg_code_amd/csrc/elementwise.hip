@@ -577,21 +577,21 @@ __global__ __launch_bounds__(256) void k_norm_wave_bwd(const bf16_t* __restrict_
 static int norm_geometry(int P, int C, int V, int* PL, int* threads, int* chunk, int* nchunks, int NS, int nrep = 1) {
     int CV = C / V;
     if (CV > 256) return -1;
-    *PL = 256 / CV;
+    *PL = 256 / CV;                              // (512 / 1024-thread blocks measured slower: the LDS reduction over PL lanes grows)
     *threads = CV * (*PL);
     int rows = (P + *PL - 1) / (*PL);
     static int ppt_n = 0;
-    if (!ppt_n) { const char* e = getenv("PHX_NORM_PPT"); ppt_n = e ? atoi(e) : 8; }     // tuning hook: pixels per thread
-    int want = (rows + ppt_n - 1) / ppt_n;                    // 8 pixels per thread on big maps (re-measured under the two-lane schedule)
+    if (!ppt_n) { const char* e = getenv("PHX_NORM_PPT"); ppt_n = e ? atoi(e) : 16; }    // tuning hook: pixels per thread
+    int want = (rows + ppt_n - 1) / ppt_n;                    // (16 / floor 256 / cap 512: re-measured with the LDS-shared prologues, round 2)
     static int fl = 0;
-    if (!fl) { const char* e = getenv("PHX_NORM_FLOOR"); fl = e ? atoi(e) : 128; }      // tuning hook (measured: tools/bench_norm.py)
+    if (!fl) { const char* e = getenv("PHX_NORM_FLOOR"); fl = e ? atoi(e) : 256; }      // tuning hook (measured: tools/bench_norm.py)
     // (the floor counts blocks of the whole launch: with per-sample statistics, NS > 1, every sample gets its share -- a
     // floor per SAMPLE cut the 128 x 128 group-norm layers into thousands of blocks of two pixels per thread: 62 us vs 19)
     const int fl_ns = (fl + (NS > 0 ? NS : 1) - 1) / (NS > 0 ? NS : 1);
     int floor_blocks = rows < fl_ns ? rows : fl_ns;
     if (want < floor_blocks) want = floor_blocks;
     static int capv = 0;
-    if (!capv) { const char* e = getenv("PHX_NORM_CAP"); capv = e ? atoi(e) : 1024; }    // tuning hook
+    if (!capv) { const char* e = getenv("PHX_NORM_CAP"); capv = e ? atoi(e) : 512; }     // tuning hook
     int cap = (nrep > 1 ? capv : 2048) / (NS > 0 ? NS : 1);   // every block ends in 2C same-address atomics (see k_norm_bwd_reduce)
     if (cap < 1) cap = 1;
     if (want > cap) want = cap;
@@ -604,16 +604,18 @@ static int norm_geometry(int P, int C, int V, int* PL, int* threads, int* chunk,
 static int stream_geometry(int P, int C, int V, int* PL, int* threads, int* chunk, int* nchunks, int NS) {
     int CV = C / V;
     if (CV > 256) return -1;
-    *PL = 256 / CV;
+    static int nthr = 0;
+    if (!nthr) { const char* e = getenv("PHX_STREAM_THREADS"); nthr = e ? atoi(e) : 256; }  // tuning hook: threads per block
+    *PL = nthr / CV;
+    if (*PL < 1) *PL = 1;
     *threads = CV * (*PL);
-    // 16 pixels per thread on big maps; on small maps fewer, so that >= ~1024 blocks exist (the kernels are latency-bound
-    // there: a thread's iterations are serially dependent loads)
+    // 8 pixels per thread on big maps (two trips of four); on small maps fewer, so that ~1024 blocks exist
     int rows = (P + *PL - 1) / (*PL);
     static int ppt_s = 0;
-    if (!ppt_s) { const char* e = getenv("PHX_STREAM_PPT"); ppt_s = e ? atoi(e) : 32; }  // tuning hook: pixels per thread
+    if (!ppt_s) { const char* e = getenv("PHX_STREAM_PPT"); ppt_s = e ? atoi(e) : 8; }   // tuning hook: pixels per thread (8 / floor 1024 since the prologues are LDS-shared; 32 / 256 before)
     int want = (rows + ppt_s - 1) / ppt_s;
     static int fl = 0;
-    if (!fl) { const char* e = getenv("PHX_STREAM_FLOOR"); fl = e ? atoi(e) : 256; }    // tuning hook (measured: tools/bench_norm.py)
+    if (!fl) { const char* e = getenv("PHX_STREAM_FLOOR"); fl = e ? atoi(e) : 1024; }   // tuning hook (measured: tools/bench_norm.py)
     // (the floor counts blocks of the whole launch: with per-sample statistics, NS > 1, every sample gets its share -- a
     // floor per SAMPLE cut the 128 x 128 group-norm layers into thousands of blocks of two pixels per thread: 62 us vs 19)
     const int fl_ns = (fl + (NS > 0 ? NS : 1) - 1) / (NS > 0 ? NS : 1);
@@ -777,45 +779,57 @@ __global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __rest
     const int CV = C / V, cg = C / G;
     const int ns = blockIdx.y;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
-    if (pl >= PL) return;
+    // The statistics are finalised ONCE per block, cooperatively, into LDS: thread g derives (mean, rstd) of statistic g, thread c
+    // the (scale, shift) of channel c.  (Every thread deriving the eight channels it streams -- 30-50 loads of the same few cache
+    // lines per thread -- made the prologue 4-5 us per block and a launch with many blocks a hot spot in one L2 channel: these
+    // kernels ran at 2.4-4.7 TB/s where a plain copy of the same tensor reaches 6-7.)
+    extern __shared__ float lds_f[];
+    float* gst = lds_f;                          // [G][2]  mean, rstd
+    float* cof = lds_f + 2 * G;                  // [C][2]  scale, shift
     const float invP = 1.f / (float)P;
+    const bool pub = blockIdx.x == 0;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        float mu, var;
+        if (cg == 1) {                                      // batch / instance norm: one channel per statistic
+            const float2 sq = *reinterpret_cast<const float2*>(sums + ((size_t)ns * C + g) * 2);
+            const float d1 = sq.x * invP;
+            mu = (pivot ? pivot[(size_t)ns * C + g] : 0.f) + d1;
+            var = fmaxf(sq.y * invP - d1 * d1, 0.f);
+        } else {
+            group_stats(sums, pivot, ns, C, g, cg, invP, eps, &mu, &var);
+        }
+        const float rs = rsqrtf(var + eps);
+        gst[2 * g] = mu;
+        gst[2 * g + 1] = rs;
+        if (pub) {
+            mean_out[ns * G + g] = mu;
+            rstd_out[ns * G + g] = rs;
+            if (momentum > 0.f && moving_mean) {          // batch norm (G == C): TF1 fused-batch-norm moving update
+                const float m = (float)P * (float)cg;
+                moving_mean[g] -= (moving_mean[g] - mu) * momentum;
+                moving_var[g] -= (moving_var[g] - var * (m / fmaxf(m - 1.f, 1.f))) * momentum;
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cg;
+        const float scv = gamma[c] * gst[2 * g + 1];
+        const float shv = beta[c] - gst[2 * g] * scv;
+        cof[2 * c] = scv;
+        cof[2 * c + 1] = shv;
+        if (pub) {
+            scale_out[(size_t)ns * C + c] = scv;
+            shift_out[(size_t)ns * C + c] = shv;
+        }
+    }
+    __syncthreads();
+    if (pl >= PL) return;
     float sc[V], sh[V];
-    int gprev = -1;
-    float mu = 0.f, var = 0.f, rs = 0.f;
-    const bool publish = blockIdx.x == 0 && pl == 0;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-        const int c = cv * V + j, g = c / cg;
-        if (cg == 1) {                                      // batch / instance norm: one channel per statistic
-            const float2 sq = *reinterpret_cast<const float2*>(sums + ((size_t)ns * C + c) * 2);
-            const float d1 = sq.x * invP;
-            mu = (pivot ? pivot[(size_t)ns * C + c] : 0.f) + d1;
-            var = fmaxf(sq.y * invP - d1 * d1, 0.f);
-            rs = rsqrtf(var + eps);
-            gprev = -1;
-        }
-        if (cg == 1 || g != gprev) {
-            if (cg != 1) {
-                group_stats(sums, pivot, ns, C, g, cg, invP, eps, &mu, &var);
-                rs = rsqrtf(var + eps);
-                gprev = g;
-            }
-            if (publish && c == g * cg) {
-                mean_out[ns * G + g] = mu;
-                rstd_out[ns * G + g] = rs;
-                if (momentum > 0.f && moving_mean) {          // batch norm (G == C): TF1 fused-batch-norm moving update
-                    const float m = (float)P * (float)cg;
-                    moving_mean[g] -= (moving_mean[g] - mu) * momentum;
-                    moving_var[g] -= (moving_var[g] - var * (m / fmaxf(m - 1.f, 1.f))) * momentum;
-                }
-            }
-        }
-        sc[j] = gamma[c] * rs;
-        sh[j] = beta[c] - mu * sc[j];
-        if (publish) {
-            scale_out[(size_t)ns * C + c] = sc[j];
-            shift_out[(size_t)ns * C + c] = sh[j];
-        }
+        sc[j] = cof[2 * (cv * V + j)];
+        sh[j] = cof[2 * (cv * V + j) + 1];
     }
     const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
     int p = p0 + pl;
@@ -852,8 +866,13 @@ __global__ void k_norm_bwd_apply_fused(const TD* __restrict__ dA, const TX* __re
     const int CV = C / V, cg = C / G;
     const int ns = blockIdx.y;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
-    // the block sums the accumulator replicas once, into LDS: st[c][2] = sum_r sums2[r][ns][c][2]
+    // finalisation once per block, cooperatively, through LDS (see k_norm_apply_fused):
+    //   st[c][2]  = sum over the accumulator replicas of {sum g, sum g * xhat}
+    //   sg[g][2]  = S0, S1 = sum over the statistic's channels of gamma_c * st[c]
+    //   cof[c][5] = a, b, c of dx = a * g + b + c * x, and the layer's (scale, shift) for the activation gradient
     extern __shared__ float st[];
+    float* sg = st + 2 * C;
+    float* cof = sg + 2 * G;
     {
         const size_t rstride = (size_t)gridDim.y * 2 * C;    // sums2[nrep][NS][C][2]
         for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
@@ -863,43 +882,30 @@ __global__ void k_norm_bwd_apply_fused(const TD* __restrict__ dA, const TX* __re
         }
     }
     __syncthreads();
-    if (pl >= PL) return;
-    const float inv_m = 1.f / ((float)P * (float)cg);
-    float sc[V], sh[V], ca[V], cb[V], cc[V];
-    int gprev = -1;
-    float S0 = 0.f, S1 = 0.f;
-    const bool publish = blockIdx.x == 0 && pl == 0;
-    auto rsum = [&](int c, float& a, float& b) { a = st[2 * c]; b = st[2 * c + 1]; };
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-        const int c = cv * V + j, g = c / cg;
-        float t0 = 0.f, t1 = 0.f;                            // this channel's {sum g, sum g * xhat}
-        if (cg == 1) {
-            rsum(c, t0, t1);
-            const float gm = gamma[c];
-            S0 = gm * t0;
-            S1 = gm * t1;
-        } else {
-            if (g != gprev) {
-                S0 = S1 = 0.f;
-                for (int q = g * cg; q < (g + 1) * cg; ++q) {
-                    float a, b;
-                    rsum(q, a, b);
-                    S0 += gamma[q] * a;
-                    S1 += gamma[q] * b;
-                }
-                gprev = g;
-            }
-            if (publish) rsum(c, t0, t1);
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        float S0 = 0.f, S1 = 0.f;
+        for (int q = g * cg; q < (g + 1) * cg; ++q) {
+            const float gm = gamma[q];
+            S0 += gm * st[2 * q];
+            S1 += gm * st[2 * q + 1];
         }
-        const int sg = ns * G + g;
-        const float rs = rstd[sg], mu = mean[sg];
-        sc[j] = scale[(size_t)ns * C + c];
-        sh[j] = shift[(size_t)ns * C + c];
-        ca[j] = rs * gamma[c];
-        cc[j] = -rs * rs * S1 * inv_m;
-        cb[j] = -rs * S0 * inv_m - cc[j] * mu;
-        if (publish) {
+        sg[2 * g] = S0;
+        sg[2 * g + 1] = S1;
+    }
+    __syncthreads();
+    const float inv_m = 1.f / ((float)P * (float)cg);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cg, sgi = ns * G + g;
+        const float rs = rstd[sgi], mu = mean[sgi], S0 = sg[2 * g], S1 = sg[2 * g + 1];
+        const float ca = rs * gamma[c];
+        const float cc = -rs * rs * S1 * inv_m;
+        cof[5 * c] = ca;
+        cof[5 * c + 1] = -rs * S0 * inv_m - cc * mu;
+        cof[5 * c + 2] = cc;
+        cof[5 * c + 3] = scale[(size_t)ns * C + c];
+        cof[5 * c + 4] = shift[(size_t)ns * C + c];
+        if (blockIdx.x == 0) {
+            const float t0 = st[2 * c], t1 = st[2 * c + 1];      // this channel's {sum g, sum g * xhat}
             atomicAdd(&dbeta[c], t0);
             atomicAdd(&dgamma[c], t1);
             if (dbias) {
@@ -907,9 +913,17 @@ __global__ void k_norm_bwd_apply_fused(const TD* __restrict__ dA, const TX* __re
                 // layers.py:126-132): sum_p dx[ns, p, c] = a * sum g + P * b + c * sum x, in closed form from the per-channel
                 // sums of both passes -- no pass over dx.  (sum x - P * mean from the shifted forward sums: no cancellation.)
                 const float dsum = fsums[((size_t)ns * C + c) * 2] + (float)P * ((fpivot ? fpivot[(size_t)ns * C + c] : 0.f) - mu);
-                atomicAdd(&dbias[c], fmaf(ca[j], t0, fmaf(cc[j], dsum, -(float)P * rs * S0 * inv_m)));
+                atomicAdd(&dbias[c], fmaf(ca, t0, fmaf(cc, dsum, -(float)P * rs * S0 * inv_m)));
             }
         }
+    }
+    __syncthreads();
+    if (pl >= PL) return;
+    float sc[V], sh[V], ca[V], cb[V], cc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const float* q = cof + 5 * (cv * V + j);
+        ca[j] = q[0]; cb[j] = q[1]; cc[j] = q[2]; sc[j] = q[3]; sh[j] = q[4];
     }
     const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
     int p = p0 + pl;
@@ -948,7 +962,7 @@ __global__ void k_norm_bwd_apply_fused(const TD* __restrict__ dA, const TX* __re
 
 // sums2[ns][c][2] += {sum g, sum g*xhat},  g = dA * act'(x*scale+shift), xhat = (x-mean)*rstd
 template <typename TD, typename TX, int V>
-__global__ void k_norm_bwd_reduce(const TD* __restrict__ dA, const TX* __restrict__ x,
+__global__ __launch_bounds__(256) void k_norm_bwd_reduce(const TD* __restrict__ dA, const TX* __restrict__ x,
                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                   const float* __restrict__ mean, const float* __restrict__ rstd,
                                   float* __restrict__ sums2, int P, int C, int G, int PL, int chunk, int act, int nrep) {
@@ -962,18 +976,42 @@ __global__ void k_norm_bwd_reduce(const TD* __restrict__ dA, const TX* __restric
     sums2 += (size_t)(blockIdx.x % nrep) * gridDim.y * 2 * C;
     float s1[V], s2[V], sc[V], sh[V], mu[V], rs[V];
     const int cg = C / G;
+    // per-channel constants through LDS: one load per channel and block instead of one per channel and thread (red is reused
+    // for the block reduction below, after the barrier that ends the streaming loop)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        red[4 * c] = scale[(size_t)ns * C + c];
+        red[4 * c + 1] = shift[(size_t)ns * C + c];
+        red[4 * c + 2] = mean[(size_t)ns * G + c / cg];
+        red[4 * c + 3] = rstd[(size_t)ns * G + c / cg];
+    }
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         const int c = cv * V + j;
         s1[j] = s2[j] = 0.f;
-        sc[j] = scale[(size_t)ns * C + c];
-        sh[j] = shift[(size_t)ns * C + c];
-        mu[j] = mean[(size_t)ns * G + c / cg];
-        rs[j] = rstd[(size_t)ns * G + c / cg];
+        sc[j] = red[4 * c]; sh[j] = red[4 * c + 1]; mu[j] = red[4 * c + 2]; rs[j] = red[4 * c + 3];
     }
+    __syncthreads();                             // constants read: red is free for the partial sums
     const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
     if (pl < PL) {
         int p = p0 + pl;
+        for (; p + 3 * PL < p1; p += 4 * PL) {   // four pixels per trip, loads first (see k_norm_stats)
+            float xv[4][V], dv[4][V];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t off = ((size_t)ns * P + p + u * PL) * C + (size_t)cv * V;
+                VecIO<TX, V>::load(x, off, xv[u]);
+                VecIO<TD, V>::load(dA, off, dv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float g = dv[u][j] * act_grad_pre(xv[u][j] * sc[j] + sh[j], act);
+                    s1[j] += g;
+                    s2[j] += g * (xv[u][j] - mu[j]) * rs[j];
+                }
+        }
         for (; p < p1; p += PL) {
             float xv[V], dv[V];
             const size_t off = ((size_t)ns * P + p) * C + (size_t)cv * V;
@@ -1420,7 +1458,7 @@ int phx_norm_apply_fused(const void* x, int x_dt, const float* sums, const float
     PHX_DT_SWITCH(x_dt, TI, PHX_DT_SWITCH(y_dt, TO, PHX_VEC_SWITCH(C, V, {
         int PL, threads, chunk, nchunks;
         PHX_REQUIRE(stream_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_apply_fused: C too large");
-        hipLaunchKernelGGL((k_norm_apply_fused<TI, TO, V>), dim3(nchunks, NS), dim3(threads), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((k_norm_apply_fused<TI, TO, V>), dim3(nchunks, NS), dim3(threads), (size_t)2 * (C + G) * sizeof(float), (hipStream_t)stream,
                            (const TI*)x, sums, pivot, gamma, beta, eps, (TO*)y, mean, rstd, scale, shift, moving_mean,
                            moving_var, momentum, P, C, G, PL, chunk, act);
     })));
@@ -1447,7 +1485,7 @@ int phx_norm_bwd_apply_fused_bias(const void* dA, int da_dt, const void* x, int 
         int PL, threads, chunk, nchunks;
         PHX_REQUIRE(stream_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_bwd_apply_fused: C too large");
         hipLaunchKernelGGL((k_norm_bwd_apply_fused<TD, TX, TD, V>), dim3(nchunks, NS), dim3(threads),
-                           (size_t)2 * C * sizeof(float), (hipStream_t)stream, (const TD*)dA, (const TX*)x, scale, shift, mean, rstd, gamma, sums2,
+                           (size_t)(7 * C + 2 * G) * sizeof(float), (hipStream_t)stream, (const TD*)dA, (const TX*)x, scale, shift, mean, rstd, gamma, sums2,
                            (TD*)dx, dgamma, dbeta, P, C, G, PL, chunk, act, nrep, fwd_sums, fwd_pivot, dbias);
     })));
     PHX_CHECK_LAUNCH();
@@ -1466,7 +1504,7 @@ int phx_norm_bwd_reduce(const void* dA, int da_dt, const void* x, int x_dt, cons
             nchunks = (P + chunk - 1) / chunk;
         }
         hipLaunchKernelGGL((k_norm_bwd_reduce<TD, TX, V>), dim3(nchunks, NS), dim3(threads),
-                           (size_t)PL * C * 2 * sizeof(float), (hipStream_t)stream, (const TD*)dA, (const TX*)x, scale,
+                           (size_t)(PL > 2 ? PL : 2) * C * 2 * sizeof(float), (hipStream_t)stream, (const TD*)dA, (const TX*)x, scale,
                            shift, mean, rstd, sums2, P, C, G, PL, chunk, act, nrep);
     })));
     PHX_CHECK_LAUNCH();

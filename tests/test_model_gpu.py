@@ -416,7 +416,11 @@ def test_bf16_gradients_n0_32_vs_simulated_bf16_oracle(norm):
         # (... and at batch 2 the H <= 4 levels normalise over 8 - 32 values per channel: a single variable's ratio has a tail --
         # 2.29x observed once in ~10 runs on a 192-element gamma of the 2 x 2 level; the MEAN over all variables below is the
         # sharp assertion)
-        bound = (2.5 if ge.size >= 64 else 3.5) * max(inh, 0.03)
+        # Batch norm at batch 2 is the ill-conditioned case (mean error 0.42 of the simulated policy itself): single variables reached
+        # 2.3 - 2.7x in about one run of five, so its per-variable bound only catches gross errors (a wrong gradient has e >= 1) and the
+        # sharp per-variable check is the group-norm instance of this test (mean error 0.06, same kernels but for the norm family).
+        fac = 4.0 if norm is None else 2.5
+        bound = (fac if ge.size >= 64 else fac + 1.0) * max(inh, 0.03)
         assert e <= bound and e_s <= bound, (name, e, e_s, inh)
         if e / bound > worst[0]:
             worst = (e / bound, name, e, inh)

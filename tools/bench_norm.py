@@ -16,7 +16,8 @@ for (H, C) in shapes:
     sums = torch.stack([x.float().sum(0), (x.float() ** 2).sum(0)], 1).contiguous()
     gamma, beta = torch.ones(C, device="cuda"), f(C)
     mean, rstd, scale, shift, mm, mv = f(C), f(C), f(C), f(C), f(C), torch.ones(C, device="cuda")
-    NREP = 8
+    import os
+    NREP = int(os.environ.get("BENCH_NREP", "8"))
     sums2, dg, db = f(NREP * 2 * C), f(C), f(C)
     def k_apply():
         L.norm_apply_fused(x.data_ptr(), BF, sums.data_ptr(), None, gamma.data_ptr(), beta.data_ptr(), 1e-3, y.data_ptr(), BF,
@@ -39,3 +40,12 @@ for (H, C) in shapes:
         us = e0.elapsed_time(e1) * 50
         out.append("%s %6.1f us %5.0f GB/s" % (name, us, P * C * bpe / us / 1e3))
     print("H=%-4d C=%-4d %6.1f MB | " % (H, C, P * C * 2 / 1e6) + " | ".join(out))
+    # yardstick: a plain device copy of the same tensor (read + write, 4 bytes per element)
+    for _ in range(3): y.copy_(x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): y.copy_(x)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 50
+    print("                         | copy_ %6.1f us %5.0f GB/s" % (us, P * C * 4 / us / 1e3))
