@@ -1280,6 +1280,36 @@ __global__ void k_add_inplace(T* __restrict__ dst, const T* __restrict__ src, si
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         stf<T>(dst, i, ldf<T>(dst, i) + ldf<T>(src, i));
 }
+// 8-element vectors (16-byte accesses), four per thread and trip with the loads first (the element-wise form above moved
+// 2.4 TB/s); both pointers 16-byte aligned
+template <typename T>
+__global__ void k_add_inplace_v16(T* __restrict__ dst, const T* __restrict__ src, size_t nvec) {
+    constexpr int VE = 8;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        float a[4][VE], b[4][VE];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            VecIO<T, VE>::load(dst, (i + u * stride) * VE, a[u]);
+            VecIO<T, VE>::load(src, (i + u * stride) * VE, b[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < VE; ++j) a[u][j] += b[u][j];
+            VecIO<T, VE>::store(dst, (i + u * stride) * VE, a[u]);
+        }
+    }
+    for (; i < nvec; i += stride) {
+        float a[VE], b[VE];
+        VecIO<T, VE>::load(dst, i * VE, a);
+        VecIO<T, VE>::load(src, i * VE, b);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) a[j] += b[j];
+        VecIO<T, VE>::store(dst, i * VE, a);
+    }
+}
 template <typename T>
 __global__ void k_channel_sum(const T* __restrict__ x, float* __restrict__ out, size_t npix, int C) {
     // block (c-chunk of 64 channels) x pixel slab; lanes along channels for coalescing
@@ -1707,6 +1737,18 @@ int phx_split2(const void* in, void* a, int Ca, void* b, int Cb, size_t npix, in
     return PHX_OK;
 }
 int phx_add_inplace(void* dst, const void* src, size_t n, int dt, void* stream) {
+    const size_t ve = 8;
+    if (n >= 4096 && n % ve == 0 && ((uintptr_t)dst | (uintptr_t)src) % 16 == 0) {
+        const size_t nvec = n / ve;
+        size_t blocks = (nvec + 256 * 4 - 1) / (256 * 4);           // four vectors per thread
+        if (blocks > 4096) blocks = 4096;
+        PHX_DT_SWITCH(dt, T, {
+            hipLaunchKernelGGL((k_add_inplace_v16<T>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (T*)dst,
+                               (const T*)src, nvec);
+        });
+        PHX_CHECK_LAUNCH();
+        return PHX_OK;
+    }
     PHX_DT_SWITCH(dt, T, {
         hipLaunchKernelGGL((k_add_inplace<T>), dim3(phx_grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (T*)dst,
                            (const T*)src, n);

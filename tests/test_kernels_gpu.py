@@ -698,6 +698,12 @@ def test_concat_split_add_cast_misc(L):
         cs = torch.zeros(Ca, dtype=torch.float32).cuda()
         L.channel_sum_accumulate(ad.data_ptr(), dt, cs.data_ptr(), 32, Ca, S())
         close(host(cs), host(ad).sum(axis=(0, 1, 2)), 1e-5, "channel_sum")
+    # the vectorised add (n >= 4096, multiple of 8): full trips of four vectors, a ragged tail, a grid capped at 4096 blocks
+    for (n, dt) in [(4096, BF16), (8 * 1000 + 8, F32), (8 * (4 * 256 * 5 + 37), BF16), (8 * 256 * 4 * 4100 + 8 * 3, BF16), (4100, F32)]:
+        a, b = torch.randn(n, device="cuda").to(tdt(dt)), torch.randn(n, device="cuda").to(tdt(dt))
+        want = (a.float() + b.float()).to(tdt(dt))
+        L.add_inplace(a.data_ptr(), b.data_ptr(), n, dt, S())
+        assert torch.equal(a, want), (n, dt)
     for (npix, C, dt) in [(64, 32, BF16), (1000, 192, BF16), (5000, 64, F32), (70000, 32, BF16), (333, 8, F32)]:
         a = RNG.standard_normal((npix, C))           # the 16-byte-load kernel (bias gradients of the group / instance norm nets)
         ad = dev(a, dt)
