@@ -580,19 +580,26 @@ static int norm_geometry(int P, int C, int V, int* PL, int* threads, int* chunk,
     *PL = 256 / CV;                              // (512 / 1024-thread blocks measured slower: the LDS reduction over PL lanes grows)
     *threads = CV * (*PL);
     int rows = (P + *PL - 1) / (*PL);
-    static int ppt_n = 0;
-    if (!ppt_n) { const char* e = getenv("PHX_NORM_PPT"); ppt_n = e ? atoi(e) : 16; }    // tuning hook: pixels per thread
-    int want = (rows + ppt_n - 1) / ppt_n;                    // (16 / floor 256 / cap 512: re-measured with the LDS-shared prologues, round 2)
-    static int fl = 0;
-    if (!fl) { const char* e = getenv("PHX_NORM_FLOOR"); fl = e ? atoi(e) : 256; }      // tuning hook (measured: tools/bench_norm.py)
+    // Every block ends in 2C same-address fp32 atomics (~45 ns each, serialised per address): the block count is a trade between
+    // streaming parallelism and that tail.  The backward reduction spreads its blocks over nrep accumulator replicas and takes
+    // more, shorter blocks (16 pixels per thread, 256..512 blocks); the forward statistics pass has one accumulator set -- 256
+    // blocks cost it 11 us of atomics on the H <= 16 levels -- and keeps 8 pixels per thread with a floor of 128 blocks.
+    static int ppt_r = 0, ppt_s = 0, fl_r = 0, fl_s = 0, capv = 0;
+    if (!ppt_r) {
+        const char* e = getenv("PHX_NORM_PPT"); ppt_r = e ? atoi(e) : 16;            // tuning hooks (tools/bench_norm.py)
+        e = getenv("PHX_NORM_FLOOR"); fl_r = e ? atoi(e) : 256;
+        e = getenv("PHX_NORM_CAP"); capv = e ? atoi(e) : 512;
+        e = getenv("PHX_STATS_PPT"); ppt_s = e ? atoi(e) : 8;
+        e = getenv("PHX_STATS_FLOOR"); fl_s = e ? atoi(e) : 128;
+    }
+    const int ppt_n = nrep > 1 ? ppt_r : ppt_s, fl = nrep > 1 ? fl_r : fl_s;
+    int want = (rows + ppt_n - 1) / ppt_n;
     // (the floor counts blocks of the whole launch: with per-sample statistics, NS > 1, every sample gets its share -- a
     // floor per SAMPLE cut the 128 x 128 group-norm layers into thousands of blocks of two pixels per thread: 62 us vs 19)
     const int fl_ns = (fl + (NS > 0 ? NS : 1) - 1) / (NS > 0 ? NS : 1);
     int floor_blocks = rows < fl_ns ? rows : fl_ns;
     if (want < floor_blocks) want = floor_blocks;
-    static int capv = 0;
-    if (!capv) { const char* e = getenv("PHX_NORM_CAP"); capv = e ? atoi(e) : 512; }     // tuning hook
-    int cap = (nrep > 1 ? capv : 2048) / (NS > 0 ? NS : 1);   // every block ends in 2C same-address atomics (see k_norm_bwd_reduce)
+    int cap = (nrep > 1 ? capv : 2048) / (NS > 0 ? NS : 1);
     if (cap < 1) cap = 1;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
@@ -600,7 +607,6 @@ static int norm_geometry(int P, int C, int V, int* PL, int* threads, int* chunk,
     *nchunks = (P + *chunk - 1) / (*chunk);
     return 0;
 }
-
 static int stream_geometry(int P, int C, int V, int* PL, int* threads, int* chunk, int* nchunks, int NS) {
     int CV = C / V;
     if (CV > 256) return -1;
