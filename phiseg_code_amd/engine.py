@@ -27,6 +27,7 @@ F32, BF16, U8 = rt.F32, rt.BF16, 2
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, U8: torch.uint8}
 _NP_DT = {F32: np.float32, U8: np.uint8}
 _ESIZE = {F32: 4, BF16: 2, U8: 1}
+_LIK_COARSE_FIRST = os.environ.get("PHX_LIK_COARSE_FIRST", "1") == "1"   # emission order of the likelihood's per-level chains
 _LIK_SIDE = os.environ.get("PHX_LIK_SIDE", "1") == "1"        # two lanes: the likelihood's per-level chains share the prior's lane
 _WGRAD_DEFER_BLOCKS = int(os.environ.get("PHX_WGRAD_DEFER_BLOCKS", "96"))  # pixel-tile split target of a deferred layer (0: as when it runs alone; measured 48..128)
 _NREP = int(os.environ.get("PHX_NREP", "8"))
@@ -435,7 +436,36 @@ class Plan:
                 continue
             want.add(op)
             stack.extend(i.op for i in op.inputs)
-        return [op for op in self.graph.ops if op in want]
+        ops = [op for op in self.graph.ops if op in want]
+        return self._coarse_first(ops) if _LIK_COARSE_FIRST else ops
+
+    @staticmethod
+    def _coarse_first(ops):
+        """The likelihood's per-level chains (z{i}_post_*, preups_{i}: independent of each other, created finest level first,
+        likelihoods.py:186-206) are emitted COARSEST level first: the top-down fusion path on the other lane starts at the coarsest
+        level and needs chain i only when it reaches level i, so it no longer waits for all five chains (0.9 ms with the 128 x 128
+        chain in front); the backward pass -- reverse emission order -- then reaches the chains in the order the top-down backward
+        releases their gradients (finest first).  Results do not depend on the order."""
+        import re
+        pat = re.compile(r"likelihood/(?:z(\d+)_post_|preups_(\d+)/)")
+        lvl = {}
+        for op in ops:
+            m = pat.match(op.name)
+            if m:
+                lvl[op] = int(m.group(1) or m.group(2))
+        if not lvl:
+            return ops
+        idx = [i for i, op in enumerate(ops) if op in lvl]
+        first, last = idx[0], idx[-1]
+        inner = ops[first:last + 1]
+        side = [op for op in inner if op in lvl]
+        rest = [op for op in inner if op not in lvl]           # (anything interleaved keeps its place after the chains' inputs)
+        chain_ops = set(side)
+        for op in rest:                                        # only safe if nothing in between consumes a chain
+            if any(i.op in chain_ops for i in op.inputs):
+                return ops
+        side.sort(key=lambda op: -lvl[op])                     # stable: a chain's own order is kept
+        return ops[:first] + rest + side + ops[last + 1:]
 
     def _build(self):
         ops = self._needed_ops()
