@@ -28,6 +28,7 @@ _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, U8: torch.uint8}
 _NP_DT = {F32: np.float32, U8: np.uint8}
 _ESIZE = {F32: 4, BF16: 2, U8: 1}
 _LIK_COARSE_FIRST = os.environ.get("PHX_LIK_COARSE_FIRST", "1") == "1"   # emission order of the likelihood's per-level chains
+XX
 _LIK_SIDE = os.environ.get("PHX_LIK_SIDE", "1") == "1"        # two lanes: the likelihood's per-level chains share the prior's lane
 _WGRAD_DEFER_BLOCKS = int(os.environ.get("PHX_WGRAD_DEFER_BLOCKS", "96"))  # pixel-tile split target of a deferred layer (0: as when it runs alone; measured 48..128)
 _NREP = int(os.environ.get("PHX_NREP", "8"))
@@ -390,7 +391,10 @@ class Plan:
             import re
             m = re.match(r"likelihood/(?:z(\d+)_post_|preups_(\d+)/)", name)
             if m:
-                return 1 if n == 2 else 2 + int(m.group(1) or m.group(2)) % (n - 2)
+                lvl = int(m.group(1) or m.group(2))
+                if n == 2:
+                    return 1 if lvl <= _LIK_SIDE_MAXLVL else 0
+                return 2 + lvl % (n - 2)
         return 0
 
     # ---------------------------------------------------------------------------------------------
