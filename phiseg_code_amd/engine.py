@@ -34,7 +34,7 @@ _LIK_COARSE_FIRST = os.environ.get("PHX_LIK_COARSE_FIRST", "1") == "1"   # emiss
 _LIK_SIDE_MAXLVL = int(os.environ.get("PHX_LIK_SIDE_MAXLVL", "3"))
 _LIK_SIDE = os.environ.get("PHX_LIK_SIDE", "1") == "1"        # two lanes: the likelihood's per-level chains share the prior's lane
 _WGRAD_DEFER_BLOCKS = int(os.environ.get("PHX_WGRAD_DEFER_BLOCKS", "96"))  # pixel-tile split target of a deferred layer (0: as when it runs alone; measured 48..128)
-_NREP = int(os.environ.get("PHX_NREP", "8"))
+_NREP = int(os.environ.get("PHX_NREP", "4"))      # accumulator replicas of the norm backward reduction (4: re-measured with the LDS-shared prologues; 8 before)
 _NORM_SMALL = os.environ.get("PHX_NORM_SMALL", "1") == "1"             # one-launch group / instance norm layers on maps <= 16 x 16 (A/B hook)
 _BIAS_GRAD_FUSED = os.environ.get("PHX_BIAS_GRAD_FUSED", "1") == "1"   # group / instance norm: conv-bias gradient in closed form (A/B hook)
 _NREP_MINP = int(os.environ.get("PHX_NREP_MINP", "4096"))
