@@ -27,11 +27,16 @@ F32, BF16, U8 = rt.F32, rt.BF16, 2
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, U8: torch.uint8}
 _NP_DT = {F32: np.float32, U8: np.uint8}
 _ESIZE = {F32: 4, BF16: 2, U8: 1}
+_KL_SIDE = os.environ.get("PHX_KL_SIDE", "0") == "1"                     # two lanes: KL launches on the prior lane (measured 2 % SLOWER: 12.17 vs 11.90 ms)
+_PRIOR_BW_FIRST = os.environ.get("PHX_PRIOR_BW_FIRST", "0") == "1"       # prior backward emitted before the likelihood's (A/B hook)
+_DEFER_EARLY = os.environ.get("PHX_DEFER_EARLY", "0") == "1"             # deferred launches of likelihood + prior on lane 1 beside the posterior backward (A/B hook)
 _LIK_COARSE_FIRST = os.environ.get("PHX_LIK_COARSE_FIRST", "1") == "1"   # emission order of the likelihood's per-level chains
 # two lanes: likelihood chains of levels <= this go to the prior's lane; the coarsest chain stays on lane 0, in front of the top-down
 # path that starts with it: lane 0 then enters the likelihood without waiting for lane 1 (with all five chains there it started only
 # when the LAST of them was done, whatever the order: 12.38 vs 11.95 ms)
 _LIK_SIDE_MAXLVL = int(os.environ.get("PHX_LIK_SIDE_MAXLVL", "3"))
+_LIK_SIDE_LEVELS = ({int(v) for v in os.environ["PHX_LIK_SIDE_LEVELS"].split(",") if v != ""}
+                    if "PHX_LIK_SIDE_LEVELS" in os.environ else None)       # explicit set of chain levels for lane 1 (experiments)
 _LIK_SIDE = os.environ.get("PHX_LIK_SIDE", "1") == "1"        # two lanes: the likelihood's per-level chains share the prior's lane
 _WGRAD_DEFER_BLOCKS = int(os.environ.get("PHX_WGRAD_DEFER_BLOCKS", "96"))  # pixel-tile split target of a deferred layer (0: as when it runs alone; measured 48..128)
 _NREP = int(os.environ.get("PHX_NREP", "4"))      # accumulator replicas of the norm backward reduction (4: re-measured with the LDS-shared prologues; 8 before)
@@ -390,12 +395,16 @@ class Plan:
         name = op.name
         if name.startswith("prior/"):
             return 1
+        if n == 2 and op.type == "kl" and _KL_SIDE:
+            return 1          # the KL terms need the posterior's and the prior's outputs only: off lane 0's likelihood -> loss chain
         if (n >= 3 or _LIK_SIDE) and name.startswith("likelihood/"):
             import re
             m = re.match(r"likelihood/(?:z(\d+)_post_|preups_(\d+)/)", name)
             if m:
                 lvl = int(m.group(1) or m.group(2))
                 if n == 2:
+                    if _LIK_SIDE_LEVELS is not None:
+                        return 1 if lvl in _LIK_SIDE_LEVELS else 0
                     return 1 if lvl <= _LIK_SIDE_MAXLVL else 0
                 return 2 + lvl % (n - 2)
         return 0
@@ -445,6 +454,26 @@ class Plan:
             stack.extend(i.op for i in op.inputs)
         ops = [op for op in self.graph.ops if op in want]
         return self._coarse_first(ops) if _LIK_COARSE_FIRST else ops
+
+    def _backward_order(self, ops, opset):
+        """Emission order of the backward pass: the reverse of the forward order, optionally (PHX_PRIOR_BW_FIRST=1) with the
+        prior's backward -- which depends on the KL terms only -- in front of the likelihood's instead of behind it."""
+        bw = list(reversed(ops))
+        if not _PRIOR_BW_FIRST:
+            return bw
+        prior = [op for op in bw if op.name.startswith("prior/")]
+        rest = [op for op in bw if not op.name.startswith("prior/")]
+        k = next((i for i, op in enumerate(rest) if op.name.startswith("likelihood/")), None)
+        if not prior or k is None:
+            return bw
+        new = rest[:k] + prior + rest[k:]
+        pos = {op: i for i, op in enumerate(new)}
+        for op in new:                                         # every consumer's backward must come first
+            for o in op.outputs:
+                for c in o.consumers:
+                    if c in opset and pos[c] > pos[op]:
+                        return bw
+        return new
 
     @staticmethod
     def _coarse_first(ops):
@@ -538,7 +567,17 @@ class Plan:
         if with_bw:
             # (Launching what the likelihood and the prior have deferred on the prior's lane as soon as their backward is
             # done, beside the posterior's backward chain, was measured 7 % slower than one batch after the join.)
-            for op in reversed(ops):
+            bw_ops = self._backward_order(ops, opset)
+            flushed = not (_DEFER_EARLY and nl > 1)
+            for op in bw_ops:
+                if not flushed and op.name.startswith("posterior/"):
+                    # everything the likelihood and the prior have deferred goes to lane 1 now, beside the posterior's
+                    # latency-bound backward chain on lane 0 (their inputs are complete once lane 0 has reached this point)
+                    flushed = True
+                    ev0 = self._record(0)
+                    self._lane = 1
+                    self._wait(ev0)
+                    self._emit_deferred()
                 if any(o in self.grad for o in op.outputs) or op.type in ("residual_ce", "kl", "l2_weights"):
                     self._lane = self.op_lane[op]
                     self._cur_bw_op = op
