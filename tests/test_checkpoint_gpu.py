@@ -91,7 +91,8 @@ def test_resume_continues_the_same_trajectory(tmp_path):
     for k in pa:
         # (Adam moves a weight by ~lr per step whatever the gradient's size: an element whose tiny gradient changes sign with
         # the summation order may differ by 2 lr between two identical runs)
-        np.testing.assert_allclose(pc[k], pa[k], rtol=0, atol=4e-5 + 1e-5 * np.abs(pa[k]).max(), err_msg=k)
+        # (two independent runs of four steps each: worst case 4 steps x 2 lr = 8e-5; 4.8e-5 observed)
+        np.testing.assert_allclose(pc[k], pa[k], rtol=0, atol=8.5e-5 + 1e-5 * np.abs(pa[k]).max(), err_msg=k)
         # the UPDATE of the two resumed steps equals the straight run's (a reset optimiser would move every weight by
         # lr * sign(g) instead of lr * m_hat / sqrt(v_hat): relative error ~1)
         da, dc = (pa[k] - pmid[k]).ravel().astype(np.float64), (pc[k] - pmid[k]).ravel().astype(np.float64)
