@@ -99,6 +99,12 @@ size_t phx_conv3x3_mfma_ws_bytes(int B, int H, int W, int K, int N);
 int phx_conv3x3_mfma_ksplit(int B, int H, int W, int K, int N);
 int phx_conv3x3_mfma_bf16_ws(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
                              void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream);
+/* The same launch with its output statistics ADDED ATOMICALLY into sums[N][2] = {sum y, sum y^2} (zeroed by the caller; the
+ * layout phx_norm_apply_fused takes, pivot = NULL) instead of per-tile partial sums: for layers with at most 64 pixel tiles (the
+ * H <= 16 levels at batch 64), where neither a reduction launch nor a statistics pass over y pays.  Not in deterministic mode. */
+int phx_conv3x3_mfma_stats_atomic_supported(int B, int H, int W, int K, int N);
+int phx_conv3x3_mfma_bf16_stats_atomic(const void* x, const void* wpk, void* y, const float* bias, int act, float* sums, int B,
+                                       int H, int W, int K, int N, void* stream);
 /* Convolution with an AFFINE epilogue: y = act(conv(x) * scale[n] + shift[n]) -- inference-mode batch norm
  * (normalisation.py:145-163 with is_training = False: y = gamma (x - moving_mean) / sqrt(moving_var + eps) + beta) and its
  * activation folded into the convolution that feeds it: one launch where the reference runs conv2d, batch_norm and relu.

@@ -266,7 +266,7 @@ struct BwdStats {
     const unsigned short* y;
     const float *scale, *shift, *mean, *rstd;
     float* part;
-    int act, _pad;
+    int act, stats_atomic;    // stats_atomic: stats_partial is the accumulator sums[N][2] itself, added to atomically
     const float* oscale;      // per-output-channel scale of the bias / activation epilogue (inference-mode batch norm folded in)
 };
 
@@ -658,7 +658,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
                 float v = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) v += red[(w * 2 + which) * BN + n];
-                stats_partial[((size_t)tile_id * 2 + which) * N + n0 + n] = v;
+                if (bws.stats_atomic) atomicAdd(&stats_partial[(size_t)(n0 + n) * 2 + which], v);
+                else stats_partial[((size_t)tile_id * 2 + which) * N + n0 + n] = v;
             }
         }
     }
@@ -2425,6 +2426,25 @@ int phx_conv3x3_mfma_bf16_ws(const void* x, const void* wpk, void* y, const floa
     return conv3x3_mfma_impl(x, wpk, y, bias, act, stats_partial, workspace, workspace_bytes, B, H, W, K, N, BwdStats{}, stream);
 }
 
+// statistics added atomically into sums[N][2] (the layout phx_norm_apply_fused reads): for launches with few pixel tiles (the
+// H <= 16 levels), where a same-address atomic per tile and channel (~45 ns each) is cheaper than a reduction launch or a pass of
+// its own over y.  Generic 256-pixel-tile kernel only.
+static bool fwd_stats_atomic_ok(int B, int H, int W, int K, int N) {
+    if (phx_deterministic() || K % KC != 0 || N % 32 != 0) return false;
+    if (phx_pp_eligible(B, H, W, K, N) || fwd_ws64(B, H, W, K, N) || fwd_dma_bn(B, H, W, K, N) || fwd_rs_bn(B, H, W, K, N) ||
+        fwd_big_tiles(B, H, W, K, N)) return false;
+    return phx_conv3x3_mfma_bf16_tiles(B, H, W, K, N) <= 64;
+}
+int phx_conv3x3_mfma_stats_atomic_supported(int B, int H, int W, int K, int N) { return fwd_stats_atomic_ok(B, H, W, K, N) ? 1 : 0; }
+int phx_conv3x3_mfma_bf16_stats_atomic(const void* x, const void* wpk, void* y, const float* bias, int act, float* sums, int B,
+                                       int H, int W, int K, int N, void* stream) {
+    PHX_REQUIRE(fwd_stats_atomic_ok(B, H, W, K, N), PHX_E_SHAPE, "conv3x3_mfma_stats_atomic: shape not supported (see ..._supported)");
+    PHX_REQUIRE(sums != nullptr, PHX_E_INVAL, "conv3x3_mfma_stats_atomic: sums is required");
+    BwdStats b{};
+    b.stats_atomic = 1;
+    return conv3x3_mfma_impl(x, wpk, y, bias, act, sums, nullptr, 0, B, H, W, K, N, b, stream);
+}
+
 int phx_conv3x3_mfma_bf16_affine(const void* x, const void* wpk, void* y, const float* scale, const float* shift, int act,
                                  void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream) {
     PHX_REQUIRE(scale != nullptr && shift != nullptr, PHX_E_INVAL, "conv3x3_mfma_affine: scale and shift are required");
@@ -2442,7 +2462,7 @@ int phx_conv3x3_mfma_bf16_bwdstats(const void* dy, const void* wpk_dgrad, void* 
     PHX_REQUIRE(y_prod && scale && shift && mean && rstd && stats2_partial, PHX_E_INVAL, "conv3x3_mfma_bwdstats: null argument");
     BwdStats b{};
     b.y = (const unsigned short*)y_prod; b.scale = scale; b.shift = shift; b.mean = mean; b.rstd = rstd;
-    b.part = stats2_partial; b.act = act_prod; b._pad = 0;
+    b.part = stats2_partial; b.act = act_prod; b.stats_atomic = 0;
     return conv3x3_mfma_impl(dy, wpk_dgrad, dA, nullptr, PHX_ACT_ID, nullptr, nullptr, 0, B, H, W, K, N, b, stream);
 }
 

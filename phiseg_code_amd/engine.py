@@ -27,6 +27,7 @@ F32, BF16, U8 = rt.F32, rt.BF16, 2
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, U8: torch.uint8}
 _NP_DT = {F32: np.float32, U8: np.uint8}
 _ESIZE = {F32: 4, BF16: 2, U8: 1}
+_STATS_ATOMIC = os.environ.get("PHX_STATS_ATOMIC", "1") == "1"           # small-map batch norm: statistics by atomics from the conv epilogue (A/B hook)
 _KL_SIDE = os.environ.get("PHX_KL_SIDE", "0") == "1"                     # two lanes: KL launches on the prior lane (measured 2 % SLOWER: 12.17 vs 11.90 ms)
 _PRIOR_BW_FIRST = os.environ.get("PHX_PRIOR_BW_FIRST", "0") == "1"       # prior backward emitted before the likelihood's (A/B hook)
 _DEFER_EARLY = os.environ.get("PHX_DEFER_EARLY", "0") == "1"             # deferred launches of likelihood + prior on lane 1 beside the posterior backward (A/B hook)
@@ -908,6 +909,11 @@ class Plan:
                 part = self._alloc((ntile * 2 * cout,), F32)
                 conv_into(y, 0, stats_part=part)
                 self._emit(Lb.norm_reduce_partials, part.ptr, ntile, cout, sums.ptr, S)
+            elif (norm == "batch" and mfma and small and _STATS_ATOMIC and not _DETERMINISTIC and not head1x1 and self.act_dt == BF16
+                  and Lb.conv3x3_mfma_stats_atomic_supported(B, H, Wd, cin_eff, cout)):
+                # few pixel tiles (the H <= 16 levels): the convolution adds its statistics straight into `sums` -- no pass over y
+                self._emit(Lb.conv3x3_mfma_bf16_stats_atomic, x.ptr, wf.ptr, y.ptr, bptr, 0, sums.ptr, B, H, Wd, cin_eff, cout, S,
+                           tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
             elif norm == "batch" and not small and not _DETERMINISTIC:
                 conv_into(y, 0, stats_direct=sums)        # (direct kernels add their tiles' sums atomically)
             else:

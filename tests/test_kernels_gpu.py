@@ -256,6 +256,35 @@ def test_dgrad_with_fused_bn_backward_statistics(L, case, monkeypatch):
 
 
 # wave-specialised variant: 8 MFMA waves + 2 DMA loader waves, 512 pixels x 64 channels per block (k_conv3x3_fwd_ws64)
+@pytest.mark.parametrize("case", [(64, 8, 8, 192, 192), (64, 16, 16, 64, 96), (3, 8, 8, 32, 32), (9, 4, 4, 64, 64), (64, 16, 16, 384, 192)])
+def test_conv3x3_mfma_statistics_by_atomics(L, case):
+    """phx_conv3x3_mfma_bf16_stats_atomic: the convolution of a layer with few pixel tiles adds {sum y, sum y^2} of its (bf16-rounded)
+    output straight into sums[N][2], the accumulator phx_norm_apply_fused reads -- the batch-norm layers of the H <= 16 levels then
+    need neither a statistics pass over y nor a reduction launch."""
+    B, H, W, K, N = case
+    assert L.conv3x3_mfma_stats_atomic_supported(B, H, W, K, N) == 1
+    assert L.conv3x3_mfma_stats_atomic_supported(64, 128, 128, 32, 32) == 0          # thousands of tiles: partial sums + reduction
+    x = RNG.standard_normal((B, H, W, K))
+    w = RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K)
+    xd, wd = dev(x, BF16), dev(w)
+    wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    wg = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    L.pack_conv3x3_bf16(wd.data_ptr(), wf.data_ptr(), wg.data_ptr(), K, N, S())
+    y0 = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
+    L.conv3x3_mfma_bf16_ws(xd.data_ptr(), wf.data_ptr(), y0.data_ptr(), None, 0, None, None, 0, B, H, W, K, N, S())
+    y = torch.empty_like(y0)
+    sums = torch.full((N, 2), 0.5, dtype=torch.float32).cuda()                        # accumulated (+=)
+    L.conv3x3_mfma_bf16_stats_atomic(xd.data_ptr(), wf.data_ptr(), y.data_ptr(), None, 0, sums.data_ptr(), B, H, W, K, N, S())
+    assert torch.equal(y, y0)
+    yf = host(y).reshape(-1, N).astype(np.float64)
+    got = host(sums) - 0.5
+    close(got[:, 0], yf.sum(0), 2e-5, "sum y")
+    close(got[:, 1], (yf ** 2).sum(0), 2e-5, "sum y^2")
+    from phiseg_code_amd.runtime import PhxError
+    with pytest.raises(PhxError):
+        L.conv3x3_mfma_bf16_stats_atomic(xd.data_ptr(), wf.data_ptr(), y.data_ptr(), None, 0, None, B, H, W, K, N, S())
+
+
 @pytest.mark.parametrize("case", [(2, 16, 32, 32, 128), (1, 32, 64, 96, 64), (3, 16, 32, 32, 192), (1, 48, 32, 64, 256),
                                   (1, 16, 64, 160, 128)])
 def test_conv3x3_mfma_wave_specialised(L, case, monkeypatch):
