@@ -53,8 +53,23 @@ class DistContext:
                 dist.broadcast(idt, src=0)
                 raw = bytes(idt.cpu().numpy().tobytes())
                 comm = ctypes.c_void_p()
-                L.comm_init(ctypes.byref(comm), self.world, self.rank, raw)
-                self._comm = (L, comm)
+                ok, err = 1, ""
+                try:
+                    L.comm_init(ctypes.byref(comm), self.world, self.rank, raw)
+                except rt.PhxError as e:           # (e.g. an RCCL build the dlopen'd entry points do not match)
+                    ok, err = 0, str(e)
+                # every rank must take the same path: if ANY rank failed, all fall back to torch.distributed's RCCL collectives
+                # (same exchange, issued through torch instead of phx_comm_*) -- loudly, it is still the HIP extension that computes
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 1:
+                    self._comm = (L, comm)
+                else:
+                    import sys
+                    if ok:
+                        L.comm_destroy(comm)
+                    print("[phiseg_code_amd.distributed] rank %d: phx_comm_init unavailable (%s); gradient exchange through "
+                          "torch.distributed (RCCL) instead" % (self.rank, err or "failed on another rank"), file=sys.stderr)
         return self._comm
 
     def allreduce_sum(self, tensor, plan=None, bucket_elems=8 << 20):
