@@ -359,6 +359,31 @@ int phx_tconv2d_dgrad(const void* dy, int dy_dt, const float* w_hwoi, void* dx, 
 int phx_tconv2d_wgrad(const void* x, int x_dt, const void* dy, int dy_dt, float* dw_hwoi, int B, int H, int W, int Cin, int Cout,
                       int kh, int kw, int sh, int sw, void* stream);
 
+/* ---- layers of tfwrapper/layers.py without a call site in the shipped experiments (csrc/gconv.hip; plain direct kernels) ----
+ * General 2-D convolution, SAME padding, stride (sh, sw) and dilation (dh, dw), NHWC, HWIO fp32 filter [kh][kw][Cin][Cout]:
+ * conv2D(strides=...) (layers.py:94-145) and dilated_conv2D = tf.nn.atrous_conv2d (layers.py:378-425).  Output size
+ * ceil(H / sh) x ceil(W / sw) (phx_gconv2d_out_size); dgrad writes dx [B,H,W,Cin]; wgrad ACCUMULATES into dw_hwio. */
+int phx_gconv2d_out_size(int H, int W, int sh, int sw, int* Ho, int* Wo);
+int phx_gconv2d_fwd(const void* x, int x_dt, const float* w_hwio, const float* bias, void* y, int y_dt, int B, int H, int W,
+                    int Cin, int Cout, int kh, int kw, int sh, int sw, int dh, int dw, int act, void* stream);
+int phx_gconv2d_dgrad(const void* dy, int dy_dt, const float* w_hwio, void* dx, int dx_dt, int B, int H, int W, int Cin, int Cout,
+                      int kh, int kw, int sh, int sw, int dh, int dw, void* stream);
+int phx_gconv2d_wgrad(const void* x, int x_dt, const void* dy, int dy_dt, float* dw_hwio, int B, int H, int W, int Cin, int Cout,
+                      int kh, int kw, int sh, int sw, int dh, int dw, void* stream);
+/* maxpool2D (layers.py:18-28): tf.nn.max_pool 2x2 / stride 2 / SAME, y [B, ceil(H/2), ceil(W/2), C]; the gradient goes to the
+ * first (row-major) maximum of each window */
+int phx_maxpool2x2_fwd(const void* x, int dt, void* y, int B, int H, int W, int C, void* stream);
+int phx_maxpool2x2_bwd(const void* x, const void* dy, int dt, void* dx, int B, int H, int W, int C, void* stream);
+/* dst[b, y, x, :] = src[b, y + off_y, x + off_x, :] inside the source, 0 outside: pad_to_size (layers.py:625-650, negative
+ * offsets) and the centre crop of crop_and_concat (layers.py:586-622, positive offsets); the gradient is the same call with the
+ * sizes swapped and the offsets negated */
+int phx_spatial_window(const void* src, void* dst, int dt, int B, int Hs, int Ws, int Hd, int Wd, int C, int off_y, int off_x,
+                       void* stream);
+/* dropout (layers.py:653-668, tf.nn.dropout): y = x * keep / keep_prob with keep[b][e] = (u < keep_prob), u the 24-bit uniform of
+ * word e % 4 of Philox block e / 4 under (seed, *step_dev, stream_id, sample_offset + b); the backward pass is the same call on dy */
+int phx_dropout(const void* x, void* y, int dt, size_t per_sample, int B, float keep_prob, uint64_t seed, const int32_t* step_dev,
+                int stream_id, int sample_offset, void* stream);
+
 /* ---- mini-batch producer on the device ---------------------------------------------------
  * Replaces data/batch_provider.py:43-67 (next_batch), 131-137 (_select_random_label) and 140-272 (_augmentation_function with
  * the cv2 helpers of utils.py:18-38) for a data set resident in HBM: images [N][X][Y] f32, labels [N][X][Y][A] u8 (A annotators).

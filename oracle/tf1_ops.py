@@ -197,3 +197,62 @@ def conv2d_transpose_same(x, w_hwoi, stride):
     pt, pl = th // 2, tw // 2
     full = F.pad(full, (0, max(0, pl + Wo - full.shape[3]), 0, max(0, pt + Ho - full.shape[2])))
     return full[:, :, pt:pt + Ho, pl:pl + Wo].permute(0, 2, 3, 1)
+
+
+# --------------------------------------------------------------------------------------------
+# (f)4  layers without a call site in the shipped experiments
+def conv2d_general_same(x, w_hwio, stride=(1, 1), dilation=(1, 1)):
+    """[TF1.12] tf.nn.conv2d(x, W, [1, sh, sw, 1], 'SAME') (conv2D with strides, tfwrapper/layers.py:123) and
+    tf.nn.atrous_conv2d(x, W, rate, 'SAME') (dilated_conv2D, layers.py:404): output ceil(H / s); with the effective kernel extent
+    ke = (k - 1) d + 1 the total padding is max((Ho - 1) s + ke - H, 0), the smaller half in front."""
+    kh, kw = int(w_hwio.shape[0]), int(w_hwio.shape[1])
+    (sh, sw), (dh, dw) = stride, dilation
+    B, H, W, _ = x.shape
+    Ho, Wo = -(-H // sh), -(-W // sw)
+    th = max((Ho - 1) * sh + (kh - 1) * dh + 1 - H, 0)
+    tw = max((Wo - 1) * sw + (kw - 1) * dw + 1 - W, 0)
+    xp = F.pad(x.permute(0, 3, 1, 2), (tw // 2, tw - tw // 2, th // 2, th - th // 2))
+    y = F.conv2d(xp, w_hwio.permute(3, 2, 0, 1), stride=(sh, sw), dilation=(dh, dw))
+    return y.permute(0, 2, 3, 1)
+
+
+def max_pool_2x2_same(x):
+    """[TF1.12] tf.nn.max_pool(x, [1,2,2,1], [1,2,2,1], 'SAME') (maxpool2D, layers.py:18-28): odd sizes are padded at the bottom /
+    right and the padding never wins (-inf); the gradient goes to the first maximum of a window (row-major), as in TF's and
+    torch's kernels."""
+    n, h, w, c = x.shape
+    xp = F.pad(x.permute(0, 3, 1, 2), (0, w % 2, 0, h % 2), value=float("-inf"))
+    return F.max_pool2d(xp, 2, 2).permute(0, 2, 3, 1)
+
+
+def spatial_window(x, out_h, out_w, off_y, off_x):
+    """dst[b, y, x] = src[b, y + off_y, x + off_x] or 0: pad_to_size (layers.py:625-650: off = -(size_diff // 2)) and the centre
+    crop of crop_and_concat (layers.py:586-622: off = (larger - output) // 2)."""
+    B, H, W, C = x.shape
+    out = torch.zeros(B, out_h, out_w, C, dtype=x.dtype)
+    ys = [y for y in range(out_h) if 0 <= y + off_y < H]
+    xs = [xx for xx in range(out_w) if 0 <= xx + off_x < W]
+    if ys and xs:
+        out[:, ys[0]:ys[-1] + 1, xs[0]:xs[-1] + 1] = x[:, ys[0] + off_y:ys[-1] + off_y + 1, xs[0] + off_x:xs[-1] + off_x + 1]
+    return out
+
+
+def dropout_keep_mask(shape, keep_prob, seed, step, stream, sample_offset=0):
+    """Keep mask of the build's dropout contract (tf.nn.dropout itself is unseeded in the reference): element e of
+    sample b keeps iff the 24-bit uniform (word e % 4 of Philox block e // 4 under (seed, step, stream, sample_offset + b)) >> 8
+    / 2^24 is below keep_prob."""
+    import numpy as np
+    from oracle import philox
+    B, per = int(shape[0]), int(np.prod(shape[1:]))
+    nblk = (per + 3) // 4
+    out = np.zeros((B, nblk * 4), dtype=bool)
+    for b in range(B):
+        ctr = np.zeros((nblk, 4), dtype=np.uint32)
+        ctr[:, 0] = np.arange(nblk)
+        ctr[:, 1] = sample_offset + b
+        ctr[:, 2] = stream
+        ctr[:, 3] = step
+        words = philox.philox4x32_10(ctr, np.array([seed & 0xffffffff, (seed >> 32) & 0xffffffff], dtype=np.uint32))
+        u = (words >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+        out[b] = (u < np.float32(keep_prob)).reshape(-1)
+    return out[:, :per].reshape(shape)
