@@ -714,27 +714,36 @@ class Plan:
         a = op.attrs
         x = self.val[op.inputs[0]]
         W, b = a["W"], a["b"]
-        kh, kw, sh, sw = a["transposed"]
-        cout, cin = W.shape[2], W.shape[3]
         B, H, Wd = x.shape[0], x.shape[1], x.shape[2]
+        S, Lb = self.stream, self.L
+        if a.get("general") is not None:
+            # strided / dilated SAME convolution on the direct kernels of gconv.hip (conv2D with strides, dilated_conv2D,
+            # dense_layer as a 1x1 convolution of the flattened input); filter HWIO (a dense layer's [F, U] is [1][1][F][U])
+            geo = (B, H, Wd, W.shape[-2], W.shape[-1]) + tuple(a["general"])
+            cin, cout = W.shape[-2], W.shape[-1]
+            conv_fwd = Lb.gconv2d_fwd
+        else:
+            kh, kw, sh, sw = a["transposed"]
+            cout, cin = W.shape[2], W.shape[3]
+            geo = (B, H, Wd, cin, cout, kh, kw, sh, sw)
+            conv_fwd = Lb.tconv2d_fwd
         out = self._alloc_like(op.outputs[0])
         self.val[op.outputs[0]] = out
         Ho, Wo = out.shape[1], out.shape[2]
         act = rt.ACT_CODES[a["act"]]
         norm = a["norm"]
         training = a["training"] if isinstance(a["training"], bool) else self.training
-        S, Lb = self.stream, self.L
         wptr, bptr = self.store.ptr(W), (self.store.ptr(b) if b is not None else None)
-        st = dict(x=x, out=out, mfma=False, norm=norm, padded=False, cin_eff=cin, k1=False, head1x1=False, transposed=a["transposed"])
-        geo = (B, H, Wd, cin, cout, kh, kw, sh, sw)
+        st = dict(x=x, out=out, mfma=False, norm=norm, padded=False, cin_eff=cin, k1=False, head1x1=False,
+                  transposed=a.get("transposed"), general=a.get("general"), geo=geo)
         if norm is None:
-            self._emit(Lb.tconv2d_fwd, x.ptr, x.dt, wptr, bptr, out.ptr, out.dt, *geo, act, S)
+            self._emit(conv_fwd, x.ptr, x.dt, wptr, bptr, out.ptr, out.dt, *geo, act, S)
             self.saved[op] = st
             return
         nv = a["norm_vars"]
         gptr, beptr = self.store.ptr(nv["gamma"]), self.store.ptr(nv["beta"])
         y = self._alloc(out.shape, out.dt)
-        self._emit(Lb.tconv2d_fwd, x.ptr, x.dt, wptr, bptr, y.ptr, y.dt, *geo, 0, S)
+        self._emit(conv_fwd, x.ptr, x.dt, wptr, bptr, y.ptr, y.dt, *geo, 0, S)
         if norm == "batch":
             NS, P, Gn = 1, B * Ho * Wo, cout
         else:
@@ -761,7 +770,7 @@ class Plan:
 
     def _fw_conv_unit(self, op, bw):
         a = op.attrs
-        if a.get("transposed") is not None:
+        if a.get("transposed") is not None or a.get("general") is not None:
             return self._fw_tconv_unit(op, bw)
         x = self.val[op.inputs[0]]
         W, b = a["W"], a["b"]
@@ -931,6 +940,38 @@ class Plan:
         if norm != "batch":
             st.update(fsums=sums, fpivot=pivot)          # forward per-channel sums: the bias gradient is closed-form from them
         self.saved[op] = st
+
+    def _fw_maxpool(self, op, bw):
+        x = self.val[op.inputs[0]]
+        out = self._alloc(self._cshape(op.outputs[0]), x.dt)
+        self.val[op.outputs[0]] = out
+        self._emit(self.L.maxpool2x2_fwd, x.ptr, x.dt, out.ptr, x.shape[0], x.shape[1], x.shape[2], x.shape[3], self.stream)
+
+    def _fw_spatial_window(self, op, bw):
+        x = self.val[op.inputs[0]]
+        out = self._alloc(self._cshape(op.outputs[0]), x.dt)
+        self.val[op.outputs[0]] = out
+        oy, ox = op.attrs["off"]
+        self._emit(self.L.spatial_window, x.ptr, out.ptr, x.dt, x.shape[0], x.shape[1], x.shape[2], out.shape[1], out.shape[2],
+                   x.shape[3], oy, ox, self.stream)
+
+    def _dropout_on(self, op):
+        tr = op.attrs["training"]
+        return (tr if isinstance(tr, bool) else self.training) and op.attrs["keep_prob"] < 1.0
+
+    def _fw_dropout(self, op, bw):
+        x = self.val[op.inputs[0]]
+        if not self._dropout_on(op):
+            self.val[op.outputs[0]] = x                      # inference: identity (layers.py:659-661)
+            return
+        out = self._alloc(x.shape, x.dt)
+        self.val[op.outputs[0]] = out
+        self._emit(self.L.dropout, x.ptr, out.ptr, x.dt, x.n // x.shape[0], x.shape[0], op.attrs["keep_prob"], self.rng_seed,
+                   self._noise_step_ptr(), op.attrs["stream"], self.sample_offset, self.stream)
+
+    def _fw_flatten(self, op, bw):
+        x = self.val[op.inputs[0]]
+        self.val[op.outputs[0]] = Buf(self._cshape(op.outputs[0]), x.dt, like=x.t)      # same memory, new shape
 
     def _fw_avgpool(self, op, bw):
         x = self.val[op.inputs[0]]
@@ -1144,6 +1185,31 @@ class Plan:
             if g is not None:
                 self._add_grad(t, buf=self._as_dt(g, self.val[t].dt))
 
+    def _bw_maxpool(self, op):
+        x, d = self.val[op.inputs[0]], self.grad[op.outputs[0]]
+        self._add_grad(op.inputs[0], write_fn=lambda g: self._emit(
+            self.L.maxpool2x2_bwd, x.ptr, d.ptr, d.dt, g.ptr, x.shape[0], x.shape[1], x.shape[2], x.shape[3], self.stream))
+
+    def _bw_spatial_window(self, op):
+        x, d = self.val[op.inputs[0]], self.grad[op.outputs[0]]
+        oy, ox = op.attrs["off"]
+        self._add_grad(op.inputs[0], write_fn=lambda g: self._emit(
+            self.L.spatial_window, d.ptr, g.ptr, d.dt, x.shape[0], d.shape[1], d.shape[2], x.shape[1], x.shape[2], x.shape[3],
+            -oy, -ox, self.stream))
+
+    def _bw_dropout(self, op):
+        d = self.grad[op.outputs[0]]
+        if not self._dropout_on(op):
+            self._add_grad(op.inputs[0], buf=d)
+            return
+        self._add_grad(op.inputs[0], write_fn=lambda g: self._emit(
+            self.L.dropout, d.ptr, g.ptr, d.dt, d.n // d.shape[0], d.shape[0], op.attrs["keep_prob"], self.rng_seed,
+            self._noise_step_ptr(), op.attrs["stream"], self.sample_offset, self.stream))
+
+    def _bw_flatten(self, op):
+        x, d = self.val[op.inputs[0]], self.grad[op.outputs[0]]
+        self._add_grad(op.inputs[0], buf=Buf(x.shape, d.dt, like=d.t))
+
     def _bw_avgpool(self, op):
         x, d = self.val[op.inputs[0]], self.grad[op.outputs[0]]
         self._add_grad(op.inputs[0], write_fn=lambda g: self._emit(
@@ -1170,7 +1236,7 @@ class Plan:
         dA = self.grad[op.outputs[0]]
         x, out = sv["x"], sv["out"]
         W, b = a["W"], a["b"]
-        k, (_, _, cin, cout) = a["ksize"], W.shape
+        k, cin, cout = a["ksize"], W.shape[-2], W.shape[-1]
         if sv.get("transposed") is not None:
             cout, cin = W.shape[2], W.shape[3]
         B, H, Wd = x.shape[0], x.shape[1], x.shape[2]
@@ -1231,6 +1297,16 @@ class Plan:
             dY = dA
         dw = self.store.grad_ptr(W)
         db = self.store.grad_ptr(b) if (b is not None and not db_done) else None
+        if sv.get("general") is not None:
+            geo = sv["geo"]
+            self._emit(Lb.gconv2d_wgrad, x.ptr, x.dt, dY.ptr, dY.dt, dw, *geo, S)
+            if db is not None:
+                self._emit(Lb.channel_sum_accumulate, dY.ptr, dY.dt, db, dY.n // cout, cout, S)
+            xin = op.inputs[0]
+            if self.req.get(xin, False):
+                self._add_grad(xin, write_fn=lambda g: self._emit(Lb.gconv2d_dgrad, dY.ptr, dY.dt, self.store.ptr(W), g.ptr, g.dt,
+                                                                   *geo, S))
+            return
         if sv.get("transposed") is not None:
             kh, kw, sh, sw = sv["transposed"]
             geo = (B, H, Wd, cin, cout, kh, kw, sh, sw)

@@ -219,16 +219,22 @@ def random_normal(like, stream):
     return get_default_graph().add_op("random_normal", [like], dict(stream=int(stream)), [(like.shape, KIND_F32)])[0]
 
 
-def conv_unit(x, W, b, ksize, norm, norm_vars, act, training, num_groups=None, head=False, name="conv", transposed=None):
+def conv_unit(x, W, b, ksize, norm, norm_vars, act, training, num_groups=None, head=False, name="conv", transposed=None,
+              general=None):
     """conv (SAME, stride 1) -> [+bias] -> [norm] -> act as ONE node (tfwrapper/layers.py:122-135).
     transposed = (kh, kw, sh, sw): tf.nn.conv2d_transpose instead (layers.py:197-258), W is [kh, kw, Cout, Cin] and the output
-    is sh x sw times larger."""
+    is sh x sw times larger.  general = (kh, kw, sh, sw, dh, dw): strided / dilated SAME convolution (conv2D with strides,
+    dilated_conv2D, dense_layer as a 1x1 convolution of the flattened input) on the direct kernels of csrc/gconv.hip; the
+    output is ceil(H / sh) x ceil(W / sw)."""
     kind = KIND_F32 if head else KIND_ACT
     attrs = dict(W=W, b=b, ksize=int(ksize), norm=norm, norm_vars=norm_vars, act=act, training=training,
-                 num_groups=num_groups, head=head, transposed=transposed)
+                 num_groups=num_groups, head=head, transposed=transposed, general=general)
     if transposed is not None:
         kh, kw, sh, sw = transposed
         shape = (x.shape[0], x.shape[1] * sh, x.shape[2] * sw, W.shape[2])
+    elif general is not None:
+        sh, sw = general[2], general[3]
+        shape = (x.shape[0], -(-x.shape[1] // sh), -(-x.shape[2] // sw), W.shape[-1])
     else:
         shape = x.shape[:3] + (W.shape[3],)
     return get_default_graph().add_op("conv_unit", [x], attrs, [(shape, kind)], name=name)[0]
@@ -237,6 +243,38 @@ def conv_unit(x, W, b, ksize, norm, norm_vars, act, training, num_groups=None, h
 def avg_pool2x2(x):
     n, h, w, c = x.shape
     return get_default_graph().add_op("avgpool", [x], {}, [((n, (h + 1) // 2, (w + 1) // 2, c), x.kind)])[0]
+
+
+def max_pool2x2(x):
+    """tf.nn.max_pool 2x2 / stride 2 / SAME (tfwrapper/layers.py:18-28)."""
+    n, h, w, c = x.shape
+    return get_default_graph().add_op("maxpool", [x], {}, [((n, (h + 1) // 2, (w + 1) // 2, c), x.kind)])[0]
+
+
+def spatial_window(x, out_h, out_w, off_y, off_x, name="window"):
+    """out[b, y, x] = x[b, y + off_y, x + off_x] inside x, 0 outside: zero padding (pad_to_size, layers.py:625-650) for negative
+    offsets, centre crop (crop_and_concat, layers.py:586-622) for positive ones."""
+    n, h, w, c = x.shape
+    return get_default_graph().add_op("spatial_window", [x], dict(off=(int(off_y), int(off_x))),
+                                      [((n, int(out_h), int(out_w), c), x.kind)], name=name)[0]
+
+
+def dropout(x, keep_prob, training, name="dropout"):
+    """tf.nn.dropout(x, keep_prob) in training mode, identity otherwise (layers.py:653-668); the keep mask follows the Philox
+    contract with stream id crc32(op name) (oracle.tf1_ops.dropout_keep_mask)."""
+    import zlib
+    out = get_default_graph().add_op("dropout", [x], dict(keep_prob=float(keep_prob), training=training), [(x.shape, x.kind)],
+                                     name=name)[0]
+    out.op.attrs["stream"] = zlib.crc32(out.op.name.encode()) & 0x3FFFFFFF
+    return out
+
+
+def flatten(x):
+    """tfwrapper/utils.py:16-22 flatten: [B, ...] -> [B, 1, 1, prod(...)] (NHWC memory order kept: a view, no launch); the
+    extra unit axes keep every tensor of the engine four-dimensional."""
+    n = x.shape[0]
+    f = int(np.prod(x.shape[1:]))
+    return get_default_graph().add_op("flatten", [x], {}, [((n, 1, 1, f), x.kind)], name="flatten")[0]
 
 
 def bilinear_up2x(x, name="ups"):

@@ -46,12 +46,15 @@ def conv2D(x,
            **kwargs):
     """Standard 2-D convolutional layer: conv -> [bias] -> normalisation -> activation.
     kwargs can carry ``training`` and normalisation parameters (``num_groups``)."""
-    if tuple(strides) != (1, 1) or padding != "SAME":
-        raise NotImplementedError("hot path: stride 1, SAME padding")
-    if tuple(kernel_size) not in ((1, 1), (3, 3)):
-        raise NotImplementedError("hot path: 1x1 and 3x3 kernels")
-    if normalise_post_activation or dropout_p is not None:
-        raise NotImplementedError("normalise_post_activation / dropout are never set by the PHiSeg configs")
+    if padding != "SAME":
+        raise NotImplementedError("conv2D: SAME padding (the only value the reference's call sites use)")
+    if normalise_post_activation:
+        raise NotImplementedError("normalise_post_activation is never set by the PHiSeg configs")
+    # stride 1 with a 1x1 / 3x3 kernel is the hot path (MFMA / direct / head kernels); anything else -- strided convolutions of the
+    # residual units, larger kernels -- runs on the general direct kernels of csrc/gconv.hip
+    general = None
+    if tuple(strides) != (1, 1) or tuple(kernel_size) not in ((1, 1), (3, 3)):
+        general = (int(kernel_size[0]), int(kernel_size[1]), int(strides[0]), int(strides[1]), 1, 1)
     if normalisation not in tfnorm.KIND:
         raise ValueError("Unknown normalisation callable %r" % (normalisation,))
     if activation not in activations.ACT_NAME:
@@ -74,9 +77,107 @@ def conv2D(x,
         norm_vars = tfnorm.make_variables(kind, num_filters)
         training = kwargs.get('training', True)
         # heads (mu / sigma / logits) keep fp32 storage in the bf16 configuration
-        head = kind is None and activation is not activations.relu
-        return G.conv_unit(x, weights, biases, kernel_size[0], kind, norm_vars, activations.ACT_NAME[activation],
-                           training, num_groups=kwargs.get('num_groups'), head=head, name='conv')
+        head = kind is None and activation is not activations.relu and general is None
+        op = G.conv_unit(x, weights, biases, kernel_size[0], kind, norm_vars, activations.ACT_NAME[activation],
+                         training, num_groups=kwargs.get('num_groups'), head=head, name='conv', general=general)
+        if dropout_p is not None:
+            op = dropout(op, keep_prob=dropout_p, training=training)
+        return op
+
+
+def dilated_conv2D(bottom,
+                   name,
+                   kernel_size=(3, 3),
+                   num_filters=32,
+                   rate=2,
+                   activation=STANDARD_NONLINEARITY,
+                   normalisation=tfnorm.identity,
+                   normalise_post_activation=False,
+                   dropout_p=None,
+                   padding="SAME",
+                   weight_init='he_normal',
+                   add_bias=True,
+                   **kwargs):
+    """tfwrapper/layers.py:378-425: tf.nn.atrous_conv2d(bottom, W, rate, SAME) -> [bias] -> normalisation -> activation
+    [-> dropout].  (Unlike conv2D the bias is kept in front of batch_norm, layers.py:406-409.)"""
+    if padding != "SAME" or normalise_post_activation:
+        raise NotImplementedError("dilated_conv2D: SAME padding, normalisation before the activation")
+    if normalisation not in tfnorm.KIND or activation not in activations.ACT_NAME:
+        raise ValueError("Unknown normalisation / activation callable")
+    cin = bottom.get_shape().as_list()[3]
+    g = G.get_default_graph()
+    with g.variable_scope(name):
+        weights = utils.get_weight_variable([kernel_size[0], kernel_size[1], cin, num_filters], name='W', type=weight_init,
+                                            regularize=True)
+        biases = utils.get_bias_variable([num_filters], name='b') if add_bias else None
+        kind = tfnorm.KIND[normalisation]
+        norm_vars = tfnorm.make_variables(kind, num_filters)
+        training = kwargs.get('training', True)
+        op = G.conv_unit(bottom, weights, biases, kernel_size[0], kind, norm_vars, activations.ACT_NAME[activation], training,
+                         num_groups=kwargs.get('num_groups'), head=False, name='atrous',
+                         general=(int(kernel_size[0]), int(kernel_size[1]), 1, 1, int(rate), int(rate)))
+        if dropout_p is not None:
+            op = dropout(op, keep_prob=dropout_p, training=training)
+        return op
+
+
+def dense_layer(bottom,
+                name,
+                hidden_units=512,
+                activation=STANDARD_NONLINEARITY,
+                normalisation=tfnorm.batch_norm,
+                normalise_post_activation=False,
+                dropout_p=None,
+                weight_init='he_normal',
+                add_bias=True,
+                **kwargs):
+    """tfwrapper/layers.py:539-582: flatten -> matmul with W [F, hidden_units] -> [bias] -> normalisation -> activation
+    [-> dropout].  Runs as a 1x1 convolution of the flattened input; the result keeps two unit axes: [B, 1, 1, hidden_units]
+    (same memory as the reference's [B, hidden_units])."""
+    if normalise_post_activation:
+        raise NotImplementedError("dense_layer: normalisation before the activation only")
+    if normalisation not in tfnorm.KIND or activation not in activations.ACT_NAME:
+        raise ValueError("Unknown normalisation / activation callable")
+    flat = G.flatten(bottom)
+    f = flat.get_shape().as_list()[3]
+    g = G.get_default_graph()
+    with g.variable_scope(name):
+        weights = utils.get_weight_variable([f, hidden_units], name='W', type=weight_init, regularize=True)
+        biases = utils.get_bias_variable([hidden_units], name='b') if add_bias else None
+        kind = tfnorm.KIND[normalisation]
+        norm_vars = tfnorm.make_variables(kind, hidden_units)
+        training = kwargs.get('training', True)
+        op = G.conv_unit(flat, weights, biases, 1, kind, norm_vars, activations.ACT_NAME[activation], training,
+                         num_groups=kwargs.get('num_groups'), head=False, name='dense', general=(1, 1, 1, 1, 1, 1))
+        if dropout_p is not None:
+            op = dropout(op, keep_prob=dropout_p, training=training)
+        return op
+
+
+def maxpool2D(x, kernel_size=(2, 2), strides=(2, 2), padding="SAME"):
+    """tf.nn.max_pool 2x2 / stride 2 / SAME (tfwrapper/layers.py:18-28)."""
+    if tuple(kernel_size) != (2, 2) or tuple(strides) != (2, 2) or padding != "SAME":
+        raise NotImplementedError("maxpool2D: 2x2 / stride 2 / SAME (the reference's defaults)")
+    return G.max_pool2x2(x)
+
+
+def pad_to_size(bottom, output_size):
+    """tfwrapper/layers.py:625-650: zero-pad the spatial axes of `bottom` to output_size = [B, H, W, C] (the odd pixel goes to the
+    bottom / right)."""
+    shp = bottom.get_shape().as_list()
+    if len(shp) != 4:
+        raise NotImplementedError('pad_to_size has not been extended to 3D (neither in the reference)')
+    dy, dx = int(output_size[1]) - shp[1], int(output_size[2]) - shp[2]
+    if dy < 0 or dx < 0:
+        raise ValueError("pad_to_size: output smaller than input")
+    return G.spatial_window(bottom, output_size[1], output_size[2], -(dy // 2), -(dx // 2), name='pad_to_size')
+
+
+def dropout(bottom, keep_prob, training):
+    """tfwrapper/layers.py:653-668: tf.nn.dropout(bottom, keep_prob) while training, identity otherwise."""
+    g = G.get_default_graph()
+    with g.variable_scope('dropout_layer'):
+        return G.dropout(bottom, keep_prob, training)
 
 
 def transposed_conv2D(bottom,
@@ -133,16 +234,19 @@ def bilinear_upsample2D(x, name, factor):
 
 
 def crop_and_concat(inputs, axis=-1):
-    """Channel concat of feature maps; the first defines the output size.  On the hot path all sizes are equal
-    (prob_unet2D decoder, likelihoods.py:136), so no crop is ever needed."""
-    out_size = inputs[0].get_shape().as_list()[1:3]
-    for t in inputs[1:]:
-        if t.get_shape().as_list()[1:3] != out_size:
-            raise NotImplementedError("crop_and_concat with unequal sizes does not occur on the hot path")
+    """tfwrapper/layers.py:586-622: the first feature map defines the output size, the others are centre-cropped to it
+    (start = (larger - output) // 2) and everything is concatenated along the channel axis."""
     if axis not in (-1, 3):
         raise ValueError("crop_and_concat: channel axis only")
+    out_size = inputs[0].get_shape().as_list()[1:3]
     out = inputs[0]
     for t in inputs[1:]:
+        larger = t.get_shape().as_list()[1:3]
+        if larger != out_size:
+            if larger[0] < out_size[0] or larger[1] < out_size[1]:
+                raise ValueError("crop_and_concat: %s cannot be cropped to %s" % (larger, out_size))
+            t = G.spatial_window(t, out_size[0], out_size[1], (larger[0] - out_size[0]) // 2, (larger[1] - out_size[1]) // 2,
+                                 name='crop')
         out = G.concat([out, t], axis=-1)
     return out
 
@@ -154,15 +258,10 @@ def _not_on_hot_path(name):
     return fn
 
 
-maxpool2D = _not_on_hot_path("maxpool2D")
 maxpool3D = _not_on_hot_path("maxpool3D")
 reshape_pool2D_layer = _not_on_hot_path("reshape_pool2D_layer")
 conv3D = _not_on_hot_path("conv3D")
 transposed_conv3D = _not_on_hot_path("transposed_conv3D")
 bilinear_upsample3D = _not_on_hot_path("bilinear_upsample3D")
-dilated_conv2D = _not_on_hot_path("dilated_conv2D")
 residual_unit2D = _not_on_hot_path("residual_unit2D")
 identity_residual_unit2D = _not_on_hot_path("identity_residual_unit2D")
-dense_layer = _not_on_hot_path("dense_layer")
-pad_to_size = _not_on_hot_path("pad_to_size")
-dropout = _not_on_hot_path("dropout")

@@ -116,3 +116,98 @@ def test_dropout_follows_the_philox_contract(L):
     assert 0.6 < keep.mean() < 0.8
     L.dropout(xd.data_ptr(), y.data_ptr(), F32, int(np.prod(shape[1:])), B, 1.0, 1, step.data_ptr(), 0, 0, S())
     assert torch.equal(y, xd)
+
+
+@pytest.mark.parametrize("norm", ["identity", "batch_norm"])
+def test_extra_layers_in_a_graph(norm):
+    """The layer functions as code written against tfwrapper/layers.py calls them -- conv2D(strides=2, 5x5), dilated_conv2D(rate 2),
+    maxpool2D, pad_to_size, crop_and_concat with a real crop, dropout, dense_layer -- compiled by the engine into one training
+    plan: loss and every gradient against torch autograd of the oracle primitives (dropout mask from the Philox contract)."""
+    from phiseg_code_amd import engine
+    from phiseg_code_amd import graph as G
+    from phiseg_code_amd.tfwrapper import activations as act
+    from phiseg_code_amd.tfwrapper import layers
+    from phiseg_code_amd.tfwrapper import normalisation as tfnorm
+    B, H, C = 3, 12, 2
+    g = G.reset_default_graph()
+    x_inp = G.placeholder(G.KIND_F32, [None, H, H, 3], name="x_input")
+    s_inp = G.placeholder(G.KIND_U8, [None, 6, 6], name="s_input")
+    nfn = getattr(tfnorm, norm)
+    with g.variable_scope("net"):
+        a = layers.conv2D(x_inp, "c1", num_filters=8, kernel_size=(5, 5), strides=(2, 2), normalisation=nfn, training=True)     # 6 x 6
+        d = layers.dilated_conv2D(x_inp, "dil", num_filters=4, rate=2, normalisation=nfn, training=True)                         # 12 x 12
+        m = layers.maxpool2D(d)                                                                                                  # 6 x 6
+        big = layers.pad_to_size(m, [None, 9, 8, 4])                                                                              # 9 x 8
+        cat = layers.crop_and_concat([a, big])                                                                                   # crop back: 6 x 6, 12 ch
+        dr = layers.dropout(cat, keep_prob=0.8, training=True)
+        fc = layers.dense_layer(dr, "fc", hidden_units=5, normalisation=nfn, training=True)                                      # [B,1,1,5]
+        gate = layers.conv2D(G.tile_pixels(G.global_average_pool(fc), 6, 6), "mix", num_filters=12, kernel_size=(1, 1),
+                             normalisation=tfnorm.identity, training=True)
+        s = layers.conv2D(G.concat([dr, gate], axis=-1), "head", num_filters=C, kernel_size=(1, 1), activation=act.identity)
+    ce, _ = G.residual_multinoulli([s], s_inp, 1.0)
+    loss = G.weighted_sum([ce[0]], [1.0])
+    names = [n for n in g.variables]
+    assert "net/fc/W" in names and g.variables["net/fc/W"].shape == (6 * 6 * 12, 5) and "net/dil/b" in names
+    store = engine.ParamStore(g, seed=3)
+    rng = np.random.default_rng(7)
+    vals = {n: (v.initial_value(3) + (0.1 * rng.standard_normal(v.shape) if not n.endswith("/W") else 0)).astype(np.float32)
+            for n, v in g.variables.items()}
+    for n in vals:
+        if n.endswith("moving_variance"):
+            vals[n] = np.abs(vals[n]) + 0.5
+    store.load(vals)
+    seed = 4242
+    plan = engine.Plan(store, [loss, s], loss=loss, batch=B, training=True, compute_dtype="f32", optimize=False, use_hip_graph=False,
+                       rng_seed=seed)
+    x = rng.standard_normal((B, H, H, 3)).astype(np.float32)
+    lab = rng.integers(0, C, (B, 6, 6)).astype(np.uint8)
+    plan.set_input("x_input", x)
+    plan.set_input("s_input", lab)
+    plan.run(sync=True)
+    got_loss, got_s = float(plan.fetch(loss)), plan.fetch(s)
+    grads = store.export(grads=True)
+    # oracle
+    p = {n: torch.as_tensor(v, dtype=torch.float64).requires_grad_(not n.rsplit("/", 1)[-1].startswith("moving_")) for n, v in vals.items()}
+
+    def nrm(t, scope):
+        if norm == "identity":
+            return t
+        y, _, _ = T.batch_norm_train(t, p[scope + "/batch_norm/BatchNorm/gamma"], p[scope + "/batch_norm/BatchNorm/beta"])
+        return y
+    xt = torch.as_tensor(x, dtype=torch.float64)
+    a = T.conv2d_general_same(xt, p["net/c1/W"], (2, 2), (1, 1))
+    if norm != "batch_norm":
+        a = T.bias_add(a, p["net/c1/b"])
+    a = T.relu(nrm(a, "net/c1"))
+    d = T.relu(nrm(T.bias_add(T.conv2d_general_same(xt, p["net/dil/W"], (1, 1), (2, 2)), p["net/dil/b"]), "net/dil"))   # bias kept
+    m = T.max_pool_2x2_same(d)
+    big = torch.nn.functional.pad(m, (0, 0, 1, 1, 1, 2))                                  # (9 - 6) // 2 = 1 top, 2 bottom; 1 / 1 in x
+    cat = torch.cat([a, big[:, 1:7, 1:7]], dim=-1)                                        # crop start (9 - 6) // 2 = 1, (8 - 6) // 2 = 1
+    import zlib
+    dname = [op.name for op in g.ops if op.type == "dropout"][0]
+    keep = T.dropout_keep_mask(tuple(cat.shape), 0.8, seed, 0, zlib.crc32(dname.encode()) & 0x3FFFFFFF)
+    dr = cat * torch.as_tensor(keep, dtype=torch.float64) / float(np.float32(0.8))
+    fc = dr.reshape(B, -1) @ p["net/fc/W"] + p["net/fc/b"]
+    fc = T.relu(nrm(fc.reshape(B, 1, 1, 5), "net/fc"))
+    gate = T.relu(T.bias_add(T.conv2d_same(fc.mean(dim=(1, 2)).reshape(B, 1, 1, 5).expand(B, 6, 6, 5), p["net/mix/W"]), p["net/mix/b"]))
+    so = T.bias_add(T.conv2d_same(torch.cat([dr, gate], dim=-1), p["net/head/W"]), p["net/head/b"])
+    ref = T.multinoulli_loss_with_logits(T.one_hot(torch.as_tensor(lab), C, torch.float64), so)
+    ref.backward()
+    np.testing.assert_allclose(got_s, so.detach().numpy(), rtol=0, atol=3e-4 * float(so.abs().max()))
+    np.testing.assert_allclose(got_loss, float(ref), rtol=3e-5)
+    checked = 0
+    for n, t in p.items():
+        if t.grad is None:
+            continue
+        r = t.grad.numpy()
+        if np.abs(r).max() < 1e-9:
+            assert np.abs(grads[n]).max() < 1e-4, n
+            continue
+        np.testing.assert_allclose(grads[n], r, rtol=0, atol=3e-3 * max(np.abs(r).max(), 1e-6), err_msg=n)
+        checked += 1
+    assert checked >= 8
+    # inference mode: dropout is the identity
+    plan2 = engine.Plan(store, [s], loss=None, batch=B, training=False, compute_dtype="f32", use_hip_graph=False, rng_seed=seed)
+    plan2.set_input("x_input", x)
+    plan2.run(sync=True)
+    assert np.isfinite(plan2.fetch(s)).all()
