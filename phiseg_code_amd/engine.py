@@ -30,6 +30,7 @@ _ESIZE = {F32: 4, BF16: 2, U8: 1}
 _STATS_ATOMIC = os.environ.get("PHX_STATS_ATOMIC", "1") == "1"           # small-map batch norm: statistics by atomics from the conv epilogue (A/B hook)
 _KL_SIDE = os.environ.get("PHX_KL_SIDE", "0") == "1"                     # two lanes: KL launches on the prior lane (measured 2 % SLOWER: 12.17 vs 11.90 ms)
 _PRIOR_BW_FIRST = os.environ.get("PHX_PRIOR_BW_FIRST", "0") == "1"       # prior backward emitted before the likelihood's (A/B hook)
+_DEFER_LANE2 = os.environ.get("PHX_DEFER_LANE2", "0") == "1"             # likelihood's deferred launches on a third stream (A/B hook)
 _DEFER_EARLY = os.environ.get("PHX_DEFER_EARLY", "0") == "1"             # deferred launches of likelihood + prior on lane 1 beside the posterior backward (A/B hook)
 _LIK_COARSE_FIRST = os.environ.get("PHX_LIK_COARSE_FIRST", "1") == "1"   # emission order of the likelihood's per-level chains
 # two lanes: likelihood chains of levels <= this go to the prior's lane; the coarsest chain stays on lane 0, in front of the top-down
@@ -254,6 +255,8 @@ class Plan:
         self._lanes = []
         if n_lanes is None:
             n_lanes = int(os.environ.get("PHX_LANES", "2"))
+            if _DEFER_LANE2 and n_lanes == 2 and loss is not None:
+                n_lanes = 3                       # experiment: a third stream that only carries the likelihood's deferred launches
         if stream is None:
             for _ in range(max(1, int(n_lanes))):
                 st = ctypes.c_void_p()
@@ -391,6 +394,8 @@ class Plan:
         cross-lane dependency then has lane 0 on one side: on ROCm 7.2 an event wait between two NON-origin streams of a
         multi-stream capture makes hipStreamEndCapture segfault (found by bisecting the launch list)."""
         n = len(self._lanes)
+        if _DEFER_LANE2 and n == 3:
+            n = 2                                 # (the third stream is not part of the operator lane plan)
         if n == 1:
             return 0
         name = op.name
@@ -570,7 +575,20 @@ class Plan:
             # done, beside the posterior's backward chain, was measured 7 % slower than one batch after the join.)
             bw_ops = self._backward_order(ops, opset)
             flushed = not (_DEFER_EARLY and nl > 1)
+            lane2_done = not (_DEFER_LANE2 and nl == 3)
             for op in bw_ops:
+                if not lane2_done and op.name.startswith("prior/"):
+                    # experiment (PHX_DEFER_LANE2=1): the likelihood's backward is complete here -- its deferred filter gradients go
+                    # to a third stream, beside the latency-bound prior / posterior backward chains (lane 2 only ever waits for lane 0)
+                    lane2_done = True
+                    ev1 = self._record(1)
+                    self._lane = 0
+                    self._wait(ev1)
+                    self._emit(_noop)
+                    ev0 = self._record(0)
+                    self._lane = 2
+                    self._wait(ev0)
+                    self._emit_deferred()
                 if not flushed and op.name.startswith("posterior/"):
                     # everything the likelihood and the prior have deferred goes to lane 1 now, beside the posterior's
                     # latency-bound backward chain on lane 0 (their inputs are complete once lane 0 has reached this point)
