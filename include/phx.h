@@ -379,6 +379,15 @@ int phx_maxpool2x2_bwd(const void* x, const void* dy, int dt, void* dx, int B, i
  * sizes swapped and the offsets negated */
 int phx_spatial_window(const void* src, void* dst, int dt, int B, int Hs, int Ws, int Hd, int Wd, int C, int off_y, int off_x,
                        void* stream);
+/* strided window with a channel offset: dst[b, y, x, c] = src[b, y sy + off_y, x sx + off_x, c + off_c] inside the source, 0
+ * outside -- the skip path of the residual units (layers.py:465-470: tf.pad along the channel axis, identity[:, ::2, ::2, :]);
+ * _bwd writes the gradient with respect to src (every element, zeros where nothing maps) */
+int phx_window4_fwd(const void* src, void* dst, int dt, int B, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int sy, int sx,
+                    int off_y, int off_x, int off_c, void* stream);
+int phx_window4_bwd(const void* ddst, void* dsrc, int dt, int B, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int sy, int sx,
+                    int off_y, int off_x, int off_c, void* stream);
+/* y = act(a + b): tf.add + activation at the end of a residual unit (layers.py:474-475); gradient: phx_act_bwd on y */
+int phx_add_act(const void* a, const void* b, void* y, int dt, size_t n, int act, void* stream);
 /* dropout (layers.py:653-668, tf.nn.dropout): y = x * keep / keep_prob with keep[b][e] = (u < keep_prob), u the 24-bit uniform of
  * word e % 4 of Philox block e / 4 under (seed, *step_dev, stream_id, sample_offset + b); the backward pass is the same call on dy */
 int phx_dropout(const void* x, void* y, int dt, size_t per_sample, int B, float keep_prob, uint64_t seed, const int32_t* step_dev,

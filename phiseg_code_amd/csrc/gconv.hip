@@ -179,6 +179,51 @@ __global__ void k_spatial_window(const T* __restrict__ src, T* __restrict__ dst,
     }
 }
 
+// general strided window with a channel offset (the skip path of the residual units, layers.py:465-470: tf.pad along the channel
+// axis and identity[:, ::2, ::2, :]):  dst[b, y, x, c] = src[b, y sy + oy, x sx + ox, c + oc] inside the source, 0 outside
+struct WGeo {
+    int B, Hs, Ws, Cs, Hd, Wd, Cd, sy, sx, oy, ox, oc;
+};
+template <typename T>
+__global__ void k_window4_fwd(const T* __restrict__ src, T* __restrict__ dst, WGeo g) {
+    const size_t n = (size_t)g.B * g.Hd * g.Wd * g.Cd;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % g.Cd);
+        size_t r = i / g.Cd;
+        const int x = (int)(r % g.Wd); r /= g.Wd;
+        const int y = (int)(r % g.Hd);
+        const int b = (int)(r / g.Hd);
+        const int yy = y * g.sy + g.oy, xx = x * g.sx + g.ox, cc = c + g.oc;
+        const bool in = yy >= 0 && yy < g.Hs && xx >= 0 && xx < g.Ws && cc >= 0 && cc < g.Cs;
+        stf<T>(dst, i, in ? ldf<T>(src, (((size_t)b * g.Hs + yy) * g.Ws + xx) * g.Cs + cc) : 0.f);
+    }
+}
+// its gradient: dsrc[b, Y, X, C] = ddst[b, (Y - oy) / sy, (X - ox) / sx, C - oc] where that position exists, else 0
+template <typename T>
+__global__ void k_window4_bwd(const T* __restrict__ ddst, T* __restrict__ dsrc, WGeo g) {
+    const size_t n = (size_t)g.B * g.Hs * g.Ws * g.Cs;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int C = (int)(i % g.Cs);
+        size_t r = i / g.Cs;
+        const int X = (int)(r % g.Ws); r /= g.Ws;
+        const int Y = (int)(r % g.Hs);
+        const int b = (int)(r / g.Hs);
+        const int ty = Y - g.oy, tx = X - g.ox, c = C - g.oc;
+        float v = 0.f;
+        if (ty >= 0 && tx >= 0 && ty % g.sy == 0 && tx % g.sx == 0 && c >= 0 && c < g.Cd) {
+            const int y = ty / g.sy, x = tx / g.sx;
+            if (y < g.Hd && x < g.Wd) v = ldf<T>(ddst, (((size_t)b * g.Hd + y) * g.Wd + x) * g.Cd + c);
+        }
+        stf<T>(dsrc, i, v);
+    }
+}
+// y = act(a + b)   (tf.add + activation of the residual units, layers.py:474-475)
+template <typename T>
+__global__ void k_add_act(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, size_t n, int act) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        stf<T>(y, i, act_fwd(ldf<T>(a, i) + ldf<T>(b, i), act));
+}
+
 // y = x * keep[b, e] / keep_prob, keep = (u < keep_prob), u = (word (e % 4) of Philox block e / 4 of (seed, step, stream, sample b) >> 8) / 2^24
 // (the same keep mask is recomputed by the backward launch: dx = dy * keep / keep_prob)
 template <typename T>
@@ -285,6 +330,47 @@ int phx_spatial_window(const void* src, void* dst, int dt, int B, int Hs, int Ws
     PHX_DT_SWITCH(dt, T, {
         hipLaunchKernelGGL((k_spatial_window<T>), dim3(phx_grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const T*)src,
                            (T*)dst, B, Hs, Ws, Hd, Wd, C, off_y, off_x);
+    });
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+static int make_wgeo(WGeo* g, int B, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int sy, int sx, int oy, int ox, int oc) {
+    PHX_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Cs > 0 && Hd > 0 && Wd > 0 && Cd > 0 && sy > 0 && sx > 0, PHX_E_SHAPE, "window4: bad shape");
+    g->B = B; g->Hs = Hs; g->Ws = Ws; g->Cs = Cs; g->Hd = Hd; g->Wd = Wd; g->Cd = Cd; g->sy = sy; g->sx = sx; g->oy = oy; g->ox = ox; g->oc = oc;
+    return PHX_OK;
+}
+int phx_window4_fwd(const void* src, void* dst, int dt, int B, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int sy, int sx,
+                    int off_y, int off_x, int off_c, void* stream) {
+    WGeo g;
+    const int rc = make_wgeo(&g, B, Hs, Ws, Cs, Hd, Wd, Cd, sy, sx, off_y, off_x, off_c);
+    if (rc != PHX_OK) return rc;
+    const size_t n = (size_t)B * Hd * Wd * Cd;
+    PHX_DT_SWITCH(dt, T, {
+        hipLaunchKernelGGL((k_window4_fwd<T>), dim3(phx_grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const T*)src,
+                           (T*)dst, g);
+    });
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+int phx_window4_bwd(const void* ddst, void* dsrc, int dt, int B, int Hs, int Ws, int Cs, int Hd, int Wd, int Cd, int sy, int sx,
+                    int off_y, int off_x, int off_c, void* stream) {
+    WGeo g;
+    const int rc = make_wgeo(&g, B, Hs, Ws, Cs, Hd, Wd, Cd, sy, sx, off_y, off_x, off_c);
+    if (rc != PHX_OK) return rc;
+    const size_t n = (size_t)B * Hs * Ws * Cs;
+    PHX_DT_SWITCH(dt, T, {
+        hipLaunchKernelGGL((k_window4_bwd<T>), dim3(phx_grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const T*)ddst,
+                           (T*)dsrc, g);
+    });
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+int phx_add_act(const void* a, const void* b, void* y, int dt, size_t n, int act, void* stream) {
+    PHX_REQUIRE(a && b && y && n > 0, PHX_E_INVAL, "add_act: bad argument");
+    PHX_DT_SWITCH(dt, T, {
+        hipLaunchKernelGGL((k_add_act<T>), dim3(phx_grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const T*)a,
+                           (const T*)b, (T*)y, n, act);
     });
     PHX_CHECK_LAUNCH();
     return PHX_OK;

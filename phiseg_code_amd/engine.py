@@ -81,6 +81,9 @@ def live_variables(loss):
                     live.add(v.name)
             for v in (a.get("norm_vars") or {}).values():
                 live.add(v.name)
+        if op.type == "norm_act":
+            for v in (op.attrs.get("norm_vars") or {}).values():
+                live.add(v.name)
         stack.extend(i.op for i in op.inputs)
     return live
 
@@ -515,7 +518,7 @@ class Plan:
         # which tensors depend on trainable variables
         self.req = {}
         for op in ops:
-            r = op.type == "conv_unit" or any(self.req.get(i, False) for i in op.inputs)
+            r = op.type in ("conv_unit", "norm_act") or any(self.req.get(i, False) for i in op.inputs)
             for o in op.outputs:
                 self.req[o] = r
         self.loss_weight = {}
@@ -987,6 +990,67 @@ class Plan:
         self._emit(self.L.dropout, x.ptr, out.ptr, x.dt, x.n // x.shape[0], x.shape[0], op.attrs["keep_prob"], self.rng_seed,
                    self._noise_step_ptr(), op.attrs["stream"], self.sample_offset, self.stream)
 
+    def _fw_window4(self, op, bw):
+        x = self.val[op.inputs[0]]
+        out = self._alloc(self._cshape(op.outputs[0]), x.dt)
+        self.val[op.outputs[0]] = out
+        (sy, sx), (oy, ox, oc) = op.attrs["stride"], op.attrs["off"]
+        self._emit(self.L.window4_fwd, x.ptr, out.ptr, x.dt, x.shape[0], x.shape[1], x.shape[2], x.shape[3], out.shape[1],
+                   out.shape[2], out.shape[3], sy, sx, oy, ox, oc, self.stream)
+
+    def _fw_add_act(self, op, bw):
+        a, b = self.val[op.inputs[0]], self.val[op.inputs[1]]
+        out = self._alloc(a.shape, a.dt)
+        self.val[op.outputs[0]] = out
+        b = self._as_dt(b, a.dt)
+        self._emit(self.L.add_act, a.ptr, b.ptr, out.ptr, a.dt, a.n, rt.ACT_CODES[op.attrs["act"]], self.stream)
+
+    def _fw_norm_act(self, op, bw):
+        """Stand-alone act(normalisation(x)): statistics pass + fused apply (the generic path of the convolution units)."""
+        a = op.attrs
+        x = self.val[op.inputs[0]]
+        out = self._alloc(x.shape, x.dt)
+        self.val[op.outputs[0]] = out
+        B, C = x.shape[0], x.shape[3]
+        HW = x.shape[1] * x.shape[2]
+        act = rt.ACT_CODES[a["act"]]
+        norm = a["norm"]
+        training = a["training"] if isinstance(a["training"], bool) else self.training
+        S, Lb = self.stream, self.L
+        if norm is None:
+            ones = Buf((C,), F32, like=torch.ones(C, dtype=torch.float32, device=_device()))
+            zeros = Buf((C,), F32, like=torch.zeros(C, dtype=torch.float32, device=_device()))
+            self._keep += [ones, zeros]
+            self._emit(Lb.affine_act, x.ptr, x.dt, ones.ptr, zeros.ptr, out.ptr, out.dt, 1, B * HW, C, act, S)
+            self.saved[op] = dict(norm=None, out=out)
+            return
+        nv = a["norm_vars"]
+        gptr, beptr = self.store.ptr(nv["gamma"]), self.store.ptr(nv["beta"])
+        if norm == "batch":
+            NS, P, Gn = 1, B * HW, C
+        else:
+            Gn = C if norm == "instance" else (a["num_groups"] or max(2, C // 16))
+            NS, P = B, HW
+        scale, shift = self._alloc((NS * C,), F32), self._alloc((NS * C,), F32)
+        mean, rstd = self._alloc((NS * Gn,), F32), self._alloc((NS * Gn,), F32)
+        eps = tfnorm.EPS[norm]
+        st = dict(norm=norm, y=x, out=out, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn)
+        if norm == "batch" and not training:
+            self._emit(Lb.bn_infer_scale_shift, gptr, beptr, self.store.ptr(nv["moving_mean"]),
+                       self.store.ptr(nv["moving_variance"]), eps, C, scale.ptr, shift.ptr, S)
+            self._emit(Lb.affine_act, x.ptr, x.dt, scale.ptr, shift.ptr, out.ptr, out.dt, NS, P, C, act, S)
+            st["inference"] = True
+        else:
+            sums = self._alloc_zeroed(NS * C * 2)
+            pivot = self._alloc((NS * C,), F32)
+            self._emit(Lb.norm_stats, x.ptr, x.dt, sums.ptr, pivot.ptr, NS, P, C, S)
+            upd = norm == "batch" and training and self.loss is not None
+            self._emit(Lb.norm_apply_fused, x.ptr, x.dt, sums.ptr, pivot.ptr, gptr, beptr, eps, out.ptr, out.dt, mean.ptr, rstd.ptr,
+                       scale.ptr, shift.ptr, self.store.ptr(nv["moving_mean"]) if upd else None,
+                       self.store.ptr(nv["moving_variance"]) if upd else None, (1.0 - tfnorm.BN_DECAY) if upd else 0.0,
+                       NS, P, C, Gn, act, S)
+        self.saved[op] = st
+
     def _fw_flatten(self, op, bw):
         x = self.val[op.inputs[0]]
         self.val[op.outputs[0]] = Buf(self._cshape(op.outputs[0]), x.dt, like=x.t)      # same memory, new shape
@@ -1223,6 +1287,49 @@ class Plan:
         self._add_grad(op.inputs[0], write_fn=lambda g: self._emit(
             self.L.dropout, d.ptr, g.ptr, d.dt, d.n // d.shape[0], d.shape[0], op.attrs["keep_prob"], self.rng_seed,
             self._noise_step_ptr(), op.attrs["stream"], self.sample_offset, self.stream))
+
+    def _bw_window4(self, op):
+        x, d = self.val[op.inputs[0]], self.grad[op.outputs[0]]
+        (sy, sx), (oy, ox, oc) = op.attrs["stride"], op.attrs["off"]
+        self._add_grad(op.inputs[0], write_fn=lambda g: self._emit(
+            self.L.window4_bwd, d.ptr, g.ptr, d.dt, x.shape[0], x.shape[1], x.shape[2], x.shape[3], d.shape[1], d.shape[2],
+            d.shape[3], sy, sx, oy, ox, oc, self.stream))
+
+    def _bw_add_act(self, op):
+        d, out = self.grad[op.outputs[0]], self.val[op.outputs[0]]
+        act = rt.ACT_CODES[op.attrs["act"]]
+        for t in op.inputs:                                   # (one buffer per input: later contributions are added in place)
+            if act != rt.ACT_ID:
+                self._add_grad(t, write_fn=lambda g: self._emit(self.L.act_bwd, d.ptr, d.dt, out.ptr, out.dt, g.ptr, g.dt, d.n, act,
+                                                                self.stream))
+            else:
+                self._add_grad(t, write_fn=lambda g: self._emit(self.L.memcpy_d2d, g.ptr, d.ptr, d.nbytes, self.stream))
+
+    def _bw_norm_act(self, op):
+        a, sv = op.attrs, self.saved[op]
+        dA = self.grad[op.outputs[0]]
+        act = rt.ACT_CODES[a["act"]]
+        S, Lb = self.stream, self.L
+        if sv["norm"] is None:
+            out = sv["out"]
+            self._add_grad(op.inputs[0], write_fn=lambda g: self._emit(Lb.act_bwd, dA.ptr, dA.dt, out.ptr, out.dt, g.ptr, g.dt, dA.n,
+                                                                       act, S))
+            return
+        if sv.get("inference"):
+            raise NotImplementedError("backward through inference-mode batch norm is not on the hot path")
+        nv = a["norm_vars"]
+        y, NS, P, Gn = sv["y"], sv["NS"], sv["P"], sv["G"]
+        C = y.shape[3]
+        nrep = _NREP if P >= _NREP_MINP else 1
+        sums2 = self._alloc_zeroed(nrep * NS * C * 2)
+
+        def wr(g):
+            self._emit(Lb.norm_bwd_reduce, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr, sv["mean"].ptr,
+                       sv["rstd"].ptr, sums2.ptr, NS, P, C, Gn, act, nrep, S)
+            self._emit(Lb.norm_bwd_apply_fused, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr, sv["mean"].ptr,
+                       sv["rstd"].ptr, self.store.ptr(nv["gamma"]), sums2.ptr, g.ptr, g.dt, self.store.grad_ptr(nv["gamma"]),
+                       self.store.grad_ptr(nv["beta"]), NS, P, C, Gn, act, nrep, S)
+        self._add_grad(op.inputs[0], write_fn=wr)
 
     def _bw_flatten(self, op):
         x, d = self.val[op.inputs[0]], self.grad[op.outputs[0]]

@@ -269,6 +269,28 @@ def dropout(x, keep_prob, training, name="dropout"):
     return out
 
 
+def window4(x, out_h, out_w, out_c, stride=(1, 1), off=(0, 0, 0), name="window"):
+    """out[b, y, x, c] = x[b, y sy + oy, x sx + ox, c + oc] inside x, 0 outside: tf.pad along the channel axis (oc = -pad) and the
+    strided slice identity[:, ::2, ::2, :] of the residual units' skip path (tfwrapper/layers.py:465-470)."""
+    n = x.shape[0]
+    return get_default_graph().add_op("window4", [x], dict(stride=(int(stride[0]), int(stride[1])), off=tuple(int(v) for v in off)),
+                                      [((n, int(out_h), int(out_w), int(out_c)), x.kind)], name=name)[0]
+
+
+def add_act(a, b, act="identity", name="add"):
+    """act(a + b): tf.add(skip, conv2) [+ activation] of the residual units (layers.py:474-475, 534)."""
+    if tuple(a.shape) != tuple(b.shape):
+        raise ValueError("add: shapes %s and %s differ" % (a.shape, b.shape))
+    return get_default_graph().add_op("add_act", [a, b], dict(act=act), [(a.shape, a.kind)], name=name)[0]
+
+
+def norm_act(x, norm, norm_vars, act, training, num_groups=None, name="norm"):
+    """act(normalisation(x)) as a node of its own: the pre-activation order of identity_residual_unit2D (layers.py:512-518), where
+    the normalisation does not follow a convolution."""
+    attrs = dict(norm=norm, norm_vars=norm_vars, act=act, training=training, num_groups=num_groups)
+    return get_default_graph().add_op("norm_act", [x], attrs, [(x.shape, x.kind)], name=name)[0]
+
+
 def flatten(x):
     """tfwrapper/utils.py:16-22 flatten: [B, ...] -> [B, 1, 1, prod(...)] (NHWC memory order kept: a view, no launch); the
     extra unit axes keep every tensor of the engine four-dimensional."""

@@ -154,6 +154,116 @@ def dense_layer(bottom,
         return op
 
 
+def _conv_norm(x, conv_name, norm_scope, num_filters, strides, kernel_size, normalisation, activation, add_bias, kwargs):
+    """conv2D(x, conv_name, activation=identity, add_bias=add_bias) -> normalisation(., scope=norm_scope) -> activation, as the
+    residual units spell it (layers.py:452-460): the convolution's variables live under conv_name, the normalisation's under
+    norm_scope, and the bias is kept even in front of batch norm."""
+    g = G.get_default_graph()
+    cin = x.get_shape().as_list()[-1]
+    with g.variable_scope(conv_name):
+        weights = utils.get_weight_variable([kernel_size[0], kernel_size[1], cin, num_filters], name='W', type='he_normal',
+                                            regularize=True)
+        biases = utils.get_bias_variable([num_filters], name='b') if add_bias else None
+    kind = tfnorm.KIND[normalisation]
+    norm_vars = tfnorm.make_variables(kind, num_filters, scope=norm_scope)
+    general = None
+    if tuple(strides) != (1, 1) or tuple(kernel_size) not in ((1, 1), (3, 3)):
+        general = (int(kernel_size[0]), int(kernel_size[1]), int(strides[0]), int(strides[1]), 1, 1)
+    return G.conv_unit(x, weights, biases, kernel_size[0], kind, norm_vars, activations.ACT_NAME[activation],
+                       kwargs.get('training', True), num_groups=kwargs.get('num_groups'), head=False, name=conv_name, general=general)
+
+
+def _residual_skip(x, num_filters, down_sample, projection, strides, activation, normalisation, add_bias, kwargs):
+    """the skip path both residual units share (layers.py:462-472, 520-530)"""
+    cin = x.get_shape().as_list()[-1]
+    if cin == num_filters and not down_sample:
+        return x
+    if projection:
+        return _conv_norm(x, 'projection', 'bn_projection', num_filters, strides, (1, 1), normalisation, activation, add_bias, kwargs)
+    pad = (num_filters - cin) // 2
+    _, h, w, _ = x.get_shape().as_list()
+    s = 2 if down_sample else 1
+    # tf.pad along the channel axis, then identity[:, ::2, ::2, :]: one strided window
+    return G.window4(x, -(-h // s), -(-w // s), cin + 2 * pad, stride=(s, s), off=(0, 0, -pad), name='identity')
+
+
+def residual_unit2D(x,
+                    name,
+                    num_filters=32,
+                    down_sample=False,
+                    projection=False,
+                    activation=STANDARD_NONLINEARITY,
+                    normalisation=tfnorm.batch_norm,
+                    add_bias=True,
+                    **kwargs):
+    """tfwrapper/layers.py:428-478 (https://arxiv.org/abs/1512.03385): conv1 -> bn1 -> act -> conv2 -> bn2, + skip, -> act."""
+    if normalisation not in tfnorm.KIND or activation not in activations.ACT_NAME:
+        raise ValueError("Unknown normalisation / activation callable")
+    strides = (2, 2) if down_sample else (1, 1)
+    g = G.get_default_graph()
+    with g.variable_scope(name):
+        conv1 = _conv_norm(x, 'conv1', 'bn1', num_filters, strides, (3, 3), normalisation, activation, add_bias, kwargs)
+        conv2 = _conv_norm(conv1, 'conv2', 'bn2', num_filters, (1, 1), (3, 3), normalisation, activations.identity, add_bias, kwargs)
+        skip = _residual_skip(x, num_filters, down_sample, projection, strides, activation, normalisation, add_bias, kwargs)
+        if skip.get_shape().as_list()[-1] != num_filters:
+            raise ValueError("residual_unit2D: channel padding needs an even difference (%d -> %d)"
+                             % (x.get_shape().as_list()[-1], num_filters))
+        return G.add_act(skip, conv2, activations.ACT_NAME[activation], name='add')
+
+
+def identity_residual_unit2D(x,
+                             name,
+                             num_filters,
+                             down_sample=False,
+                             projection=True,
+                             activation=STANDARD_NONLINEARITY,
+                             normalisation=tfnorm.batch_norm,
+                             add_bias=True,
+                             **kwargs):
+    """tfwrapper/layers.py:481-536 (identity mappings, pre-activation order): bn1 -> act -> conv1 -> bn2 -> act -> conv2, + skip."""
+    if normalisation not in tfnorm.KIND or activation not in activations.ACT_NAME:
+        raise ValueError("Unknown normalisation / activation callable")
+    cin = x.get_shape().as_list()[-1]
+    if not projection:
+        assert (cin == num_filters) or (cin * 2 == num_filters), \
+            'Number of filters must remain constant, or be increased by a ' \
+            'factor of 2. In filters: %d, Out filters: %d' % (cin, num_filters)
+    strides = (2, 2) if down_sample else (1, 1)
+    training = kwargs.get('training', True)
+    kind = tfnorm.KIND[normalisation]
+    an = activations.ACT_NAME[activation]
+    g = G.get_default_graph()
+
+    def conv(t, cname, st):
+        with g.variable_scope(cname):
+            ci = t.get_shape().as_list()[-1]
+            weights = utils.get_weight_variable([3, 3, ci, num_filters], name='W', type='he_normal', regularize=True)
+            biases = utils.get_bias_variable([num_filters], name='b') if add_bias else None
+        general = (3, 3, st[0], st[1], 1, 1) if tuple(st) != (1, 1) else None
+        return G.conv_unit(t, weights, biases, 3, None, {}, 'identity', training, head=False, name=cname, general=general)
+    with g.variable_scope(name):
+        op1 = G.norm_act(x, kind, tfnorm.make_variables(kind, cin, scope='bn1'), an, training, kwargs.get('num_groups'), name='bn1')
+        op1 = conv(op1, 'conv1', strides)
+        op2 = G.norm_act(op1, kind, tfnorm.make_variables(kind, num_filters, scope='bn2'), an, training, kwargs.get('num_groups'),
+                         name='bn2')
+        op2 = conv(op2, 'conv2', (1, 1))
+        skip = _residual_skip(x, num_filters, down_sample, projection, strides, activation, normalisation, add_bias, kwargs)
+        return G.add_act(skip, op2, 'identity', name='add')
+
+
+def reshape_pool2D_layer(x):
+    """tfwrapper/layers.py:57-67: space-to-depth by strided slices, concat([x[:,0::2,0::2], x[:,1::2,0::2], x[:,0::2,1::2],
+    x[:,1::2,1::2]], axis=3)."""
+    _, h, w, c = x.get_shape().as_list()
+    if h % 2 or w % 2:
+        raise ValueError("reshape_pool2D_layer: even spatial sizes (tf.concat of unequal slices fails in the reference too)")
+    parts = [G.window4(x, h // 2, w // 2, c, stride=(2, 2), off=(oy, ox, 0), name='slice') for (oy, ox) in ((0, 0), (1, 0), (0, 1), (1, 1))]
+    out = parts[0]
+    for t in parts[1:]:
+        out = G.concat([out, t], axis=-1)
+    return out
+
+
 def maxpool2D(x, kernel_size=(2, 2), strides=(2, 2), padding="SAME"):
     """tf.nn.max_pool 2x2 / stride 2 / SAME (tfwrapper/layers.py:18-28)."""
     if tuple(kernel_size) != (2, 2) or tuple(strides) != (2, 2) or padding != "SAME":
@@ -259,9 +369,6 @@ def _not_on_hot_path(name):
 
 
 maxpool3D = _not_on_hot_path("maxpool3D")
-reshape_pool2D_layer = _not_on_hot_path("reshape_pool2D_layer")
 conv3D = _not_on_hot_path("conv3D")
 transposed_conv3D = _not_on_hot_path("transposed_conv3D")
 bilinear_upsample3D = _not_on_hot_path("bilinear_upsample3D")
-residual_unit2D = _not_on_hot_path("residual_unit2D")
-identity_residual_unit2D = _not_on_hot_path("identity_residual_unit2D")

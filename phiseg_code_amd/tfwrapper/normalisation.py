@@ -51,22 +51,23 @@ EPS = {"batch": 1e-3, "group": 1e-5, "instance": 1e-5}
 BN_DECAY = 0.99
 
 
-def make_variables(kind, channels):
-    """Create the norm's variables inside the CURRENT scope (the conv's name scope)."""
+def make_variables(kind, channels, scope=None):
+    """Create the norm's variables inside the CURRENT scope (the conv's name scope); `scope` replaces the callable's default
+    scope name (batch_norm / group_norm / instance_norm), as the residual units pass scope='bn1' (layers.py:452-456)."""
     g = G.get_default_graph()
     if kind == "batch":
-        with g.variable_scope("batch_norm"):
+        with g.variable_scope(scope or "batch_norm"):
             with g.variable_scope("BatchNorm"):
                 return dict(beta=g.get_variable("beta", [channels], _zeros),
                             gamma=g.get_variable("gamma", [channels], _ones),
                             moving_mean=g.get_variable("moving_mean", [channels], _zeros, trainable=False),
                             moving_variance=g.get_variable("moving_variance", [channels], _ones, trainable=False))
     if kind == "group":
-        with g.variable_scope("group_norm"):
+        with g.variable_scope(scope or "group_norm"):
             return dict(gamma=g.get_variable("gamma", [1, 1, 1, channels], _ones),
                         beta=g.get_variable("beta", [1, 1, 1, channels], _zeros))
     if kind == "instance":
-        with g.variable_scope("instance_norm"):
+        with g.variable_scope(scope or "instance_norm"):
             return dict(gamma=g.get_variable("scale", [channels], lambda s, rng: 1.0 + 0.02 * rng.standard_normal(s)),
                         beta=g.get_variable("offset", [channels], _zeros))
     return {}

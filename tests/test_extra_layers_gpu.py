@@ -211,3 +211,137 @@ def test_extra_layers_in_a_graph(norm):
     plan2.set_input("x_input", x)
     plan2.run(sync=True)
     assert np.isfinite(plan2.fetch(s)).all()
+
+
+def _oracle_norm(p, t, scope, norm):
+    if norm == "identity":
+        return t
+    if norm == "batch_norm":
+        y, _, _ = T.batch_norm_train(t, p[scope + "/BatchNorm/gamma"], p[scope + "/BatchNorm/beta"])
+        return y
+    return T.group_norm(t, p[scope + "/gamma"], p[scope + "/beta"], 2)
+
+
+def _oracle_skip(p, x, scope, cout, down, proj, norm):
+    cin = x.shape[-1]
+    if cin == cout and not down:
+        return x
+    st = (2, 2) if down else (1, 1)
+    if proj:
+        t = T.bias_add(T.conv2d_general_same(x, p[scope + "/projection/W"], st, (1, 1)), p[scope + "/projection/b"])
+        return T.relu(_oracle_norm(p, t, scope + "/bn_projection", norm))
+    pad = (cout - cin) // 2
+    t = torch.nn.functional.pad(x, (pad, pad))
+    return t[:, ::2, ::2, :] if down else t
+
+
+@pytest.mark.parametrize("norm", ["identity", "batch_norm", "group_norm2D"])
+def test_residual_units_in_a_graph(norm):
+    """residual_unit2D (tfwrapper/layers.py:428-478) and identity_residual_unit2D (:481-536) with every skip variant -- plain,
+    zero-padded channels + strided slice, 1x1 strided projection -- under identity / batch / group norm, as one training plan against
+    torch autograd of the oracle primitives; variable names as the reference's scopes produce them."""
+    from phiseg_code_amd import engine
+    from phiseg_code_amd import graph as G
+    from phiseg_code_amd.tfwrapper import activations as act
+    from phiseg_code_amd.tfwrapper import layers
+    from phiseg_code_amd.tfwrapper import normalisation as tfnorm
+    B, H, C = 2, 8, 2
+    g = G.reset_default_graph()
+    x_inp = G.placeholder(G.KIND_F32, [None, H, H, 4], name="x_input")
+    s_inp = G.placeholder(G.KIND_U8, [None, 2, 2], name="s_input")
+    nfn = getattr(tfnorm, norm)
+    kw = dict(normalisation=nfn, training=True, num_groups=2)
+    with g.variable_scope("net"):
+        r1 = layers.residual_unit2D(x_inp, "r1", num_filters=4, **kw)                                           # plain skip
+        r2 = layers.residual_unit2D(r1, "r2", num_filters=8, down_sample=True, **kw)                            # pad + ::2      -> 4 x 4
+        r3 = layers.residual_unit2D(r2, "r3", num_filters=6, projection=True, **kw)                             # projection
+        i1 = layers.identity_residual_unit2D(r3, "i1", num_filters=6, **kw)                                     # plain skip
+        i2 = layers.identity_residual_unit2D(i1, "i2", num_filters=12, down_sample=True, projection=False, **kw)  # pad + ::2   -> 2 x 2
+        i3 = layers.identity_residual_unit2D(i2, "i3", num_filters=8, projection=True, **kw)
+        s = layers.conv2D(i3, "head", num_filters=C, kernel_size=(1, 1), activation=act.identity)
+    ce, _ = G.residual_multinoulli([s], s_inp, 1.0)
+    loss = G.weighted_sum([ce[0]], [1.0])
+    bn = {"identity": None, "batch_norm": "BatchNorm/gamma", "group_norm2D": "gamma"}[norm]
+    for must in ("net/r1/conv1/W", "net/r1/conv1/b", "net/r3/projection/W", "net/i2/conv2/b") + \
+            (("net/r1/bn1/" + bn, "net/r3/bn_projection/" + bn, "net/i1/bn2/" + bn) if bn else ()):
+        assert must in g.variables, must
+    store = engine.ParamStore(g, seed=3)
+    rng = np.random.default_rng(7)
+    vals = {n: (v.initial_value(3) + (0.1 * rng.standard_normal(v.shape) if not n.endswith("/W") else 0)).astype(np.float32)
+            for n, v in g.variables.items()}
+    for n in vals:
+        if n.endswith("moving_variance"):
+            vals[n] = np.abs(vals[n]) + 0.5
+    store.load(vals)
+    plan = engine.Plan(store, [loss, s], loss=loss, batch=B, training=True, compute_dtype="f32", optimize=False, use_hip_graph=False)
+    x = rng.standard_normal((B, H, H, 4)).astype(np.float32)
+    lab = rng.integers(0, C, (B, 2, 2)).astype(np.uint8)
+    plan.set_input("x_input", x)
+    plan.set_input("s_input", lab)
+    plan.run(sync=True)
+    got_loss, got_s = float(plan.fetch(loss)), plan.fetch(s)
+    grads = store.export(grads=True)
+    p = {n: torch.as_tensor(v, dtype=torch.float64).requires_grad_(not n.rsplit("/", 1)[-1].startswith("moving_")) for n, v in vals.items()}
+
+    def conv(t, scope, st=(1, 1)):
+        return T.bias_add(T.conv2d_general_same(t, p[scope + "/W"], st, (1, 1)), p[scope + "/b"])
+
+    def res(t, scope, cout, down=False, proj=False):
+        st = (2, 2) if down else (1, 1)
+        c1 = T.relu(_oracle_norm(p, conv(t, scope + "/conv1", st), scope + "/bn1", norm))
+        c2 = _oracle_norm(p, conv(c1, scope + "/conv2"), scope + "/bn2", norm)
+        return T.relu(_oracle_skip(p, t, scope, cout, down, proj, norm) + c2)
+
+    def ires(t, scope, cout, down=False, proj=True):
+        st = (2, 2) if down else (1, 1)
+        o1 = conv(T.relu(_oracle_norm(p, t, scope + "/bn1", norm)), scope + "/conv1", st)
+        o2 = conv(T.relu(_oracle_norm(p, o1, scope + "/bn2", norm)), scope + "/conv2")
+        return _oracle_skip(p, t, scope, cout, down, proj, norm) + o2
+    xt = torch.as_tensor(x, dtype=torch.float64)
+    t = res(xt, "net/r1", 4)
+    t = res(t, "net/r2", 8, down=True)
+    t = res(t, "net/r3", 6, proj=True)
+    t = ires(t, "net/i1", 6)
+    t = ires(t, "net/i2", 12, down=True, proj=False)
+    t = ires(t, "net/i3", 8, proj=True)
+    so = T.bias_add(T.conv2d_same(t, p["net/head/W"]), p["net/head/b"])
+    ref = T.multinoulli_loss_with_logits(T.one_hot(torch.as_tensor(lab), C, torch.float64), so)
+    ref.backward()
+    np.testing.assert_allclose(got_s, so.detach().numpy(), rtol=0, atol=5e-4 * float(so.detach().abs().max()))
+    np.testing.assert_allclose(got_loss, float(ref), rtol=5e-5)
+    checked = 0
+    for n, tt in p.items():
+        if tt.grad is None:
+            continue
+        r = tt.grad.numpy()
+        if np.abs(r).max() < 1e-9:
+            assert np.abs(grads[n]).max() < 2e-4, n
+            continue
+        np.testing.assert_allclose(grads[n], r, rtol=0, atol=5e-3 * max(np.abs(r).max(), 1e-6), err_msg=n)
+        checked += 1
+    assert checked >= 20
+
+
+def test_reshape_pool_layer():
+    """reshape_pool2D_layer (layers.py:57-67): space-to-depth by strided slices, forward and gradient through the engine."""
+    from phiseg_code_amd import engine
+    from phiseg_code_amd import graph as G
+    from phiseg_code_amd.tfwrapper import activations as act
+    from phiseg_code_amd.tfwrapper import layers
+    B, H, W, C = 2, 4, 6, 3
+    g = G.reset_default_graph()
+    x_inp = G.placeholder(G.KIND_F32, [None, H, W, C], name="x_input")
+    s_inp = G.placeholder(G.KIND_U8, [None, 2, 2], name="s_input")          # (unused by the check; the loss needs labels)
+    with g.variable_scope("net"):
+        c0 = layers.conv2D(x_inp, "c0", num_filters=C, kernel_size=(1, 1), activation=act.identity)
+        rp = layers.reshape_pool2D_layer(c0)
+    assert rp.get_shape().as_list()[1:] == [2, 3, 12]
+    store = engine.ParamStore(g, seed=1)
+    vals = {"net/c0/W": np.eye(C, dtype=np.float32).reshape(1, 1, C, C), "net/c0/b": np.zeros(C, dtype=np.float32)}
+    store.load(vals)
+    plan = engine.Plan(store, [rp], loss=None, batch=B, training=False, compute_dtype="f32", use_hip_graph=False)
+    x = RNG.standard_normal((B, H, W, C)).astype(np.float32)
+    plan.set_input("x_input", x)
+    plan.run(sync=True)
+    want = np.concatenate([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], axis=3)
+    np.testing.assert_allclose(plan.fetch(rp), want, rtol=0, atol=1e-6)
