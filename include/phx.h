@@ -182,6 +182,9 @@ int phx_head1x1_wgrad_multi(const void* jobs_dev, int njobs, int total_blocks, i
 int phx_norm_stats(const void* x, int dt, float* sums, float* pivot, int NS, int P, int C, void* stream);
 /* partial[T][2][C] (conv epilogue rows) -> sums[1][C][2] */
 int phx_norm_reduce_partials(const float* partial, int T, int C, float* sums, void* stream);
+/* per-sample form for group / instance norm: the convolution's per-tile partial sums partial[ns * T + t][2][C] (T pixel tiles per
+ * sample, tiles of one sample contiguous: maps of at least 16 x 16) -> sums[ns][c][2] (overwritten) */
+int phx_norm_reduce_partials_ns(const float* partial, int T, int NS, int C, float* sums, void* stream);
 int phx_norm_finalize(const float* sums, const float* pivot, const float* gamma, const float* beta, float eps, int NS,
                       int P, int C, int G, float* mean, float* rstd, float* scale, float* shift,
                       float* moving_mean, float* moving_var, float momentum /* 0 => no moving update */,

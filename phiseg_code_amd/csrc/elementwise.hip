@@ -649,6 +649,18 @@ __global__ void k_reduce_partials(const float* __restrict__ partial, int T, int 
     if (threadIdx.x == 0) sums[c * 2 + which] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// per-sample form (group / instance norm): partial[ns * T + t][2][C] -> sums[ns][c][2], T pixel tiles per sample; a thread owns one
+// (which, c) entry of one sample and walks its T tiles (coalesced across the block)
+__global__ void k_reduce_partials_ns(const float* __restrict__ partial, int T, int C, float* __restrict__ sums) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, ns = blockIdx.y;
+    if (i >= 2 * C) return;
+    const float* p = partial + (size_t)ns * T * 2 * C + i;
+    float a = 0.f;
+    for (int t = 0; t < T; ++t) a += p[(size_t)t * 2 * C];
+    const int which = i / C, c = i % C;
+    sums[((size_t)ns * C + c) * 2 + which] = a;
+}
+
 // per (ns, g): mean / rstd; per (ns, c): scale / shift; optional TF1 fused-batch-norm moving update
 __global__ void k_norm_finalize(const float* __restrict__ sums, const float* __restrict__ pivot,
                                 const float* __restrict__ gamma,
@@ -1440,6 +1452,13 @@ int phx_norm_stats(const void* x, int dt, float* sums, float* pivot, int NS, int
 
 int phx_norm_reduce_partials(const float* partial, int T, int C, float* sums, void* stream) {
     hipLaunchKernelGGL(k_reduce_partials, dim3(2 * C), dim3(256), 0, (hipStream_t)stream, partial, T, C, sums);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_norm_reduce_partials_ns(const float* partial, int T, int NS, int C, float* sums, void* stream) {
+    PHX_REQUIRE(partial && sums && T > 0 && NS > 0 && NS < 65536 && C > 0, PHX_E_INVAL, "norm_reduce_partials_ns: bad argument");
+    hipLaunchKernelGGL(k_reduce_partials_ns, dim3((2 * C + 255) / 256, NS), dim3(256), 0, (hipStream_t)stream, partial, T, C, sums);
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }

@@ -27,6 +27,7 @@ F32, BF16, U8 = rt.F32, rt.BF16, 2
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, U8: torch.uint8}
 _NP_DT = {F32: np.float32, U8: np.uint8}
 _ESIZE = {F32: 4, BF16: 2, U8: 1}
+_GN_STATS_EPILOGUE = os.environ.get("PHX_GN_STATS_EPILOGUE", "1") == "1"   # group / instance norm: per-sample sums from the conv epilogue (A/B hook)
 _STATS_ATOMIC = os.environ.get("PHX_STATS_ATOMIC", "1") == "1"           # small-map batch norm: statistics by atomics from the conv epilogue (A/B hook)
 _KL_SIDE = os.environ.get("PHX_KL_SIDE", "0") == "1"                     # two lanes: KL launches on the prior lane (measured 2 % SLOWER: 12.17 vs 11.90 ms)
 _PRIOR_BW_FIRST = os.environ.get("PHX_PRIOR_BW_FIRST", "0") == "1"       # prior backward emitted before the likelihood's (A/B hook)
@@ -944,6 +945,14 @@ class Plan:
                 # few pixel tiles (the H <= 16 levels): the convolution adds its statistics straight into `sums` -- no pass over y
                 self._emit(Lb.conv3x3_mfma_bf16_stats_atomic, x.ptr, wf.ptr, y.ptr, bptr, 0, sums.ptr, B, H, Wd, cin_eff, cout, S,
                            tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
+            elif (norm != "batch" and mfma and _GN_STATS_EPILOGUE and not head1x1 and self.act_dt == BF16 and H % 16 == 0 and Wd % 16 == 0
+                  and Lb.conv3x3_mfma_bf16_tiles(B, H, Wd, cin_eff, cout) % B == 0):
+                # group / instance norm on maps of at least 16 x 16: a pixel tile lies inside one sample, so the convolution's per-tile
+                # sums reduce to per-sample sums without another pass over y (phx_norm_reduce_partials_ns)
+                ntile = Lb.conv3x3_mfma_bf16_tiles(B, H, Wd, cin_eff, cout)
+                part = self._alloc((ntile * 2 * cout,), F32)
+                conv_into(y, 0, stats_part=part)
+                self._emit(Lb.norm_reduce_partials_ns, part.ptr, ntile // B, B, cout, sums.ptr, S)
             elif norm == "batch" and not small and not _DETERMINISTIC:
                 conv_into(y, 0, stats_direct=sums)        # (direct kernels add their tiles' sums atomically)
             else:

@@ -6,8 +6,8 @@ sys.path.insert(0, ".")
 from phiseg_code_amd import runtime as rt
 L = rt.lib()
 st = torch.cuda.current_stream().cuda_stream
-shapes = [(64, 16, 16, 192, 192), (64, 16, 16, 384, 192), (64, 8, 8, 192, 192), (64, 4, 4, 192, 192), (64, 2, 2, 192, 192),
-          (64, 8, 8, 384, 192), (64, 4, 4, 384, 192)]
+shapes = [(64, 32, 32, 128, 128), (64, 32, 32, 192, 192), (64, 16, 16, 192, 192), (64, 16, 16, 384, 192), (64, 8, 8, 192, 192),
+          (64, 4, 4, 192, 192), (64, 2, 2, 192, 192), (64, 8, 8, 384, 192), (64, 4, 4, 384, 192)]
 def timeit(fn, n=50):
     for _ in range(5): fn()
     torch.cuda.synchronize()
