@@ -345,3 +345,33 @@ def test_reshape_pool_layer():
     plan.run(sync=True)
     want = np.concatenate([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], axis=3)
     np.testing.assert_allclose(plan.fetch(rp), want, rtol=0, atol=1e-6)
+
+
+def test_window4_add_act_and_per_sample_partial_reduction(L):
+    """phx_window4_fwd / _bwd (strided window with a channel offset), phx_add_act and phx_norm_reduce_partials_ns through the C ABI."""
+    x = RNG.standard_normal((2, 7, 6, 4)).astype(np.float32)
+    xd = dev(x)
+    # zero-padded channels (1 in front, 1 behind) + [:, ::2, ::2, :]
+    out = torch.full((2, 4, 3, 6), 9.0).cuda()
+    L.window4_fwd(xd.data_ptr(), out.data_ptr(), F32, 2, 7, 6, 4, 4, 3, 6, 2, 2, 0, 0, -1, S())
+    want = np.pad(x, ((0, 0), (0, 0), (0, 0), (1, 1)))[:, ::2, ::2, :]
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+    d = RNG.standard_normal((2, 4, 3, 6)).astype(np.float32)
+    dd, dx = dev(d), torch.full((2, 7, 6, 4), 9.0).cuda()
+    L.window4_bwd(dd.data_ptr(), dx.data_ptr(), F32, 2, 7, 6, 4, 4, 3, 6, 2, 2, 0, 0, -1, S())
+    ref = np.zeros_like(x)
+    ref[:, ::2, ::2, :] = d[..., 1:5]
+    np.testing.assert_array_equal(dx.cpu().numpy(), ref)
+    # act(a + b), bf16
+    a, b = torch.randn(1000, device="cuda").to(torch.bfloat16), torch.randn(1000, device="cuda").to(torch.bfloat16)
+    y = torch.empty_like(a)
+    L.add_act(a.data_ptr(), b.data_ptr(), y.data_ptr(), BF16, 1000, 1, S())
+    assert torch.equal(y, torch.relu(a.float() + b.float()).to(torch.bfloat16))
+    # per-sample reduction of per-tile partial sums: partial[ns * T + t][2][C] -> sums[ns][c][2]
+    NS, Tt, C = 5, 7, 24
+    part = RNG.standard_normal((NS * Tt, 2, C)).astype(np.float32)
+    pd = dev(part)
+    sums = torch.full((NS, C, 2), 3.0).cuda()
+    L.norm_reduce_partials_ns(pd.data_ptr(), Tt, NS, C, sums.data_ptr(), S())
+    want = part.reshape(NS, Tt, 2, C).sum(axis=1).transpose(0, 2, 1)
+    close(sums.cpu().numpy(), want, 1e-6, "per-sample partial reduction (overwrites)")
