@@ -70,43 +70,18 @@ static bool fwd_big_tiles(int B, int H, int W, int K, int N) {
     if (en == 2) return true;                                  // dev: force
     return (N % 128 == 0 || (N == 32 && K >= 128)) && (long)B * (H / 32) * (W / 16) >= 512;
 }
-// 32 x 16-tile LDS-DMA kernel (k_conv3x3_fwd_dma): 0 = not used, else the channel-block width
-static int fwd_dma_bn(int B, int H, int W, int K, int N) {
-    // Measured (tools/bench_wgrad.py, tools/blocklog.py): 776 vs 826 TFLOP/s against the register-staged 8-wave kernel on
-    // the 128->128 @ 128x128 layer.  16-channel stages fetch 32 contiguous bytes per pixel / filter row, half a 64-byte
-    // sector, so the staging path moves twice the bytes it delivers (7.7 K cycles per stage against 4.6 K of MFMA work), and
-    // one block per CU pays ~6 K cycles of dispatch gap per tile.  Kept as a tested experimental path: off by default.
-    const char* e = getenv("PHX_FWD_DMA");                     // default 0: never; 1: policy; 2: whenever eligible (tests)
-    const int en = e ? atoi(e) : 0;
-    if (!en || H % 16 != 0 || W % 32 != 0 || K % 16 != 0 || N % 64 != 0) return 0;
-    const int bn = N % 128 == 0 ? 128 : 64;
-    if (en == 2) return bn;
-    if (en == 3) return 64;                                    // tuning: 64-wide blocks everywhere
-    return (N % 128 == 0 && (long)B * (H / 16) * (W / 32) >= 512) ? 128 : 0;
-}
-// register-staged 32 x 16-tile kernel (k_conv3x3_fwd_rs): 0 = not used, else the channel-block width
-static int fwd_rs_bn(int B, int H, int W, int K, int N) {
-    const char* e = getenv("PHX_FWD_RS");                      // 0: never; 1: policy; 2: whenever eligible (tests); 3: 64-wide everywhere
-    const int en = e ? atoi(e) : 0;
-    if (!en || H % 16 != 0 || W % 32 != 0 || N % 64 != 0) return 0;
-    const int bn = N % 128 == 0 ? 128 : 64;
-    if (en == 2) return bn;
-    if (en == 3) return 64;
-    return (N % 128 == 0 && (long)B * (H / 16) * (W / 32) >= 512) ? 128 : 0;
-}
-// 32 x 16-pixel tiles x 64 channels, LDS-DMA staged (PHX_FWD_WS selects the kernel):
-//   unset / 1: policy -- k_conv3x3_fwd_dma128 (128-pixel wave tiles, one 75 KiB stage per block, two blocks per CU) when the map
-//              has at least 512 such blocks (the 128x128 and 64x64 levels at batch 64): measured 1.1-1.3x the 256-pixel kernels
-//              there, equal on 32x32 maps
-//   0: never;  5: dma128 whenever the shape is eligible (tests);  2 / 3 / 4: the wave-specialised experiments (ws64, ws128)
+// 16 x 32-pixel tiles, LDS-DMA staged (PHX_FWD_WS selects):
+//   unset / 1: policy -- when the map has at least 512 blocks of 16 x 32 pixels x 64 (32) channels (the 128 x 128 and 64 x 64
+//              levels at batch 64): measured 1.1-1.3x the 256-pixel kernels there, equal on 32 x 32 maps
+//   0: never;  5: whenever the shape is eligible (tests)
+// PHX_FWD_DB=1: the experimental double-buffered persistent kernel k_conv3x3_fwd_db (conv_db.hip) takes the N % 64 == 0 shapes
 static int fwd_ws_mode() {
-    const char* e = getenv("PHX_FWD_WS");
+    const char* e = getenv("PHX_FWD_WS");                      // (tests flip it between calls: not cached)
     return e ? atoi(e) : 1;
 }
 static bool fwd_ws64(int B, int H, int W, int K, int N) {
     const int en = fwd_ws_mode();
-    const bool dma128 = en == 1 || en == 5;                    // (the 32-channel-block variant exists for dma128 only)
-    if (!en || H % 16 != 0 || W % 32 != 0 || N % (dma128 ? 32 : 64) != 0 || K % 32 != 0) return false;
+    if (!en || H % 16 != 0 || W % 32 != 0 || N % 32 != 0 || K % 32 != 0) return false;
     if (en >= 2) return true;
     // 32-channel blocks: 13 % faster than the 64-pixel-tile kernel at K = 32 (39 vs 45 us on 64 x 128 x 128), 8 % at K = 64,
     // 5 % SLOWER at K = 192 (the patch is staged once per 32 output channels)
@@ -116,7 +91,7 @@ static bool fwd_ws64(int B, int H, int W, int K, int N) {
     return (long)B * (H / 16) * (W / 32) * (N / (N % 64 == 0 ? 64 : 32)) >= 512;
 }
 static MTile make_mtile_fwd(int B, int H, int W, int K, int N, bool allow_dma = true) {
-    if (allow_dma && (fwd_ws64(B, H, W, K, N) || fwd_dma_bn(B, H, W, K, N) || fwd_rs_bn(B, H, W, K, N))) {
+    if (allow_dma && fwd_ws64(B, H, W, K, N)) {
         MTile g;
         g.tws = 5; g.ths = 4; g.tb = 1;
         g.tiles_x = W / 32; g.tiles_y = H / 16; g.tiles_b = B;
@@ -231,11 +206,12 @@ __global__ void k_unpad_rows_acc(const float* __restrict__ dwp, float* __restric
     }
 }
 
-// ping-pong persistent kernel for large maps (conv_pp.hip)
-bool phx_pp_eligible(int B, int H, int W, int K, int N);
-int phx_pp_partial_rows(int B, int H, int W);
-int phx_pp_launch(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial, int B, int H,
-                  int W, int K, int N, void* stream);
+// double-buffered persistent kernel for large maps (conv_db.hip)
+bool phx_db_enabled();
+int phx_db_set_trace(void* dev_buf);
+int phx_db_partial_rows(int B, int H, int W);
+int phx_db_launch(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial, int B, int H,
+                  int W, int K, int N, const float* oscale, int dbg, void* stream);
 
 // ---- forward / dgrad ----------------------------------------------------------------------------------
 __device__ unsigned long long* g_phx_trace = nullptr;      // debug: phase timestamps of block (0,0,0), thread 0
@@ -666,808 +642,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
     PHX_BLOCKLOG_END();
 }
 
-// ---- forward / data-gradient, 32x16-pixel tiles, LDS-DMA staging -----------------------------------------------------
-// The kernels above are bound by the global -> LDS path, i.e. by staged bytes per FLOP.  This one stages 16-channel
-// slices of a 512-pixel (32 x 16) patch and of a BN-wide filter slab with buffer_load ... lds (no staging registers, no
-// ds_write pass) into a DOUBLE-BUFFERED LDS image: the DMA of stage s+2 is issued right after the MFMAs of stage s and
-// lands under those of stage s+1 (counted vmcnt, raw s_barrier).  8 waves: wave = (pixel group pg of 4 tile rows) x
-// (channel half cg); 4 x NJ accumulators of 32 px x 32 ch per wave.
-// LDS rows are 32 bytes (16 channels), two 16-byte slots; slot = k-half ^ bit 3 of (patch column | channel), applied on
-// the DMA source side (the destination is lane-linear): a ds_read_b128 lane group then covers all 16 slots of the
-// 256-byte bank row exactly once, and every read address is a per-lane base plus an immediate.
-template <int BN, bool BIASACT>
-__global__ __launch_bounds__(512, 1) void k_conv3x3_fwd_dma(const unsigned short* __restrict__ x,
-                                                            const unsigned short* __restrict__ wpk,
-                                                            unsigned short* __restrict__ y, const float* __restrict__ bias,
-                                                            int act, float* __restrict__ stats_partial,
-                                                            int B, int H, int W, int K, int N, int tiles_x, int tiles_y) {
-    constexpr int NJ = BN / 64;                       // 32-channel accumulator tiles per wave
-    constexpr int AI = 20, BI = 9 * BN * 32 / 1024;   // 1 KiB DMA instructions per stage: patch (612 rows -> 20), slab
-    constexpr int NPW = (AI + BI + 7) / 8;            // per wave (7 for BN = 128; 5 with two dummies for BN = 64)
-    constexpr int STAGE = NPW * 8 * 1024;
-    constexpr int A_BYTES = AI * 1024;
-    constexpr int OROW = BN * 2 + 16;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int t = blockIdx.x;
-    const int tx0 = (t % tiles_x) << 5; t /= tiles_x;
-    const int ty0 = (t % tiles_y) << 4; t /= tiles_y;
-    const int b0 = t;
-    const int n0 = blockIdx.y * BN;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int l31 = lane & 31, khalf = lane >> 5;
-    const int pg = wave & 3, cg = wave >> 2;
-
-    // DMA plan: instruction j = wave + 8 n fills LDS bytes [j KiB, (j+1) KiB) of the stage; this lane's slot e = 64 j + lane
-    unsigned voff[NPW];
-#pragma unroll
-    for (int n = 0; n < NPW; ++n) {
-        const int j = wave + 8 * n;
-        voff[n] = 0xffffffffu;
-        if (j < AI) {
-            const int e = j * 64 + lane, pp = e >> 1, slot = e & 1;
-            const int py = pp / 34, px = pp - py * 34;
-            const int h = slot ^ ((px >> 3) & 1);
-            const int gx = tx0 + px - 1, gy = ty0 + py - 1;
-            if (pp < 612 && gx >= 0 && gx < W && gy >= 0 && gy < H) voff[n] = (unsigned)((((b0 * H + gy) * W + gx) * K) * 2 + h * 16);
-        } else if (j < AI + BI) {
-            const int e = (j - AI) * 64 + lane, rb = e >> 1, slot = e & 1;
-            const int tap = rb / BN, nn = rb - tap * BN;
-            const int h = slot ^ ((nn >> 3) & 1);
-            voff[n] = (unsigned)(((tap * N + n0 + nn) * 32) * 2 + h * 16);
-        }
-    }
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K * 2u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, (int)(9u * N * K * 2u), 0x00020000);
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    // all NPW DMA instructions of one stage (channels 16 stage ..) into buffer buf
-#define FWD_DMA_ISSUE(stage, buf)                                                                                      \
-    _Pragma("unroll") for (int n_ = 0; n_ < NPW; ++n_) {                                                               \
-        const int j_ = wave + 8 * n_;                                                                                  \
-        if (j_ < AI)                                                                                                   \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + (buf) * STAGE + j_ * 1024), 16, (int)voff[n_],\
-                                                     (stage) * 32, 0, 0);                                              \
-        else                                                                                                           \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(smem + (buf) * STAGE + j_ * 1024), 16, (int)voff[n_],\
-                                                     ((stage) >> 1) * 9 * N * 64 + ((stage) & 1) * 32, 0, 0);          \
-    }
-
-    // per-lane read bases (stage 0); tap / row-tile / channel-tile terms are immediates
-    unsigned aK[3], bK;
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw)
-        aK[kw] = (unsigned)((pg * 4 * 34 + l31 + kw) * 32 + (((khalf ^ ((l31 + kw) >> 3)) & 1) << 4));
-    bK = (unsigned)(A_BYTES + (cg * (BN / 2) + l31) * 32 + (((khalf ^ (l31 >> 3)) & 1) << 4));
-
-    f32x16 acc[4][NJ];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    PHX_BLOCKLOG_BEGIN();
-    const int nst = K / 16;
-    FWD_DMA_ISSUE(0, 0)
-    if (nst > 1) { FWD_DMA_ISSUE(1, 1) }
-    for (int s = 0; s < nst; ++s) {
-        // stage s has landed once at most the NPW instructions of stage s+1 are still outstanding
-        if (s + 1 < nst) {
-            if constexpr (NPW == 7) asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        }
-        const unsigned sb = (unsigned)((s & 1) * STAGE);
-        // nine taps: fragments of tap t+1 are read before the MFMAs of tap t (double-buffered, order pinned)
-        bf16x8 fa[2][4], fb[2][NJ];
-        auto read_frags = [&](auto tc) {
-            constexpr int tp = decltype(tc)::value;
-            constexpr int kh = tp / 3, kw = tp % 3;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                fa[tp & 1][i] = *reinterpret_cast<const bf16x8*>(smem + sb + aK[kw] + (i + kh) * 34 * 32);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                fb[tp & 1][j] = *reinterpret_cast<const bf16x8*>(smem + sb + bK + (tp * BN + j * 32) * 32);
-        };
-        read_frags(std::integral_constant<int, 0>());
-        auto taps = [&](auto self, auto tc) {
-            constexpr int tp = decltype(tc)::value;
-            if constexpr (tp < 9) {
-                if constexpr (tp < 8) read_frags(std::integral_constant<int, tp + 1>());
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tp & 1][i], fb[tp & 1][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                self(self, std::integral_constant<int, tp + 1>());
-            }
-        };
-        taps(taps, std::integral_constant<int, 0>());
-        if (s + 2 < nst) {
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done reading this buffer
-            FWD_DMA_ISSUE(s + 2, s & 1)
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // operand reads done: LDS becomes the output tile
-
-    // epilogue (interior tiles only): pack pairs of rows, statistics, transpose through LDS, 16-byte stores
-    if constexpr (BIASACT) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const float bv = bias ? bias[n0 + cg * (BN / 2) + j * 32 + l31] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r] + bv, act);
-        }
-    }
-    const int odd = lane & 1;
-    float s1[NJ], s2[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) s1[j] = s2[j] = 0.f;
-    unsigned char* lw = smem + (pg * 128 + 4 * khalf + odd) * OROW + (cg * (BN / 2) + (l31 & ~1)) * 2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int rp = 0; rp < 8; ++rp)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int r0 = 2 * rp;
-                const unsigned w2 = f2bf_pk(acc[i][j][r0], acc[i][j][r0 + 1]);
-                const float ra_ = __uint_as_float(w2 << 16), rb_ = __uint_as_float(w2 & 0xffff0000u);
-                s1[j] += ra_ + rb_;
-                s2[j] += ra_ * ra_ + rb_ * rb_;
-                const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)w2, 0xB1, 0xf, 0xf, true);
-                const unsigned word = odd ? ((nb >> 16) | (w2 & 0xffff0000u)) : ((w2 & 0xffffu) | (nb << 16));
-                *reinterpret_cast<unsigned*>(lw + (i * 32 + (r0 & 3) + 8 * (r0 >> 2)) * OROW + j * 64) = word;
-            }
-    __syncthreads();
-    {
-        constexpr int PPP = BN / 8;                   // 16-byte pieces per pixel
-        constexpr int PSTEP = 512 / PPP;              // pixels between a thread's pieces: 32 (one tile row) or 64
-        const int mt = threadIdx.x / PPP, q = threadIdx.x % PPP;
-        const unsigned char* lr = smem + mt * OROW + q * 16;
-        unsigned short* yp = y + (((size_t)b0 * H + ty0 + (mt >> 5)) * W + tx0 + (mt & 31)) * N + n0 + q * 8;
-        const size_t ystep = (size_t)(PSTEP / 32) * W * N;
-#pragma unroll
-        for (int it = 0; it < PPP; ++it)
-            *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * PSTEP * OROW);
-    }
-    if (stats_partial) {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);      // [4 pixel groups][2][BN]
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const float a = s1[j] + __shfl_xor(s1[j], 32, 64);
-            const float bq = s2[j] + __shfl_xor(s2[j], 32, 64);
-            if (khalf == 0) {
-                red[(pg * 2 + 0) * BN + cg * (BN / 2) + j * 32 + l31] = a;
-                red[(pg * 2 + 1) * BN + cg * (BN / 2) + j * 32 + l31] = bq;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 2 * BN) {
-            const int which = threadIdx.x / BN, n = threadIdx.x % BN;
-            const float v = (red[(0 * 2 + which) * BN + n] + red[(1 * 2 + which) * BN + n]) +
-                            (red[(2 * 2 + which) * BN + n] + red[(3 * 2 + which) * BN + n]);
-            stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + n] = v;
-        }
-    }
-    PHX_BLOCKLOG_END();
-#undef FWD_DMA_ISSUE
-}
-// ---- forward / data-gradient, 32x16-pixel tiles, register staging into double-buffered 16-channel LDS halves ----------
-// Tile geometry, LDS image (32-byte rows, source/slot swizzle), operand reads and epilogue of k_conv3x3_fwd_dma; the
-// staging differs: 64-byte global rows (full sectors, unlike that kernel's 32-byte DMA pieces) into registers, split into
-// the two 16-channel halves on the way into LDS.
-template <int BN, bool BIASACT>
-__global__ __launch_bounds__(512, 1) void k_conv3x3_fwd_rs(const unsigned short* __restrict__ x,
-                                                            const unsigned short* __restrict__ wpk,
-                                                            unsigned short* __restrict__ y, const float* __restrict__ bias,
-                                                            int act, float* __restrict__ stats_partial,
-                                                            int B, int H, int W, int K, int N, int tiles_x, int tiles_y) {
-    constexpr int NJ = BN / 64;                       // 32-channel accumulator tiles per wave
-    constexpr int NA = 5;                             // 612 patch rows x four 16-byte pieces / 512 threads
-    constexpr int NB = (9 * BN * 4 + 511) / 512;      // slab pieces per thread (9 for BN = 128, 4.5 -> 5 for BN = 64)
-    constexpr int A_BYTES = 640 * 32;                 // patch region of one 16-channel stage (612 rows used)
-    constexpr int STAGE = A_BYTES + 9 * BN * 32;
-    constexpr int OROW = BN * 2 + 16;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int t = blockIdx.x;
-    const int tx0 = (t % tiles_x) << 5; t /= tiles_x;
-    const int ty0 = (t % tiles_y) << 4; t /= tiles_y;
-    const int b0 = t;
-    const int n0 = blockIdx.y * BN;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int l31 = lane & 31, khalf = lane >> 5;
-    const int pg = wave & 3, cg = wave >> 2;
-
-    // Staging plan.  Piece i = tid + 512 it is the 16-byte quarter q = tid & 3 of row (tid >> 2) + 128 it: global loads
-    // fetch whole 64-byte (32-channel) rows -- full sectors -- while the LDS image holds 16-channel HALVES: quarters 0, 1
-    // ("lo" lanes) belong to the stage buffer of channels 0..15 of the chunk, quarters 2, 3 ("hi" lanes) to 16..31.
-    const int q = threadIdx.x & 3, rowt = threadIdx.x >> 2;
-    const bool hi = q >= 2;
-    unsigned gA[NA];
-    int lA[NA];
-#pragma unroll
-    for (int it = 0; it < NA; ++it) {
-        const int pp = rowt + it * 128;
-        const int py = pp / 34, px = pp - py * 34;
-        const int gx = tx0 + px - 1, gy = ty0 + py - 1;
-        gA[it] = 0xffffffffu;
-        lA[it] = pp < 612 ? pp * 32 + ((((q & 1) ^ (px >> 3)) & 1) << 4) : -1;
-        if (pp < 612 && gx >= 0 && gx < W && gy >= 0 && gy < H) gA[it] = (unsigned)((((b0 * H + gy) * W + gx) * K) * 2 + q * 16);
-    }
-    // slab rows advance 128 per piece: whole taps (BN = 128: one, BN = 64: two) -> scalar strides
-    const int rb0 = rowt, tap0 = rb0 / BN, nn0 = rb0 - tap0 * BN;
-    const unsigned gB0 = (unsigned)(((tap0 * N + n0 + nn0) * 32 + q * 8) * 2);
-    const int lB0 = A_BYTES + rb0 * 32 + ((((q & 1) ^ (nn0 >> 3)) & 1) << 4);
-    const int gBs = (128 / BN) * N * 64;              // global bytes between a thread's consecutive slab pieces
-    const bool lastB = threadIdx.x + (NB - 1) * 512 < 9 * BN * 4;
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K * 2u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, (int)(9u * N * K * 2u), 0x00020000);
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    u32x4 rA[NA], rB[NB];
-    auto load_chunk = [&](int c) {                    // 32-channel chunk c -> registers (zeros outside the image)
-#pragma unroll
-        for (int it = 0; it < NA; ++it) rA[it] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (PHX_ABLATE & 128) ? -1 : (int)gA[it], c * 64, 0);
-#pragma unroll
-        for (int it = 0; it < NB; ++it)
-            rB[it] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)(((PHX_ABLATE & 128) || (it == NB - 1 && !lastB)) ? 0xffffffffu : gB0),
-                                                           c * 9 * N * 64 + it * gBs, 0);
-    };
-    auto write_half = [&]() {                         // this lane's pieces -> its half's stage buffer
-        unsigned char* base = smem + (hi ? STAGE : 0);
-#pragma unroll
-        for (int it = 0; it < NA; ++it)
-            if (lA[it] >= 0) *reinterpret_cast<u32x4*>(base + lA[it]) = rA[it];
-#pragma unroll
-        for (int it = 0; it < NB; ++it)
-            if (it < NB - 1 || lastB) *reinterpret_cast<u32x4*>(base + lB0 + it * 4096) = rB[it];
-    };
-
-    // per-lane read bases (stage 0); tap / row-tile / channel-tile terms are immediates
-    unsigned aK[3], bK;
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw)
-        aK[kw] = (unsigned)((pg * 4 * 34 + l31 + kw) * 32 + (((khalf ^ ((l31 + kw) >> 3)) & 1) << 4));
-    bK = (unsigned)(A_BYTES + (cg * (BN / 2) + l31) * 32 + (((khalf ^ (l31 >> 3)) & 1) << 4));
-
-    f32x16 acc[4][NJ];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    PHX_BLOCKLOG_BEGIN();
-    // Pipeline over 16-channel stages s (chunk s >> 1, half s & 1), buffer s & 1.  Both buffers are free at the start, so
-    // chunk 0 goes in whole; afterwards the "lo" lanes refill buffer 0 during the odd stages (which read buffer 1) and the
-    // "hi" lanes buffer 1 during the even ones, each lane reloading its registers with the next chunk right after its own
-    // write -- two stages ahead of use.  One barrier per stage, no phase without MFMAs.
-    const int nst = K / 16, nch = K / 32;
-    load_chunk(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    write_half();
-    if (nch > 1) load_chunk(1);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    for (int s = 0; s < nst; ++s) {
-        const int cw = (s + 1) >> 1;                   // chunk whose half gets written during this stage
-        if (s >= 1 && cw < nch && hi == ((s & 1) == 0)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            write_half();
-            if (cw + 1 < nch) load_chunk(cw + 1);
-        }
-        const unsigned sb = (unsigned)((s & 1) * STAGE);
-        bf16x8 fa[2][4], fb[2][NJ];
-        auto read_frags = [&](auto tc) {
-            constexpr int tp = decltype(tc)::value;
-            constexpr int kh = tp / 3, kw = tp % 3;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                fa[tp & 1][i] = *reinterpret_cast<const bf16x8*>(smem + sb + aK[kw] + (i + kh) * 34 * 32);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                fb[tp & 1][j] = *reinterpret_cast<const bf16x8*>(smem + sb + bK + (tp * BN + j * 32) * 32);
-        };
-        read_frags(std::integral_constant<int, 0>());
-        auto taps = [&](auto self, auto tc) {
-            constexpr int tp = decltype(tc)::value;
-            if constexpr (tp < 9) {
-                if constexpr (tp < 8) read_frags(std::integral_constant<int, tp + 1>());
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        if constexpr (PHX_ABLATE & 64) acc[i][j][0] += (float)fa[tp & 1][i][0] * (float)fb[tp & 1][j][0];
-                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tp & 1][i], fb[tp & 1][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                self(self, std::integral_constant<int, tp + 1>());
-            }
-        };
-        taps(taps, std::integral_constant<int, 0>());
-        if (s + 1 < nst) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");             // operand reads done: LDS becomes the output tile
-
-    // epilogue (interior tiles only): pack pairs of rows, statistics, transpose through LDS, 16-byte stores
-    if constexpr (BIASACT) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const float bv = bias ? bias[n0 + cg * (BN / 2) + j * 32 + l31] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r] + bv, act);
-        }
-    }
-    const int odd = lane & 1;
-    float s1[NJ], s2[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) s1[j] = s2[j] = 0.f;
-    unsigned char* lw = smem + (pg * 128 + 4 * khalf + odd) * OROW + (cg * (BN / 2) + (l31 & ~1)) * 2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int rp = 0; rp < 8; ++rp)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int r0 = 2 * rp;
-                const unsigned w2 = f2bf_pk(acc[i][j][r0], acc[i][j][r0 + 1]);
-                const float ra_ = __uint_as_float(w2 << 16), rb_ = __uint_as_float(w2 & 0xffff0000u);
-                s1[j] += ra_ + rb_;
-                s2[j] += ra_ * ra_ + rb_ * rb_;
-                const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)w2, 0xB1, 0xf, 0xf, true);
-                const unsigned word = odd ? ((nb >> 16) | (w2 & 0xffff0000u)) : ((w2 & 0xffffu) | (nb << 16));
-                *reinterpret_cast<unsigned*>(lw + (i * 32 + (r0 & 3) + 8 * (r0 >> 2)) * OROW + j * 64) = word;
-            }
-    __syncthreads();
-    {
-        constexpr int PPP = BN / 8;                   // 16-byte pieces per pixel
-        constexpr int PSTEP = 512 / PPP;              // pixels between a thread's pieces: 32 (one tile row) or 64
-        const int mt = threadIdx.x / PPP, q = threadIdx.x % PPP;
-        const unsigned char* lr = smem + mt * OROW + q * 16;
-        unsigned short* yp = y + (((size_t)b0 * H + ty0 + (mt >> 5)) * W + tx0 + (mt & 31)) * N + n0 + q * 8;
-        const size_t ystep = (size_t)(PSTEP / 32) * W * N;
-#pragma unroll
-        for (int it = 0; it < PPP; ++it)
-            *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * PSTEP * OROW);
-    }
-    if (stats_partial) {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);      // [4 pixel groups][2][BN]
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const float a = s1[j] + __shfl_xor(s1[j], 32, 64);
-            const float bq = s2[j] + __shfl_xor(s2[j], 32, 64);
-            if (khalf == 0) {
-                red[(pg * 2 + 0) * BN + cg * (BN / 2) + j * 32 + l31] = a;
-                red[(pg * 2 + 1) * BN + cg * (BN / 2) + j * 32 + l31] = bq;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 2 * BN) {
-            const int which = threadIdx.x / BN, n = threadIdx.x % BN;
-            const float v = (red[(0 * 2 + which) * BN + n] + red[(1 * 2 + which) * BN + n]) +
-                            (red[(2 * 2 + which) * BN + n] + red[(3 * 2 + which) * BN + n]);
-            stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + n] = v;
-        }
-    }
-    PHX_BLOCKLOG_END();
-}
-
-// ---- forward / data-gradient, 32x16-pixel tiles x 64 channels, wave-specialised: 8 MFMA waves + 2 loader waves ----------
-// Ablation of the kernels above (tools/build_ablate.sh) shows their load and MFMA costs ADD: a wave that is issuing global
-// loads cannot issue MFMAs, interleaved or not.  Here the staging is taken out of the MFMA waves altogether: waves 8 and 9
-// only issue buffer_load ... lds DMA for the NEXT 32-channel chunk (whole 64-byte rows -> full sectors; double-buffered
-// 75 KiB stages) and wait for it to land, waves 0-7 only read operands and issue MFMAs (64 pixels x 64 channels each);
-// one s_barrier per chunk hands the buffers over.  512 pixels per slab fetch: 248 FLOP per staged byte (164 with 256).
-// LDS rows are 64 bytes, four 16-byte slots, slot ^= bits 2-3 of the patch column / channel (source-side for the DMA).
-template <bool BIASACT>
-__global__ __launch_bounds__(640, 1) void k_conv3x3_fwd_ws64(const unsigned short* __restrict__ x,
-                                                            const unsigned short* __restrict__ wpk,
-                                                            unsigned short* __restrict__ y, const float* __restrict__ bias,
-                                                            int act, float* __restrict__ stats_partial,
-                                                            int B, int H, int W, int K, int N, int tiles_x, int tiles_y) {
-    constexpr int BN = 64;
-    constexpr int AI = 39, BI = 36;                   // 1 KiB DMA instructions per chunk: 612 patch rows x 64 B, 576 slab rows
-    constexpr int NI = AI + BI, NPL = (NI + 1) / 2;   // per loader wave
-    constexpr int A_BYTES = AI * 1024, STAGE = NI * 1024;
-    constexpr int OROW = BN * 2 + 16;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int t = blockIdx.x;
-    const int tx0 = (t % tiles_x) << 5; t /= tiles_x;
-    const int ty0 = (t % tiles_y) << 4; t /= tiles_y;
-    const int b0 = t;
-    const int n0 = blockIdx.y * BN;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int l31 = lane & 31, khalf = lane >> 5;
-    const bool loader = wave >= 8;
-    const int nch = K / 32;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    PHX_BLOCKLOG_BEGIN();
-
-    if (loader) {
-        // ---- loader waves: instruction j = (wave - 8) + 2 n fills LDS bytes [j KiB, (j + 1) KiB) of the stage
-        const int lw = wave - 8;
-        unsigned voff[NPL];
-#pragma unroll
-        for (int n = 0; n < NPL; ++n) {
-            const int j = lw + 2 * n;
-            voff[n] = 0xffffffffu;
-            if (j < AI) {
-                const int e = j * 64 + lane, pp = e >> 2, slot = e & 3;
-                const int py = pp / 34, px = pp - py * 34;
-                const int piece = slot ^ ((px >> 2) & 3);
-                const int gx = tx0 + px - 1, gy = ty0 + py - 1;
-                if (pp < 612 && gx >= 0 && gx < W && gy >= 0 && gy < H) voff[n] = (unsigned)((((b0 * H + gy) * W + gx) * K) * 2 + piece * 16);
-            } else if (j < NI) {
-                const int e = (j - AI) * 64 + lane, rb = e >> 2, slot = e & 3;
-                const int tap = rb >> 6, nn = rb & 63;
-                const int piece = slot ^ ((nn >> 2) & 3);
-                voff[n] = (unsigned)(((tap * N + n0 + nn) * 32 + piece * 8) * 2);
-            }
-        }
-        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K * 2u), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, (int)(9u * N * K * 2u), 0x00020000);
-        typedef __attribute__((address_space(3))) void* lds_ptr_t;
-        for (int c = -1; c < nch; ++c) {               // c = -1: prologue (chunk 0); chunk c: stage chunk c + 1
-            if (c + 1 < nch) {
-                const int cn = c + 1, buf = cn & 1;
-#pragma unroll
-                for (int n = 0; n < NPL; ++n) {
-                    const int j = lw + 2 * n;
-                    if (j < AI)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + buf * STAGE + j * 1024), 16, (int)voff[n],
-                                                                 cn * 64, 0, 0);
-                    else if (j < NI)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(smem + buf * STAGE + j * 1024), 16, (int)voff[n],
-                                                                 cn * 9 * N * 64, 0, 0);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            asm volatile("s_barrier" ::: "memory");    // hands chunk c + 1 over / learns that chunk c's buffer is free
-        }
-    } else {
-        // ---- MFMA waves: wave w owns tile rows 2 w, 2 w + 1 (32 pixels each) x 64 channels
-        unsigned aK[3][2], bK[2];
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                aK[kw][ks] = (unsigned)((wave * 2 * 34 + l31 + kw) * 64 + (((ks * 2 + khalf) ^ (((l31 + kw) >> 2) & 3)) << 4));
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) bK[ks] = (unsigned)(A_BYTES + l31 * 64 + (((ks * 2 + khalf) ^ ((l31 >> 2) & 3)) << 4));
-        asm volatile("s_barrier" ::: "memory");        // chunk 0 has landed
-        for (int c = 0; c < nch; ++c) {
-            const unsigned sb = (unsigned)((c & 1) * STAGE);
-            bf16x8 fa[2][2], fb[2][2];
-            auto read_frags = [&](auto gc) {
-                constexpr int gi = decltype(gc)::value;
-                constexpr int tap = gi / 2, ks = gi % 2, kh = tap / 3, kw = tap % 3;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    fa[gi & 1][i] = *reinterpret_cast<const bf16x8*>(smem + sb + aK[kw][ks] + (i + kh) * 34 * 64);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    fb[gi & 1][j] = *reinterpret_cast<const bf16x8*>(smem + sb + bK[ks] + (tap * 64 + j * 32) * 64);
-            };
-            read_frags(std::integral_constant<int, 0>());
-            auto groups = [&](auto self, auto gc) {
-                constexpr int gi = decltype(gc)::value;
-                if constexpr (gi < 18) {
-                    if constexpr (gi < 17) read_frags(std::integral_constant<int, gi + 1>());
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[gi & 1][i], fb[gi & 1][j], acc[i][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    self(self, std::integral_constant<int, gi + 1>());
-                }
-            };
-            groups(groups, std::integral_constant<int, 0>());
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // done reading this buffer; next chunk has landed
-        }
-    }
-
-    // epilogue (interior tiles only): pack pairs of rows, statistics, transpose through LDS, 16-byte stores
-    const int odd = lane & 1;
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-    if (!loader) {
-        if constexpr (BIASACT) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float bv = bias ? bias[n0 + j * 32 + l31] : 0.f;
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r] + bv, act);
-            }
-        }
-        unsigned char* lwp = smem + (wave * 64 + 4 * khalf + odd) * OROW + (l31 & ~1) * 2;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int rp = 0; rp < 8; ++rp)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int r0 = 2 * rp;
-                    const unsigned w2 = f2bf_pk(acc[i][j][r0], acc[i][j][r0 + 1]);
-                    const float ra_ = __uint_as_float(w2 << 16), rb_ = __uint_as_float(w2 & 0xffff0000u);
-                    s1[j] += ra_ + rb_;
-                    s2[j] += ra_ * ra_ + rb_ * rb_;
-                    const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)w2, 0xB1, 0xf, 0xf, true);
-                    const unsigned word = odd ? ((nb >> 16) | (w2 & 0xffff0000u)) : ((w2 & 0xffffu) | (nb << 16));
-                    *reinterpret_cast<unsigned*>(lwp + (i * 32 + (r0 & 3) + 8 * (r0 >> 2)) * OROW + j * 64) = word;
-                }
-    }
-    __syncthreads();
-    if (!loader) {
-        constexpr int PPP = BN / 8;                   // 16-byte pieces per pixel
-        constexpr int PSTEP = 512 / PPP;              // 64 pixels = two tile rows between a thread's pieces
-        const int mt = threadIdx.x / PPP, q = threadIdx.x % PPP;
-        const unsigned char* lr = smem + mt * OROW + q * 16;
-        unsigned short* yp = y + (((size_t)b0 * H + ty0 + (mt >> 5)) * W + tx0 + (mt & 31)) * N + n0 + q * 8;
-        const size_t ystep = (size_t)(PSTEP / 32) * W * N;
-#pragma unroll
-        for (int it = 0; it < PPP; ++it)
-            *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * PSTEP * OROW);
-    }
-    if (stats_partial) {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);      // [8 waves][2][BN]
-        if (!loader) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float a = s1[j] + __shfl_xor(s1[j], 32, 64);
-                const float bq = s2[j] + __shfl_xor(s2[j], 32, 64);
-                if (khalf == 0) {
-                    red[(wave * 2 + 0) * BN + j * 32 + l31] = a;
-                    red[(wave * 2 + 1) * BN + j * 32 + l31] = bq;
-                }
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 2 * BN) {
-            const int which = threadIdx.x / BN, n = threadIdx.x % BN;
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) v += red[(w * 2 + which) * BN + n];
-            stats_partial[((size_t)blockIdx.x * 2 + which) * N + n0 + n] = v;
-        }
-    }
-    PHX_BLOCKLOG_END();
-}
-
-// ---- forward / data-gradient, 32x16-pixel tiles x 64 channels, wave-specialised, 128-pixel wave tiles --------------------
-// Same staging engine as k_conv3x3_fwd_ws64 (two loader waves, LDS-DMA, two 75 KiB stages), but FOUR MFMA waves that own
-// four tile rows (4 x 32 pixels) x 64 channels each.  An MFMA's 32 pixels are one tile row, so the A fragment of (row r,
-// tap row kh) is the patch row r + kh: a wave's four rows need only six patch rows per (kw, k-step) instead of twelve
-// fragment reads, and every filter fragment feeds four MFMAs instead of two -- 12 ds_read_b128 per 24 MFMAs (0.5 KiB of LDS
-// reads per MFMA against 1 KiB in the 64-pixel wave tiles, whose LDS traffic is what their MFMA rate is bounded by).
-template <bool BIASACT, int NLW>
-__global__ __launch_bounds__(256 + 64 * NLW, 1) void k_conv3x3_fwd_ws128(const unsigned short* __restrict__ x,
-                                                             const unsigned short* __restrict__ wpk,
-                                                             unsigned short* __restrict__ y, const float* __restrict__ bias,
-                                                             int act, float* __restrict__ stats_partial,
-                                                             int B, int H, int W, int K, int N, int tiles_x, int tiles_y) {
-    constexpr int BN = 64;
-    constexpr int AI = 39, BI = 36;                   // 1 KiB DMA instructions per chunk: 612 patch rows x 64 B, 576 slab rows
-    constexpr int NI = AI + BI, NPL = (NI + NLW - 1) / NLW;   // per loader wave
-    constexpr int A_BYTES = AI * 1024, STAGE = NI * 1024;
-    constexpr int OROW = BN * 2 + 16;
-    constexpr int PROW = 34 * 64;                     // bytes per patch row
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // linear block id -> (pixel tile, channel block): the N / 64 channel blocks of a tile get ids 8 apart (same XCD, dispatched
-    // back to back), so the patch they share comes from HBM once (as in k_conv3x3_mfma)
-    int tile_id, cob;
-    {
-        const int ncob = N / BN, ntl = tiles_x * tiles_y * B;
-        const int id = blockIdx.x, full = (ntl >> 3) * 8 * ncob;
-        if (id < full) {
-            const int grp = id / (8 * ncob), r = id - grp * 8 * ncob;
-            tile_id = grp * 8 + (r & 7);
-            cob = r >> 3;
-        } else {
-            const int rem = ntl & 7, r = id - full;
-            tile_id = (ntl & ~7) + r % rem;
-            cob = r / rem;
-        }
-    }
-    int t = tile_id;
-    const int tx0 = (t % tiles_x) << 5; t /= tiles_x;
-    const int ty0 = (t % tiles_y) << 4; t /= tiles_y;
-    const int b0 = t;
-    const int n0 = cob * BN;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int l31 = lane & 31, khalf = lane >> 5;
-    const bool loader = wave >= 4;
-    const int nch = K / 32;
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    PHX_BLOCKLOG_BEGIN();
-
-    if (loader) {
-        const int lw = wave - 4;
-        unsigned voff[NPL];
-#pragma unroll
-        for (int n = 0; n < NPL; ++n) {
-            const int j = lw + NLW * n;
-            voff[n] = 0xffffffffu;
-            if (j < AI) {
-                const int e = j * 64 + lane, pp = e >> 2, slot = e & 3;
-                const int py = pp / 34, px = pp - py * 34;
-                const int piece = slot ^ ((px >> 2) & 3);
-                const int gx = tx0 + px - 1, gy = ty0 + py - 1;
-                if (pp < 612 && gx >= 0 && gx < W && gy >= 0 && gy < H) voff[n] = (unsigned)((((b0 * H + gy) * W + gx) * K) * 2 + piece * 16);
-            } else if (j < NI) {
-                const int e = (j - AI) * 64 + lane, rb = e >> 2, slot = e & 3;
-                const int tap = rb >> 6, nn = rb & 63;
-                const int piece = slot ^ ((nn >> 2) & 3);
-                voff[n] = (unsigned)(((tap * N + n0 + nn) * 32 + piece * 8) * 2);
-            }
-        }
-        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K * 2u), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, (int)(9u * N * K * 2u), 0x00020000);
-        typedef __attribute__((address_space(3))) void* lds_ptr_t;
-        for (int c = -1; c < nch; ++c) {               // c = -1: prologue (chunk 0); chunk c: stage chunk c + 1
-            if (c + 1 < nch) {
-                const int cn = c + 1, buf = cn & 1;
-#pragma unroll
-                for (int n = 0; n < NPL; ++n) {
-                    const int j = lw + NLW * n;
-                    if (j < AI)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + buf * STAGE + j * 1024), 16, (int)voff[n],
-                                                                 cn * 64, 0, 0);
-                    else if (j < NI)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(smem + buf * STAGE + j * 1024), 16, (int)voff[n],
-                                                                 cn * 9 * N * 64, 0, 0);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            asm volatile("s_barrier" ::: "memory");    // hands chunk c + 1 over / learns that chunk c's buffer is free
-        }
-    } else {
-        // ---- MFMA waves: wave w owns tile rows 4 w .. 4 w + 3 (32 pixels each) x 64 channels
-        unsigned aK[3][2], bK[2];
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                aK[kw][ks] = (unsigned)((wave * 4 * 34 + l31 + kw) * 64 + (((ks * 2 + khalf) ^ (((l31 + kw) >> 2) & 3)) << 4));
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) bK[ks] = (unsigned)(A_BYTES + l31 * 64 + (((ks * 2 + khalf) ^ ((l31 >> 2) & 3)) << 4));
-        asm volatile("s_barrier" ::: "memory");        // chunk 0 has landed
-        for (int c = 0; c < nch; ++c) {
-            const unsigned sb = (unsigned)((c & 1) * STAGE);
-            bf16x8 fa[2][6], fb[2][3][2];
-            auto read_frags = [&](auto gc) {           // group g = (k-step ks, tap column kw): six patch rows, three tap rows
-                constexpr int g = decltype(gc)::value;
-                constexpr int ks = g / 3, kw = g % 3;
-#pragma unroll
-                for (int rr = 0; rr < 6; ++rr)
-                    fa[g & 1][rr] = *reinterpret_cast<const bf16x8*>(smem + sb + aK[kw][ks] + rr * PROW);
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        fb[g & 1][kh][j] = *reinterpret_cast<const bf16x8*>(smem + sb + bK[ks] + ((kh * 3 + kw) * 64 + j * 32) * 64);
-            };
-            read_frags(std::integral_constant<int, 0>());
-            auto groups = [&](auto self, auto gc) {
-                constexpr int g = decltype(gc)::value;
-                if constexpr (g < 6) {
-                    if constexpr (g < 5) read_frags(std::integral_constant<int, g + 1>());
-#pragma unroll
-                    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g & 1][i + kh], fb[g & 1][kh][j], acc[i][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    self(self, std::integral_constant<int, g + 1>());
-                }
-            };
-            groups(groups, std::integral_constant<int, 0>());
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // done reading this buffer; next chunk has landed
-        }
-    }
-
-    // epilogue (interior tiles only): pack pairs of rows, statistics, transpose through LDS, 16-byte stores
-    const int odd = lane & 1;
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-    if (!loader) {
-        if constexpr (BIASACT) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float bv = bias ? bias[n0 + j * 32 + l31] : 0.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r] + bv, act);
-            }
-        }
-        unsigned char* lwp = smem + (wave * 128 + 4 * khalf + odd) * OROW + (l31 & ~1) * 2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int rp = 0; rp < 8; ++rp)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int r0 = 2 * rp;
-                    const unsigned w2 = f2bf_pk(acc[i][j][r0], acc[i][j][r0 + 1]);
-                    const float ra_ = __uint_as_float(w2 << 16), rb_ = __uint_as_float(w2 & 0xffff0000u);
-                    s1[j] += ra_ + rb_;
-                    s2[j] += ra_ * ra_ + rb_ * rb_;
-                    const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)w2, 0xB1, 0xf, 0xf, true);
-                    const unsigned word = odd ? ((nb >> 16) | (w2 & 0xffff0000u)) : ((w2 & 0xffffu) | (nb << 16));
-                    *reinterpret_cast<unsigned*>(lwp + (i * 32 + (r0 & 3) + 8 * (r0 >> 2)) * OROW + j * 64) = word;
-                }
-    }
-    __syncthreads();
-    if (!loader) {
-        constexpr int PPP = BN / 8;                   // 16-byte pieces per pixel
-        const int mt = threadIdx.x / PPP, q = threadIdx.x % PPP;        // 256 threads: tile column mt, piece q; one tile row per step
-        const unsigned char* lr = smem + mt * OROW + q * 16;
-        unsigned short* yp = y + (((size_t)b0 * H + ty0) * W + tx0 + mt) * N + n0 + q * 8;
-        const size_t ystep = (size_t)W * N;
-#pragma unroll
-        for (int it = 0; it < 16; ++it)
-            *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * 32 * OROW);
-    }
-    if (stats_partial) {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);      // [4 waves][2][BN]
-        if (!loader) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float a = s1[j] + __shfl_xor(s1[j], 32, 64);
-                const float bq = s2[j] + __shfl_xor(s2[j], 32, 64);
-                if (khalf == 0) {
-                    red[(wave * 2 + 0) * BN + j * 32 + l31] = a;
-                    red[(wave * 2 + 1) * BN + j * 32 + l31] = bq;
-                }
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 2 * BN) {
-            const int which = threadIdx.x / BN, n = threadIdx.x % BN;
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) v += red[(w * 2 + which) * BN + n];
-            stats_partial[((size_t)tile_id * 2 + which) * N + n0 + n] = v;
-        }
-    }
-    PHX_BLOCKLOG_END();
-}
-
 // ---- the same 128-pixel wave tiles without loader waves: one 75 KiB stage per block, TWO blocks per CU -----------------
-__device__ unsigned g_phx_cu_arrivals[4096];
 template <bool BIASACT, int DBG, int BN>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned short* __restrict__ x,
                                                              const unsigned short* __restrict__ wpk,
                                                              unsigned short* __restrict__ y, const float* __restrict__ bias,
                                                              int act, float* __restrict__ stats_partial,
-                                                             int B, int H, int W, int K, int N, int tiles_x, int tiles_y, int dephase, const float* __restrict__ oscale) {
+                                                             int B, int H, int W, int K, int N, int tiles_x, int tiles_y, const float* __restrict__ oscale) {
     constexpr int NJ = BN / 32;                       // BN = 64 (two 32-channel MFMA columns per wave) or 32 (one)
     constexpr int AI = 39, BI = 9 * BN * 64 / 1024;   // 1 KiB DMA instructions per chunk: 612 patch rows x 64 B, 9 * BN slab rows
     constexpr int NLW = 4;
@@ -1543,19 +724,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
             aK[kw][ks] = (unsigned)((wave * 4 * 34 + l31 + kw) * 64 + (((ks * 2 + khalf) ^ (((l31 + kw) >> 2) & 3)) << 4));
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) bK[ks] = (unsigned)(A_BYTES + l31 * 64 + (((ks * 2 + khalf) ^ ((l31 >> 2) & 3)) << 4));
-    if (dephase > 0) {
-        // De-phasing experiment: two blocks share a CU and run identical load -> compute cycles; started together they stay in
-        // lock-step (both load, then both compute on half the matrix pipe each).  Every second block that arrives on a CU
-        // sleeps for `dephase` x 64 cycles first, so that one block's loads fall under the other's MFMAs.
-        volatile unsigned* s_old = reinterpret_cast<volatile unsigned*>(smem + STAGE);
-        if (threadIdx.x == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508) & 0xf;
-            *s_old = atomicAdd(&g_phx_cu_arrivals[(xcc << 8) | ((hw >> 8) & 0xff)], 1u);
-        }
-        __syncthreads();
-        if (*s_old & 1)
-            for (int q = 0; q < dephase; ++q) __builtin_amdgcn_s_sleep(1);
-    }
     for (int c = 0; c < nch; ++c) {
         if (c) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done reading the previous chunk
 #pragma unroll
@@ -2361,6 +1529,7 @@ int phx_unpad_filter_grad_center(const float* dw_pad, float* dw_1x1, int Cin, in
 }
 
 int phx_debug_set_trace(void* dev_buf) {
+    if (int rc = phx_db_set_trace(dev_buf)) return rc;
     unsigned long long* p = (unsigned long long*)dev_buf;
     PHX_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phx_trace), &p, sizeof(p)));
     return PHX_OK;
@@ -2373,7 +1542,7 @@ int phx_debug_set_blocklog(void* dev_buf) {
 }
 
 int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W, int K, int N) {
-    if (phx_pp_eligible(B, H, W, K, N)) return phx_pp_partial_rows(B, H, W);     // one row of partial sums per (tile, wave)
+    if (fwd_ws64(B, H, W, K, N) && N % 64 == 0 && phx_db_enabled()) return phx_db_partial_rows(B, H, W);   // one row of partial sums per (tile, wave)
     MTile g = make_mtile_fwd(B, H, W, K, N);
     return g.tiles_x * g.tiles_y * g.tiles_b;
 }
@@ -2410,8 +1579,7 @@ int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* 
 
 // the fused-statistics epilogue lives in the full-tile path of the 16-wide-tile kernels: every tile must be interior
 static bool fwd_bws_ok(int B, int H, int W, int K, int N) {
-    if (phx_pp_eligible(B, H, W, K, N)) return false;
-    if (fwd_ws64(B, H, W, K, N) || fwd_dma_bn(B, H, W, K, N) || fwd_rs_bn(B, H, W, K, N) || fwd_ksplit(B, H, W, K, N) > 1) return false;
+    if (fwd_ws64(B, H, W, K, N) || fwd_ksplit(B, H, W, K, N) > 1) return false;
     if (fwd_big_tiles(B, H, W, K, N)) return true;                       // H % 32 == 0, W % 16 == 0
     return H % 16 == 0 && W % 16 == 0;
 }
@@ -2431,8 +1599,7 @@ int phx_conv3x3_mfma_bf16_ws(const void* x, const void* wpk, void* y, const floa
 // its own over y.  Generic 256-pixel-tile kernel only.
 static bool fwd_stats_atomic_ok(int B, int H, int W, int K, int N) {
     if (phx_deterministic() || K % KC != 0 || N % 32 != 0) return false;
-    if (phx_pp_eligible(B, H, W, K, N) || fwd_ws64(B, H, W, K, N) || fwd_dma_bn(B, H, W, K, N) || fwd_rs_bn(B, H, W, K, N) ||
-        fwd_big_tiles(B, H, W, K, N)) return false;
+    if (fwd_ws64(B, H, W, K, N) || fwd_big_tiles(B, H, W, K, N)) return false;
     return phx_conv3x3_mfma_bf16_tiles(B, H, W, K, N) <= 64;
 }
 int phx_conv3x3_mfma_stats_atomic_supported(int B, int H, int W, int K, int N) { return fwd_stats_atomic_ok(B, H, W, K, N) ? 1 : 0; }
@@ -2448,8 +1615,6 @@ int phx_conv3x3_mfma_bf16_stats_atomic(const void* x, const void* wpk, void* y, 
 int phx_conv3x3_mfma_bf16_affine(const void* x, const void* wpk, void* y, const float* scale, const float* shift, int act,
                                  void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream) {
     PHX_REQUIRE(scale != nullptr && shift != nullptr, PHX_E_INVAL, "conv3x3_mfma_affine: scale and shift are required");
-    PHX_REQUIRE(!fwd_rs_bn(B, H, W, K, N) && !fwd_dma_bn(B, H, W, K, N), PHX_E_INVAL,
-                "conv3x3_mfma_affine: not implemented in the experimental rs / dma forward kernels");
     BwdStats b{};
     b.oscale = scale;
     return conv3x3_mfma_impl(x, wpk, y, shift, act, nullptr, workspace, workspace_bytes, B, H, W, K, N, b, stream);
@@ -2479,112 +1644,29 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
     }
     PHX_REQUIRE(y != nullptr || (ksplit > 1 && !bias && act == PHX_ACT_ID), PHX_E_INVAL,
                 "conv3x3_mfma: y == NULL only for a split-K launch without bias / activation (slices left in the workspace)");
-    if (bws.part == nullptr && bws.oscale == nullptr && ksplit == 1 && phx_pp_eligible(B, H, W, K, N))
-        return phx_pp_launch(x, wpk, y, bias, act, stats_partial, B, H, W, K, N, stream);
     if (fwd_ws64(B, H, W, K, N)) {
         const bool ba = bias != nullptr || act != PHX_ACT_ID || bws.oscale != nullptr;
-        const int wsm0 = fwd_ws_mode();
-        PHX_REQUIRE(bws.oscale == nullptr || wsm0 == 1 || wsm0 == 5, PHX_E_INVAL, "conv3x3_mfma: the affine epilogue is not implemented in the experimental ws64 / ws128 kernels");
-        static bool wattr = false;
-        if (!wattr) {
-            PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_ws64<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_ws64<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            wattr = true;
-        }
         PHX_REQUIRE((double)B * H * W * (K > N ? K : N) < 2147483648.0, PHX_E_SHAPE, "conv3x3_mfma: tensor exceeds 2^31 elements");
         const int ntl = B * (H / 16) * (W / 32);
-        const size_t sh = 2 * 75 * 1024;              // two 75 KiB stages (the 72 KiB output tile reuses them)
-        const int wsm = fwd_ws_mode();
-        if (wsm == 5 || wsm == 1) {                  // k_conv3x3_fwd_dma128: one stage per block, two blocks per CU
-            const char* dbe = getenv("PHX_DBG_ABLATE");   // dev: bit 1 no patch loads, 2 no slab loads, 4 no MFMAs
-            const int dbg = dbe ? atoi(dbe) : 0;
+        const char* dbe = getenv("PHX_DBG_ABLATE");   // dev: bit 1 no patch loads, 2 no slab loads, 4 no MFMAs
+        const int dbg = dbe ? atoi(dbe) : 0;
+        if (phx_db_enabled() && N % 64 == 0) return phx_db_launch(x, wpk, y, bias, act, stats_partial, B, H, W, K, N, bws.oscale, dbg, stream);
 #define D128_LAUNCH1(Av, Dv, BNv)                                                                                               \
     do {                                                                                                                        \
         PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_dma128<Av, Dv, BNv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((k_conv3x3_fwd_dma128<Av, Dv, BNv>), dim3(ntl * (N / BNv)), dim3(256), 75 * 1024 + 16, (hipStream_t)stream, \
                            (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, \
-                           H, W, K, N, W / 32, H / 16, dephase, bws.oscale);                                                    \
+                           H, W, K, N, W / 32, H / 16, bws.oscale);                                                             \
     } while (0)
 #define D128_LAUNCH(Av, Dv)                                                                                                     \
     do { if (N % 64 == 0) D128_LAUNCH1(Av, Dv, 64); else D128_LAUNCH1(Av, 0, 32); } while (0)
-            const char* dpe = getenv("PHX_DEPHASE");
-            const int dephase = dpe ? atoi(dpe) : 0;
-            if (ba) D128_LAUNCH(true, 0);
-            else switch (dbg) {
-                case 1: D128_LAUNCH(false, 1); break; case 2: D128_LAUNCH(false, 2); break; case 3: D128_LAUNCH(false, 3); break;
-                case 4: D128_LAUNCH(false, 4); break; case 5: D128_LAUNCH(false, 5); break; case 6: D128_LAUNCH(false, 6); break;
-                case 7: D128_LAUNCH(false, 7); break; default: D128_LAUNCH(false, 0);
-            }
+        if (ba) D128_LAUNCH(true, 0);
+        else switch (dbg) {
+            case 1: D128_LAUNCH(false, 1); break; case 2: D128_LAUNCH(false, 2); break; case 3: D128_LAUNCH(false, 3); break;
+            case 4: D128_LAUNCH(false, 4); break; default: D128_LAUNCH(false, 0);
+        }
 #undef D128_LAUNCH1
 #undef D128_LAUNCH
-            PHX_CHECK_LAUNCH();
-            return PHX_OK;
-        }
-        if (wsm >= 3) {                  // 128-pixel wave tiles (k_conv3x3_fwd_ws128); 3: two loader waves, 4: four
-            static bool wattr2 = false;
-            if (!wattr2) {
-                PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_ws128<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_ws128<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_ws128<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_ws128<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                wattr2 = true;
-            }
-#define WS128_LAUNCH(Av, NLWv)                                                                                                   \
-    hipLaunchKernelGGL((k_conv3x3_fwd_ws128<Av, NLWv>), dim3(ntl * (N / 64)), dim3(256 + 64 * NLWv), sh, (hipStream_t)stream,    \
-                       (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, H, \
-                       W, K, N, W / 32, H / 16)
-            if (wsm == 3) { if (ba) WS128_LAUNCH(true, 2); else WS128_LAUNCH(false, 2); }
-            else { if (ba) WS128_LAUNCH(true, 4); else WS128_LAUNCH(false, 4); }
-#undef WS128_LAUNCH
-            PHX_CHECK_LAUNCH();
-            return PHX_OK;
-        }
-        if (ba)
-            hipLaunchKernelGGL((k_conv3x3_fwd_ws64<true>), dim3(ntl, N / 64), dim3(640), sh, (hipStream_t)stream,
-                               (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B,
-                               H, W, K, N, W / 32, H / 16);
-        else
-            hipLaunchKernelGGL((k_conv3x3_fwd_ws64<false>), dim3(ntl, N / 64), dim3(640), sh, (hipStream_t)stream,
-                               (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B,
-                               H, W, K, N, W / 32, H / 16);
-        PHX_CHECK_LAUNCH();
-        return PHX_OK;
-    }
-    if (const int rbn = fwd_rs_bn(B, H, W, K, N)) {
-        const bool ba = bias != nullptr || act != PHX_ACT_ID;
-        static bool rattr = false;
-#define FR_ATTR(BNv, Av) PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_rs<BNv, Av>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-        if (!rattr) { FR_ATTR(128, false); FR_ATTR(128, true); FR_ATTR(64, false); FR_ATTR(64, true); rattr = true; }
-#undef FR_ATTR
-        PHX_REQUIRE((double)B * H * W * (K > N ? K : N) < 2147483648.0, PHX_E_SHAPE, "conv3x3_mfma: tensor exceeds 2^31 elements");
-        const int ntl = B * (H / 16) * (W / 32);
-#define FR_LAUNCH(BNv, Av, SHv)                                                                                       \
-    hipLaunchKernelGGL((k_conv3x3_fwd_rs<BNv, Av>), dim3(ntl, N / BNv), dim3(512), SHv, (hipStream_t)stream,           \
-                       (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B,  \
-                       H, W, K, N, W / 32, H / 16)
-        // LDS: two stages or the 512-pixel output tile, whichever is larger
-        if (rbn == 128) { if (ba) FR_LAUNCH(128, true, 512 * (128 * 2 + 16)); else FR_LAUNCH(128, false, 512 * (128 * 2 + 16)); }
-        else { if (ba) FR_LAUNCH(64, true, 2 * (640 * 32 + 9 * 64 * 32)); else FR_LAUNCH(64, false, 2 * (640 * 32 + 9 * 64 * 32)); }
-#undef FR_LAUNCH
-        PHX_CHECK_LAUNCH();
-        return PHX_OK;
-    }
-    if (const int dbn = fwd_dma_bn(B, H, W, K, N)) {
-        const bool ba = bias != nullptr || act != PHX_ACT_ID;
-        static bool dattr = false;
-#define FD_ATTR(BNv, Av) PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_dma<BNv, Av>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-        if (!dattr) { FD_ATTR(128, false); FD_ATTR(128, true); FD_ATTR(64, false); FD_ATTR(64, true); dattr = true; }
-#undef FD_ATTR
-        PHX_REQUIRE((double)B * H * W * (K > N ? K : N) < 2147483648.0, PHX_E_SHAPE, "conv3x3_mfma: tensor exceeds 2^31 elements");
-        const int ntl = B * (H / 16) * (W / 32);
-        // LDS: two stages (7 resp. 5 KiB-instructions per wave each) or the 512-pixel output tile, whichever is larger
-#define FD_LAUNCH(BNv, Av, SHv)                                                                                       \
-    hipLaunchKernelGGL((k_conv3x3_fwd_dma<BNv, Av>), dim3(ntl, N / BNv), dim3(512), SHv, (hipStream_t)stream,          \
-                       (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B,  \
-                       H, W, K, N, W / 32, H / 16)
-        if (dbn == 128) { if (ba) FD_LAUNCH(128, true, 512 * (128 * 2 + 16)); else FD_LAUNCH(128, false, 512 * (128 * 2 + 16)); }
-        else { if (ba) FD_LAUNCH(64, true, 2 * 5 * 8 * 1024); else FD_LAUNCH(64, false, 2 * 5 * 8 * 1024); }
-#undef FD_LAUNCH
         PHX_CHECK_LAUNCH();
         return PHX_OK;
     }

@@ -167,21 +167,6 @@ def test_conv3x3_mfma_big_tiles(L, case, monkeypatch):
     _mfma_case(L, case)
 
 
-# the 32 x 16-tile LDS-DMA forward kernels (policy: large maps with 128-wide channel blocks), forced on small shapes
-@pytest.mark.parametrize("case", [(2, 16, 32, 32, 128), (1, 32, 64, 96, 64), (3, 16, 32, 32, 192), (1, 48, 32, 64, 256)])
-def test_conv3x3_mfma_dma_tiles(L, case, monkeypatch):
-    monkeypatch.setenv("PHX_FWD_DMA", "2")
-    _mfma_case(L, case)
-
-
-# same tile geometry, register staging into double-buffered 16-channel LDS halves (k_conv3x3_fwd_rs)
-@pytest.mark.parametrize("case", [(2, 16, 32, 32, 128), (1, 32, 64, 96, 64), (3, 16, 32, 32, 192), (1, 48, 32, 64, 256),
-                                  (1, 16, 64, 160, 128)])
-def test_conv3x3_mfma_rs_tiles(L, case, monkeypatch):
-    monkeypatch.setenv("PHX_FWD_RS", "2")
-    _mfma_case(L, case)
-
-
 @pytest.mark.parametrize("case", [(2, 16, 16, 38, 32), (1, 32, 32, 64, 64)])
 def test_conv1x1_as_centre_tap(L, case):
     """1x1 filters (prob_unet2D's recombination layers, model_zoo/likelihoods.py) run on the 3x3 MFMA kernels as the centre
@@ -255,7 +240,6 @@ def test_dgrad_with_fused_bn_backward_statistics(L, case, monkeypatch):
     close(host(sums), host(sums_ref), 2e-5, "fused bn-backward sums")
 
 
-# wave-specialised variant: 8 MFMA waves + 2 DMA loader waves, 512 pixels x 64 channels per block (k_conv3x3_fwd_ws64)
 @pytest.mark.parametrize("case", [(64, 8, 8, 192, 192), (64, 16, 16, 64, 96), (3, 8, 8, 32, 32), (9, 4, 4, 64, 64), (64, 16, 16, 384, 192)])
 def test_conv3x3_mfma_statistics_by_atomics(L, case):
     """phx_conv3x3_mfma_bf16_stats_atomic: the convolution of a layer with few pixel tiles adds {sum y, sum y^2} of its (bf16-rounded)
@@ -285,28 +269,25 @@ def test_conv3x3_mfma_statistics_by_atomics(L, case):
         L.conv3x3_mfma_bf16_stats_atomic(xd.data_ptr(), wf.data_ptr(), y.data_ptr(), None, 0, None, B, H, W, K, N, S())
 
 
-@pytest.mark.parametrize("case", [(2, 16, 32, 32, 128), (1, 32, 64, 96, 64), (3, 16, 32, 32, 192), (1, 48, 32, 64, 256),
-                                  (1, 16, 64, 160, 128)])
-def test_conv3x3_mfma_wave_specialised(L, case, monkeypatch):
-    monkeypatch.setenv("PHX_FWD_WS", "2")
-    _mfma_case(L, case)
-
-
-# 128-pixel wave tiles with shared patch rows: 4 MFMA waves + 2 DMA loader waves (k_conv3x3_fwd_ws128)
+# 16 x 32-pixel tiles, 128-pixel wave tiles with shared patch rows, LDS-DMA staged (k_conv3x3_fwd_dma128; policy: large maps), forced
+# on small shapes; N % 64 == 32 takes its 32-channel-block variant
 @pytest.mark.parametrize("case", [(2, 16, 32, 32, 128), (1, 32, 64, 96, 64), (3, 16, 32, 32, 192), (1, 48, 32, 64, 256),
                                   (1, 16, 64, 160, 128), (2, 32, 32, 32, 32), (1, 16, 64, 192, 32), (2, 16, 32, 64, 96)])
-def test_conv3x3_mfma_wave_specialised_128(L, case, monkeypatch):
+def test_conv3x3_mfma_dma128(L, case, monkeypatch):
     monkeypatch.setenv("PHX_FWD_WS", "5")
+    monkeypatch.setenv("PHX_FWD_DB", "0")
     _mfma_case(L, case)
 
 
-# ping-pong persistent kernel (conv_pp.hip): forced on small shapes; PHX_PP_GRID = 3 makes every block walk several items
+# the experimental double-buffered persistent kernel (conv_db.hip, PHX_FWD_DB=1): forced on small shapes; PHX_DB_GRID = 3 makes
+# every block walk several items (chunk pipeline across item boundaries, epilogue at the head of the next item)
 @pytest.mark.parametrize("case", [(2, 16, 32, 32, 128), (1, 32, 64, 96, 64), (4, 16, 32, 32, 192), (2, 48, 32, 64, 256),
                                   (1, 16, 64, 160, 128), (6, 32, 32, 64, 64)])
 @pytest.mark.parametrize("grid", [0, 3])
-def test_conv3x3_mfma_ping_pong(L, case, grid, monkeypatch):
-    monkeypatch.setenv("PHX_FWD_PP", "2")
-    monkeypatch.setenv("PHX_PP_GRID", str(grid))
+def test_conv3x3_mfma_double_buffered(L, case, grid, monkeypatch):
+    monkeypatch.setenv("PHX_FWD_WS", "5")
+    monkeypatch.setenv("PHX_FWD_DB", "1")
+    monkeypatch.setenv("PHX_DB_GRID", str(grid))
     _mfma_case(L, case)
 
 

@@ -10,9 +10,9 @@ f = glob.glob("gpurun_out/pmc_ablate/p1/**/*counter_collection.csv", recursive=T
 dur = collections.defaultdict(list)
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
-    agg[(r["Kernel_Name"].split("(")[0], r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    agg[(r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0], r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
-        dur[(r["Kernel_Name"].split("(")[0], r["Grid_Size"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        dur[(r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0], r["Grid_Size"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 for k in sorted(agg):
     if "conv3x3" not in k[0]: continue
     a = {c: sum(v) / len(v) for c, v in agg[k].items()}
