@@ -121,6 +121,26 @@ int phx_conv3x3_mfma_bwdstats_supported(int B, int H, int W, int K, int N);
 int phx_conv3x3_mfma_bf16_bwdstats(const void* dy, const void* wpk_dgrad, void* dA, const void* y_prod, const float* scale,
                                    const float* shift, const float* mean, const float* rstd, int act_prod,
                                    float* stats2_partial, int B, int H, int W, int K, int N, void* stream);
+/* Fused conv -> norm -> act -> conv edge (tfwrapper/layers.py:123-135 feeding the next layers.conv2D; normalisation.py:17-36,
+ * 145-163): the 3x3 convolution of layer L+1 taking the RAW convolution output y_prod [B,H,W,K] bf16 of layer L.  The
+ * normalisation of layer L (training-mode batch norm: p_NS = 1, p_G = K; instance norm: p_NS = B, p_G = K; group norm: p_NS = B,
+ * p_G groups of K / p_G channels) is finalised in the launch's prologue from p_sums[p_nrep][p_NS][K][2] = {sum y, sum y^2}
+ * (shifted by p_pivot[p_NS][K] when given: the layouts of phx_norm_apply_fused), a = act_p(y_prod * scale + shift) is formed
+ * while the input patch is staged (zero padding applies to a), and
+ *   - a_out (may be NULL) receives the materialised a [B,H,W,K] bf16 (what phx_norm_apply_fused would have written),
+ *   - mean_out / rstd_out [p_NS][p_G], scale_out / shift_out [p_NS][K] are published for the backward pass,
+ *   - moving_mean / moving_var (batch norm, may be NULL) get TF1's fused-batch-norm moving update with `momentum`.
+ * Output side as phx_conv3x3_mfma_bf16_ws: y, bias / act, stats = per-tile partial sums [phx_conv3x3_xf_tiles][2][N], or with
+ * stats_atomic != 0 the accumulator sums[N][2] itself (added atomically); workspace: split-K slices (phx_conv3x3_xf_ws_bytes; only
+ * without stats).  Register-staged 256-pixel tiles on every map size; p_NS > 1 needs tiles inside one sample (H, W >= 16). */
+int phx_conv3x3_xf_supported(int B, int H, int W, int K, int N, int NS);
+int phx_conv3x3_xf_tiles(int B, int H, int W);
+size_t phx_conv3x3_xf_ws_bytes(int B, int H, int W, int K, int N);
+int phx_conv3x3_mfma_bf16_xf(const void* y_prod, const void* wpk, void* y, const float* bias, int act, float* stats, int stats_atomic,
+                             void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, const float* p_sums,
+                             const float* p_pivot, const float* p_gamma, const float* p_beta, float p_eps, int p_nrep, int p_NS,
+                             int p_G, int p_act, void* a_out, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
+                             float* moving_mean, float* moving_var, float momentum, void* stream);
 /* number of pixel tiles (= rows of stats_partial) phx_conv3x3_mfma_bf16 uses for this shape */
 int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W, int K, int N);
 /* debug: device buffer of >= 16 uint64 that receives shader-clock phase timestamps of block 0 (NULL disables) */

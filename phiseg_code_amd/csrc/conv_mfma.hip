@@ -246,6 +246,26 @@ struct BwdStats {
     const float* oscale;      // per-output-channel scale of the bias / activation epilogue (inference-mode batch norm folded in)
 };
 
+// Fused conv -> norm -> act -> conv edge (XF instantiations, tfwrapper/layers.py:123-135 + normalisation.py:17-36,145-163): the
+// input tensor x is the PRODUCER's raw convolution output y_prod; the normalisation is finalised from its {sum y, sum y^2} in
+// this kernel's prologue (every block: scale / shift of all K channels into an LDS table; ONE block publishes mean / rstd / scale /
+// shift for the backward pass and applies the batch-norm moving update), and a = act(y_prod * scale[c] + shift[c]) is formed
+// between the global load and the LDS store of the staging path -- out-of-image pieces stay zero, because SAME padding pads a,
+// not y.  The channel-block-0 work-groups also write the interior of their transformed tile to a_out (the filter gradient and any
+// later reader use the materialised a), so the stand-alone apply pass (read y, write a) and its launch disappear from the chain.
+struct XForm {
+    const float* sums;        // [nrep][NS][K][2] {sum y, sum y^2} of the producer (pivot-shifted when pivot != NULL)
+    const float* pivot;       // [NS][K] or NULL
+    const float *gamma, *beta;    // [K]
+    float eps, invP;          // invP = 1 / (pixels per (sample, channel) statistic)
+    int nrep, NS, G, act;     // NS: 1 (batch norm) or B (group / instance norm: every pixel tile lies inside one sample)
+    unsigned short* a_out;    // NULL or [B][H][W][K] bf16
+    float *mean_out, *rstd_out, *scale_out, *shift_out;     // [NS][G], [NS][K]
+    float *moving_mean, *moving_var;                        // batch norm in training mode, else NULL
+    float momentum;
+};
+constexpr int XF_TBL_BYTES = 4096;      // LDS scale / shift table in front of the stages: K <= 512 channels x 2 floats
+
 // NA = compile-time bound on the 16-byte input-patch pieces a thread stages per 32-channel chunk
 // (ceil(npatch * 4 / 256): 6 for 16x16 tiles, 7 for 8x8x4, 9 for 4x4x16, 16 for 2x2x64).
 // NW = waves per block (4: 256-pixel tiles, two blocks per CU; 8: 512-pixel 16 x 32 tiles, one block per CU -- the
@@ -254,19 +274,20 @@ struct BwdStats {
 // SPLITK (small maps: a handful of pixel tiles cannot fill 256 CUs and each block would walk all K / 32 chunks serially,
 // ~2 us apiece): gridDim.z blocks share a tile, each takes a run of chunks and stores its fp32 accumulators to
 // ws[z][pixel][N]; k_splitk_finish sums the slices, adds bias / activation and writes the bf16 tensor.
-template <int BN, int NA, bool FAST16, bool BIASACT, int NW, bool SPLITK>
+template <int BN, int NA, bool FAST16, bool BIASACT, int NW, bool SPLITK, bool XF = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const unsigned short* __restrict__ x,
                                                          const unsigned short* __restrict__ wpk,
                                                          unsigned short* __restrict__ y, const float* __restrict__ bias,
                                                          int act, float* __restrict__ stats_partial, int B, int H, int W,
-                                                         int K, int N, MTile g, float* __restrict__ ws, BwdStats bws) {
+                                                         int K, int N, MTile g, float* __restrict__ ws, BwdStats bws, XForm xf) {
     constexpr int NJ = BN / 32;
     constexpr int NT = NW * 64;                            // threads; the tile has NT pixels
     constexpr int NB = (9 * BN * 4 + NT - 1) / NT;        // filter-slab pieces per thread
     const int tw = FAST16 ? 16 : 1 << g.tws, th = FAST16 ? NT / 16 : 1 << g.ths;
     const int pw = tw + 2, ph = th + 2;
     const int npatch = FAST16 ? 18 * (NT / 16 + 2) : g.tb * ph * pw;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char* const smem = smem_raw + (XF ? XF_TBL_BYTES : 0);
     unsigned char* sA = smem;                    // [npatch][ROWB]
     // (the 512-pixel x 32-channel variant measured 12 % slower with the padded pitch -- it keeps the dense one)
     constexpr int P16 = (NW == 8 && BN == 32) ? 18 * ROWB : PITCH16;
@@ -311,6 +332,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
     // 0xffffffff = outside the image / batch / slab -> the buffer range check returns zeros, so the prefetch is
     // branch-free and can be interleaved with the MFMAs of the running chunk.
     unsigned ga[NA];
+    unsigned wmask = 0;                          // XF: pieces whose transformed value this thread also writes to a_out
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
         const int i = threadIdx.x + it * NT;
@@ -330,6 +352,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
                 off = (__umul24(pix, (unsigned)K) + q * 8) * 2;
             }
             ga[it] = in ? off : 0xffffffffu;
+            if constexpr (XF)
+                if (in && cob == 0 && xf.a_out != nullptr && px >= 1 && px <= tw && py >= 1 && py <= th) wmask |= 1u << it;
         }
     }
     // filter-slab pieces: piece `it` of a thread lies it * 64 slab rows further on, i.e. a fixed byte stride -> one VGPR
@@ -360,6 +384,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
     PHX_TRACE(0);
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     u32x4 ra[NA], rb[NB];
+    __amdgpu_buffer_rsrc_t rsa = rsx;
+    if constexpr (XF) rsa = __builtin_amdgcn_make_buffer_rsrc((void*)xf.a_out, 0, xf.a_out ? (int)((unsigned)B * H * W * K * 2u) : 0, 0x00020000);
     // piece `idx` (input-patch pieces first, then filter-slab pieces) of the chunk starting at channel c0
     auto prefetch_piece = [&](auto idxc, int c0) {
         constexpr int idx = decltype(idxc)::value;
@@ -386,15 +412,90 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
         all(all, std::integral_constant<int, 0>());
     }
     PHX_TRACE(1);
+    if constexpr (XF) {
+        // (behind the first chunk's loads) normalisation of the producer, finalised here (the formulas of k_norm_apply_fused): thread c derives channel c
+        float* tbl = reinterpret_cast<float*>(smem_raw);
+        const int ns = xf.NS > 1 ? b0 : 0;
+        const int cg = K / xf.G;
+        const bool pub = cob == 0 && tx0 == 0 && ty0 == 0 && (xf.NS > 1 || b0 == 0) && (!SPLITK || blockIdx.z == 0);
+        const size_t rstride = (size_t)xf.NS * K * 2;
+        for (int c = threadIdx.x; c < K; c += NT) {
+            const int gq = c / cg;
+            float mu = 0.f;
+            for (int q = gq * cg; q < (gq + 1) * cg; ++q) {
+                float s1 = 0.f;
+                for (int r = 0; r < xf.nrep; ++r) s1 += xf.sums[r * rstride + ((size_t)ns * K + q) * 2];
+                mu += (xf.pivot ? xf.pivot[(size_t)ns * K + q] : 0.f) + s1 * xf.invP;
+            }
+            mu /= (float)cg;
+            float var = 0.f;
+            for (int q = gq * cg; q < (gq + 1) * cg; ++q) {
+                float s1 = 0.f, s2 = 0.f;
+                for (int r = 0; r < xf.nrep; ++r) {
+                    s1 += xf.sums[r * rstride + ((size_t)ns * K + q) * 2];
+                    s2 += xf.sums[r * rstride + ((size_t)ns * K + q) * 2 + 1];
+                }
+                const float d1 = s1 * xf.invP;
+                float vc = s2 * xf.invP - d1 * d1;
+                vc = vc > 0.f ? vc : 0.f;
+                const float dm = (xf.pivot ? xf.pivot[(size_t)ns * K + q] : 0.f) + d1 - mu;
+                var += vc + dm * dm;
+            }
+            var /= (float)cg;
+            const float rs = rsqrtf(var + xf.eps);
+            const float scv = xf.gamma[c] * rs;
+            const float shv = xf.beta[c] - mu * scv;
+            tbl[2 * c] = scv;
+            tbl[2 * c + 1] = shv;
+            if (pub) {
+                xf.scale_out[(size_t)ns * K + c] = scv;
+                xf.shift_out[(size_t)ns * K + c] = shv;
+                if (c == gq * cg) {
+                    xf.mean_out[ns * xf.G + gq] = mu;
+                    xf.rstd_out[ns * xf.G + gq] = rs;
+                    if (xf.momentum > 0.f && xf.moving_mean) {       // batch norm (G == K): TF1 fused-batch-norm moving update
+                        const float m = (float)cg / xf.invP;
+                        xf.moving_mean[gq] -= (xf.moving_mean[gq] - mu) * xf.momentum;
+                        xf.moving_var[gq] -= (xf.moving_var[gq] - var * (m / fmaxf(m - 1.f, 1.f))) * xf.momentum;
+                    }
+                }
+            }
+        }
+    }
 
     // one 32-channel chunk: registers -> LDS, then 18 (tap, k-step) groups of 2 x NJ MFMAs; with PF the global loads of the
     // NEXT chunk are issued one or two per group, so the texture-address unit (64 B/clk: ~1 K cycles per chunk for the four
     // waves) works underneath the matrix pipe instead of in a phase of its own.
     constexpr int IPG = (NA + NB + 17) / 18;
-    auto chunk = [&](int cnext, auto pfc, bool tr) {   // cnext: first channel of the chunk to prefetch (plan ga/gb)
+    auto chunk = [&](int ccur, int cnext, auto pfc, bool tr) {   // ccur: first channel of the chunk in registers; cnext: of the chunk to prefetch
         constexpr bool PF = decltype(pfc)::value;
         __syncthreads();                         // every wave is done reading the previous chunk / epilogue tile from LDS
         if (tr) PHX_TRACE(2);
+        if constexpr (XF) {
+            // a = act(y * scale + shift) on the eight channels of this thread's pieces (the same eight for all of them)
+            const float* tq = reinterpret_cast<const float*>(smem_raw) + (ccur + (threadIdx.x & 3) * 8) * 2;
+            float sc[8], sh[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4 v4 = *reinterpret_cast<const float4*>(tq + 4 * e);
+                sc[2 * e] = v4.x; sh[2 * e] = v4.y; sc[2 * e + 1] = v4.z; sh[2 * e + 1] = v4.w;
+            }
+#pragma unroll
+            for (int it = 0; it < NA; ++it) {
+                u32x4 t;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const unsigned wv = ra[it][d];
+                    float lo = fmaf(__uint_as_float(wv << 16), sc[2 * d], sh[2 * d]);
+                    float hi = fmaf(__uint_as_float(wv & 0xffff0000u), sc[2 * d + 1], sh[2 * d + 1]);
+                    if (xf.act == PHX_ACT_RELU) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                    else if (xf.act != PHX_ACT_ID) { lo = act_fwd(lo, xf.act); hi = act_fwd(hi, xf.act); }
+                    t[d] = ga[it] == 0xffffffffu ? 0u : f2bf_pk(lo, hi);       // SAME padding pads a, not y
+                }
+                ra[it] = t;
+                if (wmask) __builtin_amdgcn_raw_buffer_store_b128(t, rsa, ((wmask >> it) & 1u) ? ga[it] : 0xffffffffu, ccur * 2, 0);
+            }
+        }
 #pragma unroll
         for (int it = 0; it < NA; ++it) {
             const int i = threadIdx.x + it * NT;
@@ -461,8 +562,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
     {
         const int cx0 = tx0, cy0 = ty0, cb0 = b0;
         const bool tr0 = true;
-        for (int c0 = cbeg; c0 + KC < cend; c0 += KC) chunk(c0 + KC, std::true_type(), c0 == KC);
-        chunk(0, std::false_type(), K == 2 * KC);
+        for (int c0 = cbeg; c0 + KC < cend; c0 += KC) chunk(c0, c0 + KC, std::true_type(), c0 == KC);
+        chunk(cend - KC, 0, std::false_type(), K == 2 * KC);
         if constexpr (SPLITK) {
             // fp32 partial tile -> ws[z][pixel][N]; C layout: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
             float* wz = ws + (size_t)blockIdx.z * B * H * W * N;
@@ -1704,11 +1805,11 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
             hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, false, NWv, Sv>), dim3(ntiles * (N / BNv), 1, ksplit),  \
                                dim3(NWv * 64), sh, (hipStream_t)stream, (const unsigned short*)x,                    \
                                (const unsigned short*)wpk, (unsigned short*)y, nullptr, 0, nullptr, B, H, W, K, N, g,\
-                               (float*)workspace, BwdStats{});                                                       \
+                               (float*)workspace, BwdStats{}, XForm{});                                              \
         else                                                                                                         \
             hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, Av, NWv, false>), dim3(ntiles * (N / BNv)), dim3(NWv * 64),\
                                sh, (hipStream_t)stream, (const unsigned short*)x, (const unsigned short*)wpk,        \
-                               (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, g, nullptr, bws);        \
+                               (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, g, nullptr, bws, XForm{}); \
     } while (0)
 #define CM_LAUNCH(BNv, NAv, Fv, NWv)                                                                                 \
     do {                                                                                                             \
@@ -1737,6 +1838,116 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
         const size_t total = (size_t)B * H * W * N;
         hipLaunchKernelGGL(k_splitk_finish, dim3(phx_grid_for(total / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)workspace, ksplit, total, N, bias, act, (unsigned short*)y, bws.oscale);
+        PHX_CHECK_LAUNCH();
+    }
+    return PHX_OK;
+}
+
+
+// ---- fused conv -> norm -> act -> conv edge (XF instantiations of k_conv3x3_mfma; register-staged 256-pixel tiles only) ----------
+static int xf_ksplit(int B, int H, int W, int K, int N) {
+    const char* e = getenv("PHX_FWD_SPLITK");
+    if (e && atoi(e) == 0) return 1;
+    MTile g = make_mtile(B, H, W);
+    const int blocks = g.tiles_x * g.tiles_y * g.tiles_b * (N / (N % 64 == 0 ? 64 : 32));
+    const int nck = K / KC;
+    if (blocks * 2 > 64 || nck < 2) return 1;
+    int ks = (64 + blocks - 1) / blocks;
+    if (ks > nck) ks = nck;
+    const int per = (nck + ks - 1) / ks;
+    return (nck + per - 1) / per;
+}
+int phx_conv3x3_xf_supported(int B, int H, int W, int K, int N, int NS) {
+    if (K % KC != 0 || N % 32 != 0 || K * 8 > XF_TBL_BYTES) return 0;
+    if ((double)B * H * W * (K > N ? K : N) >= 2147483648.0) return 0;
+    MTile g = make_mtile(B, H, W);
+    const bool fast16 = g.tws == 4 && g.ths == 4 && g.tb == 1;
+    if (!fast16 && (double)B * H * W >= 16777216.0) return 0;
+    if (NS > 1 && g.tb != 1) return 0;                 // per-sample statistics: a pixel tile must lie inside one sample
+    return 1;
+}
+int phx_conv3x3_xf_tiles(int B, int H, int W) {
+    MTile g = make_mtile(B, H, W);
+    return g.tiles_x * g.tiles_y * g.tiles_b;
+}
+size_t phx_conv3x3_xf_ws_bytes(int B, int H, int W, int K, int N) {
+    const int ks = xf_ksplit(B, H, W, K, N);
+    return ks > 1 ? (size_t)ks * B * H * W * N * sizeof(float) : 0;
+}
+int phx_conv3x3_mfma_bf16_xf(const void* y_prod, const void* wpk, void* y, const float* bias, int act, float* stats, int stats_atomic,
+                             void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, const float* p_sums,
+                             const float* p_pivot, const float* p_gamma, const float* p_beta, float p_eps, int p_nrep, int p_NS,
+                             int p_G, int p_act, void* a_out, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
+                             float* moving_mean, float* moving_var, float momentum, void* stream) {
+    PHX_REQUIRE(phx_conv3x3_xf_supported(B, H, W, K, N, p_NS), PHX_E_SHAPE, "conv3x3_mfma_xf: shape not supported (see ..._supported)");
+    PHX_REQUIRE((((uintptr_t)y_prod | (uintptr_t)wpk | (uintptr_t)y | (uintptr_t)a_out) & 15) == 0, PHX_E_ALIGN, "conv3x3_mfma_xf: 16-byte alignment");
+    PHX_REQUIRE(p_sums && p_gamma && p_beta && mean_out && rstd_out && scale_out && shift_out && p_nrep >= 1 && p_G >= 1 && K % p_G == 0 &&
+                (p_NS == 1 || p_NS == B), PHX_E_INVAL, "conv3x3_mfma_xf: bad normalisation arguments");
+    int ksplit = 1;
+    if (workspace && !stats) {
+        ksplit = xf_ksplit(B, H, W, K, N);
+        PHX_REQUIRE(workspace_bytes >= (size_t)(ksplit > 1 ? ksplit : 0) * B * H * W * N * sizeof(float), PHX_E_INVAL, "conv3x3_mfma_xf: workspace too small");
+    }
+    PHX_REQUIRE(!stats_atomic || (stats && !phx_deterministic()), PHX_E_INVAL, "conv3x3_mfma_xf: atomic statistics need a sums buffer (and no deterministic mode)");
+    XForm xf;
+    xf.sums = p_sums; xf.pivot = p_pivot; xf.gamma = p_gamma; xf.beta = p_beta; xf.eps = p_eps;
+    xf.invP = 1.f / (float)(p_NS > 1 ? H * W : B * H * W);
+    xf.nrep = p_nrep; xf.NS = p_NS; xf.G = p_G; xf.act = p_act; xf.a_out = (unsigned short*)a_out;
+    xf.mean_out = mean_out; xf.rstd_out = rstd_out; xf.scale_out = scale_out; xf.shift_out = shift_out;
+    xf.moving_mean = moving_mean; xf.moving_var = moving_var; xf.momentum = momentum;
+    BwdStats bws{};
+    bws.stats_atomic = stats_atomic;
+    MTile g = make_mtile(B, H, W);
+    const int tw = 1 << g.tws, th = 1 << g.ths;
+    const int npatch = g.tb * (th + 2) * (tw + 2);
+    const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
+    const int na = (npatch * 4 + 255) / 256;
+    PHX_REQUIRE(na <= 16, PHX_E_SHAPE, "conv3x3_mfma_xf: unexpected tile geometry");
+    const bool biasact = bias != nullptr || act != PHX_ACT_ID;
+    const bool fast16 = g.tws == 4 && g.ths == 4 && g.tb == 1;
+#define XF_LAUNCH1(BNv, NAv, Fv, Av, Sv)                                                                               \
+    do {                                                                                                             \
+        size_t sh = (Fv ? (size_t)(4 * 4 + 2) * PITCH16 : (size_t)npatch * ROWB) + 9 * BNv * ROWB;                   \
+        const size_t she = (size_t)4 * 64 * (BNv * 2 + 16);                                                          \
+        if (she > sh) sh = she;                                                                                      \
+        sh += XF_TBL_BYTES;                                                                                          \
+        static bool at = false;                                                                                      \
+        if (!at) {                                                                                                   \
+            PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_mfma<BNv, NAv, Fv, Av, 4, Sv, true>,            \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));              \
+            at = true;                                                                                               \
+        }                                                                                                            \
+        if (Sv)                                                                                                      \
+            hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, false, 4, Sv, true>), dim3(ntiles * (N / BNv), 1, ksplit), \
+                               dim3(256), sh, (hipStream_t)stream, (const unsigned short*)y_prod,                    \
+                               (const unsigned short*)wpk, (unsigned short*)y, nullptr, 0, nullptr, B, H, W, K, N, g,\
+                               (float*)workspace, BwdStats{}, xf);                                                   \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, Av, 4, false, true>), dim3(ntiles * (N / BNv)), dim3(256), \
+                               sh, (hipStream_t)stream, (const unsigned short*)y_prod, (const unsigned short*)wpk,   \
+                               (unsigned short*)y, bias, act, stats, B, H, W, K, N, g, nullptr, bws, xf);            \
+    } while (0)
+#define XF_LAUNCH(BNv, NAv, Fv)                                                                                      \
+    do {                                                                                                             \
+        if (ksplit > 1) XF_LAUNCH1(BNv, NAv, Fv, false, true);                                                       \
+        else if (biasact) XF_LAUNCH1(BNv, NAv, Fv, true, false);                                                     \
+        else XF_LAUNCH1(BNv, NAv, Fv, false, false);                                                                 \
+    } while (0)
+    static int n32thr = -1;
+    if (n32thr < 0) { const char* e = getenv("PHX_BN32_MAXBLOCKS"); n32thr = e ? atoi(e) : 256; }
+    const bool narrow32 = N % 64 == 0 && ksplit == 1 && ntiles * (N / 64) <= n32thr;
+    if (N % 64 == 0 && !narrow32) {
+        if (fast16) XF_LAUNCH(64, 8, true); else if (na <= 8) XF_LAUNCH(64, 8, false); else XF_LAUNCH(64, 16, false);
+    } else {
+        if (fast16) XF_LAUNCH(32, 8, true); else if (na <= 8) XF_LAUNCH(32, 8, false); else XF_LAUNCH(32, 16, false);
+    }
+#undef XF_LAUNCH
+#undef XF_LAUNCH1
+    PHX_CHECK_LAUNCH();
+    if (ksplit > 1 && y != nullptr) {
+        const size_t total = (size_t)B * H * W * N;
+        hipLaunchKernelGGL(k_splitk_finish, dim3(phx_grid_for(total / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)workspace, ksplit, total, N, bias, act, (unsigned short*)y, (const float*)nullptr);
         PHX_CHECK_LAUNCH();
     }
     return PHX_OK;

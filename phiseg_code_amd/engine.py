@@ -53,6 +53,18 @@ _STAMPS = os.environ.get("PHX_STAMPS", "0") == "1"
 _BN_SPLITK = os.environ.get("PHX_BN_SPLITK", "0") == "1"   # small batch norm consumes the split-K slices of its convolution (measured 0.5 % slower: off)
 _DETERMINISTIC = os.environ.get("PHX_DETERMINISTIC", "0") not in ("0", "")   # fixed summation orders everywhere (libphx reads the same variable)
 _BN_SMALL = int(os.environ.get("PHX_BN_SMALL", "1024"))     # one-launch batch norm up to this many pixels (0: off)
+# conv -> norm -> act -> conv edges: the consumer convolution finalises the producer's normalisation in its prologue, applies it while
+# staging and materialises a as a side effect (phx_conv3x3_mfma_bf16_xf) -- no stand-alone apply pass, no launch for it.  PHX_XF=1
+# turns it on (read when a plan is built).  OFF by default -- measured on MI355X (round 3, phiseg_7_5 B = 64): 39 of the 106
+# normalisation layers qualify, launches 1063 -> 1024, apply passes 1.18 -> 0.73 ms, but the step gets SLOWER (11.94 -> 12.82 ms):
+# the transform is ~7 VALU instructions per two elements INSIDE the convolution's staging phase (redone by every channel block of a
+# pixel tile and for the halo), where nothing overlaps it: 32 -> 32 @ 128 x 128 takes 75 us fused against 39 + 24 us (convolution +
+# apply pass at 5.5 TB/s), 128 -> 128 @ 128 x 128 0.64 ms against 0.31 + 0.09, 192 -> 192 @ 8 x 8 34 us against 15 + 9.
+def _xf_enabled():
+    return os.environ.get("PHX_XF", "0") == "1"
+
+
+_XF_MAXP = int(os.environ.get("PHX_XF_MAXP", str(1 << 30)))     # largest map (B * H * W) whose edges are fused (experiments)
 
 
 def _noop():
@@ -420,9 +432,9 @@ class Plan:
         return 0
 
     # ---------------------------------------------------------------------------------------------
-    def _emit(self, fn, *args, tag=None, flops=0.0):
+    def _emit(self, fn, *args, tag=None, flops=0.0, shape=None):
         if tag is not None:
-            self.tags[(id(self._cur), len(self._cur))] = (tag, float(flops))
+            self.tags[(id(self._cur), len(self._cur))] = (tag, float(flops), shape)
         self._cur.append((fn, args))
         self._lane_seq[self._lane] = self._lane_seq.get(self._lane, 0) + 1
 
@@ -539,6 +551,7 @@ class Plan:
         opset = set(ops)
         self._opset = opset
         self._bws = {}                # producer conv op -> (partials, tiles): BN-backward sums fused into the consumer's dgrad
+        self._xf_pending = {}         # tensor a = act(norm(y)) whose apply pass was left to its (single) consumer convolution
         fork = self._record(0) if nl > 1 else None          # lanes 1.. join the capture / wait for the memsets
         for ln in range(1, nl):
             self._lane = ln
@@ -790,11 +803,32 @@ class Plan:
         st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn)
         self.saved[op] = st
 
+    def _xf_consumer(self, op):
+        """The convolution unit that can take over the normalisation + activation of `op` (fused edge), or None: the ONLY reader of
+        a = act(norm(conv(x))) is a 3x3 convolution on the bf16 MFMA path with a multiple of 32 input channels."""
+        if not _xf_enabled() or self.act_dt != BF16:
+            return None
+        out = op.outputs[0]
+        if out in self.fetches:
+            return None
+        cons = self._real_consumers(out, self._opset)
+        if len(cons) != 1 or cons[0].type != "conv_unit":
+            return None
+        c = cons[0]
+        ca = c.attrs
+        if ca.get("transposed") is not None or ca.get("general") is not None or ca["ksize"] != 3 or c.inputs[0] is not out:
+            return None
+        cin, cout = ca["W"].shape[-2], ca["W"].shape[-1]
+        if cin % 32 != 0 or cout % 32 != 0 or self._dt_of(c.outputs[0]) != BF16:
+            return None
+        return c
+
     def _fw_conv_unit(self, op, bw):
         a = op.attrs
         if a.get("transposed") is not None or a.get("general") is not None:
             return self._fw_tconv_unit(op, bw)
         x = self.val[op.inputs[0]]
+        pend = self._xf_pending.pop(op.inputs[0], None)      # the producer left its normalisation to this convolution
         W, b = a["W"], a["b"]
         k, (_, _, cin, cout) = a["ksize"], W.shape
         B, H, Wd = x.shape[0], x.shape[1], x.shape[2]
@@ -834,8 +868,31 @@ class Plan:
         head1x1 = (k == 1 and out.dt == F32 and cout in (2, 4, 6, 8) and a["norm"] is None and b is not None)
         st["head1x1"] = head1x1
 
-        def conv_into(y, act_code, stats_direct=None, stats_part=None):
-            if head1x1:
+        if pend is not None and not (mfma and not padded and not head1x1 and x.dt == BF16):
+            # (not reached with the shapes _xf_consumer admits) the normalisation is applied by its own launch after all
+            self._emit(Lb.norm_apply_fused, *pend["apply_args"], S)
+            pend = None
+        xf = pend is not None
+
+        def tiles_fn():
+            return int(Lb.conv3x3_xf_tiles(B, H, Wd)) if xf else int(Lb.conv3x3_mfma_bf16_tiles(B, H, Wd, cin_eff, cout))
+
+        def conv_into(y, act_code, stats_direct=None, stats_part=None, stats_atomic=None):
+            if xf:
+                st_buf = stats_atomic if stats_atomic is not None else stats_part
+                wsb = int(Lb.conv3x3_xf_ws_bytes(B, H, Wd, cin_eff, cout)) if st_buf is None else 0
+                ws = self._alloc((wsb // 4,), F32) if wsb else None
+                d = pend
+                self._emit(Lb.conv3x3_mfma_bf16_xf, d["y"].ptr, wf.ptr, y.ptr, bptr, act_code, st_buf.ptr if st_buf is not None else None,
+                           1 if stats_atomic is not None else 0, ws.ptr if ws else None, wsb, B, H, Wd, cin_eff, cout,
+                           d["sums"].ptr, d["pivot"].ptr if d["pivot"] is not None else None, d["gamma"], d["beta"], d["eps"], 1,
+                           d["NS"], d["G"], d["act"], x.ptr, d["mean"].ptr, d["rstd"].ptr, d["scale"].ptr, d["shift"].ptr,
+                           d["mm"], d["mv"], d["mom"], S, tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd,
+                           shape=("xf", B, H, Wd, cin_eff, cout))
+            elif stats_atomic is not None:
+                self._emit(Lb.conv3x3_mfma_bf16_stats_atomic, x.ptr, wf.ptr, y.ptr, bptr, act_code, stats_atomic.ptr, B, H, Wd, cin_eff,
+                           cout, S, tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
+            elif head1x1:
                 self._emit(Lb.head1x1_fwd, x.ptr, x.dt, wptr, bptr, y.ptr, B * H * Wd, cin, cout, act_code, S)
             elif mfma:
                 wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cin_eff, cout)) if stats_part is None else 0
@@ -864,7 +921,7 @@ class Plan:
         scale, shift = self._alloc((NS * cout,), F32), self._alloc((NS * cout,), F32)
         mean, rstd = self._alloc((NS * Gn,), F32), self._alloc((NS * Gn,), F32)
         eps = tfnorm.EPS[norm]
-        if norm == "batch" and not training and mfma and not head1x1 and not bw and os.environ.get("PHX_BN_FOLD", "1") == "1":
+        if norm == "batch" and not training and mfma and not head1x1 and not bw and not xf and os.environ.get("PHX_BN_FOLD", "1") == "1":
             # inference-mode batch norm + activation folded into the convolution's epilogue (phx_conv3x3_mfma_bf16_affine):
             # one launch where the reference runs conv2d, batch_norm and relu; the scale / shift vectors of all layers come
             # from one launch at the head of the run
@@ -892,7 +949,7 @@ class Plan:
                 mm = self.store.ptr(nv["moving_mean"]) if upd else None
                 mv = self.store.ptr(nv["moving_variance"]) if upd else None
                 mom = (1.0 - tfnorm.BN_DECAY) if upd else 0.0
-                ks = int(Lb.conv3x3_mfma_ksplit(B, H, Wd, cin_eff, cout)) if (mfma and not head1x1 and _BN_SPLITK) else 1
+                ks = int(Lb.conv3x3_mfma_ksplit(B, H, Wd, cin_eff, cout)) if (mfma and not head1x1 and _BN_SPLITK and not xf) else 1
                 if ks > 1:        # split-K convolution: its fp32 slices go straight into the norm kernel (no finishing launch)
                     wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cin_eff, cout))
                     ws = self._alloc((wsb // 4,), F32)
@@ -913,7 +970,7 @@ class Plan:
             # wave per (sample, 16-channel slice)); a split-K convolution hands over its slices and its bias
             if (norm != "batch" and _NORM_SMALL and y.dt == BF16 and out.dt == BF16
                     and Lb.norm_small_supported(NS, P, cout, Gn, BF16)):
-                ks = int(Lb.conv3x3_mfma_ksplit(B, H, Wd, cin_eff, cout)) if (mfma and not head1x1 and _BN_SPLITK) else 1
+                ks = int(Lb.conv3x3_mfma_ksplit(B, H, Wd, cin_eff, cout)) if (mfma and not head1x1 and _BN_SPLITK and not xf) else 1
                 if ks > 1:
                     wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cin_eff, cout))
                     ws = self._alloc((wsb // 4,), F32)
@@ -936,20 +993,19 @@ class Plan:
             # a statistic has few samples (cheap there); otherwise the sums come from the conv epilogue.
             small = P <= 16384 or self.act_dt == F32
             if norm == "batch" and mfma and not small:
-                ntile = Lb.conv3x3_mfma_bf16_tiles(B, H, Wd, cin_eff, cout)
+                ntile = tiles_fn()
                 part = self._alloc((ntile * 2 * cout,), F32)
                 conv_into(y, 0, stats_part=part)
                 self._emit(Lb.norm_reduce_partials, part.ptr, ntile, cout, sums.ptr, S)
             elif (norm == "batch" and mfma and small and _STATS_ATOMIC and not _DETERMINISTIC and not head1x1 and self.act_dt == BF16
-                  and Lb.conv3x3_mfma_stats_atomic_supported(B, H, Wd, cin_eff, cout)):
+                  and (tiles_fn() <= 64 if xf else Lb.conv3x3_mfma_stats_atomic_supported(B, H, Wd, cin_eff, cout))):
                 # few pixel tiles (the H <= 16 levels): the convolution adds its statistics straight into `sums` -- no pass over y
-                self._emit(Lb.conv3x3_mfma_bf16_stats_atomic, x.ptr, wf.ptr, y.ptr, bptr, 0, sums.ptr, B, H, Wd, cin_eff, cout, S,
-                           tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
+                conv_into(y, 0, stats_atomic=sums)
             elif (norm != "batch" and mfma and _GN_STATS_EPILOGUE and not head1x1 and self.act_dt == BF16 and H % 16 == 0 and Wd % 16 == 0
-                  and Lb.conv3x3_mfma_bf16_tiles(B, H, Wd, cin_eff, cout) % B == 0):
+                  and tiles_fn() % B == 0):
                 # group / instance norm on maps of at least 16 x 16: a pixel tile lies inside one sample, so the convolution's per-tile
                 # sums reduce to per-sample sums without another pass over y (phx_norm_reduce_partials_ns)
-                ntile = Lb.conv3x3_mfma_bf16_tiles(B, H, Wd, cin_eff, cout)
+                ntile = tiles_fn()
                 part = self._alloc((ntile * 2 * cout,), F32)
                 conv_into(y, 0, stats_part=part)
                 self._emit(Lb.norm_reduce_partials_ns, part.ptr, ntile // B, B, cout, sums.ptr, S)
@@ -960,12 +1016,20 @@ class Plan:
                 conv_into(y, 0)
                 self._emit(Lb.norm_stats, y.ptr, y.dt, sums.ptr, pivot.ptr, NS, P, cout, S)
             upd = norm == "batch" and training and self.loss is not None
-            self._emit(Lb.norm_apply_fused, y.ptr, y.dt, sums.ptr, pivot.ptr if pivot is not None else None, gptr, beptr,
-                       eps, out.ptr, out.dt, mean.ptr, rstd.ptr, scale.ptr, shift.ptr,
-                       self.store.ptr(nv["moving_mean"]) if upd else None,
-                       self.store.ptr(nv["moving_variance"]) if upd else None,
-                       (1.0 - tfnorm.BN_DECAY) if upd else 0.0, NS, P, cout, Gn, act, S,
-                       tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
+            mmp = self.store.ptr(nv["moving_mean"]) if upd else None
+            mvp = self.store.ptr(nv["moving_variance"]) if upd else None
+            mom = (1.0 - tfnorm.BN_DECAY) if upd else 0.0
+            apply_args = (y.ptr, y.dt, sums.ptr, pivot.ptr if pivot is not None else None, gptr, beptr, eps, out.ptr, out.dt, mean.ptr,
+                          rstd.ptr, scale.ptr, shift.ptr, mmp, mvp, mom, NS, P, cout, Gn, act)
+            cons = self._xf_consumer(op) if (mfma and y.dt == BF16 and out.dt == BF16 and B * H * Wd <= _XF_MAXP) else None
+            if cons is not None and Lb.conv3x3_xf_supported(B, H, Wd, cout, cons.attrs["W"].shape[-1], NS):
+                # fused edge: the consumer convolution finalises these statistics, applies act(y * scale + shift) while it stages
+                # its input and writes a (= out) as a side effect
+                self._xf_pending[op.outputs[0]] = dict(y=y, sums=sums, pivot=pivot, gamma=gptr, beta=beptr, eps=eps, NS=NS, G=Gn, act=act,
+                                                       mean=mean, rstd=rstd, scale=scale, shift=shift, mm=mmp, mv=mvp, mom=mom,
+                                                       apply_args=apply_args)
+            else:
+                self._emit(Lb.norm_apply_fused, *apply_args, S, tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
         st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn)
         if norm != "batch":
             st.update(fsums=sums, fpivot=pivot)          # forward per-channel sums: the bias gradient is closed-form from them
@@ -1666,7 +1730,8 @@ class Plan:
             self.L.event_record(ev1, st)
             self.L.event_sync(ev1)
             self.L.event_elapsed_ms(ev0, ev1, ctypes.byref(ms))
-            out.append((tg[0], tg[1], ms.value / repeats, tuple(a for a in args if isinstance(a, int) and a < 1 << 20)))
+            out.append((tg[0], tg[1], ms.value / repeats,
+                        tg[2] if tg[2] is not None else tuple(a for a in args if isinstance(a, int) and a < 1 << 20)))
         self.L.event_destroy(ev0)
         self.L.event_destroy(ev1)
         return out
