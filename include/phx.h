@@ -437,6 +437,9 @@ int phx_augment_batch(const float* images, const unsigned char* labels, const vo
  *                        inside one RCCL group, ENQUEUED on `stream` (ordered after / before the work around it on that stream;
  *                        nothing blocks the host)
  * Errors: PHX_E_COMM with the RCCL error text in phx_last_error. */
+/* dlopen librccl and bind its entry points (idempotent; the other phx_comm_* calls do it implicitly): a per-rank check that can run
+ * before any collective bootstrap step */
+int phx_comm_load_api(void);
 int phx_comm_unique_id(void* id128);
 int phx_comm_init(void** comm, int world, int rank, const void* id128);
 int phx_comm_allreduce_sum_f32(void* comm, float* buf, size_t n, size_t bucket_elems, void* stream);

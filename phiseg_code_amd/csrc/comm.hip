@@ -70,6 +70,9 @@ struct Comm {
 
 extern "C" {
 
+/* dlopen librccl and bind the entry points (idempotent): lets every rank check that RCCL is usable BEFORE any collective step */
+int phx_comm_load_api(void) { return load_api(); }
+
 int phx_comm_unique_id(void* id128) {
     PHX_REQUIRE(id128 != nullptr, PHX_E_INVAL, "phx_comm_unique_id: null buffer");
     const int rc = load_api();
@@ -107,7 +110,12 @@ int phx_comm_allreduce_sum_f32(void* comm, float* buf, size_t n, size_t bucket_e
     PHX_CHECK_NCCL(g_api.GroupStart());
     for (size_t i = 0; i < n; i += bucket_elems) {
         const size_t m = n - i < bucket_elems ? n - i : bucket_elems;
-        PHX_CHECK_NCCL(g_api.AllReduce(buf + i, buf + i, m, NCCL_FLOAT32, NCCL_SUM, c->comm, (hipStream_t)stream));
+        const int r = g_api.AllReduce(buf + i, buf + i, m, NCCL_FLOAT32, NCCL_SUM, c->comm, (hipStream_t)stream);
+        if (r != 0) {                              // never leave the group open: close it, then report the first error
+            phx_set_error("phx_comm_allreduce_sum_f32: ncclAllReduce -> %s", g_api.GetErrorString(r));
+            g_api.GroupEnd();
+            return PHX_E_COMM;
+        }
     }
     PHX_CHECK_NCCL(g_api.GroupEnd());
     return PHX_OK;

@@ -128,18 +128,20 @@ int phx_memset(void* dst, int value, size_t bytes, void* stream) {
 // checkpoints carry per block and per tensor (tfwrapper/tf_checkpoint.py); *crc is the running value (0 to start).
 int phx_crc32c(const void* data, size_t n, unsigned* crc) {
     PHX_REQUIRE(crc != nullptr && (data != nullptr || n == 0), PHX_E_INVAL, "crc32c: null argument");
-    static unsigned tab[8][256];
-    static bool init = false;
-    if (!init) {
-        for (unsigned i = 0; i < 256; ++i) {
-            unsigned c = i;
-            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
-            tab[0][i] = c;
+    struct Tab {
+        unsigned t[8][256];
+        Tab() {
+            for (unsigned i = 0; i < 256; ++i) {
+                unsigned c = i;
+                for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
+                t[0][i] = c;
+            }
+            for (unsigned i = 0; i < 256; ++i)
+                for (int k = 1; k < 8; ++k) t[k][i] = (t[k - 1][i] >> 8) ^ t[0][t[k - 1][i] & 0xff];
         }
-        for (unsigned i = 0; i < 256; ++i)
-            for (int t = 1; t < 8; ++t) tab[t][i] = (tab[t - 1][i] >> 8) ^ tab[0][tab[t - 1][i] & 0xff];
-        init = true;
-    }
+    };
+    static const Tab table;                        // function-local static: initialised once, thread-safe (C++11)
+    const unsigned (*tab)[256] = table.t;
     const unsigned char* p = static_cast<const unsigned char*>(data);
     unsigned c = ~*crc;
     while (n && (reinterpret_cast<uintptr_t>(p) & 7)) { c = (c >> 8) ^ tab[0][(c ^ *p++) & 0xff]; --n; }

@@ -45,19 +45,36 @@ class DistContext:
                     and os.environ.get("PHX_COMM", "native") == "native"):
                 from phiseg_code_amd import runtime as rt
                 L = rt.lib()
-                idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-                if self.rank == 0:
-                    buf = ctypes.create_string_buffer(128)
-                    L.comm_unique_id(buf)
-                    idt.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
-                dist.broadcast(idt, src=0)
-                raw = bytes(idt.cpu().numpy().tobytes())
-                comm = ctypes.c_void_p()
+                # Every step that can fail on ONE rank is followed by a MIN-all-reduce of an ok flag BEFORE the next collective
+                # step, so a failing rank never leaves the others blocked inside a broadcast or inside ncclCommInitRank (which is
+                # itself collective): (1) the RCCL entry points load on every rank, (2) rank 0 has a rendezvous id.
+                def all_ok(ok):
+                    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    return int(flag.item()) == 1
                 ok, err = 1, ""
                 try:
-                    L.comm_init(ctypes.byref(comm), self.world, self.rank, raw)
-                except rt.PhxError as e:           # (e.g. an RCCL build the dlopen'd entry points do not match)
+                    L.comm_load_api()
+                except rt.PhxError as e:
                     ok, err = 0, str(e)
+                idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if ok and self.rank == 0:
+                    try:
+                        buf = ctypes.create_string_buffer(128)
+                        L.comm_unique_id(buf)
+                        idt.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+                    except rt.PhxError as e:
+                        ok, err = 0, str(e)
+                comm = ctypes.c_void_p()
+                if all_ok(ok):
+                    dist.broadcast(idt, src=0)
+                    raw = bytes(idt.cpu().numpy().tobytes())
+                    try:
+                        L.comm_init(ctypes.byref(comm), self.world, self.rank, raw)
+                    except rt.PhxError as e:       # (e.g. an RCCL build the dlopen'd entry points do not match)
+                        ok, err = 0, str(e)
+                else:
+                    ok, err = 0, err or "RCCL unavailable on another rank"
                 # every rank must take the same path: if ANY rank failed, all fall back to torch.distributed's RCCL collectives
                 # (same exchange, issued through torch instead of phx_comm_*) -- loudly, it is still the HIP extension that computes
                 flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
@@ -111,6 +128,14 @@ class DistContext:
             w.wait()
         if self.cuda:
             torch.cuda.current_stream().synchronize()
+
+    def broadcast_flags(self, flags, src=0):
+        """-> rank `src`'s list of small integers on every rank (decisions that must be rank-invariant)."""
+        if not self.active:
+            return list(flags)
+        t = torch.tensor([int(f) for f in flags], dtype=torch.int32, device=self._scalar_device())
+        dist.broadcast(t, src=src)
+        return [int(v) for v in t.cpu().tolist()]
 
     def barrier(self):
         if self.active:

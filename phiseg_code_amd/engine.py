@@ -685,9 +685,13 @@ class Plan:
         out = self._alloc((), F32)
         work = self._alloc((256,), F32)
         self.val[op.outputs[0]] = out
-        self._emit(self.L.l2_masked, st.params.data_ptr(), st.decay_mask.data_ptr(), st.n_train, op.attrs["scale"], work.ptr, out.ptr, self.stream)
+        # data parallel (loss_inv_batch = 1 / (B * world)): every rank evaluates the term on the full parameter set, the scalar fetches
+        # and the gradient arena are SUMMED over the ranks -> each rank carries a 1 / world share of the term and of its gradient
+        share = self.inv_batch * self.B
+        self._emit(self.L.l2_masked, st.params.data_ptr(), st.decay_mask.data_ptr(), st.n_train, op.attrs["scale"] * share, work.ptr, out.ptr,
+                   self.stream)
         if bw:
-            self._l2_weight = self.loss_weight.get(op.outputs[0], 0.0) * op.attrs["scale"]
+            self._l2_weight = self.loss_weight.get(op.outputs[0], 0.0) * op.attrs["scale"] * share
 
     def _bw_l2_weights(self, op):
         st = self.store

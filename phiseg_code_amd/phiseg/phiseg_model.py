@@ -203,6 +203,8 @@ class phiseg():
         self.train_step = TrainStep(self.loss_tot)
 
         self._multi = {}
+        self.keep_checkpoint_every_n_hours = 3.0          # tf.train.Saver(max_to_keep=1, keep_checkpoint_every_n_hours=3) (phiseg_model.py:144)
+        self._ckpt_permanent, self._ckpt_last_permanent = {}, time.time()
         self.sess = Session(self, getattr(exp_config, 'compute_dtype', 'f32'), rng_seed=rng_seed, dist=dist)
         self.dist = dist
 
@@ -281,9 +283,18 @@ class phiseg():
         cfg = self.exp_config
         store = self.sess._ensure_store()
         global_step = int(store.step.cpu().item()) - 1               # tf global_step - 1 (phiseg_model.py:532)
+        dp = self.dist is not None and self.dist.active
+        # Data parallel: every decision below that leads to a collective (save_weights averages the batch-norm moving statistics
+        # over the replicas) must be the same on all ranks -- the per-rank metrics differ (noise offsets, random annotators).  Rank 0
+        # decides; its flags are broadcast.  The replicas' moving statistics are averaged ONCE, here, so that the best-of saves
+        # further down run no collective at all.
         save = getattr(self, 'log_dir', None) is not None and os.path.isdir(getattr(self, 'log_dir', '') or '')
+        if dp:
+            save = bool(self.dist.broadcast_flags([1 if save else 0])[0])
+            self._average_replica_state()
         if save:
-            self.save_weights(os.path.join(self.log_dir, 'model.ckpt-%d' % global_step), format=self._ckpt_format())
+            self.save_weights(os.path.join(self.log_dir, 'model.ckpt-%d' % global_step), format=self._ckpt_format(),
+                              keep_prefix='model.ckpt', max_to_keep=1, average_state=False)
         if hasattr(data.validation, 'next_batch'):                   # BATCH VALIDATION of every loss term (537-556)
             names = list(self.loss_dict.keys())
             val_x, val_s = data.validation.next_batch(cfg.batch_size)
@@ -326,23 +337,68 @@ class phiseg():
         if not hasattr(self, 'best_dice'):
             self.best_dice, self.best_loss, self.best_ged, self.best_ncc = -1, np.inf, np.inf, -1
         mean_dice = float(np.mean(out['per_structure_dice']))
-        for key, value, better, fmt in (('dice', mean_dice, mean_dice >= self.best_dice, 'New best validation Dice! (%.3f)'),
-                                        ('loss', out['loss'], out['loss'] <= self.best_loss, 'New best validation loss! (%.3f)'),
-                                        ('ged', out['ged'], out['ged'] <= self.best_ged, 'New best GED score! (%.3f)'),
-                                        ('ncc', out['ncc'], out['ncc'] >= self.best_ncc, 'New best NCC score! (%.3f)')):
+        cands = (('dice', mean_dice, mean_dice >= self.best_dice, 'New best validation Dice! (%.3f)'),
+                 ('loss', out['loss'], out['loss'] <= self.best_loss, 'New best validation loss! (%.3f)'),
+                 ('ged', out['ged'], out['ged'] <= self.best_ged, 'New best GED score! (%.3f)'),
+                 ('ncc', out['ncc'], out['ncc'] >= self.best_ncc, 'New best NCC score! (%.3f)'))
+        flags = [1 if c[2] else 0 for c in cands]
+        if dp:
+            flags = self.dist.broadcast_flags(flags)                   # rank 0's metrics decide on every rank
+        for (key, value, _, fmt), better in zip(cands, flags):
             if better:
                 setattr(self, 'best_' + key, value)
                 logging.info(fmt % value)
-                if save:
-                    self.save_weights(os.path.join(self.log_dir, 'model_best_%s.ckpt-%d' % (key, global_step)), format=self._ckpt_format())
+                if save:                                               # (the reference: Saver(max_to_keep=2) per best-of saver)
+                    self.save_weights(os.path.join(self.log_dir, 'model_best_%s.ckpt-%d' % (key, global_step)), format=self._ckpt_format(),
+                                      keep_prefix='model_best_%s.ckpt' % key, max_to_keep=2, average_state=False)
         return out
+
+    def _average_replica_state(self):
+        """Data parallel: batch-norm moving statistics are per replica; average them over the ranks."""
+        store = self.sess._ensure_store()
+        if self.dist is not None and self.dist.active and store.n_state:
+            avg = store.state.clone()
+            self.dist.allreduce_sum(avg)
+            avg /= self.dist.world
+            store.state.copy_(avg)
+            engine.device_sync()
+
+    def _prune_checkpoints(self, directory, keep_prefix, max_to_keep):
+        """tf.train.Saver(max_to_keep=...) (phiseg_model.py:144-148): delete all but the newest `max_to_keep` checkpoints named
+        <keep_prefix>-<step>(.npz | .index + .data-*); -> the retained prefixes, oldest first."""
+        import glob
+        import re
+        found = {}
+        for f in glob.glob(os.path.join(directory, keep_prefix + '-*')):
+            m = re.match(re.escape(keep_prefix) + r'-(\d+)(\.npz|\.index|\.data-\d+-of-\d+)$', os.path.basename(f))
+            if m:
+                found.setdefault(int(m.group(1)), []).append(f)
+        steps = sorted(found)
+        # keep_checkpoint_every_n_hours (3 for the training saver): a checkpoint that falls out of the max_to_keep window is kept for
+        # good when that many hours of training have passed since the last one kept this way
+        keep_h = self.keep_checkpoint_every_n_hours if keep_prefix == 'model.ckpt' else None
+        perm = self._ckpt_permanent.setdefault(keep_prefix, set())
+        for s in steps[:-max_to_keep] if max_to_keep > 0 else []:
+            if s in perm:
+                continue
+            if keep_h is not None and time.time() - self._ckpt_last_permanent >= keep_h * 3600.0:
+                perm.add(s)
+                self._ckpt_last_permanent = time.time()
+                continue
+            for f in found[s]:
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
+        kept = [s for s in steps if s in perm or s in steps[-max_to_keep:]]
+        return [os.path.join(directory, '%s-%d' % (keep_prefix, s)) for s in kept]
 
     # ---- checkpoints (npz keyed by the TF variable names of SURVEY.md Appendix B) -------------------
     def _ckpt_format(self):
         """exp_config.checkpoint_format: 'npz' (default) or 'tf' (TensorFlow tensor bundles, as the reference's Saver writes)"""
         return getattr(self.exp_config, 'checkpoint_format', 'npz')
 
-    def save_weights(self, path, format='npz'):
+    def save_weights(self, path, format='npz', keep_prefix=None, max_to_keep=0, average_state=True):
         """What tf.train.Saver writes for this graph (phiseg_model.py:144-148, 534-535): every variable, the Adam slots under
         TF's names '<var>/Adam' (m) and '<var>/Adam_1' (v), and the step (TF keeps beta1_power / beta2_power and global_step;
         one integer carries the same information).  File: <path>.npz, or with format='tf' a TensorFlow tensor-bundle checkpoint
@@ -350,13 +406,8 @@ class phiseg():
         graph accepts: same variable names, beta1_power / beta2_power / global_step included.  Data-parallel: batch-norm
         moving statistics are averaged over the replicas first (per-replica statistics); rank 0 writes."""
         store = self.sess._ensure_store()
-        dp = self.dist is not None and self.dist.active
-        if dp and store.n_state:
-            avg = store.state.clone()
-            self.dist.allreduce_sum(avg)
-            avg /= self.dist.world
-            store.state.copy_(avg)
-            engine.device_sync()
+        if average_state:              # (a collective: every rank must call save_weights -- _do_validation averages once itself)
+            self._average_replica_state()
         if not self._is_writer():
             return
         blob = dict(store.export())
@@ -375,7 +426,9 @@ class phiseg():
             blob['beta2_power'] = np.asarray(b2 ** (step + 1), dtype=np.float32)
             blob['global_step'] = np.asarray(step, dtype=np.int64)
             tf_checkpoint.write(path, blob)
-            tf_checkpoint.update_checkpoint_state(os.path.dirname(os.path.abspath(path)), os.path.basename(path))
+            d = os.path.dirname(os.path.abspath(path))
+            kept = self._prune_checkpoints(d, keep_prefix, max_to_keep) if keep_prefix else None
+            tf_checkpoint.update_checkpoint_state(d, os.path.basename(path), all_paths=[os.path.basename(k) for k in kept] if kept else None)
             return
         if format != 'npz':
             raise ValueError("save_weights: format is 'npz' or 'tf'")
@@ -385,6 +438,8 @@ class phiseg():
         tmp = path + '.tmp.npz'
         np.savez(tmp, __step__=np.asarray([step], dtype=np.int32), **blob)
         os.replace(tmp, path)
+        if keep_prefix:
+            self._prune_checkpoints(os.path.dirname(os.path.abspath(path)), keep_prefix, max_to_keep)
 
     def load_weights(self, log_dir=None, type='latest', **kwargs):
         """phiseg_model.py:505-525 (+ 'best_ncc', which the reference writes but cannot load -- SURVEY.md Q9).  `log_dir` may
@@ -429,6 +484,11 @@ class phiseg():
             files = ck.files
             step = int(ck['__step__'][0]) if '__step__' in files else 0
         store.load({k: ck[k] for k in files if k in names})
+        missing = sorted(names - set(files))
+        if missing:                      # (a name-mapping error would otherwise pass silently: those variables keep their values)
+            logging.warning('load_weights: %d of %d graph variables are not in %s and keep their values (first: %s)',
+                            len(missing), len(names), path, ', '.join(missing[:3]))
+        self.last_load_missing = missing
         slots = {k[:-len('/Adam')]: (ck[k], ck[k + '_1']) for k in files if k.endswith('/Adam') and k + '_1' in files}
         if slots:
             store.load_adam(slots)

@@ -314,10 +314,10 @@ def write(prefix, tensors):
     os.replace(prefix + ".index.tmp", prefix + ".index")
 
 
-def update_checkpoint_state(folder, basename, keep=None):
+def update_checkpoint_state(folder, basename, keep=None, all_paths=None):
     """The text file `checkpoint` tf.train.Saver maintains next to its bundles (CheckpointState proto in text format):
     model_checkpoint_path = the newest prefix, all_model_checkpoint_paths = the ones kept."""
-    keep = list(keep or [basename])
+    keep = list(all_paths or keep or [basename])
     with open(os.path.join(folder, "checkpoint"), "w") as f:
         f.write('model_checkpoint_path: "%s"\n' % basename)
         for k in keep:

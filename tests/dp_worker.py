@@ -23,6 +23,10 @@ def main():
     b = cfg["B"]                                         # images per rank; global batch = world * b
     gb = b * ctx.world
     c = make_config(cfg, dtype)
+    if os.environ.get("PHX_TEST_WD"):                    # weight decay term (phiseg_model.py:126-128): data-parallel share test
+        c.weight_decay_weight = float(os.environ["PHX_TEST_WD"])
+    if os.environ.get("PHX_TEST_TRAIN_DIR"):             # model.train(data, log_dir) through several validations on every rank
+        return train_with_validation(ctx, c, os.environ["PHX_TEST_TRAIN_DIR"], out_dir)
     model = phiseg_model.phiseg(c, dist=ctx if ctx.active else None, rng_seed=cfg["eps_seed"])
     params = otrain.make_params(var_order, cfg["weight_seed"], torch.float64, perturbed=True)
     if ctx.rank == 0:                                    # only rank 0 holds the weights: the broadcast at store creation /
@@ -50,6 +54,27 @@ def main():
     for k, v in store.export().items():
         blob["param/" + k] = v
     np.savez(os.path.join(out_dir, "rank%d.npz" % ctx.rank), **blob)
+    ctx.barrier()
+    ctx.shutdown()
+
+
+def train_with_validation(ctx, c, log_dir, out_dir):
+    """train() with validation_frequency = 1: every validation takes the best-of decisions and writes checkpoints -- the ranks'
+    metrics differ (noise offsets, random annotators), the decisions and the collectives they lead to must not."""
+    from phiseg_code_amd.data import synthetic
+    from phiseg_code_amd.phiseg import phiseg_model
+    c.batch_size = 2
+    c.validation_frequency = 1
+    c.validation_samples = 4
+    c.num_validation_images = 2
+    c.annotator_range = range(4)
+    c.lr_schedule_dict = {0: 1e-3}
+    np.random.seed(100 + ctx.rank)                       # (the reference draws the validation annotator from the global numpy state)
+    model = phiseg_model.phiseg(c, dist=ctx if ctx.active else None)
+    data = synthetic.SyntheticLIDC(c, seed=1234 + ctx.rank, n_validation=3)
+    losses = model.train(data, num_iter=4, log_every=0, log_dir=log_dir)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % ctx.rank), losses=np.array(losses),
+             best=np.array([model.best_dice, model.best_loss, model.best_ged, model.best_ncc]))
     ctx.barrier()
     ctx.shutdown()
 

@@ -37,9 +37,9 @@ def test_train_writes_checkpoints_and_best_of(tmp_path):
     losses = model.train(_data(cfg), num_iter=5, log_every=0, log_dir=log_dir)
     assert len(losses) == 5 and np.all(np.isfinite(losses))
     files = sorted(os.listdir(log_dir))
-    # validation at steps 0, 2, 4: model.ckpt-<step> each time, best-of files for the four criteria
-    for st in (0, 2, 4):
-        assert "model.ckpt-%d.npz" % st in files
+    # validation at steps 0, 2, 4: model.ckpt-<step> each time -- only the newest is kept (Saver(max_to_keep=1),
+    # phiseg_model.py:144-148) -- and best-of files for the four criteria (max_to_keep=2 each)
+    assert [f for f in files if f.startswith("model.ckpt-")] == ["model.ckpt-4.npz"], files
     for crit in ("dice", "loss", "ged", "ncc"):
         assert any(f.startswith("model_best_%s.ckpt-" % crit) for f in files), files
     assert tfutils.get_latest_model_checkpoint_path(log_dir, "model.ckpt") == os.path.join(log_dir, "model.ckpt-4")
@@ -54,8 +54,14 @@ def test_train_writes_checkpoints_and_best_of(tmp_path):
     m2 = phiseg_model.phiseg(cfg)
     for t in ("latest", "best_dice", "best_loss", "best_ged", "best_ncc"):
         m2.load_weights(log_dir, type=t)
-    m2.load_weights(log_dir, type="iter", iteration=2)
-    assert int(m2.sess.store.step.cpu().item()) == 3
+    m2.load_weights(log_dir, type="iter", iteration=4)
+    assert int(m2.sess.store.step.cpu().item()) == 5
+    # keep_checkpoint_every_n_hours: with the interval at zero every checkpoint that leaves the max_to_keep window is kept for good
+    m3 = phiseg_model.phiseg(cfg)
+    m3.keep_checkpoint_every_n_hours = 0.0
+    log3 = str(tmp_path / "run3")
+    m3.train(_data(cfg), num_iter=5, log_every=0, log_dir=log3)
+    assert sorted(f for f in os.listdir(log3) if f.startswith("model.ckpt-")) == ["model.ckpt-0.npz", "model.ckpt-2.npz", "model.ckpt-4.npz"]
     with pytest.raises(ValueError):
         m2.load_weights(log_dir, type="nonsense")
 

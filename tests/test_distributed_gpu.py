@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(nproc, out_dir, case, dtype, steps, port):
-    env = dict(os.environ, PHX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+def _launch(nproc, out_dir, case, dtype, steps, port, extra_env=None):
+    env = dict(os.environ, PHX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT, **(extra_env or {}))
     env.pop("RANK", None); env.pop("WORLD_SIZE", None)
     if nproc == 1:
         cmd = [sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out_dir, case, dtype, str(steps)]
@@ -62,3 +62,62 @@ def test_two_rank_engine_step_equals_single_process_big_batch(tmp_path):
             np.testing.assert_allclose(r1[k], r0[k], rtol=0, atol=0, err_msg=k + " (replicas diverged)")
             n += 1
     assert n > 500
+
+
+def _big_batch_fixture(tmp_path, case):
+    import json
+    g = np.load(os.path.join(ROOT, "tests", "golden", case + ".npz"))
+    cfg = json.loads(str(g["meta/cfg_json"]))
+    big = tmp_path / "golden_big"
+    big.mkdir(exist_ok=True)
+    np.savez(str(big / (case + "_x2.npz")), **{k: (np.array(json.dumps(dict(cfg, B=2 * cfg["B"]))) if k == "meta/cfg_json" else g[k])
+                                              for k in g.files})
+    return str(big)
+
+
+def test_two_rank_weight_decay_share(tmp_path):
+    """The weight-decay term (phiseg_model.py:126-128, 290-299) under data parallelism: every rank evaluates it on the full parameter
+    set and the scalar fetches / the gradient arena are summed over the ranks, so each rank must carry a 1 / world share -- the
+    reported term, the total loss and the parameters after one Adam step equal the single-process step on the doubled batch."""
+    case = "tiny_phiseg_gn4"
+    d2, d1 = tmp_path / "dp2", tmp_path / "single"
+    d2.mkdir(); d1.mkdir()
+    wd = {"PHX_TEST_WD": "0.37"}
+    _launch(2, str(d2), case, "f32", 1, 29543, wd)
+    _launch(1, str(d1), case + "_x2", "f32", 1, 0, dict(wd, PHX_TEST_GOLDEN_DIR=_big_batch_fixture(tmp_path, case)))
+    r0, r1, ref = np.load(str(d2 / "rank0.npz")), np.load(str(d2 / "rank1.npz")), np.load(str(d1 / "rank0.npz"))
+    keys = [str(k) for k in ref["keys"]]
+    assert "weight_decay" in keys
+    np.testing.assert_allclose(r0["losses"], ref["losses"], rtol=2e-5)
+    np.testing.assert_allclose(r1["losses"], ref["losses"], rtol=2e-5)
+    assert ref["losses"][0][keys.index("weight_decay")] > 1.0          # (a real contribution, not a rounding-level term)
+    for k in ref.files:
+        if k.startswith("grad/"):        # (conv biases in front of a group norm: +-2e3 values that cancel -> 3e-3 from the summation order)
+            np.testing.assert_allclose(r0[k], ref[k], rtol=0, atol=6e-3 * max(np.abs(ref[k]).max(), 1e-6), err_msg=k)
+            if k.endswith("/W"):         # the decay term's own contribution: a doubled (un-shared) term would be off by 0.37 * W
+                w = ref["param/" + k[5:]]
+                assert np.abs(r0[k] - ref[k]).max() <= 0.05 * 0.37 * np.abs(w).max() + 6e-3 * np.abs(ref[k]).max(), k
+        elif k.startswith("param/"):
+            np.testing.assert_allclose(r0[k], ref[k], rtol=0, atol=5e-5, err_msg=k)
+            np.testing.assert_allclose(r1[k], r0[k], rtol=0, atol=0, err_msg=k + " (replicas diverged)")
+
+
+def test_two_rank_train_through_validations(tmp_path):
+    """model.train(data, log_dir) on two ranks, validating at every step (4 validations): the ranks score different images with
+    different annotators and noise, so their best-of comparisons differ from the second validation on -- rank 0's decisions are
+    broadcast and the replica statistics are averaged once per validation, so no rank waits in a collective the other one skips
+    (it used to: save_weights averaged the batch-norm statistics inside the per-rank `if better:`).  Also: checkpoint pruning
+    (Saver(max_to_keep=1) for model.ckpt, 2 per best-of saver, phiseg_model.py:144-148)."""
+    d2 = tmp_path / "dp2"
+    d2.mkdir()
+    log_dir = tmp_path / "run"
+    _launch(2, str(d2), "tiny_phiseg_bn", "f32", 0, 29545, {"PHX_TEST_TRAIN_DIR": str(log_dir)})
+    r0, r1 = np.load(str(d2 / "rank0.npz")), np.load(str(d2 / "rank1.npz"))
+    assert len(r0["losses"]) == 4 and np.all(np.isfinite(r0["losses"])) and np.all(np.isfinite(r1["losses"]))
+    np.testing.assert_allclose(r0["losses"], r1["losses"], rtol=1e-6)   # (Session.run reports the global-batch loss on every rank)
+    files = sorted(os.listdir(str(log_dir)))
+    latest = [f for f in files if f.startswith("model.ckpt-")]
+    assert latest == ["model.ckpt-3.npz"], files                         # max_to_keep = 1
+    for crit in ("dice", "loss", "ged", "ncc"):
+        n = [f for f in files if f.startswith("model_best_%s.ckpt-" % crit)]
+        assert 1 <= len(n) <= 2, files                                   # max_to_keep = 2
