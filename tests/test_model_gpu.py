@@ -672,3 +672,95 @@ def test_bn_double_update_switch_reproduces_update_ops_fp32():
         if k in second and k.endswith("moving_mean"):
             assert np.abs(second[k].numpy() - v.numpy()).max() > 0       # the second update really moved it
     assert n2 > 50 and any(k.startswith("posterior/") and k not in second for k in first)
+
+
+# ---- bf16 training parity where the benchmark lives: a well-conditioned batch, and config 4's real code path ---------------------
+def _bf16_plan_vs_oracle(cfg, norm_name, fac, mean_slack, term_band):
+    """One bf16 training step of the engine (lr = 0) against torch autograd of the oracle -- exact fp32 and with the bf16 storage
+    policy simulated -- on identical weights, images and Philox noise.  -> the per-term relative deviations.
+    Bounds: every loss term within max(term_band, 3x the simulated policy's own deviation) of the exact value; every variable's
+    gradient within (fac + 1) x max(simulated deviation, 3 %) of the exact gradient (relative L2) and at least 98 % of them within
+    fac x; on average no further from the exact gradient than mean_slack x the simulated policy."""
+    from oracle import init as oinit
+    from oracle import nets
+    from phiseg_code_amd.phiseg import phiseg_model
+    model = phiseg_model.phiseg(make_config(cfg, "bf16"), rng_seed=cfg["eps_seed"])
+    var_order = [(n, tuple(v.shape)) for n, v in model.graph.variables.items()]
+    params = otrain.make_params(var_order, cfg["weight_seed"], torch.float32, perturbed=True)
+    x_np, s_np = oinit.synthetic_batch(cfg["B"], cfg["H"], cfg["nlabels"], cfg["data_seed"])
+    model.set_weights({k: v.detach().numpy() for k, v in params.items()})
+    xt, st = torch.as_tensor(x_np, dtype=torch.float32), torch.as_tensor(s_np)
+
+    def oracle_eval(sim):
+        for v in params.values():
+            v.grad = None
+        eps = otrain.torch_eps_fn(cfg["eps_seed"], 0, cfg["B"], torch.float32)
+        out = nets.elbo(params, xt, st, eps, cfg, training=True, bf16_sim=sim)
+        out["loss_tot"].backward()
+        return ({k: float(v) for k, v in out["loss_dict"].items()},
+                {k: v.grad.detach().double().numpy().copy() for k, v in params.items() if v.requires_grad and v.grad is not None})
+    t_exact, g_exact = oracle_eval(False)
+    t_sim, g_sim = oracle_eval(True)
+    keys = sorted(model.loss_dict)
+    plan = model.sess.plan_for([model.loss_dict[k] for k in keys], True, cfg["B"], True)
+    plan.set_input("x_input", x_np)
+    plan.set_input("s_input", s_np)
+    model.sess.store.set_lr(0.0)
+    plan.run()
+    plan.sync()
+    terms = {k: float(plan.fetch(model.loss_dict[k])) for k in keys}
+    got = model.sess.store.export(grads=True)
+    dev = {}
+    for k in keys:
+        inh = abs(t_sim[k] - t_exact[k]) / abs(t_exact[k])
+        dev[k] = abs(terms[k] - t_exact[k]) / abs(t_exact[k])
+        assert dev[k] <= max(term_band, 3.0 * inh), (k, terms[k], t_exact[k], t_sim[k])
+    n_checked, tot_e, tot_inh, worst, viol = 0, 0.0, 0.0, (0.0, None), []
+    for name, ge in g_exact.items():
+        nrm = np.linalg.norm(ge)
+        if nrm < 1e-8 * max(1.0, np.sqrt(ge.size)):
+            continue
+        gh = got[name].astype(np.float64).reshape(ge.shape)
+        inh = np.linalg.norm(g_sim[name] - ge) / nrm
+        e = np.linalg.norm(gh - ge) / nrm
+        bound = (fac if ge.size >= 64 else fac + 1.0) * max(inh, 0.03)
+        if e > bound:
+            viol.append((name, ge.size, round(e, 3), round(inh, 3)))
+        # (two bf16 evaluations decorrelate through rounding flips: independent errors add in quadrature -> 1.4x expected, with a tail;
+        # observed 2.35x on two 192 / 384-element tensors in one run, none in the next: the hard limit sits one unit above `fac`)
+        assert e <= bound * (fac + 1.0) / fac, (name, e, inh)
+        if e / bound > worst[0]:
+            worst = (e / bound, name, e, inh)
+        tot_e += e; tot_inh += inh; n_checked += 1
+    print("beyond %.1fx:" % fac, viol)
+    assert len(viol) <= max(2, n_checked // 50), viol      # at most 2 % of the variables beyond `fac` x the simulated policy's deviation
+    print("%s bf16 B=%d: %d variables, mean rel. L2 error %.4f (simulated policy %.4f), worst %s; term deviations %s" %
+          (norm_name, cfg["B"], n_checked, tot_e / n_checked, tot_inh / n_checked, worst, {k: round(v, 4) for k, v in dev.items()}))
+    assert tot_e <= mean_slack * tot_inh + 0.03 * n_checked
+    return n_checked
+
+
+def test_bf16_training_step_batch8_batch_norm_vs_oracle():
+    """phiseg_7_5 at the benchmark's network size (n0 = 32, 128 x 128) with a WELL-CONDITIONED batch: at batch 8 the coarsest level's
+    batch norm sees 32 values per channel (8 at the golden's batch 2, where every bf16 rounding flip is amplified: per-variable
+    bound 4x, KL terms within a factor 3 there).  Here: every loss term -- 5 cross-entropy levels, 5 KL levels, the total -- within
+    15 % of the exact oracle (or 3x the simulated bf16 policy's own deviation; measured: cross-entropy levels <= 0.3 %, KL levels
+    0.2 - 1 % at levels 0 - 2, 10 % / 19 % at the 4 x 4 / 2 x 2 levels, total 2 %), at least 98 % of the variables' gradients within 2x
+    the simulated policy's deviation and all within 3x (measured mean relative L2 error 0.337 against 0.325 for the simulated policy
+    itself: bf16 STORAGE, not the kernels, sets these numbers)."""
+    g, cfg, _ = load_golden("lidc_phiseg_bn")
+    cfg = dict(cfg, B=8)
+    n = _bf16_plan_vs_oracle(cfg, "batch norm", fac=2.0, mean_slack=1.3, term_band=0.15)
+    assert n >= 360
+
+
+def test_bf16_training_step_probunet_n0_32_vs_oracle():
+    """BASELINE.json config 4's real code path: prob_unet2D at n0 = 32, 128 x 128, bf16 -- the 1x1 recombination convolutions as the
+    centre tap of the 3x3 MFMA kernels, the feature + z concat zero-padded from 38 to 64 channels, the global-average-pool latent
+    heads and the broadcast of z over the pixels -- loss terms and every variable's gradient against the oracle (the n0 = 4 fp32 golden
+    tiny_probunet_bn runs the direct kernels instead)."""
+    cfg = dict(arch="prob_unet2D", norm="batch_norm", n0=32, zdim0=6, H=128, B=4, nlabels=2, latent_levels=1, resolution_levels=7,
+               KL_weight=1.0, CE_weight=1.0, exponential_weighting=True, weight_seed=0, eps_seed=42, data_seed=1234)
+    cfg["image_size"] = (128, 128, 1)
+    n = _bf16_plan_vs_oracle(cfg, "prob_unet2D batch norm", fac=3.0, mean_slack=1.5, term_band=0.15)
+    assert n >= 100
