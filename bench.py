@@ -83,6 +83,82 @@ def gpu_first_step_loss(args, batch=12):
     return float(loss)
 
 
+def conv_family(plan):
+    """-> (rows, roofline dict) for the bf16 MFMA 3x3 forward + data-gradient launches of one step of `plan`, each timed alone with
+    HIP events on the plan's stream."""
+    rows_all = plan.time_tagged_kernels(repeats=3)
+    rows = [r for r in rows_all if r[0].startswith("conv")]
+    fam = {}
+    for tag, fl, ms, shp in rows:
+        a = fam.setdefault(tag, [0.0, 0.0, 0])
+        a[0] += fl
+        a[1] += ms
+        a[2] += 1
+    fl = sum(v[0] for k, v in fam.items() if k != "conv3x3_mfma_wgrad")
+    ms = sum(v[1] for k, v in fam.items() if k != "conv3x3_mfma_wgrad")
+    nl = sum(v[2] for k, v in fam.items() if k != "conv3x3_mfma_wgrad")
+    return rows_all, rows, fam, fl, ms, nl
+
+
+def side_workload(args, ctx, exp, norm, generate, steps=10, warmup=3):
+    """One of the other BASELINE.json configurations inside the same bench invocation (10 timed steps): images/s and the
+    convolution family's fraction of the MFMA peak, measured exactly as for the headline workload."""
+    import torch
+    from phiseg_code_amd.data import synthetic
+    from phiseg_code_amd.phiseg import phiseg_model
+    size = 192 if generate else 128
+    batch = 1 if generate else args.batch
+    spi = 16 if generate else 0
+    cfg = make_config(batch, args.dtype, exp, size, 4 if generate else 0, norm)
+    model = phiseg_model.phiseg(cfg)
+    sess = model.sess
+    if generate:
+        plan = sess.plan_for([model.sampling_graph(spi)[1]], False, batch, False)
+    else:
+        plan = sess.plan_for([model.loss_tot], True, batch, True)
+    x, s = synthetic.philox_batch(batch, size, cfg.nlabels, seed=1234)
+    plan.set_input("x_input", x)
+    if not generate:
+        plan.set_input("s_input", s)
+    sess.store.set_lr(1e-3)
+
+    def step():
+        plan.run()
+        if generate:
+            plan.L.step_increment(sess.store.noise_step.data_ptr(), plan.stream_handle())
+    for _ in range(warmup):
+        step()
+    plan.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    plan.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"images_per_s": batch * max(spi, 1) * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
+           "launches_per_step": len(plan.launches) + len(plan.opt_launches)}
+    _, _, _, fl, ms, nl = conv_family(plan)
+    if ms > 0:
+        out["conv_frac_of_mfma_peak"] = fl / ms / 1e9 / PEAK_BF16_TFLOPS
+    return out
+
+
+def train_api_rate(args, model, steps=10):
+    """The reference's actual hot loop (phiseg_model.py:186-207): sess.run([train_step, loss_tot], feed_dict) with host batches and the
+    loss fetched EVERY step -- H2D copy of the batch, graph replay, D2H of the scalar, one synchronisation per step."""
+    from phiseg_code_amd.data import synthetic
+    x, s = synthetic.philox_batch(args.batch, args.image_size, model.exp_config.nlabels, seed=4321)
+    fd = {model.x_inp: x, model.s_inp: s, model.training_pl: True, model.lr_pl: 1e-3}
+    for _ in range(2):
+        model.sess.run([model.train_step, model.loss_tot], fd)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _, loss = model.sess.run([model.train_step, model.loss_tot], fd)
+        float(loss)
+    return args.batch * steps / (time.perf_counter() - t0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +168,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip config.other_workloads / train_api_images_per_s")
     ap.add_argument("--profile-table", action="store_true", help="print the per-layer kernel timing table")
     # the other BASELINE.json configurations (the default run is config 2, the headline metric):
     ap.add_argument("--exp", default="phiseg_7_5", help="experiment config (phiseg/experiments/*.py), e.g. probunet")
@@ -185,8 +262,7 @@ def main():
     if not generate and args.exp == "phiseg_7_5" and args.image_size == 128:
         out["step_tflops"] = images / dt * F_TRAIN_GFLOP_PER_IMAGE / 1e3
     if ctx.rank == 0 and not args.no_roofline and args.dtype == "bf16":
-        rows_all = plan.time_tagged_kernels(repeats=3)
-        rows = [r for r in rows_all if r[0].startswith("conv")]
+        rows_all, rows, fam, fl, ms, nl = conv_family(plan)
         if args.profile_table:
             hb = {}
             for tag, by, ms, shp in rows_all:
@@ -197,15 +273,9 @@ def main():
                 a = hb[key]
                 print("### %-24s %-8s launches=%3d %8.3f ms  %8.1f GB/s" % (key[0], ">=64MB" if key[1] else "<64MB", a[2], a[1], a[0] / a[1] / 1e6),
                       file=sys.stderr)
-        fam = {}
-        for tag, fl, ms, shp in rows:
-            a = fam.setdefault(tag, [0.0, 0.0, 0])
-            a[0] += fl
-            a[1] += ms
-            a[2] += 1
         if args.profile_table:
-            for tag, fl, ms, shp in sorted(rows, key=lambda r: -r[2]):
-                print("# %-20s %8.3f ms %8.1f TFLOP/s  %s" % (tag, ms, fl / ms / 1e9, shp[-5:]), file=sys.stderr)
+            for tag, fl_, ms_, shp in sorted(rows, key=lambda r: -r[2]):
+                print("# %-20s %8.3f ms %8.1f TFLOP/s  %s" % (tag, ms_, fl_ / ms_ / 1e9, shp[-5:]), file=sys.stderr)
             byh = {}
             for tag, fl, ms, shp in rows:
                 key = (tag, shp[-4])                      # launch arguments end (..., B, H, W, Cin|K, Cout|N)
@@ -215,14 +285,18 @@ def main():
                 a = byh[key]
                 print("## %-20s H=%-4d launches=%3d  %8.3f ms  %8.1f TFLOP/s" % (key[0], key[1], a[2], a[1], a[0] / a[1] / 1e9),
                       file=sys.stderr)
-        fl = sum(v[0] for k, v in fam.items() if k != "conv3x3_mfma_wgrad")
-        ms = sum(v[1] for k, v in fam.items() if k != "conv3x3_mfma_wgrad")
-        nl = sum(v[2] for k, v in fam.items() if k != "conv3x3_mfma_wgrad")
+        # the dominant instantiation on its own: the launches of the shape class that takes the most time (forward + data gradient)
+        bysh = {}
+        for tag, fl_, ms_, shp in rows:
+            if tag != "conv3x3_mfma_wgrad":
+                a = bysh.setdefault(tuple(shp[-5:]), [0.0, 0.0, 0])
+                a[0] += fl_; a[1] += ms_; a[2] += 1
+        dom = max(bysh.items(), key=lambda kv: kv[1][1]) if bysh else None
         # HBM traffic of the same kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # corrected as MI355X_MICROARCH.md prescribes; see profiles/r01_pmc_hbm_traffic_final.txt): bytes per launch
         traffic = None
         try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")) else "r01_pmc_hbm_traffic_final.json")))
+            pj = json.load(open(os.path.join(ROOT, "profiles", next(f for f in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic_final.json") if os.path.exists(os.path.join(ROOT, "profiles", f))))))
             ks = [v for k, v in pj.items() if k.startswith("void k_conv3x3_mfma<") or k.startswith("void k_conv3x3_fwd_dma128<")]
             calls = sum(v["calls_per_step"] for v in ks)
             traffic = 1e6 * sum(v["fetch_x2_MB_per_step"] + v["write_MB_per_step"] for v in ks) / calls
@@ -243,6 +317,21 @@ def main():
             "families": {k: {"tflops": v[0] / v[1] / 1e9, "ms_per_step": v[1], "launches": v[2]} for k, v in fam.items()},
             "conv_ms_per_step": sum(v[1] for v in fam.values()),
         }
+        if dom is not None:
+            out["roofline"]["dominant_shape"] = {"B_H_W_K_N": list(dom[0]), "launches": dom[1][2], "ms_per_step": dom[1][1],
+                                                 "tflops": dom[1][0] / dom[1][1] / 1e9,
+                                                 "frac": dom[1][0] / dom[1][1] / 1e9 / PEAK_BF16_TFLOPS}
+    headline = (not generate and args.exp == "phiseg_7_5" and args.image_size == 128 and args.norm == "batch" and args.dtype == "bf16"
+                and args.batch == 64)
+    if ctx.rank == 0 and ctx.world == 1 and headline and not args.no_other_workloads:
+        # the other BASELINE.json configurations and the reference's own loop, inside the same invocation (the headline line above is
+        # unchanged by them: they run after its timed region)
+        out["config"]["train_api_images_per_s"] = train_api_rate(args, model)
+        ow = {}
+        ow["phiseg_7_5 group norm (config 2 as named), training step"] = side_workload(args, ctx, "phiseg_7_5", "group", False)
+        ow["probunet (config 4), training step"] = side_workload(args, ctx, "probunet", "batch", False)
+        ow["phiseg_7_5 192x192 4 classes, 16 Monte-Carlo samples per pass (config 5), generate"] = side_workload(args, ctx, "phiseg_7_5", "batch", True)
+        out["config"]["other_workloads"] = ow
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline and not generate and args.exp == "phiseg_7_5" \
             and args.image_size == 128 and args.norm == "batch":
         out["cpu_baseline"] = cpu_baseline()

@@ -121,3 +121,28 @@ def test_two_rank_train_through_validations(tmp_path):
     for crit in ("dice", "loss", "ged", "ncc"):
         n = [f for f in files if f.startswith("model_best_%s.ckpt-" % crit)]
         assert 1 <= len(n) <= 2, files                                   # max_to_keep = 2
+
+
+def _n_devices():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+@pytest.mark.skipif(_n_devices() < 2, reason="the native RCCL exchange needs two devices (RCCL refuses duplicate devices)")
+def test_native_rccl_allreduce_two_devices(tmp_path):
+    """phx_comm_allreduce_sum_f32 with world = 2 on two GPUs -- the path `bench.py --gpus N` and data-parallel training take
+    (distributed.DistContext._native: rendezvous id over torch.distributed, ncclCommInitRank, bucketed in-place all-reduce on the
+    plan's HIP stream) -- against the single-process sum.  The 1-GPU test box skips it; tests/dp_worker.py covers the engine's
+    data-parallel step there through gloo."""
+    n = 3_000_001                                         # several 64 K buckets and a ragged tail
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("PHX_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "tests", "rccl_worker.py"), str(tmp_path), str(n)]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    a0 = np.random.default_rng(100).standard_normal(n).astype(np.float32)
+    a1 = np.random.default_rng(101).standard_normal(n).astype(np.float32)
+    ref = 2.0 * (a0 + a1)                                 # two all-reduces: x -> x0 + x1 -> 2 (x0 + x1)
+    for rk in (0, 1):
+        np.testing.assert_allclose(np.load(str(tmp_path / ("rank%d.npy" % rk))), ref, rtol=1e-6, atol=1e-6)
