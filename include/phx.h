@@ -180,6 +180,19 @@ int phx_conv3x3_wgrad_mfma_bf16(const void* x, const void* dy, float* dw_hwio, v
  * w = HWIO 1x1 filter [C][nout];  fwd: y = act(x.w + b);  dgrad: dx = dy.w^T (written);  wgrad: dw += x^T.dy, db += sum dy */
 int phx_head1x1_fwd(const void* x, int x_dt, const float* w, const float* bias, float* y, size_t npix, int C, int nout,
                     int act, void* stream);
+/* The two 1x1 latent heads of a level and the sample, fused (posteriors.py:125-128, priors.py:117-120):
+ *   mu = x w_mu + b_mu;   sigma = softplus(x w_sigma + b_sigma);   z = mu + sigma * eps   (z may be NULL: heads only)
+ * x [npix][C] (bf16 / fp32), w_* the HWIO 1x1 filters [C][zdim] fp32, mu / sigma / z [npix][zdim] fp32; eps = the Philox normal
+ * phx_reparam_fwd draws for element (pixel-in-sample * zdim + channel) of sample (pixel / pix_per_sample + sample_offset).
+ * _bwd: upstream gradients dz (NULL: none), dmu, dsigma (NULL: none) -> g_mu = dz + dmu, g_sigma = (dz * eps + dsigma) *
+ * softplus'(pre-activation) (both [npix][zdim]: the dy operands of phx_head1x1_wgrad for the two heads) and
+ * dx = g_mu w_mu^T + g_sigma w_sigma^T, written once. */
+int phx_latent_heads_fwd(const void* x, int x_dt, const float* w_mu, const float* b_mu, const float* w_sigma, const float* b_sigma,
+                         float* mu, float* sigma, float* z, size_t npix, int C, int zdim, int pix_per_sample, uint64_t seed,
+                         const int32_t* step_dev, int stream_id, int sample_offset, void* stream);
+int phx_latent_heads_bwd(const float* dz, const float* dmu, const float* dsigma, const float* sigma, const float* w_mu,
+                         const float* w_sigma, void* dx, int dx_dt, float* g_mu, float* g_sigma, size_t npix, int C, int zdim,
+                         int pix_per_sample, uint64_t seed, const int32_t* step_dev, int stream_id, int sample_offset, void* stream);
 int phx_head1x1_dgrad(const float* dy, const float* w, void* dx, int dx_dt, size_t npix, int C, int nout, void* stream);
 int phx_head1x1_wgrad(const void* x, int x_dt, const float* dy, float* dw, float* db, size_t npix, int C, int nout,
                       void* stream);

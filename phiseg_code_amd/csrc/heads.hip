@@ -4,6 +4,7 @@
 // (16 bytes of bf16) of a pixel, the NOUT x 8 filter slice lives in registers, and the kernels run at HBM speed.
 #include <stdlib.h>
 #include "phx_common.h"
+#include "philox.h"
 
 template <typename T, int V> struct HVec;
 template <> struct HVec<float, 8> {
@@ -134,6 +135,138 @@ __global__ void k_head1x1_dgrad(const float* __restrict__ dy, const float* __res
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) d[o] = dy[p * NOUT + o];
         one(p, d);
+    }
+}
+
+
+// ---- fused latent heads (posteriors.py:125-128, priors.py:117-120): the two 1x1 convolutions of a latent level read the same
+// feature map, and the sample follows at once --   mu = x Wmu + bmu;  sigma = softplus(x Wsig + bsig);  z = mu + sigma * eps.
+// One pass over x instead of two and one launch instead of three (two heads + phx_reparam_fwd); eps comes from the same Philox
+// stream contract as phx_reparam_fwd (block = 4 consecutive per-sample elements, sample = global sample index).
+template <typename TX, int V, int Z>
+__global__ void k_latent_fwd(const TX* __restrict__ x, const float* __restrict__ wmu, const float* __restrict__ bmu,
+                             const float* __restrict__ wsig, const float* __restrict__ bsig, float* __restrict__ mu,
+                             float* __restrict__ sigma, float* __restrict__ z, size_t npix, int C, int PL, int iters, int hw,
+                             unsigned long long seed, const int32_t* __restrict__ step_dev, int stream_id, int sample_offset) {
+    constexpr int NOUT = 2 * Z;
+    const int CV = C / V;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    extern __shared__ float red[];                  // [HU * PL][NOUT][CV]
+    float wr[V][NOUT];
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+#pragma unroll
+        for (int o = 0; o < Z; ++o) {
+            wr[j][o] = wmu[(size_t)(cv * V + j) * Z + o];
+            wr[j][Z + o] = wsig[(size_t)(cv * V + j) * Z + o];
+        }
+    const unsigned step = z ? (unsigned)(*step_dev) : 0u;
+    for (int it = 0; it < iters; ++it) {
+        const size_t pbase = ((size_t)blockIdx.x * iters + it) * (HU * PL);
+        if (pl < PL) {
+            float xv[HU][V];
+#pragma unroll
+            for (int u = 0; u < HU; ++u) {
+                const size_t p = pbase + u * PL + pl;
+                if (p < npix) HVec<TX, V>::load(x, p * C + (size_t)cv * V, xv[u]);
+                else
+#pragma unroll
+                    for (int j = 0; j < V; ++j) xv[u][j] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < HU; ++u) {
+                float part[NOUT];
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) part[o] = 0.f;
+#pragma unroll
+                for (int j = 0; j < V; ++j)
+#pragma unroll
+                    for (int o = 0; o < NOUT; ++o) part[o] = fmaf(xv[u][j], wr[j][o], part[o]);
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) red[((u * PL + pl) * NOUT + o) * CV + cv] = part[o];
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < HU * PL * Z; t += blockDim.x) {
+            const int zc = t % Z, q = t / Z;
+            const size_t pp = pbase + q;
+            if (pp < npix) {
+                float am = bmu[zc], as = bsig[zc];
+                for (int k = 0; k < CV; ++k) {
+                    am += red[(q * NOUT + zc) * CV + k];
+                    as += red[(q * NOUT + Z + zc) * CV + k];
+                }
+                as = act_fwd(as, PHX_ACT_SOFTPLUS);
+                mu[pp * Z + zc] = am;
+                sigma[pp * Z + zc] = as;
+                if (z) {
+                    const unsigned b = (unsigned)(pp / (size_t)hw), e = (unsigned)(pp % (size_t)hw) * Z + zc;
+                    float n[4];
+                    philox_normal4(e >> 2, b + (unsigned)sample_offset, (unsigned)stream_id, step, seed, n);
+                    z[pp * Z + zc] = am + as * n[e & 3];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// backward of the same three operators in one launch: with the upstream gradients dz (of the sample; may be NULL), dmu and dsigma
+// (of the KL term; may be NULL)   g_mu = dz + dmu;   g_sig = (dz * eps + dsigma) * softplus'(pre) = (...) * (1 - exp(-sigma));
+// dx = g_mu Wmu^T + g_sig Wsig^T  -- written once (two head data gradients, three in-place adds and phx_reparam_bwd before);
+// g_mu / g_sig are kept for the deferred filter-gradient launch of the two heads.
+template <typename TO, int V, int Z>
+__global__ void k_latent_bwd(const float* __restrict__ dz, const float* __restrict__ dmu, const float* __restrict__ dsigma,
+                             const float* __restrict__ sigma, const float* __restrict__ wmu, const float* __restrict__ wsig,
+                             TO* __restrict__ dx, float* __restrict__ gmu, float* __restrict__ gsig, size_t npix, int C, int PL,
+                             int chunk, int hw, unsigned long long seed, const int32_t* __restrict__ step_dev, int stream_id,
+                             int sample_offset) {
+    constexpr int NOUT = 2 * Z;
+    const int CV = C / V;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    extern __shared__ float sg[];                   // [chunk][NOUT]
+    const size_t p0 = (size_t)blockIdx.x * chunk;
+    const size_t p1 = p0 + chunk < npix ? p0 + chunk : npix;
+    const unsigned step = dz ? (unsigned)(*step_dev) : 0u;
+    for (int t = threadIdx.x; t < (int)(p1 - p0) * Z; t += blockDim.x) {
+        const int zc = t % Z, q = t / Z;
+        const size_t pp = p0 + q, o = pp * Z + zc;
+        float gm = dmu ? dmu[o] : 0.f, gs = dsigma ? dsigma[o] : 0.f;
+        if (dz) {
+            const unsigned b = (unsigned)(pp / (size_t)hw), e = (unsigned)(pp % (size_t)hw) * Z + zc;
+            float n[4];
+            philox_normal4(e >> 2, b + (unsigned)sample_offset, (unsigned)stream_id, step, seed, n);
+            const float d = dz[o];
+            gm += d;
+            gs += d * n[e & 3];
+        }
+        gs *= act_grad_out(sigma[o], PHX_ACT_SOFTPLUS);
+        gmu[o] = gm;
+        gsig[o] = gs;
+        sg[q * NOUT + zc] = gm;
+        sg[q * NOUT + Z + zc] = gs;
+    }
+    __syncthreads();
+    if (pl >= PL) return;
+    float wr[V][NOUT];
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+#pragma unroll
+        for (int o = 0; o < Z; ++o) {
+            wr[j][o] = wmu[(size_t)(cv * V + j) * Z + o];
+            wr[j][Z + o] = wsig[(size_t)(cv * V + j) * Z + o];
+        }
+    for (size_t p = p0 + pl; p < p1; p += PL) {
+        const float* d = sg + (p - p0) * NOUT;
+        float o8[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) a = fmaf(d[o], wr[j][o], a);
+            o8[j] = a;
+        }
+        HVec<TO, V>::store(dx, p * C + (size_t)cv * V, o8);
     }
 }
 
@@ -272,6 +405,54 @@ int phx_head1x1_fwd(const void* x, int x_dt, const float* w, const float* bias, 
         const int grid = (int)((groups + iters - 1) / iters);
         hipLaunchKernelGGL((k_head1x1_fwd<TX, V, N>), dim3(grid), dim3(threads), (size_t)HU * PL * N * (C / V) * sizeof(float),
                            (hipStream_t)stream, (const TX*)x, w, bias, y, npix, C, PL, iters, act);
+    })));
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+#define LAT_Z_SWITCH(zd, Zv, ...)                                           \
+    do {                                                                    \
+        if ((zd) == 2) { constexpr int Zv = 2; __VA_ARGS__; }               \
+        else if ((zd) == 4) { constexpr int Zv = 4; __VA_ARGS__; }          \
+        else { constexpr int Zv = 6; __VA_ARGS__; }                         \
+    } while (0)
+
+int phx_latent_heads_fwd(const void* x, int x_dt, const float* w_mu, const float* b_mu, const float* w_sigma, const float* b_sigma,
+                         float* mu, float* sigma, float* z, size_t npix, int C, int zdim, int pix_per_sample, uint64_t seed,
+                         const int32_t* step_dev, int stream_id, int sample_offset, void* stream) {
+    PHX_REQUIRE(zdim == 2 || zdim == 4 || zdim == 6, PHX_E_SHAPE, "latent_heads: zdim in {2,4,6}");
+    PHX_REQUIRE(x && w_mu && b_mu && w_sigma && b_sigma && mu && sigma && pix_per_sample > 0 && npix % (size_t)pix_per_sample == 0 &&
+                (z == nullptr || step_dev != nullptr), PHX_E_INVAL, "latent_heads_fwd: bad arguments");
+    PHX_DT_SWITCH(x_dt, TX, HEAD_VEC_SWITCH(C, V, LAT_Z_SWITCH(zdim, ZZ, {
+        int PL, threads;
+        PHX_REQUIRE(head_geo(C, V, &PL, &threads) == 0, PHX_E_SHAPE, "latent_heads: C too large");
+        size_t groups = (npix + (size_t)HU * PL - 1) / ((size_t)HU * PL);
+        int iters = (int)((groups + 2047) / 2048);
+        if (iters < 1) iters = 1;
+        const int grid = (int)((groups + iters - 1) / iters);
+        hipLaunchKernelGGL((k_latent_fwd<TX, V, ZZ>), dim3(grid), dim3(threads), (size_t)HU * PL * 2 * ZZ * (C / V) * sizeof(float),
+                           (hipStream_t)stream, (const TX*)x, w_mu, b_mu, w_sigma, b_sigma, mu, sigma, z, npix, C, PL, iters,
+                           pix_per_sample, (unsigned long long)seed, step_dev, stream_id, sample_offset);
+    })));
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_latent_heads_bwd(const float* dz, const float* dmu, const float* dsigma, const float* sigma, const float* w_mu,
+                         const float* w_sigma, void* dx, int dx_dt, float* g_mu, float* g_sigma, size_t npix, int C, int zdim,
+                         int pix_per_sample, uint64_t seed, const int32_t* step_dev, int stream_id, int sample_offset, void* stream) {
+    PHX_REQUIRE(zdim == 2 || zdim == 4 || zdim == 6, PHX_E_SHAPE, "latent_heads: zdim in {2,4,6}");
+    PHX_REQUIRE(sigma && w_mu && w_sigma && dx && g_mu && g_sigma && pix_per_sample > 0 && npix % (size_t)pix_per_sample == 0 &&
+                (dz == nullptr || step_dev != nullptr), PHX_E_INVAL, "latent_heads_bwd: bad arguments");
+    PHX_DT_SWITCH(dx_dt, TO, HEAD_VEC_SWITCH(C, V, LAT_Z_SWITCH(zdim, ZZ, {
+        int PL, threads;
+        PHX_REQUIRE(head_geo(C, V, &PL, &threads) == 0, PHX_E_SHAPE, "latent_heads: C too large");
+        int chunk = PL * 8;
+        size_t grid = (npix + chunk - 1) / chunk;
+        if (grid > 4096) { chunk = (int)((npix + 4095) / 4096); grid = (npix + chunk - 1) / chunk; }
+        hipLaunchKernelGGL((k_latent_bwd<TO, V, ZZ>), dim3((unsigned)grid), dim3(threads), (size_t)chunk * 2 * ZZ * sizeof(float),
+                           (hipStream_t)stream, dz, dmu, dsigma, sigma, w_mu, w_sigma, (TO*)dx, g_mu, g_sigma, npix, C, PL, chunk,
+                           pix_per_sample, (unsigned long long)seed, step_dev, stream_id, sample_offset);
     })));
     PHX_CHECK_LAUNCH();
     return PHX_OK;

@@ -60,6 +60,9 @@ _BN_SMALL = int(os.environ.get("PHX_BN_SMALL", "1024"))     # one-launch batch n
 # the transform is ~7 VALU instructions per two elements INSIDE the convolution's staging phase (redone by every channel block of a
 # pixel tile and for the halo), where nothing overlaps it: 32 -> 32 @ 128 x 128 takes 75 us fused against 39 + 24 us (convolution +
 # apply pass at 5.5 TB/s), 128 -> 128 @ 128 x 128 0.64 ms against 0.31 + 0.09, 192 -> 192 @ 8 x 8 34 us against 15 + 9.
+_LATENT_FUSED = os.environ.get("PHX_LATENT_FUSED", "1") == "1"     # mu / sigma heads + reparameterisation of a level in one launch each way (A/B hook)
+
+
 def _xf_enabled():
     return os.environ.get("PHX_XF", "0") == "1"
 
@@ -550,6 +553,8 @@ class Plan:
         self.op_lane = {op: self._lane_of(op) for op in ops}
         opset = set(ops)
         self._opset = opset
+        self._lat = self._find_latent_heads(ops) if _LATENT_FUSED else {}     # op -> record of a fused (mu head, sigma head[, sample]) group
+        self._bw_skip = set()
         self._bws = {}                # producer conv op -> (partials, tiles): BN-backward sums fused into the consumer's dgrad
         self._xf_pending = {}         # tensor a = act(norm(y)) whose apply pass was left to its (single) consumer convolution
         fork = self._record(0) if nl > 1 else None          # lanes 1.. join the capture / wait for the memsets
@@ -583,6 +588,16 @@ class Plan:
             self._stamp_end("fw", op, n0)
             if nl > 1 and len(self._cur) > n0:
                 cross = any(self.op_lane.get(c, ln) != ln for o in op.outputs for c in self._real_consumers(o, opset))
+                rec = self._lat.get(op)
+                if rec is not None and rec["last"] is op:
+                    # the group's one launch was emitted here: it stands for all of its operators (their readers on other lanes wait
+                    # for THIS point, not for the place where the mu head alone would have run)
+                    gops = [o for o in (rec["mu"], rec["sig"], rec["add"]) if o is not None]
+                    if any(self.op_lane.get(c, ln) != ln for g in gops for o in g.outputs for c in self._real_consumers(o, opset)):
+                        ev = self._record(ln)
+                        for g in gops:
+                            self.fw_event[g] = ev
+                        cross = False
                 if cross or op.type in ("residual_ce", "kl", "weighted_sum"):
                     self.fw_event[op] = self._record(ln)
         self.n_launch_fwd = len(self.launches)
@@ -614,6 +629,8 @@ class Plan:
                     self._lane = 1
                     self._wait(ev0)
                     self._emit_deferred()
+                if op in self._bw_skip:
+                    continue                              # (its backward ran inside a fused group's launch)
                 if any(o in self.grad for o in op.outputs) or op.type in ("residual_ce", "kl", "l2_weights"):
                     self._lane = self.op_lane[op]
                     self._cur_bw_op = op
@@ -807,6 +824,102 @@ class Plan:
         st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn)
         self.saved[op] = st
 
+    # ---- fused latent heads: mu = conv1x1(x), sigma = softplus(conv1x1(x)), z = mu + sigma * eps (posteriors.py:125-128,
+    # priors.py:117-120) as one launch forward (phx_latent_heads_fwd) and one backward (phx_latent_heads_bwd) ----------------------
+    def _find_latent_heads(self, ops):
+        pos = {op: i for i, op in enumerate(ops)}
+        opset = set(ops)
+        out = {}
+
+        def is_head(op, act):
+            a = op.attrs
+            if op.type != "conv_unit" or a.get("transposed") is not None or a.get("general") is not None:
+                return False
+            W = a["W"]
+            return (a["ksize"] == 1 and a["norm"] is None and a["b"] is not None and a["act"] == act and W.shape[-1] in (2, 4, 6)
+                    and W.shape[-2] % 8 == 0 and op.outputs[0].kind == G.KIND_F32)
+        for mu in ops:
+            if mu in out or not is_head(mu, "identity"):
+                continue
+            x = mu.inputs[0]
+            sib = [c for c in x.consumers if c in opset and c is not mu and is_head(c, "softplus")
+                   and c.attrs["W"].shape == mu.attrs["W"].shape and c not in out]
+            if len(sib) != 1:
+                continue
+            sig = sib[0]
+            add = None
+            for c in mu.outputs[0].consumers:
+                if (c in opset and c.type == "add" and c.inputs[0] is mu.outputs[0] and c.inputs[1].op.type == "mul"
+                        and c.inputs[1].op.inputs[0] is sig.outputs[0] and c.inputs[1].op.inputs[1].op.type == "random_normal"):
+                    add = c
+            members = [o for o in (mu, sig, add) if o is not None]
+            last = max(members, key=lambda o: pos[o])
+            virt = {add.inputs[1].op, add.inputs[1].op.inputs[1].op} if add is not None else set()
+            # nothing may read mu / sigma before the group's launch, the heads must sit on one lane, and neither may be a fetch
+            ok = all(pos.get(c, 1 << 30) > pos[last] or c in members or c in virt
+                     for t in (mu.outputs[0], sig.outputs[0]) for c in t.consumers if c in opset)
+            ok = ok and len({self.op_lane[o] for o in members}) == 1
+            if not ok:
+                continue
+            rec = dict(mu=mu, sig=sig, add=add, last=last, x=x)
+            for o in members:
+                out[o] = rec
+        return out
+
+    def _fw_latent_group(self, rec):
+        mu_op, sig_op, add_op = rec["mu"], rec["sig"], rec["add"]
+        x = self.val[rec["x"]]
+        mu, sigma = self.val[mu_op.outputs[0]], self.val[sig_op.outputs[0]]
+        z = self.val[add_op.outputs[0]] if add_op is not None else None
+        cin, zd = mu_op.attrs["W"].shape[-2], mu_op.attrs["W"].shape[-1]
+        npix = int(np.prod(x.shape[:-1]))
+        hw = npix // x.shape[0]
+        sid = add_op.inputs[1].op.inputs[1].op.attrs["stream"] if add_op is not None else 0
+        st = self.store
+        self._emit(self.L.latent_heads_fwd, x.ptr, x.dt, st.ptr(mu_op.attrs["W"]), st.ptr(mu_op.attrs["b"]), st.ptr(sig_op.attrs["W"]),
+                   st.ptr(sig_op.attrs["b"]), mu.ptr, sigma.ptr, z.ptr if z is not None else None, npix, cin, zd, hw, self.rng_seed,
+                   self._noise_step_ptr(), sid, self.sample_offset, self.stream)
+        rec.update(npix=npix, hw=hw, sid=sid, cin=cin, zd=zd)
+
+    def _bw_latent_group(self, rec):
+        """Called at the group's LAST operator (the first one the backward sweep meets): every contribution to the gradients of mu,
+        sigma and z has been registered by then (their readers come later in the forward order)."""
+        mu_op, sig_op, add_op = rec["mu"], rec["sig"], rec["add"]
+        mu_t, sig_t = mu_op.outputs[0], sig_op.outputs[0]
+        for t in (mu_t, sig_t):
+            if t in self.grad:
+                self._finalize_grad(t)
+        dz = self.grad.get(add_op.outputs[0]) if add_op is not None else None
+        dmu, dsg = self.grad.get(mu_t), self.grad.get(sig_t)
+        for o in (mu_op, sig_op, add_op):
+            if o is not None:
+                self._bw_skip.add(o)
+        if dz is None and dmu is None and dsg is None:
+            return
+        x_t = rec["x"]
+        x, sigma = self.val[x_t], self.val[sig_t]
+        npix, cin, zd = rec["npix"], rec["cin"], rec["zd"]
+        gmu, gsig = self._alloc((npix, zd), F32), self._alloc((npix, zd), F32)
+        st, Lb = self.store, self.L
+        wmu, wsg = mu_op.attrs["W"], sig_op.attrs["W"]
+        if not self.req.get(x_t, False):
+            raise NotImplementedError("latent heads on a tensor without gradient")
+
+        def wr(g):
+            self._emit(Lb.latent_heads_bwd, dz.ptr if dz is not None else None, dmu.ptr if dmu is not None else None,
+                       dsg.ptr if dsg is not None else None, sigma.ptr, st.ptr(wmu), st.ptr(wsg), g.ptr, g.dt, gmu.ptr, gsig.ptr, npix,
+                       cin, zd, rec["hw"], self.rng_seed, self._noise_step_ptr(), rec["sid"], self.sample_offset, self.stream)
+        self._add_grad(x_t, write_fn=wr)
+        for hop, gy in ((mu_op, gmu), (sig_op, gsig)):      # the two filter / bias gradients: leaves, one launch for all heads later
+            W, b = hop.attrs["W"], hop.attrs["b"]
+            if _WGRAD_MULTI and cin % 8 == 0:
+                plan4 = (ctypes.c_int * 4)()
+                Lb.head1x1_wgrad_plan(npix, cin, zd, plan4)
+                self._headw_jobs.setdefault((x.dt, zd), []).append((x.ptr, gy.ptr, st.grad_ptr(W), st.grad_ptr(b), npix, cin, plan4[0],
+                                                                    plan4[1], plan4[2], plan4[3]))
+            else:
+                self._emit(Lb.head1x1_wgrad, x.ptr, x.dt, gy.ptr, st.grad_ptr(W), st.grad_ptr(b), npix, cin, zd, self.stream)
+
     def _xf_consumer(self, op):
         """The convolution unit that can take over the normalisation + activation of `op` (fused edge), or None: the ONLY reader of
         a = act(norm(conv(x))) is a 3x3 convolution on the bf16 MFMA path with a multiple of 32 input channels."""
@@ -831,6 +944,13 @@ class Plan:
         a = op.attrs
         if a.get("transposed") is not None or a.get("general") is not None:
             return self._fw_tconv_unit(op, bw)
+        rec = self._lat.get(op)
+        if rec is not None:                      # a latent head: its arithmetic runs in the group's one launch
+            self.val[op.outputs[0]] = self._alloc_like(op.outputs[0])
+            self.saved[op] = dict(latent=True)
+            if rec["last"] is op:
+                self._fw_latent_group(rec)
+            return
         x = self.val[op.inputs[0]]
         pend = self._xf_pending.pop(op.inputs[0], None)      # the producer left its normalisation to this convolution
         W, b = a["W"], a["b"]
@@ -1150,6 +1270,13 @@ class Plan:
         mu_t, m = op.inputs
         if m.op.type != "mul" or m.op.inputs[1].op.type != "random_normal":
             raise NotImplementedError("only z = mu + sigma * random_normal(...) is on the hot path")
+        rec = self._lat.get(op)
+        if rec is not None:
+            self.val[op.outputs[0]] = self._alloc(self.val[mu_t].shape, F32)
+            self.saved[op] = dict(latent=True)
+            if rec["last"] is op:
+                self._fw_latent_group(rec)
+            return
         sigma_t, eps_t = m.op.inputs
         mu, sigma = self.val[mu_t], self.val[sigma_t]
         z = self._alloc(mu.shape, F32)
@@ -1320,6 +1447,8 @@ class Plan:
                 self._add_grad(t, buf=g)
 
     def _bw_add(self, op):
+        if op in self._lat:
+            return self._bw_latent_group(self._lat[op])
         sv, dz = self.saved[op], self.grad[op.outputs[0]]
         self._add_grad(sv["mu_t"], buf=dz)
         B = dz.shape[0]
@@ -1434,6 +1563,8 @@ class Plan:
             self.stream))
 
     def _bw_conv_unit(self, op):
+        if op in self._lat:
+            return self._bw_latent_group(self._lat[op])
         a, sv = op.attrs, self.saved[op]
         dA = self.grad[op.outputs[0]]
         x, out = sv["x"], sv["out"]

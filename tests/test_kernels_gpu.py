@@ -1045,3 +1045,68 @@ def test_conv3x3_mfma_affine_epilogue(L, case, act):
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
+
+
+@pytest.mark.parametrize("case", [(3, 16, 16, 32, 2, BF16), (2, 8, 8, 192, 2, BF16), (5, 2, 2, 192, 2, BF16), (2, 4, 4, 64, 6, BF16),
+                                  (1, 32, 32, 64, 4, F32)])
+def test_latent_heads_fused(L, case):
+    """phx_latent_heads_fwd / _bwd -- mu = x Wmu + bmu, sigma = softplus(x Wsig + bsig), z = mu + sigma * eps in one launch, and its
+    backward in one launch (posteriors.py:125-128, priors.py:117-120) -- against the oracle (Philox noise contract included) and
+    against the five launches they replace."""
+    B, H, W, C, Z, dt = case
+    P, hw = B * H * W, H * W
+    x = RNG.standard_normal((P, C))
+    wmu, wsg = RNG.standard_normal((C, Z)) / np.sqrt(C), RNG.standard_normal((C, Z)) / np.sqrt(C)
+    bmu, bsg = RNG.standard_normal(Z) * 0.2, RNG.standard_normal(Z) * 0.2
+    xd, wmud, wsgd, bmud, bsgd = dev(x, dt), dev(wmu), dev(wsg), dev(bmu), dev(bsg)
+    step = torch.tensor([3], dtype=torch.int32).cuda()
+    seed, sid, off = 42 + (1 << 33), 17, 5
+    mu, sg, z = (torch.empty(P, Z, dtype=torch.float32).cuda() for _ in range(3))
+    L.latent_heads_fwd(xd.data_ptr(), dt, wmud.data_ptr(), bmud.data_ptr(), wsgd.data_ptr(), bsgd.data_ptr(), mu.data_ptr(),
+                       sg.data_ptr(), z.data_ptr(), P, C, Z, hw, seed, step.data_ptr(), sid, off, S())
+    xr = rounded(x, dt).requires_grad_(True)
+    wmur, wsgr = torch.as_tensor(wmu, dtype=torch.float32).double().requires_grad_(True), torch.as_tensor(wsg, dtype=torch.float32).double().requires_grad_(True)
+    eps = torch.as_tensor(philox.normal(seed, 3, sid, B, hw * Z, sample_offset=off, dtype=np.float64)).reshape(P, Z)
+    mur = xr @ wmur + torch.as_tensor(bmu, dtype=torch.float32).double()
+    sgr = T.softplus(xr @ wsgr + torch.as_tensor(bsg, dtype=torch.float32).double())
+    zr = mur + sgr * eps
+    close(host(mu), mur.detach().numpy(), 2e-5, "mu")
+    close(host(sg), sgr.detach().numpy(), 2e-5, "sigma")
+    close(host(z), zr.detach().numpy(), 2e-5, "z")
+    # the three launches it replaces
+    mu2, sg2, z2 = (torch.empty(P, Z, dtype=torch.float32).cuda() for _ in range(3))
+    L.head1x1_fwd(xd.data_ptr(), dt, wmud.data_ptr(), bmud.data_ptr(), mu2.data_ptr(), P, C, Z, 0, S())
+    L.head1x1_fwd(xd.data_ptr(), dt, wsgd.data_ptr(), bsgd.data_ptr(), sg2.data_ptr(), P, C, Z, 2, S())
+    L.reparam_fwd(mu2.data_ptr(), sg2.data_ptr(), z2.data_ptr(), B, hw * Z, seed, step.data_ptr(), sid, off, S())
+    close(host(mu), host(mu2), 1e-6, "mu vs head kernel")
+    close(host(z), host(z2), 1e-6, "z vs head + reparam kernels")
+    # heads only (z == NULL: a prior whose sample is not consumed)
+    mu3, sg3 = torch.empty_like(mu), torch.empty_like(sg)
+    L.latent_heads_fwd(xd.data_ptr(), dt, wmud.data_ptr(), bmud.data_ptr(), wsgd.data_ptr(), bsgd.data_ptr(), mu3.data_ptr(),
+                       sg3.data_ptr(), None, P, C, Z, hw, seed, None, 0, 0, S())
+    assert torch.equal(mu3, mu) and torch.equal(sg3, sg)
+    # backward: L = sum(z * gz) + sum(mu * gm) + sum(sigma * gs)
+    gz, gm, gs = RNG.standard_normal((P, Z)), RNG.standard_normal((P, Z)), RNG.standard_normal((P, Z))
+    ((zr * torch.as_tensor(gz)).sum() + (mur * torch.as_tensor(gm)).sum() + (sgr * torch.as_tensor(gs)).sum()).backward()
+    gzd, gmd, gsd = dev(gz), dev(gm), dev(gs)
+    dx = torch.empty(P, C, dtype=tdt(dt)).cuda()
+    gmu, gsig = torch.empty(P, Z, dtype=torch.float32).cuda(), torch.empty(P, Z, dtype=torch.float32).cuda()
+    L.latent_heads_bwd(gzd.data_ptr(), gmd.data_ptr(), gsd.data_ptr(), sg.data_ptr(), wmud.data_ptr(), wsgd.data_ptr(), dx.data_ptr(), dt,
+                       gmu.data_ptr(), gsig.data_ptr(), P, C, Z, hw, seed, step.data_ptr(), sid, off, S())
+    close(host(dx), xr.grad.numpy(), 2e-5 if dt == F32 else 6e-3, "dx")
+    dwm, dws = torch.zeros(C, Z, dtype=torch.float32).cuda(), torch.zeros(C, Z, dtype=torch.float32).cuda()
+    dbm, dbs = torch.zeros(Z, dtype=torch.float32).cuda(), torch.zeros(Z, dtype=torch.float32).cuda()
+    L.head1x1_wgrad(xd.data_ptr(), dt, gmu.data_ptr(), dwm.data_ptr(), dbm.data_ptr(), P, C, Z, S())
+    L.head1x1_wgrad(xd.data_ptr(), dt, gsig.data_ptr(), dws.data_ptr(), dbs.data_ptr(), P, C, Z, S())
+    close(host(dwm), wmur.grad.numpy(), 5e-5, "dWmu")
+    close(host(dws), wsgr.grad.numpy(), 5e-5, "dWsigma")
+    # no upstream sample gradient (heads feeding the KL term only)
+    dx2 = torch.empty_like(dx)
+    L.latent_heads_bwd(None, gmd.data_ptr(), gsd.data_ptr(), sg.data_ptr(), wmud.data_ptr(), wsgd.data_ptr(), dx2.data_ptr(), dt,
+                       gmu.data_ptr(), gsig.data_ptr(), P, C, Z, hw, seed, None, 0, 0, S())
+    xr.grad = None
+    xr2 = rounded(x, dt).requires_grad_(True)
+    mur2 = xr2 @ wmur.detach() + torch.as_tensor(bmu, dtype=torch.float32).double()
+    sgr2 = T.softplus(xr2 @ wsgr.detach() + torch.as_tensor(bsg, dtype=torch.float32).double())
+    ((mur2 * torch.as_tensor(gm)).sum() + (sgr2 * torch.as_tensor(gs)).sum()).backward()
+    close(host(dx2), xr2.grad.numpy(), 2e-5 if dt == F32 else 6e-3, "dx (KL only)")

@@ -32,3 +32,19 @@ for (H, C) in [(128, 32), (64, 64), (32, 128), (16, 192), (8, 192)]:
     t_c = timeit(lambda: dx.copy_(x))
     print("H=%3d C=%3d %6.1f MB | head fwd %6.1f us %5.0f GB/s | head dgrad %6.1f us %5.0f GB/s | add %6.1f us %5.0f GB/s | pool fwd %6.1f bwd %6.1f us | copy %6.1f us"
           % (H, C, mb, t_f, mb / t_f * 1e3, t_d, mb / t_d * 1e3, t_a, 3 * mb / t_a * 1e3, t_p, t_q, t_c), flush=True)
+# bilinear x2 up-sampling (TF1 legacy) and concat / split at the likelihood's top-down shapes
+for (h, C) in [(64, 192), (32, 192), (16, 192), (8, 192)]:
+    x = torch.randn(64, h, h, C, device="cuda").to(torch.bfloat16)
+    y = torch.empty(64, 2 * h, 2 * h, C, device="cuda", dtype=torch.bfloat16)
+    mb = (x.numel() + y.numel()) * 2 / 1e6
+    t_u = timeit(lambda: L.bilinear_up2x_fwd(x.data_ptr(), BF, y.data_ptr(), 64, h, h, C, st))
+    t_b = timeit(lambda: L.bilinear_up2x_bwd(y.data_ptr(), BF, x.data_ptr(), 64, h, h, C, st))
+    print("bilinear %3d -> %3d C=%3d %6.1f MB | fwd %6.1f us %5.0f GB/s | bwd %6.1f us %5.0f GB/s" % (h, 2 * h, C, mb, t_u, mb / t_u * 1e3, t_b, mb / t_b * 1e3), flush=True)
+for (H, Ca, Cb) in [(128, 32, 32), (64, 64, 64), (32, 128, 128), (16, 192, 192)]:
+    P = 64 * H * H
+    a = torch.randn(P, Ca, device="cuda").to(torch.bfloat16); b = torch.randn(P, Cb, device="cuda").to(torch.bfloat16)
+    o = torch.empty(P, Ca + Cb, device="cuda", dtype=torch.bfloat16)
+    mb = 2 * o.numel() * 2 / 1e6
+    t_c = timeit(lambda: L.concat2(a.data_ptr(), Ca, b.data_ptr(), Cb, o.data_ptr(), P, BF, st))
+    t_s = timeit(lambda: L.split2(o.data_ptr(), a.data_ptr(), Ca, b.data_ptr(), Cb, P, BF, st))
+    print("concat H=%3d %d+%d %6.1f MB | concat %6.1f us %5.0f GB/s | split %6.1f us %5.0f GB/s" % (H, Ca, Cb, mb, t_c, mb / t_c * 1e3, t_s, mb / t_s * 1e3), flush=True)
