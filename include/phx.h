@@ -350,6 +350,11 @@ int phx_residual_ce(const float* const* s, float* const* ds, const int* shift, i
 int phx_kl_diag_gauss(const float* mu0, const float* s0, const float* mu1, const float* s1, size_t n,
                       float level_w, float inv_batch, float grad_scale, float* loss, float* dmu0, float* ds0,
                       float* dmu1, float* ds1, void* stream);
+/* All levels of the hierarchical KL term (phiseg_model.py:265-287) in ONE launch.  ptrs: 9 device pointers per level {mu0, sigma0,
+ * mu1, sigma1, dmu0, dsigma0, dmu1, dsigma1, loss} (gradient pointers NULL: loss only); n[l] elements, level_w[l] = 4^l weights;
+ * loss[l] is ACCUMULATED: zero it before the launch. */
+int phx_kl_diag_gauss_multi(const void* const* ptrs, const size_t* n, const float* level_w, int L, float inv_batch, float grad_scale,
+                            void* stream);
 
 /* ---- optimiser: tf.train.AdamOptimizer (phiseg_model.py:137-141), TF 1.12 epsilon-hat form ---------- */
 /* t = *step_dev + 1;  lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  m,v EMA;  p -= lr_t*m/(sqrt(v)+eps).  One launch over

@@ -116,17 +116,22 @@ __global__ void k_residual_ce(CEArgs a, int L, const uint8_t* __restrict__ label
     }
     // losses: wave reduce -> one atomic per wave per level, spread over 64 slots
     if (loss_part) {
+        __shared__ float wl[4][CE_MAXL];             // the four wave sums meet in LDS: one atomic per level and BLOCK
 #pragma unroll
         for (int l = 0; l < CE_MAXL; ++l) {
             if (l >= L) continue;
             const float t = wave_sum(ce[l]);
-            if (lane == 0) {
-                if (det)      // deterministic mode: 32 slots of 2^-20 fixed point (integer adds commute), k_reduce_loss_parts converts
-                    atomicAdd(reinterpret_cast<unsigned long long*>(loss_part) + ((blockIdx.x * 4 + wave) & 31) * CE_MAXL + l,
-                              (unsigned long long)(long long)llrintf(t * inv_batch * 1048576.f));
-                else
-                    atomicAdd(&loss_part[((blockIdx.x * 4 + wave) & 63) * CE_MAXL + l], t * inv_batch);
-            }
+            if (lane == 0) wl[wave][l] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < L) {
+            const int l = threadIdx.x;
+            const float t = (wl[0][l] + wl[1][l]) + (wl[2][l] + wl[3][l]);
+            if (det)      // deterministic mode: 32 slots of 2^-20 fixed point (integer adds commute), k_reduce_loss_parts converts
+                atomicAdd(reinterpret_cast<unsigned long long*>(loss_part) + (blockIdx.x & 31) * CE_MAXL + l,
+                          (unsigned long long)(long long)llrintf(t * inv_batch * 1048576.f));
+            else
+                atomicAdd(&loss_part[(blockIdx.x & 63) * CE_MAXL + l], t * inv_batch);
         }
     }
     // gradients: d/ds_k = sum_{l<=k} G_l (prefix over levels, finest first), then f x f block sum
@@ -162,8 +167,9 @@ __global__ void k_residual_ce(CEArgs a, int L, const uint8_t* __restrict__ label
                         a.ds[k][(((size_t)b * hh + (py >> 4)) * ww + (px >> 4)) * C + c] = (wsum[0][c] + wsum[1][c]) + (wsum[2][c] + wsum[3][c]);
                     __syncthreads();
                 } else if (leader && valid) {
-                    float* dp = a.ds[k] + (((size_t)b * hh + (py >> sh)) * ww + (px >> sh)) * C + c;
-                    if (sh == 0) *dp = v; else atomicAdd(dp, v);
+                    // (sh <= 3: the f x f block lies inside this wave's 8 x 8 sub-tile and the shuffles above summed ALL of it -- one
+                    // writer per element, a plain store; the atomics that used to stand here cost this kernel most of its 88 us)
+                    a.ds[k][(((size_t)b * hh + (py >> sh)) * ww + (px >> sh)) * C + c] = v;
                 }
             }
         }
@@ -205,6 +211,45 @@ __global__ void k_kl(const float* __restrict__ mu0, const float* __restrict__ s0
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(loss, (sh[0] + sh[1] + sh[2] + sh[3]) * lw * inv_batch);
+}
+
+// all levels of the hierarchical KL term (phiseg_model.py:265-287) in ONE launch: block -> level by the running block counts
+#define KL_MAXL 8
+struct KLArgs {
+    const float *mu0[KL_MAXL], *s0[KL_MAXL], *mu1[KL_MAXL], *s1[KL_MAXL];
+    float *dmu0[KL_MAXL], *ds0[KL_MAXL], *dmu1[KL_MAXL], *ds1[KL_MAXL];
+    float* loss[KL_MAXL];                      // zeroed by the caller (accumulated atomically)
+    unsigned long long n[KL_MAXL];
+    float lw[KL_MAXL];
+    int blk0[KL_MAXL + 1];                     // first block of level l; blk0[L] = grid size
+};
+__global__ void k_kl_multi(KLArgs a, int L, float inv_batch, float gscale) {
+    int l = 0;
+#pragma unroll
+    for (int q = 1; q < KL_MAXL; ++q)
+        if (q < L && (int)blockIdx.x >= a.blk0[q]) l = q;
+    const int bx = blockIdx.x - a.blk0[l], nb = a.blk0[l + 1] - a.blk0[l];
+    const float *mu0 = a.mu0[l], *s0 = a.s0[l], *mu1 = a.mu1[l], *s1 = a.s1[l];
+    float *dmu0 = a.dmu0[l], *ds0 = a.ds0[l], *dmu1 = a.dmu1[l], *ds1 = a.ds1[l];
+    const size_t n = (size_t)a.n[l];
+    const float lw = a.lw[l];
+    float acc = 0.f;
+    const float c = gscale * lw * inv_batch;
+    for (size_t i = bx * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)nb * blockDim.x) {
+        const float aa = s0[i] * s0[i], bq = s1[i] * s1[i] + 1e-10f, d = mu1[i] - mu0[i];
+        acc += 0.5f * ((aa + d * d) / bq + logf(bq) - logf(aa + 1e-10f) - 1.f);
+        if (dmu0) {
+            dmu0[i] = -c * d / bq;
+            dmu1[i] = c * d / bq;
+            ds0[i] = c * s0[i] * (1.f / bq - 1.f / (aa + 1e-10f));
+            ds1[i] = c * s1[i] * (1.f / bq - (aa + d * d) / (bq * bq));
+        }
+    }
+    __shared__ float sh[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(a.loss[l], (sh[0] + sh[1] + sh[2] + sh[3]) * lw * inv_batch);
 }
 
 // ---- weight decay (phiseg_model.py:290-299): weight * sum over the 'weight_variables' collection of tf.nn.l2_loss(W) = sum w^2 / 2.
@@ -356,6 +401,34 @@ int phx_kl_diag_gauss(const float* mu0, const float* s0, const float* mu1, const
     PHX_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream));
     hipLaunchKernelGGL(k_kl, dim3(phx_deterministic() ? 1 : phx_grid_for(n, 256, 64)), dim3(256), 0, (hipStream_t)stream, mu0, s0, mu1, s1, n,
                        level_w, inv_batch, grad_scale, loss, dmu0, ds0, dmu1, ds1);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+/* every level of the hierarchical KL term in one launch.  ptrs: 9 device pointers per level {mu0, s0, mu1, s1, dmu0, ds0, dmu1, ds1,
+ * loss} (the four gradient pointers all NULL or all set), loss[l] += level_w[l] * inv_batch * sum KL -- the loss scalars must be ZERO
+ * on entry (the engine keeps them in its per-step zero arena); one block per level in deterministic mode. */
+int phx_kl_diag_gauss_multi(const void* const* ptrs, const size_t* n, const float* level_w, int L, float inv_batch, float grad_scale,
+                            void* stream) {
+    PHX_REQUIRE(L >= 1 && L <= KL_MAXL && ptrs && n && level_w, PHX_E_SHAPE, "kl_multi: 1 <= L <= 8");
+    KLArgs a;
+    int blk = 0;
+    for (int l = 0; l < KL_MAXL; ++l) {
+        const void* const* q = ptrs + 9 * (l < L ? l : 0);
+        a.mu0[l] = (const float*)q[0]; a.s0[l] = (const float*)q[1]; a.mu1[l] = (const float*)q[2]; a.s1[l] = (const float*)q[3];
+        a.dmu0[l] = (float*)q[4]; a.ds0[l] = (float*)q[5]; a.dmu1[l] = (float*)q[6]; a.ds1[l] = (float*)q[7];
+        a.loss[l] = (float*)q[8];
+        a.n[l] = l < L ? n[l] : 0;
+        a.lw[l] = l < L ? level_w[l] : 0.f;
+        a.blk0[l] = blk;
+        if (l < L) {
+            PHX_REQUIRE(q[0] && q[1] && q[2] && q[3] && q[8], PHX_E_INVAL, "kl_multi: null argument");
+            blk += phx_deterministic() ? 1 : phx_grid_for(n[l], 256, 64);
+        }
+    }
+    a.blk0[KL_MAXL] = blk;
+    for (int l = L; l <= KL_MAXL; ++l) a.blk0[l] = blk;
+    hipLaunchKernelGGL(k_kl_multi, dim3(blk), dim3(256), 0, (hipStream_t)stream, a, L, inv_batch, grad_scale);
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }

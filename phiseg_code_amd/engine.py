@@ -554,6 +554,16 @@ class Plan:
         opset = set(ops)
         self._opset = opset
         self._lat = self._find_latent_heads(ops) if _LATENT_FUSED else {}     # op -> record of a fused (mu head, sigma head[, sample]) group
+        self._kl_group = None
+        kls = [op for op in ops if op.type == "kl"]
+        if len(kls) >= 2 and len(kls) <= 8 and os.environ.get("PHX_KL_MULTI", "1") == "1":
+            ws = [self.loss_weight.get(op.outputs[0], 0.0) for op in kls]
+            i0, i1 = ops.index(kls[0]), ops.index(kls[-1])
+            between = [op for op in ops[i0:i1 + 1] if op.type != "kl"]
+            # one launch at the last level's operator: nothing in between may read a level's loss, one lane, one loss weight
+            if (len({self.op_lane[op] for op in kls}) == 1 and all(abs(w - ws[0]) < 1e-12 for w in ws)
+                    and not any(i.op in kls for b in between for i in b.inputs)):
+                self._kl_group = dict(ops=kls, recs=[], gscale=ws[0])
         self._bw_skip = set()
         self._bws = {}                # producer conv op -> (partials, tiles): BN-backward sums fused into the consumer's dgrad
         self._xf_pending = {}         # tensor a = act(norm(y)) whose apply pass was left to its (single) consumer convolution
@@ -1361,6 +1371,27 @@ class Plan:
 
     def _fw_kl(self, op, bw):
         mu0, s0, mu1, s1 = [self.val[t] for t in op.inputs]
+        grp = self._kl_group
+        if grp is not None and op in grp["ops"]:
+            # every level of the hierarchical KL term in ONE launch, emitted at the last level's operator (phx_kl_diag_gauss_multi);
+            # the loss scalars live in the per-step zero arena (accumulated atomically: no memset node per level)
+            loss = self._alloc_zeroed(1)
+            loss.shape = ()
+            self.val[op.outputs[0]] = loss
+            gs = [self._alloc(mu0.shape, F32) for _ in range(4)] if bw else [None] * 4
+            if bw:
+                self.saved[op] = dict(gs=gs)
+            grp["recs"].append((mu0, s0, mu1, s1, gs, loss, op.attrs["level_weight"]))
+            if op is grp["ops"][-1]:
+                recs = grp["recs"]
+                ptrs = rt.ptr_array([p for r in recs for p in ([r[0].ptr, r[1].ptr, r[2].ptr, r[3].ptr] +
+                                                               [g.ptr if g is not None else None for g in r[4]] + [r[5].ptr])])
+                ns = (ctypes.c_size_t * len(recs))(*[r[0].n for r in recs])
+                lws = (ctypes.c_float * len(recs))(*[r[6] for r in recs])
+                self._keep += [ptrs, ns, lws]
+                self._emit(self.L.kl_diag_gauss_multi, ptrs, ctypes.cast(ns, ctypes.c_void_p), ctypes.cast(lws, ctypes.c_void_p), len(recs),
+                           self.inv_batch, grp["gscale"] if bw else 0.0, self.stream)
+            return
         loss = self._alloc((), F32)
         self.val[op.outputs[0]] = loss
         gs = [None] * 4
