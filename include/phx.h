@@ -308,9 +308,13 @@ int phx_act_bwd(const void* dy, int dy_dt, const void* y, int y_dt, void* dpre, 
 /* ---- pooling / resize / concat (tfwrapper/layers.py:44-54, 336-345, 70-78; tf.concat) --------------- */
 int phx_avgpool2x2_fwd(const void* x, int dt, void* y, int B, int H, int W, int C, void* stream);
 int phx_avgpool2x2_bwd(const void* dy, int dt, void* dx, int B, int H, int W, int C, void* stream);
+/* the same, ADDED to dx (a tensor with several readers: the later gradient contributions accumulate in place, no add pass) */
+int phx_avgpool2x2_bwd_acc(const void* dy, int dt, void* dx, int B, int H, int W, int C, void* stream);
 /* TF 1.12 ResizeBilinear(align_corners=False), legacy coordinates, factor 2 */
 int phx_bilinear_up2x_fwd(const void* x, int dt, void* y, int B, int h, int w, int C, void* stream);
 int phx_bilinear_up2x_bwd(const void* dy, int dt, void* dx, int B, int h, int w, int C, void* stream);
+/* the same, ADDED to dx (a tensor with several readers: the later gradient contributions accumulate in place, no add pass) */
+int phx_bilinear_up2x_bwd_acc(const void* dy, int dt, void* dx, int B, int h, int w, int C, void* stream);
 int phx_concat2(const void* a, int Ca, const void* b, int Cb, void* out, size_t npix, int dt, void* stream);
 int phx_split2(const void* in, void* a, int Ca, void* b, int Cb, size_t npix, int dt, void* stream);
 int phx_add_inplace(void* dst, const void* src, size_t n, int dt, void* stream);

@@ -1162,7 +1162,7 @@ __global__ void k_avgpool_fwd(const T* __restrict__ x, T* __restrict__ y, int B,
 }
 
 template <typename T, int V>
-__global__ void k_avgpool_bwd(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int C) {
+__global__ void k_avgpool_bwd(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int C, int accumulate) {
     const int OH = (H + 1) / 2, OW = (W + 1) / 2, CV = C / V;
     const size_t items = (size_t)B * H * W * CV;
     for (size_t it = blockIdx.x * (size_t)blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
@@ -1178,6 +1178,12 @@ __global__ void k_avgpool_bwd(const T* __restrict__ dy, T* __restrict__ dx, int 
         const float inv = 1.f / (float)cnt;
 #pragma unroll
         for (int j = 0; j < V; ++j) v[j] *= inv;
+        if (accumulate) {                            // dx already holds another reader's gradient contribution
+            float o[V];
+            VecIO<T, V>::load(dx, it * V, o);
+#pragma unroll
+            for (int j = 0; j < V; ++j) v[j] += o[j];
+        }
         VecIO<T, V>::store(dx, it * V, v);
     }
 }
@@ -1221,7 +1227,7 @@ __global__ void k_bilinear_up2x_fwd(const T* __restrict__ x, T* __restrict__ y, 
 
 // adjoint (gather): 1-D taps of input k: (2k, 1), (2k+1, 1/2 [+1/2 if k == n-1]), (2k-1, 1/2 if k >= 1)
 template <typename T, int V>
-__global__ void k_bilinear_up2x_bwd(const T* __restrict__ dy, T* __restrict__ dx, int B, int h, int w, int C) {
+__global__ void k_bilinear_up2x_bwd(const T* __restrict__ dy, T* __restrict__ dx, int B, int h, int w, int C, int accumulate) {
     const int OH = 2 * h, OW = 2 * w, CV = C / V;
     const size_t items = (size_t)B * h * w * CV;
     for (size_t it = blockIdx.x * (size_t)blockDim.x + threadIdx.x; it < items; it += (size_t)gridDim.x * blockDim.x) {
@@ -1241,6 +1247,7 @@ __global__ void k_bilinear_up2x_bwd(const T* __restrict__ dy, T* __restrict__ dx
         float acc[V];
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[j] = 0.f;
+        if (accumulate) VecIO<T, V>::load(dx, it * V, acc);
         for (int a = 0; a < 3; ++a) {
             if (wy[a] == 0.f) continue;
             for (int c = 0; c < 3; ++c) {
@@ -1730,13 +1737,19 @@ int phx_avgpool2x2_fwd(const void* x, int dt, void* y, int B, int H, int W, int 
     PHX_SPATIAL_LAUNCH(k_avgpool_fwd, (size_t)B * ((H + 1) / 2) * ((W + 1) / 2), (const T*)x, (T*)y, B, H, W, C)
 }
 int phx_avgpool2x2_bwd(const void* dy, int dt, void* dx, int B, int H, int W, int C, void* stream) {
-    PHX_SPATIAL_LAUNCH(k_avgpool_bwd, (size_t)B * H * W, (const T*)dy, (T*)dx, B, H, W, C)
+    PHX_SPATIAL_LAUNCH(k_avgpool_bwd, (size_t)B * H * W, (const T*)dy, (T*)dx, B, H, W, C, 0)
+}
+int phx_avgpool2x2_bwd_acc(const void* dy, int dt, void* dx, int B, int H, int W, int C, void* stream) {
+    PHX_SPATIAL_LAUNCH(k_avgpool_bwd, (size_t)B * H * W, (const T*)dy, (T*)dx, B, H, W, C, 1)
 }
 int phx_bilinear_up2x_fwd(const void* x, int dt, void* y, int B, int h, int w, int C, void* stream) {
     PHX_SPATIAL_LAUNCH(k_bilinear_up2x_fwd, (size_t)B * h * w, (const T*)x, (T*)y, B, h, w, C)
 }
 int phx_bilinear_up2x_bwd(const void* dy, int dt, void* dx, int B, int h, int w, int C, void* stream) {
-    PHX_SPATIAL_LAUNCH(k_bilinear_up2x_bwd, (size_t)B * h * w, (const T*)dy, (T*)dx, B, h, w, C)
+    PHX_SPATIAL_LAUNCH(k_bilinear_up2x_bwd, (size_t)B * h * w, (const T*)dy, (T*)dx, B, h, w, C, 0)
+}
+int phx_bilinear_up2x_bwd_acc(const void* dy, int dt, void* dx, int B, int h, int w, int C, void* stream) {
+    PHX_SPATIAL_LAUNCH(k_bilinear_up2x_bwd, (size_t)B * h * w, (const T*)dy, (T*)dx, B, h, w, C, 1)
 }
 
 int phx_concat2(const void* a, int Ca, const void* b, int Cb, void* out, size_t npix, int dt, void* stream) {

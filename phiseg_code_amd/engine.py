@@ -1412,11 +1412,22 @@ class Plan:
         self._emit(self.L.weighted_sum, ptrs, ctypes.cast(ws, ctypes.c_void_p), len(op.inputs), out.ptr, self.stream)
 
     # ---- backward -------------------------------------------------------------------------------
-    def _add_grad(self, t, write_fn=None, buf=None):
+    def _add_grad(self, t, write_fn=None, buf=None, accum_fn=None):
         """Accumulate a gradient contribution for tensor t: either `buf` (already complete) or produced by
-        write_fn(target).  The first contribution owns the buffer; later ones are added in place."""
+        write_fn(target).  The first contribution owns the buffer; later ones are added in place -- by accum_fn(owner buffer) when
+        the contributing kernel has an accumulating form (no buffer of its own, no add pass), else by phx_add_inplace."""
         if not self.req.get(t, False):
             return
+        if accum_fn is not None and t in self.grad and os.environ.get("PHX_GRAD_ACCUM", "1") == "1":
+            g = self.grad[t]
+            own = [evl for b, evl in self.pending.get(t, []) if b is g]
+            # (only behind contributions of THIS lane: waiting here for another lane's write would tie the two backward chains
+            # together early -- measured 3 % slower than leaving that contribution in a buffer of its own for the finaliser)
+            if g.dt == self.val[t].dt and own and all(evl is None or evl[1] == self._lane for evl in own):
+                accum_fn(g)
+                evl = self._record(self._lane) if len(self._lanes) > 1 else None
+                self.pending[t].append((g, evl))             # (same buffer: the finaliser only waits for it)
+                return
         if buf is None:
             buf = self._alloc(self.val[t].shape, self.val[t].dt)
             write_fn(buf)
@@ -1455,6 +1466,8 @@ class Plan:
             g = self.grad[t]
             if buf is not g:
                 assert g.dt == buf.dt and g.n == buf.n
+                if os.environ.get("PHX_DEBUG_ADDS"):
+                    print("add_inplace", t.op.name, g.shape, [c.name for c in t.consumers if c in self._opset], getattr(self, "_cur_bw_op", None) and self._cur_bw_op.name)
                 self._emit(self.L.add_inplace, g.ptr, buf.ptr, g.n, g.dt, self.stream)
 
     def _bw_placeholder(self, op):
@@ -1575,12 +1588,16 @@ class Plan:
     def _bw_avgpool(self, op):
         x, d = self.val[op.inputs[0]], self.grad[op.outputs[0]]
         self._add_grad(op.inputs[0], write_fn=lambda g: self._emit(
-            self.L.avgpool2x2_bwd, d.ptr, d.dt, g.ptr, x.shape[0], x.shape[1], x.shape[2], x.shape[3], self.stream))
+            self.L.avgpool2x2_bwd, d.ptr, d.dt, g.ptr, x.shape[0], x.shape[1], x.shape[2], x.shape[3], self.stream),
+            accum_fn=(lambda g: self._emit(self.L.avgpool2x2_bwd_acc, d.ptr, d.dt, g.ptr, x.shape[0], x.shape[1], x.shape[2], x.shape[3],
+                                           self.stream)) if d.dt == x.dt else None)
 
     def _bw_bilinear_up(self, op):
         x, d = self.val[op.inputs[0]], self.grad[op.outputs[0]]
         self._add_grad(op.inputs[0], write_fn=lambda g: self._emit(
-            self.L.bilinear_up2x_bwd, d.ptr, d.dt, g.ptr, x.shape[0], x.shape[1], x.shape[2], x.shape[3], self.stream))
+            self.L.bilinear_up2x_bwd, d.ptr, d.dt, g.ptr, x.shape[0], x.shape[1], x.shape[2], x.shape[3], self.stream),
+            accum_fn=(lambda g: self._emit(self.L.bilinear_up2x_bwd_acc, d.ptr, d.dt, g.ptr, x.shape[0], x.shape[1], x.shape[2],
+                                           x.shape[3], self.stream)) if d.dt == x.dt else None)
 
     def _bw_global_avgpool(self, op):
         x, d = self.val[op.inputs[0]], self.grad[op.outputs[0]]

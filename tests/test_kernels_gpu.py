@@ -1110,3 +1110,21 @@ def test_latent_heads_fused(L, case):
     sgr2 = T.softplus(xr2 @ wsgr.detach() + torch.as_tensor(bsg, dtype=torch.float32).double())
     ((mur2 * torch.as_tensor(gm)).sum() + (sgr2 * torch.as_tensor(gs)).sum()).backward()
     close(host(dx2), xr2.grad.numpy(), 2e-5 if dt == F32 else 6e-3, "dx (KL only)")
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_accumulating_pool_and_resize_gradients(L, dt):
+    """phx_avgpool2x2_bwd_acc / phx_bilinear_up2x_bwd_acc: the gradient of a tensor with several readers is accumulated in place by the
+    later contributions (the engine then needs neither a second buffer nor an add pass): result = previous content + plain backward."""
+    B, H, W, C = 3, 6, 10, 16
+    prev = RNG.standard_normal((B, H, W, C))
+    dyp = RNG.standard_normal((B, (H + 1) // 2, (W + 1) // 2, C))
+    dyu = RNG.standard_normal((B, 2 * H, 2 * W, C))
+    tol = 1e-6 if dt == F32 else 1.2e-2
+    for fn, fn_acc, dy in ((L.avgpool2x2_bwd, L.avgpool2x2_bwd_acc, dyp), (L.bilinear_up2x_bwd, L.bilinear_up2x_bwd_acc, dyu)):
+        dyd = dev(dy, dt)
+        plain = torch.empty(B, H, W, C, dtype=tdt(dt)).cuda()
+        fn(dyd.data_ptr(), dt, plain.data_ptr(), B, H, W, C, S())
+        acc = dev(prev, dt)
+        fn_acc(dyd.data_ptr(), dt, acc.data_ptr(), B, H, W, C, S())
+        close(host(acc), host(plain) + rounded(prev, dt).numpy(), tol, fn_acc.__name__)
