@@ -105,6 +105,12 @@ int phx_conv3x3_mfma_bf16_ws(const void* x, const void* wpk, void* y, const floa
 int phx_conv3x3_mfma_stats_atomic_supported(int B, int H, int W, int K, int N);
 int phx_conv3x3_mfma_bf16_stats_atomic(const void* x, const void* wpk, void* y, const float* bias, int act, float* sums, int B,
                                        int H, int W, int K, int N, void* stream);
+/* ... with REPLICATED accumulators sums[nrep][N][2] (pixel tile t adds into replica t % nrep) for launches with many tiles -- any shape
+ * the policy routes to the 256-pixel or the 16 x 32 LDS-DMA kernels (phx_conv3x3_mfma_stats_rep_supported); consumer:
+ * phx_norm_apply_fused_rep.  Replaces the per-tile partial rows + phx_norm_reduce_partials launch of the large-map layers. */
+int phx_conv3x3_mfma_stats_rep_supported(int B, int H, int W, int K, int N);
+int phx_conv3x3_mfma_bf16_stats_rep(const void* x, const void* wpk, void* y, const float* bias, int act, float* sums, int nrep, int B,
+                                    int H, int W, int K, int N, void* stream);
 /* Convolution with an AFFINE epilogue: y = act(conv(x) * scale[n] + shift[n]) -- inference-mode batch norm
  * (normalisation.py:145-163 with is_training = False: y = gamma (x - moving_mean) / sqrt(moving_var + eps) + beta) and its
  * activation folded into the convolution that feeds it: one launch where the reference runs conv2d, batch_norm and relu.
@@ -241,6 +247,12 @@ int phx_norm_apply_fused(const void* x, int x_dt, const float* sums, const float
                          const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
                          float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
                          int G, int act, void* stream);
+/* the same reading REPLICATED sums[nrep][NS][C][2] (summed per block in the prologue): what phx_conv3x3_mfma_bf16_stats_rep leaves;
+ * nrep > 1 only for one channel per statistic (batch / instance norm) and pivot == NULL */
+int phx_norm_apply_fused_rep(const void* x, int x_dt, const float* sums, int nrep, const float* pivot, const float* gamma,
+                             const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
+                             float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
+                             int G, int act, void* stream);
 int phx_norm_bwd_apply_fused(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
                              const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx,
                              int dx_dt, float* dgamma, float* dbeta, int NS, int P, int C, int G, int act, int nrep,

@@ -243,6 +243,7 @@ struct BwdStats {
     const float *scale, *shift, *mean, *rstd;
     float* part;
     int act, stats_atomic;    // stats_atomic: stats_partial is the accumulator sums[N][2] itself, added to atomically
+    int stats_nrep;           // ... replicated stats_nrep (>= 1) times [rep][N][2]: pixel tile t adds into replica t % stats_nrep
     const float* oscale;      // per-output-channel scale of the bias / activation epilogue (inference-mode batch norm folded in)
 };
 
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
                 float v = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) v += red[(w * 2 + which) * BN + n];
-                if (bws.stats_atomic) atomicAdd(&stats_partial[(size_t)(n0 + n) * 2 + which], v);
+                if (bws.stats_atomic) atomicAdd(&stats_partial[((size_t)(bws.stats_nrep > 1 ? tile_id % bws.stats_nrep : 0) * N + n0 + n) * 2 + which], v);
                 else stats_partial[((size_t)tile_id * 2 + which) * N + n0 + n] = v;
             }
         }
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
                                                              const unsigned short* __restrict__ wpk,
                                                              unsigned short* __restrict__ y, const float* __restrict__ bias,
                                                              int act, float* __restrict__ stats_partial,
-                                                             int B, int H, int W, int K, int N, int tiles_x, int tiles_y, const float* __restrict__ oscale) {
+                                                             int B, int H, int W, int K, int N, int tiles_x, int tiles_y, const float* __restrict__ oscale, int stats_nrep) {
     constexpr int NJ = BN / 32;                       // BN = 64 (two 32-channel MFMA columns per wave) or 32 (one)
     constexpr int AI = 39, BI = 9 * BN * 64 / 1024;   // 1 KiB DMA instructions per chunk: 612 patch rows x 64 B, 9 * BN slab rows
     constexpr int NLW = 4;
@@ -946,7 +947,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) v += red[(w * 2 + which) * BN + n];
-            stats_partial[((size_t)tile_id * 2 + which) * N + n0 + n] = v;
+            // stats_nrep > 0: stats_partial is the replicated accumulator sums[rep][N][2] (tile t -> replica t % stats_nrep, atomics)
+            if (stats_nrep > 0) atomicAdd(&stats_partial[((size_t)(tile_id % stats_nrep) * N + n0 + n) * 2 + which], v);
+            else stats_partial[((size_t)tile_id * 2 + which) * N + n0 + n] = v;
         }
     }
     PHX_BLOCKLOG_END();
@@ -1713,6 +1716,22 @@ int phx_conv3x3_mfma_bf16_stats_atomic(const void* x, const void* wpk, void* y, 
     return conv3x3_mfma_impl(x, wpk, y, bias, act, sums, nullptr, 0, B, H, W, K, N, b, stream);
 }
 
+// The same with REPLICATED accumulators for launches with many pixel tiles (the 32 x 32 .. 128 x 128 levels): sums[nrep][N][2], tile t
+// adds into replica t % nrep (a same-address fp32 atomic retires in ~45 ns: 2 048 tiles on one address would take 90 us, on 32
+// replicas under 3 us spread over the launch), phx_norm_apply_fused_rep sums the replicas in its per-block prologue -- the
+// per-tile partial rows and the reduction launch between the convolution and the apply pass go away.  Any shape / kernel policy.
+int phx_conv3x3_mfma_bf16_stats_rep(const void* x, const void* wpk, void* y, const float* bias, int act, float* sums, int nrep, int B,
+                                    int H, int W, int K, int N, void* stream) {
+    PHX_REQUIRE(sums != nullptr && nrep >= 1 && !phx_deterministic(), PHX_E_INVAL, "conv3x3_mfma_stats_rep: sums / nrep (not in deterministic mode)");
+    BwdStats b{};
+    b.stats_atomic = 1;
+    b.stats_nrep = nrep;
+    return conv3x3_mfma_impl(x, wpk, y, bias, act, sums, nullptr, 0, B, H, W, K, N, b, stream);
+}
+int phx_conv3x3_mfma_stats_rep_supported(int B, int H, int W, int K, int N) {
+    return (!phx_deterministic() && K % KC == 0 && N % 32 == 0) ? 1 : 0;
+}
+
 int phx_conv3x3_mfma_bf16_affine(const void* x, const void* wpk, void* y, const float* scale, const float* shift, int act,
                                  void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream) {
     PHX_REQUIRE(scale != nullptr && shift != nullptr, PHX_E_INVAL, "conv3x3_mfma_affine: scale and shift are required");
@@ -1751,13 +1770,13 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
         const int ntl = B * (H / 16) * (W / 32);
         const char* dbe = getenv("PHX_DBG_ABLATE");   // dev: bit 1 no patch loads, 2 no slab loads, 4 no MFMAs
         const int dbg = dbe ? atoi(dbe) : 0;
-        if (phx_db_enabled() && N % 64 == 0) return phx_db_launch(x, wpk, y, bias, act, stats_partial, B, H, W, K, N, bws.oscale, dbg, stream);
+        if (phx_db_enabled() && N % 64 == 0 && !bws.stats_atomic) return phx_db_launch(x, wpk, y, bias, act, stats_partial, B, H, W, K, N, bws.oscale, dbg, stream);
 #define D128_LAUNCH1(Av, Dv, BNv)                                                                                               \
     do {                                                                                                                        \
         PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_dma128<Av, Dv, BNv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((k_conv3x3_fwd_dma128<Av, Dv, BNv>), dim3(ntl * (N / BNv)), dim3(256), 75 * 1024 + 16, (hipStream_t)stream, \
                            (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, \
-                           H, W, K, N, W / 32, H / 16, bws.oscale);                                                             \
+                           H, W, K, N, W / 32, H / 16, bws.oscale, bws.stats_atomic ? (bws.stats_nrep > 1 ? bws.stats_nrep : 1) : 0);                                                       \
     } while (0)
 #define D128_LAUNCH(Av, Dv)                                                                                                     \
     do { if (N % 64 == 0) D128_LAUNCH1(Av, Dv, 64); else D128_LAUNCH1(Av, 0, 32); } while (0)

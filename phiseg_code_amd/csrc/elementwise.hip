@@ -793,7 +793,7 @@ __global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __rest
                                    const float* __restrict__ pivot, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, TO* __restrict__ y, float* mean_out,
                                    float* rstd_out, float* scale_out, float* shift_out, float* moving_mean,
-                                   float* moving_var, float momentum, int P, int C, int G, int PL, int chunk, int act) {
+                                   float* moving_var, float momentum, int P, int C, int G, int PL, int chunk, int act, int nrep) {
     const int CV = C / V, cg = C / G;
     const int ns = blockIdx.y;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
@@ -809,7 +809,11 @@ __global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __rest
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
         float mu, var;
         if (cg == 1) {                                      // batch / instance norm: one channel per statistic
-            const float2 sq = *reinterpret_cast<const float2*>(sums + ((size_t)ns * C + g) * 2);
+            float2 sq = *reinterpret_cast<const float2*>(sums + ((size_t)ns * C + g) * 2);
+            for (int r = 1; r < nrep; ++r) {                    // replicated accumulators (phx_conv3x3_mfma_bf16_stats_rep)
+                const float2 q = *reinterpret_cast<const float2*>(sums + (((size_t)r * gridDim.y + ns) * C + g) * 2);
+                sq.x += q.x; sq.y += q.y;
+            }
             const float d1 = sq.x * invP;
             mu = (pivot ? pivot[(size_t)ns * C + g] : 0.f) + d1;
             var = fmaxf(sq.y * invP - d1 * d1, 0.f);
@@ -1519,21 +1523,29 @@ int phx_affine_act(const void* x, int x_dt, const float* scale, const float* shi
     return PHX_OK;
 }
 
-int phx_norm_apply_fused(const void* x, int x_dt, const float* sums, const float* pivot, const float* gamma,
-                         const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
-                         float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
-                         int G, int act, void* stream) {
+int phx_norm_apply_fused_rep(const void* x, int x_dt, const float* sums, int nrep, const float* pivot, const float* gamma,
+                             const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
+                             float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
+                             int G, int act, void* stream) {
     PHX_REQUIRE(G > 0 && C % G == 0, PHX_E_SHAPE, "norm_apply_fused: C % G != 0");
+    PHX_REQUIRE(nrep == 1 || (nrep > 1 && G == C && pivot == nullptr), PHX_E_INVAL, "norm_apply_fused_rep: replicas only for one channel per statistic, no pivot");
     PHX_REQUIRE(momentum == 0.f || (NS == 1 && G == C), PHX_E_INVAL, "moving update only for batch norm");
     PHX_DT_SWITCH(x_dt, TI, PHX_DT_SWITCH(y_dt, TO, PHX_VEC_SWITCH(C, V, {
         int PL, threads, chunk, nchunks;
         PHX_REQUIRE(stream_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_apply_fused: C too large");
         hipLaunchKernelGGL((k_norm_apply_fused<TI, TO, V>), dim3(nchunks, NS), dim3(threads), (size_t)2 * (C + G) * sizeof(float), (hipStream_t)stream,
                            (const TI*)x, sums, pivot, gamma, beta, eps, (TO*)y, mean, rstd, scale, shift, moving_mean,
-                           moving_var, momentum, P, C, G, PL, chunk, act);
+                           moving_var, momentum, P, C, G, PL, chunk, act, nrep);
     })));
     PHX_CHECK_LAUNCH();
     return PHX_OK;
+}
+int phx_norm_apply_fused(const void* x, int x_dt, const float* sums, const float* pivot, const float* gamma,
+                         const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
+                         float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
+                         int G, int act, void* stream) {
+    return phx_norm_apply_fused_rep(x, x_dt, sums, 1, pivot, gamma, beta, eps, y, y_dt, mean, rstd, scale, shift, moving_mean, moving_var,
+                                    momentum, NS, P, C, G, act, stream);
 }
 
 int phx_norm_bwd_apply_fused(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,

@@ -53,6 +53,11 @@ _STAMPS = os.environ.get("PHX_STAMPS", "0") == "1"
 _BN_SPLITK = os.environ.get("PHX_BN_SPLITK", "0") == "1"   # small batch norm consumes the split-K slices of its convolution (measured 0.5 % slower: off)
 _DETERMINISTIC = os.environ.get("PHX_DETERMINISTIC", "0") not in ("0", "")   # fixed summation orders everywhere (libphx reads the same variable)
 _BN_SMALL = int(os.environ.get("PHX_BN_SMALL", "1024"))     # one-launch batch norm up to this many pixels (0: off)
+# large-map batch norm: accumulator replicas of the conv epilogue's atomic statistics (phx_conv3x3_mfma_bf16_stats_rep ->
+# phx_norm_apply_fused_rep; 1 = per-tile partial rows + phx_norm_reduce_partials).  OFF: with 32 replicas the step has 42 launches fewer
+# (971 -> 929) and is 2 % SLOWER (11.37 -> 11.60 ms, two A/B pairs): 2 048 - 4 096 blocks x 64 - 128 atomics land on 4 cache lines per
+# replica, and fp32 atomics on ONE line retire serially (~45 ns each) -- the tail of every large-map convolution waits for them
+_STATS_REP = int(os.environ.get("PHX_STATS_REP", "1"))
 # conv -> norm -> act -> conv edges: the consumer convolution finalises the producer's normalisation in its prologue, applies it while
 # staging and materialises a as a side effect (phx_conv3x3_mfma_bf16_xf) -- no stand-alone apply pass, no launch for it.  PHX_XF=1
 # turns it on (read when a plan is built).  OFF by default -- measured on MI355X (round 3, phiseg_7_5 B = 64): 39 of the 106
@@ -1004,7 +1009,7 @@ class Plan:
 
         if pend is not None and not (mfma and not padded and not head1x1 and x.dt == BF16):
             # (not reached with the shapes _xf_consumer admits) the normalisation is applied by its own launch after all
-            self._emit(Lb.norm_apply_fused, *pend["apply_args"], S)
+            self._emit(Lb.norm_apply_fused_rep, *pend["apply_args"], S)
             pend = None
         xf = pend is not None
 
@@ -1019,7 +1024,7 @@ class Plan:
                 d = pend
                 self._emit(Lb.conv3x3_mfma_bf16_xf, d["y"].ptr, wf.ptr, y.ptr, bptr, act_code, st_buf.ptr if st_buf is not None else None,
                            1 if stats_atomic is not None else 0, ws.ptr if ws else None, wsb, B, H, Wd, cin_eff, cout,
-                           d["sums"].ptr, d["pivot"].ptr if d["pivot"] is not None else None, d["gamma"], d["beta"], d["eps"], 1,
+                           d["sums"].ptr, d["pivot"].ptr if d["pivot"] is not None else None, d["gamma"], d["beta"], d["eps"], d["nrep"],
                            d["NS"], d["G"], d["act"], x.ptr, d["mean"].ptr, d["rstd"].ptr, d["scale"].ptr, d["shift"].ptr,
                            d["mm"], d["mv"], d["mom"], S, tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd,
                            shape=("xf", B, H, Wd, cin_eff, cout))
@@ -1126,7 +1131,16 @@ class Plan:
             # shifted (pivot) sums in a stand-alone pass: always on the fp32 parity path, and on the bf16 path when
             # a statistic has few samples (cheap there); otherwise the sums come from the conv epilogue.
             small = P <= 16384 or self.act_dt == F32
-            if norm == "batch" and mfma and not small:
+            nrep_fw = 1
+            if (norm == "batch" and mfma and not small and not xf and not head1x1 and _STATS_REP > 1 and not _DETERMINISTIC
+                    and Lb.conv3x3_mfma_stats_rep_supported(B, H, Wd, cin_eff, cout)):
+                # many pixel tiles (the 32 x 32 .. 128 x 128 levels): the convolution adds its statistics atomically into _STATS_REP
+                # accumulator replicas, the apply pass sums them in its prologue -- no partial rows, no reduction launch in between
+                nrep_fw = _STATS_REP
+                sums = self._alloc_zeroed(nrep_fw * cout * 2)
+                self._emit(Lb.conv3x3_mfma_bf16_stats_rep, x.ptr, wf.ptr, y.ptr, bptr, 0, sums.ptr, nrep_fw, B, H, Wd, cin_eff, cout, S,
+                           tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
+            elif norm == "batch" and mfma and not small:
                 ntile = tiles_fn()
                 part = self._alloc((ntile * 2 * cout,), F32)
                 conv_into(y, 0, stats_part=part)
@@ -1153,17 +1167,17 @@ class Plan:
             mmp = self.store.ptr(nv["moving_mean"]) if upd else None
             mvp = self.store.ptr(nv["moving_variance"]) if upd else None
             mom = (1.0 - tfnorm.BN_DECAY) if upd else 0.0
-            apply_args = (y.ptr, y.dt, sums.ptr, pivot.ptr if pivot is not None else None, gptr, beptr, eps, out.ptr, out.dt, mean.ptr,
-                          rstd.ptr, scale.ptr, shift.ptr, mmp, mvp, mom, NS, P, cout, Gn, act)
+            apply_args = (y.ptr, y.dt, sums.ptr, nrep_fw, pivot.ptr if pivot is not None else None, gptr, beptr, eps, out.ptr, out.dt,
+                          mean.ptr, rstd.ptr, scale.ptr, shift.ptr, mmp, mvp, mom, NS, P, cout, Gn, act)
             cons = self._xf_consumer(op) if (mfma and y.dt == BF16 and out.dt == BF16 and B * H * Wd <= _XF_MAXP) else None
             if cons is not None and Lb.conv3x3_xf_supported(B, H, Wd, cout, cons.attrs["W"].shape[-1], NS):
                 # fused edge: the consumer convolution finalises these statistics, applies act(y * scale + shift) while it stages
                 # its input and writes a (= out) as a side effect
-                self._xf_pending[op.outputs[0]] = dict(y=y, sums=sums, pivot=pivot, gamma=gptr, beta=beptr, eps=eps, NS=NS, G=Gn, act=act,
+                self._xf_pending[op.outputs[0]] = dict(y=y, sums=sums, nrep=nrep_fw, pivot=pivot, gamma=gptr, beta=beptr, eps=eps, NS=NS, G=Gn, act=act,
                                                        mean=mean, rstd=rstd, scale=scale, shift=shift, mm=mmp, mv=mvp, mom=mom,
                                                        apply_args=apply_args)
             else:
-                self._emit(Lb.norm_apply_fused, *apply_args, S, tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
+                self._emit(Lb.norm_apply_fused_rep, *apply_args, S, tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
         st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn)
         if norm != "batch":
             st.update(fsums=sums, fpivot=pivot)          # forward per-channel sums: the bias gradient is closed-form from them

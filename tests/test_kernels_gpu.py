@@ -1128,3 +1128,46 @@ def test_accumulating_pool_and_resize_gradients(L, dt):
         acc = dev(prev, dt)
         fn_acc(dyd.data_ptr(), dt, acc.data_ptr(), B, H, W, C, S())
         close(host(acc), host(plain) + rounded(prev, dt).numpy(), tol, fn_acc.__name__)
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, 64, 64, 0), (1, 16, 32, 32, 96, 5), (3, 64, 32, 32, 32, 0), (2, 32, 16, 128, 32, 0)])
+def test_conv3x3_mfma_replicated_atomic_statistics(L, case, monkeypatch):
+    """phx_conv3x3_mfma_bf16_stats_rep + phx_norm_apply_fused_rep: the large-map batch-norm layers' statistics as replicated atomic
+    accumulators (pixel tile t -> replica t % nrep) summed in the apply pass' prologue, on the 256-pixel kernels, the 8-wave tiles
+    and (forced) the 16 x 32 LDS-DMA kernel: the replicas sum to {sum y, sum y^2} of the stored output, and the apply pass equals
+    phx_norm_apply_fused on the summed statistics."""
+    B, H, W, K, N, ws = case
+    if ws:
+        monkeypatch.setenv("PHX_FWD_WS", str(ws))
+    assert L.conv3x3_mfma_stats_rep_supported(B, H, W, K, N) == 1
+    x = RNG.standard_normal((B, H, W, K))
+    w = RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K)
+    xd, wd = dev(x, BF16), dev(w)
+    wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    wg = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    L.pack_conv3x3_bf16(wd.data_ptr(), wf.data_ptr(), wg.data_ptr(), K, N, S())
+    y0 = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
+    L.conv3x3_mfma_bf16(xd.data_ptr(), wf.data_ptr(), y0.data_ptr(), None, 0, None, B, H, W, K, N, S())
+    nrep = 5
+    y = torch.empty_like(y0)
+    sums = torch.zeros(nrep, N, 2, dtype=torch.float32).cuda()
+    L.conv3x3_mfma_bf16_stats_rep(xd.data_ptr(), wf.data_ptr(), y.data_ptr(), None, 0, sums.data_ptr(), nrep, B, H, W, K, N, S())
+    assert torch.equal(y, y0)
+    yf = host(y).reshape(-1, N)
+    tot = host(sums).sum(axis=0)
+    close(tot[:, 0], yf.sum(0), 2e-5, "sum y over the replicas")
+    close(tot[:, 1], (yf ** 2).sum(0), 2e-5, "sum y^2 over the replicas")
+    if B * (H // 16 if H >= 16 else 1) > 1:
+        assert (host(sums)[1:] != 0).any()                       # more than one replica is in use
+    gamma, beta = dev(1.0 + 0.2 * RNG.standard_normal(N)), dev(0.3 * RNG.standard_normal(N))
+    P = B * H * W
+    outs = []
+    for rep, sm in ((nrep, sums), (1, sums.sum(dim=0).contiguous())):
+        a = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
+        mean, rstd, scale, shift = (torch.empty(N).cuda() for _ in range(4))
+        L.norm_apply_fused_rep(y.data_ptr(), BF16, sm.data_ptr(), rep, None, gamma.data_ptr(), beta.data_ptr(), 1e-3, a.data_ptr(), BF16,
+                               mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, None, 0.0, 1, P, N, N, 1, S())
+        outs.append((host(a), host(mean), host(rstd)))
+    close(outs[0][1], outs[1][1], 1e-6, "mean")
+    close(outs[0][2], outs[1][2], 1e-6, "rstd")
+    close(outs[0][0], outs[1][0], 2 ** -7, "a")
