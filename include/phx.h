@@ -253,6 +253,22 @@ int phx_norm_apply_fused_rep(const void* x, int x_dt, const float* sums, int nre
                              const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
                              float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
                              int G, int act, void* stream);
+/* ... and with a 1x1 HEAD fused in (the likelihood's top layer feeding y_lvl0, likelihoods.py:220: the head is the only reader of
+ * a = act(norm(x))): y receives a as usual and y_head[NS * P][nout] = b_head + a w_head (w_head the HWIO 1x1 filter [C][nout]), computed
+ * from the values just produced instead of by a pass of its own over a.  bf16 in / out, C / 8 a power of two <= 64, nout in {2, 4}
+ * (phx_norm_head_supported).  Backward: phx_norm_bwd_reduce_head / phx_norm_bwd_apply_fused_head form dA = dy_head w_head^T on the fly. */
+int phx_norm_head_supported(int C, int nout, int x_dt, int y_dt);
+int phx_norm_apply_fused_head(const void* x, int x_dt, const float* sums, int nrep, const float* pivot, const float* gamma,
+                              const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
+                              float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
+                              int G, int act, const float* w_head, const float* b_head, int nout, float* y_head, void* stream);
+int phx_norm_bwd_reduce_head(const float* dy_head, const float* w_head, int nout, const void* x, const float* scale, const float* shift,
+                             const float* mean, const float* rstd, float* sums2, int NS, int P, int C, int G, int act, int nrep,
+                             void* stream);
+int phx_norm_bwd_apply_fused_head(const float* dy_head, const float* w_head, int nout, const void* x, const float* scale,
+                                  const float* shift, const float* mean, const float* rstd, const float* gamma, const float* sums2,
+                                  void* dx, float* dgamma, float* dbeta, const float* fwd_sums, const float* fwd_pivot, float* dbias,
+                                  int NS, int P, int C, int G, int act, int nrep, void* stream);
 int phx_norm_bwd_apply_fused(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
                              const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx,
                              int dx_dt, float* dgamma, float* dbeta, int NS, int P, int C, int G, int act, int nrep,

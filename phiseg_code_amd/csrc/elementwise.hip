@@ -2,6 +2,8 @@
 // pooling, TF1 bilinear resize, concat/split, casts, posterior input assembly, global pooling.
 // All are streaming kernels: 16-byte vector access along the NHWC channel axis when C % 8 == 0.
 #include <stdlib.h>
+#include <type_traits>
+
 #include "phx_common.h"
 
 // ---- 8-wide vector access ----------------------------------------------------------------------
@@ -788,12 +790,20 @@ __device__ __forceinline__ void group_stats(const float* __restrict__ sums, cons
     *var_out = var / (float)cg;
 }
 
-template <typename TI, typename TO, int V>
+// HN > 0: a 1x1 head with HN outputs reads a = act(norm(x)) and nothing else does (the likelihood's top layer feeding y_lvl0,
+// likelihoods.py:220): its forward is computed here from the values just produced -- yh[p][o] = bh[o] + sum_c a[p][c] wh[c][o], the
+// sum over the channel vectors of a pixel by lane shuffles (C / V a power of two <= 64) -- instead of by a pass of its own over a.
+struct HeadFw {
+    const float *w, *b;
+    float* y;
+};
+template <typename TI, typename TO, int V, int HN = 0>
 __global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __restrict__ sums,
                                    const float* __restrict__ pivot, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, TO* __restrict__ y, float* mean_out,
                                    float* rstd_out, float* scale_out, float* shift_out, float* moving_mean,
-                                   float* moving_var, float momentum, int P, int C, int G, int PL, int chunk, int act, int nrep) {
+                                   float* moving_var, float momentum, int P, int C, int G, int PL, int chunk, int act, int nrep,
+                                   HeadFw hd) {
     const int CV = C / V, cg = C / G;
     const int ns = blockIdx.y;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
@@ -854,6 +864,33 @@ __global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __rest
         sh[j] = cof[2 * (cv * V + j) + 1];
     }
     const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
+    float hw[V][HN > 0 ? HN : 1];
+    if constexpr (HN > 0) {
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+#pragma unroll
+            for (int o = 0; o < HN; ++o) hw[j][o] = hd.w[(size_t)(cv * V + j) * HN + o];
+    }
+    auto head = [&](size_t pix, const float (&a)[V]) {     // (all CV lanes of the pixel are active together)
+        if constexpr (HN > 0) {
+            float part[HN];
+#pragma unroll
+            for (int o = 0; o < HN; ++o) part[o] = 0.f;
+#pragma unroll
+            for (int j = 0; j < V; j += 2) {                   // the head reads a as it is stored (bf16)
+                const unsigned w2 = f2bf_pk(a[j], a[j + 1]);
+                const float a0 = __uint_as_float(w2 << 16), a1 = __uint_as_float(w2 & 0xffff0000u);
+#pragma unroll
+                for (int o = 0; o < HN; ++o) part[o] = fmaf(a1, hw[j + 1][o], fmaf(a0, hw[j][o], part[o]));
+            }
+            for (int m = 1; m < CV; m <<= 1)
+#pragma unroll
+                for (int o = 0; o < HN; ++o) part[o] += __shfl_xor(part[o], m, 64);
+            if (cv == 0)
+#pragma unroll
+                for (int o = 0; o < HN; ++o) hd.y[pix * HN + o] = part[o] + hd.b[o];
+        }
+    };
     int p = p0 + pl;
     for (; p + 3 * PL < p1; p += 4 * PL) {       // four pixels per trip, loads first (see k_norm_stats)
         float v[4][V];
@@ -864,6 +901,7 @@ __global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __rest
 #pragma unroll
             for (int j = 0; j < V; ++j) v[u][j] = act_fwd(fmaf(v[u][j], sc[j], sh[j]), act);
             VecIO<TO, V>::store(y, ((size_t)ns * P + p + u * PL) * C + (size_t)cv * V, v[u]);
+            head((size_t)ns * P + p + u * PL, v[u]);
         }
     }
     for (; p < p1; p += PL) {
@@ -873,10 +911,44 @@ __global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __rest
 #pragma unroll
         for (int j = 0; j < V; ++j) v[j] = act_fwd(fmaf(v[j], sc[j], sh[j]), act);
         VecIO<TO, V>::store(y, off, v);
+        head((size_t)ns * P + p, v);
     }
 }
 
-template <typename TD, typename TX, typename TO, int V>
+// HN > 0 (backward of the layer whose only reader is a 1x1 head, see HeadFw): the upstream gradient dA = dyh wh^T is a rank-HN
+// function of the head's tiny gradient -- it is formed here per element (rounded to the storage type, as the head's data-gradient
+// launch would have stored it) instead of being written by that launch and read back by the two backward passes.
+struct HeadBw {
+    const float *dy, *w;
+};
+template <typename TD, int V, int HN>
+__device__ __forceinline__ void load_da(const TD* __restrict__ dA, size_t off, const HeadBw& hb, size_t pix,
+                                        const float (&hw)[V][HN > 0 ? HN : 1], float (&dv)[V]) {
+    if constexpr (HN == 0) {
+        VecIO<TD, V>::load(dA, off, dv);
+    } else {
+        static_assert(HN == 0 || (V % 2 == 0 && std::is_same<TD, bf16_t>::value), "head-derived dA: bf16, even vector width");
+        float d[HN];                                      // one 8- / 16-byte load per pixel
+        if constexpr (HN == 2) {
+            const float2 q = *reinterpret_cast<const float2*>(hb.dy + pix * 2);
+            d[0] = q.x; d[1] = q.y;
+        } else {
+            const float4 q = *reinterpret_cast<const float4*>(hb.dy + pix * 4);
+            d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+        }
+#pragma unroll
+        for (int j = 0; j < V; j += 2) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int o = 0; o < HN; ++o) { a0 = fmaf(d[o], hw[j][o], a0); a1 = fmaf(d[o], hw[j + 1][o], a1); }
+            const unsigned w2 = f2bf_pk(a0, a1);          // stored precision of dA (v_cvt_pk_bf16_f32: round to nearest even)
+            dv[j] = __uint_as_float(w2 << 16);
+            dv[j + 1] = __uint_as_float(w2 & 0xffff0000u);
+        }
+    }
+}
+
+template <typename TD, typename TX, typename TO, int V, int HN = 0>
 __global__ void k_norm_bwd_apply_fused(const TD* __restrict__ dA, const TX* __restrict__ x,
                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                        const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -884,10 +956,17 @@ __global__ void k_norm_bwd_apply_fused(const TD* __restrict__ dA, const TX* __re
                                        TO* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int P,
                                        int C, int G, int PL, int chunk, int act, int nrep,
                                        const float* __restrict__ fsums, const float* __restrict__ fpivot,
-                                       float* __restrict__ dbias) {
+                                       float* __restrict__ dbias, HeadBw hb) {
     const int CV = C / V, cg = C / G;
     const int ns = blockIdx.y;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    float hw[V][HN > 0 ? HN : 1];
+    if constexpr (HN > 0) {
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+#pragma unroll
+            for (int o = 0; o < HN; ++o) hw[j][o] = hb.w[(size_t)(cv * V + j) * HN + o];
+    }
     // finalisation once per block, cooperatively, through LDS (see k_norm_apply_fused):
     //   st[c][2]  = sum over the accumulator replicas of {sum g, sum g * xhat}
     //   sg[g][2]  = S0, S1 = sum over the statistic's channels of gamma_c * st[c]
@@ -955,7 +1034,7 @@ __global__ void k_norm_bwd_apply_fused(const TD* __restrict__ dA, const TX* __re
         for (int u = 0; u < 4; ++u) {
             const size_t off = ((size_t)ns * P + p + u * PL) * C + (size_t)cv * V;
             VecIO<TX, V>::load(x, off, xv[u]);
-            VecIO<TD, V>::load(dA, off, dv[u]);
+            load_da<TD, V, HN>(dA, off, hb, (size_t)ns * P + p + u * PL, hw, dv[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -972,7 +1051,7 @@ __global__ void k_norm_bwd_apply_fused(const TD* __restrict__ dA, const TX* __re
         const size_t off = ((size_t)ns * P + p) * C + (size_t)cv * V;
         float xv[V], dv[V], o[V];
         VecIO<TX, V>::load(x, off, xv);
-        VecIO<TD, V>::load(dA, off, dv);
+        load_da<TD, V, HN>(dA, off, hb, (size_t)ns * P + p, hw, dv);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             const float gq = dv[j] * act_grad_pre(fmaf(xv[j], sc[j], sh[j]), act);
@@ -983,14 +1062,21 @@ __global__ void k_norm_bwd_apply_fused(const TD* __restrict__ dA, const TX* __re
 }
 
 // sums2[ns][c][2] += {sum g, sum g*xhat},  g = dA * act'(x*scale+shift), xhat = (x-mean)*rstd
-template <typename TD, typename TX, int V>
+template <typename TD, typename TX, int V, int HN = 0>
 __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const TD* __restrict__ dA, const TX* __restrict__ x,
                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                   const float* __restrict__ mean, const float* __restrict__ rstd,
-                                  float* __restrict__ sums2, int P, int C, int G, int PL, int chunk, int act, int nrep) {
+                                  float* __restrict__ sums2, int P, int C, int G, int PL, int chunk, int act, int nrep, HeadBw hb) {
     const int CV = C / V;
     const int ns = blockIdx.y;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    float hw[V][HN > 0 ? HN : 1];
+    if constexpr (HN > 0) {
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+#pragma unroll
+            for (int o = 0; o < HN; ++o) hw[j][o] = hb.w[(size_t)(cv * V + j) * HN + o];
+    }
     extern __shared__ float red[];
     // Same-address fp32 atomics retire at ~1 per 45 ns on MI355X (memory-side), so with a thousand blocks the adds into
     // one sums2 entry -- not the streaming -- set the kernel time: block b adds into replica b % nrep, the consumer
@@ -1023,7 +1109,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const TD* __restrict__ 
             for (int u = 0; u < 4; ++u) {
                 const size_t off = ((size_t)ns * P + p + u * PL) * C + (size_t)cv * V;
                 VecIO<TX, V>::load(x, off, xv[u]);
-                VecIO<TD, V>::load(dA, off, dv[u]);
+                load_da<TD, V, HN>(dA, off, hb, (size_t)ns * P + p + u * PL, hw, dv[u]);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -1038,7 +1124,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const TD* __restrict__ 
             float xv[V], dv[V];
             const size_t off = ((size_t)ns * P + p) * C + (size_t)cv * V;
             VecIO<TX, V>::load(x, off, xv);
-            VecIO<TD, V>::load(dA, off, dv);
+            load_da<TD, V, HN>(dA, off, hb, (size_t)ns * P + p, hw, dv);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 const float g = dv[j] * act_grad_pre(xv[j] * sc[j] + sh[j], act);
@@ -1523,19 +1609,55 @@ int phx_affine_act(const void* x, int x_dt, const float* scale, const float* shi
     return PHX_OK;
 }
 
+static int norm_apply_impl(const void* x, int x_dt, const float* sums, int nrep, const float* pivot, const float* gamma,
+                           const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
+                           float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
+                           int G, int act, HeadFw hd, int hn, void* stream);
 int phx_norm_apply_fused_rep(const void* x, int x_dt, const float* sums, int nrep, const float* pivot, const float* gamma,
                              const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
                              float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
                              int G, int act, void* stream) {
+    return norm_apply_impl(x, x_dt, sums, nrep, pivot, gamma, beta, eps, y, y_dt, mean, rstd, scale, shift, moving_mean, moving_var, momentum,
+                           NS, P, C, G, act, HeadFw{nullptr, nullptr, nullptr}, 0, stream);
+}
+int phx_norm_head_supported(int C, int nout, int x_dt, int y_dt) {
+    const int cv = C / 8;
+    return (x_dt == PHX_BF16 && y_dt == PHX_BF16 && C % 8 == 0 && (nout == 2 || nout == 4) && cv >= 1 && cv <= 64 && (cv & (cv - 1)) == 0) ? 1 : 0;
+}
+int phx_norm_apply_fused_head(const void* x, int x_dt, const float* sums, int nrep, const float* pivot, const float* gamma,
+                              const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
+                              float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
+                              int G, int act, const float* w_head, const float* b_head, int nout, float* y_head, void* stream) {
+    PHX_REQUIRE(phx_norm_head_supported(C, nout, x_dt, y_dt) && w_head && b_head && y_head, PHX_E_SHAPE,
+                "norm_apply_fused_head: bf16, C / 8 a power of two <= 64, nout in {2, 4}");
+    return norm_apply_impl(x, x_dt, sums, nrep, pivot, gamma, beta, eps, y, y_dt, mean, rstd, scale, shift, moving_mean, moving_var, momentum,
+                           NS, P, C, G, act, HeadFw{w_head, b_head, y_head}, nout, stream);
+}
+static int norm_apply_impl(const void* x, int x_dt, const float* sums, int nrep, const float* pivot, const float* gamma,
+                           const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
+                           float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
+                           int G, int act, HeadFw hd, int hn, void* stream) {
     PHX_REQUIRE(G > 0 && C % G == 0, PHX_E_SHAPE, "norm_apply_fused: C % G != 0");
     PHX_REQUIRE(nrep == 1 || (nrep > 1 && G == C && pivot == nullptr), PHX_E_INVAL, "norm_apply_fused_rep: replicas only for one channel per statistic, no pivot");
+    if (hn > 0) {
+        int PL, threads, chunk, nchunks;
+        PHX_REQUIRE(stream_geometry(P, C, 8, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_apply_fused_head: C too large");
+#define NAH_LAUNCH(HNv)                                                                                                          \
+        hipLaunchKernelGGL((k_norm_apply_fused<bf16_t, bf16_t, 8, HNv>), dim3(nchunks, NS), dim3(threads), (size_t)2 * (C + G) * sizeof(float), \
+                           (hipStream_t)stream, (const bf16_t*)x, sums, pivot, gamma, beta, eps, (bf16_t*)y, mean, rstd, scale, shift,  \
+                           moving_mean, moving_var, momentum, P, C, G, PL, chunk, act, nrep, hd)
+        if (hn == 2) NAH_LAUNCH(2); else NAH_LAUNCH(4);
+#undef NAH_LAUNCH
+        PHX_CHECK_LAUNCH();
+        return PHX_OK;
+    }
     PHX_REQUIRE(momentum == 0.f || (NS == 1 && G == C), PHX_E_INVAL, "moving update only for batch norm");
     PHX_DT_SWITCH(x_dt, TI, PHX_DT_SWITCH(y_dt, TO, PHX_VEC_SWITCH(C, V, {
         int PL, threads, chunk, nchunks;
         PHX_REQUIRE(stream_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_apply_fused: C too large");
         hipLaunchKernelGGL((k_norm_apply_fused<TI, TO, V>), dim3(nchunks, NS), dim3(threads), (size_t)2 * (C + G) * sizeof(float), (hipStream_t)stream,
                            (const TI*)x, sums, pivot, gamma, beta, eps, (TO*)y, mean, rstd, scale, shift, moving_mean,
-                           moving_var, momentum, P, C, G, PL, chunk, act, nrep);
+                           moving_var, momentum, P, C, G, PL, chunk, act, nrep, hd);
     })));
     PHX_CHECK_LAUNCH();
     return PHX_OK;
@@ -1568,8 +1690,48 @@ int phx_norm_bwd_apply_fused_bias(const void* dA, int da_dt, const void* x, int 
         PHX_REQUIRE(stream_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_bwd_apply_fused: C too large");
         hipLaunchKernelGGL((k_norm_bwd_apply_fused<TD, TX, TD, V>), dim3(nchunks, NS), dim3(threads),
                            (size_t)(7 * C + 2 * G) * sizeof(float), (hipStream_t)stream, (const TD*)dA, (const TX*)x, scale, shift, mean, rstd, gamma, sums2,
-                           (TD*)dx, dgamma, dbeta, P, C, G, PL, chunk, act, nrep, fwd_sums, fwd_pivot, dbias);
+                           (TD*)dx, dgamma, dbeta, P, C, G, PL, chunk, act, nrep, fwd_sums, fwd_pivot, dbias, HeadBw{nullptr, nullptr});
     })));
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+/* backward of a normalisation layer whose only reader is a 1x1 head (phx_norm_apply_fused_head): the upstream gradient is
+ * dA = dy_head w_head^T (rounded to bf16), formed on the fly from dy_head [NS * P][nout] -- the head's data-gradient launch, its
+ * [NS * P][C] output and the two reads of it disappear.  bf16 tensors, C % 8 == 0, nout in {2, 4}. */
+int phx_norm_bwd_reduce_head(const float* dy_head, const float* w_head, int nout, const void* x, const float* scale, const float* shift,
+                             const float* mean, const float* rstd, float* sums2, int NS, int P, int C, int G, int act, int nrep,
+                             void* stream) {
+    PHX_REQUIRE(dy_head && w_head && (nout == 2 || nout == 4) && C % 8 == 0 && nrep >= 1, PHX_E_INVAL, "norm_bwd_reduce_head: bad arguments");
+    int PL, threads, chunk, nchunks;
+    PHX_REQUIRE(norm_geometry(P, C, 8, &PL, &threads, &chunk, &nchunks, NS, nrep) == 0, PHX_E_SHAPE, "norm_bwd_reduce_head: C too large");
+    if (phx_deterministic() && nchunks > nrep) {
+        chunk = (P + nrep - 1) / nrep;
+        nchunks = (P + chunk - 1) / chunk;
+    }
+#define NRH_LAUNCH(HNv)                                                                                                           \
+    hipLaunchKernelGGL((k_norm_bwd_reduce<bf16_t, bf16_t, 8, HNv>), dim3(nchunks, NS), dim3(threads),                              \
+                       (size_t)(PL > 2 ? PL : 2) * C * 2 * sizeof(float), (hipStream_t)stream, (const bf16_t*)nullptr, (const bf16_t*)x, \
+                       scale, shift, mean, rstd, sums2, P, C, G, PL, chunk, act, nrep, HeadBw{dy_head, w_head})
+    if (nout == 2) NRH_LAUNCH(2); else NRH_LAUNCH(4);
+#undef NRH_LAUNCH
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+int phx_norm_bwd_apply_fused_head(const float* dy_head, const float* w_head, int nout, const void* x, const float* scale,
+                                  const float* shift, const float* mean, const float* rstd, const float* gamma, const float* sums2,
+                                  void* dx, float* dgamma, float* dbeta, const float* fwd_sums, const float* fwd_pivot, float* dbias,
+                                  int NS, int P, int C, int G, int act, int nrep, void* stream) {
+    PHX_REQUIRE(dy_head && w_head && (nout == 2 || nout == 4) && C % 8 == 0 && nrep >= 1, PHX_E_INVAL, "norm_bwd_apply_fused_head: bad arguments");
+    PHX_REQUIRE(dbias == nullptr || fwd_sums != nullptr, PHX_E_INVAL, "norm_bwd_apply_fused_head: dbias needs the forward sums");
+    int PL, threads, chunk, nchunks;
+    PHX_REQUIRE(stream_geometry(P, C, 8, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_bwd_apply_fused_head: C too large");
+#define NAH_LAUNCH(HNv)                                                                                                           \
+    hipLaunchKernelGGL((k_norm_bwd_apply_fused<bf16_t, bf16_t, bf16_t, 8, HNv>), dim3(nchunks, NS), dim3(threads),                 \
+                       (size_t)(7 * C + 2 * G) * sizeof(float), (hipStream_t)stream, (const bf16_t*)nullptr, (const bf16_t*)x, scale, shift, \
+                       mean, rstd, gamma, sums2, (bf16_t*)dx, dgamma, dbeta, P, C, G, PL, chunk, act, nrep, fwd_sums, fwd_pivot, dbias, \
+                       HeadBw{dy_head, w_head})
+    if (nout == 2) NAH_LAUNCH(2); else NAH_LAUNCH(4);
+#undef NAH_LAUNCH
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }
@@ -1587,7 +1749,7 @@ int phx_norm_bwd_reduce(const void* dA, int da_dt, const void* x, int x_dt, cons
         }
         hipLaunchKernelGGL((k_norm_bwd_reduce<TD, TX, V>), dim3(nchunks, NS), dim3(threads),
                            (size_t)(PL > 2 ? PL : 2) * C * 2 * sizeof(float), (hipStream_t)stream, (const TD*)dA, (const TX*)x, scale,
-                           shift, mean, rstd, sums2, P, C, G, PL, chunk, act, nrep);
+                           shift, mean, rstd, sums2, P, C, G, PL, chunk, act, nrep, HeadBw{nullptr, nullptr});
     })));
     PHX_CHECK_LAUNCH();
     return PHX_OK;

@@ -65,6 +65,7 @@ _STATS_REP = int(os.environ.get("PHX_STATS_REP", "1"))
 # the transform is ~7 VALU instructions per two elements INSIDE the convolution's staging phase (redone by every channel block of a
 # pixel tile and for the halo), where nothing overlaps it: 32 -> 32 @ 128 x 128 takes 75 us fused against 39 + 24 us (convolution +
 # apply pass at 5.5 TB/s), 128 -> 128 @ 128 x 128 0.64 ms against 0.31 + 0.09, 192 -> 192 @ 8 x 8 34 us against 15 + 9.
+_NORM_HEAD = os.environ.get("PHX_NORM_HEAD", "1") == "1"     # a 1x1 head that is the only reader of act(norm(conv)) rides on the apply pass; its data gradient is formed on the fly in the norm backward passes (A/B hook)
 _LATENT_FUSED = os.environ.get("PHX_LATENT_FUSED", "1") == "1"     # mu / sigma heads + reparameterisation of a level in one launch each way (A/B hook)
 
 
@@ -138,6 +139,15 @@ class Buf:
         torch.cuda.synchronize()
         a = self.t[:self.n].float().cpu().numpy() if self.dt != U8 else self.t[:self.n].cpu().numpy()
         return a.reshape(self.shape)
+
+
+class HeadGrad:
+    """Placeholder for the gradient of a = act(norm(y)) whose only reader is a 1x1 head: dA = dy_head w_head^T is never materialised,
+    the producer's norm backward launches form it on the fly (phx_norm_bwd_reduce_head / phx_norm_bwd_apply_fused_head)."""
+
+    def __init__(self, like, dy, w_ptr, nout):
+        self.shape, self.dt, self.n = like.shape, like.dt, like.n
+        self.dy, self.w_ptr, self.nout = dy, w_ptr, nout
 
 
 class ParamStore:
@@ -572,6 +582,7 @@ class Plan:
         self._bw_skip = set()
         self._bws = {}                # producer conv op -> (partials, tiles): BN-backward sums fused into the consumer's dgrad
         self._xf_pending = {}         # tensor a = act(norm(y)) whose apply pass was left to its (single) consumer convolution
+        self._norm_head = {}          # 1x1 head op -> the conv unit whose apply pass computed it (phx_norm_apply_fused_head)
         fork = self._record(0) if nl > 1 else None          # lanes 1.. join the capture / wait for the memsets
         for ln in range(1, nl):
             self._lane = ln
@@ -935,6 +946,23 @@ class Plan:
             else:
                 self._emit(Lb.head1x1_wgrad, x.ptr, x.dt, gy.ptr, st.grad_ptr(W), st.grad_ptr(b), npix, cin, zd, self.stream)
 
+    def _norm_head_consumer(self, op):
+        """The 1x1 head (bias, no norm, identity, fp32 out, 2 / 4 outputs) that is the ONLY reader of this unit's output, or None."""
+        if not _NORM_HEAD or self.act_dt != BF16:
+            return None
+        out = op.outputs[0]
+        if out in self.fetches:
+            return None
+        cons = self._real_consumers(out, self._opset)
+        if len(cons) != 1 or cons[0].type != "conv_unit" or cons[0] in self._lat:
+            return None
+        c, ca = cons[0], cons[0].attrs
+        if (ca.get("transposed") is not None or ca.get("general") is not None or ca["ksize"] != 1 or ca["norm"] is not None
+                or ca["b"] is None or ca["act"] != "identity" or c.inputs[0] is not out or c.outputs[0].kind != G.KIND_F32
+                or c.outputs[0] in self.fetches or self.op_lane.get(c) != self.op_lane.get(op)):
+            return None
+        return c
+
     def _xf_consumer(self, op):
         """The convolution unit that can take over the normalisation + activation of `op` (fused edge), or None: the ONLY reader of
         a = act(norm(conv(x))) is a 3x3 convolution on the bf16 MFMA path with a multiple of 32 input channels."""
@@ -959,6 +987,12 @@ class Plan:
         a = op.attrs
         if a.get("transposed") is not None or a.get("general") is not None:
             return self._fw_tconv_unit(op, bw)
+        if op in self._norm_head:                # its forward ran inside the producer's apply pass
+            x = self.val[op.inputs[0]]
+            W = a["W"]
+            self.saved[op] = dict(x=x, out=self.val[op.outputs[0]], mfma=False, norm=None, padded=False, cin_eff=W.shape[-2], k1=False,
+                                  head1x1=True, norm_head=True)
+            return
         rec = self._lat.get(op)
         if rec is not None:                      # a latent head: its arithmetic runs in the group's one launch
             self.val[op.outputs[0]] = self._alloc_like(op.outputs[0])
@@ -1177,7 +1211,17 @@ class Plan:
                                                        mean=mean, rstd=rstd, scale=scale, shift=shift, mm=mmp, mv=mvp, mom=mom,
                                                        apply_args=apply_args)
             else:
-                self._emit(Lb.norm_apply_fused_rep, *apply_args, S, tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
+                hop = self._norm_head_consumer(op) if (y.dt == BF16 and out.dt == BF16) else None
+                if hop is not None and Lb.norm_head_supported(cout, hop.attrs["W"].shape[-1], y.dt, out.dt):
+                    # the head rides on the apply pass (phx_norm_apply_fused_head): no pass of its own over a
+                    hW, hb = hop.attrs["W"], hop.attrs["b"]
+                    yh = self._alloc_like(hop.outputs[0])
+                    self.val[hop.outputs[0]] = yh
+                    self._emit(Lb.norm_apply_fused_head, *apply_args, self.store.ptr(hW), self.store.ptr(hb), hW.shape[-1], yh.ptr, S,
+                               tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
+                    self._norm_head[hop] = op
+                else:
+                    self._emit(Lb.norm_apply_fused_rep, *apply_args, S, tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
         st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn)
         if norm != "batch":
             st.update(fsums=sums, fpivot=pivot)          # forward per-channel sums: the bias gradient is closed-form from them
@@ -1667,8 +1711,13 @@ class Plan:
                 sums2 = self._alloc_zeroed(nrep * NS * cout * 2)
                 Sg = self._alloc((NS * Gn * 2,), F32)
                 dY = self._alloc(y.shape, y.dt)
+                hg = dA if isinstance(dA, HeadGrad) else None
                 if fused is not None:
                     self._emit(Lb.norm_reduce_partials, fused[0].ptr, fused[1], cout, sums2.ptr, S)
+                elif hg is not None:
+                    self._emit(Lb.norm_bwd_reduce_head, hg.dy.ptr, hg.w_ptr, hg.nout, y.ptr, sv["scale"].ptr, sv["shift"].ptr,
+                               sv["mean"].ptr, sv["rstd"].ptr, sums2.ptr, NS, P, cout, Gn, act, nrep, S,
+                               tag="bytes_norm_bwd_reduce", flops=float(y.nbytes))
                 else:
                     self._emit(Lb.norm_bwd_reduce, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
                                sv["mean"].ptr, sv["rstd"].ptr, sums2.ptr, NS, P, cout, Gn, act, nrep, S,
@@ -1678,13 +1727,22 @@ class Plan:
                 fs = sv.get("fsums") if (b is not None and _BIAS_GRAD_FUSED) else None
                 if fs is not None:
                     db_done = True
-                self._emit(Lb.norm_bwd_apply_fused_bias, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
-                           sv["mean"].ptr, sv["rstd"].ptr, self.store.ptr(nv["gamma"]), sums2.ptr, dY.ptr, dY.dt,
-                           self.store.grad_ptr(nv["gamma"]), self.store.grad_ptr(nv["beta"]),
-                           fs.ptr if fs is not None else None,
-                           sv["fpivot"].ptr if (fs is not None and sv.get("fpivot") is not None) else None,
-                           self.store.grad_ptr(b) if fs is not None else None, NS, P, cout, Gn, act, nrep, S,
-                           tag="bytes_norm_bwd_apply", flops=float(dA.nbytes + y.nbytes + dY.nbytes))
+                if hg is not None:
+                    self._emit(Lb.norm_bwd_apply_fused_head, hg.dy.ptr, hg.w_ptr, hg.nout, y.ptr, sv["scale"].ptr, sv["shift"].ptr,
+                               sv["mean"].ptr, sv["rstd"].ptr, self.store.ptr(nv["gamma"]), sums2.ptr, dY.ptr,
+                               self.store.grad_ptr(nv["gamma"]), self.store.grad_ptr(nv["beta"]),
+                               fs.ptr if fs is not None else None,
+                               sv["fpivot"].ptr if (fs is not None and sv.get("fpivot") is not None) else None,
+                               self.store.grad_ptr(b) if fs is not None else None, NS, P, cout, Gn, act, nrep, S,
+                               tag="bytes_norm_bwd_apply", flops=float(y.nbytes + dY.nbytes))
+                else:
+                    self._emit(Lb.norm_bwd_apply_fused_bias, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr,
+                               sv["mean"].ptr, sv["rstd"].ptr, self.store.ptr(nv["gamma"]), sums2.ptr, dY.ptr, dY.dt,
+                               self.store.grad_ptr(nv["gamma"]), self.store.grad_ptr(nv["beta"]),
+                               fs.ptr if fs is not None else None,
+                               sv["fpivot"].ptr if (fs is not None and sv.get("fpivot") is not None) else None,
+                               self.store.grad_ptr(b) if fs is not None else None, NS, P, cout, Gn, act, nrep, S,
+                               tag="bytes_norm_bwd_apply", flops=float(dA.nbytes + y.nbytes + dY.nbytes))
         elif act != rt.ACT_ID:
             dY = self._alloc(out.shape, dA.dt)
             self._emit(Lb.act_bwd, dA.ptr, dA.dt, out.ptr, out.dt, dY.ptr, dY.dt, dA.n, act, S)
@@ -1776,7 +1834,9 @@ class Plan:
             self._emit(Lb.conv2d_direct_wgrad, x.ptr, x.dt, dY.ptr, dY.dt, dw, db, B, H, Wd, cin, cout, k, S)
         xin = op.inputs[0]
         if self.req.get(xin, False):
-            if sv.get("head1x1"):
+            if sv.get("norm_head"):              # no data-gradient launch: the producer's norm backward forms dA = dY W^T itself
+                self._add_grad(xin, buf=HeadGrad(self.val[xin], dY, self.store.ptr(W), cout))
+            elif sv.get("head1x1"):
                 self._add_grad(xin, write_fn=lambda g: self._emit(
                     Lb.head1x1_dgrad, dY.ptr, self.store.ptr(W), g.ptr, g.dt, B * H * Wd, cin, cout, S))
             elif sv.get("padded"):

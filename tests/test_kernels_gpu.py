@@ -1171,3 +1171,62 @@ def test_conv3x3_mfma_replicated_atomic_statistics(L, case, monkeypatch):
     close(outs[0][1], outs[1][1], 1e-6, "mean")
     close(outs[0][2], outs[1][2], 1e-6, "rstd")
     close(outs[0][0], outs[1][0], 2 ** -7, "a")
+
+
+@pytest.mark.parametrize("case", [("batch", 2, 16, 16, 128, 2), ("batch", 3, 8, 24, 32, 4), ("group", 2, 16, 16, 64, 2)])
+def test_norm_layer_with_fused_head(L, case):
+    """phx_norm_apply_fused_head / phx_norm_bwd_reduce_head / phx_norm_bwd_apply_fused_head: a 1x1 head that is the only reader of
+    a = relu(norm(y)) (the likelihood's top layer feeding y_lvl0, likelihoods.py:220) computed inside the apply pass, and in the
+    backward pass dA = dy_head w_head^T formed on the fly -- against the separate launches they replace (phx_head1x1_fwd /
+    phx_head1x1_dgrad + the plain norm kernels), which are themselves checked against the oracle above."""
+    kind, B, H, W, C, NO = case
+    NS = 1 if kind == "batch" else B
+    G = C if kind == "batch" else 4
+    P = B * H * W if kind == "batch" else H * W
+    eps = 1e-3 if kind == "batch" else 1e-5
+    npix = B * H * W
+    y = dev(RNG.standard_normal((B, H, W, C)) * 1.5 + 0.3, BF16)
+    gamma, beta = dev(1.0 + 0.2 * RNG.standard_normal(C)), dev(0.3 * RNG.standard_normal(C))
+    wh, bh = dev(RNG.standard_normal((C, NO)) / np.sqrt(C)), dev(RNG.standard_normal(NO) * 0.2)
+    yf = y.float()
+    red = (0, 1, 2) if kind == "batch" else (1, 2)
+    sums = torch.stack([yf.sum(dim=red), (yf * yf).sum(dim=red)], dim=-1).reshape(NS, C, 2).contiguous()
+    assert L.norm_head_supported(C, NO, BF16, BF16) == 1 and L.norm_head_supported(192, 2, BF16, BF16) == 0
+
+    def bufs():
+        return (torch.empty(B, H, W, C, dtype=torch.bfloat16).cuda(), torch.empty(NS * G).cuda(), torch.empty(NS * G).cuda(),
+                torch.empty(NS * C).cuda(), torch.empty(NS * C).cuda())
+    a1, mean, rstd, scale, shift = bufs()
+    L.norm_apply_fused_rep(y.data_ptr(), BF16, sums.data_ptr(), 1, None, gamma.data_ptr(), beta.data_ptr(), eps, a1.data_ptr(), BF16,
+                           mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, None, 0.0, NS, P, C, G, 1, S())
+    yh1 = torch.empty(npix, NO, dtype=torch.float32).cuda()
+    L.head1x1_fwd(a1.data_ptr(), BF16, wh.data_ptr(), bh.data_ptr(), yh1.data_ptr(), npix, C, NO, 0, S())
+    a2, mean2, rstd2, scale2, shift2 = bufs()
+    yh2 = torch.empty(npix, NO, dtype=torch.float32).cuda()
+    L.norm_apply_fused_head(y.data_ptr(), BF16, sums.data_ptr(), 1, None, gamma.data_ptr(), beta.data_ptr(), eps, a2.data_ptr(), BF16,
+                            mean2.data_ptr(), rstd2.data_ptr(), scale2.data_ptr(), shift2.data_ptr(), None, None, 0.0, NS, P, C, G, 1,
+                            wh.data_ptr(), bh.data_ptr(), NO, yh2.data_ptr(), S())
+    assert torch.equal(a1, a2) and torch.equal(scale, scale2)
+    close(host(yh2), host(yh1), 2e-6, "head output")
+    # backward
+    dyh = dev(RNG.standard_normal((npix, NO)))
+    dA = torch.empty(B, H, W, C, dtype=torch.bfloat16).cuda()
+    L.head1x1_dgrad(dyh.data_ptr(), wh.data_ptr(), dA.data_ptr(), BF16, npix, C, NO, S())
+    nrep = 3
+    s_ref = torch.zeros(nrep, NS, C, 2).cuda()
+    L.norm_bwd_reduce(dA.data_ptr(), BF16, y.data_ptr(), BF16, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                      s_ref.data_ptr(), NS, P, C, G, 1, nrep, S())
+    s_new = torch.zeros(nrep, NS, C, 2).cuda()
+    L.norm_bwd_reduce_head(dyh.data_ptr(), wh.data_ptr(), NO, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                           rstd.data_ptr(), s_new.data_ptr(), NS, P, C, G, 1, nrep, S())
+    close(host(s_new).sum(0), host(s_ref).sum(0), 1e-5, "backward sums")
+    dx1, dx2 = torch.empty_like(dA), torch.empty_like(dA)
+    dg1, db1, dg2, db2 = (torch.zeros(C).cuda() for _ in range(4))
+    L.norm_bwd_apply_fused_bias(dA.data_ptr(), BF16, y.data_ptr(), BF16, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                rstd.data_ptr(), gamma.data_ptr(), s_ref.data_ptr(), dx1.data_ptr(), BF16, dg1.data_ptr(), db1.data_ptr(),
+                                None, None, None, NS, P, C, G, 1, nrep, S())
+    L.norm_bwd_apply_fused_head(dyh.data_ptr(), wh.data_ptr(), NO, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                rstd.data_ptr(), gamma.data_ptr(), s_ref.data_ptr(), dx2.data_ptr(), dg2.data_ptr(), db2.data_ptr(),
+                                None, None, None, NS, P, C, G, 1, nrep, S())
+    assert torch.equal(dx1, dx2)
+    close(host(dg2), host(dg1), 1e-6, "dgamma")
