@@ -265,10 +265,10 @@ def main():
         rows_all, rows, fam, fl, ms, nl = conv_family(plan)
         if args.profile_table:
             hb = {}
-            for tag, by, ms, shp in rows_all:
+            for tag, by, ms_, shp in rows_all:
                 if tag.startswith("bytes_"):
                     a = hb.setdefault((tag, by >= 64e6), [0.0, 0.0, 0])
-                    a[0] += by; a[1] += ms; a[2] += 1
+                    a[0] += by; a[1] += ms_; a[2] += 1
             for key in sorted(hb):
                 a = hb[key]
                 print("### %-24s %-8s launches=%3d %8.3f ms  %8.1f GB/s" % (key[0], ">=64MB" if key[1] else "<64MB", a[2], a[1], a[0] / a[1] / 1e6),
@@ -277,10 +277,10 @@ def main():
             for tag, fl_, ms_, shp in sorted(rows, key=lambda r: -r[2]):
                 print("# %-20s %8.3f ms %8.1f TFLOP/s  %s" % (tag, ms_, fl_ / ms_ / 1e9, shp[-5:]), file=sys.stderr)
             byh = {}
-            for tag, fl, ms, shp in rows:
+            for tag, fl_, ms_, shp in rows:
                 key = (tag, shp[-4])                      # launch arguments end (..., B, H, W, Cin|K, Cout|N)
                 a = byh.setdefault(key, [0.0, 0.0, 0])
-                a[0] += fl; a[1] += ms; a[2] += 1
+                a[0] += fl_; a[1] += ms_; a[2] += 1
             for key in sorted(byh):
                 a = byh[key]
                 print("## %-20s H=%-4d launches=%3d  %8.3f ms  %8.1f TFLOP/s" % (key[0], key[1], a[2], a[1], a[0] / a[1] / 1e9),

@@ -7,11 +7,11 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
 mkdir -p $O
 cd $R
-python bench.py --steps 20 --warmup 5 --profile-table > $O/bench.json 2> $O/bench_table.txt
+[ -n "$SKIP_BENCH" ] || python bench.py --steps 20 --warmup 5 --profile-table > $O/bench.json 2> $O/bench_table.txt
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/stats -- python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-roofline > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats -- python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-roofline --no-other-workloads > $O/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc/$c -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-roofline > $O/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc/$c -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-roofline --no-other-workloads > $O/pmc_$c.log 2>&1
   f=$(find $O/pmc/$c -name "*counter_collection.csv" | head -1)
   cp "$f" $O/pmc/$c/p_counter_collection.csv
 done
@@ -21,7 +21,7 @@ python tools/prof_summary.py $db 11 > $O/kernel_stats.txt
 python tools/pmc_summary.py $O/pmc 4 $O/pmc_hbm_traffic.txt $O/pmc_hbm_traffic.json > /dev/null
 # MFMA / LDS utilisation of the convolution kernels (one more PMC pass, kernel trace only)
 cd /tmp
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc/MFMA -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-roofline > $O/pmc_MFMA.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc/MFMA -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-roofline --no-other-workloads > $O/pmc_MFMA.log 2>&1
 cd $R
 f=$(find $O/pmc/MFMA -name "*counter_collection.csv" | head -1)
 python tools/pmc_mfma_summary.py "$f" 4 $O/pmc_mfma_lds_util.txt > /dev/null 2>&1 || true
