@@ -111,6 +111,18 @@ int phx_conv3x3_mfma_bf16_stats_atomic(const void* x, const void* wpk, void* y, 
 int phx_conv3x3_mfma_stats_rep_supported(int B, int H, int W, int K, int N);
 int phx_conv3x3_mfma_bf16_stats_rep(const void* x, const void* wpk, void* y, const float* bias, int act, float* sums, int nrep, int B,
                                     int H, int W, int K, int N, void* stream);
+/* Convolution + batch norm (training mode) + activation in ONE launch on small maps (tfwrapper/layers.py:123-135 +
+ * normalisation.py:17-36; replaces conv [+ split-K finish] + statistics + apply): the blocks add their tiles' {sum y, sum y^2} to
+ * sums[N][2] (zero at launch) with returning device-scope atomics, meet at counters[N / 32] (unsigned, zero at launch), read the sums
+ * back and write both y (pre-normalisation, bf16: the backward pass reads it) and a_out = act(y * scale + shift); one block per
+ * channel block publishes mean / rstd / scale / shift [N] and applies the TF1 moving update (momentum = 1 - decay; 0: none).
+ * phx_conv3x3_fbn_supported -> 0 when the launch would have more than PHX_FBN_MAXBLOCKS (192) blocks (all of them must be resident
+ * at once) or in deterministic mode, else the channels per block. */
+int phx_conv3x3_fbn_supported(int B, int H, int W, int K, int N);
+int phx_conv3x3_mfma_bf16_fbn(const void* x, const void* wpk, void* y, void* a_out, float* sums, void* counters, const float* gamma,
+                              const float* beta, float eps, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
+                              float* moving_mean, float* moving_var, float momentum, int act, int B, int H, int W, int K, int N,
+                              void* stream);
 /* Convolution with an AFFINE epilogue: y = act(conv(x) * scale[n] + shift[n]) -- inference-mode batch norm
  * (normalisation.py:145-163 with is_training = False: y = gamma (x - moving_mean) / sqrt(moving_var + eps) + beta) and its
  * activation folded into the convolution that feeds it: one launch where the reference runs conv2d, batch_norm and relu.

@@ -264,6 +264,7 @@ struct XForm {
     float *mean_out, *rstd_out, *scale_out, *shift_out;     // [NS][G], [NS][K]
     float *moving_mean, *moving_var;                        // batch norm in training mode, else NULL
     float momentum;
+    unsigned* counter;        // FBN: [N / BN] arrival counters (zero at launch), one per output-channel block
 };
 constexpr int XF_TBL_BYTES = 4096;      // LDS scale / shift table in front of the stages: K <= 512 channels x 2 floats
 
@@ -275,7 +276,13 @@ constexpr int XF_TBL_BYTES = 4096;      // LDS scale / shift table in front of t
 // SPLITK (small maps: a handful of pixel tiles cannot fill 256 CUs and each block would walk all K / 32 chunks serially,
 // ~2 us apiece): gridDim.z blocks share a tile, each takes a run of chunks and stores its fp32 accumulators to
 // ws[z][pixel][N]; k_splitk_finish sums the slices, adds bias / activation and writes the bf16 tensor.
-template <int BN, int NA, bool FAST16, bool BIASACT, int NW, bool SPLITK, bool XF = false>
+// FBN (small maps, batch norm in training mode; tfwrapper/layers.py:123-135 + normalisation.py:17-36 in ONE launch): the epilogue adds
+// the tile's {sum y, sum y^2} to sums[N][2] with RETURNING device-scope atomics, the blocks of one output-channel block meet at an
+// arrival counter (every block of the launch is resident: the launcher bounds the grid), read the finished sums back, and write
+// a = act(y * scale + shift) from the accumulators they still hold -- no statistics / split-K-finish / apply launches, and nothing
+// but atomics crosses the XCDs' L2s (a bulk hand-off would need an L2 write-back: 38 us).  xf carries the
+// normalisation's arguments (sums, gamma, beta, eps, invP, act, a_out, the published vectors, the moving statistics, counter).
+template <int BN, int NA, bool FAST16, bool BIASACT, int NW, bool SPLITK, bool XF = false, bool FBN = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const unsigned short* __restrict__ x,
                                                          const unsigned short* __restrict__ wpk,
                                                          unsigned short* __restrict__ y, const float* __restrict__ bias,
@@ -736,8 +743,77 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
                 float v = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) v += red[(w * 2 + which) * BN + n];
-                if (bws.stats_atomic) atomicAdd(&stats_partial[((size_t)(bws.stats_nrep > 1 ? tile_id % bws.stats_nrep : 0) * N + n0 + n) * 2 + which], v);
+                if constexpr (FBN) {
+                    // returning form: the value comes back from the coherence point, i.e. the add has been performed when it arrives
+                    const float old = atomicAdd(&stats_partial[((size_t)n0 + n) * 2 + which], v);
+                    asm volatile("" ::"v"(old));
+                } else if (bws.stats_atomic) atomicAdd(&stats_partial[((size_t)(bws.stats_nrep > 1 ? tile_id % bws.stats_nrep : 0) * N + n0 + n) * 2 + which], v);
                 else stats_partial[((size_t)tile_id * 2 + which) * N + n0 + n] = v;
+            }
+        }
+        if constexpr (FBN) {
+            const int ntl = g.tiles_x * g.tiles_y * g.tiles_b;
+            __syncthreads();                             // every thread has its atomics' return values: this block's sums are in
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_add(xf.counter + cob, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int spins = 0;                           // (bounded: a launch that cannot be co-resident must not hang the GPU)
+                while (__hip_atomic_load(xf.counter + cob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ntl && ++spins < (1 << 24))
+                    __builtin_amdgcn_s_sleep(2);
+            }
+            __syncthreads();
+            float sc[NJ], sh[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int c = n0 + j * 32 + l31;
+                const float t1 = __hip_atomic_load(&stats_partial[(size_t)c * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float t2 = __hip_atomic_load(&stats_partial[(size_t)c * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float mu = t1 * xf.invP;
+                float var = t2 * xf.invP - mu * mu;
+                var = var > 0.f ? var : 0.f;
+                const float rs = rsqrtf(var + xf.eps);
+                sc[j] = xf.gamma[c] * rs;
+                sh[j] = xf.beta[c] - mu * sc[j];
+                if (tile_id == 0 && wave == 0 && khalf == 0) {        // one block per channel block publishes (backward pass, moving update)
+                    xf.mean_out[c] = mu; xf.rstd_out[c] = rs; xf.scale_out[c] = sc[j]; xf.shift_out[c] = sh[j];
+                    if (xf.momentum > 0.f && xf.moving_mean) {        // TF1 fused-batch-norm moving update (unbiased variance)
+                        const float m = 1.f / xf.invP;
+                        xf.moving_mean[c] -= (xf.moving_mean[c] - mu) * xf.momentum;
+                        xf.moving_var[c] -= (xf.moving_var[c] - var * (m / fmaxf(m - 1.f, 1.f))) * xf.momentum;
+                    }
+                }
+            }
+            // second pass over the accumulators: a = act(bf16(y) * scale + shift), transposed through LDS like y (masked path)
+            const int wave_o = threadIdx.x >> 6, l31_o = threadIdx.x & 31, khalf_o = (threadIdx.x >> 5) & 1, odd_o = threadIdx.x & 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {
+                    const int r0 = 2 * rp;
+                    const int m0 = wave_o * 64 + i * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * khalf_o;
+                    const int mrow = odd_o ? m0 + 1 : m0;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const unsigned w2 = f2bf_pk(acc[i][j][r0], acc[i][j][r0 + 1]);       // the y values as stored
+                        float lo = fmaf(__uint_as_float(w2 << 16), sc[j], sh[j]);
+                        float hi = fmaf(__uint_as_float(w2 & 0xffff0000u), sc[j], sh[j]);
+                        if (xf.act == PHX_ACT_RELU) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                        else if (xf.act != PHX_ACT_ID) { lo = act_fwd(lo, xf.act); hi = act_fwd(hi, xf.act); }
+                        const unsigned w3 = f2bf_pk(lo, hi);
+                        const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)w3, 0xB1, 0xf, 0xf, true);
+                        *reinterpret_cast<unsigned*>(smem + mrow * OROW + (j * 32 + (l31_o & ~1)) * 2) =
+                            odd_o ? ((nb >> 16) | (w3 & 0xffff0000u)) : ((w3 & 0xffffu) | (nb << 16));
+                    }
+                }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < PPP; ++it) {
+                const int i = threadIdx.x + it * NT;
+                const int m = i / PPP, q = i % PPP;
+                const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
+                const int ox = cx0 + lx, oy = cy0 + ly, ob = cb0 + lb;
+                if (ox < W && oy < H && ob < B)
+                    *reinterpret_cast<uint4*>(xf.a_out + (((size_t)ob * H + oy) * W + ox) * N + n0 + q * 8) =
+                        *reinterpret_cast<const uint4*>(smem + m * OROW + q * 16);
             }
         }
     }
@@ -1730,6 +1806,63 @@ int phx_conv3x3_mfma_bf16_stats_rep(const void* x, const void* wpk, void* y, con
 }
 int phx_conv3x3_mfma_stats_rep_supported(int B, int H, int W, int K, int N) {
     return (!phx_deterministic() && K % KC == 0 && N % 32 == 0) ? 1 : 0;
+}
+
+// ---- conv + batch norm (training mode) + activation in one launch on small maps (FBN instantiations of k_conv3x3_mfma) --------
+// Every block of the launch has to be resident at once (they meet at an arrival counter): at most PHX_FBN_MAXBLOCKS (192) blocks, so
+// that the launches of two lanes fit the 512 block slots of the chip side by side.  -> 32 / 64 (channels per block), 0: not supported.
+static int fbn_plan(int B, int H, int W, int K, int N) {
+    if (phx_deterministic() || K % KC != 0 || N % 32 != 0) return 0;
+    if ((double)B * H * W >= 16777216.0) return 0;
+    static int maxb = -1;
+    if (maxb < 0) { const char* e = getenv("PHX_FBN_MAXBLOCKS"); maxb = e ? atoi(e) : 192; }
+    MTile g = make_mtile(B, H, W);
+    const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
+    if (ntiles * (N / 32) <= maxb) return 32;
+    if (N % 64 == 0 && ntiles * (N / 64) <= maxb) return 64;
+    return 0;
+}
+int phx_conv3x3_fbn_supported(int B, int H, int W, int K, int N) { return fbn_plan(B, H, W, K, N); }
+int phx_conv3x3_mfma_bf16_fbn(const void* x, const void* wpk, void* y, void* a_out, float* sums, void* counters, const float* gamma,
+                              const float* beta, float eps, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
+                              float* moving_mean, float* moving_var, float momentum, int act, int B, int H, int W, int K, int N,
+                              void* stream) {
+    const int bn = fbn_plan(B, H, W, K, N);
+    PHX_REQUIRE(bn != 0, PHX_E_SHAPE, "conv3x3_mfma_fbn: shape not supported (see phx_conv3x3_fbn_supported)");
+    PHX_REQUIRE(x && wpk && y && a_out && sums && counters && gamma && beta && mean_out && rstd_out && scale_out && shift_out, PHX_E_INVAL,
+                "conv3x3_mfma_fbn: null argument");
+    PHX_REQUIRE((((uintptr_t)x | (uintptr_t)wpk | (uintptr_t)y | (uintptr_t)a_out) & 15) == 0, PHX_E_ALIGN, "conv3x3_mfma_fbn: 16-byte alignment");
+    MTile g = make_mtile(B, H, W);
+    const int tw = 1 << g.tws, th = 1 << g.ths;
+    const int npatch = g.tb * (th + 2) * (tw + 2);
+    const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
+    const int na = (npatch * 4 + 255) / 256;
+    PHX_REQUIRE(na <= 16, PHX_E_SHAPE, "conv3x3_mfma_fbn: unexpected tile geometry");
+    const bool fast16 = g.tws == 4 && g.ths == 4 && g.tb == 1;
+    BwdStats b{};
+    b.stats_atomic = 1;
+    XForm xf{};
+    xf.gamma = gamma; xf.beta = beta; xf.eps = eps; xf.invP = 1.f / ((float)B * H * W); xf.act = act;
+    xf.a_out = (unsigned short*)a_out; xf.mean_out = mean_out; xf.rstd_out = rstd_out; xf.scale_out = scale_out; xf.shift_out = shift_out;
+    xf.moving_mean = moving_mean; xf.moving_var = moving_var; xf.momentum = momentum; xf.counter = (unsigned*)counters;
+#define FBN_LAUNCH(BNv, NAv, Fv)                                                                                        \
+    do {                                                                                                                \
+        auto kfn = k_conv3x3_mfma<BNv, NAv, Fv, false, 4, false, false, true>;                                          \
+        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));   \
+        size_t sh = (Fv ? (size_t)(4 * 4 + 2) * PITCH16 : (size_t)npatch * ROWB) + 9 * BNv * ROWB;                      \
+        const size_t she = (size_t)256 * (BNv * 2 + 16);                                                                \
+        if (she > sh) sh = she;                                                                                         \
+        hipLaunchKernelGGL(kfn, dim3(ntiles * (N / BNv)), dim3(256), sh, (hipStream_t)stream, (const unsigned short*)x, \
+                           (const unsigned short*)wpk, (unsigned short*)y, nullptr, 0, sums, B, H, W, K, N, g, nullptr, b, xf); \
+    } while (0)
+    if (bn == 64) {
+        if (fast16) FBN_LAUNCH(64, 8, true); else if (na <= 8) FBN_LAUNCH(64, 8, false); else FBN_LAUNCH(64, 16, false);
+    } else {
+        if (fast16) FBN_LAUNCH(32, 8, true); else if (na <= 8) FBN_LAUNCH(32, 8, false); else FBN_LAUNCH(32, 16, false);
+    }
+#undef FBN_LAUNCH
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
 }
 
 int phx_conv3x3_mfma_bf16_affine(const void* x, const void* wpk, void* y, const float* scale, const float* shift, int act,

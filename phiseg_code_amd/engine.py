@@ -33,6 +33,10 @@ _KL_SIDE = os.environ.get("PHX_KL_SIDE", "0") == "1"                     # two l
 _PRIOR_BW_FIRST = os.environ.get("PHX_PRIOR_BW_FIRST", "0") == "1"       # prior backward emitted before the likelihood's (A/B hook)
 _DEFER_LANE2 = os.environ.get("PHX_DEFER_LANE2", "0") == "1"             # likelihood's deferred launches on a third stream (A/B hook)
 _DEFER_EARLY = os.environ.get("PHX_DEFER_EARLY", "0") == "1"             # deferred launches of likelihood + prior on lane 1 beside the posterior backward (A/B hook)
+# deferred filter-gradient launches that run BESIDE a latency-bound chain (PHX_DEFER_LANE2 / PHX_DEFER_EARLY) request at least this
+# much dynamic LDS, so that only one of their (long-running, persistent) blocks fits a CU and the chain's small launches always
+# find free wave slots and LDS ("polite" occupancy); 0: as the kernels need
+_POLITE_LDS = int(os.environ.get("PHX_POLITE_LDS", "0"))
 _LIK_COARSE_FIRST = os.environ.get("PHX_LIK_COARSE_FIRST", "1") == "1"   # emission order of the likelihood's per-level chains
 # two lanes: likelihood chains of levels <= this go to the prior's lane; the coarsest chain stays on lane 0, in front of the top-down
 # path that starts with it: lane 0 then enters the likelihood without waiting for lane 1 (with all five chains there it started only
@@ -66,6 +70,9 @@ _STATS_REP = int(os.environ.get("PHX_STATS_REP", "1"))
 # pixel tile and for the halo), where nothing overlaps it: 32 -> 32 @ 128 x 128 takes 75 us fused against 39 + 24 us (convolution +
 # apply pass at 5.5 TB/s), 128 -> 128 @ 128 x 128 0.64 ms against 0.31 + 0.09, 192 -> 192 @ 8 x 8 34 us against 15 + 9.
 _NORM_HEAD = os.environ.get("PHX_NORM_HEAD", "1") == "1"     # a 1x1 head that is the only reader of act(norm(conv)) rides on the apply pass; its data gradient is formed on the fly in the norm backward passes (A/B hook)
+# small maps, batch norm in training mode: convolution + statistics + normalisation + activation in ONE launch (phx_conv3x3_mfma_bf16_fbn:
+# the blocks meet at an arrival counter inside the launch) for layers of up to PHX_FBN_MAXP pixels (B * H * W); 0: off (A/B hook)
+_FBN_MAXP = int(os.environ.get("PHX_FBN_MAXP", "4096"))
 _LATENT_FUSED = os.environ.get("PHX_LATENT_FUSED", "1") == "1"     # mu / sigma heads + reparameterisation of a level in one launch each way (A/B hook)
 
 
@@ -377,14 +384,14 @@ class Plan:
             self._emit(self.L.stamp, self._stamp_buf.data_ptr() + 8 * (self._stamp_i + 1), self.stream)
             self.stamps.append((phase, op.name, self._lane, self._stamp_i))
 
-    def _emit_deferred(self):
+    def _emit_deferred(self, polite=False):
         """Launch everything the backward pass has deferred so far (filter gradients of the small / mid-size maps, the sums
         over partial filters, padded-filter folds, head filter gradients) on the current lane, and clear the lists."""
         for variant, grp in sorted(self._wgm_jobs.items()):
             desc = torch.frombuffer(bytearray(b"".join(grp["recs"])), dtype=torch.uint8).to(_device())
             self._keep.append(desc)
-            self._emit(self.L.conv3x3_wgrad_multi, desc.data_ptr(), len(grp["recs"]), grp["blocks"], variant, grp["lds"],
-                       self.stream)
+            self._emit(self.L.conv3x3_wgrad_multi, desc.data_ptr(), len(grp["recs"]), grp["blocks"], variant,
+                       max(grp["lds"], _POLITE_LDS) if polite else grp["lds"], self.stream)
         if self._wgr_jobs:
             rec = np.zeros(len(self._wgr_jobs), dtype=[("ws", "<u8"), ("dw", "<u8"), ("nslice", "<i4"), ("cin", "<i4"), ("cout", "<i4"),
                                                        ("tci", "<i4"), ("tco", "<i4"), ("gx", "<i4"), ("gy", "<i4"), ("blk0", "<i4")])
@@ -646,7 +653,7 @@ class Plan:
                     ev0 = self._record(0)
                     self._lane = 2
                     self._wait(ev0)
-                    self._emit_deferred()
+                    self._emit_deferred(polite=True)
                 if not flushed and op.name.startswith("posterior/"):
                     # everything the likelihood and the prior have deferred goes to lane 1 now, beside the posterior's
                     # latency-bound backward chain on lane 0 (their inputs are complete once lane 0 has reached this point)
@@ -654,7 +661,7 @@ class Plan:
                     ev0 = self._record(0)
                     self._lane = 1
                     self._wait(ev0)
-                    self._emit_deferred()
+                    self._emit_deferred(polite=True)
                 if op in self._bw_skip:
                     continue                              # (its backward ran inside a fused group's launch)
                 if any(o in self.grad for o in op.outputs) or op.type in ("residual_ce", "kl", "l2_weights"):
@@ -1113,6 +1120,20 @@ class Plan:
             conv_into(y, 0)
             self._emit(Lb.affine_act, y.ptr, y.dt, scale.ptr, shift.ptr, out.ptr, out.dt, NS, P, cout, act, S)
         else:
+            if (norm == "batch" and training and mfma and not head1x1 and not xf and P <= _FBN_MAXP and not _DETERMINISTIC
+                    and y.dt == BF16 and out.dt == BF16 and x.dt == BF16 and Lb.conv3x3_fbn_supported(B, H, Wd, cin_eff, cout)):
+                # small maps: convolution, batch statistics, normalisation and activation in one launch
+                upd = self.loss is not None
+                acc = self._alloc_zeroed(cout * 2 + (cout // 32 + 3) // 4 * 4)        # sums[N][2] | arrival counters
+                self._emit(Lb.conv3x3_mfma_bf16_fbn, x.ptr, wf.ptr, y.ptr, out.ptr, acc.ptr, acc.ptr + cout * 8, gptr, beptr, eps,
+                           mean.ptr, rstd.ptr, scale.ptr, shift.ptr,
+                           self.store.ptr(nv["moving_mean"]) if upd else None, self.store.ptr(nv["moving_variance"]) if upd else None,
+                           (1.0 - tfnorm.BN_DECAY) if upd else 0.0, act, B, H, Wd, cin_eff, cout, S,
+                           tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
+                st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn,
+                          bn_small=bool(P <= _BN_SMALL and Lb.bn_small_supported(P, cout, BF16)))
+                self.saved[op] = st
+                return
             # H <= 8 levels: the whole batch-norm layer in one launch (phx_bn_small_fwd / _bwd; csrc/elementwise.hip)
             # (policy P <= 1024, the H <= 4 levels: at P = 4096 the single launch measured no faster than the chain)
             bn_small = (norm == "batch" and y.dt == BF16 and out.dt == BF16 and P <= _BN_SMALL

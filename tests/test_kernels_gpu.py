@@ -1230,3 +1230,56 @@ def test_norm_layer_with_fused_head(L, case):
                                 None, None, None, NS, P, C, G, 1, nrep, S())
     assert torch.equal(dx1, dx2)
     close(host(dg2), host(dg1), 1e-6, "dgamma")
+
+
+@pytest.mark.parametrize("case", [(64, 8, 8, 192, 192), (64, 4, 4, 256, 192), (64, 2, 2, 192, 192), (9, 4, 4, 64, 64), (3, 8, 8, 32, 96),
+                                  (12, 16, 16, 64, 64), (64, 2, 2, 32, 32)])
+@pytest.mark.parametrize("act", [1, 0])
+def test_conv3x3_fused_batch_norm_one_launch(L, case, act):
+    """phx_conv3x3_mfma_bf16_fbn (tfwrapper/layers.py:123-135 + normalisation.py:17-36 in one launch): y bit-equal to the plain
+    convolution, a / mean / rstd / scale / shift / moving statistics against the oracle's batch norm of that (bf16) y, and the
+    sums left in the accumulator."""
+    from oracle import tf1_ops as O
+    B, H, W, K, N = case
+    assert L.conv3x3_fbn_supported(B, H, W, K, N) in (32, 64)
+    assert L.conv3x3_fbn_supported(64, 128, 128, 32, 32) == 0          # thousands of blocks cannot meet inside a launch
+    x = RNG.standard_normal((B, H, W, K)) + 0.3
+    w = RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K)
+    gamma, beta = 1.0 + 0.2 * RNG.standard_normal(N), 0.3 * RNG.standard_normal(N)
+    mm0, mv0 = 0.1 * RNG.standard_normal(N), 1.0 + 0.1 * RNG.random(N)
+    xd, wd = dev(x, BF16), dev(w)
+    wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    wg = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    L.pack_conv3x3_bf16(wd.data_ptr(), wf.data_ptr(), wg.data_ptr(), K, N, S())
+    y0 = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
+    L.conv3x3_mfma_bf16_ws(xd.data_ptr(), wf.data_ptr(), y0.data_ptr(), None, 0, None, None, 0, B, H, W, K, N, S())
+    for rep in range(3):                                               # (relaunch: the rendezvous must not depend on timing)
+        y, a = torch.empty_like(y0), torch.empty_like(y0)
+        acc = torch.zeros(N * 2 + 64, dtype=torch.float32).cuda()
+        g_, b_ = dev(gamma), dev(beta)
+        mean, rstd, scale, shift = (torch.empty(N, dtype=torch.float32).cuda() for _ in range(4))
+        mm, mv = dev(mm0), dev(mv0)
+        L.conv3x3_mfma_bf16_fbn(xd.data_ptr(), wf.data_ptr(), y.data_ptr(), a.data_ptr(), acc.data_ptr(), acc.data_ptr() + N * 8,
+                                g_.data_ptr(), b_.data_ptr(), O.BN_EPS, mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                mm.data_ptr(), mv.data_ptr(), 0.01, act, B, H, W, K, N, S())
+        torch.cuda.synchronize()
+        assert torch.equal(y, y0)
+        yf = host(y).astype(np.float64)
+        P = B * H * W
+        eps = O.BN_EPS
+        a_ref, mu_t, varu_t = O.batch_norm_train(torch.as_tensor(yf), torch.as_tensor(gamma), torch.as_tensor(beta))
+        if act == 1:
+            a_ref = O.relu(a_ref)
+        mu, var = mu_t.numpy(), varu_t.numpy() * max(P - 1, 1) / P
+        close(host(mean), mu, 2e-5, "mean")
+        close(host(rstd), 1.0 / np.sqrt(var + eps), 2e-4, "rstd")
+        close(host(a), a_ref.numpy(), 1.2e-2, "a = act(bn(y))")               # bf16 output
+        close(host(scale), gamma / np.sqrt(var + eps), 2e-4, "scale")
+        close(host(shift), beta - mu * gamma / np.sqrt(var + eps), 5e-4, "shift")
+        close(host(mm), O.batch_norm_moving_update(torch.as_tensor(mm0), mu_t, 0.99).numpy(), 2e-5, "moving mean")
+        close(host(mv), O.batch_norm_moving_update(torch.as_tensor(mv0), varu_t, 0.99).numpy(), 2e-5, "moving variance")
+        got = host(acc)[:2 * N].reshape(N, 2)
+        close(got[:, 0], yf.reshape(P, N).sum(0), 2e-5, "sum y")
+        cnt = acc[2 * N:].view(torch.int32).cpu().numpy()
+        bn = L.conv3x3_fbn_supported(B, H, W, K, N)
+        assert (cnt[:N // bn] == cnt[0]).all() and cnt[0] >= 1 and (cnt[N // bn:] == 0).all()

@@ -1,0 +1,14 @@
+#!/bin/bash
+# GPU box: conv + batch norm + activation in one launch on small maps (PHX_FBN_MAXP: largest B*H*W fused; 0 = off)
+run() {
+  env "$@" python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-other-workloads 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('$*', round(d['value'],1), 'img/s', round(d['ms_per_step'],3), 'ms', d['config']['launches_per_step'], d['config']['final_loss'])"
+}
+run PHX_FBN_MAXP=0
+run PHX_FBN_MAXP=1024
+run PHX_FBN_MAXP=4096
+run PHX_FBN_MAXP=16384
+run PHX_FBN_MAXP=16384 PHX_FBN_MAXBLOCKS=256
+run PHX_FBN_MAXP=0
+run PHX_FBN_MAXP=4096
