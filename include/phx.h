@@ -111,6 +111,22 @@ int phx_conv3x3_mfma_bf16_stats_atomic(const void* x, const void* wpk, void* y, 
 int phx_conv3x3_mfma_stats_rep_supported(int B, int H, int W, int K, int N);
 int phx_conv3x3_mfma_bf16_stats_rep(const void* x, const void* wpk, void* y, const float* bias, int act, float* sums, int nrep, int B,
                                     int H, int W, int K, int N, void* stream);
+/* Concat-free convolution (the reference feeds tf.concat([a, b], axis=3) to a 3x3 conv2D: posteriors.py:87,120, priors.py:112,
+ * likelihoods.py:210).  One-shot modifiers of the NEXT forward / data-gradient launch made from the calling thread through any
+ * phx_conv3x3_mfma_bf16* entry point (not ..._xf / ..._bwdstats), consumed by it:
+ *   ..._next_dual_input : reduction channels [0, K1) are read from the launch's x (pixel stride K1), [K1, K) from x2 (stride K - K1)
+ *   ..._next_dual_output: output channels [0, N1) go to the launch's y (stride N1), [N1, N) to y2 (stride N - N1); plain outputs only
+ * The filter-gradient counterparts take the second tensor explicitly (K1 % 32 == 0; a block's input channels lie in one tensor, so
+ * K1 % 64 != 0 selects 32-channel tiles: use the ..._dual plan / workspace queries with the same K1). */
+int phx_conv3x3_next_dual_input(const void* x2, int K1);
+int phx_conv3x3_next_dual_output(void* y2, int N1);
+size_t phx_conv3x3_wgrad_ws_bytes_dual(int B, int H, int W, int Cin, int Cout, int K1);
+int phx_conv3x3_wgrad_reduce_plan_dual(int B, int H, int W, int Cin, int Cout, int K1, int* plan6);
+int phx_conv3x3_wgrad_multi_job_dual(const void* x, const void* x2, int K1, const void* dy, float* dw_hwio, void* workspace,
+                                     size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int blocks_target, int blk0,
+                                     void* job_out, int* info9);
+int phx_conv3x3_wgrad_mfma_bf16_dual(const void* x, const void* x2, int K1, const void* dy, float* dw_hwio, void* workspace,
+                                     size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int reduce, void* stream);
 /* Convolution + batch norm (training mode) + activation in ONE launch on small maps (tfwrapper/layers.py:123-135 +
  * normalisation.py:17-36; replaces conv [+ split-K finish] + statistics + apply): the blocks add their tiles' {sum y, sum y^2} to
  * sums[N][2] (zero at launch) with returning device-scope atomics, meet at counters[N / 32] (unsigned, zero at launch), read the sums

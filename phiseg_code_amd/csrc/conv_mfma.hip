@@ -266,6 +266,15 @@ struct XForm {
     float momentum;
     unsigned* counter;        // FBN: [N / BN] arrival counters (zero at launch), one per output-channel block
 };
+// Concat-free convolution (posteriors.py:87,120, priors.py:112, likelihoods.py:210 feed tf.concat([a, b], axis=3) to a 3x3 conv2D):
+// forward / filter gradient read the two tensors in place -- reduction channels [0, K1) from x (pixel stride K1), [K1, K) from x2
+// (pixel stride K - K1), K1 % 32 == 0 -- and the data gradient writes the two halves of d(concat) to two tensors: output channels
+// [0, N1) to y (stride N1), [N1, N) to y2 (stride N - N1), N1 % 8 == 0.  x2 / y2 == NULL: the ordinary single-tensor launch.
+struct Dual {
+    const unsigned short* x2;
+    unsigned short* y2;
+    int K1, N1;
+};
 constexpr int XF_TBL_BYTES = 4096;      // LDS scale / shift table in front of the stages: K <= 512 channels x 2 floats
 
 // NA = compile-time bound on the 16-byte input-patch pieces a thread stages per 32-channel chunk
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
                                                          const unsigned short* __restrict__ wpk,
                                                          unsigned short* __restrict__ y, const float* __restrict__ bias,
                                                          int act, float* __restrict__ stats_partial, int B, int H, int W,
-                                                         int K, int N, MTile g, float* __restrict__ ws, BwdStats bws, XForm xf) {
+                                                         int K, int N, MTile g, float* __restrict__ ws, BwdStats bws, XForm xf, Dual du) {
     constexpr int NJ = BN / 32;
     constexpr int NT = NW * 64;                            // threads; the tile has NT pixels
     constexpr int NB = (9 * BN * 4 + NT - 1) / NT;        // filter-slab pieces per thread
@@ -341,29 +350,31 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
     // branch-free and can be interleaved with the MFMAs of the running chunk.
     unsigned ga[NA];
     unsigned wmask = 0;                          // XF: pieces whose transformed value this thread also writes to a_out
+    auto make_plan = [&](const int Ks) {         // Ks: pixel stride (channels) of the tensor the patch is read from
 #pragma unroll
-    for (int it = 0; it < NA; ++it) {
-        const int i = threadIdx.x + it * NT;
-        const int q = i & 3, pp = i >> 2;
-        ga[it] = 0xffffffffu;
-        if (pp < npatch) {
-            // 16-wide tiles: the patch is 18 wide -> compile-time divisors (runtime division costs ~40 instructions)
-            int px, py, pb;
-            if constexpr (FAST16) { px = pp % 18; py = pp / 18; pb = 0; }
-            else patch_coords(g, pp, pw, ph, &px, &py, &pb);
-            const int gx = tx0 + px - 1, gy = ty0 + py - 1, gbi = b0 + pb;
-            const bool in = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && gbi < B;
-            unsigned off;
-            if constexpr (FAST16) off = (unsigned)((((gbi * H + gy) * W + gx) * K + q * 8) * 2);
-            else {                                             // small maps: B * H * W < 2^24 (checked by the launcher)
-                const unsigned pix = __umul24(__umul24((unsigned)gbi, (unsigned)H) + gy, (unsigned)W) + gx;
-                off = (__umul24(pix, (unsigned)K) + q * 8) * 2;
+        for (int it = 0; it < NA; ++it) {
+            const int i = threadIdx.x + it * NT;
+            const int q = i & 3, pp = i >> 2;
+            ga[it] = 0xffffffffu;
+            if (pp < npatch) {
+                // 16-wide tiles: the patch is 18 wide -> compile-time divisors (runtime division costs ~40 instructions)
+                int px, py, pb;
+                if constexpr (FAST16) { px = pp % 18; py = pp / 18; pb = 0; }
+                else patch_coords(g, pp, pw, ph, &px, &py, &pb);
+                const int gx = tx0 + px - 1, gy = ty0 + py - 1, gbi = b0 + pb;
+                const bool in = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && gbi < B;
+                unsigned off;
+                if constexpr (FAST16) off = (unsigned)((((gbi * H + gy) * W + gx) * Ks + q * 8) * 2);
+                else {                                             // small maps: B * H * W < 2^24 (checked by the launcher)
+                    const unsigned pix = __umul24(__umul24((unsigned)gbi, (unsigned)H) + gy, (unsigned)W) + gx;
+                    off = (__umul24(pix, (unsigned)Ks) + q * 8) * 2;
+                }
+                ga[it] = in ? off : 0xffffffffu;
+                if constexpr (XF)
+                    if (in && cob == 0 && xf.a_out != nullptr && px >= 1 && px <= tw && py >= 1 && py <= th) wmask |= 1u << it;
             }
-            ga[it] = in ? off : 0xffffffffu;
-            if constexpr (XF)
-                if (in && cob == 0 && xf.a_out != nullptr && px >= 1 && px <= tw && py >= 1 && py <= th) wmask |= 1u << it;
         }
-    }
+    };
     // filter-slab pieces: piece `it` of a thread lies it * 64 slab rows further on, i.e. a fixed byte stride -> one VGPR
     // offset plus a scalar stride (gbl: the last piece, only partly populated when 9 * BN * 4 is not a multiple of NT)
     unsigned gb0, gbl;
@@ -377,7 +388,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
     static_assert(NT / 4 % BN == 0, "slab piece stride must be whole taps");
     const int gbs = (NT / 4 / BN) * N * 64;
     const int gcs = 9 * N * 64;                   // bytes per 32-channel chunk of the packed filter
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K * 2u), 0x00020000);
+    // source tensor of the running chunks: x (channels [0, K1)) or du.x2 (channels [K1, K)); cbase = first channel of the source
+    const int K1 = du.x2 ? du.K1 : K;
+    __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K1 * 2u), 0x00020000);
+    int cbase = 0;
+    auto second_source = [&]() {
+        rsx = __builtin_amdgcn_make_buffer_rsrc((void*)du.x2, 0, (int)((unsigned)B * H * W * (K - K1) * 2u), 0x00020000);
+        cbase = K1;
+        make_plan(K - K1);
+    };
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, (int)(9u * N * K * 2u), 0x00020000);
 
     f32x16 acc[2][NJ];
@@ -398,7 +417,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
     auto prefetch_piece = [&](auto idxc, int c0) {
         constexpr int idx = decltype(idxc)::value;
         if constexpr (PHX_ABLATE & 1) return;
-        if constexpr (idx < NA) ra[idx] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ga[idx], c0 * 2, 0);
+        if constexpr (idx < NA) ra[idx] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ga[idx], (c0 - cbase) * 2, 0);
         else if constexpr (idx < NA + NB)
             rb[idx - NA] = __builtin_amdgcn_raw_buffer_load_b128(rsw, idx - NA == NB - 1 ? gbl : gb0, (c0 >> 5) * gcs + (idx - NA) * gbs, 0);
     };
@@ -409,6 +428,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
         cbeg = blockIdx.z * per * KC;
         cend = min(K, cbeg + per * KC);
     }
+    if (cbeg >= K1) second_source(); else make_plan(K1);
     {
         auto all = [&](auto self, auto idxc) {
             constexpr int idx = decltype(idxc)::value;
@@ -570,7 +590,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
     {
         const int cx0 = tx0, cy0 = ty0, cb0 = b0;
         const bool tr0 = true;
-        for (int c0 = cbeg; c0 + KC < cend; c0 += KC) chunk(c0, c0 + KC, std::true_type(), c0 == KC);
+        for (int c0 = cbeg; c0 + KC < cend; c0 += KC) {
+            if (c0 + KC == K1) second_source();          // (the chunk being prefetched is the first of x2)
+            chunk(c0, c0 + KC, std::true_type(), c0 == KC);
+        }
         chunk(cend - KC, 0, std::false_type(), K == 2 * KC);
         if constexpr (SPLITK) {
             // fp32 partial tile -> ws[z][pixel][N]; C layout: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -642,8 +665,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
             if (tr0) PHX_TRACE(9);
             const int mt = threadIdx.x / PPP, q = threadIdx.x % PPP;          // piece it: pixel mt + it * (NT / PPP)
             const unsigned char* lr = smem + mt * OROW + q * 16;
-            unsigned short* yp = y + (((size_t)cb0 * H + cy0 + (mt >> 4)) * W + cx0 + (mt & 15)) * N + n0 + q * 8;
-            const size_t ystep = (size_t)(NT / PPP / 16) * W * N;
+            // (dual destination: the piece's eight channels lie in y (row length N1) or in du.y2 (row length N - N1))
+            unsigned short* ybase = y;
+            int yld = N, ych = n0 + q * 8;
+            if (du.y2) {
+                if (ych < du.N1) yld = du.N1;
+                else { ybase = du.y2; yld = N - du.N1; ych -= du.N1; }
+            }
+            unsigned short* yp = ybase + (((size_t)cb0 * H + cy0 + (mt >> 4)) * W + cx0 + (mt & 15)) * yld + ych;
+            const size_t ystep = (size_t)(NT / PPP / 16) * W * yld;
             if (bws.part == nullptr) {
 #pragma unroll
                 for (int it = 0; it < PPP; ++it)
@@ -720,7 +750,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
                 const int ox = cx0 + lx, oy = cy0 + ly, ob = cb0 + lb;
                 if (ox < W && oy < H && ob < B) {
                     const uint4 v = *reinterpret_cast<const uint4*>(smem + m * OROW + q * 16);
-                    *reinterpret_cast<uint4*>(y + (((size_t)ob * H + oy) * W + ox) * N + n0 + q * 8) = v;
+                    unsigned short* ybase = y;
+                    int yld = N, ych = n0 + q * 8;
+                    if (du.y2) {
+                        if (ych < du.N1) yld = du.N1;
+                        else { ybase = du.y2; yld = N - du.N1; ych -= du.N1; }
+                    }
+                    *reinterpret_cast<uint4*>(ybase + (((size_t)ob * H + oy) * W + ox) * yld + ych) = v;
                 }
             }
         }
@@ -826,7 +862,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
                                                              const unsigned short* __restrict__ wpk,
                                                              unsigned short* __restrict__ y, const float* __restrict__ bias,
                                                              int act, float* __restrict__ stats_partial,
-                                                             int B, int H, int W, int K, int N, int tiles_x, int tiles_y, const float* __restrict__ oscale, int stats_nrep) {
+                                                             int B, int H, int W, int K, int N, int tiles_x, int tiles_y, const float* __restrict__ oscale, int stats_nrep, Dual du) {
     constexpr int NJ = BN / 32;                       // BN = 64 (two 32-channel MFMA columns per wave) or 32 (one)
     constexpr int AI = 39, BI = 9 * BN * 64 / 1024;   // 1 KiB DMA instructions per chunk: 612 patch rows x 64 B, 9 * BN slab rows
     constexpr int NLW = 4;
@@ -874,24 +910,36 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
     // DMA latency, prologue and epilogue run under the other block's MFMAs
     const int lw = wave;
     unsigned voff[NPL];
+    auto plan_patch = [&](const int Ks) {             // Ks: pixel stride (channels) of the tensor the patch is read from
+#pragma unroll
+        for (int n = 0; n < NPL; ++n) {
+            const int j = lw + NLW * n;
+            if (j < AI) {
+                voff[n] = 0xffffffffu;
+                const int e = j * 64 + lane, pp = e >> 2, slot = e & 3;
+                const int py = pp / 34, px = pp - py * 34;
+                const int piece = slot ^ ((px >> 2) & 3);
+                const int gx = tx0 + px - 1, gy = ty0 + py - 1;
+                if (pp < 612 && gx >= 0 && gx < W && gy >= 0 && gy < H && !(DBG & 1)) voff[n] = (unsigned)((((b0 * H + gy) * W + gx) * Ks) * 2 + piece * 16);
+            }
+        }
+    };
 #pragma unroll
     for (int n = 0; n < NPL; ++n) {
         const int j = lw + NLW * n;
         voff[n] = 0xffffffffu;
-        if (j < AI) {
-            const int e = j * 64 + lane, pp = e >> 2, slot = e & 3;
-            const int py = pp / 34, px = pp - py * 34;
-            const int piece = slot ^ ((px >> 2) & 3);
-            const int gx = tx0 + px - 1, gy = ty0 + py - 1;
-            if (pp < 612 && gx >= 0 && gx < W && gy >= 0 && gy < H && !(DBG & 1)) voff[n] = (unsigned)((((b0 * H + gy) * W + gx) * K) * 2 + piece * 16);
-        } else if (j < NI) {
+        if (j >= AI && j < NI) {
             const int e = (j - AI) * 64 + lane, rb = e >> 2, slot = e & 3;
             const int tap = rb / BN, nn = rb % BN;
             const int piece = slot ^ ((nn >> 2) & 3);
             if (!(DBG & 2)) voff[n] = (unsigned)(((tap * N + n0 + nn) * 32 + piece * 8) * 2);
         }
     }
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K * 2u), 0x00020000);
+    // (concat-free input, struct Dual: chunks [0, K1 / 32) come from x, the rest from du.x2)
+    const int K1 = du.x2 ? du.K1 : K;
+    plan_patch(K1);
+    __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K1 * 2u), 0x00020000);
+    int cb = 0;
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, (int)(9u * N * K * 2u), 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     unsigned aK[3][2], bK[2];
@@ -904,11 +952,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
     for (int ks = 0; ks < 2; ++ks) bK[ks] = (unsigned)(A_BYTES + l31 * 64 + (((ks * 2 + khalf) ^ ((l31 >> 2) & 3)) << 4));
     for (int c = 0; c < nch; ++c) {
         if (c) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done reading the previous chunk
+        if (c * 32 == K1) {                           // second source tensor from here on
+            rsx = __builtin_amdgcn_make_buffer_rsrc((void*)du.x2, 0, (int)((unsigned)B * H * W * (K - K1) * 2u), 0x00020000);
+            cb = c;
+            plan_patch(K - K1);
+        }
 #pragma unroll
         for (int n = 0; n < NPL; ++n) {
             const int j = lw + NLW * n;
             if (j < AI)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + j * 1024), 16, (int)voff[n], c * 64, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + j * 1024), 16, (int)voff[n], (c - cb) * 64, 0, 0);
             else if (j < NI)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(smem + j * 1024), 16, (int)voff[n], c * 9 * N * 64, 0, 0);
         }
@@ -997,8 +1050,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
         constexpr int PSTEP = 256 / PPP;              // pixels per step of the 256 storing threads (32: one tile row; 64: two)
         const int mt = threadIdx.x / PPP, q = threadIdx.x % PPP;
         const unsigned char* lr = smem + mt * OROW + q * 16;
-        unsigned short* yp = y + (((size_t)b0 * H + ty0 + (mt >> 5)) * W + tx0 + (mt & 31)) * N + n0 + q * 8;
-        const size_t ystep = (size_t)(PSTEP / 32) * W * N;
+        unsigned short* ybase = y;                    // (dual destination, struct Dual)
+        int yld = N, ych = n0 + q * 8;
+        if (du.y2) {
+            if (ych < du.N1) yld = du.N1;
+            else { ybase = du.y2; yld = N - du.N1; ych -= du.N1; }
+        }
+        unsigned short* yp = ybase + (((size_t)b0 * H + ty0 + (mt >> 5)) * W + tx0 + (mt & 31)) * yld + ych;
+        const size_t ystep = (size_t)(PSTEP / 32) * W * yld;
 #pragma unroll
         for (int it = 0; it < 512 / PSTEP; ++it)
             *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * PSTEP * OROW);
@@ -1046,10 +1105,17 @@ __device__ __forceinline__ int wswz(int pix, int byte_in_row) {
 // BIGP selects the bound on the per-thread staging pieces: false -> 16x16 / 8x8x4 tiles, true -> 4x4x16 / 2x2x64 tiles
 // (body shared by the one-layer kernel and the multi-layer one below: bx / by / bz / gdx / gdy stand in for blockIdx, gridDim)
 template <int TCI, int TCO, bool BIGP, bool FAST16>
-__device__ __forceinline__ void conv3x3_wgrad_body(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
+__device__ __forceinline__ void conv3x3_wgrad_body(const unsigned short* __restrict__ x0, const unsigned short* __restrict__ dy,
                                                    float* __restrict__ dw, float* __restrict__ ws, int B, int H, int W, int Cin,
                                                    int Cout, MTile g, int ntiles, int tiles_per_block, const int bx,
-                                                   const int by, const int bz, const int gdx, const int gdy) {
+                                                   const int by, const int bz, const int gdx, const int gdy,
+                                                   const unsigned short* __restrict__ x2 = nullptr, const int K1 = 0) {
+    // concat-free input (struct Dual): this block's TCI input channels lie in x0 (channels [0, K1), pixel stride K1) or in x2
+    // (channels [K1, Cin), pixel stride Cin - K1); K1 % TCI == 0.  xC = pixel stride, xc0 = first channel inside the source.
+    const bool src2 = x2 != nullptr && by * TCI >= K1;
+    const unsigned short* __restrict__ x = src2 ? x2 : x0;
+    const int xC = x2 == nullptr ? Cin : (src2 ? Cin - K1 : K1);
+    const int xc0 = by * TCI - (src2 ? K1 : 0);
     constexpr int WI = TCI / 32, WJ = TCO / 32, WK = 4 / (WI * WJ);
     constexpr int RBX = TCI * 2, RBD = TCO * 2;
     constexpr int QX = TCI / 8, QD = TCO / 8;                        // 16-byte pieces per pixel
@@ -1111,7 +1177,7 @@ __device__ __forceinline__ void conv3x3_wgrad_body(const unsigned short* __restr
     }
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     u32x4 rx[NXI], rd[QD];
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * Cin * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * xC * 2u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * H * W * Cout * 2u), 0x00020000);
     const int qxb = (threadIdx.x % QX) * 16, qdb = (threadIdx.x % QD) * 16;      // 256 % QX == 0: the same for every piece
     // global -> registers for tile t.  Branch-free: a piece outside the image / batch gets buffer offset 0xffffffff and
@@ -1125,8 +1191,8 @@ __device__ __forceinline__ void conv3x3_wgrad_body(const unsigned short* __restr
         for (int it = 0; it < NXI; ++it) {
             const int gx = tx0 + (planx[it] & 255) - 1, gy = ty0 + ((planx[it] >> 8) & 255) - 1, gb = b0 + (planx[it] >> 16);
             const bool ok = planx[it] >= 0 && (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && gb < B;
-            const unsigned vo = ok ? (unsigned)(((gb * H + gy) * W + gx) * Cin * 2 + qxb) : 0xffffffffu;
-            rx[it] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)vo, ci0 * 2, 0);
+            const unsigned vo = ok ? (unsigned)(((gb * H + gy) * W + gx) * xC * 2 + qxb) : 0xffffffffu;
+            rx[it] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)vo, xc0 * 2, 0);
         }
 #pragma unroll
         for (int it = 0; it < QD; ++it) {
@@ -1151,8 +1217,8 @@ __device__ __forceinline__ void conv3x3_wgrad_body(const unsigned short* __restr
         if constexpr (idx < NXI) {
             const int gx = ptx0 + (planx[idx] & 255) - 1, gy = pty0 + ((planx[idx] >> 8) & 255) - 1, gb = pb0 + (planx[idx] >> 16);
             const bool ok = planx[idx] >= 0 && gx >= 0 && gx < W && gy >= 0 && gy < H && gb < B;
-            const unsigned vo = ok ? (unsigned)(((gb * H + gy) * W + gx) * Cin * 2 + qxb) : 0xffffffffu;
-            rx[idx] = __builtin_amdgcn_raw_buffer_load_b128(rsx, vo, ci0 * 2, 0);
+            const unsigned vo = ok ? (unsigned)(((gb * H + gy) * W + gx) * xC * 2 + qxb) : 0xffffffffu;
+            rx[idx] = __builtin_amdgcn_raw_buffer_load_b128(rsx, vo, xc0 * 2, 0);
         } else if constexpr (idx < NXI + QD) {
             constexpr int it = idx - NXI;
             const int ox = ptx0 + (pland[it] & 255), oy = pty0 + ((pland[it] >> 8) & 255), ob = pb0 + (pland[it] >> 16);
@@ -1334,9 +1400,9 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad(const unsigned short* 
                                                           const unsigned short* __restrict__ dy,
                                                           float* __restrict__ dw, float* __restrict__ ws, int B, int H,
                                                           int W, int Cin, int Cout, MTile g, int ntiles,
-                                                          int tiles_per_block) {
+                                                          int tiles_per_block, const unsigned short* __restrict__ x2, int K1) {
     conv3x3_wgrad_body<TCI, TCO, BIGP, FAST16>(x, dy, dw, ws, B, H, W, Cin, Cout, g, ntiles, tiles_per_block, blockIdx.x,
-                                               blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+                                               blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, x2, K1);
 }
 // Small-map filter gradients are leaves of the backward graph and latency-bound (a few tiles, 9-36 blocks, ~20 us each, in
 // the middle of the posterior / prior / likelihood chains).  The engine defers them: ONE launch per kernel variant runs the
@@ -1346,6 +1412,7 @@ struct WgMJob {
     int B, H, W, Cin, Cout;
     MTile g;
     int ntiles, tpb, gdx, gdy, gdz, blk0;
+    const unsigned short* x2; int K1, pad_;      // concat-free input (struct Dual); x2 == NULL: single tensor
 };
 template <int TCI, int TCO, bool BIGP>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_multi(const WgMJob* __restrict__ jobs, int njobs) {
@@ -1357,7 +1424,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_multi(const WgMJob* __
     const WgMJob j = jobs[lo];
     const int local = blockIdx.x - j.blk0;
     conv3x3_wgrad_body<TCI, TCO, BIGP, false>(j.x, j.dy, j.dw, j.ws, j.B, j.H, j.W, j.Cin, j.Cout, j.g, j.ntiles, j.tpb,
-                                              local % j.gdx, (local / j.gdx) % j.gdy, local / (j.gdx * j.gdy), j.gdx, j.gdy);
+                                              local % j.gdx, (local / j.gdx) % j.gdy, local / (j.gdx * j.gdy), j.gdx, j.gdy, j.x2, j.K1);
 }
 
 // ---- filter gradient, 16x16 tiles, LDS-DMA staging ---------------------------------------------------------------
@@ -1368,10 +1435,15 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_multi(const WgMJob* __
 // 128-byte rows is applied on the SOURCE side (each lane fetches the piece that belongs in its slot); pieces outside the
 // image carry offset 0xffffffff and the buffer range check writes zeros for them.  Partial filters go to the workspace.
 template <int TCI, int TCO>
-__device__ __forceinline__ void conv3x3_wgrad_dma_body(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
+__device__ __forceinline__ void conv3x3_wgrad_dma_body(const unsigned short* __restrict__ x0, const unsigned short* __restrict__ dy,
                                                        float* __restrict__ ws, int B, int H, int W, int Cin, int Cout, MTile g,
                                                        int ntiles, int tiles_per_block, const int bx, const int by, const int bz,
-                                                       const int gdx, const int gdy) {
+                                                       const int gdx, const int gdy,
+                                                       const unsigned short* __restrict__ x2 = nullptr, const int K1 = 0) {
+    const bool src2 = x2 != nullptr && by * TCI >= K1;       // concat-free input: see conv3x3_wgrad_body
+    const unsigned short* __restrict__ x = src2 ? x2 : x0;
+    const int xC = x2 == nullptr ? Cin : (src2 ? Cin - K1 : K1);
+    const int xc0 = by * TCI - (src2 ? K1 : 0);
     constexpr int WI = TCI / 32, WJ = TCO / 32, WK = 4 / (WI * WJ);
     constexpr int RBX = TCI * 2, RBD = TCO * 2;
     constexpr int QX = TCI / 8, QD = TCO / 8;                        // 16-byte pieces per pixel
@@ -1428,7 +1500,7 @@ __device__ __forceinline__ void conv3x3_wgrad_dma_body(const unsigned short* __r
 #pragma unroll
         for (int n = 0; n < DN; ++n) pland[n] = plan_d(n);
     }
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * Cin * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * xC * 2u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * H * W * Cout * 2u), 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -1448,8 +1520,8 @@ __device__ __forceinline__ void conv3x3_wgrad_dma_body(const unsigned short* __r
                 if constexpr (RPLAN) pk = planx[n]; else pk = plan_x(n);
                 const int gx = tx0 + (pk & 255) - 1, gy = ty0 + ((pk >> 8) & 255) - 1;
                 const bool ok = pk >= 0 && gx >= 0 && gx < W && gy >= 0 && gy < H;
-                const unsigned vo = ok ? (unsigned)((((b0 * H + gy) * W + gx) * Cin) * 2 + (pk >> 16) * 16) : 0xffffffffu;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + (wave + 4 * n) * 1024), 16, vo, ci0 * 2, 0, 0);
+                const unsigned vo = ok ? (unsigned)((((b0 * H + gy) * W + gx) * xC) * 2 + (pk >> 16) * 16) : 0xffffffffu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + (wave + 4 * n) * 1024), 16, vo, xc0 * 2, 0, 0);
             }
         }
 #pragma unroll
@@ -1560,9 +1632,9 @@ template <int TCI, int TCO>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_dma(const unsigned short* __restrict__ x,
                                                               const unsigned short* __restrict__ dy, float* __restrict__ ws,
                                                               int B, int H, int W, int Cin, int Cout, MTile g, int ntiles,
-                                                              int tiles_per_block) {
+                                                              int tiles_per_block, const unsigned short* __restrict__ x2, int K1) {
     conv3x3_wgrad_dma_body<TCI, TCO>(x, dy, ws, B, H, W, Cin, Cout, g, ntiles, tiles_per_block, blockIdx.x, blockIdx.y, blockIdx.z,
-                                     gridDim.x, gridDim.y);
+                                     gridDim.x, gridDim.y, x2, K1);
 }
 // multi-layer form (see k_conv3x3_wgrad_multi): the 16x16-tile layers with few tiles (H = 16 at batch 64)
 template <int TCI, int TCO>
@@ -1575,7 +1647,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_dma_multi(const WgMJob
     const WgMJob j = jobs[lo];
     const int local = blockIdx.x - j.blk0;
     conv3x3_wgrad_dma_body<TCI, TCO>(j.x, j.dy, j.ws, j.B, j.H, j.W, j.Cin, j.Cout, j.g, j.ntiles, j.tpb, local % j.gdx,
-                                     (local / j.gdx) % j.gdy, local / (j.gdx * j.gdy), j.gdx, j.gdy);
+                                     (local / j.gdx) % j.gdy, local / (j.gdx * j.gdy), j.gdx, j.gdy, j.x2, j.K1);
 }
 
 // dw[k][ci][co] += sum over the nslice partial tiles written by the filter-gradient kernels.  A thread owns four
@@ -1637,7 +1709,8 @@ __global__ void k_wgrad_reduce_multi(const WgrJob* __restrict__ jobs, int njobs)
 
 // y[pix][n] = bf16(act(sum_z ws[z][pix][n] + bias[n])), four channels per thread
 __global__ void k_splitk_finish(const float* __restrict__ ws, int nz, size_t total, int N, const float* __restrict__ bias,
-                                int act, unsigned short* __restrict__ y, const float* __restrict__ oscale) {
+                                int act, unsigned short* __restrict__ y, const float* __restrict__ oscale,
+                                unsigned short* __restrict__ y2, int N1) {
     for (size_t i4 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i4 * 4 < total; i4 += (size_t)gridDim.x * blockDim.x) {
         const size_t i = i4 * 4;
         f32x4 a = *reinterpret_cast<const f32x4*>(ws + i);
@@ -1650,6 +1723,12 @@ __global__ void k_splitk_finish(const float* __restrict__ ws, int nz, size_t tot
         uint2 o;
         o.x = f2bf_pk(a[0], a[1]);
         o.y = f2bf_pk(a[2], a[3]);
+        if (y2 != nullptr) {                       // dual destination (see struct Dual): channels [0, N1) -> y, [N1, N) -> y2
+            const size_t pix = i / N;
+            const int n = (int)(i - pix * N);
+            if (n < N1) *reinterpret_cast<uint2*>(y + pix * N1 + n) = o;
+            else *reinterpret_cast<uint2*>(y2 + pix * (N - N1) + (n - N1)) = o;
+        } else
         *reinterpret_cast<uint2*>(y + i) = o;
     }
 }
@@ -1808,6 +1887,25 @@ int phx_conv3x3_mfma_stats_rep_supported(int B, int H, int W, int K, int N) {
     return (!phx_deterministic() && K % KC == 0 && N % 32 == 0) ? 1 : 0;
 }
 
+// One-shot modifiers of the NEXT forward / data-gradient launch made from the calling thread (any phx_conv3x3_mfma_bf16* entry point
+// except ..._xf / ..._bwdstats): see struct Dual.  Consumed (and cleared) by that launch, whether it succeeds or not.
+static thread_local Dual g_next_dual = {nullptr, nullptr, 0, 0};
+int phx_conv3x3_next_dual_input(const void* x2, int K1) {
+    PHX_REQUIRE(x2 != nullptr && K1 > 0 && K1 % 32 == 0 && ((uintptr_t)x2 & 15) == 0, PHX_E_INVAL, "conv3x3_next_dual_input: x2 (16-byte aligned), K1 % 32 == 0");
+    g_next_dual.x2 = (const unsigned short*)x2; g_next_dual.K1 = K1;
+    return PHX_OK;
+}
+int phx_conv3x3_next_dual_output(void* y2, int N1) {
+    PHX_REQUIRE(y2 != nullptr && N1 > 0 && N1 % 8 == 0 && ((uintptr_t)y2 & 15) == 0, PHX_E_INVAL, "conv3x3_next_dual_output: y2 (16-byte aligned), N1 % 8 == 0");
+    g_next_dual.y2 = (unsigned short*)y2; g_next_dual.N1 = N1;
+    return PHX_OK;
+}
+static Dual take_next_dual() {
+    const Dual d = g_next_dual;
+    g_next_dual = Dual{nullptr, nullptr, 0, 0};
+    return d;
+}
+
 // ---- conv + batch norm (training mode) + activation in one launch on small maps (FBN instantiations of k_conv3x3_mfma) --------
 // Every block of the launch has to be resident at once (they meet at an arrival counter): at most PHX_FBN_MAXBLOCKS (192) blocks, so
 // that the launches of two lanes fit the 512 block slots of the chip side by side.  -> 32 / 64 (channels per block), 0: not supported.
@@ -1827,6 +1925,8 @@ int phx_conv3x3_mfma_bf16_fbn(const void* x, const void* wpk, void* y, void* a_o
                               const float* beta, float eps, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
                               float* moving_mean, float* moving_var, float momentum, int act, int B, int H, int W, int K, int N,
                               void* stream) {
+    const Dual du = take_next_dual();
+    PHX_REQUIRE(du.y2 == nullptr && (du.x2 == nullptr || du.K1 < K), PHX_E_SHAPE, "conv3x3_mfma_fbn: dual input needs 0 < K1 < K; no dual output");
     const int bn = fbn_plan(B, H, W, K, N);
     PHX_REQUIRE(bn != 0, PHX_E_SHAPE, "conv3x3_mfma_fbn: shape not supported (see phx_conv3x3_fbn_supported)");
     PHX_REQUIRE(x && wpk && y && a_out && sums && counters && gamma && beta && mean_out && rstd_out && scale_out && shift_out, PHX_E_INVAL,
@@ -1853,7 +1953,7 @@ int phx_conv3x3_mfma_bf16_fbn(const void* x, const void* wpk, void* y, void* a_o
         const size_t she = (size_t)256 * (BNv * 2 + 16);                                                                \
         if (she > sh) sh = she;                                                                                         \
         hipLaunchKernelGGL(kfn, dim3(ntiles * (N / BNv)), dim3(256), sh, (hipStream_t)stream, (const unsigned short*)x, \
-                           (const unsigned short*)wpk, (unsigned short*)y, nullptr, 0, sums, B, H, W, K, N, g, nullptr, b, xf); \
+                           (const unsigned short*)wpk, (unsigned short*)y, nullptr, 0, sums, B, H, W, K, N, g, nullptr, b, xf, du); \
     } while (0)
     if (bn == 64) {
         if (fast16) FBN_LAUNCH(64, 8, true); else if (na <= 8) FBN_LAUNCH(64, 8, false); else FBN_LAUNCH(64, 16, false);
@@ -1887,7 +1987,11 @@ int phx_conv3x3_mfma_bf16_bwdstats(const void* dy, const void* wpk_dgrad, void* 
 static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
                              void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, BwdStats bws,
                              void* stream) {
+    const Dual du = take_next_dual();
     PHX_REQUIRE(K % KC == 0 && N % 32 == 0, PHX_E_SHAPE, "conv3x3_mfma: K % 32 == 0 and N % 32 == 0 required");
+    PHX_REQUIRE(du.x2 == nullptr || du.K1 < K, PHX_E_SHAPE, "conv3x3_mfma: dual input needs 0 < K1 < K");
+    PHX_REQUIRE(du.y2 == nullptr || (du.N1 < N && (N - du.N1) % 8 == 0 && y != nullptr && stats_partial == nullptr && bws.part == nullptr),
+                PHX_E_SHAPE, "conv3x3_mfma: dual output needs 0 < N1 < N, (N - N1) % 8 == 0, an output tensor and no statistics epilogue");
     PHX_REQUIRE((((uintptr_t)x | (uintptr_t)wpk | (uintptr_t)y) & 15) == 0, PHX_E_ALIGN, "conv3x3_mfma: 16-byte alignment");
     int ksplit = 1;
     if (workspace && !stats_partial) {
@@ -1903,13 +2007,13 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
         const int ntl = B * (H / 16) * (W / 32);
         const char* dbe = getenv("PHX_DBG_ABLATE");   // dev: bit 1 no patch loads, 2 no slab loads, 4 no MFMAs
         const int dbg = dbe ? atoi(dbe) : 0;
-        if (phx_db_enabled() && N % 64 == 0 && !bws.stats_atomic) return phx_db_launch(x, wpk, y, bias, act, stats_partial, B, H, W, K, N, bws.oscale, dbg, stream);
+        if (phx_db_enabled() && N % 64 == 0 && !bws.stats_atomic && !du.x2 && !du.y2) return phx_db_launch(x, wpk, y, bias, act, stats_partial, B, H, W, K, N, bws.oscale, dbg, stream);
 #define D128_LAUNCH1(Av, Dv, BNv)                                                                                               \
     do {                                                                                                                        \
         PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_dma128<Av, Dv, BNv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((k_conv3x3_fwd_dma128<Av, Dv, BNv>), dim3(ntl * (N / BNv)), dim3(256), 75 * 1024 + 16, (hipStream_t)stream, \
                            (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, \
-                           H, W, K, N, W / 32, H / 16, bws.oscale, bws.stats_atomic ? (bws.stats_nrep > 1 ? bws.stats_nrep : 1) : 0);                                                       \
+                           H, W, K, N, W / 32, H / 16, bws.oscale, bws.stats_atomic ? (bws.stats_nrep > 1 ? bws.stats_nrep : 1) : 0, du);                                                       \
     } while (0)
 #define D128_LAUNCH(Av, Dv)                                                                                                     \
     do { if (N % 64 == 0) D128_LAUNCH1(Av, Dv, 64); else D128_LAUNCH1(Av, 0, 32); } while (0)
@@ -1957,11 +2061,11 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
             hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, false, NWv, Sv>), dim3(ntiles * (N / BNv), 1, ksplit),  \
                                dim3(NWv * 64), sh, (hipStream_t)stream, (const unsigned short*)x,                    \
                                (const unsigned short*)wpk, (unsigned short*)y, nullptr, 0, nullptr, B, H, W, K, N, g,\
-                               (float*)workspace, BwdStats{}, XForm{});                                              \
+                               (float*)workspace, BwdStats{}, XForm{}, du);                                            \
         else                                                                                                         \
             hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, Av, NWv, false>), dim3(ntiles * (N / BNv)), dim3(NWv * 64),\
                                sh, (hipStream_t)stream, (const unsigned short*)x, (const unsigned short*)wpk,        \
-                               (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, g, nullptr, bws, XForm{}); \
+                               (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, g, nullptr, bws, XForm{}, du); \
     } while (0)
 #define CM_LAUNCH(BNv, NAv, Fv, NWv)                                                                                 \
     do {                                                                                                             \
@@ -1989,7 +2093,7 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
     if (ksplit > 1 && y != nullptr) {                // (y == NULL: the caller consumes the fp32 slices itself)
         const size_t total = (size_t)B * H * W * N;
         hipLaunchKernelGGL(k_splitk_finish, dim3(phx_grid_for(total / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)workspace, ksplit, total, N, bias, act, (unsigned short*)y, bws.oscale);
+                           (const float*)workspace, ksplit, total, N, bias, act, (unsigned short*)y, bws.oscale, du.y2, du.N1);
         PHX_CHECK_LAUNCH();
     }
     return PHX_OK;
@@ -2073,11 +2177,11 @@ int phx_conv3x3_mfma_bf16_xf(const void* y_prod, const void* wpk, void* y, const
             hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, false, 4, Sv, true>), dim3(ntiles * (N / BNv), 1, ksplit), \
                                dim3(256), sh, (hipStream_t)stream, (const unsigned short*)y_prod,                    \
                                (const unsigned short*)wpk, (unsigned short*)y, nullptr, 0, nullptr, B, H, W, K, N, g,\
-                               (float*)workspace, BwdStats{}, xf);                                                   \
+                               (float*)workspace, BwdStats{}, xf, Dual{});                                                 \
         else                                                                                                         \
             hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, Av, 4, false, true>), dim3(ntiles * (N / BNv)), dim3(256), \
                                sh, (hipStream_t)stream, (const unsigned short*)y_prod, (const unsigned short*)wpk,   \
-                               (unsigned short*)y, bias, act, stats, B, H, W, K, N, g, nullptr, bws, xf);            \
+                               (unsigned short*)y, bias, act, stats, B, H, W, K, N, g, nullptr, bws, xf, Dual{});    \
     } while (0)
 #define XF_LAUNCH(BNv, NAv, Fv)                                                                                      \
     do {                                                                                                             \
@@ -2099,7 +2203,7 @@ int phx_conv3x3_mfma_bf16_xf(const void* y_prod, const void* wpk, void* y, const
     if (ksplit > 1 && y != nullptr) {
         const size_t total = (size_t)B * H * W * N;
         hipLaunchKernelGGL(k_splitk_finish, dim3(phx_grid_for(total / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)workspace, ksplit, total, N, bias, act, (unsigned short*)y, (const float*)nullptr);
+                           (const float*)workspace, ksplit, total, N, bias, act, (unsigned short*)y, (const float*)nullptr, (unsigned short*)nullptr, 0);
         PHX_CHECK_LAUNCH();
     }
     return PHX_OK;
@@ -2117,10 +2221,11 @@ static size_t wgrad_dma_lds(int tci, int tco) {
     return stage > red ? stage : red;
 }
 static int wgrad_plan(int B, int H, int W, int Cin, int Cout, MTile* g, int* tci, int* tco, int* gx, int* tpb, int* wk,
-                      int target_override = 0) {
+                      int target_override = 0, int K1 = 0) {
     *g = make_mtile(B, H, W);
     const int ntiles = g->tiles_x * g->tiles_y * g->tiles_b;
     *tci = Cin % 64 == 0 ? 64 : 32;
+    if (K1 > 0 && K1 % 64 != 0) *tci = 32;         // concat-free input: a block's input channels lie in ONE of the two tensors
     *tco = Cout % 64 == 0 ? 64 : 32;
     *wk = 4 / ((*tci / 32) * (*tco / 32));
     if (wgrad_dma_enabled() && g->tws == 4 && g->ths == 4 && g->tb == 1) *wk = 1;   // the LDS-DMA kernel sums its wave groups in LDS
@@ -2140,11 +2245,12 @@ static int wgrad_plan(int B, int H, int W, int Cin, int Cout, MTile* g, int* tci
     return ntiles;
 }
 
-size_t phx_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout) {
+size_t phx_conv3x3_wgrad_ws_bytes_dual(int B, int H, int W, int Cin, int Cout, int K1) {
     MTile g; int tci, tco, gx, tpb, wk;
-    wgrad_plan(B, H, W, Cin, Cout, &g, &tci, &tco, &gx, &tpb, &wk);
+    wgrad_plan(B, H, W, Cin, Cout, &g, &tci, &tco, &gx, &tpb, &wk, 0, K1);
     return (size_t)(Cin / tci) * (Cout / tco) * gx * wk * 9 * tci * tco * sizeof(float);
 }
+size_t phx_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout) { return phx_conv3x3_wgrad_ws_bytes_dual(B, H, W, Cin, Cout, 0); }
 
 static int wgrad_atomic_tiles() {
     static int atl = -1;
@@ -2161,8 +2267,11 @@ static void wgrad_reduce_geometry(int Cin, int Cout, int nslice, int* rgx, int* 
 }
 /* plan6 = {uses_workspace, nslice, tci, tco, reduce grid x, reduce grid y} of the launch phx_conv3x3_wgrad_mfma_bf16 makes */
 int phx_conv3x3_wgrad_reduce_plan(int B, int H, int W, int Cin, int Cout, int* plan6) {
+    return phx_conv3x3_wgrad_reduce_plan_dual(B, H, W, Cin, Cout, 0, plan6);
+}
+int phx_conv3x3_wgrad_reduce_plan_dual(int B, int H, int W, int Cin, int Cout, int K1, int* plan6) {
     MTile g; int tci, tco, gx, tpb, wk;
-    const int ntiles = wgrad_plan(B, H, W, Cin, Cout, &g, &tci, &tco, &gx, &tpb, &wk);
+    const int ntiles = wgrad_plan(B, H, W, Cin, Cout, &g, &tci, &tco, &gx, &tpb, &wk, 0, K1);
     plan6[0] = ntiles > wgrad_atomic_tiles();
     plan6[1] = gx * wk; plan6[2] = tci; plan6[3] = tco;
     wgrad_reduce_geometry(Cin, Cout, gx * wk, &plan6[4], &plan6[5]);
@@ -2176,7 +2285,7 @@ int phx_wgrad_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, vo
     return PHX_OK;
 }
 static int wgrad_impl(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes, int B, int H,
-                      int W, int Cin, int Cout, bool reduce, void* stream);
+                      int W, int Cin, int Cout, bool reduce, void* stream, const void* x2 = nullptr, int K1 = 0);
 /* Deferred small-map filter gradients (see k_conv3x3_wgrad_multi).  phx_conv3x3_wgrad_multi_job fills ONE job record of
  * phx_conv3x3_wgrad_multi_job_bytes() bytes in HOST memory for the launch phx_conv3x3_wgrad_mfma_bf16_partial would make;
  * info = {variant (0: not deferred), blocks, dynamic LDS bytes, uses_workspace, nslice, tci, tco, reduce grid x, y} (9 ints).  The caller concatenates the records of one variant (blk0 = running sum of blocks), copies them to the
@@ -2184,11 +2293,19 @@ static int wgrad_impl(const void* x, const void* dy, float* dw_hwio, void* works
 int phx_conv3x3_wgrad_multi_job_bytes(void) { return (int)sizeof(WgMJob); }
 int phx_conv3x3_wgrad_multi_job(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes, int B,
                                 int H, int W, int Cin, int Cout, int blocks_target, int blk0, void* job_out, int* info4) {
+    return phx_conv3x3_wgrad_multi_job_dual(x, nullptr, 0, dy, dw_hwio, workspace, workspace_bytes, B, H, W, Cin, Cout, blocks_target, blk0,
+                                            job_out, info4);
+}
+int phx_conv3x3_wgrad_multi_job_dual(const void* x, const void* x2, int K1, const void* dy, float* dw_hwio, void* workspace,
+                                     size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int blocks_target, int blk0,
+                                     void* job_out, int* info4) {
     PHX_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, PHX_E_SHAPE, "conv3x3_wgrad_multi_job: Cin % 32 == 0 and Cout % 32 == 0 required");
+    PHX_REQUIRE(x2 == nullptr || (K1 > 0 && K1 < Cin && K1 % 32 == 0), PHX_E_SHAPE, "conv3x3_wgrad_multi_job: 0 < K1 < Cin, K1 % 32 == 0");
+    if (x2 == nullptr) K1 = 0;
     MTile g; int tci, tco, gx, tpb, wk;
     // blocks_target > 0: pixel-tile split of THIS job (a multi-layer launch has thousands of blocks in all, so a layer needs far
     // fewer partial filters than when it runs alone -- less workspace traffic for the launch and for the reduction)
-    const int ntiles = wgrad_plan(B, H, W, Cin, Cout, &g, &tci, &tco, &gx, &tpb, &wk, blocks_target);
+    const int ntiles = wgrad_plan(B, H, W, Cin, Cout, &g, &tci, &tco, &gx, &tpb, &wk, blocks_target, K1);
     for (int i = 0; i < 9; ++i) info4[i] = 0;
     const bool fast16 = g.tws == 4 && g.ths == 4 && g.tb == 1;
     if (fast16) {
@@ -2208,6 +2325,7 @@ int phx_conv3x3_wgrad_multi_job(const void* x, const void* dy, float* dw_hwio, v
     j.x = (const unsigned short*)x; j.dy = (const unsigned short*)dy; j.dw = dw_hwio; j.ws = use_ws ? (float*)workspace : nullptr;
     j.B = B; j.H = H; j.W = W; j.Cin = Cin; j.Cout = Cout; j.g = g; j.ntiles = ntiles; j.tpb = tpb;
     j.gdx = gx; j.gdy = Cin / tci; j.gdz = Cout / tco; j.blk0 = blk0;
+    j.x2 = (const unsigned short*)x2; j.K1 = K1; j.pad_ = 0;
     memcpy(job_out, &j, sizeof(j));
     info4[0] = 1 + (tco == 64 ? 1 : 0) + (tci == 64 ? 2 : 0) + (fast16 ? 8 : npatch > 400 ? 4 : 0);     // 9..12: LDS-DMA kernels
     info4[1] = j.gdx * j.gdy * j.gdz;
@@ -2263,16 +2381,22 @@ int phx_conv3x3_wgrad_mfma_bf16_partial(const void* x, const void* dy, float* dw
                                         int B, int H, int W, int Cin, int Cout, void* stream) {
     return wgrad_impl(x, dy, dw_hwio, workspace, workspace_bytes, B, H, W, Cin, Cout, false, stream);
 }
+int phx_conv3x3_wgrad_mfma_bf16_dual(const void* x, const void* x2, int K1, const void* dy, float* dw_hwio, void* workspace,
+                                     size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int reduce, void* stream) {
+    PHX_REQUIRE(x2 != nullptr && K1 > 0 && K1 < Cin && K1 % 32 == 0, PHX_E_SHAPE, "conv3x3_wgrad_mfma_dual: x2, 0 < K1 < Cin, K1 % 32 == 0");
+    return wgrad_impl(x, dy, dw_hwio, workspace, workspace_bytes, B, H, W, Cin, Cout, reduce != 0, stream, x2, K1);
+}
 static int wgrad_impl(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes, int B, int H,
-                      int W, int Cin, int Cout, bool reduce, void* stream) {
+                      int W, int Cin, int Cout, bool reduce, void* stream, const void* x2, int K1) {
     PHX_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, PHX_E_SHAPE, "conv3x3_wgrad_mfma: Cin % 32 == 0 and Cout % 32 == 0 required");
+    if (x2 == nullptr) K1 = 0;
     MTile g; int tci, tco, gx, tpb, wk;
-    const int ntiles = wgrad_plan(B, H, W, Cin, Cout, &g, &tci, &tco, &gx, &tpb, &wk);
+    const int ntiles = wgrad_plan(B, H, W, Cin, Cout, &g, &tci, &tco, &gx, &tpb, &wk, 0, K1);
     const int tw = 1 << g.tws, th = 1 << g.ths;
     const int npatch = g.tb * (th + 2) * (tw + 2);
     float* ws = nullptr;
     if (workspace) {
-        PHX_REQUIRE(workspace_bytes >= phx_conv3x3_wgrad_ws_bytes(B, H, W, Cin, Cout), PHX_E_INVAL, "conv3x3_wgrad_mfma: workspace too small");
+        PHX_REQUIRE(workspace_bytes >= phx_conv3x3_wgrad_ws_bytes_dual(B, H, W, Cin, Cout, K1), PHX_E_INVAL, "conv3x3_wgrad_mfma: workspace too small");
         ws = (float*)workspace;
         // a handful of pixel tiles (H <= 4 at batch 64): the partial filters are few, so adding them straight into dw with
         // atomics beats the extra k_wgrad_reduce launch on the latency-bound small-map chains (26 -> 20 us at 4 x 4)
@@ -2297,7 +2421,8 @@ static int wgrad_impl(const void* x, const void* dy, float* dw_hwio, void* works
 #define WD_LAUNCH(A, Bq)                                                                                              \
     hipLaunchKernelGGL((k_conv3x3_wgrad_dma<A, Bq>), dim3(gx, Cin / A, Cout / Bq), dim3(256),                         \
                        wgrad_dma_lds(A, Bq), (hipStream_t)stream,                                                     \
-                       (const unsigned short*)x, (const unsigned short*)dy, ws, B, H, W, Cin, Cout, g, ntiles, tpb)
+                       (const unsigned short*)x, (const unsigned short*)dy, ws, B, H, W, Cin, Cout, g, ntiles, tpb,    \
+                       (const unsigned short*)x2, K1)
         if (tci == 64 && tco == 64) WD_LAUNCH(64, 64);
         else if (tci == 64) WD_LAUNCH(64, 32);
         else if (tco == 64) WD_LAUNCH(32, 64);
@@ -2308,7 +2433,8 @@ static int wgrad_impl(const void* x, const void* dy, float* dw_hwio, void* works
     const size_t sh = (size_t)npatch * tci * 2 + (size_t)256 * tco * 2;
 #define WG_LAUNCH(A, Bq, C, F)                                                                                            \
     hipLaunchKernelGGL((k_conv3x3_wgrad<A, Bq, C, F>), dim3(gx, Cin / A, Cout / Bq), dim3(256), sh, (hipStream_t)stream,  \
-                       (const unsigned short*)x, (const unsigned short*)dy, dw_hwio, ws, B, H, W, Cin, Cout, g, ntiles, tpb)
+                       (const unsigned short*)x, (const unsigned short*)dy, dw_hwio, ws, B, H, W, Cin, Cout, g, ntiles, tpb, \
+                       (const unsigned short*)x2, K1)
 #define WG_LAUNCH2(A, Bq)                                                                  \
     do {                                                                                   \
         if (g.tws == 4 && g.ths == 4 && g.tb == 1) WG_LAUNCH(A, Bq, false, true);          \

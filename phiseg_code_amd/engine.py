@@ -72,7 +72,10 @@ _STATS_REP = int(os.environ.get("PHX_STATS_REP", "1"))
 _NORM_HEAD = os.environ.get("PHX_NORM_HEAD", "1") == "1"     # a 1x1 head that is the only reader of act(norm(conv)) rides on the apply pass; its data gradient is formed on the fly in the norm backward passes (A/B hook)
 # small maps, batch norm in training mode: convolution + statistics + normalisation + activation in ONE launch (phx_conv3x3_mfma_bf16_fbn:
 # the blocks meet at an arrival counter inside the launch) for layers of up to PHX_FBN_MAXP pixels (B * H * W); 0: off (A/B hook)
-_FBN_MAXP = int(os.environ.get("PHX_FBN_MAXP", "4096"))
+def _fbn_maxp():
+    return int(os.environ.get("PHX_FBN_MAXP", "4096"))      # (read when a plan is built)
+def _dual_enabled():
+    return os.environ.get("PHX_DUAL", "1") == "1"      # concat -> conv3x3 edges without the concatenated tensor (A/B hook; read when a plan is built)
 _LATENT_FUSED = os.environ.get("PHX_LATENT_FUSED", "1") == "1"     # mu / sigma heads + reparameterisation of a level in one launch each way (A/B hook)
 
 
@@ -146,6 +149,17 @@ class Buf:
         torch.cuda.synchronize()
         a = self.t[:self.n].float().cpu().numpy() if self.dt != U8 else self.t[:self.n].cpu().numpy()
         return a.reshape(self.shape)
+
+
+class DualBuf:
+    """The value of tf.concat([a, b], axis=3) whose only reader is a 3x3 convolution: never materialised -- the convolution reads
+    the two tensors in place (struct Dual in csrc/conv_mfma.hip), its data gradient writes their two gradients directly."""
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+        self.shape = tuple(a.shape[:-1]) + (a.shape[-1] + b.shape[-1],)
+        self.dt, self.ptr, self.n, self.shift = a.dt, a.ptr, a.n + b.n, 0
+        self.k1 = a.shape[-1]
 
 
 class HeadGrad:
@@ -768,8 +782,20 @@ class Plan:
 
     def _fw_concat(self, op, bw):
         a, b = op.inputs
-        out = self._alloc_like(op.outputs[0])
-        self.val[op.outputs[0]] = out
+        ot = op.outputs[0]
+        va, vb = self.val.get(a), self.val.get(b)
+        cons = self._real_consumers(ot, self._opset)
+        if (_dual_enabled() and self.act_dt == BF16 and self._dt_of(ot) == BF16 and isinstance(va, Buf) and isinstance(vb, Buf) and va.dt == BF16 and vb.dt == BF16
+                and len(va.shape) == 4 and va.shape[-1] % 32 == 0 and vb.shape[-1] % 32 == 0 and len(cons) == 1 and ot not in self.fetches):
+            c = cons[0]
+            ca = c.attrs if c.type == "conv_unit" else None
+            if (ca is not None and ca["ksize"] == 3 and ca.get("transposed") is None and ca.get("general") is None
+                    and ca["W"].shape[-1] % 32 == 0 and self.op_lane.get(c) == self.op_lane.get(op) and c not in self._lat):
+                # concat-free: the one reader, a 3x3 convolution on the MFMA path, takes the two tensors as they are (no launch here)
+                self.val[ot] = DualBuf(va, vb)
+                return
+        out = self._alloc_like(ot)
+        self.val[ot] = out
         npix = int(np.prod(out.shape[:-1]))
         if b.op.type == "sub_const" and b.op.inputs[0].op.type == "one_hot":
             # concat[x, one_hot(s) - 0.5] (posteriors.py:87) in one kernel
@@ -1019,6 +1045,19 @@ class Plan:
         mfma = (self.act_dt == BF16 and x.dt == BF16 and out.dt == BF16 and k == 3 and cin % 32 == 0
                 and cout % 32 == 0)
         S, Lb = self.stream, self.L
+        dual = x if isinstance(x, DualBuf) else None
+        assert dual is None or (mfma and pend is None), "concat-free input reached a convolution off the MFMA path"
+
+        def cv(fn):
+            """fn, preceded by the one-shot dual-input modifier when this convolution reads a concat-free pair (one plan entry)"""
+            if dual is None:
+                return fn
+            x2p, k1 = dual.b.ptr, dual.k1
+
+            def call(*args):
+                Lb.conv3x3_next_dual_input(x2p, k1)
+                fn(*args)
+            return call
         cin_eff = cin
         # Convolutions the 3x3 MFMA kernels do not take as they are: input channels not a multiple of 32 (image Cin = 1 / 3,
         # latent Cin = 2, prob_unet2D's feature + z concat) are zero-padded, and 1x1 filters (prob_unet2D's recombination
@@ -1070,14 +1109,14 @@ class Plan:
                            d["mm"], d["mv"], d["mom"], S, tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd,
                            shape=("xf", B, H, Wd, cin_eff, cout))
             elif stats_atomic is not None:
-                self._emit(Lb.conv3x3_mfma_bf16_stats_atomic, x.ptr, wf.ptr, y.ptr, bptr, act_code, stats_atomic.ptr, B, H, Wd, cin_eff,
+                self._emit(cv(Lb.conv3x3_mfma_bf16_stats_atomic), x.ptr, wf.ptr, y.ptr, bptr, act_code, stats_atomic.ptr, B, H, Wd, cin_eff,
                            cout, S, tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
             elif head1x1:
                 self._emit(Lb.head1x1_fwd, x.ptr, x.dt, wptr, bptr, y.ptr, B * H * Wd, cin, cout, act_code, S)
             elif mfma:
                 wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cin_eff, cout)) if stats_part is None else 0
                 ws = self._alloc((wsb // 4,), F32) if wsb else None          # split-K slices (small maps)
-                self._emit(Lb.conv3x3_mfma_bf16_ws, x.ptr, wf.ptr, y.ptr, bptr, act_code,
+                self._emit(cv(Lb.conv3x3_mfma_bf16_ws), x.ptr, wf.ptr, y.ptr, bptr, act_code,
                            stats_part.ptr if stats_part is not None else None, ws.ptr if ws else None, wsb,
                            B, H, Wd, cin_eff, cout, S,
                            tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
@@ -1109,7 +1148,7 @@ class Plan:
                                        scale.ptr, shift.ptr, cout, eps))
             wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cin_eff, cout))
             ws = self._alloc((wsb // 4,), F32) if wsb else None
-            self._emit(Lb.conv3x3_mfma_bf16_affine, x.ptr, wf.ptr, out.ptr, scale.ptr, shift.ptr, act, ws.ptr if ws else None, wsb,
+            self._emit(cv(Lb.conv3x3_mfma_bf16_affine), x.ptr, wf.ptr, out.ptr, scale.ptr, shift.ptr, act, ws.ptr if ws else None, wsb,
                        B, H, Wd, cin_eff, cout, S, tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
             st.update(scale=scale, shift=shift, NS=NS, P=P, G=Gn)
             self.saved[op] = st
@@ -1120,12 +1159,12 @@ class Plan:
             conv_into(y, 0)
             self._emit(Lb.affine_act, y.ptr, y.dt, scale.ptr, shift.ptr, out.ptr, out.dt, NS, P, cout, act, S)
         else:
-            if (norm == "batch" and training and mfma and not head1x1 and not xf and P <= _FBN_MAXP and not _DETERMINISTIC
+            if (norm == "batch" and training and mfma and not head1x1 and not xf and P <= _fbn_maxp() and not _DETERMINISTIC
                     and y.dt == BF16 and out.dt == BF16 and x.dt == BF16 and Lb.conv3x3_fbn_supported(B, H, Wd, cin_eff, cout)):
                 # small maps: convolution, batch statistics, normalisation and activation in one launch
                 upd = self.loss is not None
                 acc = self._alloc_zeroed(cout * 2 + (cout // 32 + 3) // 4 * 4)        # sums[N][2] | arrival counters
-                self._emit(Lb.conv3x3_mfma_bf16_fbn, x.ptr, wf.ptr, y.ptr, out.ptr, acc.ptr, acc.ptr + cout * 8, gptr, beptr, eps,
+                self._emit(cv(Lb.conv3x3_mfma_bf16_fbn), x.ptr, wf.ptr, y.ptr, out.ptr, acc.ptr, acc.ptr + cout * 8, gptr, beptr, eps,
                            mean.ptr, rstd.ptr, scale.ptr, shift.ptr,
                            self.store.ptr(nv["moving_mean"]) if upd else None, self.store.ptr(nv["moving_variance"]) if upd else None,
                            (1.0 - tfnorm.BN_DECAY) if upd else 0.0, act, B, H, Wd, cin_eff, cout, S,
@@ -1147,7 +1186,7 @@ class Plan:
                 if ks > 1:        # split-K convolution: its fp32 slices go straight into the norm kernel (no finishing launch)
                     wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cin_eff, cout))
                     ws = self._alloc((wsb // 4,), F32)
-                    self._emit(Lb.conv3x3_mfma_bf16_ws, x.ptr, wf.ptr, None, None, 0, None, ws.ptr, wsb, B, H, Wd, cin_eff,
+                    self._emit(cv(Lb.conv3x3_mfma_bf16_ws), x.ptr, wf.ptr, None, None, 0, None, ws.ptr, wsb, B, H, Wd, cin_eff,
                                cout, S, tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
                     self._emit(Lb.bn_small_fwd_splitk, ws.ptr, ks, y.ptr, gptr, beptr, eps, out.ptr, mean.ptr, rstd.ptr,
                                scale.ptr, shift.ptr, mm, mv, mom, P, cout, act, S,
@@ -1168,7 +1207,7 @@ class Plan:
                 if ks > 1:
                     wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cin_eff, cout))
                     ws = self._alloc((wsb // 4,), F32)
-                    self._emit(Lb.conv3x3_mfma_bf16_ws, x.ptr, wf.ptr, None, None, 0, None, ws.ptr, wsb, B, H, Wd, cin_eff,
+                    self._emit(cv(Lb.conv3x3_mfma_bf16_ws), x.ptr, wf.ptr, None, None, 0, None, ws.ptr, wsb, B, H, Wd, cin_eff,
                                cout, S, tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
                     self._emit(Lb.norm_small_fwd, y.ptr, ws.ptr, ks, bptr, gptr, beptr, eps, out.ptr, mean.ptr, rstd.ptr,
                                scale.ptr, shift.ptr, NS, P, cout, Gn, act, S,
@@ -1193,7 +1232,7 @@ class Plan:
                 # accumulator replicas, the apply pass sums them in its prologue -- no partial rows, no reduction launch in between
                 nrep_fw = _STATS_REP
                 sums = self._alloc_zeroed(nrep_fw * cout * 2)
-                self._emit(Lb.conv3x3_mfma_bf16_stats_rep, x.ptr, wf.ptr, y.ptr, bptr, 0, sums.ptr, nrep_fw, B, H, Wd, cin_eff, cout, S,
+                self._emit(cv(Lb.conv3x3_mfma_bf16_stats_rep), x.ptr, wf.ptr, y.ptr, bptr, 0, sums.ptr, nrep_fw, B, H, Wd, cin_eff, cout, S,
                            tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
             elif norm == "batch" and mfma and not small:
                 ntile = tiles_fn()
@@ -1809,12 +1848,15 @@ class Plan:
             padded = bool(sv.get("padded"))
             ce = sv["cin_eff"] if padded else cin
             tgt = self._alloc_zeroed(9 * ce * cout).ptr if padded else dw
-            wsb = int(Lb.conv3x3_wgrad_ws_bytes(B, H, Wd, ce, cout))
+            dual = x if isinstance(x, DualBuf) else None       # concat-free input: the filter gradient reads the two tensors in place
+            k1d = dual.k1 if dual is not None else 0
+            wsb = int(Lb.conv3x3_wgrad_ws_bytes_dual(B, H, Wd, ce, cout, k1d))
             wsp = self._alloc((wsb // 4,), F32)      # per-layer workspace of partial filters (no cross-lane sharing)
             plan6 = (ctypes.c_int * 6)()
-            Lb.conv3x3_wgrad_reduce_plan(B, H, Wd, ce, cout, plan6)
+            Lb.conv3x3_wgrad_reduce_plan_dual(B, H, Wd, ce, cout, k1d, plan6)
             rjob = (wsp.ptr, tgt, plan6[1], ce, cout, plan6[2], plan6[3], plan6[4], plan6[5])
             wargs = (x.ptr, dY.ptr, tgt, wsp.ptr, wsb, B, H, Wd, ce, cout)
+            dargs = (x.ptr, dual.b.ptr if dual is not None else None, k1d) + wargs[1:]      # (x, x2, K1, dy, ...)
             wflops = 18.0 * cin * cout * B * H * Wd
             deferred = False
             if _WGRAD_MULTI and _WGRAD_DEFER_SMALL:
@@ -1823,10 +1865,10 @@ class Plan:
                 # (phx_conv3x3_wgrad_multi); their latency leaves the posterior / prior / likelihood chains.
                 nb = int(Lb.conv3x3_wgrad_multi_job_bytes())
                 jb, info = ctypes.create_string_buffer(nb), (ctypes.c_int * 9)()
-                Lb.conv3x3_wgrad_multi_job(*wargs, _WGRAD_DEFER_BLOCKS, 0, jb, info)
+                Lb.conv3x3_wgrad_multi_job_dual(*dargs, _WGRAD_DEFER_BLOCKS, 0, jb, info)
                 if info[0]:
                     grp = self._wgm_jobs.setdefault(int(info[0]), dict(recs=[], blocks=0, lds=0))
-                    Lb.conv3x3_wgrad_multi_job(*wargs, _WGRAD_DEFER_BLOCKS, grp["blocks"], jb, info)
+                    Lb.conv3x3_wgrad_multi_job_dual(*dargs, _WGRAD_DEFER_BLOCKS, grp["blocks"], jb, info)
                     grp["recs"].append(jb.raw)
                     grp["blocks"] += int(info[1])
                     grp["lds"] = max(grp["lds"], int(info[2]))
@@ -1838,9 +1880,14 @@ class Plan:
             elif _WGRAD_MULTI and plan6[0]:
                 # large maps: the launch stays here, only the sum over its partial filters is deferred to ONE launch for all
                 # layers (phx_wgrad_reduce_multi)
-                self._emit(Lb.conv3x3_wgrad_mfma_bf16_partial, *wargs, S, tag="conv3x3_mfma_wgrad", flops=wflops)
+                if dual is not None:
+                    self._emit(Lb.conv3x3_wgrad_mfma_bf16_dual, *dargs, 0, S, tag="conv3x3_mfma_wgrad", flops=wflops)
+                else:
+                    self._emit(Lb.conv3x3_wgrad_mfma_bf16_partial, *wargs, S, tag="conv3x3_mfma_wgrad", flops=wflops)
                 self._wgr_jobs.append(rjob)
                 deferred = True
+            elif dual is not None:
+                self._emit(Lb.conv3x3_wgrad_mfma_bf16_dual, *dargs, 1, S, tag="conv3x3_mfma_wgrad", flops=wflops)
             else:
                 self._emit(Lb.conv3x3_wgrad_mfma_bf16, *wargs, S, tag="conv3x3_mfma_wgrad", flops=wflops)
             if padded:
@@ -1854,7 +1901,24 @@ class Plan:
         else:
             self._emit(Lb.conv2d_direct_wgrad, x.ptr, x.dt, dY.ptr, dY.dt, dw, db, B, H, Wd, cin, cout, k, S)
         xin = op.inputs[0]
-        if self.req.get(xin, False):
+        if isinstance(x, DualBuf) and self.req.get(xin, False):
+            # concat-free: the two halves of d(concat) are written straight to the gradients of the concatenated tensors
+            ta, tb = xin.op.inputs
+            _, wd = self._packed(W)
+            g1, g2 = self._alloc(x.a.shape, BF16), self._alloc(x.b.shape, BF16)
+            wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cout, cin))
+            ws = self._alloc((wsb // 4,), F32) if wsb else None      # split-K slices (small maps)
+            g2p, k1 = g2.ptr, x.k1
+
+            def dgrad_dual(*args):
+                Lb.conv3x3_next_dual_output(g2p, k1)
+                Lb.conv3x3_mfma_bf16_ws(*args)
+            self._emit(dgrad_dual, dY.ptr, wd.ptr, g1.ptr, None, 0, None, ws.ptr if ws else None, wsb, B, H, Wd, cout, cin, S,
+                       tag="conv3x3_mfma_dgrad", flops=18.0 * cin * cout * B * H * Wd)
+            for t, gb in ((ta, g1), (tb, g2)):
+                if self.req.get(t, False):
+                    self._add_grad(t, buf=gb)
+        elif self.req.get(xin, False):
             if sv.get("norm_head"):              # no data-gradient launch: the producer's norm backward forms dA = dY W^T itself
                 self._add_grad(xin, buf=HeadGrad(self.val[xin], dY, self.store.ptr(W), cout))
             elif sv.get("head1x1"):

@@ -197,3 +197,41 @@ def test_training_plan_with_fused_edges_equals_unfused_plan(norm, monkeypatch):
     for name in p0:                                    # batch-norm moving statistics: updated by the fused launches as by the apply pass
         if "moving_" in name:
             np.testing.assert_allclose(p1[name], p0[name], rtol=1e-2, atol=3e-3)     # (a missing or doubled update moves them by ~1e-2)
+
+
+@pytest.mark.parametrize("switch,off,on,norm", [("PHX_DUAL", "0", "1", "group_norm"), ("PHX_DUAL", "0", "1", None),
+                                               ("PHX_FBN_MAXP", "0", "4096", None)])
+def test_training_plan_concat_free_and_one_launch_layers_equal_the_plain_plan(switch, off, on, norm, monkeypatch):
+    """The bf16 training plan of phiseg_7_5 (n0 = 32, 128 x 128, batch 2) with concat-free convolutions (PHX_DUAL: the twelve
+    tf.concat -> conv2D edges of posteriors.py:87,120 / priors.py:112 / likelihoods.py:210 read and write their two tensors in place)
+    and with one-launch conv + batch norm layers on the small maps (PHX_FBN_MAXP) against the plan without them: same weights, inputs,
+    noise.  Concat-free is the same arithmetic (forward / data gradient bit-equal per layer, filter gradients up to summation order):
+    under group norm the loss agrees to 1e-4 and the gradients to 1 %."""
+    from tests.test_model_gpu import _lidc_setup
+    res = {}
+    for v in (off, on):
+        monkeypatch.setenv(switch, v)
+        cfg, model, params, x_np, s_np = _lidc_setup("bf16", perturbed=True, norm=norm)
+        plan = model.sess.plan_for([model.loss_tot], True, cfg["B"], True)
+        plan.set_input("x_input", x_np)
+        plan.set_input("s_input", s_np)
+        model.sess.store.set_lr(0.0)
+        plan.run()
+        plan.sync()
+        res[v] = (float(plan.fetch(model.loss_tot)), model.sess.store.export(grads=True), len(plan.launches), model.sess.store.export())
+    l0, g0, n0, p0 = res[off]
+    l1, g1, n1, p1 = res[on]
+    assert n1 <= n0 - 12, (n0, n1)
+    sharp = norm is not None
+    assert abs(l1 - l0) <= (1e-4 if sharp else 2e-2) * abs(l0), (l0, l1)
+    errs = []
+    for name, ga in g0.items():
+        nrm = np.linalg.norm(ga)
+        if nrm < 1e-8 * max(1.0, np.sqrt(ga.size)):
+            continue
+        errs.append(np.linalg.norm(g1[name] - ga) / nrm)
+    assert len(errs) >= 360
+    assert np.mean(errs) <= (0.01 if sharp else 0.5), np.mean(errs)
+    for name in p0:
+        if "moving_" in name:
+            np.testing.assert_allclose(p1[name], p0[name], rtol=1e-2, atol=3e-3)

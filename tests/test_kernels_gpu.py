@@ -1283,3 +1283,98 @@ def test_conv3x3_fused_batch_norm_one_launch(L, case, act):
         cnt = acc[2 * N:].view(torch.int32).cpu().numpy()
         bn = L.conv3x3_fbn_supported(B, H, W, K, N)
         assert (cnt[:N // bn] == cnt[0]).all() and cnt[0] >= 1 and (cnt[N // bn:] == 0).all()
+
+
+@pytest.mark.parametrize("case", [(64, 4, 4, 192, 64, 192), (64, 8, 8, 192, 64, 192), (16, 16, 16, 192, 64, 192), (8, 16, 16, 192, 192, 192),
+                                  (4, 32, 32, 128, 64, 128), (3, 32, 32, 128, 128, 192), (64, 2, 2, 192, 64, 96), (2, 16, 32, 32, 32, 128),
+                                  (1, 32, 64, 64, 64, 192), (2, 16, 32, 64, 32, 96)])
+@pytest.mark.parametrize("force_dma", [0, 1])
+def test_conv3x3_concat_free(L, case, force_dma, monkeypatch):
+    """Concat-free convolution (tf.concat([a, b], axis=3) -> conv2D 3x3: posteriors.py:87,120, priors.py:112, likelihoods.py:210):
+    forward with a dual input, data gradient with a dual output and the filter gradient with a dual input equal the same launches on
+    the materialised concatenation (forward / data gradient bit for bit), and the forward pass matches the oracle's concat + conv."""
+    from oracle import tf1_ops as O
+    B, H, W, K1, K2, N = case
+    if force_dma:
+        if H % 16 or W % 32:
+            pytest.skip("16 x 32-pixel tiles only")
+        monkeypatch.setenv("PHX_FWD_WS", "5")
+    monkeypatch.setenv("PHX_FWD_DB", "0")
+    K = K1 + K2
+    xa, xb = RNG.standard_normal((B, H, W, K1)), RNG.standard_normal((B, H, W, K2))
+    w = RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K)
+    dy = RNG.standard_normal((B, H, W, N))
+    xad, xbd, wd, dyd = dev(xa, BF16), dev(xb, BF16), dev(w), dev(dy, BF16)
+    xcd = torch.cat([xad, xbd], dim=3).contiguous()
+    wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    wg = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    L.pack_conv3x3_bf16(wd.data_ptr(), wf.data_ptr(), wg.data_ptr(), K, N, S())
+
+    def ws_for(k, n):
+        nb = int(L.conv3x3_mfma_ws_bytes(B, H, W, k, n))
+        t = torch.empty(max(nb // 4, 1), dtype=torch.float32).cuda()
+        return (t.data_ptr() if nb else None), nb, t
+    # forward
+    wp, wb, _k1 = ws_for(K, N)
+    y_ref, y = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda(), torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
+    L.conv3x3_mfma_bf16_ws(xcd.data_ptr(), wf.data_ptr(), y_ref.data_ptr(), None, 0, None, wp, wb, B, H, W, K, N, S())
+    L.conv3x3_next_dual_input(xbd.data_ptr(), K1)
+    L.conv3x3_mfma_bf16_ws(xad.data_ptr(), wf.data_ptr(), y.data_ptr(), None, 0, None, wp, wb, B, H, W, K, N, S())
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref)
+    ref = O.conv2d_same(torch.cat([rounded(xa, BF16), rounded(xb, BF16)], dim=3), rounded(w, BF16))
+    close(host(y), ref.numpy(), 1.5e-2, "dual forward vs oracle concat + conv")
+    # the modifier is one-shot: the next launch is an ordinary one again
+    y2 = torch.empty_like(y)
+    L.conv3x3_mfma_bf16_ws(xcd.data_ptr(), wf.data_ptr(), y2.data_ptr(), None, 0, None, wp, wb, B, H, W, K, N, S())
+    assert torch.equal(y2, y_ref)
+    # data gradient: d(concat) = conv(dy, flipped filter), written as two tensors
+    wp, wb, _k2 = ws_for(N, K)
+    dx_ref = torch.empty(B, H, W, K, dtype=torch.bfloat16).cuda()
+    L.conv3x3_mfma_bf16_ws(dyd.data_ptr(), wg.data_ptr(), dx_ref.data_ptr(), None, 0, None, wp, wb, B, H, W, N, K, S())
+    g1 = torch.full((B, H, W, K1), 7.0, dtype=torch.bfloat16).cuda()
+    g2 = torch.full((B, H, W, K2), 7.0, dtype=torch.bfloat16).cuda()
+    L.conv3x3_next_dual_output(g2.data_ptr(), K1)
+    L.conv3x3_mfma_bf16_ws(dyd.data_ptr(), wg.data_ptr(), g1.data_ptr(), None, 0, None, wp, wb, B, H, W, N, K, S())
+    torch.cuda.synchronize()
+    assert torch.equal(g1, dx_ref[..., :K1]) and torch.equal(g2, dx_ref[..., K1:])
+    # filter gradient
+    nb = int(L.conv3x3_wgrad_ws_bytes(B, H, W, K, N))
+    nbd = int(L.conv3x3_wgrad_ws_bytes_dual(B, H, W, K, N, K1))
+    wsr, wsd = torch.empty(max(nb // 4, 1), dtype=torch.float32).cuda(), torch.empty(max(nbd // 4, 1), dtype=torch.float32).cuda()
+    dw_ref, dw = torch.zeros(9 * K * N, dtype=torch.float32).cuda(), torch.zeros(9 * K * N, dtype=torch.float32).cuda()
+    L.conv3x3_wgrad_mfma_bf16(xcd.data_ptr(), dyd.data_ptr(), dw_ref.data_ptr(), wsr.data_ptr(), nb, B, H, W, K, N, S())
+    L.conv3x3_wgrad_mfma_bf16_dual(xad.data_ptr(), xbd.data_ptr(), K1, dyd.data_ptr(), dw.data_ptr(), wsd.data_ptr(), nbd, B, H, W, K, N, 1, S())
+    close(host(dw), host(dw_ref), 2e-5, "dual filter gradient")
+
+
+def test_conv3x3_concat_free_statistics_and_fused_norm(L):
+    """the dual-input modifier composes with the statistics epilogues and the one-launch conv + batch norm"""
+    B, H, W, K1, K2, N = 64, 4, 4, 192, 64, 192
+    K = K1 + K2
+    xad, xbd = dev(RNG.standard_normal((B, H, W, K1)), BF16), dev(RNG.standard_normal((B, H, W, K2)), BF16)
+    xcd = torch.cat([xad, xbd], dim=3).contiguous()
+    wd = dev(RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K))
+    wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    wg = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    L.pack_conv3x3_bf16(wd.data_ptr(), wf.data_ptr(), wg.data_ptr(), K, N, S())
+    outs = []
+    for dual in (False, True):
+        y, a = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda(), torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
+        acc = torch.zeros(N * 2 + 64, dtype=torch.float32).cuda()
+        sums = torch.zeros(N, 2, dtype=torch.float32).cuda()
+        g_, b_ = torch.ones(N).cuda(), torch.zeros(N).cuda()
+        vec = [torch.empty(N, dtype=torch.float32).cuda() for _ in range(4)]
+        if dual:
+            L.conv3x3_next_dual_input(xbd.data_ptr(), K1)
+        L.conv3x3_mfma_bf16_fbn((xad if dual else xcd).data_ptr(), wf.data_ptr(), y.data_ptr(), a.data_ptr(), acc.data_ptr(), acc.data_ptr() + N * 8,
+                                g_.data_ptr(), b_.data_ptr(), 1e-3, *[v.data_ptr() for v in vec], None, None, 0.0, 1, B, H, W, K, N, S())
+        y2 = torch.empty_like(y)
+        if dual:
+            L.conv3x3_next_dual_input(xbd.data_ptr(), K1)
+        L.conv3x3_mfma_bf16_stats_atomic((xad if dual else xcd).data_ptr(), wf.data_ptr(), y2.data_ptr(), None, 0, sums.data_ptr(), B, H, W, K, N, S())
+        torch.cuda.synchronize()
+        outs.append((y, a, y2, host(sums)))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][0], outs[0][2])
+    close(host(outs[1][1]), host(outs[0][1]), 1e-2, "fused norm output")
+    close(outs[1][3], outs[0][3], 2e-5, "statistics")
