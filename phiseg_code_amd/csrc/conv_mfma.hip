@@ -31,6 +31,7 @@
 struct MTile {
     int tws, ths, tb, tiles_x, tiles_y, tiles_b;
     unsigned mpw, mpp;      // ceil(2^20 / (tw + 2)), ceil(2^20 / ((tw + 2) (th + 2))): exact quotients for dividends < 4096
+    int rpitch, ipitch;     // forward / data-gradient LDS image of the small-map tiles: bytes per patch row / per image patch
 };
 // halo-patch index -> (x, y, batch) by multiply-shift: a runtime integer division costs ~40 instructions, and the staging
 // plans of the small-map tiles do three per 16-byte piece (48 per thread -- microseconds of a launch that has 1 us of MFMAs)
@@ -38,6 +39,19 @@ static void mtile_magic(MTile* g) {
     const unsigned pw = (1u << g->tws) + 2, ph = (1u << g->ths) + 2;
     g->mpw = ((1u << 20) + pw - 1) / pw;
     g->mpp = ((1u << 20) + pw * ph - 1) / (pw * ph);
+    // LDS pitches of the packed small-map tiles (several images per 256-pixel tile).  A ds_read_b128 is served in the 16-lane groups
+    // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (x 2 half waves) and is conflict-free when a group's 16 pixels fall on the 16 different
+    // 16-byte slots of a 256-byte bank row.  With 80-byte pixels (slot 5 x mod 16) the DENSE images are 3- to 4-way conflicted (a
+    // group spans two to four tile rows / images whose slot sets collide: measured 50-55 % of the LDS cycles, and the operand reads
+    // are what bounds these kernels); padded to the pitches below -- found by enumeration -- every group is a permutation.
+    g->rpitch = (int)pw * ROWB;
+    g->ipitch = (int)ph * g->rpitch;
+    static int pad = -1;
+    if (pad < 0) { const char* e = getenv("PHX_LDS_PAD"); pad = e ? atoi(e) : 1; }      // A/B hook (0: dense images)
+    if (!pad) return;
+    if (g->tws == 3 && g->ths == 3) { g->rpitch = 56 * 16; g->ipitch = 560 * 16; }
+    else if (g->tws == 2 && g->ths == 2) { g->rpitch = 36 * 16; g->ipitch = 224 * 16; }
+    else if (g->tws == 1 && g->ths == 1) { g->rpitch = 22 * 16; g->ipitch = 92 * 16; }
 }
 __device__ __forceinline__ void patch_coords(const MTile& g, int pp, int pw, int ph, int* px, int* py, int* pb) {
     // (24-bit multiplies: full rate, v_mul_lo_u32 is quarter rate; every operand here is < 2^21)
@@ -291,8 +305,12 @@ constexpr int XF_TBL_BYTES = 4096;      // LDS scale / shift table in front of t
 // a = act(y * scale + shift) from the accumulators they still hold -- no statistics / split-K-finish / apply launches, and nothing
 // but atomics crosses the XCDs' L2s (a bulk hand-off would need an L2 write-back: 38 us).  xf carries the
 // normalisation's arguments (sums, gamma, beta, eps, invP, act, a_out, the published vectors, the moving statistics, counter).
-template <int BN, int NA, bool FAST16, bool BIASACT, int NW, bool SPLITK, bool XF = false, bool FBN = false>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const unsigned short* __restrict__ x,
+// DUAL (struct Dual; its own instantiations, so that the ordinary launches carry neither the second plan nor the selects): the
+// second offset plan ga2 addresses du.x2, every prefetched chunk picks its tensor by a scalar compare; the epilogue stores by piece.
+template <int BN, int NA, bool FAST16, bool BIASACT, int NW, bool SPLITK, bool XF = false, bool FBN = false, bool DUAL = false>
+// (NA = 16 -- the 4 x 4 x 16 / 2 x 2 x 64 tiles of the H <= 4 levels: at most a few dozen blocks per launch -- is compiled for one
+// block per CU: 96 staging registers + plan + accumulators do not fit 256, and the spills went to scratch memory)
+__global__ __launch_bounds__(NW * 64, (NW == 8 || NA > 8) ? 1 : 2) void k_conv3x3_mfma(const unsigned short* __restrict__ x,
                                                          const unsigned short* __restrict__ wpk,
                                                          unsigned short* __restrict__ y, const float* __restrict__ bias,
                                                          int act, float* __restrict__ stats_partial, int B, int H, int W,
@@ -308,8 +326,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
     unsigned char* sA = smem;                    // [npatch][ROWB]
     // (the 512-pixel x 32-channel variant measured 12 % slower with the padded pitch -- it keeps the dense one)
     constexpr int P16 = (NW == 8 && BN == 32) ? 18 * ROWB : PITCH16;
-    const int pitch = FAST16 ? P16 : pw * ROWB;
-    unsigned char* sB = smem + (FAST16 ? (NT / 16 + 2) * P16 : npatch * ROWB);    // [9][BN][ROWB]
+    const int pitch = FAST16 ? P16 : g.rpitch;
+    unsigned char* sB = smem + (FAST16 ? (NT / 16 + 2) * P16 : g.tb * g.ipitch);    // [9][BN][ROWB]
 
     // Linear block id -> (pixel tile, channel block).  Work-groups go round-robin over the 8 XCDs (id % 8), each with its
     // own L2: the N / BN channel blocks of a tile get ids 8 apart -- same XCD, dispatched back to back -- so the input
@@ -341,7 +359,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
     for (int i = 0; i < 2; ++i) {
         const int m = wave * 64 + i * 32 + l31;
         const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
-        aoff[i] = (lb * ph + ly) * pitch + lx * ROWB + khalf * 16;
+        aoff[i] = (FAST16 ? (lb * ph + ly) * pitch : lb * g.ipitch + ly * pitch) + lx * ROWB + khalf * 16;
     }
     const int boff = l31 * ROWB + khalf * 16;
 
@@ -349,32 +367,40 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
     // 0xffffffff = outside the image / batch / slab -> the buffer range check returns zeros, so the prefetch is
     // branch-free and can be interleaved with the MFMAs of the running chunk.
     unsigned ga[NA];
+    unsigned ga2[DUAL ? NA : 1];                 // DUAL: the same pieces in du.x2 (pixel stride K - K1)
+    unsigned sa[FAST16 ? 1 : NA];                // small-map tiles: LDS byte offset of the piece's pixel (padded pitches, see mtile_magic)
     unsigned wmask = 0;                          // XF: pieces whose transformed value this thread also writes to a_out
-    auto make_plan = [&](const int Ks) {         // Ks: pixel stride (channels) of the tensor the patch is read from
+    const int K1 = (DUAL && du.x2 != nullptr) ? du.K1 : K;      // channels (= pixel stride) of x
 #pragma unroll
-        for (int it = 0; it < NA; ++it) {
-            const int i = threadIdx.x + it * NT;
-            const int q = i & 3, pp = i >> 2;
-            ga[it] = 0xffffffffu;
-            if (pp < npatch) {
-                // 16-wide tiles: the patch is 18 wide -> compile-time divisors (runtime division costs ~40 instructions)
-                int px, py, pb;
-                if constexpr (FAST16) { px = pp % 18; py = pp / 18; pb = 0; }
-                else patch_coords(g, pp, pw, ph, &px, &py, &pb);
-                const int gx = tx0 + px - 1, gy = ty0 + py - 1, gbi = b0 + pb;
-                const bool in = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && gbi < B;
-                unsigned off;
-                if constexpr (FAST16) off = (unsigned)((((gbi * H + gy) * W + gx) * Ks + q * 8) * 2);
-                else {                                             // small maps: B * H * W < 2^24 (checked by the launcher)
-                    const unsigned pix = __umul24(__umul24((unsigned)gbi, (unsigned)H) + gy, (unsigned)W) + gx;
-                    off = (__umul24(pix, (unsigned)Ks) + q * 8) * 2;
-                }
-                ga[it] = in ? off : 0xffffffffu;
-                if constexpr (XF)
-                    if (in && cob == 0 && xf.a_out != nullptr && px >= 1 && px <= tw && py >= 1 && py <= th) wmask |= 1u << it;
+    for (int it = 0; it < NA; ++it) {
+        const int i = threadIdx.x + it * NT;
+        const int q = i & 3, pp = i >> 2;
+        ga[it] = 0xffffffffu;
+        if constexpr (DUAL) ga2[it] = 0xffffffffu;
+        if constexpr (!FAST16) sa[it] = 0;
+        if (pp < npatch) {
+            // 16-wide tiles: the patch is 18 wide -> compile-time divisors (runtime division costs ~40 instructions)
+            int px, py, pb;
+            if constexpr (FAST16) { px = pp % 18; py = pp / 18; pb = 0; }
+            else patch_coords(g, pp, pw, ph, &px, &py, &pb);
+            if constexpr (!FAST16) sa[it] = (unsigned)(pb * g.ipitch + py * g.rpitch + px * ROWB);
+            const int gx = tx0 + px - 1, gy = ty0 + py - 1, gbi = b0 + pb;
+            const bool in = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H && gbi < B;
+            unsigned off, off2 = 0;
+            if constexpr (FAST16) {
+                off = (unsigned)((((gbi * H + gy) * W + gx) * K1 + q * 8) * 2);
+                if constexpr (DUAL) off2 = (unsigned)((((gbi * H + gy) * W + gx) * (K - K1) + q * 8) * 2);
+            } else {                                           // small maps: B * H * W < 2^24 (checked by the launcher)
+                const unsigned pix = __umul24(__umul24((unsigned)gbi, (unsigned)H) + gy, (unsigned)W) + gx;
+                off = (__umul24(pix, (unsigned)K1) + q * 8) * 2;
+                if constexpr (DUAL) off2 = (__umul24(pix, (unsigned)(K - K1)) + q * 8) * 2;
             }
+            ga[it] = in ? off : 0xffffffffu;
+            if constexpr (DUAL) ga2[it] = in ? off2 : 0xffffffffu;
+            if constexpr (XF)
+                if (in && cob == 0 && xf.a_out != nullptr && px >= 1 && px <= tw && py >= 1 && py <= th) wmask |= 1u << it;
         }
-    };
+    }
     // filter-slab pieces: piece `it` of a thread lies it * 64 slab rows further on, i.e. a fixed byte stride -> one VGPR
     // offset plus a scalar stride (gbl: the last piece, only partly populated when 9 * BN * 4 is not a multiple of NT)
     unsigned gb0, gbl;
@@ -388,15 +414,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
     static_assert(NT / 4 % BN == 0, "slab piece stride must be whole taps");
     const int gbs = (NT / 4 / BN) * N * 64;
     const int gcs = 9 * N * 64;                   // bytes per 32-channel chunk of the packed filter
-    // source tensor of the running chunks: x (channels [0, K1)) or du.x2 (channels [K1, K)); cbase = first channel of the source
-    const int K1 = du.x2 ? du.K1 : K;
-    __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K1 * 2u), 0x00020000);
-    int cbase = 0;
-    auto second_source = [&]() {
-        rsx = __builtin_amdgcn_make_buffer_rsrc((void*)du.x2, 0, (int)((unsigned)B * H * W * (K - K1) * 2u), 0x00020000);
-        cbase = K1;
-        make_plan(K - K1);
-    };
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K1 * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? du.x2 : x), 0, DUAL ? (int)((unsigned)B * H * W * (K - K1) * 2u) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, (int)(9u * N * K * 2u), 0x00020000);
 
     f32x16 acc[2][NJ];
@@ -417,7 +436,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
     auto prefetch_piece = [&](auto idxc, int c0) {
         constexpr int idx = decltype(idxc)::value;
         if constexpr (PHX_ABLATE & 1) return;
-        if constexpr (idx < NA) ra[idx] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ga[idx], (c0 - cbase) * 2, 0);
+        if constexpr (idx < NA) {
+            if constexpr (DUAL) {
+                if (c0 >= K1) ra[idx] = __builtin_amdgcn_raw_buffer_load_b128(rsx2, ga2[idx], (c0 - K1) * 2, 0);
+                else ra[idx] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ga[idx], c0 * 2, 0);
+            } else ra[idx] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ga[idx], c0 * 2, 0);
+        }
         else if constexpr (idx < NA + NB)
             rb[idx - NA] = __builtin_amdgcn_raw_buffer_load_b128(rsw, idx - NA == NB - 1 ? gbl : gb0, (c0 >> 5) * gcs + (idx - NA) * gbs, 0);
     };
@@ -428,7 +452,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
         cbeg = blockIdx.z * per * KC;
         cend = min(K, cbeg + per * KC);
     }
-    if (cbeg >= K1) second_source(); else make_plan(K1);
     {
         auto all = [&](auto self, auto idxc) {
             constexpr int idx = decltype(idxc)::value;
@@ -528,7 +551,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
         for (int it = 0; it < NA; ++it) {
             const int i = threadIdx.x + it * NT;
             const int pp = i >> 2;
-            const int so = FAST16 ? (pp / 18) * (P16 - 18 * ROWB) + pp * ROWB : pp * ROWB;
+            const int so = FAST16 ? (pp / 18) * (P16 - 18 * ROWB) + pp * ROWB : (int)sa[FAST16 ? 0 : it];
             if (!(PHX_ABLATE & 2) && pp < npatch) *reinterpret_cast<u32x4*>(sA + so + (i & 3) * 16) = ra[it];
         }
 #pragma unroll
@@ -590,10 +613,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
     {
         const int cx0 = tx0, cy0 = ty0, cb0 = b0;
         const bool tr0 = true;
-        for (int c0 = cbeg; c0 + KC < cend; c0 += KC) {
-            if (c0 + KC == K1) second_source();          // (the chunk being prefetched is the first of x2)
-            chunk(c0, c0 + KC, std::true_type(), c0 == KC);
-        }
+        for (int c0 = cbeg; c0 + KC < cend; c0 += KC) chunk(c0, c0 + KC, std::true_type(), c0 == KC);
         chunk(cend - KC, 0, std::false_type(), K == 2 * KC);
         if constexpr (SPLITK) {
             // fp32 partial tile -> ws[z][pixel][N]; C layout: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -668,10 +688,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
             // (dual destination: the piece's eight channels lie in y (row length N1) or in du.y2 (row length N - N1))
             unsigned short* ybase = y;
             int yld = N, ych = n0 + q * 8;
-            if (du.y2) {
-                if (ych < du.N1) yld = du.N1;
-                else { ybase = du.y2; yld = N - du.N1; ych -= du.N1; }
-            }
+            if constexpr (DUAL)
+                if (du.y2) {
+                    if (ych < du.N1) yld = du.N1;
+                    else { ybase = du.y2; yld = N - du.N1; ych -= du.N1; }
+                }
             unsigned short* yp = ybase + (((size_t)cb0 * H + cy0 + (mt >> 4)) * W + cx0 + (mt & 15)) * yld + ych;
             const size_t ystep = (size_t)(NT / PPP / 16) * W * yld;
             if (bws.part == nullptr) {
@@ -752,10 +773,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
                     const uint4 v = *reinterpret_cast<const uint4*>(smem + m * OROW + q * 16);
                     unsigned short* ybase = y;
                     int yld = N, ych = n0 + q * 8;
-                    if (du.y2) {
-                        if (ych < du.N1) yld = du.N1;
-                        else { ybase = du.y2; yld = N - du.N1; ych -= du.N1; }
-                    }
+                    if constexpr (DUAL)
+                        if (du.y2) {
+                            if (ych < du.N1) yld = du.N1;
+                            else { ybase = du.y2; yld = N - du.N1; ych -= du.N1; }
+                        }
                     *reinterpret_cast<uint4*>(ybase + (((size_t)ob * H + oy) * W + ox) * yld + ych) = v;
                 }
             }
@@ -857,7 +879,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void k_conv3x3_mfma(const
 }
 
 // ---- the same 128-pixel wave tiles without loader waves: one 75 KiB stage per block, TWO blocks per CU -----------------
-template <bool BIASACT, int DBG, int BN>
+template <bool BIASACT, int DBG, int BN, bool DUAL = false>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned short* __restrict__ x,
                                                              const unsigned short* __restrict__ wpk,
                                                              unsigned short* __restrict__ y, const float* __restrict__ bias,
@@ -910,36 +932,31 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
     // DMA latency, prologue and epilogue run under the other block's MFMAs
     const int lw = wave;
     unsigned voff[NPL];
-    auto plan_patch = [&](const int Ks) {             // Ks: pixel stride (channels) of the tensor the patch is read from
-#pragma unroll
-        for (int n = 0; n < NPL; ++n) {
-            const int j = lw + NLW * n;
-            if (j < AI) {
-                voff[n] = 0xffffffffu;
-                const int e = j * 64 + lane, pp = e >> 2, slot = e & 3;
-                const int py = pp / 34, px = pp - py * 34;
-                const int piece = slot ^ ((px >> 2) & 3);
-                const int gx = tx0 + px - 1, gy = ty0 + py - 1;
-                if (pp < 612 && gx >= 0 && gx < W && gy >= 0 && gy < H && !(DBG & 1)) voff[n] = (unsigned)((((b0 * H + gy) * W + gx) * Ks) * 2 + piece * 16);
-            }
-        }
-    };
+    unsigned voff2[DUAL ? NPL : 1];                   // DUAL (struct Dual): the patch pieces in du.x2 (pixel stride K - K1)
+    const int K1 = (DUAL && du.x2 != nullptr) ? du.K1 : K;
 #pragma unroll
     for (int n = 0; n < NPL; ++n) {
         const int j = lw + NLW * n;
         voff[n] = 0xffffffffu;
-        if (j >= AI && j < NI) {
+        if constexpr (DUAL) voff2[n] = 0xffffffffu;
+        if (j < AI) {
+            const int e = j * 64 + lane, pp = e >> 2, slot = e & 3;
+            const int py = pp / 34, px = pp - py * 34;
+            const int piece = slot ^ ((px >> 2) & 3);
+            const int gx = tx0 + px - 1, gy = ty0 + py - 1;
+            if (pp < 612 && gx >= 0 && gx < W && gy >= 0 && gy < H && !(DBG & 1)) {
+                voff[n] = (unsigned)((((b0 * H + gy) * W + gx) * K1) * 2 + piece * 16);
+                if constexpr (DUAL) voff2[n] = (unsigned)((((b0 * H + gy) * W + gx) * (K - K1)) * 2 + piece * 16);
+            }
+        } else if (j < NI) {
             const int e = (j - AI) * 64 + lane, rb = e >> 2, slot = e & 3;
             const int tap = rb / BN, nn = rb % BN;
             const int piece = slot ^ ((nn >> 2) & 3);
             if (!(DBG & 2)) voff[n] = (unsigned)(((tap * N + n0 + nn) * 32 + piece * 8) * 2);
         }
     }
-    // (concat-free input, struct Dual: chunks [0, K1 / 32) come from x, the rest from du.x2)
-    const int K1 = du.x2 ? du.K1 : K;
-    plan_patch(K1);
-    __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K1 * 2u), 0x00020000);
-    int cb = 0;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K1 * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? du.x2 : x), 0, DUAL ? (int)((unsigned)B * H * W * (K - K1) * 2u) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, (int)(9u * N * K * 2u), 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     unsigned aK[3][2], bK[2];
@@ -952,16 +969,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
     for (int ks = 0; ks < 2; ++ks) bK[ks] = (unsigned)(A_BYTES + l31 * 64 + (((ks * 2 + khalf) ^ ((l31 >> 2) & 3)) << 4));
     for (int c = 0; c < nch; ++c) {
         if (c) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done reading the previous chunk
-        if (c * 32 == K1) {                           // second source tensor from here on
-            rsx = __builtin_amdgcn_make_buffer_rsrc((void*)du.x2, 0, (int)((unsigned)B * H * W * (K - K1) * 2u), 0x00020000);
-            cb = c;
-            plan_patch(K - K1);
-        }
 #pragma unroll
         for (int n = 0; n < NPL; ++n) {
             const int j = lw + NLW * n;
-            if (j < AI)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + j * 1024), 16, (int)voff[n], (c - cb) * 64, 0, 0);
+            if (j < AI) {
+                if constexpr (DUAL) {
+                    if (c * 32 >= K1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx2, (lds_ptr_t)(smem + j * 1024), 16, (int)voff2[n], c * 64 - K1 * 2, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + j * 1024), 16, (int)voff[n], c * 64, 0, 0);
+                } else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + j * 1024), 16, (int)voff[n], c * 64, 0, 0);
+            }
             else if (j < NI)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(smem + j * 1024), 16, (int)voff[n], c * 9 * N * 64, 0, 0);
         }
@@ -1052,10 +1069,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
         const unsigned char* lr = smem + mt * OROW + q * 16;
         unsigned short* ybase = y;                    // (dual destination, struct Dual)
         int yld = N, ych = n0 + q * 8;
-        if (du.y2) {
-            if (ych < du.N1) yld = du.N1;
-            else { ybase = du.y2; yld = N - du.N1; ych -= du.N1; }
-        }
+        if constexpr (DUAL)
+            if (du.y2) {
+                if (ych < du.N1) yld = du.N1;
+                else { ybase = du.y2; yld = N - du.N1; ych -= du.N1; }
+            }
         unsigned short* yp = ybase + (((size_t)b0 * H + ty0 + (mt >> 5)) * W + tx0 + (mt & 31)) * yld + ych;
         const size_t ystep = (size_t)(PSTEP / 32) * W * yld;
 #pragma unroll
@@ -1947,9 +1965,10 @@ int phx_conv3x3_mfma_bf16_fbn(const void* x, const void* wpk, void* y, void* a_o
     xf.moving_mean = moving_mean; xf.moving_var = moving_var; xf.momentum = momentum; xf.counter = (unsigned*)counters;
 #define FBN_LAUNCH(BNv, NAv, Fv)                                                                                        \
     do {                                                                                                                \
-        auto kfn = k_conv3x3_mfma<BNv, NAv, Fv, false, 4, false, false, true>;                                          \
+        auto kfn = du.x2 ? k_conv3x3_mfma<BNv, NAv, Fv, false, 4, false, false, true, true>                             \
+                         : k_conv3x3_mfma<BNv, NAv, Fv, false, 4, false, false, true, false>;                           \
         PHX_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));   \
-        size_t sh = (Fv ? (size_t)(4 * 4 + 2) * PITCH16 : (size_t)npatch * ROWB) + 9 * BNv * ROWB;                      \
+        size_t sh = (Fv ? (size_t)(4 * 4 + 2) * PITCH16 : (size_t)g.tb * g.ipitch) + 9 * BNv * ROWB;                    \
         const size_t she = (size_t)256 * (BNv * 2 + 16);                                                                \
         if (she > sh) sh = she;                                                                                         \
         hipLaunchKernelGGL(kfn, dim3(ntiles * (N / BNv)), dim3(256), sh, (hipStream_t)stream, (const unsigned short*)x, \
@@ -2013,22 +2032,35 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
         PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_dma128<Av, Dv, BNv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((k_conv3x3_fwd_dma128<Av, Dv, BNv>), dim3(ntl * (N / BNv)), dim3(256), 75 * 1024 + 16, (hipStream_t)stream, \
                            (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, \
-                           H, W, K, N, W / 32, H / 16, bws.oscale, bws.stats_atomic ? (bws.stats_nrep > 1 ? bws.stats_nrep : 1) : 0, du);                                                       \
+                           H, W, K, N, W / 32, H / 16, bws.oscale, bws.stats_atomic ? (bws.stats_nrep > 1 ? bws.stats_nrep : 1) : 0, Dual{});                                                       \
     } while (0)
 #define D128_LAUNCH(Av, Dv)                                                                                                     \
     do { if (N % 64 == 0) D128_LAUNCH1(Av, Dv, 64); else D128_LAUNCH1(Av, 0, 32); } while (0)
-        if (ba) D128_LAUNCH(true, 0);
+#define D128_DUAL(Av, BNv)                                                                                                      \
+    do {                                                                                                                        \
+        auto kfd = k_conv3x3_fwd_dma128<Av, 0, BNv, true>;                                                                      \
+        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)kfd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
+        hipLaunchKernelGGL(kfd, dim3(ntl * (N / BNv)), dim3(256), 75 * 1024 + 16, (hipStream_t)stream, (const unsigned short*)x, \
+                           (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, W / 32, H / 16, \
+                           bws.oscale, bws.stats_atomic ? (bws.stats_nrep > 1 ? bws.stats_nrep : 1) : 0, du);                  \
+    } while (0)
+        if (du.x2 != nullptr || du.y2 != nullptr) {
+            if (N % 64 == 0) { if (ba) D128_DUAL(true, 64); else D128_DUAL(false, 64); }
+            else { if (ba) D128_DUAL(true, 32); else D128_DUAL(false, 32); }
+        } else if (ba) D128_LAUNCH(true, 0);
         else switch (dbg) {
             case 1: D128_LAUNCH(false, 1); break; case 2: D128_LAUNCH(false, 2); break; case 3: D128_LAUNCH(false, 3); break;
             case 4: D128_LAUNCH(false, 4); break; default: D128_LAUNCH(false, 0);
         }
 #undef D128_LAUNCH1
 #undef D128_LAUNCH
+#undef D128_DUAL
         PHX_CHECK_LAUNCH();
         return PHX_OK;
     }
-    MTile g = make_mtile_fwd(B, H, W, K, N, false);
-    const bool big = fwd_big_tiles(B, H, W, K, N);
+    const bool dual = du.x2 != nullptr || du.y2 != nullptr;       // (DUAL instantiations exist for the 256-pixel tiles)
+    MTile g = dual ? make_mtile(B, H, W) : make_mtile_fwd(B, H, W, K, N, false);
+    const bool big = !dual && fwd_big_tiles(B, H, W, K, N);
     const int tw = 1 << g.tws, th = 1 << g.ths;
     const int npatch = g.tb * (th + 2) * (tw + 2);
     const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
@@ -2054,18 +2086,18 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
 #define CM_LAUNCH1(BNv, NAv, Fv, Av, NWv, Sv)                                                                          \
     do {                                                                                                             \
         size_t sh = (Fv ? (size_t)(NWv * 4 + 2) * ((NWv == 8 && BNv == 32) ? 18 * ROWB : PITCH16)                    \
-                        : (size_t)npatch * ROWB) + 9 * BNv * ROWB;                                                   \
+                        : (size_t)g.tb * g.ipitch) + 9 * BNv * ROWB;                                                 \
         const size_t she = (size_t)NWv * 64 * (BNv * 2 + 16);                                                        \
         if (she > sh) sh = she;                                                                                      \
         if (Sv)                                                                                                      \
             hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, false, NWv, Sv>), dim3(ntiles * (N / BNv), 1, ksplit),  \
                                dim3(NWv * 64), sh, (hipStream_t)stream, (const unsigned short*)x,                    \
                                (const unsigned short*)wpk, (unsigned short*)y, nullptr, 0, nullptr, B, H, W, K, N, g,\
-                               (float*)workspace, BwdStats{}, XForm{}, du);                                            \
+                               (float*)workspace, BwdStats{}, XForm{}, Dual{});                                        \
         else                                                                                                         \
             hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, Av, NWv, false>), dim3(ntiles * (N / BNv)), dim3(NWv * 64),\
                                sh, (hipStream_t)stream, (const unsigned short*)x, (const unsigned short*)wpk,        \
-                               (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, g, nullptr, bws, XForm{}, du); \
+                               (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, g, nullptr, bws, XForm{}, Dual{}); \
     } while (0)
 #define CM_LAUNCH(BNv, NAv, Fv, NWv)                                                                                 \
     do {                                                                                                             \
@@ -2080,7 +2112,31 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
     static int n32thr = -1;
     if (n32thr < 0) { const char* e = getenv("PHX_BN32_MAXBLOCKS"); n32thr = e ? atoi(e) : 256; }
     const bool narrow32 = N % 64 == 0 && !big && ksplit == 1 && ntiles * (N / 64) <= n32thr;
-    if (big) {
+#define CM_DUAL1(BNv, NAv, Fv, Av, Sv)                                                                                \
+    do {                                                                                                             \
+        size_t sh = (Fv ? (size_t)(4 * 4 + 2) * PITCH16 : (size_t)g.tb * g.ipitch) + 9 * BNv * ROWB;                  \
+        const size_t she = (size_t)256 * (BNv * 2 + 16);                                                             \
+        if (she > sh) sh = she;                                                                                      \
+        auto kfd = k_conv3x3_mfma<BNv, NAv, Fv, Av, 4, Sv, false, false, true>;                                      \
+        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)kfd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL(kfd, dim3(ntiles * (N / BNv), 1, Sv ? ksplit : 1), dim3(256), sh, (hipStream_t)stream,     \
+                           (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, Sv ? nullptr : bias, \
+                           Sv ? 0 : act, Sv ? nullptr : stats_partial, B, H, W, K, N, g, Sv ? (float*)workspace : nullptr, \
+                           Sv ? BwdStats{} : bws, XForm{}, du);                                                      \
+    } while (0)
+#define CM_DUAL(BNv, NAv, Fv)                                                                                        \
+    do {                                                                                                             \
+        if (ksplit > 1) CM_DUAL1(BNv, NAv, Fv, false, true);                                                         \
+        else if (biasact) CM_DUAL1(BNv, NAv, Fv, true, false);                                                       \
+        else CM_DUAL1(BNv, NAv, Fv, false, false);                                                                   \
+    } while (0)
+    if (dual) {                                      // concat-free input / output (struct Dual): the DUAL instantiations
+        if (N % 64 == 0 && !narrow32) {
+            if (fast16) CM_DUAL(64, 8, true); else if (na <= 8) CM_DUAL(64, 8, false); else CM_DUAL(64, 16, false);
+        } else {
+            if (fast16) CM_DUAL(32, 8, true); else if (na <= 8) CM_DUAL(32, 8, false); else CM_DUAL(32, 16, false);
+        }
+    } else if (big) {
         if (N % 128 == 0) CM_LAUNCH(128, 5, true, 8); else if (N % 64 == 0) CM_LAUNCH(64, 5, true, 8); else CM_LAUNCH(32, 5, true, 8);
     } else if (N % 64 == 0 && !narrow32) {
         if (fast16) CM_LAUNCH(64, 8, true, 4); else if (na <= 8) CM_LAUNCH(64, 8, false, 4); else CM_LAUNCH(64, 16, false, 4);
@@ -2089,6 +2145,8 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
     }
 #undef CM_LAUNCH
 #undef CM_LAUNCH1
+#undef CM_DUAL
+#undef CM_DUAL1
     PHX_CHECK_LAUNCH();
     if (ksplit > 1 && y != nullptr) {                // (y == NULL: the caller consumes the fp32 slices itself)
         const size_t total = (size_t)B * H * W * N;
@@ -2163,7 +2221,7 @@ int phx_conv3x3_mfma_bf16_xf(const void* y_prod, const void* wpk, void* y, const
     const bool fast16 = g.tws == 4 && g.ths == 4 && g.tb == 1;
 #define XF_LAUNCH1(BNv, NAv, Fv, Av, Sv)                                                                               \
     do {                                                                                                             \
-        size_t sh = (Fv ? (size_t)(4 * 4 + 2) * PITCH16 : (size_t)npatch * ROWB) + 9 * BNv * ROWB;                   \
+        size_t sh = (Fv ? (size_t)(4 * 4 + 2) * PITCH16 : (size_t)g.tb * g.ipitch) + 9 * BNv * ROWB;                 \
         const size_t she = (size_t)4 * 64 * (BNv * 2 + 16);                                                          \
         if (she > sh) sh = she;                                                                                      \
         sh += XF_TBL_BYTES;                                                                                          \

@@ -184,7 +184,7 @@ def test_training_plan_with_fused_edges_equals_unfused_plan(norm, monkeypatch):
                    model.sess.store.export())
     l0, g0, n0, p0 = res["0"]
     l1, g1, n1, p1 = res["1"]
-    assert n1 < n0 - 10, (n0, n1)                      # the fused plan really dropped its apply launches
+    assert n1 < n0 - 5, (n0, n1)                       # the fused plan really dropped its apply launches (the small maps run conv + batch norm in one launch anyway)
     assert abs(l1 - l0) <= 2e-2 * abs(l0), (l0, l1)
     errs = []
     for name, ga in g0.items():
