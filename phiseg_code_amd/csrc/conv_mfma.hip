@@ -308,9 +308,9 @@ constexpr int XF_TBL_BYTES = 4096;      // LDS scale / shift table in front of t
 // DUAL (struct Dual; its own instantiations, so that the ordinary launches carry neither the second plan nor the selects): the
 // second offset plan ga2 addresses du.x2, every prefetched chunk picks its tensor by a scalar compare; the epilogue stores by piece.
 template <int BN, int NA, bool FAST16, bool BIASACT, int NW, bool SPLITK, bool XF = false, bool FBN = false, bool DUAL = false>
-// (NA = 16 -- the 4 x 4 x 16 / 2 x 2 x 64 tiles of the H <= 4 levels: at most a few dozen blocks per launch -- is compiled for one
-// block per CU: 96 staging registers + plan + accumulators do not fit 256, and the spills went to scratch memory)
-__global__ __launch_bounds__(NW * 64, (NW == 8 || NA > 8) ? 1 : 2) void k_conv3x3_mfma(const unsigned short* __restrict__ x,
+// (NA = 16 -- the 4 x 4 x 16 / 2 x 2 x 64 tiles of the H <= 4 levels: at most a few dozen blocks per launch -- with the second plan of
+// the DUAL instantiations is compiled for one block per CU: 96 staging registers + two plans + accumulators do not fit 256)
+__global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) void k_conv3x3_mfma(const unsigned short* __restrict__ x,
                                                          const unsigned short* __restrict__ wpk,
                                                          unsigned short* __restrict__ y, const float* __restrict__ bias,
                                                          int act, float* __restrict__ stats_partial, int B, int H, int W,
