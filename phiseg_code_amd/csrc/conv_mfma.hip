@@ -222,6 +222,10 @@ __global__ void k_unpad_rows_acc(const float* __restrict__ dwp, float* __restric
 
 // double-buffered persistent kernel for large maps (conv_db.hip)
 bool phx_db_enabled();
+int phx_c32_set_trace(void* dev_buf);
+bool phx_c32_enabled();                       // conv_c32.hip: the 32 -> 32-channel layers on large maps (filter in registers, persistent)
+int phx_c32_launch(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial, int B, int H, int W,
+                   const float* oscale, int stats_nrep, void* stream);
 int phx_db_set_trace(void* dev_buf);
 int phx_db_partial_rows(int B, int H, int W);
 int phx_db_launch(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial, int B, int H,
@@ -1807,6 +1811,7 @@ int phx_unpad_filter_grad_center(const float* dw_pad, float* dw_1x1, int Cin, in
 
 int phx_debug_set_trace(void* dev_buf) {
     if (int rc = phx_db_set_trace(dev_buf)) return rc;
+    if (int rc = phx_c32_set_trace(dev_buf)) return rc;
     unsigned long long* p = (unsigned long long*)dev_buf;
     PHX_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phx_trace), &p, sizeof(p)));
     return PHX_OK;
@@ -2026,6 +2031,9 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
         const int ntl = B * (H / 16) * (W / 32);
         const char* dbe = getenv("PHX_DBG_ABLATE");   // dev: bit 1 no patch loads, 2 no slab loads, 4 no MFMAs
         const int dbg = dbe ? atoi(dbe) : 0;
+        if (K == 32 && N == 32 && dbg == 0 && !du.x2 && !du.y2 && phx_c32_enabled())
+            return phx_c32_launch(x, wpk, y, bias, act, stats_partial, B, H, W, bws.oscale,
+                                  bws.stats_atomic ? (bws.stats_nrep > 1 ? bws.stats_nrep : 1) : 0, stream);
         if (phx_db_enabled() && N % 64 == 0 && !bws.stats_atomic && !du.x2 && !du.y2) return phx_db_launch(x, wpk, y, bias, act, stats_partial, B, H, W, K, N, bws.oscale, dbg, stream);
 #define D128_LAUNCH1(Av, Dv, BNv)                                                                                               \
     do {                                                                                                                        \

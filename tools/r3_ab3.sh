@@ -1,0 +1,10 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT
+b() { python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --no-other-workloads 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print(round(d['value'],1), 'img/s', round(d['ms_per_step'],3), 'ms', d['config']['launches_per_step'])"; }
+for i in 1 2; do
+echo "== bench old"; (cd $R/_old_ab && b)
+echo "== bench new"; (cd $R && b)
+echo "== bench new, $1"; (cd $R && export $1 && b)
+done
