@@ -317,6 +317,12 @@ def main():
             "families": {k: {"tflops": v[0] / v[1] / 1e9, "ms_per_step": v[1], "launches": v[2]} for k, v in fam.items()},
             "conv_ms_per_step": sum(v[1] for v in fam.values()),
         }
+        # launches of the family that also carry the layer's batch norm (phx_conv3x3_mfma_bf16_fbn: statistics, rendezvous, second
+        # pass): counted in `achieved` with their whole duration, listed here so that the convolution-only part can be read off
+        fb = [(fl_, ms_) for tag, fl_, ms_, shp in rows if shp and shp[0] == "fbn"]
+        if fb:
+            out["roofline"]["fused_conv_bn_launches"] = {"launches": len(fb), "ms_per_step": sum(m for _, m in fb),
+                                                         "gflop_per_step": sum(f for f, _ in fb) / 1e9}
         if dom is not None:
             out["roofline"]["dominant_shape"] = {"B_H_W_K_N": list(dom[0]), "launches": dom[1][2], "ms_per_step": dom[1][1],
                                                  "tflops": dom[1][0] / dom[1][1] / 1e9,

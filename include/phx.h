@@ -135,6 +135,9 @@ int phx_conv3x3_wgrad_mfma_bf16_dual(const void* x, const void* x2, int K1, cons
  * phx_conv3x3_fbn_supported -> 0 when the launch would have more than PHX_FBN_MAXBLOCKS (192) blocks (all of them must be resident
  * at once) or in deterministic mode, else the channels per block. */
 int phx_conv3x3_fbn_supported(int B, int H, int W, int K, int N);
+/* number of blocks of ..._fbn launches that gave up waiting at the rendezvous since the library was loaded (synchronises the device;
+ * 0 unless a launch could not be co-resident -- its results are invalid then; the engine checks it whenever it fetches) */
+int phx_conv3x3_fbn_timeouts(int* count);
 int phx_conv3x3_mfma_bf16_fbn(const void* x, const void* wpk, void* y, void* a_out, float* sums, void* counters, const float* gamma,
                               const float* beta, float eps, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
                               float* moving_mean, float* moving_var, float momentum, int act, int B, int H, int W, int K, int N,

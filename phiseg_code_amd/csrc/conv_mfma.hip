@@ -232,6 +232,7 @@ int phx_db_launch(const void* x, const void* wpk, void* y, const float* bias, in
                   int W, int K, int N, const float* oscale, int dbg, void* stream);
 
 // ---- forward / dgrad ----------------------------------------------------------------------------------
+__device__ unsigned g_phx_fbn_timeouts = 0;                // FBN launches whose rendezvous gave up (phx_conv3x3_fbn_timeouts)
 __device__ unsigned long long* g_phx_trace = nullptr;      // debug: phase timestamps of block (0,0,0), thread 0
 __device__ unsigned long long* g_phx_blocklog = nullptr;   // debug: per-block {start, end, HW_ID | XCC_ID << 32, realtime}
 #define PHX_BLOCKLOG_BEGIN() const unsigned long long bl_t0 = g_phx_blocklog ? __builtin_readcyclecounter() : 0ull
@@ -828,6 +829,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
                 int spins = 0;                           // (bounded: a launch that cannot be co-resident must not hang the GPU)
                 while (__hip_atomic_load(xf.counter + cob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ntl && ++spins < (1 << 24))
                     __builtin_amdgcn_s_sleep(2);
+                if (spins >= (1 << 24)) atomicAdd(&g_phx_fbn_timeouts, 1u);      // the blocks were not co-resident: results are invalid
             }
             __syncthreads();
             float sc[NJ], sh[NJ];
@@ -1956,6 +1958,12 @@ static int fbn_plan(int B, int H, int W, int K, int N) {
     return 0;
 }
 int phx_conv3x3_fbn_supported(int B, int H, int W, int K, int N) { return fbn_plan(B, H, W, K, N); }
+int phx_conv3x3_fbn_timeouts(int* count) {
+    unsigned v = 0;
+    PHX_CHECK_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_phx_fbn_timeouts), sizeof(v)));
+    *count = (int)v;
+    return PHX_OK;
+}
 int phx_conv3x3_mfma_bf16_fbn(const void* x, const void* wpk, void* y, void* a_out, float* sums, void* counters, const float* gamma,
                               const float* beta, float eps, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
                               float* moving_mean, float* moving_var, float momentum, int act, int B, int H, int W, int K, int N,

@@ -74,6 +74,10 @@ _NORM_HEAD = os.environ.get("PHX_NORM_HEAD", "1") == "1"     # a 1x1 head that i
 # the blocks meet at an arrival counter inside the launch) for layers of up to PHX_FBN_MAXP pixels (B * H * W); 0: off (A/B hook)
 def _fbn_maxp():
     return int(os.environ.get("PHX_FBN_MAXP", "4096"))      # (read when a plan is built)
+
+
+def _fbn_maxk():
+    return int(os.environ.get("PHX_FBN_MAXK", str(1 << 20)))      # ... and at most this many input channels (experiments)
 def _dual_enabled():
     return os.environ.get("PHX_DUAL", "1") == "1"      # concat -> conv3x3 edges without the concatenated tensor (A/B hook; read when a plan is built)
 _LATENT_FUSED = os.environ.get("PHX_LATENT_FUSED", "1") == "1"     # mu / sigma heads + reparameterisation of a level in one launch each way (A/B hook)
@@ -1159,7 +1163,7 @@ class Plan:
             conv_into(y, 0)
             self._emit(Lb.affine_act, y.ptr, y.dt, scale.ptr, shift.ptr, out.ptr, out.dt, NS, P, cout, act, S)
         else:
-            if (norm == "batch" and training and mfma and not head1x1 and not xf and P <= _fbn_maxp() and not _DETERMINISTIC
+            if (norm == "batch" and training and mfma and not head1x1 and not xf and P <= _fbn_maxp() and cin_eff <= _fbn_maxk() and not _DETERMINISTIC
                     and y.dt == BF16 and out.dt == BF16 and x.dt == BF16 and Lb.conv3x3_fbn_supported(B, H, Wd, cin_eff, cout)):
                 # small maps: convolution, batch statistics, normalisation and activation in one launch
                 upd = self.loss is not None
@@ -1168,7 +1172,7 @@ class Plan:
                            mean.ptr, rstd.ptr, scale.ptr, shift.ptr,
                            self.store.ptr(nv["moving_mean"]) if upd else None, self.store.ptr(nv["moving_variance"]) if upd else None,
                            (1.0 - tfnorm.BN_DECAY) if upd else 0.0, act, B, H, Wd, cin_eff, cout, S,
-                           tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
+                           tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd, shape=("fbn", B, H, Wd, cin_eff, cout))
                 st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn,
                           bn_small=bool(P <= _BN_SMALL and Lb.bn_small_supported(P, cout, BF16)))
                 self.saved[op] = st
@@ -2078,8 +2082,16 @@ class Plan:
         self.L.event_destroy(ev1)
         return out
 
+    def _check_rendezvous(self):
+        n = ctypes.c_int(0)
+        self.L.conv3x3_fbn_timeouts(ctypes.byref(n))
+        if n.value:
+            raise rt.PhxError("%d block(s) of one-launch conv + batch-norm layers timed out at their rendezvous (the launch was not "
+                              "co-resident: another process on this GPU?) -- results are invalid; set PHX_FBN_MAXP=0" % n.value)
+
     def fetch(self, t):
         self.sync()
+        self._check_rendezvous()
         b = self.val[t]
         a = b.numpy()
         if b.shift:                     # nearest-neighbour view (likelihoods.py:221): expand on the host

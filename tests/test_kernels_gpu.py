@@ -1283,6 +1283,10 @@ def test_conv3x3_fused_batch_norm_one_launch(L, case, act):
         cnt = acc[2 * N:].view(torch.int32).cpu().numpy()
         bn = L.conv3x3_fbn_supported(B, H, W, K, N)
         assert (cnt[:N // bn] == cnt[0]).all() and cnt[0] >= 1 and (cnt[N // bn:] == 0).all()
+    import ctypes
+    nto = ctypes.c_int(-1)
+    L.conv3x3_fbn_timeouts(ctypes.byref(nto))
+    assert nto.value == 0                                               # no block ever gave up at the rendezvous
 
 
 @pytest.mark.parametrize("case", [(64, 4, 4, 192, 64, 192), (64, 8, 8, 192, 64, 192), (16, 16, 16, 192, 64, 192), (8, 16, 16, 192, 192, 192),
