@@ -614,7 +614,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
         if (tr) PHX_TRACE(4);
     };
     const int odd = lane & 1;
-    constexpr int OROW = BN * 2 + 16;
+    // Epilogue tile [pixel][BN] bf16 in LDS.  32 / 64-channel blocks: DENSE rows -- a lane group of the 16-byte read-back covers all 16
+    // slots of a bank row, and the 32-bit writes of a lane pair's four rows (r, r + 1, r + 4, r + 5) hit every bank twice, the
+    // minimum for 64 lanes; for 64-channel blocks that needs the 16-byte piece index XORed with 4 * (row & 1) (rows r and r + 1
+    // would share their 16 banks otherwise).  The padded rows used before (80 / 144 bytes) were two- to three-way conflicted on
+    // the read-back (23 % of these kernels' LDS cycles).  128-channel blocks keep the padded pitch.
+    constexpr int OROW = BN == 128 ? BN * 2 + 16 : BN * 2;
+    constexpr int OSWZ = BN == 64 ? 64 : 0;               // byte XOR (piece bit 2) applied on odd rows
     {
         const int cx0 = tx0, cy0 = ty0, cb0 = b0;
         const bool tr0 = true;
@@ -682,20 +688,20 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
         const bool full = (cx0 + tw) <= W && (cy0 + th) <= H && (cb0 + g.tb) <= B;
         if (FAST16 && full) {
             // interior 16x16 tile: every address is one per-thread base plus compile-time / scalar terms, no masks
-            unsigned char* lw = smem + (wave * 64 + 4 * khalf + odd) * OROW + (l31 & ~1) * 2;
+            unsigned char* lw = smem + (wave * 64 + 4 * khalf + odd) * OROW + (l31 & ~1) * 2;      // (row parity = odd: swizzle below)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int rp = 0; rp < 8; ++rp)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        *reinterpret_cast<unsigned*>(lw + (i * 32 + ((2 * rp) & 3) + 8 * ((2 * rp) >> 2)) * OROW + j * 64) =
+                        *reinterpret_cast<unsigned*>(lw + (i * 32 + ((2 * rp) & 3) + 8 * ((2 * rp) >> 2)) * OROW + ((j * 64) ^ (odd ? OSWZ : 0))) =
                             pack_pair(i, j, 2 * rp, 1.f, 1.f);
             if (tr0) PHX_TRACE(8);
             __syncthreads();
             if (tr0) PHX_TRACE(9);
             const int mt = threadIdx.x / PPP, q = threadIdx.x % PPP;          // piece it: pixel mt + it * (NT / PPP)
-            const unsigned char* lr = smem + mt * OROW + q * 16;
+            const unsigned char* lr = smem + mt * OROW + ((q * 16) ^ ((mt & 1) ? OSWZ : 0));      // (NT / PPP is even: row parity = mt & 1)
             // (dual destination: the piece's eight channels lie in y (row length N1) or in du.y2 (row length N - N1))
             unsigned short* ybase = y;
             int yld = N, ych = n0 + q * 8;
@@ -769,7 +775,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
                     const int mrow = odd_o ? m1 : m0;
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        *reinterpret_cast<unsigned*>(smem + mrow * OROW + (j * 32 + (l31_o & ~1)) * 2) = pack_pair(i, j, r0, f0, f1);
+                        *reinterpret_cast<unsigned*>(smem + mrow * OROW + (((j * 32 + (l31_o & ~1)) * 2) ^ (odd_o ? OSWZ : 0))) = pack_pair(i, j, r0, f0, f1);
                 }
             if (tr0) PHX_TRACE(8);
             __syncthreads();
@@ -781,7 +787,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
                 const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
                 const int ox = cx0 + lx, oy = cy0 + ly, ob = cb0 + lb;
                 if (ox < W && oy < H && ob < B) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(smem + m * OROW + q * 16);
+                    const uint4 v = *reinterpret_cast<const uint4*>(smem + m * OROW + ((q * 16) ^ ((m & 1) ? OSWZ : 0)));
                     unsigned short* ybase = y;
                     int yld = N, ych = n0 + q * 8;
                     if constexpr (DUAL)
@@ -871,7 +877,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
                         else if (xf.act != PHX_ACT_ID) { lo = act_fwd(lo, xf.act); hi = act_fwd(hi, xf.act); }
                         const unsigned w3 = f2bf_pk(lo, hi);
                         const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)w3, 0xB1, 0xf, 0xf, true);
-                        *reinterpret_cast<unsigned*>(smem + mrow * OROW + (j * 32 + (l31_o & ~1)) * 2) =
+                        *reinterpret_cast<unsigned*>(smem + mrow * OROW + (((j * 32 + (l31_o & ~1)) * 2) ^ (odd_o ? OSWZ : 0))) =
                             odd_o ? ((nb >> 16) | (w3 & 0xffff0000u)) : ((w3 & 0xffffu) | (nb << 16));
                     }
                 }
@@ -884,7 +890,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
                 const int ox = cx0 + lx, oy = cy0 + ly, ob = cb0 + lb;
                 if (ox < W && oy < H && ob < B)
                     *reinterpret_cast<uint4*>(xf.a_out + (((size_t)ob * H + oy) * W + ox) * N + n0 + q * 8) =
-                        *reinterpret_cast<const uint4*>(smem + m * OROW + q * 16);
+                        *reinterpret_cast<const uint4*>(smem + m * OROW + ((q * 16) ^ ((m & 1) ? OSWZ : 0)));
             }
         }
     }
@@ -903,7 +909,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
     constexpr int NLW = 4;
     constexpr int NI = AI + BI, NPL = (NI + NLW - 1) / NLW;   // DMA instructions per wave
     constexpr int A_BYTES = AI * 1024, STAGE = NI * 1024;
-    constexpr int OROW = BN * 2 + 16;
+    constexpr int OROW = BN * 2;                      // dense epilogue rows, piece index XORed with 4 * (row & 1) for BN = 64 (see k_conv3x3_mfma)
+    constexpr int OSWZ = BN == 64 ? 64 : 0;
     constexpr int PROW = 34 * 64;                     // bytes per patch row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // linear block id -> (pixel tile, channel block): the N / 64 channel blocks of a tile get ids 8 apart (same XCD, dispatched
@@ -1075,7 +1082,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
                         s2v[j] += rv * rv;
                     }
                     const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)w2, 0xB1, 0xf, 0xf, true);
-                    *reinterpret_cast<unsigned*>(lwp + (i * 32 + (r0 & 3) + 8 * (r0 >> 2)) * OROW + j * 64) = __builtin_amdgcn_perm(nb, w2, psel);
+                    *reinterpret_cast<unsigned*>(lwp + (i * 32 + (r0 & 3) + 8 * (r0 >> 2)) * OROW + ((j * 64) ^ (odd ? OSWZ : 0))) = __builtin_amdgcn_perm(nb, w2, psel);
                 }
     }
     __syncthreads();
@@ -1083,7 +1090,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
         constexpr int PPP = BN / 8;                   // 16-byte pieces per pixel
         constexpr int PSTEP = 256 / PPP;              // pixels per step of the 256 storing threads (32: one tile row; 64: two)
         const int mt = threadIdx.x / PPP, q = threadIdx.x % PPP;
-        const unsigned char* lr = smem + mt * OROW + q * 16;
+        const unsigned char* lr = smem + mt * OROW + ((q * 16) ^ ((mt & 1) ? OSWZ : 0));
         unsigned short* ybase = y;                    // (dual destination, struct Dual)
         int yld = N, ych = n0 + q * 8;
         if constexpr (DUAL)
