@@ -8,10 +8,14 @@ OBJS=""
 for s in $SRCS; do
   o="build_${s%.hip}.o"
   if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ phx_common.h -nt "$o" ] || [ philox.h -nt "$o" ] || [ ../../include/phx.h -nt "$o" ]; then
+    rm -f "$o"                       # (a failed compile must not leave the previous object behind for the link)
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -c "$s" -o "$o" &
   fi
   OBJS="$OBJS $o"
 done
 wait
+for o in $OBJS; do
+  [ -f "$o" ] || { echo "build.sh: compiling ${o#build_} failed" >&2; exit 1; }
+done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -ldl -o $OUT
 echo "built $(realpath $OUT)"

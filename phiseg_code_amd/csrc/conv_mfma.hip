@@ -898,12 +898,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
 }
 
 // ---- the same 128-pixel wave tiles without loader waves: one 75 KiB stage per block, TWO blocks per CU -----------------
-template <bool BIASACT, int DBG, int BN, bool DUAL = false>
+// BWS (data-gradient launches, struct BwdStats): the store loop also reads the producer layer's y tile and emits the batch-norm
+// backward partial sums part[tile][2][N] -- the stand-alone phx_norm_bwd_reduce pass over dA and y (and its launch) disappears.
+template <bool BIASACT, int DBG, int BN, bool DUAL = false, bool BWS = false>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned short* __restrict__ x,
                                                              const unsigned short* __restrict__ wpk,
                                                              unsigned short* __restrict__ y, const float* __restrict__ bias,
                                                              int act, float* __restrict__ stats_partial,
-                                                             int B, int H, int W, int K, int N, int tiles_x, int tiles_y, const float* __restrict__ oscale, int stats_nrep, Dual du) {
+                                                             int B, int H, int W, int K, int N, int tiles_x, int tiles_y, const float* __restrict__ oscale, int stats_nrep, Dual du,
+                                                             BwdStats bws = BwdStats{}) {
     constexpr int NJ = BN / 32;                       // BN = 64 (two 32-channel MFMA columns per wave) or 32 (one)
     constexpr int AI = 39, BI = 9 * BN * 64 / 1024;   // 1 KiB DMA instructions per chunk: 612 patch rows x 64 B, 9 * BN slab rows
     constexpr int NLW = 4;
@@ -1100,9 +1103,53 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
             }
         unsigned short* yp = ybase + (((size_t)b0 * H + ty0 + (mt >> 5)) * W + tx0 + (mt & 31)) * yld + ych;
         const size_t ystep = (size_t)(PSTEP / 32) * W * yld;
+        if constexpr (!BWS) {
 #pragma unroll
-        for (int it = 0; it < 512 / PSTEP; ++it)
-            *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * PSTEP * OROW);
+            for (int it = 0; it < 512 / PSTEP; ++it)
+                *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * PSTEP * OROW);
+        } else {
+            // this thread's pieces all belong to channels n0 + 8 q .. + 7: g = dA * act'(y * scale + shift), xhat = (y - mean) * rstd
+            constexpr int NIT = 512 / PSTEP;
+            const unsigned short* yq = bws.y + (yp - y);
+            uint4 yv[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) yv[it] = *reinterpret_cast<const uint4*>(yq + it * ystep);
+            float sc[8], sh[8], mu[8], rs[8], t1[8], t2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = n0 + q * 8 + e;
+                sc[e] = bws.scale[c]; sh[e] = bws.shift[c]; mu[e] = bws.mean[c]; rs[e] = bws.rstd[c];
+                t1[e] = t2[e] = 0.f;
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const uint4 v = *reinterpret_cast<const uint4*>(lr + it * PSTEP * OROW);
+                *reinterpret_cast<uint4*>(yp + it * ystep) = v;
+                const unsigned vw[4] = {v.x, v.y, v.z, v.w}, yw[4] = {yv[it].x, yv[it].y, yv[it].z, yv[it].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float da = __uint_as_float((e & 1) ? (vw[e >> 1] & 0xffff0000u) : (vw[e >> 1] << 16));
+                    const float yy = __uint_as_float((e & 1) ? (yw[e >> 1] & 0xffff0000u) : (yw[e >> 1] << 16));
+                    const float gq = da * act_grad_pre(yy * sc[e] + sh[e], bws.act);
+                    t1[e] += gq;
+                    t2[e] += gq * (yy - mu[e]) * rs[e];
+                }
+            }
+            __syncthreads();                             // the output tile has been read: LDS becomes reduction scratch
+            float* scr = reinterpret_cast<float*>(smem);  // [256][16]
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                scr[threadIdx.x * 16 + e] = t1[e];
+                scr[threadIdx.x * 16 + 8 + e] = t2[e];
+            }
+            __syncthreads();
+            if (threadIdx.x < 2 * BN) {
+                const int which = threadIdx.x / BN, n = threadIdx.x % BN;
+                float a = 0.f;
+                for (int m2 = 0; m2 < 256 / PPP; ++m2) a += scr[(m2 * PPP + (n >> 3)) * 16 + which * 8 + (n & 7)];
+                bws.part[((size_t)tile_id * 2 + which) * N + n0 + n] = a;
+            }
+        }
     }
     if (stats_partial) {
         __syncthreads();
@@ -1882,7 +1929,8 @@ int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* 
 
 // the fused-statistics epilogue lives in the full-tile path of the 16-wide-tile kernels: every tile must be interior
 static bool fwd_bws_ok(int B, int H, int W, int K, int N) {
-    if (fwd_ws64(B, H, W, K, N) || fwd_ksplit(B, H, W, K, N) > 1) return false;
+    if (fwd_ws64(B, H, W, K, N)) return !(K == 32 && N == 32 && phx_c32_enabled()) && !phx_db_enabled();      // LDS-DMA kernel: BWS instantiations
+    if (fwd_ksplit(B, H, W, K, N) > 1) return false;
     if (fwd_big_tiles(B, H, W, K, N)) return true;                       // H % 32 == 0, W % 16 == 0
     return H % 16 == 0 && W % 16 == 0;
 }
@@ -2058,7 +2106,7 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
         const int ntl = B * (H / 16) * (W / 32);
         const char* dbe = getenv("PHX_DBG_ABLATE");   // dev: bit 1 no patch loads, 2 no slab loads, 4 no MFMAs
         const int dbg = dbe ? atoi(dbe) : 0;
-        if (K == 32 && N == 32 && dbg == 0 && !du.x2 && !du.y2 && phx_c32_enabled())
+        if (K == 32 && N == 32 && dbg == 0 && !du.x2 && !du.y2 && bws.part == nullptr && phx_c32_enabled())
             return phx_c32_launch(x, wpk, y, bias, act, stats_partial, B, H, W, bws.oscale,
                                   bws.stats_atomic ? (bws.stats_nrep > 1 ? bws.stats_nrep : 1) : 0, stream);
         if (phx_db_enabled() && N % 64 == 0 && !bws.stats_atomic && !du.x2 && !du.y2) return phx_db_launch(x, wpk, y, bias, act, stats_partial, B, H, W, K, N, bws.oscale, dbg, stream);
@@ -2067,7 +2115,7 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
         PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_dma128<Av, Dv, BNv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL((k_conv3x3_fwd_dma128<Av, Dv, BNv>), dim3(ntl * (N / BNv)), dim3(256), 75 * 1024 + 16, (hipStream_t)stream, \
                            (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, \
-                           H, W, K, N, W / 32, H / 16, bws.oscale, bws.stats_atomic ? (bws.stats_nrep > 1 ? bws.stats_nrep : 1) : 0, Dual{});                                                       \
+                           H, W, K, N, W / 32, H / 16, bws.oscale, bws.stats_atomic ? (bws.stats_nrep > 1 ? bws.stats_nrep : 1) : 0, Dual{}, BwdStats{});                                                       \
     } while (0)
 #define D128_LAUNCH(Av, Dv)                                                                                                     \
     do { if (N % 64 == 0) D128_LAUNCH1(Av, Dv, 64); else D128_LAUNCH1(Av, 0, 32); } while (0)
@@ -2077,9 +2125,21 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
         PHX_CHECK_HIP(hipFuncSetAttribute((const void*)kfd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
         hipLaunchKernelGGL(kfd, dim3(ntl * (N / BNv)), dim3(256), 75 * 1024 + 16, (hipStream_t)stream, (const unsigned short*)x, \
                            (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, W / 32, H / 16, \
-                           bws.oscale, bws.stats_atomic ? (bws.stats_nrep > 1 ? bws.stats_nrep : 1) : 0, du);                  \
+                           bws.oscale, bws.stats_atomic ? (bws.stats_nrep > 1 ? bws.stats_nrep : 1) : 0, du, BwdStats{});      \
     } while (0)
-        if (du.x2 != nullptr || du.y2 != nullptr) {
+        if (bws.part != nullptr) {
+            PHX_REQUIRE(!ba && !du.x2 && !du.y2 && !stats_partial, PHX_E_INVAL, "conv3x3_mfma: fused bn-backward sums take a plain data-gradient launch");
+#define D128_BWS(BNv)                                                                                                           \
+    do {                                                                                                                        \
+        auto kfb = k_conv3x3_fwd_dma128<false, 0, BNv, false, true>;                                                            \
+        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)kfb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
+        hipLaunchKernelGGL(kfb, dim3(ntl * (N / BNv)), dim3(256), 75 * 1024 + 16, (hipStream_t)stream, (const unsigned short*)x, \
+                           (const unsigned short*)wpk, (unsigned short*)y, nullptr, 0, nullptr, B, H, W, K, N, W / 32, H / 16,  \
+                           nullptr, 0, Dual{}, bws);                                                                            \
+    } while (0)
+            if (N % 64 == 0) D128_BWS(64); else D128_BWS(32);
+#undef D128_BWS
+        } else if (du.x2 != nullptr || du.y2 != nullptr) {
             if (N % 64 == 0) { if (ba) D128_DUAL(true, 64); else D128_DUAL(false, 64); }
             else { if (ba) D128_DUAL(true, 32); else D128_DUAL(false, 32); }
         } else if (ba) D128_LAUNCH(true, 0);

@@ -1959,6 +1959,7 @@ class Plan:
                         and len(self._real_consumers(xin, self._opset)) == 1
                         and os.environ.get("PHX_FUSE_BWS", "0") == "1"
                         and B * H * Wd <= int(os.environ.get("PHX_FUSE_BWS_MAXP", str(1 << 30)))
+                        and B * H * Wd >= int(os.environ.get("PHX_FUSE_BWS_MINP", "0"))
                         and bool(Lb.conv3x3_mfma_bwdstats_supported(B, H, Wd, cout, cin)))
 
                 def wr_mfma(g):

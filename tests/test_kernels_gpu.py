@@ -207,10 +207,15 @@ def test_conv1x1_as_centre_tap(L, case):
     close(host(dw), wr.grad.numpy()[0, 0], 1e-4, "1x1 wgrad")
 
 
-@pytest.mark.parametrize("case", [(2, 32, 32, 64, 64), (1, 16, 48, 32, 192), (3, 64, 32, 128, 128), (40, 16, 16, 64, 96)])
+@pytest.mark.parametrize("case", [(2, 32, 32, 64, 64), (1, 16, 48, 32, 192), (3, 64, 32, 128, 128), (40, 16, 16, 64, 96),
+                                  (2, 32, 32, 64, 64, "dma"), (1, 16, 64, 96, 32, "dma"), (3, 48, 32, 128, 128, "dma"), (2, 16, 32, 32, 96, "dma")])
 def test_dgrad_with_fused_bn_backward_statistics(L, case, monkeypatch):
     """Data-gradient launch that also emits the producer layer's batch-norm backward sums: same dA as the plain launch,
-    and its reduced partials equal phx_norm_bwd_reduce run on that dA."""
+    and its reduced partials equal phx_norm_bwd_reduce run on that dA.  ("dma": the LDS-DMA 16 x 32-tile kernel's BWS instantiations)"""
+    if len(case) == 6:
+        monkeypatch.setenv("PHX_FWD_WS", "5")
+        monkeypatch.setenv("PHX_FWD_DB", "0")
+        case = case[:5]
     B, H, W, K, N = case                       # K = channels of dy (consumer's Cout), N = channels of dA / y_prod
     if case[1] % 32 == 0:
         monkeypatch.setenv("PHX_FWD_BIG", "2")  # exercise the 16 x 32-tile kernels too
