@@ -330,6 +330,16 @@ int phx_bn_small_fwd_splitk(const float* ws, int nz, void* x_out, const float* g
 int phx_bn_small_bwd(const void* dA, const void* x, const float* scale, const float* shift, const float* mean,
                      const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, int P, int C, int act,
                      void* stream);
+/* Batch-norm backward (+ activation gradient) of a mid-size layer in ONE launch: phx_bn_small_bwd's arithmetic with the pixels of a
+ * 16-channel slice split over several blocks that add their partial sums to sums2[C][2] (zero at launch) with returning device-scope
+ * atomics and meet at counters[C / 16] (unsigned, zero at launch) -- replaces phx_norm_bwd_reduce + phx_norm_bwd_apply_fused for
+ * bf16 tensors whose launch fits PHX_BN_MID_MAXBLOCKS (192) resident blocks (P <= 65 536 at C = 192).  ..._supported -> 0 or the
+ * pixels per block / 512; ..._timeouts: blocks that gave up at the rendezvous since the library was loaded (results invalid then). */
+int phx_bn_mid_supported(int P, int C, int dt);
+int phx_bn_mid_timeouts(int* count);
+int phx_bn_mid_bwd(const void* dA, const void* x, const float* scale, const float* shift, const float* mean, const float* rstd,
+                   const float* gamma, void* dx, float* dgamma, float* dbeta, float* sums2, void* counters, int P, int C, int act,
+                   void* stream);
 /* Group / instance norm (tfwrapper/normalisation.py:3-36), bf16 NHWC, the whole layer in ONE launch when a sample has
  * P = H*W <= 256 pixels (maps up to 16 x 16) and the statistic is per channel (G == C: instance norm) or per 16-channel
  * group (G * 16 == C: group_norm2D's default groups for C >= 32): a wave owns (sample, 16-channel slice) pairs, keeps the

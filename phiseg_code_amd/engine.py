@@ -76,6 +76,14 @@ def _fbn_maxp():
     return int(os.environ.get("PHX_FBN_MAXP", "4096"))      # (read when a plan is built)
 
 
+def _bn_mid_maxp():
+    # batch-norm backward in one launch (phx_bn_mid_bwd) up to this many pixels; 0: off.  Measured (step time, same box): 4 096 (the
+    # 8 x 8 level) 10.86 vs 10.88 ms with 18 launches fewer; 16 384: 11.05 (the 192 x 1 024-thread launch with its 16-wave block
+    # reductions and the rendezvous is slower than two streaming launches); 65 536: 12.1 ms and rendezvous time-outs beside the
+    # other lane's launches -- the one-launch form pays only where a layer is a handful of blocks
+    return int(os.environ.get("PHX_BN_MID_MAXP", "4096"))
+
+
 def _fbn_maxk():
     return int(os.environ.get("PHX_FBN_MAXK", str(1 << 20)))      # ... and at most this many input channels (experiments)
 def _dual_enabled():
@@ -1765,6 +1773,15 @@ class Plan:
                            NS, P, cout, Gn, act, S,
                            tag="bytes_norm_bwd_apply", flops=float(dA.nbytes + y.nbytes + dY.nbytes))
                 db_done = True
+            elif (sv["norm"] == "batch" and isinstance(dA, Buf) and dA.dt == BF16 and y.dt == BF16 and op not in self._bws
+                  and P <= _bn_mid_maxp() and not _DETERMINISTIC and Lb.bn_mid_supported(P, cout, BF16)):
+                # mid-size maps: reduction + apply in ONE launch (phx_bn_mid_bwd: the blocks of a channel slice meet inside the launch)
+                dY = self._alloc(y.shape, y.dt)
+                acc = self._alloc_zeroed(cout * 2 + (cout // 16 + 3) // 4 * 4)          # sums2[C][2] | arrival counters
+                self._emit(Lb.bn_mid_bwd, dA.ptr, y.ptr, sv["scale"].ptr, sv["shift"].ptr, sv["mean"].ptr, sv["rstd"].ptr,
+                           self.store.ptr(nv["gamma"]), dY.ptr, self.store.grad_ptr(nv["gamma"]), self.store.grad_ptr(nv["beta"]),
+                           acc.ptr, acc.ptr + cout * 8, P, cout, act, S,
+                           tag="bytes_norm_bwd_apply", flops=float(dA.nbytes + y.nbytes + dY.nbytes))
             else:
                 nrep = _NREP if P >= _NREP_MINP else 1   # replicated accumulators: see k_norm_bwd_reduce
                 if _DETERMINISTIC and P >= _NREP_MINP:
@@ -2086,9 +2103,12 @@ class Plan:
     def _check_rendezvous(self):
         n = ctypes.c_int(0)
         self.L.conv3x3_fbn_timeouts(ctypes.byref(n))
+        m = ctypes.c_int(0)
+        self.L.bn_mid_timeouts(ctypes.byref(m))
+        n.value += m.value
         if n.value:
             raise rt.PhxError("%d block(s) of one-launch conv + batch-norm layers timed out at their rendezvous (the launch was not "
-                              "co-resident: another process on this GPU?) -- results are invalid; set PHX_FBN_MAXP=0" % n.value)
+                              "co-resident: another process on this GPU?) -- results are invalid; set PHX_FBN_MAXP=0 PHX_BN_MID_MAXP=0" % n.value)
 
     def fetch(self, t):
         self.sync()

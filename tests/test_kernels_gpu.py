@@ -1387,3 +1387,48 @@ def test_conv3x3_concat_free_statistics_and_fused_norm(L):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][0], outs[0][2])
     close(host(outs[1][1]), host(outs[0][1]), 1e-2, "fused norm output")
     close(outs[1][3], outs[0][3], 2e-5, "statistics")
+
+
+@pytest.mark.parametrize("case", [(64, 8, 8, 192, 1), (64, 16, 16, 192, 1), (64, 32, 32, 128, 1), (23, 6, 6, 128, 1), (64, 16, 16, 64, 0),
+                                  (5, 16, 24, 32, 1), (64, 32, 32, 32, 1)])
+def test_bn_mid_backward_one_launch(L, case):
+    """phx_bn_mid_bwd (batch-norm + activation backward of a mid-size layer in one launch: partial sums by returning atomics, the
+    blocks of a channel slice meet at an arrival counter) against the oracle's batch norm + ReLU autograd and against the two-launch
+    path it replaces (phx_norm_bwd_reduce + phx_norm_bwd_apply_fused_bias); relaunched to show the rendezvous does not depend on timing."""
+    import ctypes
+    B, H, W, C, act = case
+    P = B * H * W
+    assert L.bn_mid_supported(P, C, BF16) in (1, 2, 4, 8)
+    assert L.bn_mid_supported(64 * 128 * 128, 128, BF16) == 0 and L.bn_mid_supported(P, 24, BF16) == 0
+    x = RNG.standard_normal((B, H, W, C)) * 1.5 + 0.3
+    gamma, beta = 1.0 + 0.2 * RNG.standard_normal(C), 0.1 * RNG.standard_normal(C)
+    xr = rounded(x, BF16).requires_grad_(True)
+    gr = torch.as_tensor(gamma, dtype=torch.float32).double().requires_grad_(True)
+    br = torch.as_tensor(beta, dtype=torch.float32).double().requires_grad_(True)
+    yr, mean_r, _ = T.batch_norm_train(xr, gr, br)
+    ar = T.relu(yr) if act else yr
+    dA = RNG.standard_normal((B, H, W, C))
+    (ar * rounded(dA, BF16)).sum().backward()
+    var_b = xr.detach().reshape(P, C).var(0, unbiased=False).numpy()
+    rstd_np = 1.0 / np.sqrt(var_b + T.BN_EPS)
+    xd, dAd, gd = dev(x, BF16), dev(dA, BF16), dev(gamma)
+    mean, rstd = dev(mean_r.detach().numpy()), dev(rstd_np)
+    scale, shift = dev(gamma * rstd_np), dev(beta - mean_r.detach().numpy() * gamma * rstd_np)
+    for rep in range(3):
+        dx = torch.empty(B, H, W, C, dtype=torch.bfloat16).cuda()
+        dgamma = torch.full((C,), 0.5, dtype=torch.float32).cuda()        # accumulated (+=), not overwritten
+        dbeta = torch.full((C,), -0.25, dtype=torch.float32).cuda()
+        acc = torch.zeros(C * 2 + 64, dtype=torch.float32).cuda()
+        L.bn_mid_bwd(dAd.data_ptr(), xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gd.data_ptr(),
+                     dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), acc.data_ptr(), acc.data_ptr() + C * 8, P, C, act, S())
+        close(host(dx), xr.grad.numpy(), 8e-3, "bn_mid dx")
+        close(host(dgamma) - 0.5, gr.grad.numpy(), 2e-3, "bn_mid dgamma")
+        close(host(dbeta) + 0.25, br.grad.numpy(), 2e-3, "bn_mid dbeta")
+    # the two-launch path on the same inputs
+    sums2 = torch.zeros(1, C, 2, dtype=torch.float32).cuda()
+    L.norm_bwd_reduce(dAd.data_ptr(), BF16, xd.data_ptr(), BF16, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                      sums2.data_ptr(), 1, P, C, C, act, 1, S())
+    close(host(acc)[:2 * C].reshape(C, 2), host(sums2).reshape(C, 2), 2e-5, "bn_mid sums vs norm_bwd_reduce")
+    nto = ctypes.c_int(-1)
+    L.bn_mid_timeouts(ctypes.byref(nto))
+    assert nto.value == 0
