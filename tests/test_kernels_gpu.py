@@ -1432,3 +1432,40 @@ def test_bn_mid_backward_one_launch(L, case):
     nto = ctypes.c_int(-1)
     L.bn_mid_timeouts(ctypes.byref(nto))
     assert nto.value == 0
+
+
+@pytest.mark.parametrize("case", [(64, 16, 32), (5, 48, 96), (3, 16, 64), (2, 32, 32)])
+def test_conv3x3_c32_against_the_general_kernel(L, case, monkeypatch):
+    """k_conv3x3_c32 (32 -> 32 channels, filter in registers, persistent tiles; PHX_C32=1, the default) against k_conv3x3_fwd_dma128<32>
+    (PHX_C32=0) through the same entry points: plain output bit-equal; bias + activation epilogue bit-equal; per-tile partial
+    statistics and replicated atomic statistics to fp32 summation order; and against the oracle's conv2d."""
+    B, H, W = case
+    K = N = 32
+    monkeypatch.setenv("PHX_FWD_WS", "5")
+    monkeypatch.setenv("PHX_FWD_DB", "0")
+    x = RNG.standard_normal((B, H, W, K))
+    w = RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K)
+    bias = RNG.standard_normal(N) * 0.3
+    xd, wd, bd = dev(x, BF16), dev(w), dev(bias)
+    wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    wg = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    L.pack_conv3x3_bf16(wd.data_ptr(), wf.data_ptr(), wg.data_ptr(), K, N, S())
+    ntile = L.conv3x3_mfma_bf16_tiles(B, H, W, K, N)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PHX_C32", mode)
+        y, yb, yr = (torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda() for _ in range(3))
+        part = torch.zeros(ntile, 2, N, dtype=torch.float32).cuda()
+        rep = torch.zeros(4, N, 2, dtype=torch.float32).cuda()
+        L.conv3x3_mfma_bf16(xd.data_ptr(), wf.data_ptr(), y.data_ptr(), None, 0, part.data_ptr(), B, H, W, K, N, S())
+        L.conv3x3_mfma_bf16(xd.data_ptr(), wf.data_ptr(), yb.data_ptr(), bd.data_ptr(), 1, None, B, H, W, K, N, S())
+        L.conv3x3_mfma_bf16_stats_rep(xd.data_ptr(), wf.data_ptr(), yr.data_ptr(), None, 0, rep.data_ptr(), 4, B, H, W, K, N, S())
+        torch.cuda.synchronize()
+        res[mode] = (y, yb, yr, host(part).sum(0), host(rep).sum(0))
+    a, b = res["0"], res["1"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(b[0], b[2])
+    close(b[3], a[3], 2e-5, "partial-row statistics")
+    close(b[4].T, b[3], 2e-5, "replicated statistics = partial rows")
+    ref = T.conv2d_same(rounded(x, BF16), rounded(w, BF16))
+    close(host(b[0]), ref.numpy(), 1.5e-2, "c32 forward vs oracle")
+    close(host(b[1]), T.relu(T.bias_add(ref, torch.as_tensor(bias))).numpy(), 1.5e-2, "c32 bias + relu vs oracle")
