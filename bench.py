@@ -319,7 +319,7 @@ def main():
         }
         # launches of the family that also carry the layer's batch norm (phx_conv3x3_mfma_bf16_fbn: statistics, rendezvous, second
         # pass): counted in `achieved` with their whole duration, listed here so that the convolution-only part can be read off
-        fb = [(fl_, ms_) for tag, fl_, ms_, shp in rows if shp and shp[0] == "fbn"]
+        fb = [(fl_, ms_) for tag, fl_, ms_, shp in rows if shp and shp[0] in ("fbn", "fgn")]
         if fb:
             out["roofline"]["fused_conv_bn_launches"] = {"launches": len(fb), "ms_per_step": sum(m for _, m in fb),
                                                          "gflop_per_step": sum(f for f, _ in fb) / 1e9}

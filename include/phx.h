@@ -127,6 +127,15 @@ int phx_conv3x3_wgrad_multi_job_dual(const void* x, const void* x2, int K1, cons
                                      void* job_out, int* info9);
 int phx_conv3x3_wgrad_mfma_bf16_dual(const void* x, const void* x2, int K1, const void* dy, float* dw_hwio, void* workspace,
                                      size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int reduce, void* stream);
+/* Convolution + bias + group norm (16-channel groups) / instance norm + activation in ONE launch (the fused block of north_star:
+ * tfwrapper/layers.py:123-135 + normalisation.py:3-36) on maps that fit one pixel tile (H, W in {2, 4, 8, 16}): a block holds whole
+ * samples and whole groups, so the two-pass statistics are block-local -- no statistics / reduction / apply launches and no
+ * cross-block step.  Writes y = bf16(conv + bias) (the backward pass reads it), a_out = act((y - mean) * rstd * gamma + beta) and the
+ * per-sample vectors mean / rstd [B][G], scale / shift [B][N] in phx_norm_small_bwd's layout.  G == N: instance norm. */
+int phx_conv3x3_fgn_supported(int B, int H, int W, int K, int N, int G);
+int phx_conv3x3_mfma_bf16_fgn(const void* x, const void* wpk, void* y, void* a_out, const float* bias, const float* gamma,
+                              const float* beta, float eps, int G, int act, float* mean_out, float* rstd_out, float* scale_out,
+                              float* shift_out, int B, int H, int W, int K, int N, void* stream);
 /* Convolution + batch norm (training mode) + activation in ONE launch on small maps (tfwrapper/layers.py:123-135 +
  * normalisation.py:17-36; replaces conv [+ split-K finish] + statistics + apply): the blocks add their tiles' {sum y, sum y^2} to
  * sums[N][2] (zero at launch) with returning device-scope atomics, meet at counters[N / 32] (unsigned, zero at launch), read the sums

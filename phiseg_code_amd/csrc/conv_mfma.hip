@@ -312,7 +312,12 @@ constexpr int XF_TBL_BYTES = 4096;      // LDS scale / shift table in front of t
 // normalisation's arguments (sums, gamma, beta, eps, invP, act, a_out, the published vectors, the moving statistics, counter).
 // DUAL (struct Dual; its own instantiations, so that the ordinary launches carry neither the second plan nor the selects): the
 // second offset plan ga2 addresses du.x2, every prefetched chunk picks its tensor by a scalar compare; the epilogue stores by piece.
-template <int BN, int NA, bool FAST16, bool BIASACT, int NW, bool SPLITK, bool XF = false, bool FBN = false, bool DUAL = false>
+// FGN (maps of at most 16 x 16 pixels = whole samples per pixel tile; group norm with 16-channel groups or instance norm): the
+// north_star's fused block -- conv2d + bias + group / instance norm + activation (tfwrapper/layers.py:123-135, normalisation.py:3-36)
+// in ONE launch with no cross-block step at all: a block owns its samples' pixels for its BN channels, i.e. whole groups, so the
+// two-pass statistics (sum, then sum of squared deviations, through a small LDS table) are block-local.  xf carries gamma / beta /
+// eps / act / G / a_out and the published per-sample vectors; bias is the convolution's.
+template <int BN, int NA, bool FAST16, bool BIASACT, int NW, bool SPLITK, bool XF = false, bool FBN = false, bool DUAL = false, bool FGN = false>
 // (NA = 16 -- the 4 x 4 x 16 / 2 x 2 x 64 tiles of the H <= 4 levels: at most a few dozen blocks per launch -- with the second plan of
 // the DUAL instantiations is compiled for one block per CU: 96 staging registers + two plans + accumulators do not fit 256)
 __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) void k_conv3x3_mfma(const unsigned short* __restrict__ x,
@@ -626,6 +631,129 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
         const bool tr0 = true;
         for (int c0 = cbeg; c0 + KC < cend; c0 += KC) chunk(c0, c0 + KC, std::true_type(), c0 == KC);
         chunk(cend - KC, 0, std::false_type(), K == 2 * KC);
+        if constexpr (FGN) {
+            constexpr int OROWG = BN * 2, OSWZG = BN == 64 ? 64 : 0;      // the epilogue tile of the standard path (dense, swizzled)
+            const int psh = g.tws + g.ths;                   // log2(pixels per sample)
+            const int cg = N / xf.G, ngb = BN / cg;          // channels per group (16 or 1), groups in this channel block
+            const float inv_n = 1.f / (float)((1 << psh) * cg);
+            float* tbl = reinterpret_cast<float*>(smem + NT * OROWG);     // [tb][ngb][2]: {sum, sum of squared deviations}
+            const int odd_g = lane & 1;
+            __syncthreads();                                 // all MFMA operand reads are done
+            for (int t2 = threadIdx.x; t2 < g.tb * ngb * 2; t2 += NT) tbl[t2] = 0.f;
+            // y = bf16(conv + bias): what is stored, normalised and read back by the backward pass
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float bv = bias ? bias[n0 + j * 32 + l31] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int rp = 0; rp < 8; ++rp) {
+                        const unsigned w2 = f2bf_pk(acc[i][j][2 * rp] + bv, acc[i][j][2 * rp + 1] + bv);
+                        acc[i][j][2 * rp] = __uint_as_float(w2 << 16);
+                        acc[i][j][2 * rp + 1] = __uint_as_float(w2 & 0xffff0000u);
+                    }
+            }
+            __syncthreads();
+            // a segment = the four pixels (r & 3) of accumulator rows 4 rq .. 4 rq + 3: consecutive pixels, always inside one sample
+            auto seg_img = [&](int i, int rq) { return (wave * 64 + i * 32 + 8 * rq + 4 * khalf) >> psh; };
+            auto group_sum = [&](float v) {                  // over the 16 channels of a group (lanes l31 ^ 1, 2, 4, 8: same khalf)
+                if (cg == 16) {
+                    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                }
+                return v;
+            };
+            const bool leader = cg == 1 || (l31 & 15) == 0;
+            float mg[2][4][NJ], rg[2][4][NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const float sv = group_sum((acc[i][j][4 * rq] + acc[i][j][4 * rq + 1]) + (acc[i][j][4 * rq + 2] + acc[i][j][4 * rq + 3]));
+                        if (leader) atomicAdd(&tbl[(seg_img(i, rq) * ngb + (j * 32 + l31) / cg) * 2], sv);
+                    }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const float mu = tbl[(seg_img(i, rq) * ngb + (j * 32 + l31) / cg) * 2] * inv_n;
+                        mg[i][rq][j] = mu;
+                        float d2 = 0.f;
+#pragma unroll
+                        for (int k2 = 0; k2 < 4; ++k2) { const float dd = acc[i][j][4 * rq + k2] - mu; d2 = fmaf(dd, dd, d2); }
+                        d2 = group_sum(d2);
+                        if (leader) atomicAdd(&tbl[(seg_img(i, rq) * ngb + (j * 32 + l31) / cg) * 2 + 1], d2);
+                    }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq)
+                        rg[i][rq][j] = rsqrtf(tbl[(seg_img(i, rq) * ngb + (j * 32 + l31) / cg) * 2 + 1] * inv_n + xf.eps);
+            // published per-sample vectors (backward pass): mean / rstd [NS][G], scale / shift [NS][N]
+            for (int t2 = threadIdx.x; t2 < g.tb * BN; t2 += NT) {
+                const int img = t2 / BN, ch = t2 - img * BN;
+                if (b0 + img < B) {
+                    const float mu = tbl[(img * ngb + ch / cg) * 2] * inv_n;
+                    const float rs = rsqrtf(tbl[(img * ngb + ch / cg) * 2 + 1] * inv_n + xf.eps);
+                    const float scv = xf.gamma[n0 + ch] * rs;
+                    xf.scale_out[(size_t)(b0 + img) * N + n0 + ch] = scv;
+                    xf.shift_out[(size_t)(b0 + img) * N + n0 + ch] = xf.beta[n0 + ch] - mu * scv;
+                    if (ch % cg == 0) {
+                        xf.mean_out[(size_t)(b0 + img) * xf.G + (n0 + ch) / cg] = mu;
+                        xf.rstd_out[(size_t)(b0 + img) * xf.G + (n0 + ch) / cg] = rs;
+                    }
+                }
+            }
+            // y, then a = act((y - mean) * rstd * gamma + beta), each transposed through LDS and stored 16 bytes per lane (masked path)
+            const unsigned pselg = odd_g ? 0x03020706u : 0x05040100u;
+            for (int pass = 0; pass < 2; ++pass) {
+                unsigned short* dst = pass == 0 ? y : xf.a_out;
+                __syncthreads();                             // the previous pass has read its tile (pass 0: the table is no longer needed ... it lives behind the tile)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const float gmv = xf.gamma[n0 + j * 32 + l31], bev = xf.beta[n0 + j * 32 + l31];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int rp = 0; rp < 8; ++rp) {
+                            const int r0 = 2 * rp;
+                            float v0 = acc[i][j][r0], v1 = acc[i][j][r0 + 1];
+                            if (pass == 1) {
+                                const float scv = rg[i][rp >> 1][j] * gmv, shv = bev - mg[i][rp >> 1][j] * scv;
+                                v0 = fmaf(v0, scv, shv); v1 = fmaf(v1, scv, shv);
+                                if (xf.act == PHX_ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                                else if (xf.act != PHX_ACT_ID) { v0 = act_fwd(v0, xf.act); v1 = act_fwd(v1, xf.act); }
+                            }
+                            const unsigned w2 = f2bf_pk(v0, v1);
+                            const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)w2, 0xB1, 0xf, 0xf, true);
+                            const int m0 = wave * 64 + i * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * khalf;
+                            *reinterpret_cast<unsigned*>(smem + (m0 + odd_g) * OROWG + (((j * 32 + (l31 & ~1)) * 2) ^ (odd_g ? OSWZG : 0))) =
+                                __builtin_amdgcn_perm(nb, w2, pselg);
+                        }
+                }
+                __syncthreads();
+                constexpr int PPPG = BN / 8;
+#pragma unroll
+                for (int it = 0; it < PPPG; ++it) {
+                    const int i2 = threadIdx.x + it * NT;
+                    const int m = i2 / PPPG, q = i2 % PPPG;
+                    const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
+                    const int ox = cx0 + lx, oy = cy0 + ly, ob = cb0 + lb;
+                    if (ox < W && oy < H && ob < B)
+                        *reinterpret_cast<uint4*>(dst + (((size_t)ob * H + oy) * W + ox) * N + n0 + q * 8) =
+                            *reinterpret_cast<const uint4*>(smem + m * OROWG + ((q * 16) ^ ((m & 1) ? OSWZG : 0)));
+                }
+            }
+            PHX_BLOCKLOG_END();
+            return;
+        }
         if constexpr (SPLITK) {
             // fp32 partial tile -> ws[z][pixel][N]; C layout: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
             float* wz = ws + (size_t)blockIdx.z * B * H * W * N;
@@ -1996,6 +2124,59 @@ static Dual take_next_dual() {
     const Dual d = g_next_dual;
     g_next_dual = Dual{nullptr, nullptr, 0, 0};
     return d;
+}
+
+// ---- conv + bias + group / instance norm + activation in one launch (FGN instantiations of k_conv3x3_mfma) ----------------------
+// Maps that fit ONE pixel tile (H, W in {2, 4, 8, 16}): a block then holds whole samples and whole 16-channel groups.  -> 32 / 64
+// (channels per block), 0: not supported.
+static int fgn_plan(int B, int H, int W, int K, int N, int G) {
+    if (K % KC != 0 || N % 32 != 0 || G < 1 || !(G == N || G * 16 == N)) return 0;
+    if (H > 16 || W > 16 || (H & (H - 1)) || (W & (W - 1)) || H < 2 || W < 2) return 0;
+    if ((double)B * H * W >= 16777216.0) return 0;
+    MTile g = make_mtile(B, H, W);
+    const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
+    return (N % 64 == 0 && ntiles * (N / 64) > 256) ? 64 : 32;
+}
+int phx_conv3x3_fgn_supported(int B, int H, int W, int K, int N, int G) { return fgn_plan(B, H, W, K, N, G); }
+int phx_conv3x3_mfma_bf16_fgn(const void* x, const void* wpk, void* y, void* a_out, const float* bias, const float* gamma,
+                              const float* beta, float eps, int G, int act, float* mean_out, float* rstd_out, float* scale_out,
+                              float* shift_out, int B, int H, int W, int K, int N, void* stream) {
+    const Dual du = take_next_dual();
+    PHX_REQUIRE(du.x2 == nullptr && du.y2 == nullptr, PHX_E_INVAL, "conv3x3_mfma_fgn: no dual input / output");
+    const int bn = fgn_plan(B, H, W, K, N, G);
+    PHX_REQUIRE(bn != 0, PHX_E_SHAPE, "conv3x3_mfma_fgn: shape not supported (see phx_conv3x3_fgn_supported)");
+    PHX_REQUIRE(x && wpk && y && a_out && gamma && beta && mean_out && rstd_out && scale_out && shift_out, PHX_E_INVAL,
+                "conv3x3_mfma_fgn: null argument");
+    PHX_REQUIRE((((uintptr_t)x | (uintptr_t)wpk | (uintptr_t)y | (uintptr_t)a_out) & 15) == 0, PHX_E_ALIGN, "conv3x3_mfma_fgn: 16-byte alignment");
+    MTile g = make_mtile(B, H, W);
+    const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
+    const int npatch = g.tb * ((1 << g.ths) + 2) * ((1 << g.tws) + 2);
+    const int na = (npatch * 4 + 255) / 256;
+    PHX_REQUIRE(na <= 16, PHX_E_SHAPE, "conv3x3_mfma_fgn: unexpected tile geometry");
+    const bool fast16 = g.tws == 4 && g.ths == 4 && g.tb == 1;
+    XForm xf{};
+    xf.gamma = gamma; xf.beta = beta; xf.eps = eps; xf.act = act; xf.G = G; xf.NS = B;
+    xf.a_out = (unsigned short*)a_out; xf.mean_out = mean_out; xf.rstd_out = rstd_out; xf.scale_out = scale_out; xf.shift_out = shift_out;
+    const int cg = N / G;
+#define FGN_LAUNCH(BNv, NAv, Fv)                                                                                        \
+    do {                                                                                                                \
+        auto kfn = k_conv3x3_mfma<BNv, NAv, Fv, false, 4, false, false, false, false, true>;                            \
+        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));   \
+        size_t sh = (Fv ? (size_t)(4 * 4 + 2) * PITCH16 : (size_t)g.tb * g.ipitch) + 9 * BNv * ROWB;                    \
+        const size_t she = (size_t)256 * BNv * 2 + (size_t)g.tb * (BNv / cg) * 8;                                       \
+        if (she > sh) sh = she;                                                                                         \
+        hipLaunchKernelGGL(kfn, dim3(ntiles * (N / BNv)), dim3(256), sh, (hipStream_t)stream, (const unsigned short*)x, \
+                           (const unsigned short*)wpk, (unsigned short*)y, bias, 0, nullptr, B, H, W, K, N, g, nullptr,  \
+                           BwdStats{}, xf, Dual{});                                                                     \
+    } while (0)
+    if (bn == 64) {
+        if (fast16) FGN_LAUNCH(64, 8, true); else if (na <= 8) FGN_LAUNCH(64, 8, false); else FGN_LAUNCH(64, 16, false);
+    } else {
+        if (fast16) FGN_LAUNCH(32, 8, true); else if (na <= 8) FGN_LAUNCH(32, 8, false); else FGN_LAUNCH(32, 16, false);
+    }
+#undef FGN_LAUNCH
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
 }
 
 // ---- conv + batch norm (training mode) + activation in one launch on small maps (FBN instantiations of k_conv3x3_mfma) --------

@@ -84,6 +84,13 @@ def _bn_mid_maxp():
     return int(os.environ.get("PHX_BN_MID_MAXP", "4096"))
 
 
+def _fgn_mode():
+    # conv + bias + group norm + activation in one launch on maps <= 16 x 16 (phx_conv3x3_mfma_bf16_fgn).  1: group norm (16-channel
+    # groups); 2: instance norm too (per-channel statistics: every lane adds to the LDS table -- measured 11.24 vs 11.15 ms, so not
+    # by default); 0: off.  Group norm, phiseg_7_5 B = 64: 11.28 vs 11.28 - 11.30 ms with 57 launches fewer.
+    return int(os.environ.get("PHX_FGN", "1"))
+
+
 def _fbn_maxk():
     return int(os.environ.get("PHX_FBN_MAXK", str(1 << 20)))      # ... and at most this many input channels (experiments)
 def _dual_enabled():
@@ -1209,6 +1216,17 @@ class Plan:
                                mm, mv, mom, P, cout, act, S,
                                tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
                 st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn, bn_small=True)
+                self.saved[op] = st
+                return
+            if (norm != "batch" and mfma and not head1x1 and not xf and dual is None and (_fgn_mode() >= 2 or (_fgn_mode() == 1 and Gn != cout)) and y.dt == BF16 and out.dt == BF16
+                    and x.dt == BF16 and Lb.conv3x3_fgn_supported(B, H, Wd, cin_eff, cout, Gn)
+                    and Lb.norm_small_supported(NS, P, cout, Gn, BF16)):
+                # maps of at most 16 x 16: convolution, bias, group / instance norm and activation in ONE launch (a block holds whole
+                # samples and whole groups: no cross-block step); the backward pass is phx_norm_small_bwd's
+                self._emit(Lb.conv3x3_mfma_bf16_fgn, x.ptr, wf.ptr, y.ptr, out.ptr, bptr, gptr, beptr, eps, Gn, act, mean.ptr, rstd.ptr,
+                           scale.ptr, shift.ptr, B, H, Wd, cin_eff, cout, S,
+                           tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd, shape=("fgn", B, H, Wd, cin_eff, cout))
+                st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn, norm_small=True)
                 self.saved[op] = st
                 return
             # group / instance norm on maps of up to 256 pixels: the whole layer in one launch as well (phx_norm_small_fwd / _bwd: a

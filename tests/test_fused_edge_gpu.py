@@ -200,7 +200,7 @@ def test_training_plan_with_fused_edges_equals_unfused_plan(norm, monkeypatch):
 
 
 @pytest.mark.parametrize("switch,off,on,norm", [("PHX_DUAL", "0", "1", "group_norm"), ("PHX_DUAL", "0", "1", None),
-                                               ("PHX_FBN_MAXP", "0", "4096", None)])
+                                               ("PHX_FBN_MAXP", "0", "4096", None), ("PHX_FGN", "0", "1", "group_norm")])
 def test_training_plan_concat_free_and_one_launch_layers_equal_the_plain_plan(switch, off, on, norm, monkeypatch):
     """The bf16 training plan of phiseg_7_5 (n0 = 32, 128 x 128, batch 2) with concat-free convolutions (PHX_DUAL: the twelve
     tf.concat -> conv2D edges of posteriors.py:87,120 / priors.py:112 / likelihoods.py:210 read and write their two tensors in place)
@@ -209,6 +209,8 @@ def test_training_plan_concat_free_and_one_launch_layers_equal_the_plain_plan(sw
     under group norm the loss agrees to 1e-4 and the gradients to 1 %."""
     from tests.test_model_gpu import _lidc_setup
     res = {}
+    if switch == "PHX_DUAL":
+        monkeypatch.setenv("PHX_FGN", "0")      # (a concat-free layer keeps the two-launch group norm: compare like with like)
     for v in (off, on):
         monkeypatch.setenv(switch, v)
         cfg, model, params, x_np, s_np = _lidc_setup("bf16", perturbed=True, norm=norm)
@@ -223,7 +225,8 @@ def test_training_plan_concat_free_and_one_launch_layers_equal_the_plain_plan(sw
     l1, g1, n1, p1 = res[on]
     assert n1 <= n0 - 12, (n0, n1)
     sharp = norm is not None
-    assert abs(l1 - l0) <= (1e-4 if sharp else 2e-2) * abs(l0), (l0, l1)
+    exact = switch == "PHX_DUAL"            # (concat-free: identical arithmetic; the one-launch layers re-order their statistics -> bf16 flips)
+    assert abs(l1 - l0) <= ((1e-4 if exact else 2e-3) if sharp else 2e-2) * abs(l0), (l0, l1)
     errs = []
     for name, ga in g0.items():
         nrm = np.linalg.norm(ga)
@@ -231,7 +234,7 @@ def test_training_plan_concat_free_and_one_launch_layers_equal_the_plain_plan(sw
             continue
         errs.append(np.linalg.norm(g1[name] - ga) / nrm)
     assert len(errs) >= 360
-    assert np.mean(errs) <= (0.01 if sharp else 0.5), np.mean(errs)
+    assert np.mean(errs) <= ((0.01 if exact else 0.05) if sharp else 0.5), np.mean(errs)
     for name in p0:
         if "moving_" in name:
             np.testing.assert_allclose(p1[name], p0[name], rtol=1e-2, atol=3e-3)

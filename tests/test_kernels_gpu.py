@@ -1469,3 +1469,48 @@ def test_conv3x3_c32_against_the_general_kernel(L, case, monkeypatch):
     ref = T.conv2d_same(rounded(x, BF16), rounded(w, BF16))
     close(host(b[0]), ref.numpy(), 1.5e-2, "c32 forward vs oracle")
     close(host(b[1]), T.relu(T.bias_add(ref, torch.as_tensor(bias))).numpy(), 1.5e-2, "c32 bias + relu vs oracle")
+
+
+@pytest.mark.parametrize("case", [(64, 8, 8, 192, 192, 12), (64, 4, 4, 64, 192, 12), (64, 2, 2, 192, 192, 12), (5, 16, 16, 64, 64, 4),
+                                  (7, 8, 8, 32, 32, 32), (3, 16, 16, 64, 96, 96), (70, 2, 2, 32, 64, 4), (9, 4, 8, 32, 32, 2)])
+@pytest.mark.parametrize("act", [1, 0])
+def test_conv3x3_fused_group_norm_one_launch(L, case, act):
+    """phx_conv3x3_mfma_bf16_fgn -- conv2d + bias + group norm (16-channel groups) / instance norm + activation in one launch
+    (tfwrapper/layers.py:123-135 + normalisation.py:3-36): y bit-equal to the convolution with its bias epilogue; a, mean, rstd, scale,
+    shift against the oracle's group_norm / instance_norm of that (bf16) y."""
+    B, H, W, K, N, G = case
+    assert L.conv3x3_fgn_supported(B, H, W, K, N, G) in (32, 64)
+    assert L.conv3x3_fgn_supported(B, 32, 32, K, N, G) == 0 and L.conv3x3_fgn_supported(B, H, W, K, N, 5) == 0
+    x = RNG.standard_normal((B, H, W, K)) + 0.2
+    w = RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K)
+    bias = 0.3 * RNG.standard_normal(N)
+    gamma, beta = 1.0 + 0.2 * RNG.standard_normal(N), 0.3 * RNG.standard_normal(N)
+    xd, wd, bd, g_, b_ = dev(x, BF16), dev(w), dev(bias), dev(gamma), dev(beta)
+    wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    wg = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    L.pack_conv3x3_bf16(wd.data_ptr(), wf.data_ptr(), wg.data_ptr(), K, N, S())
+    y0 = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
+    L.conv3x3_mfma_bf16_ws(xd.data_ptr(), wf.data_ptr(), y0.data_ptr(), bd.data_ptr(), 0, None, None, 0, B, H, W, K, N, S())
+    y, a = torch.empty_like(y0), torch.empty_like(y0)
+    mean, rstd = torch.empty(B, G, dtype=torch.float32).cuda(), torch.empty(B, G, dtype=torch.float32).cuda()
+    scale, shift = torch.empty(B, N, dtype=torch.float32).cuda(), torch.empty(B, N, dtype=torch.float32).cuda()
+    eps = 1e-5
+    L.conv3x3_mfma_bf16_fgn(xd.data_ptr(), wf.data_ptr(), y.data_ptr(), a.data_ptr(), bd.data_ptr(), g_.data_ptr(), b_.data_ptr(), eps, G, act,
+                            mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), B, H, W, K, N, S())
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0)
+    yf = torch.as_tensor(host(y))
+    if G == N:
+        ref = T.instance_norm(yf, torch.as_tensor(gamma), torch.as_tensor(beta), eps)
+    else:
+        ref = T.group_norm(yf, torch.as_tensor(gamma), torch.as_tensor(beta), G, eps)
+    if act == 1:
+        ref = T.relu(ref)
+    close(host(a), ref.numpy(), 1.2e-2, "a = act(gn(conv + bias))")               # bf16 output
+    yg = yf.numpy().reshape(B, H * W, G, N // G)
+    mu, var = yg.mean(axis=(1, 3)), yg.var(axis=(1, 3))
+    close(host(mean), mu, 2e-5, "mean")
+    close(host(rstd), 1.0 / np.sqrt(var + eps), 2e-4, "rstd")
+    sc_ref = np.repeat(1.0 / np.sqrt(var + eps), N // G, axis=1) * gamma
+    close(host(scale), sc_ref, 2e-4, "scale")
+    close(host(shift), beta - np.repeat(mu, N // G, axis=1) * sc_ref, 5e-4, "shift")
