@@ -206,7 +206,7 @@ def test_training_plan_concat_free_and_one_launch_layers_equal_the_plain_plan(sw
     tf.concat -> conv2D edges of posteriors.py:87,120 / priors.py:112 / likelihoods.py:210 read and write their two tensors in place)
     and with one-launch conv + batch norm layers on the small maps (PHX_FBN_MAXP) against the plan without them: same weights, inputs,
     noise.  Concat-free is the same arithmetic (forward / data gradient bit-equal per layer, filter gradients up to summation order):
-    under group norm the loss agrees to 1e-4 and the gradients to 1 %."""
+    under group norm the loss agrees to 1e-4 and the gradients to 1 % (the one-launch layers re-order their statistics: bf16 flips, 1e-2 / 5 %)."""
     from tests.test_model_gpu import _lidc_setup
     res = {}
     if switch == "PHX_DUAL":
@@ -226,7 +226,7 @@ def test_training_plan_concat_free_and_one_launch_layers_equal_the_plain_plan(sw
     assert n1 <= n0 - 12, (n0, n1)
     sharp = norm is not None
     exact = switch == "PHX_DUAL"            # (concat-free: identical arithmetic; the one-launch layers re-order their statistics -> bf16 flips)
-    assert abs(l1 - l0) <= ((1e-4 if exact else 2e-3) if sharp else 2e-2) * abs(l0), (l0, l1)
+    assert abs(l1 - l0) <= ((1e-4 if exact else 1e-2) if sharp else 2e-2) * abs(l0), (l0, l1)
     errs = []
     for name, ga in g0.items():
         nrm = np.linalg.norm(ga)
