@@ -3,11 +3,11 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libphx.so
-SRCS="runtime.hip elementwise.hip losses_opt.hip conv_direct.hip conv_mfma.hip conv_db.hip conv_c32.hip heads.hip metrics.hip comm.hip augment.hip tconv.hip gconv.hip"
+SRCS="runtime.hip elementwise.hip losses_opt.hip conv_direct.hip conv_mfma.hip conv_wgrad.hip conv_db.hip conv_c32.hip heads.hip metrics.hip comm.hip augment.hip tconv.hip gconv.hip"
 OBJS=""
 for s in $SRCS; do
   o="build_${s%.hip}.o"
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ phx_common.h -nt "$o" ] || [ philox.h -nt "$o" ] || [ ../../include/phx.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ phx_common.h -nt "$o" ] || [ conv_common.h -nt "$o" ] || [ philox.h -nt "$o" ] || [ ../../include/phx.h -nt "$o" ]; then
     rm -f "$o"                       # (a failed compile must not leave the previous object behind for the link)
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -c "$s" -o "$o" &
   fi
