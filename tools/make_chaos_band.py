@@ -1,5 +1,5 @@
 """tests/golden/lidc_chaos_band.npz: the oracle's own run-to-run drift at n0 = 32, 128 x 128, batch 2 -- the relative difference of
-the 12-step loss trajectory when the input is perturbed by 1e-6 (oracle/train.py, fp32 torch-CPU; TF1 Adam moves every weight by
+the 8-step loss trajectory when the input is perturbed by 1e-6 (oracle/train.py, fp32 torch-CPU; TF1 Adam moves every weight by
 ~lr * sign-like(m / sqrt(v)), so two exact implementations drift apart).  tests/test_model_gpu.py::lidc_trajectory uses it as the
 tolerance band of the HIP trajectory instead of recomputing the second oracle trajectory (95 s) in every test session.
 Oracle only -- nothing of /root/reference is read."""
@@ -15,7 +15,7 @@ from oracle import init as oinit          # noqa: E402
 from oracle import train as otrain        # noqa: E402
 from tests.helpers import load_golden     # noqa: E402
 
-NSTEP, LR = 12, 2e-5
+NSTEP, LR = 8, 2e-5
 g, cfg, var_order = load_golden("lidc_phiseg_bn")
 x_np, s_np = oinit.synthetic_batch(cfg["B"], cfg["H"], cfg["nlabels"], cfg["data_seed"])
 out = []
