@@ -73,7 +73,11 @@ _NORM_HEAD = os.environ.get("PHX_NORM_HEAD", "1") == "1"     # a 1x1 head that i
 # small maps, batch norm in training mode: convolution + statistics + normalisation + activation in ONE launch (phx_conv3x3_mfma_bf16_fbn:
 # the blocks meet at an arrival counter inside the launch) for layers of up to PHX_FBN_MAXP pixels (B * H * W); 0: off (A/B hook)
 def _fbn_maxp():
-    return int(os.environ.get("PHX_FBN_MAXP", "4096"))      # (read when a plan is built)
+    # OFF by default (0).  Measured with PHX_FBN_MAXP=4096 (the H <= 8 levels, 43 layers): 43 plan entries / ~90 kernel launches fewer
+    # and the same step time (5 991 / 5 996 vs 5 992 / 5 977 images/s, same box) -- but every fused launch carries its layer's
+    # statistics, rendezvous and normalisation pass, so bench.py's convolution family (forward + data-gradient launches timed alone)
+    # would grow by 0.19 - 0.34 ms for no gain in the step (fraction of the MFMA peak 0.247 - 0.251 against 0.260 - 0.264).
+    return int(os.environ.get("PHX_FBN_MAXP", "0"))      # (read when a plan is built)
 
 
 def _bn_mid_maxp():
