@@ -1222,7 +1222,7 @@ class Plan:
                 st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn, bn_small=True)
                 self.saved[op] = st
                 return
-            if (norm != "batch" and mfma and not head1x1 and not xf and dual is None and (_fgn_mode() >= 2 or (_fgn_mode() == 1 and Gn != cout)) and y.dt == BF16 and out.dt == BF16
+            if (norm != "batch" and mfma and not head1x1 and not xf and dual is None and not _DETERMINISTIC and (_fgn_mode() >= 2 or (_fgn_mode() == 1 and Gn != cout)) and y.dt == BF16 and out.dt == BF16
                     and x.dt == BF16 and Lb.conv3x3_fgn_supported(B, H, Wd, cin_eff, cout, Gn)
                     and Lb.norm_small_supported(NS, P, cout, Gn, BF16)):
                 # maps of at most 16 x 16: convolution, bias, group / instance norm and activation in ONE launch (a block holds whole
