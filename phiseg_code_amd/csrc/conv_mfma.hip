@@ -1571,6 +1571,7 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
     const Dual du = take_next_dual();
     PHX_REQUIRE(K % KC == 0 && N % 32 == 0, PHX_E_SHAPE, "conv3x3_mfma: K % 32 == 0 and N % 32 == 0 required");
     PHX_REQUIRE(du.x2 == nullptr || du.K1 < K, PHX_E_SHAPE, "conv3x3_mfma: dual input needs 0 < K1 < K");
+    PHX_REQUIRE(bws.part == nullptr || (du.x2 == nullptr && du.y2 == nullptr), PHX_E_INVAL, "conv3x3_mfma: fused bn-backward sums take no dual input / output");
     PHX_REQUIRE(du.y2 == nullptr || (du.N1 < N && (N - du.N1) % 8 == 0 && y != nullptr && stats_partial == nullptr && bws.part == nullptr),
                 PHX_E_SHAPE, "conv3x3_mfma: dual output needs 0 < N1 < N, (N - N1) % 8 == 0, an output tensor and no statistics epilogue");
     PHX_REQUIRE((((uintptr_t)x | (uintptr_t)wpk | (uintptr_t)y) & 15) == 0, PHX_E_ALIGN, "conv3x3_mfma: 16-byte alignment");
@@ -1770,6 +1771,8 @@ int phx_conv3x3_mfma_bf16_xf(const void* y_prod, const void* wpk, void* y, const
                              const float* p_pivot, const float* p_gamma, const float* p_beta, float p_eps, int p_nrep, int p_NS,
                              int p_G, int p_act, void* a_out, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
                              float* moving_mean, float* moving_var, float momentum, void* stream) {
+    const Dual du_xf = take_next_dual();          // (a pending dual-input / -output modifier must not leak into a later launch)
+    PHX_REQUIRE(du_xf.x2 == nullptr && du_xf.y2 == nullptr, PHX_E_INVAL, "conv3x3_mfma_xf: no dual input / output");
     PHX_REQUIRE(phx_conv3x3_xf_supported(B, H, W, K, N, p_NS), PHX_E_SHAPE, "conv3x3_mfma_xf: shape not supported (see ..._supported)");
     PHX_REQUIRE((((uintptr_t)y_prod | (uintptr_t)wpk | (uintptr_t)y | (uintptr_t)a_out) & 15) == 0, PHX_E_ALIGN, "conv3x3_mfma_xf: 16-byte alignment");
     PHX_REQUIRE(p_sums && p_gamma && p_beta && mean_out && rstd_out && scale_out && shift_out && p_nrep >= 1 && p_G >= 1 && K % p_G == 0 &&

@@ -1187,6 +1187,7 @@ class Plan:
                 # small maps: convolution, batch statistics, normalisation and activation in one launch
                 upd = self.loss is not None
                 acc = self._alloc_zeroed(cout * 2 + (cout // 32 + 3) // 4 * 4)        # sums[N][2] | arrival counters
+                self._has_rendezvous = True
                 self._emit(cv(Lb.conv3x3_mfma_bf16_fbn), x.ptr, wf.ptr, y.ptr, out.ptr, acc.ptr, acc.ptr + cout * 8, gptr, beptr, eps,
                            mean.ptr, rstd.ptr, scale.ptr, shift.ptr,
                            self.store.ptr(nv["moving_mean"]) if upd else None, self.store.ptr(nv["moving_variance"]) if upd else None,
@@ -1800,6 +1801,7 @@ class Plan:
                 # mid-size maps: reduction + apply in ONE launch (phx_bn_mid_bwd: the blocks of a channel slice meet inside the launch)
                 dY = self._alloc(y.shape, y.dt)
                 acc = self._alloc_zeroed(cout * 2 + (cout // 16 + 3) // 4 * 4)          # sums2[C][2] | arrival counters
+                self._has_rendezvous = True
                 self._emit(Lb.bn_mid_bwd, dA.ptr, y.ptr, sv["scale"].ptr, sv["shift"].ptr, sv["mean"].ptr, sv["rstd"].ptr,
                            self.store.ptr(nv["gamma"]), dY.ptr, self.store.grad_ptr(nv["gamma"]), self.store.grad_ptr(nv["beta"]),
                            acc.ptr, acc.ptr + cout * 8, P, cout, act, S,
@@ -2123,6 +2125,8 @@ class Plan:
         return out
 
     def _check_rendezvous(self):
+        if not getattr(self, "_has_rendezvous", False):       # (no launch of this plan meets inside a kernel)
+            return
         n = ctypes.c_int(0)
         self.L.conv3x3_fbn_timeouts(ctypes.byref(n))
         m = ctypes.c_int(0)
