@@ -182,6 +182,23 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const unsigned short* __
         // (channels n, n + 1) trade rows by DPP so that a lane writes one 32-bit word {ch n, ch n + 1}; [pixel][32 ch] bf16, 64-byte rows
         // (v_perm_b32 builds the word from this lane's and the neighbour's packed pairs in one instruction; the statistics run on
         // packed fp32 pairs: the pack loop is the VALU-bound part of this kernel -- 17 -> 8 instructions per word)
+        if constexpr (BIASACT) {                     // (the activation code is uniform per launch: one scalar branch, not two per element)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = fmaf(acc[i][r], sv, bv);
+            if (act == PHX_ACT_RELU) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] = fmaxf(acc[i][r], 0.f);
+            } else if (act != PHX_ACT_ID) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] = act_fwd(acc[i][r], act);
+            }
+        }
         typedef __attribute__((ext_vector_type(2))) float f32x2_t;
         f32x2_t s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
         const unsigned psel = odd ? 0x03020706u : 0x05040100u;       // even lane: {own lo, neighbour lo}; odd: {neighbour hi, own hi}
@@ -192,7 +209,6 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const unsigned short* __
             for (int rp = 0; rp < 8; ++rp) {
                 const int r0 = 2 * rp;
                 float v0 = acc[i][r0], v1 = acc[i][r0 + 1];
-                if constexpr (BIASACT) { v0 = act_fwd(fmaf(v0, sv, bv), act); v1 = act_fwd(fmaf(v1, sv, bv), act); }
                 const unsigned w2 = f2bf_pk(v0, v1);
                 if (stats_partial) {
                     const f32x2_t rv = {__uint_as_float(w2 << 16), __uint_as_float(w2 & 0xffff0000u)};

@@ -239,7 +239,24 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fwd_db(const unsigned short*
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(fmaf(acc[i][j][r], sv, bv), act);
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaf(acc[i][j][r], sv, bv);
+            }
+            // the activation code is uniform per launch: ONE scalar branch here, not two per element (with act_fwd() inside the loops
+            // every element carried the compare-and-branch pairs of the ReLU / softplus tests: a third of this epilogue's time)
+            if (act == PHX_ACT_RELU) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
+            } else if (act != PHX_ACT_ID) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r], act);
             }
         }
         unsigned char* scr = smem + DB_OFF_SCR + wave * DB_SCR_WAVE;

@@ -711,7 +711,24 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(fmaf(acc[i][j][r], sv, bv), act);
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaf(acc[i][j][r], sv, bv);
+            }
+            // the activation code is uniform per launch: ONE scalar branch here, not two per element (with act_fwd() inside the loops
+            // every element carried the compare-and-branch pairs of the ReLU / softplus tests: a third of this epilogue's time)
+            if (act == PHX_ACT_RELU) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
+            } else if (act != PHX_ACT_ID) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r], act);
             }
         }
         // Lane pairs (channels n, n+1) trade one of two rows so that each lane writes ONE 32-bit word {ch n, ch n+1} per
@@ -1111,7 +1128,24 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned sh
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(fmaf(acc[i][j][r], sv, bv), act);
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaf(acc[i][j][r], sv, bv);
+            }
+            // the activation code is uniform per launch: ONE scalar branch here, not two per element (with act_fwd() inside the loops
+            // every element carried the compare-and-branch pairs of the ReLU / softplus tests: a third of this epilogue's time)
+            if (act == PHX_ACT_RELU) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
+            } else if (act != PHX_ACT_ID) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r], act);
             }
         }
         unsigned char* lwp = smem + (wave * 128 + 4 * khalf + odd) * OROW + (l31 & ~1) * 2;
