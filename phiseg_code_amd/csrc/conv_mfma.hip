@@ -631,22 +631,44 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
             const unsigned pselg = odd_g ? 0x03020706u : 0x05040100u;
             for (int pass = 0; pass < 2; ++pass) {
                 unsigned short* dst = pass == 0 ? y : xf.a_out;
+                if (pass == 1) {                             // normalise the accumulators in place: uniform branches only
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const float gmv = xf.gamma[n0 + j * 32 + l31], bev = xf.beta[n0 + j * 32 + l31];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int rq = 0; rq < 4; ++rq) {
+                                const float scv = rg[i][rq][j] * gmv, shv = bev - mg[i][rq][j] * scv;
+#pragma unroll
+                                for (int k2 = 0; k2 < 4; ++k2) acc[i][j][4 * rq + k2] = fmaf(acc[i][j][4 * rq + k2], scv, shv);
+                            }
+                    }
+                    if (xf.act == PHX_ACT_RELU) {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
+                    } else if (xf.act != PHX_ACT_ID) {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r], xf.act);
+                    }
+                }
                 __syncthreads();                             // the previous pass has read its tile (pass 0: the table is no longer needed ... it lives behind the tile)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const float gmv = xf.gamma[n0 + j * 32 + l31], bev = xf.beta[n0 + j * 32 + l31];
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int rp = 0; rp < 8; ++rp) {
                             const int r0 = 2 * rp;
-                            float v0 = acc[i][j][r0], v1 = acc[i][j][r0 + 1];
-                            if (pass == 1) {
-                                const float scv = rg[i][rp >> 1][j] * gmv, shv = bev - mg[i][rp >> 1][j] * scv;
-                                v0 = fmaf(v0, scv, shv); v1 = fmaf(v1, scv, shv);
-                                if (xf.act == PHX_ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                                else if (xf.act != PHX_ACT_ID) { v0 = act_fwd(v0, xf.act); v1 = act_fwd(v1, xf.act); }
-                            }
+                            const float v0 = acc[i][j][r0], v1 = acc[i][j][r0 + 1];
                             const unsigned w2 = f2bf_pk(v0, v1);
                             const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)w2, 0xB1, 0xf, 0xf, true);
                             const int m0 = wave * 64 + i * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * khalf;
