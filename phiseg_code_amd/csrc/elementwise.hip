@@ -582,6 +582,12 @@ __global__ __launch_bounds__(256) void k_norm_wave_bwd(const bf16_t* __restrict_
 #pragma unroll
     for (int j = 0; j < NA; ++j) acc[j] = 0.f;
     const float inv_m = 1.f / ((float)P * (MODE == 1 ? 16.f : 1.f));
+    // The activation is uniform per launch: ReLU / identity through a threshold, softplus in its own copy of the loop.  With
+    // act_grad_pre(pre, act) per element this kernel carried two scalar branches per element (585 in the 256-pixel instantiation,
+    // 8 777 instructions; 90 and 5 143 now).  NOT done in the streaming kernels below: measured slower there.
+    const float thr = act == PHX_ACT_RELU ? 0.f : -INFINITY;
+    auto run = [&](auto softc) {
+    constexpr bool SOFT = decltype(softc)::value;
     for (int i = 0; i < passes; ++i) {
         const int ns = ((blockIdx.y * passes + i) * 4 + wave) * SPW + m.ss;
         const bool live = ns < NS;
@@ -616,7 +622,8 @@ __global__ __launch_bounds__(256) void k_norm_wave_bwd(const bf16_t* __restrict_
             const bool in = live && m.q + it * LPS < P;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float g = df[j] * act_grad_pre(fmaf(xf[j], sc[j], sh[j]), act);
+                const float pre = fmaf(xf[j], sc[j], sh[j]);
+                const float g = SOFT ? df[j] * act_grad_pre(pre, PHX_ACT_SOFTPLUS) : (pre > thr ? df[j] : 0.f);
                 s[j] += g;
                 s[8 + j] = fmaf(g * (xf[j] - mu[j]), rs[j], s[8 + j]);
                 if constexpr (MODE == 1) s[16 + j] += in ? xf[j] - mu[j] : 0.f;
@@ -650,13 +657,16 @@ __global__ __launch_bounds__(256) void k_norm_wave_bwd(const bf16_t* __restrict_
                 bf16x8_unpack(rd[it], df);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float gq = df[j] * act_grad_pre(fmaf(xf[j], sc[j], sh[j]), act);
+                    const float pre = fmaf(xf[j], sc[j], sh[j]);
+                    const float gq = SOFT ? df[j] * act_grad_pre(pre, PHX_ACT_SOFTPLUS) : (pre > thr ? df[j] : 0.f);
                     o[j] = fmaf(ca[j], gq, fmaf(cc[j], xf[j], cb[j]));
                 }
                 VecIO<bf16_t, 8>::store(dx, base + (size_t)p * C, o);
             }
         }
     }
+    };
+    if (act == PHX_ACT_SOFTPLUS) run(std::true_type()); else run(std::false_type());
     // the block's run of samples: one add per channel (every pixel lane of a slot holds the slot's totals; lane q == 0 speaks)
     if (m.q == 0)
 #pragma unroll
