@@ -462,6 +462,9 @@ __global__ __launch_bounds__(256) void k_norm_wave_fwd(bf16_t* __restrict__ x, c
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gm[j] = gamma[c0 + j]; be[j] = beta[c0 + j]; }
     const float inv_m = 1.f / ((float)P * (MODE == 1 ? 16.f : 1.f));
+    const float lo = act == PHX_ACT_RELU ? 0.f : -INFINITY;     // (uniform activation: see k_norm_wave_bwd)
+    auto run = [&](auto softc) {
+    constexpr bool SOFT = decltype(softc)::value;
     for (int i = 0; i < passes; ++i) {
         const int ns = ((blockIdx.y * passes + i) * 4 + wave) * SPW + m.ss;
         const bool live = ns < NS;
@@ -553,11 +556,13 @@ __global__ __launch_bounds__(256) void k_norm_wave_fwd(bf16_t* __restrict__ x, c
                 float f[8];
                 bf16x8_unpack(r[it], f);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] = act_fwd(fmaf(f[j], sc[j], sh[j]), act);
+                for (int j = 0; j < 8; ++j) { const float v = fmaf(f[j], sc[j], sh[j]); f[j] = SOFT ? act_fwd(v, PHX_ACT_SOFTPLUS) : fmaxf(v, lo); }
                 VecIO<bf16_t, 8>::store(y, base + (size_t)p * C, f);
             }
         }
     }
+    };
+    if (act == PHX_ACT_SOFTPLUS) run(std::true_type()); else run(std::false_type());
 }
 
 // dbias: the gradient of a convolution bias in front of the normalisation, sum over samples and pixels of dx, in closed form
