@@ -1286,12 +1286,47 @@ __global__ void k_splitk_finish(const float* __restrict__ ws, int nz, size_t tot
                                 unsigned short* __restrict__ y2, int N1) {
     for (size_t i4 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i4 * 4 < total; i4 += (size_t)gridDim.x * blockDim.x) {
         const size_t i = i4 * 4;
+        // (loads first, four slices at a time -- the plain loop compiled to load / wait / add per slice -- and the slices are added
+        // in their old order: bit-identical sums)
         f32x4 a = *reinterpret_cast<const f32x4*>(ws + i);
-        for (int z = 1; z < nz; ++z) a += *reinterpret_cast<const f32x4*>(ws + (size_t)z * total + i);
-        if (bias != nullptr || act != PHX_ACT_ID || oscale != nullptr) {
+        const bool affine = bias != nullptr || oscale != nullptr;
+        f32x4 sv = {1.f, 1.f, 1.f, 1.f}, bv = {0.f, 0.f, 0.f, 0.f};
+        if (affine) {
             const int n = (int)(i % N);
+            if (oscale != nullptr) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = act_fwd(fmaf(a[q], oscale ? oscale[n + q] : 1.f, bias ? bias[n + q] : 0.f), act);
+                for (int q = 0; q < 4; ++q) sv[q] = oscale[n + q];
+            }
+            if (bias != nullptr) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[q] = bias[n + q];
+            }
+        }
+        int z = 1;
+        for (; z + 3 < nz; z += 4) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(ws + (size_t)z * total + i);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(ws + (size_t)(z + 1) * total + i);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(ws + (size_t)(z + 2) * total + i);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(ws + (size_t)(z + 3) * total + i);
+            a += v0; a += v1; a += v2; a += v3;
+        }
+        if (z + 1 < nz) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(ws + (size_t)z * total + i);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(ws + (size_t)(z + 1) * total + i);
+            a += v0; a += v1;
+            z += 2;
+        }
+        if (z < nz) a += *reinterpret_cast<const f32x4*>(ws + (size_t)z * total + i);
+        if (affine) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = fmaf(a[q], sv[q], bv[q]);
+        }
+        if (act == PHX_ACT_RELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = a[q] > 0.f ? a[q] : 0.f;
+        } else if (act != PHX_ACT_ID) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = act_fwd(a[q], act);
         }
         uint2 o;
         o.x = f2bf_pk(a[0], a[1]);

@@ -769,10 +769,17 @@ __global__ void k_reduce_partials_ns(const float* __restrict__ partial, int T, i
     const int i = blockIdx.x * blockDim.x + threadIdx.x, ns = blockIdx.y;
     if (i >= 2 * C) return;
     const float* p = partial + (size_t)ns * T * 2 * C + i;
-    float a = 0.f;
-    for (int t = 0; t < T; ++t) a += p[(size_t)t * 2 * C];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;             // four independent chains: the T loads of a thread overlap
+    int t = 0;
+    for (; t + 3 < T; t += 4) {
+        a0 += p[(size_t)t * 2 * C];
+        a1 += p[(size_t)(t + 1) * 2 * C];
+        a2 += p[(size_t)(t + 2) * 2 * C];
+        a3 += p[(size_t)(t + 3) * 2 * C];
+    }
+    for (; t < T; ++t) a0 += p[(size_t)t * 2 * C];
     const int which = i / C, c = i % C;
-    sums[((size_t)ns * C + c) * 2 + which] = a;
+    sums[((size_t)ns * C + c) * 2 + which] = (a0 + a1) + (a2 + a3);
 }
 
 // per (ns, g): mean / rstd; per (ns, c): scale / shift; optional TF1 fused-batch-norm moving update
