@@ -754,8 +754,19 @@ static int stream_geometry(int P, int C, int V, int* PL, int* threads, int* chun
 __global__ void k_reduce_partials(const float* __restrict__ partial, int T, int C, float* __restrict__ sums) {
     const int i = blockIdx.x;                 // 0 .. 2C-1 : (which, c)
     const int which = i / C, c = i % C;
-    float a = 0.f;
-    for (int t = threadIdx.x; t < T; t += blockDim.x) a += partial[((size_t)t * 2 + which) * C + c];
+    // (four independent chains: the plain loop compiled to load / wait / add per tile, 16 serial round trips at 4 096 tiles)
+    const float* p = partial + (size_t)which * C + c;
+    const int st = blockDim.x;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int t = threadIdx.x;
+    for (; t + 3 * st < T; t += 4 * st) {
+        a0 += p[(size_t)t * 2 * C];
+        a1 += p[(size_t)(t + st) * 2 * C];
+        a2 += p[(size_t)(t + 2 * st) * 2 * C];
+        a3 += p[(size_t)(t + 3 * st) * 2 * C];
+    }
+    for (; t < T; t += st) a0 += p[(size_t)t * 2 * C];
+    float a = (a0 + a1) + (a2 + a3);
     __shared__ float sh[4];
     a = wave_sum(a);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
