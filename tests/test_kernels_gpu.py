@@ -1514,3 +1514,49 @@ def test_conv3x3_fused_group_norm_one_launch(L, case, act):
     sc_ref = np.repeat(1.0 / np.sqrt(var + eps), N // G, axis=1) * gamma
     close(host(scale), sc_ref, 2e-4, "scale")
     close(host(shift), beta - np.repeat(mu, N // G, axis=1) * sc_ref, 5e-4, "shift")
+
+
+@pytest.mark.parametrize("C", [32, 192])
+def test_norm_reduce_partials_every_tail(L, C):
+    """phx_norm_reduce_partials / _ns (per-tile statistics rows of the convolution epilogue -> sums[c][2] / sums[ns][c][2]): the
+    four-chain loops and their remainders -- tile counts below, at and off the multiples of 4 x 256 (batch form: 256 threads stride
+    the tiles) and of 4 (per-sample form: a thread walks its sample's tiles)."""
+    for ntile in (1, 3, 255, 256, 257, 1024, 1030, 4099):
+        part = RNG.standard_normal((ntile, 2, C))
+        sums = torch.full((C, 2), 7.0, dtype=torch.float32).cuda()
+        L.norm_reduce_partials(dev(part).data_ptr(), ntile, C, sums.data_ptr(), S())
+        close(host(sums), np.float32(part).astype(np.float64).sum(axis=0).T, 2e-6 * np.sqrt(ntile) + 1e-6, "reduce_partials T=%d" % ntile)
+    NS = 3
+    for T_ in (1, 2, 4, 6, 7, 64, 67):
+        part = RNG.standard_normal((NS, T_, 2, C))
+        sums = torch.full((NS, C, 2), 7.0, dtype=torch.float32).cuda()
+        L.norm_reduce_partials_ns(dev(part).data_ptr(), T_, NS, C, sums.data_ptr(), S())
+        ref = np.float32(part).astype(np.float64).sum(axis=1).transpose(0, 2, 1)
+        close(host(sums), ref, 2e-6 * np.sqrt(T_) + 1e-6, "reduce_partials_ns T=%d" % T_)
+
+
+def test_conv3x3_split_k_finish_slice_counts(L):
+    """k_splitk_finish sums its fp32 slices four at a time (loads first) with remainders of two and one: shapes whose split-K
+    factor covers 2 .. 9+ slices, against the unsplit launch of the same convolution (bf16 outputs: one rounding apart at most,
+    the fp32 sums differ by summation order only), with bias + ReLU and without."""
+    seen = set()
+    for (B, H, W, K, N) in [(1, 4, 4, 64, 32), (2, 4, 4, 96, 32), (2, 4, 4, 128, 64), (1, 8, 8, 160, 32), (2, 8, 8, 192, 192),
+                            (1, 2, 2, 192, 64), (2, 2, 2, 288, 32), (1, 4, 4, 384, 64), (1, 8, 8, 576, 64), (4, 16, 16, 192, 192)]:
+        ks = int(L.conv3x3_mfma_ksplit(B, H, W, K, N))
+        seen.add(ks)
+        x = RNG.standard_normal((B, H, W, K))
+        w = RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K)
+        b = RNG.standard_normal(N) * 0.3
+        xd, wd, bd = dev(x, BF16), dev(w), dev(b)
+        wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+        wg = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+        L.pack_conv3x3_bf16(wd.data_ptr(), wf.data_ptr(), wg.data_ptr(), K, N, S())
+        wsb = int(L.conv3x3_mfma_ws_bytes(B, H, W, K, N))
+        wsk = torch.empty(max(wsb // 4, 1), dtype=torch.float32).cuda()
+        for (bp, act) in ((None, 0), (bd.data_ptr(), 1)):
+            y1 = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
+            y2 = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
+            L.conv3x3_mfma_bf16(xd.data_ptr(), wf.data_ptr(), y1.data_ptr(), bp, act, None, B, H, W, K, N, S())
+            L.conv3x3_mfma_bf16_ws(xd.data_ptr(), wf.data_ptr(), y2.data_ptr(), bp, act, None, wsk.data_ptr(), wsb, B, H, W, K, N, S())
+            close(host(y2), host(y1), 5e-3, "split-K (%d slices) vs unsplit, %s" % (ks, (B, H, W, K, N)))
+    assert len([k for k in seen if k > 1]) >= 3, sorted(seen)       # (the shapes above are meant to reach several slice counts)
