@@ -57,7 +57,9 @@ def test_two_rank_engine_step_equals_single_process_big_batch(tmp_path):
         if k.startswith("grad/") or k.startswith("param/"):
             # fp32 summation order differs between 2 + 2 and 4 samples (conditioning bound of the gradients: 3e-2, see
             # test_model_gpu.GRAD_RTOL); Adam moves a weight by ~lr = 1e-5 per step whatever the gradient's size
-            tol = 2e-3 * max(np.abs(ref[k]).max(), 1e-6) if k.startswith("grad/") else 5e-5
+            # (atomic accumulation order varies run to run: 3.2e-3 of a tensor's largest entry seen once in eight runs of this test,
+            # always in the first run on a cold device -- 1e-2 stays 3x under the conditioning bound)
+            tol = 1e-2 * max(np.abs(ref[k]).max(), 1e-6) if k.startswith("grad/") else 5e-5
             np.testing.assert_allclose(r0[k], ref[k], rtol=0, atol=tol, err_msg=k)
             np.testing.assert_allclose(r1[k], r0[k], rtol=0, atol=0, err_msg=k + " (replicas diverged)")
             n += 1
@@ -93,7 +95,7 @@ def test_two_rank_weight_decay_share(tmp_path):
     assert ref["losses"][0][keys.index("weight_decay")] > 1.0          # (a real contribution, not a rounding-level term)
     for k in ref.files:
         if k.startswith("grad/"):        # (conv biases in front of a group norm: +-2e3 values that cancel -> 3e-3 from the summation order)
-            np.testing.assert_allclose(r0[k], ref[k], rtol=0, atol=6e-3 * max(np.abs(ref[k]).max(), 1e-6), err_msg=k)
+            np.testing.assert_allclose(r0[k], ref[k], rtol=0, atol=1e-2 * max(np.abs(ref[k]).max(), 1e-6), err_msg=k)   # (run-to-run atomics order: see above)
             if k.endswith("/W"):         # the decay term's own contribution: a doubled (un-shared) term would be off by 0.37 * W
                 w = ref["param/" + k[5:]]
                 assert np.abs(r0[k] - ref[k]).max() <= 0.05 * 0.37 * np.abs(w).max() + 6e-3 * np.abs(ref[k]).max(), k
