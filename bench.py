@@ -159,6 +159,28 @@ def train_api_rate(args, model, steps=10):
     return args.batch * steps / (time.perf_counter() - t0)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` from a plain shell (no WORLD_SIZE in the environment): become
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <argv>`,
+    one rank per GPU; rank 0 prints the one JSON line.  (RCCL refuses two ranks on one device: with fewer GPUs than ranks only
+    PHX_DIST_BACKEND=gloo -- the protocol-test transport -- is accepted.)"""
+    import socket
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and os.environ.get("PHX_DIST_BACKEND") != "gloo":
+        sys.exit("bench.py: --gpus %d but %d GPU(s) visible (RCCL needs one device per rank; PHX_DIST_BACKEND=gloo runs "
+                 "the ranks on the GPUs there are, host-staged: protocol check only)" % (n, have))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,6 +204,8 @@ def main():
                     help="generate: Monte-Carlo samples drawn per image in one pass (the prior's x-only encoder is shared); "
                          "0: one sample per image and pass, the reference's call pattern")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)            # does not return: this process becomes torch.distributed.run
 
     import numpy as np
     import torch
@@ -240,6 +264,7 @@ def main():
     ctx.barrier()
     dt = ctx.max_float(time.perf_counter() - t0)
     loss = None if generate else float(plan.fetch(model.loss_tot))
+    ranks_seen = int(round(ctx.sum_float(1.0)))          # every rank that really took part in the timed collectives
     images = args.batch * max(spi, 1) * ctx.world * args.steps
     out = {
         "metric": ("segmentation samples/sec (prior sample + likelihood decode) %s %dx%d" % (args.exp, args.image_size, args.image_size))
@@ -257,7 +282,9 @@ def main():
                                                                    args.dtype, args.norm, args.batch,
                                                                    " + RCCL grad all-reduce" if ctx.world > 1 else ""),
                    "global_batch": args.batch * ctx.world, "parallelism": "dp%d" % ctx.world,
-                   "launches_per_step": len(plan.launches) + len(plan.opt_launches), "final_loss": loss},
+                   "launches_per_step": len(plan.launches) + len(plan.opt_launches), "final_loss": loss,
+                   # which transport carried the timed gradient exchange (a fallback cannot be timed unnoticed)
+                   "comm": {"path": ctx.comm_path(), "ranks_seen": ranks_seen}},
     }
     if not generate and args.exp == "phiseg_7_5" and args.image_size == 128:
         out["step_tflops"] = images / dt * F_TRAIN_GFLOP_PER_IMAGE / 1e3

@@ -167,6 +167,13 @@ int phx_db_partial_rows(int B, int H, int W);
 int phx_db_launch(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial, int B, int H,
                   int W, int K, int N, const float* oscale, int dbg, void* stream);
 
+// anti-phase pair kernel for large maps (conv_pp.hip)
+struct Dual;
+bool phx_pp_shape_ok(int B, int H, int W, int K, int N);
+int phx_pp_set_trace(void* dev_buf);
+int phx_pp_launch(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial, int B, int H, int W,
+                  int K, int N, const float* oscale, int stats_nrep, Dual du, int dbg, void* stream);
+
 // ---- forward / dgrad ----------------------------------------------------------------------------------
 __device__ unsigned g_phx_fbn_timeouts = 0;                // FBN launches whose rendezvous gave up (phx_conv3x3_fbn_timeouts)
 // Fused batch-norm backward statistics (data-gradient launches): the tensor this launch writes is dA, the gradient w.r.t. the
@@ -1398,6 +1405,7 @@ int phx_unpad_filter_grad_center(const float* dw_pad, float* dw_1x1, int Cin, in
 int phx_debug_set_trace(void* dev_buf) {
     if (int rc = phx_db_set_trace(dev_buf)) return rc;
     if (int rc = phx_c32_set_trace(dev_buf)) return rc;
+    if (int rc = phx_pp_set_trace(dev_buf)) return rc;
     if (int rc = phx_wgrad_set_debug(dev_buf, nullptr, 0)) return rc;
     unsigned long long* p = (unsigned long long*)dev_buf;
     PHX_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phx_trace), &p, sizeof(p)));
@@ -1680,6 +1688,14 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
         const int ntl = B * (H / 16) * (W / 32);
         const char* dbe = getenv("PHX_DBG_ABLATE");   // dev: bit 1 no patch loads, 2 no slab loads, 4 no MFMAs
         const int dbg = dbe ? atoi(dbe) : 0;
+        {
+            const char* ppe = getenv("PHX_FWD_PP");   // dev: 0 = the one-stage kernel (A/B while both exist)
+            const int pp = ppe ? atoi(ppe) : 1;
+            const bool c32 = K == 32 && N == 32 && !du.x2 && !du.y2 && phx_c32_enabled();
+            if (pp && (!c32 || pp == 2) && bws.part == nullptr && (act == PHX_ACT_ID || act == PHX_ACT_RELU) && phx_pp_shape_ok(B, H, W, K, N))
+                return phx_pp_launch(x, wpk, y, bias, act, stats_partial, B, H, W, K, N, bws.oscale,
+                                     bws.stats_atomic ? (bws.stats_nrep > 1 ? bws.stats_nrep : 1) : 0, du, dbg, stream);
+        }
         if (K == 32 && N == 32 && dbg == 0 && !du.x2 && !du.y2 && bws.part == nullptr && phx_c32_enabled())
             return phx_c32_launch(x, wpk, y, bias, act, stats_partial, B, H, W, bws.oscale,
                                   bws.stats_atomic ? (bws.stats_nrep > 1 ? bws.stats_nrep : 1) : 0, stream);

@@ -89,6 +89,16 @@ class DistContext:
                           "torch.distributed (RCCL) instead" % (self.rank, err or "failed on another rank"), file=sys.stderr)
         return self._comm
 
+    def comm_path(self):
+        """Which transport `allreduce_sum` uses for the gradient arena of a GPU plan: "phx_comm_rccl" (the library's own RCCL
+        communicator on the plan's stream), "torch_rccl" (torch.distributed's RCCL collectives: the loud fallback of _native()),
+        "torch_gloo_host_staged" (several ranks on one GPU: protocol tests) or "none" (single process)."""
+        if not self.active:
+            return "none"
+        if dist.get_backend() == "gloo":
+            return "torch_gloo_host_staged" if self.cuda else "torch_gloo"
+        return "phx_comm_rccl" if (self.cuda and self._native()) else "torch_rccl"
+
     def allreduce_sum(self, tensor, plan=None, bucket_elems=8 << 20):
         """Sum `tensor` (the live part of the flat gradient arena) over ranks, in ~32 MB buckets so RCCL pipelines them over
         the xGMI links.  `plan`: the engine plan whose stream produced the gradients and will consume the sums.

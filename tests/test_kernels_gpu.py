@@ -1560,3 +1560,18 @@ def test_conv3x3_split_k_finish_slice_counts(L):
             L.conv3x3_mfma_bf16_ws(xd.data_ptr(), wf.data_ptr(), y2.data_ptr(), bp, act, None, wsk.data_ptr(), wsb, B, H, W, K, N, S())
             close(host(y2), host(y1), 5e-3, "split-K (%d slices) vs unsplit, %s" % (ks, (B, H, W, K, N)))
     assert len([k for k in seen if k > 1]) >= 3, sorted(seen)       # (the shapes above are meant to reach several slice counts)
+
+
+# the anti-phase pair kernel k_conv3x3_pp (conv_pp.hip; policy: large maps), forced on small shapes.  PHX_PP_GRID = 1 / 3 makes a block
+# walk several (tile pair, channel block) work items (persistent pipeline across tile boundaries, epilogue in the partner's matrix
+# phase); odd tile counts leave the last pair's second half without a tile; N % 64 == 32 takes the 32-channel-block instantiation
+@pytest.mark.parametrize("case", [(2, 16, 32, 32, 128), (1, 32, 64, 96, 64), (3, 16, 32, 32, 192), (1, 48, 32, 64, 256),
+                                  (1, 16, 64, 160, 128), (2, 32, 32, 32, 32), (1, 16, 64, 192, 32), (3, 16, 32, 64, 96),
+                                  (5, 16, 32, 64, 64), (1, 16, 32, 32, 64)])
+@pytest.mark.parametrize("grid", [0, 1, 3])
+def test_conv3x3_mfma_pair_kernel(L, case, grid, monkeypatch):
+    monkeypatch.setenv("PHX_FWD_WS", "5")
+    monkeypatch.setenv("PHX_FWD_DB", "0")
+    monkeypatch.setenv("PHX_FWD_PP", "2")
+    monkeypatch.setenv("PHX_PP_GRID", str(grid))
+    _mfma_case(L, case)
