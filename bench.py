@@ -335,7 +335,7 @@ def main():
                 Bq, Hq, Wq, Kq, Nq = shp[-5:]
                 alg_bytes += 2.0 * Bq * Hq * Wq * (Kq + Nq) + 18.0 * Kq * Nq
         out["roofline"] = {
-            "bound": "mfma", "kernel": "k_conv3x3_mfma<BN> / k_conv3x3_fwd_dma128 (forward + data-gradient launches of one step)",
+            "bound": "mfma", "kernel": "k_conv3x3_pp / k_conv3x3_c32 (large maps) + k_conv3x3_mfma<BN> (forward + data-gradient launches of one step)",
             "achieved": fl / ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS,
             "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 passes; profiles/r0x_pmc_hbm_traffic*.txt)",
             "algorithmic_bytes_per_launch_avg": alg_bytes / max(nl, 1),
@@ -344,11 +344,11 @@ def main():
             "families": {k: {"tflops": v[0] / v[1] / 1e9, "ms_per_step": v[1], "launches": v[2]} for k, v in fam.items()},
             "conv_ms_per_step": sum(v[1] for v in fam.values()),
         }
-        # launches of the family that also carry the layer's batch norm (phx_conv3x3_mfma_bf16_fbn: statistics, rendezvous, second
-        # pass): counted in `achieved` with their whole duration, listed here so that the convolution-only part can be read off
-        fb = [(fl_, ms_) for tag, fl_, ms_, shp in rows if shp and shp[0] in ("fbn", "fgn")]
+        # launches of the family that also carry the layer's group norm (phx_conv3x3_mfma_bf16_fgn: statistics, second pass):
+        # counted in `achieved` with their whole duration, listed here so that the convolution-only part can be read off
+        fb = [(fl_, ms_) for tag, fl_, ms_, shp in rows if shp and shp[0] == "fgn"]
         if fb:
-            out["roofline"]["fused_conv_bn_launches"] = {"launches": len(fb), "ms_per_step": sum(m for _, m in fb),
+            out["roofline"]["fused_conv_gn_launches"] = {"launches": len(fb), "ms_per_step": sum(m for _, m in fb),
                                                          "gflop_per_step": sum(f for f, _ in fb) / 1e9}
         if dom is not None:
             out["roofline"]["dominant_shape"] = {"B_H_W_K_N": list(dom[0]), "launches": dom[1][2], "ms_per_step": dom[1][1],
@@ -386,15 +386,4 @@ def main():
 
 
 if __name__ == "__main__":
-    try:
-        main()
-    except Exception as e:            # noqa: BLE001
-        # The one-launch conv + batch-norm / batch-norm-backward layers meet inside a launch and need all their blocks resident; if
-        # something else on this GPU ever prevents that, the engine raises at the first fetch instead of returning invalid numbers.
-        # Measure without those layers rather than not at all (single-process runs only: ranks must agree on the plan).
-        if "rendezvous" in str(e) and int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("PHX_FBN_MAXP") != "0":
-            print("bench.py: %s -- re-running with PHX_FBN_MAXP=0 PHX_BN_MID_MAXP=0" % e, file=sys.stderr)
-            os.environ["PHX_FBN_MAXP"] = "0"
-            os.environ["PHX_BN_MID_MAXP"] = "0"
-            os.execv(sys.executable, [sys.executable] + sys.argv)
-        raise
+    main()

@@ -105,21 +105,19 @@ int phx_conv3x3_mfma_bf16_ws(const void* x, const void* wpk, void* y, const floa
 int phx_conv3x3_mfma_stats_atomic_supported(int B, int H, int W, int K, int N);
 int phx_conv3x3_mfma_bf16_stats_atomic(const void* x, const void* wpk, void* y, const float* bias, int act, float* sums, int B,
                                        int H, int W, int K, int N, void* stream);
-/* ... with REPLICATED accumulators sums[nrep][N][2] (pixel tile t adds into replica t % nrep) for launches with many tiles -- any shape
- * the policy routes to the 256-pixel or the 16 x 32 LDS-DMA kernels (phx_conv3x3_mfma_stats_rep_supported); consumer:
- * phx_norm_apply_fused_rep.  Replaces the per-tile partial rows + phx_norm_reduce_partials launch of the large-map layers. */
-int phx_conv3x3_mfma_stats_rep_supported(int B, int H, int W, int K, int N);
-int phx_conv3x3_mfma_bf16_stats_rep(const void* x, const void* wpk, void* y, const float* bias, int act, float* sums, int nrep, int B,
-                                    int H, int W, int K, int N, void* stream);
 /* Concat-free convolution (the reference feeds tf.concat([a, b], axis=3) to a 3x3 conv2D: posteriors.py:87,120, priors.py:112,
- * likelihoods.py:210).  One-shot modifiers of the NEXT forward / data-gradient launch made from the calling thread through any
- * phx_conv3x3_mfma_bf16* entry point (not ..._xf / ..._bwdstats), consumed by it:
- *   ..._next_dual_input : reduction channels [0, K1) are read from the launch's x (pixel stride K1), [K1, K) from x2 (stride K - K1)
- *   ..._next_dual_output: output channels [0, N1) go to the launch's y (stride N1), [N1, N) to y2 (stride N - N1); plain outputs only
- * The filter-gradient counterparts take the second tensor explicitly (K1 % 32 == 0; a block's input channels lie in one tensor, so
- * K1 % 64 != 0 selects 32-channel tiles: use the ..._dual plan / workspace queries with the same K1). */
-int phx_conv3x3_next_dual_input(const void* x2, int K1);
-int phx_conv3x3_next_dual_output(void* y2, int N1);
+ * likelihoods.py:210): the forward / data-gradient launch with every option of the entry points above and a second tensor on
+ * either side --
+ *   x2 != NULL: reduction channels [0, K1) are read from x (pixel stride K1), [K1, K) from x2 (stride K - K1), K1 % 32 == 0
+ *   y2 != NULL: output channels [0, N1) go to y (stride N1), [N1, N) to y2 (stride N - N1), N1 % 8 == 0; no statistics epilogue
+ *   oscale     : per-channel scale of the epilogue (NULL: 1), bias: its shift -- see phx_conv3x3_mfma_bf16_affine
+ *   stats_mode : 0 none (stats == NULL), 1 per-tile partial rows stats[tiles][2][N], 2 added atomically into stats[N][2]
+ *                (phx_conv3x3_mfma_stats_atomic_supported)
+ * The filter-gradient counterparts take the second tensor explicitly too (K1 % 32 == 0; a block's input channels lie in one
+ * tensor, so K1 % 64 != 0 selects 32-channel tiles: use the ..._dual plan / workspace queries with the same K1). */
+int phx_conv3x3_mfma_bf16_dual(const void* x, const void* x2, int K1, const void* wpk, void* y, void* y2, int N1, const float* bias,
+                               const float* oscale, int act, float* stats, int stats_mode, void* workspace, size_t workspace_bytes,
+                               int B, int H, int W, int K, int N, void* stream);
 size_t phx_conv3x3_wgrad_ws_bytes_dual(int B, int H, int W, int Cin, int Cout, int K1);
 int phx_conv3x3_wgrad_reduce_plan_dual(int B, int H, int W, int Cin, int Cout, int K1, int* plan6);
 int phx_conv3x3_wgrad_multi_job_dual(const void* x, const void* x2, int K1, const void* dy, float* dw_hwio, void* workspace,
@@ -136,63 +134,24 @@ int phx_conv3x3_fgn_supported(int B, int H, int W, int K, int N, int G);
 int phx_conv3x3_mfma_bf16_fgn(const void* x, const void* wpk, void* y, void* a_out, const float* bias, const float* gamma,
                               const float* beta, float eps, int G, int act, float* mean_out, float* rstd_out, float* scale_out,
                               float* shift_out, int B, int H, int W, int K, int N, void* stream);
-/* Convolution + batch norm (training mode) + activation in ONE launch on small maps (tfwrapper/layers.py:123-135 +
- * normalisation.py:17-36; replaces conv [+ split-K finish] + statistics + apply): the blocks add their tiles' {sum y, sum y^2} to
- * sums[N][2] (zero at launch) with returning device-scope atomics, meet at counters[N / 32] (unsigned, zero at launch), read the sums
- * back and write both y (pre-normalisation, bf16: the backward pass reads it) and a_out = act(y * scale + shift); one block per
- * channel block publishes mean / rstd / scale / shift [N] and applies the TF1 moving update (momentum = 1 - decay; 0: none).
- * phx_conv3x3_fbn_supported -> 0 when the launch would have more than PHX_FBN_MAXBLOCKS (192) blocks (all of them must be resident
- * at once) or in deterministic mode, else the channels per block. */
-int phx_conv3x3_fbn_supported(int B, int H, int W, int K, int N);
-/* number of blocks of ..._fbn launches that gave up waiting at the rendezvous since the library was loaded (synchronises the device;
- * 0 unless a launch could not be co-resident -- its results are invalid then; the engine checks it whenever it fetches) */
-int phx_conv3x3_fbn_timeouts(int* count);
-int phx_conv3x3_mfma_bf16_fbn(const void* x, const void* wpk, void* y, void* a_out, float* sums, void* counters, const float* gamma,
-                              const float* beta, float eps, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
-                              float* moving_mean, float* moving_var, float momentum, int act, int B, int H, int W, int K, int N,
-                              void* stream);
 /* Convolution with an AFFINE epilogue: y = act(conv(x) * scale[n] + shift[n]) -- inference-mode batch norm
  * (normalisation.py:145-163 with is_training = False: y = gamma (x - moving_mean) / sqrt(moving_var + eps) + beta) and its
  * activation folded into the convolution that feeds it: one launch where the reference runs conv2d, batch_norm and relu.
  * scale / shift: phx_bn_infer_scale_shift(_multi).  workspace as for phx_conv3x3_mfma_bf16_ws (may be NULL / 0). */
 int phx_conv3x3_mfma_bf16_affine(const void* x, const void* wpk, void* y, const float* scale, const float* shift, int act,
                                  void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream);
-/* Data-gradient launch with the batch-norm backward statistics of the PRODUCER layer fused into its epilogue: dA (the
- * gradient w.r.t. a = act(bn(y_prod)), [B,H,W,N] bf16) is written as by phx_conv3x3_mfma_bf16(dy, wpk_dgrad, dA, ...), and
- * stats2_partial[tiles][2][N] receives per pixel tile {sum g, sum g * xhat}, g = dA * act'(y_prod * scale + shift),
- * xhat = (y_prod - mean) * rstd (scale/shift/mean/rstd: the producer's [N] vectors, batch norm only) -- the sums
- * phx_norm_bwd_reduce computes in a pass of its own; reduce the rows with phx_norm_reduce_partials.  Only for shapes where
- * phx_conv3x3_mfma_bwdstats_supported(B,H,W,K,N) != 0 (16-wide tiles, every tile interior, no split-K). */
-int phx_conv3x3_mfma_bwdstats_supported(int B, int H, int W, int K, int N);
-int phx_conv3x3_mfma_bf16_bwdstats(const void* dy, const void* wpk_dgrad, void* dA, const void* y_prod, const float* scale,
-                                   const float* shift, const float* mean, const float* rstd, int act_prod,
-                                   float* stats2_partial, int B, int H, int W, int K, int N, void* stream);
-/* Fused conv -> norm -> act -> conv edge (tfwrapper/layers.py:123-135 feeding the next layers.conv2D; normalisation.py:17-36,
- * 145-163): the 3x3 convolution of layer L+1 taking the RAW convolution output y_prod [B,H,W,K] bf16 of layer L.  The
- * normalisation of layer L (training-mode batch norm: p_NS = 1, p_G = K; instance norm: p_NS = B, p_G = K; group norm: p_NS = B,
- * p_G groups of K / p_G channels) is finalised in the launch's prologue from p_sums[p_nrep][p_NS][K][2] = {sum y, sum y^2}
- * (shifted by p_pivot[p_NS][K] when given: the layouts of phx_norm_apply_fused), a = act_p(y_prod * scale + shift) is formed
- * while the input patch is staged (zero padding applies to a), and
- *   - a_out (may be NULL) receives the materialised a [B,H,W,K] bf16 (what phx_norm_apply_fused would have written),
- *   - mean_out / rstd_out [p_NS][p_G], scale_out / shift_out [p_NS][K] are published for the backward pass,
- *   - moving_mean / moving_var (batch norm, may be NULL) get TF1's fused-batch-norm moving update with `momentum`.
- * Output side as phx_conv3x3_mfma_bf16_ws: y, bias / act, stats = per-tile partial sums [phx_conv3x3_xf_tiles][2][N], or with
- * stats_atomic != 0 the accumulator sums[N][2] itself (added atomically); workspace: split-K slices (phx_conv3x3_xf_ws_bytes; only
- * without stats).  Register-staged 256-pixel tiles on every map size; p_NS > 1 needs tiles inside one sample (H, W >= 16). */
-int phx_conv3x3_xf_supported(int B, int H, int W, int K, int N, int NS);
-int phx_conv3x3_xf_tiles(int B, int H, int W);
-size_t phx_conv3x3_xf_ws_bytes(int B, int H, int W, int K, int N);
-int phx_conv3x3_mfma_bf16_xf(const void* y_prod, const void* wpk, void* y, const float* bias, int act, float* stats, int stats_atomic,
-                             void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, const float* p_sums,
-                             const float* p_pivot, const float* p_gamma, const float* p_beta, float p_eps, int p_nrep, int p_NS,
-                             int p_G, int p_act, void* a_out, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
-                             float* moving_mean, float* moving_var, float momentum, void* stream);
 /* number of pixel tiles (= rows of stats_partial) phx_conv3x3_mfma_bf16 uses for this shape */
 int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W, int K, int N);
 /* debug: device buffer of >= 16 uint64 that receives shader-clock phase timestamps of block 0 (NULL disables) */
 int phx_debug_set_trace(void* dev_buf);
 /* debug: device buffer of 4 uint64 per block {start, end, HW_ID | XCC_ID << 32, realtime} written by the MFMA conv kernels */
 int phx_debug_set_blocklog(void* dev_buf);
+/* debug / tests: kernel-selection policy of the forward / data-gradient launches, process-wide (1 = the measured policy, the
+ * default; 0 = never; 2 = whenever the shape is eligible) -- large_maps: the 16 x 32-tile large-map kernels (k_conv3x3_pp,
+ * k_conv3x3_c32); big_tiles: the 16 x 32-tile instantiations of the 256-pixel kernel.  The tests force every family onto small
+ * shapes with it; phx_debug_pair_kernel_grid: persistent grid of the pair kernel (0: one work-group per CU). */
+int phx_debug_conv_policy(int large_maps, int big_tiles);
+int phx_debug_pair_kernel_grid(int blocks);
 /* dw_hwio[kh][kw][ci][co] += sum x * dy, Cin % 32 == 0, Cout % 32 == 0.  With a workspace (>= phx_conv3x3_wgrad_ws_bytes)
  * the per-block partial filters are stored with plain writes and summed by a second kernel; workspace == NULL falls back
  * to fp32 atomics straight into dw_hwio (a CU issues those at ~1 lane/clock: 46 us per block on MI355X). */
@@ -339,16 +298,6 @@ int phx_bn_small_fwd_splitk(const float* ws, int nz, void* x_out, const float* g
 int phx_bn_small_bwd(const void* dA, const void* x, const float* scale, const float* shift, const float* mean,
                      const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, int P, int C, int act,
                      void* stream);
-/* Batch-norm backward (+ activation gradient) of a mid-size layer in ONE launch: phx_bn_small_bwd's arithmetic with the pixels of a
- * 16-channel slice split over several blocks that add their partial sums to sums2[C][2] (zero at launch) with returning device-scope
- * atomics and meet at counters[C / 16] (unsigned, zero at launch) -- replaces phx_norm_bwd_reduce + phx_norm_bwd_apply_fused for
- * bf16 tensors whose launch fits PHX_BN_MID_MAXBLOCKS (192) resident blocks (P <= 65 536 at C = 192).  ..._supported -> 0 or the
- * pixels per block / 512; ..._timeouts: blocks that gave up at the rendezvous since the library was loaded (results invalid then). */
-int phx_bn_mid_supported(int P, int C, int dt);
-int phx_bn_mid_timeouts(int* count);
-int phx_bn_mid_bwd(const void* dA, const void* x, const float* scale, const float* shift, const float* mean, const float* rstd,
-                   const float* gamma, void* dx, float* dgamma, float* dbeta, float* sums2, void* counters, int P, int C, int act,
-                   void* stream);
 /* Group / instance norm (tfwrapper/normalisation.py:3-36), bf16 NHWC, the whole layer in ONE launch when a sample has
  * P = H*W <= 256 pixels (maps up to 16 x 16) and the statistic is per channel (G == C: instance norm) or per 16-channel
  * group (G * 16 == C: group_norm2D's default groups for C >= 32): a wave owns (sample, 16-channel slice) pairs, keeps the

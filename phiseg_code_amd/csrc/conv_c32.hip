@@ -269,23 +269,18 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const unsigned short* __
 
 }  // namespace
 
-// PHX_C32 (read per call; default 1): 0 leaves the 32 -> 32 layers to k_conv3x3_fwd_dma128<32>
 int phx_c32_set_trace(void* dev_buf) {
     PHX_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_c32_trace), &dev_buf, sizeof(void*)));
     return PHX_OK;
 }
-bool phx_c32_enabled() {
-    const char* e = getenv("PHX_C32");
-    return e ? atoi(e) != 0 : true;
-}
+bool phx_c32_enabled() { return true; }
 
-// same contract as the k_conv3x3_fwd_dma128 launch inside conv3x3_mfma_impl (K = N = 32, H % 16 == 0, W % 32 == 0): statistics as
+// same contract as the pair-kernel launch inside conv3x3_mfma_impl (K = N = 32, H % 16 == 0, W % 32 == 0): statistics as
 // per-tile partial rows [tile][2][32] (stats_nrep == 0) or added to stats_nrep accumulator replicas
 int phx_c32_launch(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial, int B, int H, int W,
                    const float* oscale, int stats_nrep, void* stream) {
     const int tiles_x = W / 32, tiles_y = H / 16, ntiles = B * tiles_x * tiles_y;
-    const char* ge = getenv("PHX_C32_GRID");      // persistent grid size (default: two blocks per CU)
-    const int cap = ge && atoi(ge) > 0 ? atoi(ge) : 512;
+    const int cap = 512;                          // persistent grid: two blocks per CU
     const int grid = ntiles < cap ? ntiles : cap;
     const bool ba = bias != nullptr || act != PHX_ACT_ID || oscale != nullptr;
     PHX_REQUIRE(ntiles < 65536, PHX_E_SHAPE, "conv3x3_c32: more than 65535 tiles");

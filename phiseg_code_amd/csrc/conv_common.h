@@ -41,9 +41,6 @@ static void mtile_magic(MTile* g) {
     // are what bounds these kernels); padded to the pitches below -- found by enumeration -- every group is a permutation.
     g->rpitch = (int)pw * ROWB;
     g->ipitch = (int)ph * g->rpitch;
-    static int pad = -1;
-    if (pad < 0) { const char* e = getenv("PHX_LDS_PAD"); pad = e ? atoi(e) : 1; }      // A/B hook (0: dense images)
-    if (!pad) return;
     if (g->tws == 3 && g->ths == 3) { g->rpitch = 56 * 16; g->ipitch = 560 * 16; }
     else if (g->tws == 2 && g->ths == 2) { g->rpitch = 36 * 16; g->ipitch = 224 * 16; }
     else if (g->tws == 1 && g->ths == 1) { g->rpitch = 22 * 16; g->ipitch = 92 * 16; }

@@ -9,34 +9,27 @@
 // re-used by all nine filter taps from LDS.
 #include "conv_common.h"
 
+// Kernel-selection policy of the forward / data-gradient launches: 1 = the measured policy below (the default), 0 = never, 2 =
+// whenever the shape is eligible.  Process-wide; phx_debug_conv_policy sets it -- the tests force every kernel family onto small shapes.
+static int g_ws_policy = 1;                // large-map kernels on 16 x 32-pixel tiles (k_conv3x3_pp, k_conv3x3_c32)
+static int g_tile_policy = 1;              // 16 x 32-pixel / 8-wave instantiations of k_conv3x3_mfma
+
 // forward / data-gradient tiles.  16 x 32 tiles (512 pixels, 8-wave blocks, one per CU) halve the filter-slab bytes staged
 // per FLOP but give up the overlap of two independent blocks per CU: measured, they win for 128-wide output-channel blocks
 // and for the K >= 128 -> 32 layers, when the map has at least two such tiles per CU; everything else uses 256-pixel tiles.
 static bool fwd_big_tiles(int B, int H, int W, int K, int N) {
-    const char* e = getenv("PHX_FWD_BIG");                     // 0: never, 2: whenever the map allows (tests), default: policy
-    const int en = e ? atoi(e) : 1;
-    if (!en || H % 32 != 0 || W % 16 != 0) return false;
-    if (en == 2) return true;                                  // dev: force
+    if (!g_tile_policy || H % 32 != 0 || W % 16 != 0) return false;
+    if (g_tile_policy == 2) return true;                       // tests: whenever the map allows
     return (N % 128 == 0 || (N == 32 && K >= 128)) && (long)B * (H / 32) * (W / 16) >= 512;
 }
-// 16 x 32-pixel tiles, LDS-DMA staged (PHX_FWD_WS selects):
-//   unset / 1: policy -- when the map has at least 512 blocks of 16 x 32 pixels x 64 (32) channels (the 128 x 128 and 64 x 64
-//              levels at batch 64): measured 1.1-1.3x the 256-pixel kernels there, equal on 32 x 32 maps
-//   0: never;  5: whenever the shape is eligible (tests)
-// PHX_FWD_DB=1: the experimental double-buffered persistent kernel k_conv3x3_fwd_db (conv_db.hip) takes the N % 64 == 0 shapes
-static int fwd_ws_mode() {
-    const char* e = getenv("PHX_FWD_WS");                      // (tests flip it between calls: not cached)
-    return e ? atoi(e) : 1;
-}
+// Large maps: 16 x 32-pixel tiles, LDS-DMA staged, when the map has at least 512 tiles x 64 (32)-channel blocks, i.e. a work item per
+// CU for the pair kernel (the 128 x 128 and 64 x 64 levels at batch 64): measured 1.1-1.5x the 256-pixel kernels there, equal or
+// behind on 32 x 32 maps.  32-channel blocks (N % 64 == 32): 13 % faster than the 256-pixel kernel at K = 32, 8 % at K = 64, 5 %
+// SLOWER at K = 192 (the patch is staged once per 32 output channels).
 static bool fwd_ws64(int B, int H, int W, int K, int N) {
-    const int en = fwd_ws_mode();
-    if (!en || H % 16 != 0 || W % 32 != 0 || N % 32 != 0 || K % 32 != 0) return false;
-    if (en >= 2) return true;
-    // 32-channel blocks: 13 % faster than the 64-pixel-tile kernel at K = 32 (39 vs 45 us on 64 x 128 x 128), 8 % at K = 64,
-    // 5 % SLOWER at K = 192 (the patch is staged once per 32 output channels)
-    static int n32 = -1;
-    if (n32 < 0) { const char* t = getenv("PHX_FWD_N32"); n32 = t ? atoi(t) : 1; }                 // A/B hook
-    if (N % 64 != 0 && (K > 64 || !n32)) return false;
+    if (!g_ws_policy || H % 16 != 0 || W % 32 != 0 || N % 32 != 0 || K % 32 != 0) return false;
+    if (g_ws_policy >= 2) return true;
+    if (N % 64 != 0 && K > 64) return false;
     return (long)B * (H / 16) * (W / 32) * (N / (N % 64 == 0 ? 64 : 32)) >= 512;
 }
 static MTile make_mtile_fwd(int B, int H, int W, int K, int N, bool allow_dma = true) {
@@ -155,58 +148,33 @@ __global__ void k_unpad_rows_acc(const float* __restrict__ dwp, float* __restric
     }
 }
 
-// double-buffered persistent kernel for large maps (conv_db.hip)
-bool phx_db_enabled();
 int phx_c32_set_trace(void* dev_buf);
 int phx_wgrad_set_debug(void* trace_buf, void* blocklog_buf, int which);      // conv_wgrad.hip
 bool phx_c32_enabled();                       // conv_c32.hip: the 32 -> 32-channel layers on large maps (filter in registers, persistent)
 int phx_c32_launch(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial, int B, int H, int W,
                    const float* oscale, int stats_nrep, void* stream);
-int phx_db_set_trace(void* dev_buf);
-int phx_db_partial_rows(int B, int H, int W);
-int phx_db_launch(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial, int B, int H,
-                  int W, int K, int N, const float* oscale, int dbg, void* stream);
-
 // anti-phase pair kernel for large maps (conv_pp.hip)
 struct Dual;
 bool phx_pp_shape_ok(int B, int H, int W, int K, int N);
 int phx_pp_set_trace(void* dev_buf);
+int phx_pp_set_grid(int blocks);
 int phx_pp_launch(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial, int B, int H, int W,
                   int K, int N, const float* oscale, int stats_nrep, Dual du, int dbg, void* stream);
 
 // ---- forward / dgrad ----------------------------------------------------------------------------------
-__device__ unsigned g_phx_fbn_timeouts = 0;                // FBN launches whose rendezvous gave up (phx_conv3x3_fbn_timeouts)
-// Fused batch-norm backward statistics (data-gradient launches): the tensor this launch writes is dA, the gradient w.r.t. the
-// OUTPUT a = act(bn(y)) of the producer layer; with y and the producer's per-channel scale / shift / mean / rstd the
-// epilogue also emits part[tile][2][N] = {sum g, sum g * xhat}, g = dA * act'(y * scale + shift), xhat = (y - mean) * rstd --
-// what k_norm_bwd_reduce would compute in a pass of its own over dA and y (4 B/element and a launch per layer).
-struct BwdStats {
-    const unsigned short* y;
-    const float *scale, *shift, *mean, *rstd;
-    float* part;
-    int act, stats_atomic;    // stats_atomic: stats_partial is the accumulator sums[N][2] itself, added to atomically
-    int stats_nrep;           // ... replicated stats_nrep (>= 1) times [rep][N][2]: pixel tile t adds into replica t % stats_nrep
+// Options of the forward / data-gradient epilogue.
+struct EpiOpts {
+    int stats_atomic;         // stats_partial is the accumulator sums[N][2] itself, added to atomically (few pixel tiles)
     const float* oscale;      // per-output-channel scale of the bias / activation epilogue (inference-mode batch norm folded in)
 };
 
-// Fused conv -> norm -> act -> conv edge (XF instantiations, tfwrapper/layers.py:123-135 + normalisation.py:17-36,145-163): the
-// input tensor x is the PRODUCER's raw convolution output y_prod; the normalisation is finalised from its {sum y, sum y^2} in
-// this kernel's prologue (every block: scale / shift of all K channels into an LDS table; ONE block publishes mean / rstd / scale /
-// shift for the backward pass and applies the batch-norm moving update), and a = act(y_prod * scale[c] + shift[c]) is formed
-// between the global load and the LDS store of the staging path -- out-of-image pieces stay zero, because SAME padding pads a,
-// not y.  The channel-block-0 work-groups also write the interior of their transformed tile to a_out (the filter gradient and any
-// later reader use the materialised a), so the stand-alone apply pass (read y, write a) and its launch disappear from the chain.
+// Arguments of the one-launch conv + bias + group / instance norm + activation epilogue (FGN instantiations).
 struct XForm {
-    const float* sums;        // [nrep][NS][K][2] {sum y, sum y^2} of the producer (pivot-shifted when pivot != NULL)
-    const float* pivot;       // [NS][K] or NULL
-    const float *gamma, *beta;    // [K]
-    float eps, invP;          // invP = 1 / (pixels per (sample, channel) statistic)
-    int nrep, NS, G, act;     // NS: 1 (batch norm) or B (group / instance norm: every pixel tile lies inside one sample)
-    unsigned short* a_out;    // NULL or [B][H][W][K] bf16
-    float *mean_out, *rstd_out, *scale_out, *shift_out;     // [NS][G], [NS][K]
-    float *moving_mean, *moving_var;                        // batch norm in training mode, else NULL
-    float momentum;
-    unsigned* counter;        // FBN: [N / BN] arrival counters (zero at launch), one per output-channel block
+    const float *gamma, *beta;    // [N]
+    float eps;
+    int G, act;
+    unsigned short* a_out;    // [B][H][W][N] bf16
+    float *mean_out, *rstd_out, *scale_out, *shift_out;     // [B][G], [B][N]
 };
 // Concat-free convolution (posteriors.py:87,120, priors.py:112, likelihoods.py:210 feed tf.concat([a, b], axis=3) to a 3x3 conv2D):
 // forward / filter gradient read the two tensors in place -- reduction channels [0, K1) from x (pixel stride K1), [K1, K) from x2
@@ -217,7 +185,6 @@ struct Dual {
     unsigned short* y2;
     int K1, N1;
 };
-constexpr int XF_TBL_BYTES = 4096;      // LDS scale / shift table in front of the stages: K <= 512 channels x 2 floats
 
 // NA = compile-time bound on the 16-byte input-patch pieces a thread stages per 32-channel chunk
 // (ceil(npatch * 4 / 256): 6 for 16x16 tiles, 7 for 8x8x4, 9 for 4x4x16, 16 for 2x2x64).
@@ -227,12 +194,6 @@ constexpr int XF_TBL_BYTES = 4096;      // LDS scale / shift table in front of t
 // SPLITK (small maps: a handful of pixel tiles cannot fill 256 CUs and each block would walk all K / 32 chunks serially,
 // ~2 us apiece): gridDim.z blocks share a tile, each takes a run of chunks and stores its fp32 accumulators to
 // ws[z][pixel][N]; k_splitk_finish sums the slices, adds bias / activation and writes the bf16 tensor.
-// FBN (small maps, batch norm in training mode; tfwrapper/layers.py:123-135 + normalisation.py:17-36 in ONE launch): the epilogue adds
-// the tile's {sum y, sum y^2} to sums[N][2] with RETURNING device-scope atomics, the blocks of one output-channel block meet at an
-// arrival counter (every block of the launch is resident: the launcher bounds the grid), read the finished sums back, and write
-// a = act(y * scale + shift) from the accumulators they still hold -- no statistics / split-K-finish / apply launches, and nothing
-// but atomics crosses the XCDs' L2s (a bulk hand-off would need an L2 write-back: 38 us).  xf carries the
-// normalisation's arguments (sums, gamma, beta, eps, invP, act, a_out, the published vectors, the moving statistics, counter).
 // DUAL (struct Dual; its own instantiations, so that the ordinary launches carry neither the second plan nor the selects): the
 // second offset plan ga2 addresses du.x2, every prefetched chunk picks its tensor by a scalar compare; the epilogue stores by piece.
 // FGN (maps of at most 16 x 16 pixels = whole samples per pixel tile; group norm with 16-channel groups or instance norm): the
@@ -240,22 +201,21 @@ constexpr int XF_TBL_BYTES = 4096;      // LDS scale / shift table in front of t
 // in ONE launch with no cross-block step at all: a block owns its samples' pixels for its BN channels, i.e. whole groups, so the
 // two-pass statistics (sum, then sum of squared deviations, through a small LDS table) are block-local.  xf carries gamma / beta /
 // eps / act / G / a_out and the published per-sample vectors; bias is the convolution's.
-template <int BN, int NA, bool FAST16, bool BIASACT, int NW, bool SPLITK, bool XF = false, bool FBN = false, bool DUAL = false, bool FGN = false>
+template <int BN, int NA, bool FAST16, bool BIASACT, int NW, bool SPLITK, bool DUAL = false, bool FGN = false>
 // (NA = 16 -- the 4 x 4 x 16 / 2 x 2 x 64 tiles of the H <= 4 levels: at most a few dozen blocks per launch -- with the second plan of
 // the DUAL instantiations is compiled for one block per CU: 96 staging registers + two plans + accumulators do not fit 256)
 __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) void k_conv3x3_mfma(const unsigned short* __restrict__ x,
                                                          const unsigned short* __restrict__ wpk,
                                                          unsigned short* __restrict__ y, const float* __restrict__ bias,
                                                          int act, float* __restrict__ stats_partial, int B, int H, int W,
-                                                         int K, int N, MTile g, float* __restrict__ ws, BwdStats bws, XForm xf, Dual du) {
+                                                         int K, int N, MTile g, float* __restrict__ ws, EpiOpts bws, XForm xf, Dual du) {
     constexpr int NJ = BN / 32;
     constexpr int NT = NW * 64;                            // threads; the tile has NT pixels
     constexpr int NB = (9 * BN * 4 + NT - 1) / NT;        // filter-slab pieces per thread
     const int tw = FAST16 ? 16 : 1 << g.tws, th = FAST16 ? NT / 16 : 1 << g.ths;
     const int pw = tw + 2, ph = th + 2;
     const int npatch = FAST16 ? 18 * (NT / 16 + 2) : g.tb * ph * pw;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned char* const smem = smem_raw + (XF ? XF_TBL_BYTES : 0);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;                    // [npatch][ROWB]
     // (the 512-pixel x 32-channel variant measured 12 % slower with the padded pitch -- it keeps the dense one)
     constexpr int P16 = (NW == 8 && BN == 32) ? 18 * ROWB : PITCH16;
@@ -302,7 +262,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
     unsigned ga[NA];
     unsigned ga2[DUAL ? NA : 1];                 // DUAL: the same pieces in du.x2 (pixel stride K - K1)
     unsigned sa[FAST16 ? 1 : NA];                // small-map tiles: LDS byte offset of the piece's pixel (padded pitches, see mtile_magic)
-    unsigned wmask = 0;                          // XF: pieces whose transformed value this thread also writes to a_out
     const int K1 = (DUAL && du.x2 != nullptr) ? du.K1 : K;      // channels (= pixel stride) of x
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
@@ -330,8 +289,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
             }
             ga[it] = in ? off : 0xffffffffu;
             if constexpr (DUAL) ga2[it] = in ? off2 : 0xffffffffu;
-            if constexpr (XF)
-                if (in && cob == 0 && xf.a_out != nullptr && px >= 1 && px <= tw && py >= 1 && py <= th) wmask |= 1u << it;
         }
     }
     // filter-slab pieces: piece `it` of a thread lies it * 64 slab rows further on, i.e. a fixed byte stride -> one VGPR
@@ -363,8 +320,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
     PHX_TRACE(0);
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     u32x4 ra[NA], rb[NB];
-    __amdgpu_buffer_rsrc_t rsa = rsx;
-    if constexpr (XF) rsa = __builtin_amdgcn_make_buffer_rsrc((void*)xf.a_out, 0, xf.a_out ? (int)((unsigned)B * H * W * K * 2u) : 0, 0x00020000);
     // piece `idx` (input-patch pieces first, then filter-slab pieces) of the chunk starting at channel c0
     auto prefetch_piece = [&](auto idxc, int c0) {
         constexpr int idx = decltype(idxc)::value;
@@ -396,57 +351,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
         all(all, std::integral_constant<int, 0>());
     }
     PHX_TRACE(1);
-    if constexpr (XF) {
-        // (behind the first chunk's loads) normalisation of the producer, finalised here (the formulas of k_norm_apply_fused): thread c derives channel c
-        float* tbl = reinterpret_cast<float*>(smem_raw);
-        const int ns = xf.NS > 1 ? b0 : 0;
-        const int cg = K / xf.G;
-        const bool pub = cob == 0 && tx0 == 0 && ty0 == 0 && (xf.NS > 1 || b0 == 0) && (!SPLITK || blockIdx.z == 0);
-        const size_t rstride = (size_t)xf.NS * K * 2;
-        for (int c = threadIdx.x; c < K; c += NT) {
-            const int gq = c / cg;
-            float mu = 0.f;
-            for (int q = gq * cg; q < (gq + 1) * cg; ++q) {
-                float s1 = 0.f;
-                for (int r = 0; r < xf.nrep; ++r) s1 += xf.sums[r * rstride + ((size_t)ns * K + q) * 2];
-                mu += (xf.pivot ? xf.pivot[(size_t)ns * K + q] : 0.f) + s1 * xf.invP;
-            }
-            mu /= (float)cg;
-            float var = 0.f;
-            for (int q = gq * cg; q < (gq + 1) * cg; ++q) {
-                float s1 = 0.f, s2 = 0.f;
-                for (int r = 0; r < xf.nrep; ++r) {
-                    s1 += xf.sums[r * rstride + ((size_t)ns * K + q) * 2];
-                    s2 += xf.sums[r * rstride + ((size_t)ns * K + q) * 2 + 1];
-                }
-                const float d1 = s1 * xf.invP;
-                float vc = s2 * xf.invP - d1 * d1;
-                vc = vc > 0.f ? vc : 0.f;
-                const float dm = (xf.pivot ? xf.pivot[(size_t)ns * K + q] : 0.f) + d1 - mu;
-                var += vc + dm * dm;
-            }
-            var /= (float)cg;
-            const float rs = rsqrtf(var + xf.eps);
-            const float scv = xf.gamma[c] * rs;
-            const float shv = xf.beta[c] - mu * scv;
-            tbl[2 * c] = scv;
-            tbl[2 * c + 1] = shv;
-            if (pub) {
-                xf.scale_out[(size_t)ns * K + c] = scv;
-                xf.shift_out[(size_t)ns * K + c] = shv;
-                if (c == gq * cg) {
-                    xf.mean_out[ns * xf.G + gq] = mu;
-                    xf.rstd_out[ns * xf.G + gq] = rs;
-                    if (xf.momentum > 0.f && xf.moving_mean) {       // batch norm (G == K): TF1 fused-batch-norm moving update
-                        const float m = (float)cg / xf.invP;
-                        xf.moving_mean[gq] -= (xf.moving_mean[gq] - mu) * xf.momentum;
-                        xf.moving_var[gq] -= (xf.moving_var[gq] - var * (m / fmaxf(m - 1.f, 1.f))) * xf.momentum;
-                    }
-                }
-            }
-        }
-    }
-
     // one 32-channel chunk: registers -> LDS, then 18 (tap, k-step) groups of 2 x NJ MFMAs; with PF the global loads of the
     // NEXT chunk are issued one or two per group, so the texture-address unit (64 B/clk: ~1 K cycles per chunk for the four
     // waves) works underneath the matrix pipe instead of in a phase of its own.
@@ -455,31 +359,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
         constexpr bool PF = decltype(pfc)::value;
         __syncthreads();                         // every wave is done reading the previous chunk / epilogue tile from LDS
         if (tr) PHX_TRACE(2);
-        if constexpr (XF) {
-            // a = act(y * scale + shift) on the eight channels of this thread's pieces (the same eight for all of them)
-            const float* tq = reinterpret_cast<const float*>(smem_raw) + (ccur + (threadIdx.x & 3) * 8) * 2;
-            float sc[8], sh[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float4 v4 = *reinterpret_cast<const float4*>(tq + 4 * e);
-                sc[2 * e] = v4.x; sh[2 * e] = v4.y; sc[2 * e + 1] = v4.z; sh[2 * e + 1] = v4.w;
-            }
-#pragma unroll
-            for (int it = 0; it < NA; ++it) {
-                u32x4 t;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const unsigned wv = ra[it][d];
-                    float lo = fmaf(__uint_as_float(wv << 16), sc[2 * d], sh[2 * d]);
-                    float hi = fmaf(__uint_as_float(wv & 0xffff0000u), sc[2 * d + 1], sh[2 * d + 1]);
-                    if (xf.act == PHX_ACT_RELU) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-                    else if (xf.act != PHX_ACT_ID) { lo = act_fwd(lo, xf.act); hi = act_fwd(hi, xf.act); }
-                    t[d] = ga[it] == 0xffffffffu ? 0u : f2bf_pk(lo, hi);       // SAME padding pads a, not y
-                }
-                ra[it] = t;
-                if (wmask) __builtin_amdgcn_raw_buffer_store_b128(t, rsa, ((wmask >> it) & 1u) ? ga[it] : 0xffffffffu, ccur * 2, 0);
-            }
-        }
 #pragma unroll
         for (int it = 0; it < NA; ++it) {
             const int i = threadIdx.x + it * NT;
@@ -802,51 +681,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
                 }
             unsigned short* yp = ybase + (((size_t)cb0 * H + cy0 + (mt >> 4)) * W + cx0 + (mt & 15)) * yld + ych;
             const size_t ystep = (size_t)(NT / PPP / 16) * W * yld;
-            if (bws.part == nullptr) {
 #pragma unroll
-                for (int it = 0; it < PPP; ++it)
-                    if (!(PHX_ABLATE & 8) || cx0 < 0)
-                        *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * (NT / PPP) * OROW);
-            } else {
-                // fused BN-backward statistics: this thread's pieces all belong to channels n0 + 8 q .. + 7
-                float sc[8], sh[8], mu[8], rs[8], t1[8], t2[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int c = n0 + q * 8 + e;
-                    sc[e] = bws.scale[c]; sh[e] = bws.shift[c]; mu[e] = bws.mean[c]; rs[e] = bws.rstd[c];
-                    t1[e] = t2[e] = 0.f;
-                }
-                const unsigned short* yq = bws.y + (yp - y);
-#pragma unroll
-                for (int it = 0; it < PPP; ++it) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(lr + it * (NT / PPP) * OROW);
-                    const uint4 yv = *reinterpret_cast<const uint4*>(yq + it * ystep);
-                    *reinterpret_cast<uint4*>(yp + it * ystep) = v;
-                    const unsigned vw[4] = {v.x, v.y, v.z, v.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float da = __uint_as_float((e & 1) ? (vw[e >> 1] & 0xffff0000u) : (vw[e >> 1] << 16));
-                        const float yy = __uint_as_float((e & 1) ? (yw[e >> 1] & 0xffff0000u) : (yw[e >> 1] << 16));
-                        const float gq = da * act_grad_pre(yy * sc[e] + sh[e], bws.act);
-                        t1[e] += gq;
-                        t2[e] += gq * (yy - mu[e]) * rs[e];
-                    }
-                }
-                __syncthreads();                             // the output tile has been read: LDS becomes reduction scratch
-                float* scr = reinterpret_cast<float*>(smem);  // [NT][16]
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    scr[threadIdx.x * 16 + e] = t1[e];
-                    scr[threadIdx.x * 16 + 8 + e] = t2[e];
-                }
-                __syncthreads();
-                if (threadIdx.x < 2 * BN) {
-                    const int which = threadIdx.x / BN, n = threadIdx.x % BN;
-                    float a = 0.f;
-                    for (int m2 = 0; m2 < NT / PPP; ++m2) a += scr[(m2 * PPP + (n >> 3)) * 16 + which * 8 + (n & 7)];
-                    bws.part[((size_t)tile_id * 2 + which) * N + n0 + n] = a;
-                }
-            }
+            for (int it = 0; it < PPP; ++it)
+                if (!(PHX_ABLATE & 8) || cx0 < 0)
+                    *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * (NT / PPP) * OROW);
         } else {
             // edge tiles and the small-map tile shapes: per-row masks and addresses
             const int tid_o = threadIdx.x;
@@ -909,379 +747,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
                 float v = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) v += red[(w * 2 + which) * BN + n];
-                if constexpr (FBN) {
-                    // returning form: the value comes back from the coherence point, i.e. the add has been performed when it arrives
-                    const float old = atomicAdd(&stats_partial[((size_t)n0 + n) * 2 + which], v);
-                    asm volatile("" ::"v"(old));
-                } else if (bws.stats_atomic) atomicAdd(&stats_partial[((size_t)(bws.stats_nrep > 1 ? tile_id % bws.stats_nrep : 0) * N + n0 + n) * 2 + which], v);
+                if (bws.stats_atomic) atomicAdd(&stats_partial[((size_t)n0 + n) * 2 + which], v);
                 else stats_partial[((size_t)tile_id * 2 + which) * N + n0 + n] = v;
             }
-        }
-        if constexpr (FBN) {
-            const int ntl = g.tiles_x * g.tiles_y * g.tiles_b;
-            __syncthreads();                             // every thread has its atomics' return values: this block's sums are in
-            if (threadIdx.x == 0) {
-                __hip_atomic_fetch_add(xf.counter + cob, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int spins = 0;                           // (bounded: a launch that cannot be co-resident must not hang the GPU)
-                while (__hip_atomic_load(xf.counter + cob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ntl && ++spins < (1 << 24))
-                    __builtin_amdgcn_s_sleep(2);
-                if (spins >= (1 << 24)) atomicAdd(&g_phx_fbn_timeouts, 1u);      // the blocks were not co-resident: results are invalid
-            }
-            __syncthreads();
-            float sc[NJ], sh[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int c = n0 + j * 32 + l31;
-                const float t1 = __hip_atomic_load(&stats_partial[(size_t)c * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float t2 = __hip_atomic_load(&stats_partial[(size_t)c * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float mu = t1 * xf.invP;
-                float var = t2 * xf.invP - mu * mu;
-                var = var > 0.f ? var : 0.f;
-                const float rs = rsqrtf(var + xf.eps);
-                sc[j] = xf.gamma[c] * rs;
-                sh[j] = xf.beta[c] - mu * sc[j];
-                if (tile_id == 0 && wave == 0 && khalf == 0) {        // one block per channel block publishes (backward pass, moving update)
-                    xf.mean_out[c] = mu; xf.rstd_out[c] = rs; xf.scale_out[c] = sc[j]; xf.shift_out[c] = sh[j];
-                    if (xf.momentum > 0.f && xf.moving_mean) {        // TF1 fused-batch-norm moving update (unbiased variance)
-                        const float m = 1.f / xf.invP;
-                        xf.moving_mean[c] -= (xf.moving_mean[c] - mu) * xf.momentum;
-                        xf.moving_var[c] -= (xf.moving_var[c] - var * (m / fmaxf(m - 1.f, 1.f))) * xf.momentum;
-                    }
-                }
-            }
-            // second pass over the accumulators: a = act(bf16(y) * scale + shift), transposed through LDS like y (masked path)
-            const int wave_o = threadIdx.x >> 6, l31_o = threadIdx.x & 31, khalf_o = (threadIdx.x >> 5) & 1, odd_o = threadIdx.x & 1;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int rp = 0; rp < 8; ++rp) {
-                    const int r0 = 2 * rp;
-                    const int m0 = wave_o * 64 + i * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * khalf_o;
-                    const int mrow = odd_o ? m0 + 1 : m0;
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        const unsigned w2 = f2bf_pk(acc[i][j][r0], acc[i][j][r0 + 1]);       // the y values as stored
-                        float lo = fmaf(__uint_as_float(w2 << 16), sc[j], sh[j]);
-                        float hi = fmaf(__uint_as_float(w2 & 0xffff0000u), sc[j], sh[j]);
-                        if (xf.act == PHX_ACT_RELU) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-                        else if (xf.act != PHX_ACT_ID) { lo = act_fwd(lo, xf.act); hi = act_fwd(hi, xf.act); }
-                        const unsigned w3 = f2bf_pk(lo, hi);
-                        const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)w3, 0xB1, 0xf, 0xf, true);
-                        *reinterpret_cast<unsigned*>(smem + mrow * OROW + (((j * 32 + (l31_o & ~1)) * 2) ^ (odd_o ? OSWZ : 0))) =
-                            odd_o ? ((nb >> 16) | (w3 & 0xffff0000u)) : ((w3 & 0xffffu) | (nb << 16));
-                    }
-                }
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < PPP; ++it) {
-                const int i = threadIdx.x + it * NT;
-                const int m = i / PPP, q = i % PPP;
-                const int lx = m & (tw - 1), ly = (m >> g.tws) & (th - 1), lb = m >> (g.tws + g.ths);
-                const int ox = cx0 + lx, oy = cy0 + ly, ob = cb0 + lb;
-                if (ox < W && oy < H && ob < B)
-                    *reinterpret_cast<uint4*>(xf.a_out + (((size_t)ob * H + oy) * W + ox) * N + n0 + q * 8) =
-                        *reinterpret_cast<const uint4*>(smem + m * OROW + ((q * 16) ^ ((m & 1) ? OSWZ : 0)));
-            }
-        }
-    }
-    PHX_BLOCKLOG_END();
-}
-
-// ---- the same 128-pixel wave tiles without loader waves: one 75 KiB stage per block, TWO blocks per CU -----------------
-// BWS (data-gradient launches, struct BwdStats): the store loop also reads the producer layer's y tile and emits the batch-norm
-// backward partial sums part[tile][2][N] -- the stand-alone phx_norm_bwd_reduce pass over dA and y (and its launch) disappears.
-template <bool BIASACT, int DBG, int BN, bool DUAL = false, bool BWS = false>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_fwd_dma128(const unsigned short* __restrict__ x,
-                                                             const unsigned short* __restrict__ wpk,
-                                                             unsigned short* __restrict__ y, const float* __restrict__ bias,
-                                                             int act, float* __restrict__ stats_partial,
-                                                             int B, int H, int W, int K, int N, int tiles_x, int tiles_y, const float* __restrict__ oscale, int stats_nrep, Dual du,
-                                                             BwdStats bws = BwdStats{}) {
-    constexpr int NJ = BN / 32;                       // BN = 64 (two 32-channel MFMA columns per wave) or 32 (one)
-    constexpr int AI = 39, BI = 9 * BN * 64 / 1024;   // 1 KiB DMA instructions per chunk: 612 patch rows x 64 B, 9 * BN slab rows
-    constexpr int NLW = 4;
-    constexpr int NI = AI + BI, NPL = (NI + NLW - 1) / NLW;   // DMA instructions per wave
-    constexpr int A_BYTES = AI * 1024, STAGE = NI * 1024;
-    constexpr int OROW = BN * 2;                      // dense epilogue rows, piece index XORed with 4 * (row & 1) for BN = 64 (see k_conv3x3_mfma)
-    constexpr int OSWZ = BN == 64 ? 64 : 0;
-    constexpr int PROW = 34 * 64;                     // bytes per patch row
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // linear block id -> (pixel tile, channel block): the N / 64 channel blocks of a tile get ids 8 apart (same XCD, dispatched
-    // back to back), so the patch they share comes from HBM once (as in k_conv3x3_mfma)
-    int tile_id, cob;
-    {
-        const int ncob = N / BN, ntl = tiles_x * tiles_y * B;
-        const int id = blockIdx.x, full = (ntl >> 3) * 8 * ncob;
-        if (id < full) {
-            const int grp = id / (8 * ncob), r = id - grp * 8 * ncob;
-            tile_id = grp * 8 + (r & 7);
-            cob = r >> 3;
-        } else {
-            const int rem = ntl & 7, r = id - full;
-            tile_id = (ntl & ~7) + r % rem;
-            cob = r / rem;
-        }
-    }
-    int t = tile_id;
-    const int tx0 = (t % tiles_x) << 5; t /= tiles_x;
-    const int ty0 = (t % tiles_y) << 4; t /= tiles_y;
-    const int b0 = t;
-    const int n0 = cob * BN;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int l31 = lane & 31, khalf = lane >> 5;
-    constexpr bool loader = false;
-    const int nch = K / 32;
-
-    f32x16 acc[4][NJ];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    PHX_BLOCKLOG_BEGIN();
-
-    // every wave stages its share of the chunk (LDS-DMA), then computes: ONE stage per block, two blocks per CU -- one block's
-    // DMA latency, prologue and epilogue run under the other block's MFMAs
-    const int lw = wave;
-    unsigned voff[NPL];
-    unsigned voff2[DUAL ? NPL : 1];                   // DUAL (struct Dual): the patch pieces in du.x2 (pixel stride K - K1)
-    const int K1 = (DUAL && du.x2 != nullptr) ? du.K1 : K;
-#pragma unroll
-    for (int n = 0; n < NPL; ++n) {
-        const int j = lw + NLW * n;
-        voff[n] = 0xffffffffu;
-        if constexpr (DUAL) voff2[n] = 0xffffffffu;
-        if (j < AI) {
-            const int e = j * 64 + lane, pp = e >> 2, slot = e & 3;
-            const int py = pp / 34, px = pp - py * 34;
-            const int piece = slot ^ ((px >> 2) & 3);
-            const int gx = tx0 + px - 1, gy = ty0 + py - 1;
-            if (pp < 612 && gx >= 0 && gx < W && gy >= 0 && gy < H && !(DBG & 1)) {
-                voff[n] = (unsigned)((((b0 * H + gy) * W + gx) * K1) * 2 + piece * 16);
-                if constexpr (DUAL) voff2[n] = (unsigned)((((b0 * H + gy) * W + gx) * (K - K1)) * 2 + piece * 16);
-            }
-        } else if (j < NI) {
-            const int e = (j - AI) * 64 + lane, rb = e >> 2, slot = e & 3;
-            const int tap = rb / BN, nn = rb % BN;
-            const int piece = slot ^ ((nn >> 2) & 3);
-            if (!(DBG & 2)) voff[n] = (unsigned)(((tap * N + n0 + nn) * 32 + piece * 8) * 2);
-        }
-    }
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K1 * 2u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? du.x2 : x), 0, DUAL ? (int)((unsigned)B * H * W * (K - K1) * 2u) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, (int)(9u * N * K * 2u), 0x00020000);
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    unsigned aK[3][2], bK[2];
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            aK[kw][ks] = (unsigned)((wave * 4 * 34 + l31 + kw) * 64 + (((ks * 2 + khalf) ^ (((l31 + kw) >> 2) & 3)) << 4));
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) bK[ks] = (unsigned)(A_BYTES + l31 * 64 + (((ks * 2 + khalf) ^ ((l31 >> 2) & 3)) << 4));
-    for (int c = 0; c < nch; ++c) {
-        if (c) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done reading the previous chunk
-#pragma unroll
-        for (int n = 0; n < NPL; ++n) {
-            const int j = lw + NLW * n;
-            if (j < AI) {
-                if constexpr (DUAL) {
-                    if (c * 32 >= K1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx2, (lds_ptr_t)(smem + j * 1024), 16, (int)voff2[n], c * 64 - K1 * 2, 0, 0);
-                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + j * 1024), 16, (int)voff[n], c * 64, 0, 0);
-                } else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + j * 1024), 16, (int)voff[n], c * 64, 0, 0);
-            }
-            else if (j < NI)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(smem + j * 1024), 16, (int)voff[n], c * 9 * N * 64, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        // 12 half-steps per chunk: step t = (group g = t / 2 = (k-step ks, tap column kw), channel half j = t % 2).  The six patch
-        // rows of a group are read once (fa, double-buffered by group parity), the three tap-row filter fragments per half-step
-        // (fb, by step parity); the next half-step's reads are pinned AHEAD of this one's 12 MFMAs (left alone, the compiler
-        // sinks them to their first use and every group pays the LDS latency).
-        bf16x8 fa[2][6], fb[2][3];
-        auto read_a = [&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            constexpr int ks = g / 3, kw = g % 3;
-#pragma unroll
-            for (int rr = 0; rr < 6; ++rr)
-                fa[g & 1][rr] = *reinterpret_cast<const bf16x8*>(smem + aK[kw][ks] + rr * PROW);
-        };
-        auto read_b = [&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            constexpr int g = t / NJ, j = t % NJ, ks = g / 3, kw = g % 3;
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-                fb[t & 1][kh] = *reinterpret_cast<const bf16x8*>(smem + bK[ks] + ((kh * 3 + kw) * BN + j * 32) * 64);
-        };
-        read_a(std::integral_constant<int, 0>());
-        read_b(std::integral_constant<int, 0>());
-        auto steps = [&](auto self, auto tc) {
-            constexpr int t = decltype(tc)::value;
-            if constexpr (t < 6 * NJ) {
-                constexpr int g = t / NJ, j = t % NJ;
-                if constexpr (t + 1 < 6 * NJ) {
-                    if constexpr (j == NJ - 1) read_a(std::integral_constant<int, g + 1>());
-                    read_b(std::integral_constant<int, t + 1>());
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!(DBG & 4))
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g & 1][i + kh], fb[t & 1][kh], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                self(self, std::integral_constant<int, t + 1>());
-            }
-        };
-        steps(steps, std::integral_constant<int, 0>());
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
-    // epilogue (interior tiles only): pack pairs of rows, statistics, transpose through LDS, 16-byte stores
-    const int odd = lane & 1;
-    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-    f32x2_t s1v[NJ], s2v[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) { s1v[j] = f32x2_t{0.f, 0.f}; s2v[j] = f32x2_t{0.f, 0.f}; }
-    const bool do_stats = stats_partial != nullptr;
-    const unsigned psel = odd ? 0x03020706u : 0x05040100u;
-    if (!loader) {
-        if constexpr (BIASACT) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const float bv = bias ? bias[n0 + j * 32 + l31] : 0.f;
-                const float sv = oscale ? oscale[n0 + j * 32 + l31] : 1.f;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaf(acc[i][j][r], sv, bv);
-            }
-            // the activation code is uniform per launch: ONE scalar branch here, not two per element (with act_fwd() inside the loops
-            // every element carried the compare-and-branch pairs of the ReLU / softplus tests: a third of this epilogue's time)
-            if (act == PHX_ACT_RELU) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
-            } else if (act != PHX_ACT_ID) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] = act_fwd(acc[i][j][r], act);
-            }
-        }
-        unsigned char* lwp = smem + (wave * 128 + 4 * khalf + odd) * OROW + (l31 & ~1) * 2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int rp = 0; rp < 8; ++rp)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int r0 = 2 * rp;
-                    const unsigned w2 = f2bf_pk(acc[i][j][r0], acc[i][j][r0 + 1]);
-                    if (do_stats) {
-                        const f32x2_t rv = {__uint_as_float(w2 << 16), __uint_as_float(w2 & 0xffff0000u)};
-                        s1v[j] += rv;
-                        s2v[j] += rv * rv;
-                    }
-                    const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)w2, 0xB1, 0xf, 0xf, true);
-                    *reinterpret_cast<unsigned*>(lwp + (i * 32 + (r0 & 3) + 8 * (r0 >> 2)) * OROW + ((j * 64) ^ (odd ? OSWZ : 0))) = __builtin_amdgcn_perm(nb, w2, psel);
-                }
-    }
-    __syncthreads();
-    if (!loader) {
-        constexpr int PPP = BN / 8;                   // 16-byte pieces per pixel
-        constexpr int PSTEP = 256 / PPP;              // pixels per step of the 256 storing threads (32: one tile row; 64: two)
-        const int mt = threadIdx.x / PPP, q = threadIdx.x % PPP;
-        const unsigned char* lr = smem + mt * OROW + ((q * 16) ^ ((mt & 1) ? OSWZ : 0));
-        unsigned short* ybase = y;                    // (dual destination, struct Dual)
-        int yld = N, ych = n0 + q * 8;
-        if constexpr (DUAL)
-            if (du.y2) {
-                if (ych < du.N1) yld = du.N1;
-                else { ybase = du.y2; yld = N - du.N1; ych -= du.N1; }
-            }
-        unsigned short* yp = ybase + (((size_t)b0 * H + ty0 + (mt >> 5)) * W + tx0 + (mt & 31)) * yld + ych;
-        const size_t ystep = (size_t)(PSTEP / 32) * W * yld;
-        if constexpr (!BWS) {
-#pragma unroll
-            for (int it = 0; it < 512 / PSTEP; ++it)
-                *reinterpret_cast<uint4*>(yp + it * ystep) = *reinterpret_cast<const uint4*>(lr + it * PSTEP * OROW);
-        } else {
-            // this thread's pieces all belong to channels n0 + 8 q .. + 7: g = dA * act'(y * scale + shift), xhat = (y - mean) * rstd
-            constexpr int NIT = 512 / PSTEP;
-            const unsigned short* yq = bws.y + (yp - y);
-            uint4 yv[NIT];
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) yv[it] = *reinterpret_cast<const uint4*>(yq + it * ystep);
-            float sc[8], sh[8], mu[8], rs[8], t1[8], t2[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = n0 + q * 8 + e;
-                sc[e] = bws.scale[c]; sh[e] = bws.shift[c]; mu[e] = bws.mean[c]; rs[e] = bws.rstd[c];
-                t1[e] = t2[e] = 0.f;
-            }
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const uint4 v = *reinterpret_cast<const uint4*>(lr + it * PSTEP * OROW);
-                *reinterpret_cast<uint4*>(yp + it * ystep) = v;
-                const unsigned vw[4] = {v.x, v.y, v.z, v.w}, yw[4] = {yv[it].x, yv[it].y, yv[it].z, yv[it].w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float da = __uint_as_float((e & 1) ? (vw[e >> 1] & 0xffff0000u) : (vw[e >> 1] << 16));
-                    const float yy = __uint_as_float((e & 1) ? (yw[e >> 1] & 0xffff0000u) : (yw[e >> 1] << 16));
-                    const float gq = da * act_grad_pre(yy * sc[e] + sh[e], bws.act);
-                    t1[e] += gq;
-                    t2[e] += gq * (yy - mu[e]) * rs[e];
-                }
-            }
-            __syncthreads();                             // the output tile has been read: LDS becomes reduction scratch
-            float* scr = reinterpret_cast<float*>(smem);  // [256][16]
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                scr[threadIdx.x * 16 + e] = t1[e];
-                scr[threadIdx.x * 16 + 8 + e] = t2[e];
-            }
-            __syncthreads();
-            if (threadIdx.x < 2 * BN) {
-                const int which = threadIdx.x / BN, n = threadIdx.x % BN;
-                float a = 0.f;
-                for (int m2 = 0; m2 < 256 / PPP; ++m2) a += scr[(m2 * PPP + (n >> 3)) * 16 + which * 8 + (n & 7)];
-                bws.part[((size_t)tile_id * 2 + which) * N + n0 + n] = a;
-            }
-        }
-    }
-    if (stats_partial) {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);      // [4 waves][2][BN]
-        if (!loader) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const float t1 = s1v[j][0] + s1v[j][1], t2 = s2v[j][0] + s2v[j][1];
-                const float a = t1 + __shfl_xor(t1, 32, 64);
-                const float bq = t2 + __shfl_xor(t2, 32, 64);
-                if (khalf == 0) {
-                    red[(wave * 2 + 0) * BN + j * 32 + l31] = a;
-                    red[(wave * 2 + 1) * BN + j * 32 + l31] = bq;
-                }
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 2 * BN) {
-            const int which = threadIdx.x / BN, n = threadIdx.x % BN;
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) v += red[(w * 2 + which) * BN + n];
-            // stats_nrep > 0: stats_partial is the replicated accumulator sums[rep][N][2] (tile t -> replica t % stats_nrep, atomics)
-            if (stats_nrep > 0) atomicAdd(&stats_partial[((size_t)(tile_id % stats_nrep) * N + n0 + n) * 2 + which], v);
-            else stats_partial[((size_t)tile_id * 2 + which) * N + n0 + n] = v;
         }
     }
     PHX_BLOCKLOG_END();
@@ -1403,13 +871,24 @@ int phx_unpad_filter_grad_center(const float* dw_pad, float* dw_1x1, int Cin, in
 }
 
 int phx_debug_set_trace(void* dev_buf) {
-    if (int rc = phx_db_set_trace(dev_buf)) return rc;
     if (int rc = phx_c32_set_trace(dev_buf)) return rc;
     if (int rc = phx_pp_set_trace(dev_buf)) return rc;
     if (int rc = phx_wgrad_set_debug(dev_buf, nullptr, 0)) return rc;
     unsigned long long* p = (unsigned long long*)dev_buf;
     PHX_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phx_trace), &p, sizeof(p)));
     return PHX_OK;
+}
+
+int phx_debug_conv_policy(int large_maps, int big_tiles) {
+    PHX_REQUIRE(large_maps >= 0 && large_maps <= 2 && big_tiles >= 0 && big_tiles <= 2, PHX_E_INVAL, "debug_conv_policy: 0 never, 1 policy, 2 force");
+    g_ws_policy = large_maps;
+    g_tile_policy = big_tiles;
+    return PHX_OK;
+}
+
+int phx_debug_pair_kernel_grid(int blocks) {
+    PHX_REQUIRE(blocks >= 0, PHX_E_INVAL, "debug_pair_kernel_grid: blocks >= 0 (0: one per CU)");
+    return phx_pp_set_grid(blocks);
 }
 
 int phx_debug_set_blocklog(void* dev_buf) {
@@ -1420,22 +899,18 @@ int phx_debug_set_blocklog(void* dev_buf) {
 }
 
 int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W, int K, int N) {
-    if (fwd_ws64(B, H, W, K, N) && N % 64 == 0 && phx_db_enabled()) return phx_db_partial_rows(B, H, W);   // one row of partial sums per (tile, wave)
     MTile g = make_mtile_fwd(B, H, W, K, N);
     return g.tiles_x * g.tiles_y * g.tiles_b;
 }
 
 // split-K factor for the forward / data-gradient kernel: > 1 only for the 256-pixel-tile kernels on maps whose tiles x
-// channel blocks leave most CUs idle (H <= 16 at batch 64); aims at ~256 blocks
+// channel blocks leave most CUs idle (H <= 16 at batch 64); aims at ~64 blocks
 static int fwd_ksplit(int B, int H, int W, int K, int N) {
-    const char* e = getenv("PHX_FWD_SPLITK");
-    if (e && atoi(e) == 0) return 1;
     if (fwd_big_tiles(B, H, W, K, N)) return 1;
     MTile g = make_mtile(B, H, W);
     const int blocks = g.tiles_x * g.tiles_y * g.tiles_b * (N / (N % 64 == 0 ? 64 : 32));
     const int nck = K / KC;
-    static int tgt = 0;
-    if (!tgt) { const char* t = getenv("PHX_FWD_SPLITK_BLOCKS"); tgt = t ? atoi(t) : 64; }     // tuning hook (re-measured under the two-lane schedule: 32-96 equal, 128+ 0.6 % slower)
+    const int tgt = 64;                              // (re-measured under the two-lane schedule: 32-96 equal, 128+ 0.6 % slower)
     if (blocks * 2 > tgt || nck < 2) return 1;
     int ks = (tgt + blocks - 1) / blocks;
     if (ks > nck) ks = nck;
@@ -1450,27 +925,18 @@ size_t phx_conv3x3_mfma_ws_bytes(int B, int H, int W, int K, int N) {
     return ks > 1 ? (size_t)ks * B * H * W * N * sizeof(float) : 0;
 }
 
+static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
+                             void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, EpiOpts bws, Dual du,
+                             void* stream);
+
 int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
                           int B, int H, int W, int K, int N, void* stream) {
-    return phx_conv3x3_mfma_bf16_ws(x, wpk, y, bias, act, stats_partial, nullptr, 0, B, H, W, K, N, stream);
+    return conv3x3_mfma_impl(x, wpk, y, bias, act, stats_partial, nullptr, 0, B, H, W, K, N, EpiOpts{}, Dual{}, stream);
 }
-
-// the fused-statistics epilogue lives in the full-tile path of the 16-wide-tile kernels: every tile must be interior
-static bool fwd_bws_ok(int B, int H, int W, int K, int N) {
-    if (fwd_ws64(B, H, W, K, N)) return !(K == 32 && N == 32 && phx_c32_enabled()) && !phx_db_enabled();      // LDS-DMA kernel: BWS instantiations
-    if (fwd_ksplit(B, H, W, K, N) > 1) return false;
-    if (fwd_big_tiles(B, H, W, K, N)) return true;                       // H % 32 == 0, W % 16 == 0
-    return H % 16 == 0 && W % 16 == 0;
-}
-int phx_conv3x3_mfma_bwdstats_supported(int B, int H, int W, int K, int N) { return fwd_bws_ok(B, H, W, K, N) ? 1 : 0; }
-
-static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
-                             void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, BwdStats bws,
-                             void* stream);
 
 int phx_conv3x3_mfma_bf16_ws(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
                              void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream) {
-    return conv3x3_mfma_impl(x, wpk, y, bias, act, stats_partial, workspace, workspace_bytes, B, H, W, K, N, BwdStats{}, stream);
+    return conv3x3_mfma_impl(x, wpk, y, bias, act, stats_partial, workspace, workspace_bytes, B, H, W, K, N, EpiOpts{}, Dual{}, stream);
 }
 
 // statistics added atomically into sums[N][2] (the layout phx_norm_apply_fused reads): for launches with few pixel tiles (the
@@ -1486,44 +952,35 @@ int phx_conv3x3_mfma_bf16_stats_atomic(const void* x, const void* wpk, void* y, 
                                        int H, int W, int K, int N, void* stream) {
     PHX_REQUIRE(fwd_stats_atomic_ok(B, H, W, K, N), PHX_E_SHAPE, "conv3x3_mfma_stats_atomic: shape not supported (see ..._supported)");
     PHX_REQUIRE(sums != nullptr, PHX_E_INVAL, "conv3x3_mfma_stats_atomic: sums is required");
-    BwdStats b{};
+    EpiOpts b{};
     b.stats_atomic = 1;
-    return conv3x3_mfma_impl(x, wpk, y, bias, act, sums, nullptr, 0, B, H, W, K, N, b, stream);
+    return conv3x3_mfma_impl(x, wpk, y, bias, act, sums, nullptr, 0, B, H, W, K, N, b, Dual{}, stream);
 }
 
-// The same with REPLICATED accumulators for launches with many pixel tiles (the 32 x 32 .. 128 x 128 levels): sums[nrep][N][2], tile t
-// adds into replica t % nrep (a same-address fp32 atomic retires in ~45 ns: 2 048 tiles on one address would take 90 us, on 32
-// replicas under 3 us spread over the launch), phx_norm_apply_fused_rep sums the replicas in its per-block prologue -- the
-// per-tile partial rows and the reduction launch between the convolution and the apply pass go away.  Any shape / kernel policy.
-int phx_conv3x3_mfma_bf16_stats_rep(const void* x, const void* wpk, void* y, const float* bias, int act, float* sums, int nrep, int B,
-                                    int H, int W, int K, int N, void* stream) {
-    PHX_REQUIRE(sums != nullptr && nrep >= 1 && !phx_deterministic(), PHX_E_INVAL, "conv3x3_mfma_stats_rep: sums / nrep (not in deterministic mode)");
-    BwdStats b{};
-    b.stats_atomic = 1;
-    b.stats_nrep = nrep;
-    return conv3x3_mfma_impl(x, wpk, y, bias, act, sums, nullptr, 0, B, H, W, K, N, b, stream);
-}
-int phx_conv3x3_mfma_stats_rep_supported(int B, int H, int W, int K, int N) {
-    return (!phx_deterministic() && K % KC == 0 && N % 32 == 0) ? 1 : 0;
+int phx_conv3x3_mfma_bf16_affine(const void* x, const void* wpk, void* y, const float* scale, const float* shift, int act,
+                                 void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream) {
+    PHX_REQUIRE(scale != nullptr && shift != nullptr, PHX_E_INVAL, "conv3x3_mfma_affine: scale and shift are required");
+    EpiOpts b{};
+    b.oscale = scale;
+    return conv3x3_mfma_impl(x, wpk, y, shift, act, nullptr, workspace, workspace_bytes, B, H, W, K, N, b, Dual{}, stream);
 }
 
-// One-shot modifiers of the NEXT forward / data-gradient launch made from the calling thread (any phx_conv3x3_mfma_bf16* entry point
-// except ..._xf / ..._bwdstats): see struct Dual.  Consumed (and cleared) by that launch, whether it succeeds or not.
-static thread_local Dual g_next_dual = {nullptr, nullptr, 0, 0};
-int phx_conv3x3_next_dual_input(const void* x2, int K1) {
-    PHX_REQUIRE(x2 != nullptr && K1 > 0 && K1 % 32 == 0 && ((uintptr_t)x2 & 15) == 0, PHX_E_INVAL, "conv3x3_next_dual_input: x2 (16-byte aligned), K1 % 32 == 0");
-    g_next_dual.x2 = (const unsigned short*)x2; g_next_dual.K1 = K1;
-    return PHX_OK;
-}
-int phx_conv3x3_next_dual_output(void* y2, int N1) {
-    PHX_REQUIRE(y2 != nullptr && N1 > 0 && N1 % 8 == 0 && ((uintptr_t)y2 & 15) == 0, PHX_E_INVAL, "conv3x3_next_dual_output: y2 (16-byte aligned), N1 % 8 == 0");
-    g_next_dual.y2 = (unsigned short*)y2; g_next_dual.N1 = N1;
-    return PHX_OK;
-}
-static Dual take_next_dual() {
-    const Dual d = g_next_dual;
-    g_next_dual = Dual{nullptr, nullptr, 0, 0};
-    return d;
+// Concat-free forward / data gradient (struct Dual): every option of the entry points above in one call.
+//   x2 != NULL: reduction channels [0, K1) are read from x (pixel stride K1), [K1, K) from x2 (stride K - K1), K1 % 32 == 0
+//   y2 != NULL: output channels [0, N1) go to y (stride N1), [N1, N) to y2 (stride N - N1), N1 % 8 == 0; no statistics epilogue
+//   stats_mode : 0 none, 1 per-tile partial rows stats[tile][2][N], 2 atomically into stats[N][2] (see ..._stats_atomic)
+int phx_conv3x3_mfma_bf16_dual(const void* x, const void* x2, int K1, const void* wpk, void* y, void* y2, int N1, const float* bias,
+                               const float* oscale, int act, float* stats, int stats_mode, void* workspace, size_t workspace_bytes,
+                               int B, int H, int W, int K, int N, void* stream) {
+    PHX_REQUIRE(x2 == nullptr || (K1 > 0 && K1 % 32 == 0 && ((uintptr_t)x2 & 15) == 0), PHX_E_INVAL, "conv3x3_mfma_dual: x2 (16-byte aligned), K1 % 32 == 0");
+    PHX_REQUIRE(y2 == nullptr || (N1 > 0 && N1 % 8 == 0 && ((uintptr_t)y2 & 15) == 0), PHX_E_INVAL, "conv3x3_mfma_dual: y2 (16-byte aligned), N1 % 8 == 0");
+    PHX_REQUIRE(stats_mode >= 0 && stats_mode <= 2 && (stats_mode == 0) == (stats == nullptr), PHX_E_INVAL, "conv3x3_mfma_dual: stats / stats_mode");
+    PHX_REQUIRE(stats_mode != 2 || fwd_stats_atomic_ok(B, H, W, K, N), PHX_E_SHAPE, "conv3x3_mfma_dual: atomic statistics not supported for this shape");
+    EpiOpts b{};
+    b.stats_atomic = stats_mode == 2;
+    b.oscale = oscale;
+    Dual du{(const unsigned short*)x2, (unsigned short*)y2, x2 ? K1 : 0, y2 ? N1 : 0};
+    return conv3x3_mfma_impl(x, wpk, y, bias, act, stats, workspace, workspace_bytes, B, H, W, K, N, b, du, stream);
 }
 
 // ---- conv + bias + group / instance norm + activation in one launch (FGN instantiations of k_conv3x3_mfma) ----------------------
@@ -1541,8 +998,6 @@ int phx_conv3x3_fgn_supported(int B, int H, int W, int K, int N, int G) { return
 int phx_conv3x3_mfma_bf16_fgn(const void* x, const void* wpk, void* y, void* a_out, const float* bias, const float* gamma,
                               const float* beta, float eps, int G, int act, float* mean_out, float* rstd_out, float* scale_out,
                               float* shift_out, int B, int H, int W, int K, int N, void* stream) {
-    const Dual du = take_next_dual();
-    PHX_REQUIRE(du.x2 == nullptr && du.y2 == nullptr, PHX_E_INVAL, "conv3x3_mfma_fgn: no dual input / output");
     const int bn = fgn_plan(B, H, W, K, N, G);
     PHX_REQUIRE(bn != 0, PHX_E_SHAPE, "conv3x3_mfma_fgn: shape not supported (see phx_conv3x3_fgn_supported)");
     PHX_REQUIRE(x && wpk && y && a_out && gamma && beta && mean_out && rstd_out && scale_out && shift_out, PHX_E_INVAL,
@@ -1555,19 +1010,19 @@ int phx_conv3x3_mfma_bf16_fgn(const void* x, const void* wpk, void* y, void* a_o
     PHX_REQUIRE(na <= 16, PHX_E_SHAPE, "conv3x3_mfma_fgn: unexpected tile geometry");
     const bool fast16 = g.tws == 4 && g.ths == 4 && g.tb == 1;
     XForm xf{};
-    xf.gamma = gamma; xf.beta = beta; xf.eps = eps; xf.act = act; xf.G = G; xf.NS = B;
+    xf.gamma = gamma; xf.beta = beta; xf.eps = eps; xf.act = act; xf.G = G;
     xf.a_out = (unsigned short*)a_out; xf.mean_out = mean_out; xf.rstd_out = rstd_out; xf.scale_out = scale_out; xf.shift_out = shift_out;
     const int cg = N / G;
 #define FGN_LAUNCH(BNv, NAv, Fv)                                                                                        \
     do {                                                                                                                \
-        auto kfn = k_conv3x3_mfma<BNv, NAv, Fv, false, 4, false, false, false, false, true>;                            \
+        auto kfn = k_conv3x3_mfma<BNv, NAv, Fv, false, 4, false, false, true>;                            \
         PHX_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));   \
         size_t sh = (Fv ? (size_t)(4 * 4 + 2) * PITCH16 : (size_t)g.tb * g.ipitch) + 9 * BNv * ROWB;                    \
         const size_t she = (size_t)256 * BNv * 2 + (size_t)g.tb * (BNv / cg) * 8;                                       \
         if (she > sh) sh = she;                                                                                         \
         hipLaunchKernelGGL(kfn, dim3(ntiles * (N / BNv)), dim3(256), sh, (hipStream_t)stream, (const unsigned short*)x, \
                            (const unsigned short*)wpk, (unsigned short*)y, bias, 0, nullptr, B, H, W, K, N, g, nullptr,  \
-                           BwdStats{}, xf, Dual{});                                                                     \
+                           EpiOpts{}, xf, Dual{});                                                                     \
     } while (0)
     if (bn == 64) {
         if (fast16) FGN_LAUNCH(64, 8, true); else if (na <= 8) FGN_LAUNCH(64, 8, false); else FGN_LAUNCH(64, 16, false);
@@ -1579,99 +1034,12 @@ int phx_conv3x3_mfma_bf16_fgn(const void* x, const void* wpk, void* y, void* a_o
     return PHX_OK;
 }
 
-// ---- conv + batch norm (training mode) + activation in one launch on small maps (FBN instantiations of k_conv3x3_mfma) --------
-// Every block of the launch has to be resident at once (they meet at an arrival counter): at most PHX_FBN_MAXBLOCKS (192) blocks, so
-// that the launches of two lanes fit the 512 block slots of the chip side by side.  -> 32 / 64 (channels per block), 0: not supported.
-static int fbn_plan(int B, int H, int W, int K, int N) {
-    if (phx_deterministic() || K % KC != 0 || N % 32 != 0) return 0;
-    if ((double)B * H * W >= 16777216.0) return 0;
-    static int maxb = -1;
-    if (maxb < 0) { const char* e = getenv("PHX_FBN_MAXBLOCKS"); maxb = e ? atoi(e) : 192; }
-    MTile g = make_mtile(B, H, W);
-    const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
-    if (ntiles * (N / 32) <= maxb) return 32;
-    if (N % 64 == 0 && ntiles * (N / 64) <= maxb) return 64;
-    return 0;
-}
-int phx_conv3x3_fbn_supported(int B, int H, int W, int K, int N) { return fbn_plan(B, H, W, K, N); }
-int phx_conv3x3_fbn_timeouts(int* count) {
-    unsigned v = 0;
-    PHX_CHECK_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_phx_fbn_timeouts), sizeof(v)));
-    *count = (int)v;
-    return PHX_OK;
-}
-int phx_conv3x3_mfma_bf16_fbn(const void* x, const void* wpk, void* y, void* a_out, float* sums, void* counters, const float* gamma,
-                              const float* beta, float eps, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
-                              float* moving_mean, float* moving_var, float momentum, int act, int B, int H, int W, int K, int N,
-                              void* stream) {
-    const Dual du = take_next_dual();
-    PHX_REQUIRE(du.y2 == nullptr && (du.x2 == nullptr || du.K1 < K), PHX_E_SHAPE, "conv3x3_mfma_fbn: dual input needs 0 < K1 < K; no dual output");
-    const int bn = fbn_plan(B, H, W, K, N);
-    PHX_REQUIRE(bn != 0, PHX_E_SHAPE, "conv3x3_mfma_fbn: shape not supported (see phx_conv3x3_fbn_supported)");
-    PHX_REQUIRE(x && wpk && y && a_out && sums && counters && gamma && beta && mean_out && rstd_out && scale_out && shift_out, PHX_E_INVAL,
-                "conv3x3_mfma_fbn: null argument");
-    PHX_REQUIRE((((uintptr_t)x | (uintptr_t)wpk | (uintptr_t)y | (uintptr_t)a_out) & 15) == 0, PHX_E_ALIGN, "conv3x3_mfma_fbn: 16-byte alignment");
-    MTile g = make_mtile(B, H, W);
-    const int tw = 1 << g.tws, th = 1 << g.ths;
-    const int npatch = g.tb * (th + 2) * (tw + 2);
-    const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
-    const int na = (npatch * 4 + 255) / 256;
-    PHX_REQUIRE(na <= 16, PHX_E_SHAPE, "conv3x3_mfma_fbn: unexpected tile geometry");
-    const bool fast16 = g.tws == 4 && g.ths == 4 && g.tb == 1;
-    BwdStats b{};
-    b.stats_atomic = 1;
-    XForm xf{};
-    xf.gamma = gamma; xf.beta = beta; xf.eps = eps; xf.invP = 1.f / ((float)B * H * W); xf.act = act;
-    xf.a_out = (unsigned short*)a_out; xf.mean_out = mean_out; xf.rstd_out = rstd_out; xf.scale_out = scale_out; xf.shift_out = shift_out;
-    xf.moving_mean = moving_mean; xf.moving_var = moving_var; xf.momentum = momentum; xf.counter = (unsigned*)counters;
-#define FBN_LAUNCH(BNv, NAv, Fv)                                                                                        \
-    do {                                                                                                                \
-        auto kfn = du.x2 ? k_conv3x3_mfma<BNv, NAv, Fv, false, 4, false, false, true, true>                             \
-                         : k_conv3x3_mfma<BNv, NAv, Fv, false, 4, false, false, true, false>;                           \
-        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));   \
-        size_t sh = (Fv ? (size_t)(4 * 4 + 2) * PITCH16 : (size_t)g.tb * g.ipitch) + 9 * BNv * ROWB;                    \
-        const size_t she = (size_t)256 * (BNv * 2 + 16);                                                                \
-        if (she > sh) sh = she;                                                                                         \
-        hipLaunchKernelGGL(kfn, dim3(ntiles * (N / BNv)), dim3(256), sh, (hipStream_t)stream, (const unsigned short*)x, \
-                           (const unsigned short*)wpk, (unsigned short*)y, nullptr, 0, sums, B, H, W, K, N, g, nullptr, b, xf, du); \
-    } while (0)
-    if (bn == 64) {
-        if (fast16) FBN_LAUNCH(64, 8, true); else if (na <= 8) FBN_LAUNCH(64, 8, false); else FBN_LAUNCH(64, 16, false);
-    } else {
-        if (fast16) FBN_LAUNCH(32, 8, true); else if (na <= 8) FBN_LAUNCH(32, 8, false); else FBN_LAUNCH(32, 16, false);
-    }
-#undef FBN_LAUNCH
-    PHX_CHECK_LAUNCH();
-    return PHX_OK;
-}
-
-int phx_conv3x3_mfma_bf16_affine(const void* x, const void* wpk, void* y, const float* scale, const float* shift, int act,
-                                 void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream) {
-    PHX_REQUIRE(scale != nullptr && shift != nullptr, PHX_E_INVAL, "conv3x3_mfma_affine: scale and shift are required");
-    BwdStats b{};
-    b.oscale = scale;
-    return conv3x3_mfma_impl(x, wpk, y, shift, act, nullptr, workspace, workspace_bytes, B, H, W, K, N, b, stream);
-}
-
-int phx_conv3x3_mfma_bf16_bwdstats(const void* dy, const void* wpk_dgrad, void* dA, const void* y_prod, const float* scale,
-                                   const float* shift, const float* mean, const float* rstd, int act_prod,
-                                   float* stats2_partial, int B, int H, int W, int K, int N, void* stream) {
-    PHX_REQUIRE(fwd_bws_ok(B, H, W, K, N), PHX_E_SHAPE, "conv3x3_mfma_bwdstats: shape not supported (see ..._supported)");
-    PHX_REQUIRE(y_prod && scale && shift && mean && rstd && stats2_partial, PHX_E_INVAL, "conv3x3_mfma_bwdstats: null argument");
-    BwdStats b{};
-    b.y = (const unsigned short*)y_prod; b.scale = scale; b.shift = shift; b.mean = mean; b.rstd = rstd;
-    b.part = stats2_partial; b.act = act_prod; b.stats_atomic = 0;
-    return conv3x3_mfma_impl(dy, wpk_dgrad, dA, nullptr, PHX_ACT_ID, nullptr, nullptr, 0, B, H, W, K, N, b, stream);
-}
-
 static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
-                             void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, BwdStats bws,
+                             void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, EpiOpts bws, Dual du,
                              void* stream) {
-    const Dual du = take_next_dual();
     PHX_REQUIRE(K % KC == 0 && N % 32 == 0, PHX_E_SHAPE, "conv3x3_mfma: K % 32 == 0 and N % 32 == 0 required");
     PHX_REQUIRE(du.x2 == nullptr || du.K1 < K, PHX_E_SHAPE, "conv3x3_mfma: dual input needs 0 < K1 < K");
-    PHX_REQUIRE(bws.part == nullptr || (du.x2 == nullptr && du.y2 == nullptr), PHX_E_INVAL, "conv3x3_mfma: fused bn-backward sums take no dual input / output");
-    PHX_REQUIRE(du.y2 == nullptr || (du.N1 < N && (N - du.N1) % 8 == 0 && y != nullptr && stats_partial == nullptr && bws.part == nullptr),
+    PHX_REQUIRE(du.y2 == nullptr || (du.N1 < N && (N - du.N1) % 8 == 0 && y != nullptr && stats_partial == nullptr),
                 PHX_E_SHAPE, "conv3x3_mfma: dual output needs 0 < N1 < N, (N - N1) % 8 == 0, an output tensor and no statistics epilogue");
     PHX_REQUIRE((((uintptr_t)x | (uintptr_t)wpk | (uintptr_t)y) & 15) == 0, PHX_E_ALIGN, "conv3x3_mfma: 16-byte alignment");
     int ksplit = 1;
@@ -1682,69 +1050,17 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
     }
     PHX_REQUIRE(y != nullptr || (ksplit > 1 && !bias && act == PHX_ACT_ID), PHX_E_INVAL,
                 "conv3x3_mfma: y == NULL only for a split-K launch without bias / activation (slices left in the workspace)");
+    const bool dual = du.x2 != nullptr || du.y2 != nullptr;
     if (fwd_ws64(B, H, W, K, N)) {
-        const bool ba = bias != nullptr || act != PHX_ACT_ID || bws.oscale != nullptr;
-        PHX_REQUIRE((double)B * H * W * (K > N ? K : N) < 2147483648.0, PHX_E_SHAPE, "conv3x3_mfma: tensor exceeds 2^31 elements");
-        const int ntl = B * (H / 16) * (W / 32);
-        const char* dbe = getenv("PHX_DBG_ABLATE");   // dev: bit 1 no patch loads, 2 no slab loads, 4 no MFMAs
-        const int dbg = dbe ? atoi(dbe) : 0;
-        {
-            const char* ppe = getenv("PHX_FWD_PP");   // dev: 0 = the one-stage kernel (A/B while both exist)
-            const int pp = ppe ? atoi(ppe) : 1;
-            const bool c32 = K == 32 && N == 32 && !du.x2 && !du.y2 && phx_c32_enabled();
-            if (pp && (!c32 || pp == 2) && bws.part == nullptr && (act == PHX_ACT_ID || act == PHX_ACT_RELU) && phx_pp_shape_ok(B, H, W, K, N))
-                return phx_pp_launch(x, wpk, y, bias, act, stats_partial, B, H, W, K, N, bws.oscale,
-                                     bws.stats_atomic ? (bws.stats_nrep > 1 ? bws.stats_nrep : 1) : 0, du, dbg, stream);
-        }
-        if (K == 32 && N == 32 && dbg == 0 && !du.x2 && !du.y2 && bws.part == nullptr && phx_c32_enabled())
-            return phx_c32_launch(x, wpk, y, bias, act, stats_partial, B, H, W, bws.oscale,
-                                  bws.stats_atomic ? (bws.stats_nrep > 1 ? bws.stats_nrep : 1) : 0, stream);
-        if (phx_db_enabled() && N % 64 == 0 && !bws.stats_atomic && !du.x2 && !du.y2) return phx_db_launch(x, wpk, y, bias, act, stats_partial, B, H, W, K, N, bws.oscale, dbg, stream);
-#define D128_LAUNCH1(Av, Dv, BNv)                                                                                               \
-    do {                                                                                                                        \
-        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_fwd_dma128<Av, Dv, BNv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        hipLaunchKernelGGL((k_conv3x3_fwd_dma128<Av, Dv, BNv>), dim3(ntl * (N / BNv)), dim3(256), 75 * 1024 + 16, (hipStream_t)stream, \
-                           (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, \
-                           H, W, K, N, W / 32, H / 16, bws.oscale, bws.stats_atomic ? (bws.stats_nrep > 1 ? bws.stats_nrep : 1) : 0, Dual{}, BwdStats{});                                                       \
-    } while (0)
-#define D128_LAUNCH(Av, Dv)                                                                                                     \
-    do { if (N % 64 == 0) D128_LAUNCH1(Av, Dv, 64); else D128_LAUNCH1(Av, 0, 32); } while (0)
-#define D128_DUAL(Av, BNv)                                                                                                      \
-    do {                                                                                                                        \
-        auto kfd = k_conv3x3_fwd_dma128<Av, 0, BNv, true>;                                                                      \
-        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)kfd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
-        hipLaunchKernelGGL(kfd, dim3(ntl * (N / BNv)), dim3(256), 75 * 1024 + 16, (hipStream_t)stream, (const unsigned short*)x, \
-                           (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, W / 32, H / 16, \
-                           bws.oscale, bws.stats_atomic ? (bws.stats_nrep > 1 ? bws.stats_nrep : 1) : 0, du, BwdStats{});      \
-    } while (0)
-        if (bws.part != nullptr) {
-            PHX_REQUIRE(!ba && !du.x2 && !du.y2 && !stats_partial, PHX_E_INVAL, "conv3x3_mfma: fused bn-backward sums take a plain data-gradient launch");
-#define D128_BWS(BNv)                                                                                                           \
-    do {                                                                                                                        \
-        auto kfb = k_conv3x3_fwd_dma128<false, 0, BNv, false, true>;                                                            \
-        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)kfb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));           \
-        hipLaunchKernelGGL(kfb, dim3(ntl * (N / BNv)), dim3(256), 75 * 1024 + 16, (hipStream_t)stream, (const unsigned short*)x, \
-                           (const unsigned short*)wpk, (unsigned short*)y, nullptr, 0, nullptr, B, H, W, K, N, W / 32, H / 16,  \
-                           nullptr, 0, Dual{}, bws);                                                                            \
-    } while (0)
-            if (N % 64 == 0) D128_BWS(64); else D128_BWS(32);
-#undef D128_BWS
-        } else if (du.x2 != nullptr || du.y2 != nullptr) {
-            if (N % 64 == 0) { if (ba) D128_DUAL(true, 64); else D128_DUAL(false, 64); }
-            else { if (ba) D128_DUAL(true, 32); else D128_DUAL(false, 32); }
-        } else if (ba) D128_LAUNCH(true, 0);
-        else switch (dbg) {
-            case 1: D128_LAUNCH(false, 1); break; case 2: D128_LAUNCH(false, 2); break; case 3: D128_LAUNCH(false, 3); break;
-            case 4: D128_LAUNCH(false, 4); break; default: D128_LAUNCH(false, 0);
-        }
-#undef D128_LAUNCH1
-#undef D128_LAUNCH
-#undef D128_DUAL
-        PHX_CHECK_LAUNCH();
-        return PHX_OK;
+        // large maps (16 x 32-pixel tiles; phx_conv3x3_mfma_bf16_tiles counts those): the 32 -> 32-channel layers take the
+        // filter-in-registers kernel (conv_c32.hip), everything else the anti-phase pair kernel (conv_pp.hip)
+        PHX_REQUIRE(act == PHX_ACT_ID || act == PHX_ACT_RELU, PHX_E_INVAL, "conv3x3_mfma: large maps take an identity / ReLU epilogue");
+        PHX_REQUIRE(!bws.stats_atomic, PHX_E_SHAPE, "conv3x3_mfma: atomic statistics are for launches with few pixel tiles");
+        if (K == 32 && N == 32 && !dual && phx_c32_enabled())
+            return phx_c32_launch(x, wpk, y, bias, act, stats_partial, B, H, W, bws.oscale, 0, stream);
+        return phx_pp_launch(x, wpk, y, bias, act, stats_partial, B, H, W, K, N, bws.oscale, 0, du, 0, stream);
     }
-    const bool dual = du.x2 != nullptr || du.y2 != nullptr;       // (DUAL instantiations exist for the 256-pixel tiles)
-    MTile g = dual ? make_mtile(B, H, W) : make_mtile_fwd(B, H, W, K, N, false);
+    MTile g = dual ? make_mtile(B, H, W) : make_mtile_fwd(B, H, W, K, N, false);       // (DUAL instantiations exist for the 256-pixel tiles)
     const bool big = !dual && fwd_big_tiles(B, H, W, K, N);
     const int tw = 1 << g.tws, th = 1 << g.ths;
     const int npatch = g.tb * (th + 2) * (tw + 2);
@@ -1778,7 +1094,7 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
             hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, false, NWv, Sv>), dim3(ntiles * (N / BNv), 1, ksplit),  \
                                dim3(NWv * 64), sh, (hipStream_t)stream, (const unsigned short*)x,                    \
                                (const unsigned short*)wpk, (unsigned short*)y, nullptr, 0, nullptr, B, H, W, K, N, g,\
-                               (float*)workspace, BwdStats{}, XForm{}, Dual{});                                        \
+                               (float*)workspace, EpiOpts{}, XForm{}, Dual{});                                        \
         else                                                                                                         \
             hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, Av, NWv, false>), dim3(ntiles * (N / BNv)), dim3(NWv * 64),\
                                sh, (hipStream_t)stream, (const unsigned short*)x, (const unsigned short*)wpk,        \
@@ -1794,20 +1110,18 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
     PHX_REQUIRE(fast16 || big || (double)B * H * W < 16777216.0, PHX_E_SHAPE, "conv3x3_mfma: small-map tiles need B*H*W < 2^24");
     // fewer 64-channel blocks than CUs: every block runs alone on its CU and the launch is one block's latency chain --
     // 32-channel blocks double the block count (two per CU) and halve each block's chain
-    static int n32thr = -1;
-    if (n32thr < 0) { const char* e = getenv("PHX_BN32_MAXBLOCKS"); n32thr = e ? atoi(e) : 256; }
-    const bool narrow32 = N % 64 == 0 && !big && ksplit == 1 && ntiles * (N / 64) <= n32thr;
+    const bool narrow32 = N % 64 == 0 && !big && ksplit == 1 && ntiles * (N / 64) <= 256;
 #define CM_DUAL1(BNv, NAv, Fv, Av, Sv)                                                                                \
     do {                                                                                                             \
         size_t sh = (Fv ? (size_t)(4 * 4 + 2) * PITCH16 : (size_t)g.tb * g.ipitch) + 9 * BNv * ROWB;                  \
         const size_t she = (size_t)256 * (BNv * 2 + 16);                                                             \
         if (she > sh) sh = she;                                                                                      \
-        auto kfd = k_conv3x3_mfma<BNv, NAv, Fv, Av, 4, Sv, false, false, true>;                                      \
+        auto kfd = k_conv3x3_mfma<BNv, NAv, Fv, Av, 4, Sv, true>;                                                    \
         PHX_CHECK_HIP(hipFuncSetAttribute((const void*)kfd, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         hipLaunchKernelGGL(kfd, dim3(ntiles * (N / BNv), 1, Sv ? ksplit : 1), dim3(256), sh, (hipStream_t)stream,     \
                            (const unsigned short*)x, (const unsigned short*)wpk, (unsigned short*)y, Sv ? nullptr : bias, \
                            Sv ? 0 : act, Sv ? nullptr : stats_partial, B, H, W, K, N, g, Sv ? (float*)workspace : nullptr, \
-                           Sv ? BwdStats{} : bws, XForm{}, du);                                                      \
+                           Sv ? EpiOpts{} : bws, XForm{}, du);                                                       \
     } while (0)
 #define CM_DUAL(BNv, NAv, Fv)                                                                                        \
     do {                                                                                                             \
@@ -1837,118 +1151,6 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
         const size_t total = (size_t)B * H * W * N;
         hipLaunchKernelGGL(k_splitk_finish, dim3(phx_grid_for(total / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)workspace, ksplit, total, N, bias, act, (unsigned short*)y, bws.oscale, du.y2, du.N1);
-        PHX_CHECK_LAUNCH();
-    }
-    return PHX_OK;
-}
-
-
-// ---- fused conv -> norm -> act -> conv edge (XF instantiations of k_conv3x3_mfma; register-staged 256-pixel tiles only) ----------
-static int xf_ksplit(int B, int H, int W, int K, int N) {
-    const char* e = getenv("PHX_FWD_SPLITK");
-    if (e && atoi(e) == 0) return 1;
-    MTile g = make_mtile(B, H, W);
-    const int blocks = g.tiles_x * g.tiles_y * g.tiles_b * (N / (N % 64 == 0 ? 64 : 32));
-    const int nck = K / KC;
-    if (blocks * 2 > 64 || nck < 2) return 1;
-    int ks = (64 + blocks - 1) / blocks;
-    if (ks > nck) ks = nck;
-    const int per = (nck + ks - 1) / ks;
-    return (nck + per - 1) / per;
-}
-int phx_conv3x3_xf_supported(int B, int H, int W, int K, int N, int NS) {
-    if (K % KC != 0 || N % 32 != 0 || K * 8 > XF_TBL_BYTES) return 0;
-    if ((double)B * H * W * (K > N ? K : N) >= 2147483648.0) return 0;
-    MTile g = make_mtile(B, H, W);
-    const bool fast16 = g.tws == 4 && g.ths == 4 && g.tb == 1;
-    if (!fast16 && (double)B * H * W >= 16777216.0) return 0;
-    if (NS > 1 && g.tb != 1) return 0;                 // per-sample statistics: a pixel tile must lie inside one sample
-    return 1;
-}
-int phx_conv3x3_xf_tiles(int B, int H, int W) {
-    MTile g = make_mtile(B, H, W);
-    return g.tiles_x * g.tiles_y * g.tiles_b;
-}
-size_t phx_conv3x3_xf_ws_bytes(int B, int H, int W, int K, int N) {
-    const int ks = xf_ksplit(B, H, W, K, N);
-    return ks > 1 ? (size_t)ks * B * H * W * N * sizeof(float) : 0;
-}
-int phx_conv3x3_mfma_bf16_xf(const void* y_prod, const void* wpk, void* y, const float* bias, int act, float* stats, int stats_atomic,
-                             void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, const float* p_sums,
-                             const float* p_pivot, const float* p_gamma, const float* p_beta, float p_eps, int p_nrep, int p_NS,
-                             int p_G, int p_act, void* a_out, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
-                             float* moving_mean, float* moving_var, float momentum, void* stream) {
-    const Dual du_xf = take_next_dual();          // (a pending dual-input / -output modifier must not leak into a later launch)
-    PHX_REQUIRE(du_xf.x2 == nullptr && du_xf.y2 == nullptr, PHX_E_INVAL, "conv3x3_mfma_xf: no dual input / output");
-    PHX_REQUIRE(phx_conv3x3_xf_supported(B, H, W, K, N, p_NS), PHX_E_SHAPE, "conv3x3_mfma_xf: shape not supported (see ..._supported)");
-    PHX_REQUIRE((((uintptr_t)y_prod | (uintptr_t)wpk | (uintptr_t)y | (uintptr_t)a_out) & 15) == 0, PHX_E_ALIGN, "conv3x3_mfma_xf: 16-byte alignment");
-    PHX_REQUIRE(p_sums && p_gamma && p_beta && mean_out && rstd_out && scale_out && shift_out && p_nrep >= 1 && p_G >= 1 && K % p_G == 0 &&
-                (p_NS == 1 || p_NS == B), PHX_E_INVAL, "conv3x3_mfma_xf: bad normalisation arguments");
-    int ksplit = 1;
-    if (workspace && !stats) {
-        ksplit = xf_ksplit(B, H, W, K, N);
-        PHX_REQUIRE(workspace_bytes >= (size_t)(ksplit > 1 ? ksplit : 0) * B * H * W * N * sizeof(float), PHX_E_INVAL, "conv3x3_mfma_xf: workspace too small");
-    }
-    PHX_REQUIRE(!stats_atomic || (stats && !phx_deterministic()), PHX_E_INVAL, "conv3x3_mfma_xf: atomic statistics need a sums buffer (and no deterministic mode)");
-    XForm xf;
-    xf.sums = p_sums; xf.pivot = p_pivot; xf.gamma = p_gamma; xf.beta = p_beta; xf.eps = p_eps;
-    xf.invP = 1.f / (float)(p_NS > 1 ? H * W : B * H * W);
-    xf.nrep = p_nrep; xf.NS = p_NS; xf.G = p_G; xf.act = p_act; xf.a_out = (unsigned short*)a_out;
-    xf.mean_out = mean_out; xf.rstd_out = rstd_out; xf.scale_out = scale_out; xf.shift_out = shift_out;
-    xf.moving_mean = moving_mean; xf.moving_var = moving_var; xf.momentum = momentum;
-    BwdStats bws{};
-    bws.stats_atomic = stats_atomic;
-    MTile g = make_mtile(B, H, W);
-    const int tw = 1 << g.tws, th = 1 << g.ths;
-    const int npatch = g.tb * (th + 2) * (tw + 2);
-    const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
-    const int na = (npatch * 4 + 255) / 256;
-    PHX_REQUIRE(na <= 16, PHX_E_SHAPE, "conv3x3_mfma_xf: unexpected tile geometry");
-    const bool biasact = bias != nullptr || act != PHX_ACT_ID;
-    const bool fast16 = g.tws == 4 && g.ths == 4 && g.tb == 1;
-#define XF_LAUNCH1(BNv, NAv, Fv, Av, Sv)                                                                               \
-    do {                                                                                                             \
-        size_t sh = (Fv ? (size_t)(4 * 4 + 2) * PITCH16 : (size_t)g.tb * g.ipitch) + 9 * BNv * ROWB;                 \
-        const size_t she = (size_t)4 * 64 * (BNv * 2 + 16);                                                          \
-        if (she > sh) sh = she;                                                                                      \
-        sh += XF_TBL_BYTES;                                                                                          \
-        static bool at = false;                                                                                      \
-        if (!at) {                                                                                                   \
-            PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_mfma<BNv, NAv, Fv, Av, 4, Sv, true>,            \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));              \
-            at = true;                                                                                               \
-        }                                                                                                            \
-        if (Sv)                                                                                                      \
-            hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, false, 4, Sv, true>), dim3(ntiles * (N / BNv), 1, ksplit), \
-                               dim3(256), sh, (hipStream_t)stream, (const unsigned short*)y_prod,                    \
-                               (const unsigned short*)wpk, (unsigned short*)y, nullptr, 0, nullptr, B, H, W, K, N, g,\
-                               (float*)workspace, BwdStats{}, xf, Dual{});                                                 \
-        else                                                                                                         \
-            hipLaunchKernelGGL((k_conv3x3_mfma<BNv, NAv, Fv, Av, 4, false, true>), dim3(ntiles * (N / BNv)), dim3(256), \
-                               sh, (hipStream_t)stream, (const unsigned short*)y_prod, (const unsigned short*)wpk,   \
-                               (unsigned short*)y, bias, act, stats, B, H, W, K, N, g, nullptr, bws, xf, Dual{});    \
-    } while (0)
-#define XF_LAUNCH(BNv, NAv, Fv)                                                                                      \
-    do {                                                                                                             \
-        if (ksplit > 1) XF_LAUNCH1(BNv, NAv, Fv, false, true);                                                       \
-        else if (biasact) XF_LAUNCH1(BNv, NAv, Fv, true, false);                                                     \
-        else XF_LAUNCH1(BNv, NAv, Fv, false, false);                                                                 \
-    } while (0)
-    static int n32thr = -1;
-    if (n32thr < 0) { const char* e = getenv("PHX_BN32_MAXBLOCKS"); n32thr = e ? atoi(e) : 256; }
-    const bool narrow32 = N % 64 == 0 && ksplit == 1 && ntiles * (N / 64) <= n32thr;
-    if (N % 64 == 0 && !narrow32) {
-        if (fast16) XF_LAUNCH(64, 8, true); else if (na <= 8) XF_LAUNCH(64, 8, false); else XF_LAUNCH(64, 16, false);
-    } else {
-        if (fast16) XF_LAUNCH(32, 8, true); else if (na <= 8) XF_LAUNCH(32, 8, false); else XF_LAUNCH(32, 16, false);
-    }
-#undef XF_LAUNCH
-#undef XF_LAUNCH1
-    PHX_CHECK_LAUNCH();
-    if (ksplit > 1 && y != nullptr) {
-        const size_t total = (size_t)B * H * W * N;
-        hipLaunchKernelGGL(k_splitk_finish, dim3(phx_grid_for(total / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)workspace, ksplit, total, N, bias, act, (unsigned short*)y, (const float*)nullptr, (unsigned short*)nullptr, 0);
         PHX_CHECK_LAUNCH();
     }
     return PHX_OK;

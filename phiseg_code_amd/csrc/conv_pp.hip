@@ -34,6 +34,10 @@ struct Dual {                                // (as in conv_mfma.hip: concat-fre
     int K1, N1;
 };
 
+#ifndef PP_FENCE          // dev: scheduling fence every PP_FENCE row pairs of the epilogue's pack loop (0: none)
+#define PP_FENCE 2
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -59,7 +63,7 @@ __device__ unsigned long long* g_pp_trace = nullptr;      // dev: cycle stamps o
             *reinterpret_cast<unsigned long long*>(smem + OFF_TRACE + ((slot) * 8 + wave) * 8) = __builtin_readcyclecounter(); \
     } while (0)
 
-// DBG (dev, tools/bench_pp.py): 1 no patch DMA, 2 no slab DMA, 4 no MFMAs, 8 no epilogue
+// DBG (dev builds with -DPP_DEV_ABLATE, tools/bench_pp.py): 1 no patch DMA, 2 no slab DMA, 4 no MFMAs
 template <int BN, bool BIASACT, bool DUAL, int DBG>
 __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __restrict__ x, const unsigned short* __restrict__ wpk,
                                                        unsigned short* __restrict__ y, const float* __restrict__ bias, int act,
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __r
         n0 = cob * BN;
         pbase = (unsigned)((b0 * H + ty0 - 1) * W + tx0 - 1);                              // patch pixel (0, 0); may wrap below zero
         pout = 16u | (tx0 == 0 ? 1u : 0u) | (tx0 + 32 >= W ? 2u : 0u) | (ty0 == 0 ? 4u : 0u) | (ty0 + 16 >= H ? 8u : 0u);
-        if (!t_valid || (DBG & 1)) pout = 31u;
+        if (!t_valid || (DBG & 1)) pout |= 32u;        // no tile (odd tile count) / dev: every piece reads as zero
     };
     // DMA of this half's patch for chunk c of the current tile
     auto load_patch = [&](int c) __attribute__((always_inline)) {
@@ -153,15 +157,19 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __r
         int ln = lane;
         asm volatile("" : "+v"(ln));                   // (opaque: nothing lane-derived below is hoisted out of the phase loop)
         const int pp0 = lw * (PP_APW * 16) + (ln >> 2), slot = ln & 3;
+        // a piece lies outside the image only in patch column 0 / 33 or patch row 0 / 17 of a tile on the matching image edge (pout);
+        // the rows behind the patch (pp >= 612 <=> py >= 18) belong to no pixel
+        const int xlo = (int)(pout & 1u), xw = 33 - (int)((pout >> 1) & 1u) - xlo;
+        const int ylo = (int)((pout >> 2) & 1u), yw = 17 - (int)((pout >> 3) & 1u) - ylo;
+        const bool none = (pout & 32u) != 0u;
 #pragma unroll
         for (int n = 0; n < PP_APW; ++n) {
             const int j = lw * PP_APW + n;
             if (j < PP_AI) {
-                const int pp = pp0 + n * 16;
-                const int py = (int)(((unsigned)pp * 1928u) >> 16), px = pp - py * 34;      // pp / 34 for pp < 1024
-                const unsigned edge = (pp < 612 ? 0u : 16u) | (px == 0 ? 1u : 0u) | (px == 33 ? 2u : 0u) | (py == 0 ? 4u : 0u) | (py == 17 ? 8u : 0u);
-                const bool bad = (edge & pout) != 0u;
-                const unsigned vo = bad ? 0xffffffffu : pb + (unsigned)(py * W + px) * stride + (unsigned)((slot ^ ((px >> 2) & 3)) << 4);
+                const int pp = pp0 + n * 16;           // (per piece, independent of the others: ten chains for the scheduler to interleave)
+                const int py = (int)(((unsigned)pp * 1928u) >> 16), px = pp - py * 34;      // pp / 34, pp % 34 (pp < 1024)
+                const bool bad = none || (unsigned)(px - xlo) > (unsigned)xw || (unsigned)(py - ylo) > (unsigned)yw;
+                const unsigned vo = bad ? 0xffffffffu : pb + __umul24((unsigned)(py * W + px), stride) + (unsigned)((slot ^ ((px >> 2) & 3)) << 4);
                 if (DUAL && second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx2, (lds_ptr_t)(patch + j * 1024), 16, (int)vo, so, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(patch + j * 1024), 16, (int)vo, so, 0, 0);
             }
@@ -277,7 +285,6 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __r
     int sp_id = 0, sp_n0 = 0;
     float* const red = reinterpret_cast<float*>(smem + OFF_RED) + wave * 2 * BN;       // [which][BN] of this wave
     auto epilogue = [&](int sb) __attribute__((always_inline)) {
-        if (DBG & 8) return;
         if (!et_valid) return;
         // (everything lane-derived is recomputed here from an opaque copy of the lane id: hoisted out of the phase loop these values
         // would stay live across the MFMA stream, which has no register to spare)
@@ -287,11 +294,11 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __r
         unsigned char* const scr = smem + (sb ? OFF_S1 : OFF_S0) + (half * SP + CW * lw) * 1024;
         const unsigned psel = odd ? 0x03020706u : 0x05040100u;
         const bool do_stats = stats_partial != nullptr;
-        float s1[NJ], s2[NJ];
+        float s1[NJ][2], s2[NJ][2];                    // (two accumulators per statistic: half the dependent chain)
         [[maybe_unused]] float bv[NJ], sv[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            s1[j] = s2[j] = 0.f;
+            s1[j][0] = s1[j][1] = s2[j][0] = s2[j][1] = 0.f;
             if constexpr (BIASACT) {
                 bv[j] = bias ? bias[et_n0 + j * 32 + l31e] : 0.f;
                 sv[j] = oscale ? oscale[et_n0 + j * 32 + l31e] : 1.f;
@@ -312,12 +319,20 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __r
         const unsigned vo_y = (unsigned)((prow * N + q * 8) * 2);
         // one pass = one tile row of the wave (32 pixels x BN channels): pack pairs of accumulator rows (bias / scale / activation on
         // the way: AM = 0 none, 1 ReLU -- uniform per launch, one branch per tile), statistics of the values as stored,
-        // exchange with the neighbour lane (DPP) so that a lane holds two adjacent channels of ONE pixel, 32-bit LDS writes
-        auto pass = [&](auto ic, auto amc) __attribute__((always_inline)) {
+        // exchange with the neighbour lane (DPP) so that a lane holds two adjacent channels of ONE pixel, 32-bit LDS writes,
+        // read back 16 bytes per lane, store
+        // Software pipeline over the four passes: W0 R0 | W1 S0 R1 | W2 S1 R2 | W3 S2 R3 | S3 -- the read-back of pass i returns under
+        // the packing of pass i + 1 (a wave's LDS operations execute in order, so the writes of pass i + 1 cannot overtake the reads
+        // of pass i although they share the scratch); left to the compiler the four passes ran write -> read -> WAIT -> store.
+        u32x4_t vst[2][PPP / 2];
+        auto pack_write = [&](auto ic, auto amc) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value, AM = decltype(amc)::value & 3;
             constexpr bool ST = (decltype(amc)::value & 4) != 0;
 #pragma unroll
-            for (int rp = 0; rp < 8; ++rp)
+            for (int rp = 0; rp < 8; ++rp) {
+                // (scheduling fence per row pair -- per two without the bias arithmetic: left alone, the machine scheduler hoists the cheap head of all sixteen chains
+                // of a pass -- bias multiply-adds, conversions -- in front of the first LDS write and spills the results)
+                if (PP_FENCE && (BIASACT || rp % PP_FENCE == 0)) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int r0 = 2 * rp;
@@ -329,30 +344,47 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __r
                     const unsigned w2 = f2bf_pk(v0, v1);
                     if constexpr (ST) {            // of the values as stored: v_dot2c_f32_bf16 (products of bf16 pairs are exact in fp32)
                         const bf16x2_t wv = __builtin_bit_cast(bf16x2_t, w2);
-                        s1[j] = __builtin_amdgcn_fdot2_f32_bf16(wv, __builtin_bit_cast(bf16x2_t, 0x3f803f80u), s1[j], false);
-                        s2[j] = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, s2[j], false);
+                        s1[j][rp & 1] = __builtin_amdgcn_fdot2_f32_bf16(wv, __builtin_bit_cast(bf16x2_t, 0x3f803f80u), s1[j][rp & 1], false);
+                        s2[j][rp & 1] = __builtin_amdgcn_fdot2_f32_bf16(wv, wv, s2[j][rp & 1], false);
                     }
                     const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)w2, 0xB1, 0xf, 0xf, true);
                     *reinterpret_cast<unsigned*>(lwp + ((r0 & 3) + 8 * (r0 >> 2)) * OROW + ((j * 64) ^ (odd ? OSWZ : 0))) = __builtin_amdgcn_perm(nb, w2, psel);
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto read_back = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+#pragma unroll
+            for (int it = 0; it < PPP / 2; ++it) vst[i & 1][it] = *reinterpret_cast<const u32x4_t*>(lr + it * (64 / PPP) * OROW);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto store = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
             const int oy = et_ty0 + 4 * lw + i;
             const int pix0 = (et_b0 * H + oy) * W + et_tx0;
-            u32x4_t v[PPP / 2];
-#pragma unroll
-            for (int it = 0; it < PPP / 2; ++it) v[it] = *reinterpret_cast<const u32x4_t*>(lr + it * (64 / PPP) * OROW);
-            __builtin_amdgcn_sched_barrier(0);         // (all reads of the pass in flight before the first store waits for one)
 #pragma unroll
             for (int it = 0; it < PPP / 2; ++it) {
                 if constexpr (DUAL) {
-                    *reinterpret_cast<u32x4_t*>(ybase + ((size_t)pix0 + prow + it * (64 / PPP)) * yld + ych) = v[it];
+                    *reinterpret_cast<u32x4_t*>(ybase + ((size_t)pix0 + prow + it * (64 / PPP)) * yld + ych) = vst[i & 1][it];
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b128(v[it], rsy, (int)vo_y, (pix0 + it * (64 / PPP)) * N * 2 + et_n0 * 2, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(vst[i & 1][it], rsy, (int)vo_y, (pix0 + it * (64 / PPP)) * N * 2 + et_n0 * 2, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         };
 #define IC(v) std::integral_constant<int, (v)>()
         const int am = ((BIASACT && act == PHX_ACT_RELU) ? 1 : 0) + (do_stats ? 4 : 0);
-#define PP_PASSES(m) do { pass(IC(0), IC(m)); pass(IC(1), IC(m)); pass(IC(2), IC(m)); pass(IC(3), IC(m)); } while (0)
+#define PP_PASSES(m)                                                                                     \
+    do {                                                                                                 \
+        PP_TRACE(88);                                                                                    \
+        pack_write(IC(0), IC(m)); PP_TRACE(89); read_back(IC(0)); PP_TRACE(90);                          \
+        pack_write(IC(1), IC(m)); PP_TRACE(91); store(IC(0)); PP_TRACE(92); read_back(IC(1));            \
+        pack_write(IC(2), IC(m)); PP_TRACE(93); store(IC(1)); read_back(IC(2));                          \
+        pack_write(IC(3), IC(m)); store(IC(2)); read_back(IC(3)); PP_TRACE(94);                          \
+        store(IC(3));                                                                                    \
+        PP_TRACE(95);                                                                                    \
+    } while (0)
         if (am == 0) PP_PASSES(0);
         else if (am == 4) PP_PASSES(4);
         else if constexpr (BIASACT) {                 // (identity / ReLU only: the launcher refuses other activations)
@@ -364,8 +396,9 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __r
         if (do_stats) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const float a = s1[j] + __shfl_xor(s1[j], 32, 64);
-                const float bq = s2[j] + __shfl_xor(s2[j], 32, 64);
+                const float a0 = s1[j][0] + s1[j][1], b0q = s2[j][0] + s2[j][1];
+                const float a = a0 + __shfl_xor(a0, 32, 64);
+                const float bq = b0q + __shfl_xor(b0q, 32, 64);
                 if (khalfe == 0) {
                     red[j * 32 + l31e] = a;
                     red[BN + j * 32 + l31e] = bq;
@@ -425,13 +458,10 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __r
     // both halves run the same body one phase apart: [matrix phase of item `it`] barrier [load phase in front of item it + 1] barrier
     for (int it = 0; it < total; ++it) {
         flush_stats();
-        PP_TRACE(it * 8 + 0);
-        if constexpr (DBG & 16) __builtin_amdgcn_s_setprio(2);
+        if (it < 11) PP_TRACE(it * 8 + 0);
         if (c == 0) compute(it & 1, std::true_type());
         else compute(it & 1, std::false_type());
-        if constexpr (DBG & 16) __builtin_amdgcn_s_setprio(0);
-        if constexpr (DBG & 32) __builtin_amdgcn_s_setprio(2);
-        PP_TRACE(it * 8 + 1);
+        if (it < 11) PP_TRACE(it * 8 + 1);
         const bool last = c + 1 == nch;
         if (last) {
             et_id = t_id; et_tx0 = tx0; et_ty0 = ty0; et_b0 = b0; et_n0 = n0; et_valid = t_valid;
@@ -440,14 +470,14 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __r
             if (it + 1 < total) set_work(wk);
         } else ++c;
         PP_BARRIER();
-        PP_TRACE(it * 8 + 2);
+        if (it < 11) PP_TRACE(it * 8 + 2);
         if (it + 1 < total) load_patch(c);
-        PP_TRACE(it * 8 + 3);
+        if (it < 11) PP_TRACE(it * 8 + 3);
         if (last) {
             epilogue((it + 1 + half) & 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the scratch has been read before the DMA overwrites it
         }
-        PP_TRACE(it * 8 + 4);
+        if (it < 11) PP_TRACE(it * 8 + 4);
         if (half == 0) {
             if (it + 1 < total) load_slab(c, n0, (it + 1) & 1);
         } else if (it + 2 < total) {
@@ -455,12 +485,11 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __r
             next_slab(&cn, &n0n);
             load_slab(cn, n0n, it & 1);
         }
-        PP_TRACE(it * 8 + 5);
+        if (it < 11) PP_TRACE(it * 8 + 5);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        PP_TRACE(it * 8 + 6);
-        if constexpr (DBG & 32) __builtin_amdgcn_s_setprio(0);
+        if (it < 11) PP_TRACE(it * 8 + 6);
         PP_BARRIER();
-        PP_TRACE(it * 8 + 7);
+        if (it < 11) PP_TRACE(it * 8 + 7);
     }
     if (half == 0) PP_BARRIER();                      // (B is one phase behind)
     flush_stats();
@@ -472,6 +501,12 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __r
 }
 
 }  // namespace
+
+static int g_pp_grid = 0;                 // tests: persistent grid size (0: one block per CU)
+int phx_pp_set_grid(int blocks) {
+    g_pp_grid = blocks;
+    return PHX_OK;
+}
 
 int phx_pp_set_trace(void* dev_buf) {
     PHX_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pp_trace), &dev_buf, sizeof(void*)));
@@ -503,8 +538,7 @@ int phx_pp_launch(const void* x, const void* wpk, void* y, const float* bias, in
         hipDeviceProp_t pr;
         ncu_dev = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
     }
-    const char* ge = getenv("PHX_PP_GRID");           // dev / tests: persistent grid size (default: one block per CU)
-    const int ncu = (ge && atoi(ge) > 0) ? atoi(ge) : ncu_dev;
+    const int ncu = g_pp_grid > 0 ? g_pp_grid : ncu_dev;
     // equal rounds: the grid that gives every block the same number of work items (no block waits for a straggler's extra item)
     int grid = gm.nitems < ncu ? gm.nitems : ncu;
     if (gm.nitems > ncu) {
@@ -526,17 +560,19 @@ int phx_pp_launch(const void* x, const void* wpk, void* y, const float* bias, in
     if (bn == 64) {
         if (dual) { if (ba) PP_LAUNCH(64, true, true, 0); else PP_LAUNCH(64, false, true, 0); }
         else if (ba) PP_LAUNCH(64, true, false, 0);
-        else switch (dbg) {
-            case 1: PP_LAUNCH(64, false, false, 1); break; case 2: PP_LAUNCH(64, false, false, 2); break;
-            case 3: PP_LAUNCH(64, false, false, 3); break; case 4: PP_LAUNCH(64, false, false, 4); break;
-            case 16: PP_LAUNCH(64, false, false, 16); break; case 32: PP_LAUNCH(64, false, false, 32); break;
-            default: PP_LAUNCH(64, false, false, 0);
-        }
+#ifdef PP_DEV_ABLATE          // dev builds (tools/ppc.sh -DPP_DEV_ABLATE): staging / matrix phases switched off
+        else if (dbg == 1) PP_LAUNCH(64, false, false, 1);
+        else if (dbg == 2) PP_LAUNCH(64, false, false, 2);
+        else if (dbg == 3) PP_LAUNCH(64, false, false, 3);
+        else if (dbg == 4) PP_LAUNCH(64, false, false, 4);
+#endif
+        else PP_LAUNCH(64, false, false, 0);
     } else {
         if (dual) { if (ba) PP_LAUNCH(32, true, true, 0); else PP_LAUNCH(32, false, true, 0); }
         else if (ba) PP_LAUNCH(32, true, false, 0);
         else PP_LAUNCH(32, false, false, 0);
     }
+    (void)dbg;
 #undef PP_LAUNCH
     PHX_CHECK_LAUNCH();
     return PHX_OK;

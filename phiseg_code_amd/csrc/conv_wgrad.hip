@@ -631,11 +631,7 @@ int phx_wgrad_set_debug(void* trace_buf, void* blocklog_buf, int which) {
 
 extern "C" {
 
-static bool wgrad_dma_enabled() {
-    static int dma_en = -1;
-    if (dma_en < 0) { const char* e = getenv("PHX_WGRAD_DMA"); dma_en = e ? atoi(e) : 1; }
-    return dma_en != 0;
-}
+static bool wgrad_dma_enabled() { return true; }
 // dynamic LDS of the LDS-DMA filter-gradient kernels: the staged tile, or the 2 x 36 KiB of the wave-group reduction
 static size_t wgrad_dma_lds(int tci, int tco) {
     const size_t stage = (size_t)((324 * (tci / 8) + 63) / 64) * 1024 + (size_t)256 * tco * 2;
@@ -657,7 +653,6 @@ static int wgrad_plan(int B, int H, int W, int Cin, int Cout, MTile* g, int* tci
     // re-reads) a full 9*TCI*TCO partial filter
     int target_blocks = cblocks <= 4 && *tci == 64 && *tco == 64 ? 512 : 384;
     if (ntiles <= 256 && target_blocks > 256) target_blocks = 256;
-    if (const char* e = getenv("PHX_WGRAD_BLOCKS")) target_blocks = atoi(e);      // tuning hook
     if (target_override > 0) target_blocks = target_override;                     // deferred multi-layer launches (see below)
     int split = (target_blocks + cblocks - 1) / cblocks;
     if (split > ntiles) split = ntiles;
@@ -675,9 +670,7 @@ size_t phx_conv3x3_wgrad_ws_bytes_dual(int B, int H, int W, int Cin, int Cout, i
 size_t phx_conv3x3_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout) { return phx_conv3x3_wgrad_ws_bytes_dual(B, H, W, Cin, Cout, 0); }
 
 static int wgrad_atomic_tiles() {
-    static int atl = -1;
-    if (atl < 0) { const char* e = getenv("PHX_WGRAD_ATOMIC_TILES"); atl = e ? atoi(e) : 4; }
-    return phx_deterministic() ? 0 : atl;        // deterministic mode: always partial filters + ordered reduction
+    return phx_deterministic() ? 0 : 4;        // deterministic mode: always partial filters + ordered reduction
 }
 static void wgrad_reduce_geometry(int Cin, int Cout, int nslice, int* rgx, int* rgy) {
     const size_t total = (size_t)9 * Cin * Cout;
@@ -734,8 +727,7 @@ int phx_conv3x3_wgrad_multi_job_dual(const void* x, const void* x2, int K1, cons
         // 16x16 tiles: the LDS-DMA kernel with a workspace; measured: deferring up to 1024 tiles (H <= 64 at batch 64) helps,
         // the 128x128 layers are as fast inline (their inputs are still in the Infinity Cache right after the backward
         // normalisation pass)
-        static int dtl = -1;
-        if (dtl < 0) { const char* e = getenv("PHX_WGRAD_DEFER_TILES"); dtl = e ? atoi(e) : 1024; }
+        const int dtl = 1024;
         if (!workspace || ntiles > dtl || ntiles <= wgrad_atomic_tiles() || !wgrad_dma_enabled()) return PHX_OK;
     }
     const int npatch = g.tb * ((1 << g.ths) + 2) * ((1 << g.tws) + 2);

@@ -319,103 +319,6 @@ __global__ __launch_bounds__(1024) void k_bn_small_bwd(const bf16_t* __restrict_
     }
 }
 
-// Batch-norm backward of a MID-SIZE layer (1 024 < P <= 65 536 pixels: the 8 x 8 .. 32 x 32 levels at batch 64) in ONE launch: the
-// k_bn_small_bwd arithmetic with the pixels of a 16-channel slice split over S blocks.  A block keeps its pixels in registers,
-// adds its partial {sum g, sum g xhat} to sums2[C][2] with RETURNING device-scope atomics (the value comes back from the coherence
-// point: the add has been performed when it arrives), the S blocks of a slice meet at an arrival counter (all blocks of the launch
-// are resident: the launcher bounds the grid; the spin is bounded), read the totals back and write dx -- the reduction launch, its
-// fixed ~8 us tail and the second pass over dA and x of the two-launch form (phx_norm_bwd_reduce + _apply) disappear.
-__device__ unsigned g_bn_mid_timeouts = 0;
-template <int NIT>
-__global__ __launch_bounds__(1024) void k_bn_mid_bwd(const bf16_t* __restrict__ dA, const bf16_t* __restrict__ x,
-                                                     const float* __restrict__ scale, const float* __restrict__ shift,
-                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     const float* __restrict__ gamma, bf16_t* __restrict__ dx, float* dgamma,
-                                                     float* dbeta, float* sums2, unsigned* counters, int P, int C, int act) {
-    __shared__ float red[17 * 2 * 16];
-    const int v = threadIdx.x & 1, pl = threadIdx.x >> 1;
-    const int c0 = blockIdx.x * 16 + v * 8;
-    const int p0 = blockIdx.y * (NIT * 512);
-    uint4 rx[NIT], rd[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int p = p0 + pl + it * 512;
-        rx[it] = rd[it] = make_uint4(0, 0, 0, 0);
-        if (p < P) {
-            rx[it] = *reinterpret_cast<const uint4*>(x + (size_t)p * C + c0);
-            rd[it] = *reinterpret_cast<const uint4*>(dA + (size_t)p * C + c0);
-        }
-    }
-    float sc[8], sh[8], mu[8], rs[8], gmv[8], s[16];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int c = c0 + j;
-        sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; rs[j] = rstd[c]; gmv[j] = gamma[c];
-        s[j] = s[8 + j] = 0.f;
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {                  // (pixels past P: dA = 0 -> g = 0)
-        float xf[8], df[8];
-        bf16x8_unpack(rx[it], xf);
-        bf16x8_unpack(rd[it], df);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float g = df[j] * act_grad_pre(fmaf(xf[j], sc[j], sh[j]), act);
-            s[j] += g;
-            s[8 + j] = fmaf(g * (xf[j] - mu[j]), rs[j], s[8 + j]);
-        }
-    }
-    small_block_sum<16>(s, red);                        // every thread now holds its v-half's block totals
-    if (pl == 0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float o1 = atomicAdd(&sums2[(size_t)(c0 + j) * 2], s[j]);
-            const float o2 = atomicAdd(&sums2[(size_t)(c0 + j) * 2 + 1], s[8 + j]);
-            asm volatile("" ::"v"(o1), "v"(o2));
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int spins = 0;
-        while (__hip_atomic_load(counters + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.y && ++spins < (1 << 24))
-            __builtin_amdgcn_s_sleep(2);
-        if (spins >= (1 << 24)) atomicAdd(&g_bn_mid_timeouts, 1u);
-    }
-    __syncthreads();
-    const float inv_m = 1.f / (float)P;
-    float ca[8], cb[8], cc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int c = c0 + j;
-        const float t1 = __hip_atomic_load(&sums2[(size_t)c * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float t2 = __hip_atomic_load(&sums2[(size_t)c * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float gm = gmv[j];
-        ca[j] = rs[j] * gm;
-        cc[j] = -rs[j] * rs[j] * gm * t2 * inv_m;
-        cb[j] = -rs[j] * gm * t1 * inv_m - cc[j] * mu[j];
-        if (pl == 0 && blockIdx.y == 0) {               // (accumulate: a variable may be used by several layers)
-            atomicAdd(&dbeta[c], t1);
-            atomicAdd(&dgamma[c], t2);
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int p = p0 + pl + it * 512;
-        if (p < P) {
-            float xf[8], df[8], o[8];
-            bf16x8_unpack(rx[it], xf);
-            bf16x8_unpack(rd[it], df);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float gq = df[j] * act_grad_pre(fmaf(xf[j], sc[j], sh[j]), act);
-                o[j] = fmaf(ca[j], gq, fmaf(cc[j], xf[j], cb[j]));
-            }
-            VecIO<bf16_t, 8>::store(dx, (size_t)p * C + c0, o);
-        }
-    }
-}
-
 // =================================================================================================
 // Group / instance norm on small maps (a sample has P = H*W <= 256 pixels: the H <= 16 levels), bf16 NHWC: the whole layer
 // in one launch, like k_bn_small_* -- but the statistics are per SAMPLE, so nothing is reduced across waves: a wave owns
@@ -698,14 +601,7 @@ static int norm_geometry(int P, int C, int V, int* PL, int* threads, int* chunk,
     // streaming parallelism and that tail.  The backward reduction spreads its blocks over nrep accumulator replicas and takes
     // more, shorter blocks (16 pixels per thread, 256..512 blocks); the forward statistics pass has one accumulator set -- 256
     // blocks cost it 11 us of atomics on the H <= 16 levels -- and keeps 8 pixels per thread with a floor of 128 blocks.
-    static int ppt_r = 0, ppt_s = 0, fl_r = 0, fl_s = 0, capv = 0;
-    if (!ppt_r) {
-        const char* e = getenv("PHX_NORM_PPT"); ppt_r = e ? atoi(e) : 16;            // tuning hooks (tools/bench_norm.py)
-        e = getenv("PHX_NORM_FLOOR"); fl_r = e ? atoi(e) : 256;
-        e = getenv("PHX_NORM_CAP"); capv = e ? atoi(e) : 512;
-        e = getenv("PHX_STATS_PPT"); ppt_s = e ? atoi(e) : 8;
-        e = getenv("PHX_STATS_FLOOR"); fl_s = e ? atoi(e) : 128;
-    }
+    const int ppt_r = 16, fl_r = 256, capv = 512, ppt_s = 8, fl_s = 128;        // (measured: tools/bench_norm.py)
     const int ppt_n = nrep > 1 ? ppt_r : ppt_s, fl = nrep > 1 ? fl_r : fl_s;
     int want = (rows + ppt_n - 1) / ppt_n;
     // (the floor counts blocks of the whole launch: with per-sample statistics, NS > 1, every sample gets its share -- a
@@ -724,18 +620,15 @@ static int norm_geometry(int P, int C, int V, int* PL, int* threads, int* chunk,
 static int stream_geometry(int P, int C, int V, int* PL, int* threads, int* chunk, int* nchunks, int NS) {
     int CV = C / V;
     if (CV > 256) return -1;
-    static int nthr = 0;
-    if (!nthr) { const char* e = getenv("PHX_STREAM_THREADS"); nthr = e ? atoi(e) : 256; }  // tuning hook: threads per block
+    const int nthr = 256;                        // threads per block
     *PL = nthr / CV;
     if (*PL < 1) *PL = 1;
     *threads = CV * (*PL);
     // 8 pixels per thread on big maps (two trips of four); on small maps fewer, so that ~1024 blocks exist
     int rows = (P + *PL - 1) / (*PL);
-    static int ppt_s = 0;
-    if (!ppt_s) { const char* e = getenv("PHX_STREAM_PPT"); ppt_s = e ? atoi(e) : 8; }   // tuning hook: pixels per thread (8 / floor 1024 since the prologues are LDS-shared; 32 / 256 before)
+    const int ppt_s = 8;                         // pixels per thread (8 / floor 1024 since the prologues are LDS-shared; 32 / 256 before)
     int want = (rows + ppt_s - 1) / ppt_s;
-    static int fl = 0;
-    if (!fl) { const char* e = getenv("PHX_STREAM_FLOOR"); fl = e ? atoi(e) : 1024; }   // tuning hook (measured: tools/bench_norm.py)
+    const int fl = 1024;                         // (measured: tools/bench_norm.py)
     // (the floor counts blocks of the whole launch: with per-sample statistics, NS > 1, every sample gets its share -- a
     // floor per SAMPLE cut the 128 x 128 group-norm layers into thousands of blocks of two pixels per thread: 62 us vs 19)
     const int fl_ns = (fl + (NS > 0 ? NS : 1) - 1) / (NS > 0 ? NS : 1);
@@ -1924,45 +1817,6 @@ int phx_bn_small_bwd(const void* dA, const void* x, const float* scale, const fl
                        (const bf16_t*)x, scale, shift, mean, rstd, gamma, (bf16_t*)dx, dgamma, dbeta, P, C, act)
     if (P <= 512) BNS_B(1); else if (P <= 1024) BNS_B(2); else if (P <= 2048) BNS_B(4); else BNS_B(8);
 #undef BNS_B
-    PHX_CHECK_LAUNCH();
-    return PHX_OK;
-}
-
-// ---- batch-norm backward of a mid-size layer in one launch (k_bn_mid_bwd) ----
-// -> pixels per block / 512 (1, 2, 4 or 8), 0: not supported.  The grid is (C / 16) x S blocks of 1 024 threads with S = ceil(P /
-// (512 NIT)); all of them have to be resident at once: at most PHX_BN_MID_MAXBLOCKS (192: two such launches side by side fit the
-// chip's 512 slots of 1 024 threads).
-static int bn_mid_plan(int P, int C, int dt) {
-    if (dt != PHX_BF16 || C % 16 != 0 || P < 1 || phx_deterministic()) return 0;
-    static int maxb = -1;
-    if (maxb < 0) { const char* e = getenv("PHX_BN_MID_MAXBLOCKS"); maxb = e ? atoi(e) : 192; }
-    for (int nit = 1; nit <= 8; nit *= 2) {
-        const int S = (P + 512 * nit - 1) / (512 * nit);
-        if ((C / 16) * S <= maxb) return nit;
-    }
-    return 0;
-}
-int phx_bn_mid_supported(int P, int C, int dt) { return bn_mid_plan(P, C, dt); }
-int phx_bn_mid_timeouts(int* count) {
-    unsigned v = 0;
-    PHX_CHECK_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_bn_mid_timeouts), sizeof(v)));
-    *count = (int)v;
-    return PHX_OK;
-}
-int phx_bn_mid_bwd(const void* dA, const void* x, const float* scale, const float* shift, const float* mean, const float* rstd,
-                   const float* gamma, void* dx, float* dgamma, float* dbeta, float* sums2, void* counters, int P, int C, int act,
-                   void* stream) {
-    const int nit = bn_mid_plan(P, C, PHX_BF16);
-    PHX_REQUIRE(nit != 0, PHX_E_SHAPE, "bn_mid_bwd: shape not supported (see phx_bn_mid_supported)");
-    PHX_REQUIRE(dA && x && scale && shift && mean && rstd && gamma && dx && dgamma && dbeta && sums2 && counters, PHX_E_INVAL,
-                "bn_mid_bwd: null argument");
-    const int S = (P + 512 * nit - 1) / (512 * nit);
-#define BNM_B(NITv)                                                                                                    \
-    hipLaunchKernelGGL((k_bn_mid_bwd<NITv>), dim3(C / 16, S), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)dA,     \
-                       (const bf16_t*)x, scale, shift, mean, rstd, gamma, (bf16_t*)dx, dgamma, dbeta, sums2,            \
-                       (unsigned*)counters, P, C, act)
-    if (nit == 1) BNM_B(1); else if (nit == 2) BNM_B(2); else if (nit == 4) BNM_B(4); else BNM_B(8);
-#undef BNM_B
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }

@@ -477,8 +477,7 @@ static void head_wgrad_geometry(size_t npix, int PL, int* chunk, int* grid) {
     int ch = PL * 32;
     size_t g = (npix + ch - 1) / ch;
     // every block ends in C * nout same-address atomics (~45 ns each, serialised): few, long blocks
-    static int cap = 0;
-    if (!cap) { const char* e = getenv("PHX_HEADW_BLOCKS"); cap = e ? atoi(e) : 1024; }
+    const int cap = 1024;
     if (g > (size_t)cap) { ch = (int)((npix + cap - 1) / cap); g = (npix + ch - 1) / ch; }
     if (phx_deterministic()) { ch = (int)npix; g = 1; }     // one block per head: fixed summation order
     *chunk = ch; *grid = (int)g;

@@ -27,65 +27,16 @@ F32, BF16, U8 = rt.F32, rt.BF16, 2
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, U8: torch.uint8}
 _NP_DT = {F32: np.float32, U8: np.uint8}
 _ESIZE = {F32: 4, BF16: 2, U8: 1}
-_GN_STATS_EPILOGUE = os.environ.get("PHX_GN_STATS_EPILOGUE", "1") == "1"   # group / instance norm: per-sample sums from the conv epilogue (A/B hook)
-_STATS_ATOMIC = os.environ.get("PHX_STATS_ATOMIC", "1") == "1"           # small-map batch norm: statistics by atomics from the conv epilogue (A/B hook)
-_KL_SIDE = os.environ.get("PHX_KL_SIDE", "0") == "1"                     # two lanes: KL launches on the prior lane (measured 2 % SLOWER: 12.17 vs 11.90 ms)
-_PRIOR_BW_FIRST = os.environ.get("PHX_PRIOR_BW_FIRST", "0") == "1"       # prior backward emitted before the likelihood's (A/B hook)
-_DEFER_LANE2 = os.environ.get("PHX_DEFER_LANE2", "0") == "1"             # likelihood's deferred launches on a third stream (A/B hook)
-_DEFER_EARLY = os.environ.get("PHX_DEFER_EARLY", "0") == "1"             # deferred launches of likelihood + prior on lane 1 beside the posterior backward (A/B hook)
-# deferred filter-gradient launches that run BESIDE a latency-bound chain (PHX_DEFER_LANE2 / PHX_DEFER_EARLY) request at least this
-# much dynamic LDS, so that only one of their (long-running, persistent) blocks fits a CU and the chain's small launches always
-# find free wave slots and LDS ("polite" occupancy); 0: as the kernels need
-_POLITE_LDS = int(os.environ.get("PHX_POLITE_LDS", "0"))
-_LIK_COARSE_FIRST = os.environ.get("PHX_LIK_COARSE_FIRST", "1") == "1"   # emission order of the likelihood's per-level chains
 # two lanes: likelihood chains of levels <= this go to the prior's lane; the coarsest chain stays on lane 0, in front of the top-down
 # path that starts with it: lane 0 then enters the likelihood without waiting for lane 1 (with all five chains there it started only
 # when the LAST of them was done, whatever the order: 12.38 vs 11.95 ms)
-_LIK_SIDE_MAXLVL = int(os.environ.get("PHX_LIK_SIDE_MAXLVL", "3"))
-_LIK_SIDE_LEVELS = ({int(v) for v in os.environ["PHX_LIK_SIDE_LEVELS"].split(",") if v != ""}
-                    if "PHX_LIK_SIDE_LEVELS" in os.environ else None)       # explicit set of chain levels for lane 1 (experiments)
-_LIK_SIDE = os.environ.get("PHX_LIK_SIDE", "1") == "1"        # two lanes: the likelihood's per-level chains share the prior's lane
-_WGRAD_DEFER_BLOCKS = int(os.environ.get("PHX_WGRAD_DEFER_BLOCKS", "96"))  # pixel-tile split target of a deferred layer (0: as when it runs alone; measured 48..128)
-_NREP = int(os.environ.get("PHX_NREP", "4"))      # accumulator replicas of the norm backward reduction (4: re-measured with the LDS-shared prologues; 8 before)
-_NORM_SMALL = os.environ.get("PHX_NORM_SMALL", "1") == "1"             # one-launch group / instance norm layers on maps <= 16 x 16 (A/B hook)
-_BIAS_GRAD_FUSED = os.environ.get("PHX_BIAS_GRAD_FUSED", "1") == "1"   # group / instance norm: conv-bias gradient in closed form (A/B hook)
-_NREP_MINP = int(os.environ.get("PHX_NREP_MINP", "4096"))
-_WGRAD_DEFER_SMALL = os.environ.get("PHX_WGRAD_DEFER_SMALL", "1") == "1"   # small-map filter-gradient launches deferred too
-_WGRAD_MULTI = os.environ.get("PHX_WGRAD_MULTI", "1") == "1"   # one reduction launch for all layers' partial filter gradients
-_EARLY_TOUCH = os.environ.get("PHX_EARLY_TOUCH", "1") == "1"
-_STAMPS = os.environ.get("PHX_STAMPS", "0") == "1"
-_BN_SPLITK = os.environ.get("PHX_BN_SPLITK", "0") == "1"   # small batch norm consumes the split-K slices of its convolution (measured 0.5 % slower: off)
+_LIK_SIDE_MAXLVL = 3
+_WGRAD_DEFER_BLOCKS = 96      # pixel-tile split target of a deferred layer (measured 16 .. 192: fewer slices are long tail blocks)
+_NREP = 4                     # accumulator replicas of the norm backward reduction (re-measured with the LDS-shared prologues; 8 before)
+_NREP_MINP = 4096
+_STAMPS = os.environ.get("PHX_STAMPS", "0") == "1"           # dev: per-operator device time stamps (tools/lane_timeline.py)
 _DETERMINISTIC = os.environ.get("PHX_DETERMINISTIC", "0") not in ("0", "")   # fixed summation orders everywhere (libphx reads the same variable)
-_BN_SMALL = int(os.environ.get("PHX_BN_SMALL", "1024"))     # one-launch batch norm up to this many pixels (0: off)
-# large-map batch norm: accumulator replicas of the conv epilogue's atomic statistics (phx_conv3x3_mfma_bf16_stats_rep ->
-# phx_norm_apply_fused_rep; 1 = per-tile partial rows + phx_norm_reduce_partials).  OFF: with 32 replicas the step has 42 launches fewer
-# (971 -> 929) and is 2 % SLOWER (11.37 -> 11.60 ms, two A/B pairs): 2 048 - 4 096 blocks x 64 - 128 atomics land on 4 cache lines per
-# replica, and fp32 atomics on ONE line retire serially (~45 ns each) -- the tail of every large-map convolution waits for them
-_STATS_REP = int(os.environ.get("PHX_STATS_REP", "1"))
-# conv -> norm -> act -> conv edges: the consumer convolution finalises the producer's normalisation in its prologue, applies it while
-# staging and materialises a as a side effect (phx_conv3x3_mfma_bf16_xf) -- no stand-alone apply pass, no launch for it.  PHX_XF=1
-# turns it on (read when a plan is built).  OFF by default -- measured on MI355X (round 3, phiseg_7_5 B = 64): 39 of the 106
-# normalisation layers qualify, launches 1063 -> 1024, apply passes 1.18 -> 0.73 ms, but the step gets SLOWER (11.94 -> 12.82 ms):
-# the transform is ~7 VALU instructions per two elements INSIDE the convolution's staging phase (redone by every channel block of a
-# pixel tile and for the halo), where nothing overlaps it: 32 -> 32 @ 128 x 128 takes 75 us fused against 39 + 24 us (convolution +
-# apply pass at 5.5 TB/s), 128 -> 128 @ 128 x 128 0.64 ms against 0.31 + 0.09, 192 -> 192 @ 8 x 8 34 us against 15 + 9.
-_NORM_HEAD = os.environ.get("PHX_NORM_HEAD", "1") == "1"     # a 1x1 head that is the only reader of act(norm(conv)) rides on the apply pass; its data gradient is formed on the fly in the norm backward passes (A/B hook)
-# small maps, batch norm in training mode: convolution + statistics + normalisation + activation in ONE launch (phx_conv3x3_mfma_bf16_fbn:
-# the blocks meet at an arrival counter inside the launch) for layers of up to PHX_FBN_MAXP pixels (B * H * W); 0: off (A/B hook)
-def _fbn_maxp():
-    # OFF by default (0).  Measured with PHX_FBN_MAXP=4096 (the H <= 8 levels, 43 layers): 43 plan entries / ~90 kernel launches fewer
-    # and the same step time (5 991 / 5 996 vs 5 992 / 5 977 images/s, same box) -- but every fused launch carries its layer's
-    # statistics, rendezvous and normalisation pass, so bench.py's convolution family (forward + data-gradient launches timed alone)
-    # would grow by 0.19 - 0.34 ms for no gain in the step (fraction of the MFMA peak 0.247 - 0.251 against 0.260 - 0.264).
-    return int(os.environ.get("PHX_FBN_MAXP", "0"))      # (read when a plan is built)
-
-
-def _bn_mid_maxp():
-    # batch-norm backward in one launch (phx_bn_mid_bwd) up to this many pixels; 0: off.  Measured (step time, same box): 4 096 (the
-    # 8 x 8 level) 10.86 vs 10.88 ms with 18 launches fewer; 16 384: 11.05 (the 192 x 1 024-thread launch with its 16-wave block
-    # reductions and the rendezvous is slower than two streaming launches); 65 536: 12.1 ms and rendezvous time-outs beside the
-    # other lane's launches -- the one-launch form pays only where a layer is a handful of blocks
-    return int(os.environ.get("PHX_BN_MID_MAXP", "4096"))
+_BN_SMALL = 1024              # one-launch batch norm up to this many pixels
 
 
 def _fgn_mode():
@@ -95,18 +46,8 @@ def _fgn_mode():
     return int(os.environ.get("PHX_FGN", "1"))
 
 
-def _fbn_maxk():
-    return int(os.environ.get("PHX_FBN_MAXK", str(1 << 20)))      # ... and at most this many input channels (experiments)
 def _dual_enabled():
     return os.environ.get("PHX_DUAL", "1") == "1"      # concat -> conv3x3 edges without the concatenated tensor (A/B hook; read when a plan is built)
-_LATENT_FUSED = os.environ.get("PHX_LATENT_FUSED", "1") == "1"     # mu / sigma heads + reparameterisation of a level in one launch each way (A/B hook)
-
-
-def _xf_enabled():
-    return os.environ.get("PHX_XF", "0") == "1"
-
-
-_XF_MAXP = int(os.environ.get("PHX_XF_MAXP", str(1 << 30)))     # largest map (B * H * W) whose edges are fused (experiments)
 
 
 def _noop():
@@ -333,8 +274,6 @@ class Plan:
         self._lanes = []
         if n_lanes is None:
             n_lanes = int(os.environ.get("PHX_LANES", "2"))
-            if _DEFER_LANE2 and n_lanes == 2 and loss is not None:
-                n_lanes = 3                       # experiment: a third stream that only carries the likelihood's deferred launches
         if stream is None:
             for _ in range(max(1, int(n_lanes))):
                 st = ctypes.c_void_p()
@@ -398,7 +337,7 @@ class Plan:
             # nothing but a graph edge (~3 us each in the replayed hipGraph)
             lst, pos = self._ev_order.get(evl[0].value, (None, -1))
             key = (self._lane, evl[1], lst)
-            if pos >= 0 and self._waited.get(key, -1) >= pos and os.environ.get("PHX_DEDUP_WAITS", "1") == "1":
+            if pos >= 0 and self._waited.get(key, -1) >= pos:
                 return
             self._waited[key] = pos
             self._cur.append((self.L.stream_wait_event, (self.stream, evl[0])))
@@ -421,14 +360,14 @@ class Plan:
             self._emit(self.L.stamp, self._stamp_buf.data_ptr() + 8 * (self._stamp_i + 1), self.stream)
             self.stamps.append((phase, op.name, self._lane, self._stamp_i))
 
-    def _emit_deferred(self, polite=False):
+    def _emit_deferred(self):
         """Launch everything the backward pass has deferred so far (filter gradients of the small / mid-size maps, the sums
         over partial filters, padded-filter folds, head filter gradients) on the current lane, and clear the lists."""
         for variant, grp in sorted(self._wgm_jobs.items()):
             desc = torch.frombuffer(bytearray(b"".join(grp["recs"])), dtype=torch.uint8).to(_device())
             self._keep.append(desc)
             self._emit(self.L.conv3x3_wgrad_multi, desc.data_ptr(), len(grp["recs"]), grp["blocks"], variant,
-                       max(grp["lds"], _POLITE_LDS) if polite else grp["lds"], self.stream)
+                       grp["lds"], self.stream)
         if self._wgr_jobs:
             rec = np.zeros(len(self._wgr_jobs), dtype=[("ws", "<u8"), ("dw", "<u8"), ("nslice", "<i4"), ("cin", "<i4"), ("cout", "<i4"),
                                                        ("tci", "<i4"), ("tco", "<i4"), ("gx", "<i4"), ("gy", "<i4"), ("blk0", "<i4")])
@@ -458,8 +397,6 @@ class Plan:
         """Every gradient contribution records an event in case another lane folds it in; most are consumed on the lane
         that produced them and nobody waits.  An unwaited record is still a node of the captured graph (214 records against
         60 waits in the PHiSeg training plan): replace those by no-ops -- the launch list keeps its indices."""
-        if os.environ.get("PHX_PRUNE_EVENTS", "1") == "0":
-            return
         for lst in (self.launches, self.opt_launches):
             waited = {a[1].value for f, a in lst if f is self.L.stream_wait_event}
             for i, (f, a) in enumerate(lst):
@@ -472,23 +409,17 @@ class Plan:
         cross-lane dependency then has lane 0 on one side: on ROCm 7.2 an event wait between two NON-origin streams of a
         multi-stream capture makes hipStreamEndCapture segfault (found by bisecting the launch list)."""
         n = len(self._lanes)
-        if _DEFER_LANE2 and n == 3:
-            n = 2                                 # (the third stream is not part of the operator lane plan)
         if n == 1:
             return 0
         name = op.name
         if name.startswith("prior/"):
             return 1
-        if n == 2 and op.type == "kl" and _KL_SIDE:
-            return 1          # the KL terms need the posterior's and the prior's outputs only: off lane 0's likelihood -> loss chain
-        if (n >= 3 or _LIK_SIDE) and name.startswith("likelihood/"):
+        if name.startswith("likelihood/"):
             import re
             m = re.match(r"likelihood/(?:z(\d+)_post_|preups_(\d+)/)", name)
             if m:
                 lvl = int(m.group(1) or m.group(2))
                 if n == 2:
-                    if _LIK_SIDE_LEVELS is not None:
-                        return 1 if lvl in _LIK_SIDE_LEVELS else 0
                     return 1 if lvl <= _LIK_SIDE_MAXLVL else 0
                 return 2 + lvl % (n - 2)
         return 0
@@ -537,27 +468,11 @@ class Plan:
             want.add(op)
             stack.extend(i.op for i in op.inputs)
         ops = [op for op in self.graph.ops if op in want]
-        return self._coarse_first(ops) if _LIK_COARSE_FIRST else ops
+        return self._coarse_first(ops)
 
     def _backward_order(self, ops, opset):
-        """Emission order of the backward pass: the reverse of the forward order, optionally (PHX_PRIOR_BW_FIRST=1) with the
-        prior's backward -- which depends on the KL terms only -- in front of the likelihood's instead of behind it."""
-        bw = list(reversed(ops))
-        if not _PRIOR_BW_FIRST:
-            return bw
-        prior = [op for op in bw if op.name.startswith("prior/")]
-        rest = [op for op in bw if not op.name.startswith("prior/")]
-        k = next((i for i, op in enumerate(rest) if op.name.startswith("likelihood/")), None)
-        if not prior or k is None:
-            return bw
-        new = rest[:k] + prior + rest[k:]
-        pos = {op: i for i, op in enumerate(new)}
-        for op in new:                                         # every consumer's backward must come first
-            for o in op.outputs:
-                for c in o.consumers:
-                    if c in opset and pos[c] > pos[op]:
-                        return bw
-        return new
+        """Emission order of the backward pass: the reverse of the forward order."""
+        return list(reversed(ops))
 
     @staticmethod
     def _coarse_first(ops):
@@ -612,10 +527,10 @@ class Plan:
         self.op_lane = {op: self._lane_of(op) for op in ops}
         opset = set(ops)
         self._opset = opset
-        self._lat = self._find_latent_heads(ops) if _LATENT_FUSED else {}     # op -> record of a fused (mu head, sigma head[, sample]) group
+        self._lat = self._find_latent_heads(ops)     # op -> record of a fused (mu head, sigma head[, sample]) group
         self._kl_group = None
         kls = [op for op in ops if op.type == "kl"]
-        if len(kls) >= 2 and len(kls) <= 8 and os.environ.get("PHX_KL_MULTI", "1") == "1":
+        if len(kls) >= 2 and len(kls) <= 8:
             ws = [self.loss_weight.get(op.outputs[0], 0.0) for op in kls]
             i0, i1 = ops.index(kls[0]), ops.index(kls[-1])
             between = [op for op in ops[i0:i1 + 1] if op.type != "kl"]
@@ -624,14 +539,12 @@ class Plan:
                     and not any(i.op in kls for b in between for i in b.inputs)):
                 self._kl_group = dict(ops=kls, recs=[], gscale=ws[0])
         self._bw_skip = set()
-        self._bws = {}                # producer conv op -> (partials, tiles): BN-backward sums fused into the consumer's dgrad
-        self._xf_pending = {}         # tensor a = act(norm(y)) whose apply pass was left to its (single) consumer convolution
         self._norm_head = {}          # 1x1 head op -> the conv unit whose apply pass computed it (phx_norm_apply_fused_head)
         fork = self._record(0) if nl > 1 else None          # lanes 1.. join the capture / wait for the memsets
         for ln in range(1, nl):
             self._lane = ln
             self._wait(fork)
-        if nl > 1 and _EARLY_TOUCH:
+        if nl > 1:
             # ROCm 7.2's graph executor starts a forked branch only when the origin stream first WAITS for it (measured with
             # PHX_STAMPS: the prior lane, ready at t = 0, begins after lane 0's whole forward, alone on the GPU).  With
             # lane 0 waiting right here for a token kernel at the head of every other lane, the prior encoder runs FIRST and
@@ -676,29 +589,7 @@ class Plan:
             # (Launching what the likelihood and the prior have deferred on the prior's lane as soon as their backward is
             # done, beside the posterior's backward chain, was measured 7 % slower than one batch after the join.)
             bw_ops = self._backward_order(ops, opset)
-            flushed = not (_DEFER_EARLY and nl > 1)
-            lane2_done = not (_DEFER_LANE2 and nl == 3)
             for op in bw_ops:
-                if not lane2_done and op.name.startswith("prior/"):
-                    # experiment (PHX_DEFER_LANE2=1): the likelihood's backward is complete here -- its deferred filter gradients go
-                    # to a third stream, beside the latency-bound prior / posterior backward chains (lane 2 only ever waits for lane 0)
-                    lane2_done = True
-                    ev1 = self._record(1)
-                    self._lane = 0
-                    self._wait(ev1)
-                    self._emit(_noop)
-                    ev0 = self._record(0)
-                    self._lane = 2
-                    self._wait(ev0)
-                    self._emit_deferred(polite=True)
-                if not flushed and op.name.startswith("posterior/"):
-                    # everything the likelihood and the prior have deferred goes to lane 1 now, beside the posterior's
-                    # latency-bound backward chain on lane 0 (their inputs are complete once lane 0 has reached this point)
-                    flushed = True
-                    ev0 = self._record(0)
-                    self._lane = 1
-                    self._wait(ev0)
-                    self._emit_deferred(polite=True)
                 if op in self._bw_skip:
                     continue                              # (its backward ran inside a fused group's launch)
                 if any(o in self.grad for o in op.outputs) or op.type in ("residual_ce", "kl", "l2_weights"):
@@ -994,7 +885,7 @@ class Plan:
         self._add_grad(x_t, write_fn=wr)
         for hop, gy in ((mu_op, gmu), (sig_op, gsig)):      # the two filter / bias gradients: leaves, one launch for all heads later
             W, b = hop.attrs["W"], hop.attrs["b"]
-            if _WGRAD_MULTI and cin % 8 == 0:
+            if cin % 8 == 0:
                 plan4 = (ctypes.c_int * 4)()
                 Lb.head1x1_wgrad_plan(npix, cin, zd, plan4)
                 self._headw_jobs.setdefault((x.dt, zd), []).append((x.ptr, gy.ptr, st.grad_ptr(W), st.grad_ptr(b), npix, cin, plan4[0],
@@ -1004,7 +895,7 @@ class Plan:
 
     def _norm_head_consumer(self, op):
         """The 1x1 head (bias, no norm, identity, fp32 out, 2 / 4 outputs) that is the ONLY reader of this unit's output, or None."""
-        if not _NORM_HEAD or self.act_dt != BF16:
+        if self.act_dt != BF16:
             return None
         out = op.outputs[0]
         if out in self.fetches:
@@ -1016,26 +907,6 @@ class Plan:
         if (ca.get("transposed") is not None or ca.get("general") is not None or ca["ksize"] != 1 or ca["norm"] is not None
                 or ca["b"] is None or ca["act"] != "identity" or c.inputs[0] is not out or c.outputs[0].kind != G.KIND_F32
                 or c.outputs[0] in self.fetches or self.op_lane.get(c) != self.op_lane.get(op)):
-            return None
-        return c
-
-    def _xf_consumer(self, op):
-        """The convolution unit that can take over the normalisation + activation of `op` (fused edge), or None: the ONLY reader of
-        a = act(norm(conv(x))) is a 3x3 convolution on the bf16 MFMA path with a multiple of 32 input channels."""
-        if not _xf_enabled() or self.act_dt != BF16:
-            return None
-        out = op.outputs[0]
-        if out in self.fetches:
-            return None
-        cons = self._real_consumers(out, self._opset)
-        if len(cons) != 1 or cons[0].type != "conv_unit":
-            return None
-        c = cons[0]
-        ca = c.attrs
-        if ca.get("transposed") is not None or ca.get("general") is not None or ca["ksize"] != 3 or c.inputs[0] is not out:
-            return None
-        cin, cout = ca["W"].shape[-2], ca["W"].shape[-1]
-        if cin % 32 != 0 or cout % 32 != 0 or self._dt_of(c.outputs[0]) != BF16:
             return None
         return c
 
@@ -1057,7 +928,6 @@ class Plan:
                 self._fw_latent_group(rec)
             return
         x = self.val[op.inputs[0]]
-        pend = self._xf_pending.pop(op.inputs[0], None)      # the producer left its normalisation to this convolution
         W, b = a["W"], a["b"]
         k, (_, _, cin, cout) = a["ksize"], W.shape
         B, H, Wd = x.shape[0], x.shape[1], x.shape[2]
@@ -1069,18 +939,14 @@ class Plan:
                 and cout % 32 == 0)
         S, Lb = self.stream, self.L
         dual = x if isinstance(x, DualBuf) else None
-        assert dual is None or (mfma and pend is None), "concat-free input reached a convolution off the MFMA path"
+        assert dual is None or mfma, "concat-free input reached a convolution off the MFMA path"
 
-        def cv(fn):
-            """fn, preceded by the one-shot dual-input modifier when this convolution reads a concat-free pair (one plan entry)"""
-            if dual is None:
-                return fn
-            x2p, k1 = dual.b.ptr, dual.k1
-
-            def call(*args):
-                Lb.conv3x3_next_dual_input(x2p, k1)
-                fn(*args)
-            return call
+        def mfma_conv(y, bias_p, oscale_p, act_code, stats, stats_mode, ws, wsb):
+            """One forward launch on the bf16 MFMA path (plain or concat-free input): phx_conv3x3_mfma_bf16_dual takes every option"""
+            self._emit(Lb.conv3x3_mfma_bf16_dual, x.ptr, dual.b.ptr if dual is not None else None, dual.k1 if dual is not None else 0,
+                       wf.ptr, y.ptr if y is not None else None, None, 0, bias_p, oscale_p, act_code,
+                       stats.ptr if stats is not None else None, stats_mode, ws.ptr if ws is not None else None, wsb,
+                       B, H, Wd, cin_eff, cout, S, tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
         cin_eff = cin
         # Convolutions the 3x3 MFMA kernels do not take as they are: input channels not a multiple of 32 (image Cin = 1 / 3,
         # latent Cin = 2, prob_unet2D's feature + z concat) are zero-padded, and 1x1 filters (prob_unet2D's recombination
@@ -1110,39 +976,18 @@ class Plan:
         head1x1 = (k == 1 and out.dt == F32 and cout in (2, 4, 6, 8) and a["norm"] is None and b is not None)
         st["head1x1"] = head1x1
 
-        if pend is not None and not (mfma and not padded and not head1x1 and x.dt == BF16):
-            # (not reached with the shapes _xf_consumer admits) the normalisation is applied by its own launch after all
-            self._emit(Lb.norm_apply_fused_rep, *pend["apply_args"], S)
-            pend = None
-        xf = pend is not None
-
         def tiles_fn():
-            return int(Lb.conv3x3_xf_tiles(B, H, Wd)) if xf else int(Lb.conv3x3_mfma_bf16_tiles(B, H, Wd, cin_eff, cout))
+            return int(Lb.conv3x3_mfma_bf16_tiles(B, H, Wd, cin_eff, cout))
 
         def conv_into(y, act_code, stats_direct=None, stats_part=None, stats_atomic=None):
-            if xf:
-                st_buf = stats_atomic if stats_atomic is not None else stats_part
-                wsb = int(Lb.conv3x3_xf_ws_bytes(B, H, Wd, cin_eff, cout)) if st_buf is None else 0
-                ws = self._alloc((wsb // 4,), F32) if wsb else None
-                d = pend
-                self._emit(Lb.conv3x3_mfma_bf16_xf, d["y"].ptr, wf.ptr, y.ptr, bptr, act_code, st_buf.ptr if st_buf is not None else None,
-                           1 if stats_atomic is not None else 0, ws.ptr if ws else None, wsb, B, H, Wd, cin_eff, cout,
-                           d["sums"].ptr, d["pivot"].ptr if d["pivot"] is not None else None, d["gamma"], d["beta"], d["eps"], d["nrep"],
-                           d["NS"], d["G"], d["act"], x.ptr, d["mean"].ptr, d["rstd"].ptr, d["scale"].ptr, d["shift"].ptr,
-                           d["mm"], d["mv"], d["mom"], S, tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd,
-                           shape=("xf", B, H, Wd, cin_eff, cout))
-            elif stats_atomic is not None:
-                self._emit(cv(Lb.conv3x3_mfma_bf16_stats_atomic), x.ptr, wf.ptr, y.ptr, bptr, act_code, stats_atomic.ptr, B, H, Wd, cin_eff,
-                           cout, S, tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
+            if stats_atomic is not None:
+                mfma_conv(y, bptr, None, act_code, stats_atomic, 2, None, 0)
             elif head1x1:
                 self._emit(Lb.head1x1_fwd, x.ptr, x.dt, wptr, bptr, y.ptr, B * H * Wd, cin, cout, act_code, S)
             elif mfma:
                 wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cin_eff, cout)) if stats_part is None else 0
                 ws = self._alloc((wsb // 4,), F32) if wsb else None          # split-K slices (small maps)
-                self._emit(cv(Lb.conv3x3_mfma_bf16_ws), x.ptr, wf.ptr, y.ptr, bptr, act_code,
-                           stats_part.ptr if stats_part is not None else None, ws.ptr if ws else None, wsb,
-                           B, H, Wd, cin_eff, cout, S,
-                           tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
+                mfma_conv(y, bptr, None, act_code, stats_part, 1 if stats_part is not None else 0, ws, wsb)
             else:
                 self._emit(Lb.conv2d_direct, x.ptr, x.dt, wptr, bptr, y.ptr, y.dt, B, H, Wd, cin, cout, k, act_code,
                            0, stats_direct.ptr if stats_direct is not None else None, S)
@@ -1163,7 +1008,7 @@ class Plan:
         scale, shift = self._alloc((NS * cout,), F32), self._alloc((NS * cout,), F32)
         mean, rstd = self._alloc((NS * Gn,), F32), self._alloc((NS * Gn,), F32)
         eps = tfnorm.EPS[norm]
-        if norm == "batch" and not training and mfma and not head1x1 and not bw and not xf and os.environ.get("PHX_BN_FOLD", "1") == "1":
+        if norm == "batch" and not training and mfma and not head1x1 and not bw:
             # inference-mode batch norm + activation folded into the convolution's epilogue (phx_conv3x3_mfma_bf16_affine):
             # one launch where the reference runs conv2d, batch_norm and relu; the scale / shift vectors of all layers come
             # from one launch at the head of the run
@@ -1171,8 +1016,7 @@ class Plan:
                                        scale.ptr, shift.ptr, cout, eps))
             wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cin_eff, cout))
             ws = self._alloc((wsb // 4,), F32) if wsb else None
-            self._emit(cv(Lb.conv3x3_mfma_bf16_affine), x.ptr, wf.ptr, out.ptr, scale.ptr, shift.ptr, act, ws.ptr if ws else None, wsb,
-                       B, H, Wd, cin_eff, cout, S, tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
+            mfma_conv(out, shift.ptr, scale.ptr, act, None, 0, ws, wsb)
             st.update(scale=scale, shift=shift, NS=NS, P=P, G=Gn)
             self.saved[op] = st
             return
@@ -1182,21 +1026,6 @@ class Plan:
             conv_into(y, 0)
             self._emit(Lb.affine_act, y.ptr, y.dt, scale.ptr, shift.ptr, out.ptr, out.dt, NS, P, cout, act, S)
         else:
-            if (norm == "batch" and training and mfma and not head1x1 and not xf and P <= _fbn_maxp() and cin_eff <= _fbn_maxk() and not _DETERMINISTIC
-                    and y.dt == BF16 and out.dt == BF16 and x.dt == BF16 and Lb.conv3x3_fbn_supported(B, H, Wd, cin_eff, cout)):
-                # small maps: convolution, batch statistics, normalisation and activation in one launch
-                upd = self.loss is not None
-                acc = self._alloc_zeroed(cout * 2 + (cout // 32 + 3) // 4 * 4)        # sums[N][2] | arrival counters
-                self._has_rendezvous = True
-                self._emit(cv(Lb.conv3x3_mfma_bf16_fbn), x.ptr, wf.ptr, y.ptr, out.ptr, acc.ptr, acc.ptr + cout * 8, gptr, beptr, eps,
-                           mean.ptr, rstd.ptr, scale.ptr, shift.ptr,
-                           self.store.ptr(nv["moving_mean"]) if upd else None, self.store.ptr(nv["moving_variance"]) if upd else None,
-                           (1.0 - tfnorm.BN_DECAY) if upd else 0.0, act, B, H, Wd, cin_eff, cout, S,
-                           tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd, shape=("fbn", B, H, Wd, cin_eff, cout))
-                st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn,
-                          bn_small=bool(P <= _BN_SMALL and Lb.bn_small_supported(P, cout, BF16)))
-                self.saved[op] = st
-                return
             # H <= 8 levels: the whole batch-norm layer in one launch (phx_bn_small_fwd / _bwd; csrc/elementwise.hip)
             # (policy P <= 1024, the H <= 4 levels: at P = 4096 the single launch measured no faster than the chain)
             bn_small = (norm == "batch" and y.dt == BF16 and out.dt == BF16 and P <= _BN_SMALL
@@ -1206,24 +1035,14 @@ class Plan:
                 mm = self.store.ptr(nv["moving_mean"]) if upd else None
                 mv = self.store.ptr(nv["moving_variance"]) if upd else None
                 mom = (1.0 - tfnorm.BN_DECAY) if upd else 0.0
-                ks = int(Lb.conv3x3_mfma_ksplit(B, H, Wd, cin_eff, cout)) if (mfma and not head1x1 and _BN_SPLITK and not xf) else 1
-                if ks > 1:        # split-K convolution: its fp32 slices go straight into the norm kernel (no finishing launch)
-                    wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cin_eff, cout))
-                    ws = self._alloc((wsb // 4,), F32)
-                    self._emit(cv(Lb.conv3x3_mfma_bf16_ws), x.ptr, wf.ptr, None, None, 0, None, ws.ptr, wsb, B, H, Wd, cin_eff,
-                               cout, S, tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
-                    self._emit(Lb.bn_small_fwd_splitk, ws.ptr, ks, y.ptr, gptr, beptr, eps, out.ptr, mean.ptr, rstd.ptr,
-                               scale.ptr, shift.ptr, mm, mv, mom, P, cout, act, S,
-                               tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
-                else:
-                    conv_into(y, 0)
-                    self._emit(Lb.bn_small_fwd, y.ptr, gptr, beptr, eps, out.ptr, mean.ptr, rstd.ptr, scale.ptr, shift.ptr,
-                               mm, mv, mom, P, cout, act, S,
-                               tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
+                conv_into(y, 0)
+                self._emit(Lb.bn_small_fwd, y.ptr, gptr, beptr, eps, out.ptr, mean.ptr, rstd.ptr, scale.ptr, shift.ptr,
+                           mm, mv, mom, P, cout, act, S,
+                           tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
                 st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn, bn_small=True)
                 self.saved[op] = st
                 return
-            if (norm != "batch" and mfma and not head1x1 and not xf and dual is None and not _DETERMINISTIC and (_fgn_mode() >= 2 or (_fgn_mode() == 1 and Gn != cout)) and y.dt == BF16 and out.dt == BF16
+            if (norm != "batch" and mfma and not head1x1 and dual is None and not _DETERMINISTIC and (_fgn_mode() >= 2 or (_fgn_mode() == 1 and Gn != cout)) and y.dt == BF16 and out.dt == BF16
                     and x.dt == BF16 and Lb.conv3x3_fgn_supported(B, H, Wd, cin_eff, cout, Gn)
                     and Lb.norm_small_supported(NS, P, cout, Gn, BF16)):
                 # maps of at most 16 x 16: convolution, bias, group / instance norm and activation in ONE launch (a block holds whole
@@ -1236,22 +1055,12 @@ class Plan:
                 return
             # group / instance norm on maps of up to 256 pixels: the whole layer in one launch as well (phx_norm_small_fwd / _bwd: a
             # wave per (sample, 16-channel slice)); a split-K convolution hands over its slices and its bias
-            if (norm != "batch" and _NORM_SMALL and y.dt == BF16 and out.dt == BF16
+            if (norm != "batch" and y.dt == BF16 and out.dt == BF16
                     and Lb.norm_small_supported(NS, P, cout, Gn, BF16)):
-                ks = int(Lb.conv3x3_mfma_ksplit(B, H, Wd, cin_eff, cout)) if (mfma and not head1x1 and _BN_SPLITK and not xf) else 1
-                if ks > 1:
-                    wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cin_eff, cout))
-                    ws = self._alloc((wsb // 4,), F32)
-                    self._emit(cv(Lb.conv3x3_mfma_bf16_ws), x.ptr, wf.ptr, None, None, 0, None, ws.ptr, wsb, B, H, Wd, cin_eff,
-                               cout, S, tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
-                    self._emit(Lb.norm_small_fwd, y.ptr, ws.ptr, ks, bptr, gptr, beptr, eps, out.ptr, mean.ptr, rstd.ptr,
-                               scale.ptr, shift.ptr, NS, P, cout, Gn, act, S,
-                               tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
-                else:
-                    conv_into(y, 0)
-                    self._emit(Lb.norm_small_fwd, y.ptr, None, 0, None, gptr, beptr, eps, out.ptr, mean.ptr, rstd.ptr,
-                               scale.ptr, shift.ptr, NS, P, cout, Gn, act, S,
-                               tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
+                conv_into(y, 0)
+                self._emit(Lb.norm_small_fwd, y.ptr, None, 0, None, gptr, beptr, eps, out.ptr, mean.ptr, rstd.ptr,
+                           scale.ptr, shift.ptr, NS, P, cout, Gn, act, S,
+                           tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
                 st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn, norm_small=True)
                 self.saved[op] = st
                 return
@@ -1261,24 +1070,16 @@ class Plan:
             # a statistic has few samples (cheap there); otherwise the sums come from the conv epilogue.
             small = P <= 16384 or self.act_dt == F32
             nrep_fw = 1
-            if (norm == "batch" and mfma and not small and not xf and not head1x1 and _STATS_REP > 1 and not _DETERMINISTIC
-                    and Lb.conv3x3_mfma_stats_rep_supported(B, H, Wd, cin_eff, cout)):
-                # many pixel tiles (the 32 x 32 .. 128 x 128 levels): the convolution adds its statistics atomically into _STATS_REP
-                # accumulator replicas, the apply pass sums them in its prologue -- no partial rows, no reduction launch in between
-                nrep_fw = _STATS_REP
-                sums = self._alloc_zeroed(nrep_fw * cout * 2)
-                self._emit(cv(Lb.conv3x3_mfma_bf16_stats_rep), x.ptr, wf.ptr, y.ptr, bptr, 0, sums.ptr, nrep_fw, B, H, Wd, cin_eff, cout, S,
-                           tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
-            elif norm == "batch" and mfma and not small:
+            if norm == "batch" and mfma and not small:
                 ntile = tiles_fn()
                 part = self._alloc((ntile * 2 * cout,), F32)
                 conv_into(y, 0, stats_part=part)
                 self._emit(Lb.norm_reduce_partials, part.ptr, ntile, cout, sums.ptr, S)
-            elif (norm == "batch" and mfma and small and _STATS_ATOMIC and not _DETERMINISTIC and not head1x1 and self.act_dt == BF16
-                  and (tiles_fn() <= 64 if xf else Lb.conv3x3_mfma_stats_atomic_supported(B, H, Wd, cin_eff, cout))):
+            elif (norm == "batch" and mfma and small and not _DETERMINISTIC and not head1x1 and self.act_dt == BF16
+                  and Lb.conv3x3_mfma_stats_atomic_supported(B, H, Wd, cin_eff, cout)):
                 # few pixel tiles (the H <= 16 levels): the convolution adds its statistics straight into `sums` -- no pass over y
                 conv_into(y, 0, stats_atomic=sums)
-            elif (norm != "batch" and mfma and _GN_STATS_EPILOGUE and not head1x1 and self.act_dt == BF16 and H % 16 == 0 and Wd % 16 == 0
+            elif (norm != "batch" and mfma and not head1x1 and self.act_dt == BF16 and H % 16 == 0 and Wd % 16 == 0
                   and tiles_fn() % B == 0):
                 # group / instance norm on maps of at least 16 x 16: a pixel tile lies inside one sample, so the convolution's per-tile
                 # sums reduce to per-sample sums without another pass over y (phx_norm_reduce_partials_ns)
@@ -1298,14 +1099,7 @@ class Plan:
             mom = (1.0 - tfnorm.BN_DECAY) if upd else 0.0
             apply_args = (y.ptr, y.dt, sums.ptr, nrep_fw, pivot.ptr if pivot is not None else None, gptr, beptr, eps, out.ptr, out.dt,
                           mean.ptr, rstd.ptr, scale.ptr, shift.ptr, mmp, mvp, mom, NS, P, cout, Gn, act)
-            cons = self._xf_consumer(op) if (mfma and y.dt == BF16 and out.dt == BF16 and B * H * Wd <= _XF_MAXP) else None
-            if cons is not None and Lb.conv3x3_xf_supported(B, H, Wd, cout, cons.attrs["W"].shape[-1], NS):
-                # fused edge: the consumer convolution finalises these statistics, applies act(y * scale + shift) while it stages
-                # its input and writes a (= out) as a side effect
-                self._xf_pending[op.outputs[0]] = dict(y=y, sums=sums, nrep=nrep_fw, pivot=pivot, gamma=gptr, beta=beptr, eps=eps, NS=NS, G=Gn, act=act,
-                                                       mean=mean, rstd=rstd, scale=scale, shift=shift, mm=mmp, mv=mvp, mom=mom,
-                                                       apply_args=apply_args)
-            else:
+            if True:
                 hop = self._norm_head_consumer(op) if (y.dt == BF16 and out.dt == BF16) else None
                 if hop is not None and Lb.norm_head_supported(cout, hop.attrs["W"].shape[-1], y.dt, out.dt):
                     # the head rides on the apply pass (phx_norm_apply_fused_head): no pass of its own over a
@@ -1571,7 +1365,7 @@ class Plan:
         the contributing kernel has an accumulating form (no buffer of its own, no add pass), else by phx_add_inplace."""
         if not self.req.get(t, False):
             return
-        if accum_fn is not None and t in self.grad and os.environ.get("PHX_GRAD_ACCUM", "1") == "1":
+        if accum_fn is not None and t in self.grad:
             g = self.grad[t]
             own = [evl for b, evl in self.pending.get(t, []) if b is g]
             # (only behind contributions of THIS lane: waiting here for another lane's write would tie the two backward chains
@@ -1619,8 +1413,6 @@ class Plan:
             g = self.grad[t]
             if buf is not g:
                 assert g.dt == buf.dt and g.n == buf.n
-                if os.environ.get("PHX_DEBUG_ADDS"):
-                    print("add_inplace", t.op.name, g.shape, [c.name for c in t.consumers if c in self._opset], getattr(self, "_cur_bw_op", None) and self._cur_bw_op.name)
                 self._emit(self.L.add_inplace, g.ptr, buf.ptr, g.n, g.dt, self.stream)
 
     def _bw_placeholder(self, op):
@@ -1796,30 +1588,15 @@ class Plan:
                            NS, P, cout, Gn, act, S,
                            tag="bytes_norm_bwd_apply", flops=float(dA.nbytes + y.nbytes + dY.nbytes))
                 db_done = True
-            elif (sv["norm"] == "batch" and isinstance(dA, Buf) and dA.dt == BF16 and y.dt == BF16 and op not in self._bws
-                  and P <= _bn_mid_maxp() and not _DETERMINISTIC and Lb.bn_mid_supported(P, cout, BF16)):
-                # mid-size maps: reduction + apply in ONE launch (phx_bn_mid_bwd: the blocks of a channel slice meet inside the launch)
-                dY = self._alloc(y.shape, y.dt)
-                acc = self._alloc_zeroed(cout * 2 + (cout // 16 + 3) // 4 * 4)          # sums2[C][2] | arrival counters
-                self._has_rendezvous = True
-                self._emit(Lb.bn_mid_bwd, dA.ptr, y.ptr, sv["scale"].ptr, sv["shift"].ptr, sv["mean"].ptr, sv["rstd"].ptr,
-                           self.store.ptr(nv["gamma"]), dY.ptr, self.store.grad_ptr(nv["gamma"]), self.store.grad_ptr(nv["beta"]),
-                           acc.ptr, acc.ptr + cout * 8, P, cout, act, S,
-                           tag="bytes_norm_bwd_apply", flops=float(dA.nbytes + y.nbytes + dY.nbytes))
             else:
                 nrep = _NREP if P >= _NREP_MINP else 1   # replicated accumulators: see k_norm_bwd_reduce
                 if _DETERMINISTIC and P >= _NREP_MINP:
                     nrep = 64                             # one block per replica there: more replicas = more blocks
-                fused = self._bws.pop(op, None)        # the consumer's data-gradient launch already produced the sums
-                if fused is not None:
-                    nrep = 1
                 sums2 = self._alloc_zeroed(nrep * NS * cout * 2)
                 Sg = self._alloc((NS * Gn * 2,), F32)
                 dY = self._alloc(y.shape, y.dt)
                 hg = dA if isinstance(dA, HeadGrad) else None
-                if fused is not None:
-                    self._emit(Lb.norm_reduce_partials, fused[0].ptr, fused[1], cout, sums2.ptr, S)
-                elif hg is not None:
+                if hg is not None:
                     self._emit(Lb.norm_bwd_reduce_head, hg.dy.ptr, hg.w_ptr, hg.nout, y.ptr, sv["scale"].ptr, sv["shift"].ptr,
                                sv["mean"].ptr, sv["rstd"].ptr, sums2.ptr, NS, P, cout, Gn, act, nrep, S,
                                tag="bytes_norm_bwd_reduce", flops=float(y.nbytes))
@@ -1829,7 +1606,7 @@ class Plan:
                                tag="bytes_norm_bwd_reduce", flops=float(dA.nbytes + y.nbytes))
                 # group / instance norm keep the convolution bias: its gradient (the per-channel sum of dY) comes out of this
                 # launch in closed form instead of a pass over dY (phx_norm_bwd_apply_fused_bias)
-                fs = sv.get("fsums") if (b is not None and _BIAS_GRAD_FUSED) else None
+                fs = sv.get("fsums") if b is not None else None
                 if fs is not None:
                     db_done = True
                 if hg is not None:
@@ -1879,7 +1656,7 @@ class Plan:
         # (The filter gradient is a leaf of the backward graph; moving these launches to another lane, beside the data-
         # gradient chain, was measured 20 % SLOWER: both are bound by the same global->LDS path, so the kernel on the
         # critical path just gets half of it.)
-        if sv.get("head1x1") and _WGRAD_MULTI and cin % 8 == 0 and db is not None:
+        if sv.get("head1x1") and cin % 8 == 0 and db is not None:
             # a leaf of the backward graph: all heads share one launch after the lanes have joined (phx_head1x1_wgrad_multi)
             plan4 = (ctypes.c_int * 4)()
             Lb.head1x1_wgrad_plan(B * H * Wd, cin, cout, plan4)
@@ -1904,7 +1681,7 @@ class Plan:
             dargs = (x.ptr, dual.b.ptr if dual is not None else None, k1d) + wargs[1:]      # (x, x2, K1, dy, ...)
             wflops = 18.0 * cin * cout * B * H * Wd
             deferred = False
-            if _WGRAD_MULTI and _WGRAD_DEFER_SMALL:
+            if True:
                 # The filter gradients are leaves of the backward graph.  Small and mid-size maps: the launch itself is
                 # deferred -- one launch per kernel variant runs all such layers side by side after the lanes have joined
                 # (phx_conv3x3_wgrad_multi); their latency leaves the posterior / prior / likelihood chains.
@@ -1922,7 +1699,7 @@ class Plan:
                     deferred = True
             if deferred:
                 pass
-            elif _WGRAD_MULTI and plan6[0]:
+            elif plan6[0]:
                 # large maps: the launch stays here, only the sum over its partial filters is deferred to ONE launch for all
                 # layers (phx_wgrad_reduce_multi)
                 if dual is not None:
@@ -1953,12 +1730,8 @@ class Plan:
             g1, g2 = self._alloc(x.a.shape, BF16), self._alloc(x.b.shape, BF16)
             wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cout, cin))
             ws = self._alloc((wsb // 4,), F32) if wsb else None      # split-K slices (small maps)
-            g2p, k1 = g2.ptr, x.k1
-
-            def dgrad_dual(*args):
-                Lb.conv3x3_next_dual_output(g2p, k1)
-                Lb.conv3x3_mfma_bf16_ws(*args)
-            self._emit(dgrad_dual, dY.ptr, wd.ptr, g1.ptr, None, 0, None, ws.ptr if ws else None, wsb, B, H, Wd, cout, cin, S,
+            self._emit(Lb.conv3x3_mfma_bf16_dual, dY.ptr, None, 0, wd.ptr, g1.ptr, g2.ptr, x.k1, None, None, 0, None, 0,
+                       ws.ptr if ws else None, wsb, B, H, Wd, cout, cin, S,
                        tag="conv3x3_mfma_dgrad", flops=18.0 * cin * cout * B * H * Wd)
             for t, gb in ((ta, g1), (tb, g2)):
                 if self.req.get(t, False):
@@ -1986,33 +1759,7 @@ class Plan:
             elif sv["mfma"]:
                 _, wd = self._packed(W)
 
-                # Optional fusion (PHX_FUSE_BWS=1, off by default): when the ONLY consumer of a = relu(bn(y)) of a batch-norm
-                # producer is this convolution, the data-gradient epilogue can also emit the producer's batch-norm backward
-                # sums (phx_conv3x3_mfma_bf16_bwdstats) and the producer skips its phx_norm_bwd_reduce pass.  Measured on
-                # MI355X: 25 of the 106 layers qualify; the data-gradient launches get 0.65 ms/step slower (the extra y-tile
-                # loads hit the staging path that already bounds them) while the dropped reduce passes, which stream at
-                # 4.6 TB/s, only saved 0.51 ms -- a net loss of 1.3 %.
-                prod = xin.op
-                psv = self.saved.get(prod) if prod is not None else None
-                fuse = (psv is not None and prod.type == "conv_unit" and psv.get("norm") == "batch" and "y" in psv
-                        and "mean" in psv and psv.get("NS") == 1 and psv.get("G") == cin and xin is prod.outputs[0]
-                        and self.val[xin].dt == BF16 and psv["y"].dt == BF16
-                        and len(self._real_consumers(xin, self._opset)) == 1
-                        and os.environ.get("PHX_FUSE_BWS", "0") == "1"
-                        and B * H * Wd <= int(os.environ.get("PHX_FUSE_BWS_MAXP", str(1 << 30)))
-                        and B * H * Wd >= int(os.environ.get("PHX_FUSE_BWS_MINP", "0"))
-                        and bool(Lb.conv3x3_mfma_bwdstats_supported(B, H, Wd, cout, cin)))
-
                 def wr_mfma(g):
-                    if fuse:
-                        ntile = Lb.conv3x3_mfma_bf16_tiles(B, H, Wd, cout, cin)
-                        part2 = self._alloc((ntile * 2 * cin,), F32)
-                        self._emit(Lb.conv3x3_mfma_bf16_bwdstats, dY.ptr, wd.ptr, g.ptr, psv["y"].ptr, psv["scale"].ptr,
-                                   psv["shift"].ptr, psv["mean"].ptr, psv["rstd"].ptr, rt.ACT_CODES[prod.attrs["act"]],
-                                   part2.ptr, B, H, Wd, cout, cin, S,
-                                   tag="conv3x3_mfma_dgrad", flops=18.0 * cin * cout * B * H * Wd)
-                        self._bws[prod] = (part2, ntile)
-                        return
                     wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cout, cin))
                     ws = self._alloc((wsb // 4,), F32) if wsb else None      # split-K slices (small maps)
                     self._emit(Lb.conv3x3_mfma_bf16_ws, dY.ptr, wd.ptr, g.ptr, None, 0, None, ws.ptr if ws else None, wsb,
@@ -2124,21 +1871,8 @@ class Plan:
         self.L.event_destroy(ev1)
         return out
 
-    def _check_rendezvous(self):
-        if not getattr(self, "_has_rendezvous", False):       # (no launch of this plan meets inside a kernel)
-            return
-        n = ctypes.c_int(0)
-        self.L.conv3x3_fbn_timeouts(ctypes.byref(n))
-        m = ctypes.c_int(0)
-        self.L.bn_mid_timeouts(ctypes.byref(m))
-        n.value += m.value
-        if n.value:
-            raise rt.PhxError("%d block(s) of one-launch conv + batch-norm layers timed out at their rendezvous (the launch was not "
-                              "co-resident: another process on this GPU?) -- results are invalid; set PHX_FBN_MAXP=0 PHX_BN_MID_MAXP=0" % n.value)
-
     def fetch(self, t):
         self.sync()
-        self._check_rendezvous()
         b = self.val[t]
         a = b.numpy()
         if b.shift:                     # nearest-neighbour view (likelihoods.py:221): expand on the host

@@ -148,3 +148,23 @@ def test_native_rccl_allreduce_two_devices(tmp_path):
     ref = 2.0 * (a0 + a1)                                 # two all-reduces: x -> x0 + x1 -> 2 (x0 + x1)
     for rk in (0, 1):
         np.testing.assert_allclose(np.load(str(tmp_path / ("rank%d.npy" % rk))), ref, rtol=1e-6, atol=1e-6)
+
+
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` from a plain shell (no WORLD_SIZE): bench.py re-executes itself under torch.distributed.run with
+    two ranks (here both on the test box's one GPU, gloo carrying the exchange), rank 0 prints the one JSON line, and the line says
+    which transport the timed gradient exchange took and how many ranks took part (config.comm)."""
+    import json
+    env = dict(os.environ, PHX_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--batch", "4",
+           "--no-cpu-baseline", "--no-roofline", "--no-other-workloads"]
+    r = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["comm"] == {"path": "torch_gloo_host_staged", "ranks_seen": 2}
+    assert out["value"] > 0 and np.isfinite(out["config"]["final_loss"])

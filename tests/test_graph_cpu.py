@@ -99,27 +99,18 @@ def test_dropin_aliases():
     assert hasattr(utils, "generalised_energy_distance") and hasattr(utils, "variance_ncc_dist")
 
 
-def test_launch_plans_of_the_round3_kernels_host_side():
+def test_launch_plans_host_side():
     """Host-side plan queries of libphx (no GPU needed): which layers the one-launch kernels take at the benchmark's shapes, and
     that the concat-free filter gradient sizes its workspace for the tile split it will use."""
     import ctypes
     from phiseg_code_amd import runtime as rt
     L = rt.lib()
-    BF16 = 1
-    # conv + batch norm in one launch: every block must be resident -> small maps only (<= 192 blocks)
-    assert L.conv3x3_fbn_supported(64, 8, 8, 192, 192) in (32, 64)
-    assert L.conv3x3_fbn_supported(64, 2, 2, 192, 192) == 32
-    assert L.conv3x3_fbn_supported(64, 128, 128, 32, 32) == 0 and L.conv3x3_fbn_supported(64, 8, 8, 48, 192) == 0
     # conv + group / instance norm in one launch: maps that fit one pixel tile, 16-channel groups or per-channel statistics
     assert L.conv3x3_fgn_supported(64, 16, 16, 192, 192, 12) in (32, 64)
     assert L.conv3x3_fgn_supported(64, 4, 4, 64, 192, 192) in (32, 64)             # instance norm
     assert L.conv3x3_fgn_supported(64, 32, 32, 128, 128, 8) == 0                   # a sample spans several tiles
     assert L.conv3x3_fgn_supported(64, 8, 8, 192, 192, 6) == 0                     # 32-channel groups
     assert L.conv3x3_fgn_supported(64, 12, 12, 192, 192, 12) == 0                  # not a power of two
-    # batch-norm backward in one launch: (C / 16) x S blocks of 1 024 threads, at most 192
-    assert L.bn_mid_supported(4096, 192, BF16) in (1, 2, 4, 8)
-    assert L.bn_mid_supported(64 * 128 * 128, 128, BF16) == 0 and L.bn_mid_supported(4096, 24, BF16) == 0
-    assert L.bn_mid_supported(4096, 192, 0) == 0                                   # fp32 tensors take the two-launch path
     # concat-free filter gradient: K1 % 64 != 0 forces 32-channel input tiles -> more (smaller) partial filters, same total elements
     same = L.conv3x3_wgrad_ws_bytes_dual(64, 64, 64, 128, 192, 64)
     assert same == L.conv3x3_wgrad_ws_bytes(64, 64, 64, 128, 192)
@@ -128,6 +119,7 @@ def test_launch_plans_of_the_round3_kernels_host_side():
     L.conv3x3_wgrad_reduce_plan_dual(64, 128, 128, 64, 128, 32, plan_b)
     assert plan_a[2] == 64 and plan_b[2] == 32 and plan_a[3] == plan_b[3] == 64    # tci 64 -> 32, tco unchanged
     assert L.conv3x3_wgrad_ws_bytes_dual(64, 128, 128, 64, 128, 32) > 0
-    # bn-backward sums in the data-gradient epilogue: LDS-DMA shapes included, the 32 -> 32 persistent kernel excluded
-    assert L.conv3x3_mfma_bwdstats_supported(64, 128, 128, 128, 128) == 1
-    assert L.conv3x3_mfma_bwdstats_supported(64, 128, 128, 32, 32) == 0
+    # the large-map kernels count 16 x 32-pixel tiles, the 256-pixel kernel its own; atomic statistics only with few tiles
+    assert L.conv3x3_mfma_bf16_tiles(64, 128, 128, 128, 128) == 64 * 8 * 4
+    assert L.conv3x3_mfma_bf16_tiles(64, 16, 16, 192, 192) == 64
+    assert L.conv3x3_mfma_stats_atomic_supported(64, 16, 16, 192, 192) == 1 and L.conv3x3_mfma_stats_atomic_supported(64, 128, 128, 32, 32) == 0

@@ -26,6 +26,18 @@ def L():
     return rt.lib()
 
 
+@pytest.fixture
+def policy(L):
+    """Kernel-selection policy of the forward / data-gradient launches (phx_debug_conv_policy / phx_debug_pair_kernel_grid), restored
+    to the defaults afterwards: policy(large_maps, big_tiles, pair_grid)."""
+    def set_(large_maps=1, big_tiles=1, pair_grid=0):
+        L.debug_conv_policy(large_maps, big_tiles)
+        L.debug_pair_kernel_grid(pair_grid)
+    yield set_
+    L.debug_conv_policy(1, 1)
+    L.debug_pair_kernel_grid(0)
+
+
 def S():
     return torch.cuda.current_stream().cuda_stream
 
@@ -162,8 +174,8 @@ def test_conv3x3_mfma_fwd_dgrad_wgrad(L, case):
 
 # the 16 x 32-pixel-tile / 8-wave forward kernels (chosen by policy only for large maps): forced here on small ones
 @pytest.mark.parametrize("case", [(2, 32, 32, 64, 128), (1, 64, 32, 32, 32), (3, 32, 16, 96, 64), (1, 32, 48, 32, 256)])
-def test_conv3x3_mfma_big_tiles(L, case, monkeypatch):
-    monkeypatch.setenv("PHX_FWD_BIG", "2")
+def test_conv3x3_mfma_big_tiles(L, case, policy):
+    policy(big_tiles=2)
     _mfma_case(L, case)
 
 
@@ -207,44 +219,6 @@ def test_conv1x1_as_centre_tap(L, case):
     close(host(dw), wr.grad.numpy()[0, 0], 1e-4, "1x1 wgrad")
 
 
-@pytest.mark.parametrize("case", [(2, 32, 32, 64, 64), (1, 16, 48, 32, 192), (3, 64, 32, 128, 128), (40, 16, 16, 64, 96),
-                                  (2, 32, 32, 64, 64, "dma"), (1, 16, 64, 96, 32, "dma"), (3, 48, 32, 128, 128, "dma"), (2, 16, 32, 32, 96, "dma")])
-def test_dgrad_with_fused_bn_backward_statistics(L, case, monkeypatch):
-    """Data-gradient launch that also emits the producer layer's batch-norm backward sums: same dA as the plain launch,
-    and its reduced partials equal phx_norm_bwd_reduce run on that dA.  ("dma": the LDS-DMA 16 x 32-tile kernel's BWS instantiations)"""
-    if len(case) == 6:
-        monkeypatch.setenv("PHX_FWD_WS", "5")
-        monkeypatch.setenv("PHX_FWD_DB", "0")
-        case = case[:5]
-    B, H, W, K, N = case                       # K = channels of dy (consumer's Cout), N = channels of dA / y_prod
-    if case[1] % 32 == 0:
-        monkeypatch.setenv("PHX_FWD_BIG", "2")  # exercise the 16 x 32-tile kernels too
-    assert L.conv3x3_mfma_bwdstats_supported(B, H, W, K, N)
-    w = RNG.standard_normal((3, 3, N, K)) / np.sqrt(9 * N)
-    wd_ = dev(w)
-    wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
-    wg = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
-    L.pack_conv3x3_bf16(wd_.data_ptr(), wf.data_ptr(), wg.data_ptr(), N, K, S())
-    dy = dev(RNG.standard_normal((B, H, W, K)), BF16)
-    yp = dev(RNG.standard_normal((B, H, W, N)) * 1.3 + 0.2, BF16)
-    scale, shift = dev(1.0 + 0.2 * RNG.standard_normal(N)), dev(0.3 * RNG.standard_normal(N))
-    mean, rstd = dev(0.2 * RNG.standard_normal(N)), dev(0.8 + 0.3 * RNG.random(N))
-    dA1 = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
-    L.conv3x3_mfma_bf16(dy.data_ptr(), wg.data_ptr(), dA1.data_ptr(), None, 0, None, B, H, W, K, N, S())
-    sums_ref = torch.zeros(N, 2, dtype=torch.float32).cuda()
-    L.norm_bwd_reduce(dA1.data_ptr(), BF16, yp.data_ptr(), BF16, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
-                      rstd.data_ptr(), sums_ref.data_ptr(), 1, B * H * W, N, N, 1, 1, S())
-    ntile = L.conv3x3_mfma_bf16_tiles(B, H, W, K, N)
-    part = torch.zeros(ntile, 2, N, dtype=torch.float32).cuda()
-    dA2 = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
-    L.conv3x3_mfma_bf16_bwdstats(dy.data_ptr(), wg.data_ptr(), dA2.data_ptr(), yp.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                 mean.data_ptr(), rstd.data_ptr(), 1, part.data_ptr(), B, H, W, K, N, S())
-    assert torch.equal(dA1, dA2)
-    sums = torch.zeros(N, 2, dtype=torch.float32).cuda()
-    L.norm_reduce_partials(part.data_ptr(), ntile, N, sums.data_ptr(), S())
-    close(host(sums), host(sums_ref), 2e-5, "fused bn-backward sums")
-
-
 @pytest.mark.parametrize("case", [(64, 8, 8, 192, 192), (64, 16, 16, 64, 96), (3, 8, 8, 32, 32), (9, 4, 4, 64, 64), (64, 16, 16, 384, 192)])
 def test_conv3x3_mfma_statistics_by_atomics(L, case):
     """phx_conv3x3_mfma_bf16_stats_atomic: the convolution of a layer with few pixel tiles adds {sum y, sum y^2} of its (bf16-rounded)
@@ -272,28 +246,6 @@ def test_conv3x3_mfma_statistics_by_atomics(L, case):
     from phiseg_code_amd.runtime import PhxError
     with pytest.raises(PhxError):
         L.conv3x3_mfma_bf16_stats_atomic(xd.data_ptr(), wf.data_ptr(), y.data_ptr(), None, 0, None, B, H, W, K, N, S())
-
-
-# 16 x 32-pixel tiles, 128-pixel wave tiles with shared patch rows, LDS-DMA staged (k_conv3x3_fwd_dma128; policy: large maps), forced
-# on small shapes; N % 64 == 32 takes its 32-channel-block variant
-@pytest.mark.parametrize("case", [(2, 16, 32, 32, 128), (1, 32, 64, 96, 64), (3, 16, 32, 32, 192), (1, 48, 32, 64, 256),
-                                  (1, 16, 64, 160, 128), (2, 32, 32, 32, 32), (1, 16, 64, 192, 32), (2, 16, 32, 64, 96)])
-def test_conv3x3_mfma_dma128(L, case, monkeypatch):
-    monkeypatch.setenv("PHX_FWD_WS", "5")
-    monkeypatch.setenv("PHX_FWD_DB", "0")
-    _mfma_case(L, case)
-
-
-# the experimental double-buffered persistent kernel (conv_db.hip, PHX_FWD_DB=1): forced on small shapes; PHX_DB_GRID = 3 makes
-# every block walk several items (chunk pipeline across item boundaries, epilogue at the head of the next item)
-@pytest.mark.parametrize("case", [(2, 16, 32, 32, 128), (1, 32, 64, 96, 64), (4, 16, 32, 32, 192), (2, 48, 32, 64, 256),
-                                  (1, 16, 64, 160, 128), (6, 32, 32, 64, 64)])
-@pytest.mark.parametrize("grid", [0, 3])
-def test_conv3x3_mfma_double_buffered(L, case, grid, monkeypatch):
-    monkeypatch.setenv("PHX_FWD_WS", "5")
-    monkeypatch.setenv("PHX_FWD_DB", "1")
-    monkeypatch.setenv("PHX_DB_GRID", str(grid))
-    _mfma_case(L, case)
 
 
 def _mfma_case(L, case):
@@ -927,7 +879,7 @@ def test_wgrad_deferred_small_map_launches(L):
         keep.append((x, dy, ws, ws2))
         if not info[0]:                                       # a 16x16-tile shape with <= 4 tiles adds straight into dw: per-layer launch
             # (with the LDS-DMA kernels switched off -- PHX_WGRAD_DMA=0, a debug hook -- no 16x16-tile layer is deferred)
-            assert (B, H, W) == (2, 16, 16) or os.environ.get("PHX_WGRAD_DMA") == "0"
+            assert (B, H, W) == (2, 16, 16)
             continue
         g = groups.setdefault(int(info[0]), dict(recs=[], blocks=0, lds=0))
         L.conv3x3_wgrad_multi_job(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws2.data_ptr(), wsb, B, H, W, K, N, tgt, g["blocks"], jb, info)
@@ -1008,7 +960,7 @@ def test_comm_abi_single_rank_rccl(L):
 def test_conv3x3_mfma_affine_epilogue(L, case, act):
     """Inference-mode batch norm + activation folded into the convolution (reference: conv2d -> batch_norm(is_training=False)
     -> relu, tfwrapper/layers.py:123-135, normalisation.py:145-163): y = act(conv(x) * scale + shift) in one launch, on the
-    256-pixel tiles, the split-K small-map path and (forced) the 32 x 16-tile LDS-DMA kernel."""
+    256-pixel tiles, the split-K small-map path and (forced) the large-map kernels."""
     B, H, W, K, N = case
     x = RNG.standard_normal((B, H, W, K))
     w = RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K)
@@ -1036,20 +988,15 @@ def test_conv3x3_mfma_affine_epilogue(L, case, act):
     wsb = int(L.conv3x3_mfma_ws_bytes(B, H, W, K, N))
     ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32).cuda()
     y = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
-    for env in ({}, {"PHX_FWD_WS": "5"}, {"PHX_FWD_WS": "0"}):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
+    for env in (1, 2, 0):
+        L.debug_conv_policy(env, 1)
         try:
             y.zero_()
             L.conv3x3_mfma_bf16_affine(xd.data_ptr(), wf.data_ptr(), y.data_ptr(), scale.data_ptr(), shift.data_ptr(), ACT[act],
                                        ws.data_ptr() if wsb else None, wsb, B, H, W, K, N, S())
-            close(host(y), ref.numpy(), 6e-3, "affine epilogue %s" % (env,))
+            close(host(y), ref.numpy(), 6e-3, "affine epilogue, large-map policy %d" % env)
         finally:
-            for k, v in old.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+            L.debug_conv_policy(1, 1)
 
 
 @pytest.mark.parametrize("case", [(3, 16, 16, 32, 2, BF16), (2, 8, 8, 192, 2, BF16), (5, 2, 2, 192, 2, BF16), (2, 4, 4, 64, 6, BF16),
@@ -1135,49 +1082,6 @@ def test_accumulating_pool_and_resize_gradients(L, dt):
         close(host(acc), host(plain) + rounded(prev, dt).numpy(), tol, fn_acc.__name__)
 
 
-@pytest.mark.parametrize("case", [(2, 32, 32, 64, 64, 0), (1, 16, 32, 32, 96, 5), (3, 64, 32, 32, 32, 0), (2, 32, 16, 128, 32, 0)])
-def test_conv3x3_mfma_replicated_atomic_statistics(L, case, monkeypatch):
-    """phx_conv3x3_mfma_bf16_stats_rep + phx_norm_apply_fused_rep: the large-map batch-norm layers' statistics as replicated atomic
-    accumulators (pixel tile t -> replica t % nrep) summed in the apply pass' prologue, on the 256-pixel kernels, the 8-wave tiles
-    and (forced) the 16 x 32 LDS-DMA kernel: the replicas sum to {sum y, sum y^2} of the stored output, and the apply pass equals
-    phx_norm_apply_fused on the summed statistics."""
-    B, H, W, K, N, ws = case
-    if ws:
-        monkeypatch.setenv("PHX_FWD_WS", str(ws))
-    assert L.conv3x3_mfma_stats_rep_supported(B, H, W, K, N) == 1
-    x = RNG.standard_normal((B, H, W, K))
-    w = RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K)
-    xd, wd = dev(x, BF16), dev(w)
-    wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
-    wg = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
-    L.pack_conv3x3_bf16(wd.data_ptr(), wf.data_ptr(), wg.data_ptr(), K, N, S())
-    y0 = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
-    L.conv3x3_mfma_bf16(xd.data_ptr(), wf.data_ptr(), y0.data_ptr(), None, 0, None, B, H, W, K, N, S())
-    nrep = 5
-    y = torch.empty_like(y0)
-    sums = torch.zeros(nrep, N, 2, dtype=torch.float32).cuda()
-    L.conv3x3_mfma_bf16_stats_rep(xd.data_ptr(), wf.data_ptr(), y.data_ptr(), None, 0, sums.data_ptr(), nrep, B, H, W, K, N, S())
-    assert torch.equal(y, y0)
-    yf = host(y).reshape(-1, N)
-    tot = host(sums).sum(axis=0)
-    close(tot[:, 0], yf.sum(0), 2e-5, "sum y over the replicas")
-    close(tot[:, 1], (yf ** 2).sum(0), 2e-5, "sum y^2 over the replicas")
-    if B * (H // 16 if H >= 16 else 1) > 1:
-        assert (host(sums)[1:] != 0).any()                       # more than one replica is in use
-    gamma, beta = dev(1.0 + 0.2 * RNG.standard_normal(N)), dev(0.3 * RNG.standard_normal(N))
-    P = B * H * W
-    outs = []
-    for rep, sm in ((nrep, sums), (1, sums.sum(dim=0).contiguous())):
-        a = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
-        mean, rstd, scale, shift = (torch.empty(N).cuda() for _ in range(4))
-        L.norm_apply_fused_rep(y.data_ptr(), BF16, sm.data_ptr(), rep, None, gamma.data_ptr(), beta.data_ptr(), 1e-3, a.data_ptr(), BF16,
-                               mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, None, 0.0, 1, P, N, N, 1, S())
-        outs.append((host(a), host(mean), host(rstd)))
-    close(outs[0][1], outs[1][1], 1e-6, "mean")
-    close(outs[0][2], outs[1][2], 1e-6, "rstd")
-    close(outs[0][0], outs[1][0], 2 ** -7, "a")
-
-
 @pytest.mark.parametrize("case", [("batch", 2, 16, 16, 128, 2), ("batch", 3, 8, 24, 32, 4), ("group", 2, 16, 16, 64, 2)])
 def test_norm_layer_with_fused_head(L, case):
     """phx_norm_apply_fused_head / phx_norm_bwd_reduce_head / phx_norm_bwd_apply_fused_head: a 1x1 head that is the only reader of
@@ -1237,68 +1141,11 @@ def test_norm_layer_with_fused_head(L, case):
     close(host(dg2), host(dg1), 1e-6, "dgamma")
 
 
-@pytest.mark.parametrize("case", [(64, 8, 8, 192, 192), (64, 4, 4, 256, 192), (64, 2, 2, 192, 192), (9, 4, 4, 64, 64), (3, 8, 8, 32, 96),
-                                  (12, 16, 16, 64, 64), (64, 2, 2, 32, 32)])
-@pytest.mark.parametrize("act", [1, 0])
-def test_conv3x3_fused_batch_norm_one_launch(L, case, act):
-    """phx_conv3x3_mfma_bf16_fbn (tfwrapper/layers.py:123-135 + normalisation.py:17-36 in one launch): y bit-equal to the plain
-    convolution, a / mean / rstd / scale / shift / moving statistics against the oracle's batch norm of that (bf16) y, and the
-    sums left in the accumulator."""
-    from oracle import tf1_ops as O
-    B, H, W, K, N = case
-    assert L.conv3x3_fbn_supported(B, H, W, K, N) in (32, 64)
-    assert L.conv3x3_fbn_supported(64, 128, 128, 32, 32) == 0          # thousands of blocks cannot meet inside a launch
-    x = RNG.standard_normal((B, H, W, K)) + 0.3
-    w = RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K)
-    gamma, beta = 1.0 + 0.2 * RNG.standard_normal(N), 0.3 * RNG.standard_normal(N)
-    mm0, mv0 = 0.1 * RNG.standard_normal(N), 1.0 + 0.1 * RNG.random(N)
-    xd, wd = dev(x, BF16), dev(w)
-    wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
-    wg = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
-    L.pack_conv3x3_bf16(wd.data_ptr(), wf.data_ptr(), wg.data_ptr(), K, N, S())
-    y0 = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
-    L.conv3x3_mfma_bf16_ws(xd.data_ptr(), wf.data_ptr(), y0.data_ptr(), None, 0, None, None, 0, B, H, W, K, N, S())
-    for rep in range(3):                                               # (relaunch: the rendezvous must not depend on timing)
-        y, a = torch.empty_like(y0), torch.empty_like(y0)
-        acc = torch.zeros(N * 2 + 64, dtype=torch.float32).cuda()
-        g_, b_ = dev(gamma), dev(beta)
-        mean, rstd, scale, shift = (torch.empty(N, dtype=torch.float32).cuda() for _ in range(4))
-        mm, mv = dev(mm0), dev(mv0)
-        L.conv3x3_mfma_bf16_fbn(xd.data_ptr(), wf.data_ptr(), y.data_ptr(), a.data_ptr(), acc.data_ptr(), acc.data_ptr() + N * 8,
-                                g_.data_ptr(), b_.data_ptr(), O.BN_EPS, mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                mm.data_ptr(), mv.data_ptr(), 0.01, act, B, H, W, K, N, S())
-        torch.cuda.synchronize()
-        assert torch.equal(y, y0)
-        yf = host(y).astype(np.float64)
-        P = B * H * W
-        eps = O.BN_EPS
-        a_ref, mu_t, varu_t = O.batch_norm_train(torch.as_tensor(yf), torch.as_tensor(gamma), torch.as_tensor(beta))
-        if act == 1:
-            a_ref = O.relu(a_ref)
-        mu, var = mu_t.numpy(), varu_t.numpy() * max(P - 1, 1) / P
-        close(host(mean), mu, 2e-5, "mean")
-        close(host(rstd), 1.0 / np.sqrt(var + eps), 2e-4, "rstd")
-        close(host(a), a_ref.numpy(), 1.2e-2, "a = act(bn(y))")               # bf16 output
-        close(host(scale), gamma / np.sqrt(var + eps), 2e-4, "scale")
-        close(host(shift), beta - mu * gamma / np.sqrt(var + eps), 5e-4, "shift")
-        close(host(mm), O.batch_norm_moving_update(torch.as_tensor(mm0), mu_t, 0.99).numpy(), 2e-5, "moving mean")
-        close(host(mv), O.batch_norm_moving_update(torch.as_tensor(mv0), varu_t, 0.99).numpy(), 2e-5, "moving variance")
-        got = host(acc)[:2 * N].reshape(N, 2)
-        close(got[:, 0], yf.reshape(P, N).sum(0), 2e-5, "sum y")
-        cnt = acc[2 * N:].view(torch.int32).cpu().numpy()
-        bn = L.conv3x3_fbn_supported(B, H, W, K, N)
-        assert (cnt[:N // bn] == cnt[0]).all() and cnt[0] >= 1 and (cnt[N // bn:] == 0).all()
-    import ctypes
-    nto = ctypes.c_int(-1)
-    L.conv3x3_fbn_timeouts(ctypes.byref(nto))
-    assert nto.value == 0                                               # no block ever gave up at the rendezvous
-
-
 @pytest.mark.parametrize("case", [(64, 4, 4, 192, 64, 192), (64, 8, 8, 192, 64, 192), (16, 16, 16, 192, 64, 192), (8, 16, 16, 192, 192, 192),
                                   (4, 32, 32, 128, 64, 128), (3, 32, 32, 128, 128, 192), (64, 2, 2, 192, 64, 96), (2, 16, 32, 32, 32, 128),
                                   (1, 32, 64, 64, 64, 192), (2, 16, 32, 64, 32, 96)])
 @pytest.mark.parametrize("force_dma", [0, 1])
-def test_conv3x3_concat_free(L, case, force_dma, monkeypatch):
+def test_conv3x3_concat_free(L, case, force_dma, policy):
     """Concat-free convolution (tf.concat([a, b], axis=3) -> conv2D 3x3: posteriors.py:87,120, priors.py:112, likelihoods.py:210):
     forward with a dual input, data gradient with a dual output and the filter gradient with a dual input equal the same launches on
     the materialised concatenation (forward / data gradient bit for bit), and the forward pass matches the oracle's concat + conv."""
@@ -1307,8 +1154,7 @@ def test_conv3x3_concat_free(L, case, force_dma, monkeypatch):
     if force_dma:
         if H % 16 or W % 32:
             pytest.skip("16 x 32-pixel tiles only")
-        monkeypatch.setenv("PHX_FWD_WS", "5")
-    monkeypatch.setenv("PHX_FWD_DB", "0")
+        policy(large_maps=2)
     K = K1 + K2
     xa, xb = RNG.standard_normal((B, H, W, K1)), RNG.standard_normal((B, H, W, K2))
     w = RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K)
@@ -1327,24 +1173,41 @@ def test_conv3x3_concat_free(L, case, force_dma, monkeypatch):
     wp, wb, _k1 = ws_for(K, N)
     y_ref, y = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda(), torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
     L.conv3x3_mfma_bf16_ws(xcd.data_ptr(), wf.data_ptr(), y_ref.data_ptr(), None, 0, None, wp, wb, B, H, W, K, N, S())
-    L.conv3x3_next_dual_input(xbd.data_ptr(), K1)
-    L.conv3x3_mfma_bf16_ws(xad.data_ptr(), wf.data_ptr(), y.data_ptr(), None, 0, None, wp, wb, B, H, W, K, N, S())
+    L.conv3x3_mfma_bf16_dual(xad.data_ptr(), xbd.data_ptr(), K1, wf.data_ptr(), y.data_ptr(), None, 0, None, None, 0, None, 0, wp, wb,
+                             B, H, W, K, N, S())
     torch.cuda.synchronize()
     assert torch.equal(y, y_ref)
     ref = O.conv2d_same(torch.cat([rounded(xa, BF16), rounded(xb, BF16)], dim=3), rounded(w, BF16))
     close(host(y), ref.numpy(), 1.5e-2, "dual forward vs oracle concat + conv")
-    # the modifier is one-shot: the next launch is an ordinary one again
-    y2 = torch.empty_like(y)
-    L.conv3x3_mfma_bf16_ws(xcd.data_ptr(), wf.data_ptr(), y2.data_ptr(), None, 0, None, wp, wb, B, H, W, K, N, S())
-    assert torch.equal(y2, y_ref)
+    # ... with bias + ReLU, and with the statistics epilogue of the batch-norm layers (partial rows; atomics where few tiles exist)
+    bias = dev(RNG.standard_normal(N) * 0.3)
+    yb_ref, yb = torch.empty_like(y), torch.empty_like(y)
+    L.conv3x3_mfma_bf16_ws(xcd.data_ptr(), wf.data_ptr(), yb_ref.data_ptr(), bias.data_ptr(), 1, None, wp, wb, B, H, W, K, N, S())
+    L.conv3x3_mfma_bf16_dual(xad.data_ptr(), xbd.data_ptr(), K1, wf.data_ptr(), yb.data_ptr(), None, 0, bias.data_ptr(), None, 1, None, 0,
+                             wp, wb, B, H, W, K, N, S())
+    torch.cuda.synchronize()
+    assert torch.equal(yb, yb_ref)
+    ntile = L.conv3x3_mfma_bf16_tiles(B, H, W, K, N)
+    part_ref, part = torch.zeros(ntile, 2, N).cuda(), torch.zeros(ntile, 2, N).cuda()
+    L.conv3x3_mfma_bf16(xcd.data_ptr(), wf.data_ptr(), yb_ref.data_ptr(), None, 0, part_ref.data_ptr(), B, H, W, K, N, S())
+    L.conv3x3_mfma_bf16_dual(xad.data_ptr(), xbd.data_ptr(), K1, wf.data_ptr(), yb.data_ptr(), None, 0, None, None, 0, part.data_ptr(), 1,
+                             None, 0, B, H, W, K, N, S())
+    torch.cuda.synchronize()
+    assert torch.equal(yb, yb_ref)
+    close(host(part).sum(0), host(part_ref).sum(0), 2e-5, "dual input, partial-row statistics")
+    if L.conv3x3_mfma_stats_atomic_supported(B, H, W, K, N):
+        sums = torch.zeros(N, 2).cuda()
+        L.conv3x3_mfma_bf16_dual(xad.data_ptr(), xbd.data_ptr(), K1, wf.data_ptr(), yb.data_ptr(), None, 0, None, None, 0, sums.data_ptr(), 2,
+                                 None, 0, B, H, W, K, N, S())
+        close(host(sums).T, host(part_ref).sum(0), 2e-5, "dual input, atomic statistics")
     # data gradient: d(concat) = conv(dy, flipped filter), written as two tensors
     wp, wb, _k2 = ws_for(N, K)
     dx_ref = torch.empty(B, H, W, K, dtype=torch.bfloat16).cuda()
     L.conv3x3_mfma_bf16_ws(dyd.data_ptr(), wg.data_ptr(), dx_ref.data_ptr(), None, 0, None, wp, wb, B, H, W, N, K, S())
     g1 = torch.full((B, H, W, K1), 7.0, dtype=torch.bfloat16).cuda()
     g2 = torch.full((B, H, W, K2), 7.0, dtype=torch.bfloat16).cuda()
-    L.conv3x3_next_dual_output(g2.data_ptr(), K1)
-    L.conv3x3_mfma_bf16_ws(dyd.data_ptr(), wg.data_ptr(), g1.data_ptr(), None, 0, None, wp, wb, B, H, W, N, K, S())
+    L.conv3x3_mfma_bf16_dual(dyd.data_ptr(), None, 0, wg.data_ptr(), g1.data_ptr(), g2.data_ptr(), K1, None, None, 0, None, 0, wp, wb,
+                             B, H, W, N, K, S())
     torch.cuda.synchronize()
     assert torch.equal(g1, dx_ref[..., :K1]) and torch.equal(g2, dx_ref[..., K1:])
     # filter gradient
@@ -1357,92 +1220,13 @@ def test_conv3x3_concat_free(L, case, force_dma, monkeypatch):
     close(host(dw), host(dw_ref), 2e-5, "dual filter gradient")
 
 
-def test_conv3x3_concat_free_statistics_and_fused_norm(L):
-    """the dual-input modifier composes with the statistics epilogues and the one-launch conv + batch norm"""
-    B, H, W, K1, K2, N = 64, 4, 4, 192, 64, 192
-    K = K1 + K2
-    xad, xbd = dev(RNG.standard_normal((B, H, W, K1)), BF16), dev(RNG.standard_normal((B, H, W, K2)), BF16)
-    xcd = torch.cat([xad, xbd], dim=3).contiguous()
-    wd = dev(RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K))
-    wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
-    wg = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
-    L.pack_conv3x3_bf16(wd.data_ptr(), wf.data_ptr(), wg.data_ptr(), K, N, S())
-    outs = []
-    for dual in (False, True):
-        y, a = torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda(), torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda()
-        acc = torch.zeros(N * 2 + 64, dtype=torch.float32).cuda()
-        sums = torch.zeros(N, 2, dtype=torch.float32).cuda()
-        g_, b_ = torch.ones(N).cuda(), torch.zeros(N).cuda()
-        vec = [torch.empty(N, dtype=torch.float32).cuda() for _ in range(4)]
-        if dual:
-            L.conv3x3_next_dual_input(xbd.data_ptr(), K1)
-        L.conv3x3_mfma_bf16_fbn((xad if dual else xcd).data_ptr(), wf.data_ptr(), y.data_ptr(), a.data_ptr(), acc.data_ptr(), acc.data_ptr() + N * 8,
-                                g_.data_ptr(), b_.data_ptr(), 1e-3, *[v.data_ptr() for v in vec], None, None, 0.0, 1, B, H, W, K, N, S())
-        y2 = torch.empty_like(y)
-        if dual:
-            L.conv3x3_next_dual_input(xbd.data_ptr(), K1)
-        L.conv3x3_mfma_bf16_stats_atomic((xad if dual else xcd).data_ptr(), wf.data_ptr(), y2.data_ptr(), None, 0, sums.data_ptr(), B, H, W, K, N, S())
-        torch.cuda.synchronize()
-        outs.append((y, a, y2, host(sums)))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][0], outs[0][2])
-    close(host(outs[1][1]), host(outs[0][1]), 1e-2, "fused norm output")
-    close(outs[1][3], outs[0][3], 2e-5, "statistics")
-
-
-@pytest.mark.parametrize("case", [(64, 8, 8, 192, 1), (64, 16, 16, 192, 1), (64, 32, 32, 128, 1), (23, 6, 6, 128, 1), (64, 16, 16, 64, 0),
-                                  (5, 16, 24, 32, 1), (64, 32, 32, 32, 1)])
-def test_bn_mid_backward_one_launch(L, case):
-    """phx_bn_mid_bwd (batch-norm + activation backward of a mid-size layer in one launch: partial sums by returning atomics, the
-    blocks of a channel slice meet at an arrival counter) against the oracle's batch norm + ReLU autograd and against the two-launch
-    path it replaces (phx_norm_bwd_reduce + phx_norm_bwd_apply_fused_bias); relaunched to show the rendezvous does not depend on timing."""
-    import ctypes
-    B, H, W, C, act = case
-    P = B * H * W
-    assert L.bn_mid_supported(P, C, BF16) in (1, 2, 4, 8)
-    assert L.bn_mid_supported(64 * 128 * 128, 128, BF16) == 0 and L.bn_mid_supported(P, 24, BF16) == 0
-    x = RNG.standard_normal((B, H, W, C)) * 1.5 + 0.3
-    gamma, beta = 1.0 + 0.2 * RNG.standard_normal(C), 0.1 * RNG.standard_normal(C)
-    xr = rounded(x, BF16).requires_grad_(True)
-    gr = torch.as_tensor(gamma, dtype=torch.float32).double().requires_grad_(True)
-    br = torch.as_tensor(beta, dtype=torch.float32).double().requires_grad_(True)
-    yr, mean_r, _ = T.batch_norm_train(xr, gr, br)
-    ar = T.relu(yr) if act else yr
-    dA = RNG.standard_normal((B, H, W, C))
-    (ar * rounded(dA, BF16)).sum().backward()
-    var_b = xr.detach().reshape(P, C).var(0, unbiased=False).numpy()
-    rstd_np = 1.0 / np.sqrt(var_b + T.BN_EPS)
-    xd, dAd, gd = dev(x, BF16), dev(dA, BF16), dev(gamma)
-    mean, rstd = dev(mean_r.detach().numpy()), dev(rstd_np)
-    scale, shift = dev(gamma * rstd_np), dev(beta - mean_r.detach().numpy() * gamma * rstd_np)
-    for rep in range(3):
-        dx = torch.empty(B, H, W, C, dtype=torch.bfloat16).cuda()
-        dgamma = torch.full((C,), 0.5, dtype=torch.float32).cuda()        # accumulated (+=), not overwritten
-        dbeta = torch.full((C,), -0.25, dtype=torch.float32).cuda()
-        acc = torch.zeros(C * 2 + 64, dtype=torch.float32).cuda()
-        L.bn_mid_bwd(dAd.data_ptr(), xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gd.data_ptr(),
-                     dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), acc.data_ptr(), acc.data_ptr() + C * 8, P, C, act, S())
-        close(host(dx), xr.grad.numpy(), 8e-3, "bn_mid dx")
-        close(host(dgamma) - 0.5, gr.grad.numpy(), 2e-3, "bn_mid dgamma")
-        close(host(dbeta) + 0.25, br.grad.numpy(), 2e-3, "bn_mid dbeta")
-    # the two-launch path on the same inputs
-    sums2 = torch.zeros(1, C, 2, dtype=torch.float32).cuda()
-    L.norm_bwd_reduce(dAd.data_ptr(), BF16, xd.data_ptr(), BF16, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                      sums2.data_ptr(), 1, P, C, C, act, 1, S())
-    close(host(acc)[:2 * C].reshape(C, 2), host(sums2).reshape(C, 2), 2e-5, "bn_mid sums vs norm_bwd_reduce")
-    nto = ctypes.c_int(-1)
-    L.bn_mid_timeouts(ctypes.byref(nto))
-    assert nto.value == 0
-
-
 @pytest.mark.parametrize("case", [(64, 16, 32), (5, 48, 96), (3, 16, 64), (2, 32, 32)])
-def test_conv3x3_c32_against_the_general_kernel(L, case, monkeypatch):
-    """k_conv3x3_c32 (32 -> 32 channels, filter in registers, persistent tiles; PHX_C32=1, the default) against k_conv3x3_fwd_dma128<32>
-    (PHX_C32=0) through the same entry points: plain output bit-equal; bias + activation epilogue bit-equal; per-tile partial
-    statistics and replicated atomic statistics to fp32 summation order; and against the oracle's conv2d."""
+def test_conv3x3_c32_against_the_general_kernel(L, case, policy):
+    """k_conv3x3_c32 (32 -> 32 channels on large maps: filter in registers, persistent tiles; forced here on small maps) against the
+    256-pixel kernel through the same entry points -- plain output, bias + activation epilogue, per-tile partial statistics -- and
+    against the oracle's conv2d."""
     B, H, W = case
     K = N = 32
-    monkeypatch.setenv("PHX_FWD_WS", "5")
-    monkeypatch.setenv("PHX_FWD_DB", "0")
     x = RNG.standard_normal((B, H, W, K))
     w = RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K)
     bias = RNG.standard_normal(N) * 0.3
@@ -1450,25 +1234,24 @@ def test_conv3x3_c32_against_the_general_kernel(L, case, monkeypatch):
     wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
     wg = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
     L.pack_conv3x3_bf16(wd.data_ptr(), wf.data_ptr(), wg.data_ptr(), K, N, S())
-    ntile = L.conv3x3_mfma_bf16_tiles(B, H, W, K, N)
     res = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("PHX_C32", mode)
-        y, yb, yr = (torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda() for _ in range(3))
+    for mode in (0, 2):
+        policy(large_maps=mode)
+        ntile = L.conv3x3_mfma_bf16_tiles(B, H, W, K, N)
+        y, yb = (torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda() for _ in range(2))
         part = torch.zeros(ntile, 2, N, dtype=torch.float32).cuda()
-        rep = torch.zeros(4, N, 2, dtype=torch.float32).cuda()
         L.conv3x3_mfma_bf16(xd.data_ptr(), wf.data_ptr(), y.data_ptr(), None, 0, part.data_ptr(), B, H, W, K, N, S())
         L.conv3x3_mfma_bf16(xd.data_ptr(), wf.data_ptr(), yb.data_ptr(), bd.data_ptr(), 1, None, B, H, W, K, N, S())
-        L.conv3x3_mfma_bf16_stats_rep(xd.data_ptr(), wf.data_ptr(), yr.data_ptr(), None, 0, rep.data_ptr(), 4, B, H, W, K, N, S())
         torch.cuda.synchronize()
-        res[mode] = (y, yb, yr, host(part).sum(0), host(rep).sum(0))
-    a, b = res["0"], res["1"]
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(b[0], b[2])
-    close(b[3], a[3], 2e-5, "partial-row statistics")
-    close(b[4].T, b[3], 2e-5, "replicated statistics = partial rows")
+        res[mode] = (host(y), host(yb), host(part).sum(0))
+    a, b = res[0], res[2]
+    close(b[0], a[0], 2 ** -7, "c32 vs 256-pixel kernel")            # (one chunk of 32 channels: same products, summation order of the taps)
+    close(b[1], a[1], 2 ** -7, "c32 vs 256-pixel kernel, bias + relu")
+    close(b[2], b[0].reshape(-1, N).sum(0)[None].repeat(2, 0) * 0 + np.stack([b[0].reshape(-1, N).sum(0), (b[0].reshape(-1, N) ** 2).sum(0)]), 2e-5,
+          "partial-row statistics of the stored output")
     ref = T.conv2d_same(rounded(x, BF16), rounded(w, BF16))
-    close(host(b[0]), ref.numpy(), 1.5e-2, "c32 forward vs oracle")
-    close(host(b[1]), T.relu(T.bias_add(ref, torch.as_tensor(bias))).numpy(), 1.5e-2, "c32 bias + relu vs oracle")
+    close(b[0], ref.numpy(), 1.5e-2, "c32 forward vs oracle")
+    close(b[1], T.relu(T.bias_add(ref, torch.as_tensor(bias))).numpy(), 1.5e-2, "c32 bias + relu vs oracle")
 
 
 @pytest.mark.parametrize("case", [(64, 8, 8, 192, 192, 12), (64, 4, 4, 64, 192, 12), (64, 2, 2, 192, 192, 12), (5, 16, 16, 64, 64, 4),
@@ -1562,16 +1345,13 @@ def test_conv3x3_split_k_finish_slice_counts(L):
     assert len([k for k in seen if k > 1]) >= 3, sorted(seen)       # (the shapes above are meant to reach several slice counts)
 
 
-# the anti-phase pair kernel k_conv3x3_pp (conv_pp.hip; policy: large maps), forced on small shapes.  PHX_PP_GRID = 1 / 3 makes a block
+# the anti-phase pair kernel k_conv3x3_pp (conv_pp.hip; policy: large maps), forced on small shapes.  A persistent grid of 1 / 3 blocks makes a block
 # walk several (tile pair, channel block) work items (persistent pipeline across tile boundaries, epilogue in the partner's matrix
 # phase); odd tile counts leave the last pair's second half without a tile; N % 64 == 32 takes the 32-channel-block instantiation
 @pytest.mark.parametrize("case", [(2, 16, 32, 32, 128), (1, 32, 64, 96, 64), (3, 16, 32, 32, 192), (1, 48, 32, 64, 256),
                                   (1, 16, 64, 160, 128), (2, 32, 32, 32, 32), (1, 16, 64, 192, 32), (3, 16, 32, 64, 96),
                                   (5, 16, 32, 64, 64), (1, 16, 32, 32, 64)])
 @pytest.mark.parametrize("grid", [0, 1, 3])
-def test_conv3x3_mfma_pair_kernel(L, case, grid, monkeypatch):
-    monkeypatch.setenv("PHX_FWD_WS", "5")
-    monkeypatch.setenv("PHX_FWD_DB", "0")
-    monkeypatch.setenv("PHX_FWD_PP", "2")
-    monkeypatch.setenv("PHX_PP_GRID", str(grid))
+def test_conv3x3_mfma_pair_kernel(L, case, grid, policy):
+    policy(large_maps=2, pair_grid=grid)
     _mfma_case(L, case)

@@ -1,0 +1,50 @@
+"""Plan variants of the bf16 training step (MI355X): the concat-free convolutions (struct Dual) and the one-launch conv + group norm
+layers are default-on graph rewrites of the engine; each is compared here against the plan without it (PHX_DUAL=0 / PHX_FGN=0) on
+the same weights, inputs and noise."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("switch,off,on,norm", [("PHX_DUAL", "0", "1", "group_norm"), ("PHX_DUAL", "0", "1", None),
+                                               ("PHX_FGN", "0", "1", "group_norm")])
+def test_training_plan_concat_free_and_one_launch_layers_equal_the_plain_plan(switch, off, on, norm, monkeypatch):
+    """The bf16 training plan of phiseg_7_5 (n0 = 32, 128 x 128, batch 2) with concat-free convolutions (PHX_DUAL: the twelve
+    tf.concat -> conv2D edges of posteriors.py:87,120 / priors.py:112 / likelihoods.py:210 read and write their two tensors in place)
+    and with one-launch conv + group norm layers on the small maps (PHX_FGN) against the plan without them: same weights, inputs,
+    noise.  Concat-free is the same arithmetic (forward / data gradient bit-equal per layer, filter gradients up to summation order):
+    under group norm the loss agrees to 1e-4 and the gradients to 1 % (the one-launch layers re-order their statistics: bf16 flips, 1e-2 / 8 %)."""
+    from tests.test_model_gpu import _lidc_setup
+    res = {}
+    if switch == "PHX_DUAL":
+        monkeypatch.setenv("PHX_FGN", "0")      # (a concat-free layer keeps the two-launch group norm: compare like with like)
+    for v in (off, on):
+        monkeypatch.setenv(switch, v)
+        cfg, model, params, x_np, s_np = _lidc_setup("bf16", perturbed=True, norm=norm)
+        plan = model.sess.plan_for([model.loss_tot], True, cfg["B"], True)
+        plan.set_input("x_input", x_np)
+        plan.set_input("s_input", s_np)
+        model.sess.store.set_lr(0.0)
+        plan.run()
+        plan.sync()
+        res[v] = (float(plan.fetch(model.loss_tot)), model.sess.store.export(grads=True), len(plan.launches), model.sess.store.export())
+    l0, g0, n0, p0 = res[off]
+    l1, g1, n1, p1 = res[on]
+    assert n1 <= n0 - 12, (n0, n1)
+    sharp = norm is not None
+    exact = switch == "PHX_DUAL"            # (concat-free: identical arithmetic; the one-launch layers re-order their statistics -> bf16 flips)
+    assert abs(l1 - l0) <= ((1e-4 if exact else 1e-2) if sharp else 2e-2) * abs(l0), (l0, l1)
+    errs = []
+    for name, ga in g0.items():
+        nrm = np.linalg.norm(ga)
+        if nrm < 1e-8 * max(1.0, np.sqrt(ga.size)):
+            continue
+        errs.append(np.linalg.norm(g1[name] - ga) / nrm)
+    assert len(errs) >= 360
+    # (one-launch group norm: 0.04 - 0.055 observed, depending on the summation order of the PLAIN plan's statistics -- bf16 flips
+    # of both plans, not a trend; a wrong statistic or a missing term moves the mean error to O(1))
+    assert np.mean(errs) <= ((0.01 if exact else 0.08) if sharp else 0.5), np.mean(errs)
+    for name in p0:
+        if "moving_" in name:
+            np.testing.assert_allclose(p1[name], p0[name], rtol=1e-2, atol=3e-3)

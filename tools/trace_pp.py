@@ -6,7 +6,7 @@ sys.path.insert(0, ".")
 from phiseg_code_amd import runtime as rt
 L = rt.lib()
 st = torch.cuda.current_stream().cuda_stream
-os.environ["PHX_FWD_WS"] = "5"; os.environ["PHX_FWD_DB"] = "0"; os.environ["PHX_FWD_PP"] = "2"
+L.debug_conv_policy(2, 1)
 B, H, W, K, N = [int(v) for v in (sys.argv[1:6] if len(sys.argv) >= 6 else (64, 128, 128, 128, 128))]
 stats = len(sys.argv) > 6 and sys.argv[6] == "stats"
 x = torch.relu(torch.randn(B, H, W, K, device="cuda")).to(torch.bfloat16)
@@ -27,7 +27,7 @@ nch = K // 32
 names = ["compute", "->bar", "patchDMA", "epilogue", "slabDMA", "vm wait", "barrier"]
 for wv in (0, 4):
     print("wave %d (%s)" % (wv, "A" if wv < 4 else "B"))
-    for it in range(0, 3 * nch):
+    for it in range(0, min(3 * nch, 11)):
         r = t[it * 8: it * 8 + 8, wv]
         if r[0] == 0: break
         nxt = t[(it + 1) * 8, wv]
@@ -37,3 +37,7 @@ for wv in (0, 4):
 it = nch
 print("end-of-compute stamps, item %d, waves 0-7 relative to wave 0:" % it, (t[it * 8 + 1] - t[it * 8 + 1, 0]).tolist())
 print("start-of-compute stamps:", (t[it * 8 + 0] - t[it * 8 + 0, 0]).tolist())
+e = t[88:96]
+for wv in (0, 4):
+    d = e[1:, wv] - e[:-1, wv]
+    print("last epilogue, wave %d: W0 %d  R0 %d  W1 %d  S0 %d  R1+W2 %d  (S1 R2 W3 S2 R3) %d  S3 %d   total %d" % ((wv,) + tuple(d.tolist()) + (e[7, wv] - e[0, wv],)))
