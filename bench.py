@@ -41,12 +41,12 @@ def make_config(batch, compute_dtype, exp="phiseg_7_5", image_size=128, nlabels=
     return cfg
 
 
-def cpu_baseline(batch=12, steps=2):
+def cpu_baseline(batch=12, steps=5):
     """The oracle (oracle/: port of the reference's TF 1.12 graph to torch-CPU, fp32) running the SAME training step on the
     host cores, from the SAME initial weights (seed 0, Philox stream contract) and the SAME synthetic images (seed 1234) as
     the GPU leg: `steps` timed steps at batch 12 -- the reference's own batch size (phiseg_7_5.py:40) -- after one warm-up.
-    Two steps, not ten: a step takes ~14.5 s on the 128 host threads, so this is already a ~30 s sample (the bound asked of
-    a default bench run); the per-step time varies by < 2 % between steps (round 1: 0.82 / 0.89 images/s on two boxes).
+    Five steps (round-3 review): a step takes ~14.5 s on the 128 host threads, a ~75 s sample; the per-step time varies by < 2 %
+    between steps (round 1: 0.82 / 0.89 images/s on two boxes).
     Smaller batches are NOT a cheaper stand-in: at batch 2 the same port reaches only 0.32 images/s (the host threads
     starve), which would understate the CPU path."""
     import numpy as np
@@ -321,12 +321,16 @@ def main():
         dom = max(bysh.items(), key=lambda kv: kv[1][1]) if bysh else None
         # HBM traffic of the same kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # corrected as MI355X_MICROARCH.md prescribes; see profiles/r01_pmc_hbm_traffic_final.txt): bytes per launch
-        traffic = None
+        traffic = in_situ = None
         try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", next(f for f in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic_final.json") if os.path.exists(os.path.join(ROOT, "profiles", f))))))
-            ks = [v for k, v in pj.items() if k.startswith("void k_conv3x3_mfma<") or k.startswith("void k_conv3x3_fwd_dma128<")]
+            pj = json.load(open(os.path.join(ROOT, "profiles", next(f for f in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))))))
+            ks = [v for k, v in pj.items() if any(t in k for t in ("k_conv3x3_pp", "k_conv3x3_c32", "k_conv3x3_mfma", "k_conv3x3_fwd_dma128"))]
             calls = sum(v["calls_per_step"] for v in ks)
             traffic = 1e6 * sum(v["fetch_x2_MB_per_step"] + v["write_MB_per_step"] for v in ks) / calls
+        except Exception:
+            pass
+        try:          # the same family inside the running step: kernel trace of the timed steps (tools/collect_profiles.sh, committed)
+            in_situ = json.load(open(os.path.join(ROOT, "profiles", "r04_conv_in_situ.json")))
         except Exception:
             pass
         alg_bytes = 0.0
@@ -344,6 +348,9 @@ def main():
             "families": {k: {"tflops": v[0] / v[1] / 1e9, "ms_per_step": v[1], "launches": v[2]} for k, v in fam.items()},
             "conv_ms_per_step": sum(v[1] for v in fam.values()),
         }
+        if in_situ:       # the family's time inside the step (profiles/r04_rocprofv3_kernel_stats.txt) against the same FLOPs
+            out["roofline"]["frac_in_situ"] = fl / in_situ["conv_fwd_dgrad_ms_per_step"] / 1e9 / PEAK_BF16_TFLOPS
+            out["roofline"]["in_situ"] = in_situ
         # launches of the family that also carry the layer's group norm (phx_conv3x3_mfma_bf16_fgn: statistics, second pass):
         # counted in `achieved` with their whole duration, listed here so that the convolution-only part can be read off
         fb = [(fl_, ms_) for tag, fl_, ms_, shp in rows if shp and shp[0] == "fgn"]

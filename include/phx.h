@@ -142,6 +142,9 @@ int phx_conv3x3_mfma_bf16_affine(const void* x, const void* wpk, void* y, const 
                                  void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream);
 /* number of pixel tiles (= rows of stats_partial) phx_conv3x3_mfma_bf16 uses for this shape */
 int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W, int K, int N);
+/* ... of a concat-free launch (phx_conv3x3_mfma_bf16_dual with x2 or y2 set): those never take the 16 x 32-tile instantiations
+ * of the 256-pixel kernel, so their row count differs where the policy would pick them */
+int phx_conv3x3_mfma_bf16_tiles_dual(int B, int H, int W, int K, int N);
 /* debug: device buffer of >= 16 uint64 that receives shader-clock phase timestamps of block 0 (NULL disables) */
 int phx_debug_set_trace(void* dev_buf);
 /* debug: device buffer of 4 uint64 per block {start, end, HW_ID | XCC_ID << 32, realtime} written by the MFMA conv kernels */

@@ -903,6 +903,13 @@ int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W, int K, int N) {
     return g.tiles_x * g.tiles_y * g.tiles_b;
 }
 
+// ... of a concat-free launch (phx_conv3x3_mfma_bf16_dual with x2 / y2): large maps as above, everything else the 256-pixel tiles
+// (the DUAL instantiations exist for those only)
+int phx_conv3x3_mfma_bf16_tiles_dual(int B, int H, int W, int K, int N) {
+    MTile g = fwd_ws64(B, H, W, K, N) ? make_mtile_fwd(B, H, W, K, N) : make_mtile(B, H, W);
+    return g.tiles_x * g.tiles_y * g.tiles_b;
+}
+
 // split-K factor for the forward / data-gradient kernel: > 1 only for the 256-pixel-tile kernels on maps whose tiles x
 // channel blocks leave most CUs idle (H <= 16 at batch 64); aims at ~64 blocks
 static int fwd_ksplit(int B, int H, int W, int K, int N) {

@@ -977,6 +977,8 @@ class Plan:
         st["head1x1"] = head1x1
 
         def tiles_fn():
+            if dual is not None:
+                return int(Lb.conv3x3_mfma_bf16_tiles_dual(B, H, Wd, cin_eff, cout))
             return int(Lb.conv3x3_mfma_bf16_tiles(B, H, Wd, cin_eff, cout))
 
         def conv_into(y, act_code, stats_direct=None, stats_part=None, stats_atomic=None):

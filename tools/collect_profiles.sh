@@ -17,7 +17,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 db=$(find $O/stats -name "*results.db" | head -1)
-python tools/prof_summary.py $db 11 > $O/kernel_stats.txt
+python tools/prof_summary.py $db 11 40 $O/conv_in_situ.json > $O/kernel_stats.txt
 python tools/pmc_summary.py $O/pmc 4 $O/pmc_hbm_traffic.txt $O/pmc_hbm_traffic.json > /dev/null
 # MFMA / LDS utilisation of the convolution kernels (one more PMC pass, kernel trace only)
 cd /tmp

@@ -5,7 +5,7 @@ tab = collections.defaultdict(dict)
 for f in sorted(glob.glob(d + "/p*/**/*counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(lambda: [0.0, 0])
     for row in csv.DictReader(open(f)):
-        k = (row["Kernel_Name"].split("(")[0][:60], row.get("Grid_Size", ""), row.get("LDS_Block_Size", ""))
+        k = (row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:60], row.get("Grid_Size", ""), row.get("LDS_Block_Size", ""))
         a = agg[(k, row["Counter_Name"])]
         a[0] += float(row["Counter_Value"]); a[1] += 1
     for (k, c), (v, n) in agg.items():

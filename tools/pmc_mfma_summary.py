@@ -8,7 +8,7 @@ f, steps, out = sys.argv[1], float(sys.argv[2]), sys.argv[3]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 for row in csv.DictReader(open(f)):
-    k = row["Kernel_Name"].split("(")[0]
+    k = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
     agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
     if row["Counter_Name"] == "GRBM_GUI_ACTIVE":
         cnt[k] += 1

@@ -5,7 +5,7 @@ res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(lambda: [0.0, 0])
     for row in csv.DictReader(open("%s/%s/p_counter_collection.csv" % (d, c))):
-        k = row["Kernel_Name"].split("(")[0]
+        k = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
         agg[k][0] += float(row["Counter_Value"]); agg[k][1] += 1
     res[c] = agg
 names = sorted(res["FETCH_SIZE"], key=lambda k: -(2 * res["FETCH_SIZE"][k][0] + res["WRITE_SIZE"].get(k, [0, 0])[0]))
