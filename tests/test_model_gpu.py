@@ -821,3 +821,36 @@ def test_bf16_trains_like_fp32_n0_32_batch12_300_steps():
     check("cross-entropy, all levels", f[:, ce].sum(axis=1), b[:, ce].sum(axis=1), 0.05)
     for i in ce:
         check(keys[i], f[:, i], b[:, i], 0.05)
+
+
+def test_bf16_shared_encoder_sampling_graph_16_samples_192x192_vs_oracle():
+    """The graph `bench.py --workload generate` times (BASELINE config 5): ONE 192 x 192 image, 4 classes, 16 Monte-Carlo samples in
+    one pass through model.sampling_graph(16) -- prior encoder once, features repeated (graph.tile_batch), latent path + likelihood
+    at batch 16, inference-mode batch norm folded into the convolution epilogues (phx_conv3x3_mfma_bf16_affine), bf16, n0 = 32 --
+    against the oracle's sampler on the reference's own batching, np.tile(x, [16, 1, 1, 1]) (phiseg_model.py:577-585), with the
+    same Philox noise per (image, sample) row.  Bound: RMS deviation of the logits <= 3 % of their range (bf16 storage, see
+    test_bf16_path_lidc); the 16 samples differ from one another."""
+    from oracle import init as oinit
+    from oracle import nets
+    from phiseg_code_amd.phiseg import phiseg_model
+    n = 16
+    cfg = dict(arch="phiseg", norm="batch_norm", n0=32, zdim0=2, H=192, B=1, nlabels=4, latent_levels=5,
+               resolution_levels=7, image_size=(192, 192, 1), KL_weight=1.0, CE_weight=1.0, exponential_weighting=True)
+    model = phiseg_model.phiseg(make_config(cfg, "bf16"), rng_seed=42)
+    var_order = [(nm, v.shape) for nm, v in model.graph.variables.items()]
+    params = otrain.make_params(var_order, 0, torch.float64, perturbed=False)
+    model.set_weights({k: v.detach().numpy() for k, v in params.items()})
+    x_np, _ = oinit.synthetic_batch(1, 192, 4, 1234)
+    s_multi, sm_multi = model.sampling_graph(n)
+    s_out, sm = model.sess.run([s_multi, sm_multi], {model.x_inp: x_np, model.training_pl: False})
+    assert s_out.shape == (n, 192, 192, 4)
+    xt = np.repeat(x_np, n, axis=0)
+    with torch.no_grad():
+        ref = nets.sample(params, torch.as_tensor(xt, dtype=torch.float64), otrain.torch_eps_fn(42, 0, n), dict(cfg, B=n))
+    r = ref["s_out_eval"].numpy()
+    rms = np.sqrt(((s_out - r) ** 2).mean()) / np.abs(r).max()
+    print("shared-encoder sampling graph, 16 samples: RMS deviation %.4f of the logit range" % rms)
+    assert rms < 0.03, rms
+    assert np.abs(sm.sum(axis=-1) - 1.0).max() < 1e-5
+    assert (sm.argmax(-1) == ref["s_out_eval_sm"].numpy().argmax(-1)).mean() > 0.97
+    assert np.abs(s_out[0] - s_out[1]).max() > 1e-3 * np.abs(r).max()
