@@ -64,7 +64,11 @@ __device__ unsigned long long* g_pp_trace = nullptr;      // dev: cycle stamps o
     } while (0)
 
 // DBG (dev builds with -DPP_DEV_ABLATE, tools/bench_pp.py): 1 no patch DMA, 2 no slab DMA, 4 no MFMAs
-template <int BN, bool BIASACT, bool DUAL, int DBG>
+// TR (launches without bias / activation / statistics: every data gradient): the MFMA operands are swapped -- D = filter x patch --
+// so that a lane holds ONE pixel and four consecutive output channels per accumulator quad: the epilogue packs and writes 8 bytes per
+// lane and quad (32 ds_write_b64 per tile and wave) instead of trading rows with the neighbour lane (64 DPP + 64 v_perm + 64
+// ds_write_b32).  The epilogue is LDS-issue-bound (~47 cycles per LDS instruction beside the partner's operand reads and the DMA).
+template <int BN, bool BIASACT, bool DUAL, int DBG, bool TR = false>
 __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __restrict__ x, const unsigned short* __restrict__ wpk,
                                                        unsigned short* __restrict__ y, const float* __restrict__ bias, int act,
                                                        float* __restrict__ stats_partial, int B, int H, int W, int K, int N,
@@ -236,10 +240,11 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __r
                 auto slot = [&](auto sc) {
                     constexpr int s = decltype(sc)::value, kh = s / 4, i = s % 4;
                     if constexpr (!(DBG & 4)) {
+                        const bf16x8 opa = TR ? fb[t & 1][kh] : fa[g & 1][i + kh], opb = TR ? fa[g & 1][i + kh] : fb[t & 1][kh];
                         if constexpr (FIRST && g == 0 && kh == 0)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g & 1][i + kh], fb[t & 1][kh], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opa, opb, f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                         else
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g & 1][i + kh], fb[t & 1][kh], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opa, opb, acc[i][j], 0, 0, 0);
                     }
                     // one read of the next half-step's fragments behind every second MFMA
                     if constexpr (more && (s & 1) == 0) {
@@ -306,7 +311,9 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __r
         }
         // lane part of a store: piece p = lane + 64 it of the pass's 32 PPP pieces -> pixel row p / PPP, 16-byte piece q = p % PPP
         const int prow = ln / PPP, q = ln % PPP;
-        const unsigned char* const lr = scr + prow * OROW + ((q * 16) ^ ((prow & 1) ? OSWZ : 0));
+        // (TR: the 16-byte piece index of a row is XORed with the row's low bits -- the 8-byte writes of 16 consecutive pixels spread over
+        // eight pieces, two lanes per bank pair)
+        const unsigned char* const lr = scr + prow * OROW + (TR ? ((q ^ (prow & (PPP - 1))) * 16) : ((q * 16) ^ ((prow & 1) ? OSWZ : 0)));
         unsigned char* const lwp = scr + (4 * khalfe + odd) * OROW + (l31e & ~1) * 2;
         // destination of piece (pass i, it): pixel (et_ty0 + 4 lw + i, et_tx0 + prow + it * 64 / PPP), channels et_n0 + 8 q ..
         [[maybe_unused]] unsigned short* ybase = y;
@@ -353,6 +360,19 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __r
             }
             __builtin_amdgcn_sched_barrier(0);
         };
+        auto pack_write_tr = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            unsigned char* const wr = scr + l31e * OROW + 8 * khalfe;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+                    const u32x2_t w = {f2bf_pk(acc[i][j][4 * qd], acc[i][j][4 * qd + 1]), f2bf_pk(acc[i][j][4 * qd + 2], acc[i][j][4 * qd + 3])};
+                    *reinterpret_cast<u32x2_t*>(wr + (((j * 4 + qd) ^ (l31e & (PPP - 1))) * 16)) = w;
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        };
         auto read_back = [&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value;
 #pragma unroll
@@ -385,7 +405,15 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __r
         store(IC(3));                                                                                    \
         PP_TRACE(95);                                                                                    \
     } while (0)
-        if (am == 0) PP_PASSES(0);
+        if constexpr (TR) {
+            PP_TRACE(88);
+            pack_write_tr(IC(0)); PP_TRACE(89); read_back(IC(0)); PP_TRACE(90);
+            pack_write_tr(IC(1)); store(IC(0)); read_back(IC(1));
+            pack_write_tr(IC(2)); store(IC(1)); read_back(IC(2));
+            pack_write_tr(IC(3)); store(IC(2)); read_back(IC(3));
+            store(IC(3));
+            PP_TRACE(95);
+        } else if (am == 0) PP_PASSES(0);
         else if (am == 4) PP_PASSES(4);
         else if constexpr (BIASACT) {                 // (identity / ReLU only: the launcher refuses other activations)
             if (am == 1) PP_PASSES(1);
@@ -548,9 +576,10 @@ int phx_pp_launch(const void* x, const void* wpk, void* y, const float* bias, in
     const bool ba = bias != nullptr || act != PHX_ACT_ID || oscale != nullptr;
     const bool dual = du.x2 != nullptr || du.y2 != nullptr;
     const size_t lds64 = 160 * 1024, lds32 = 160 * 1024;      // (one block per CU by design; the tail holds the dev stamps)
-#define PP_LAUNCH(BNv, Av, Dv, Gv)                                                                                                 \
+#define PP_LAUNCH(BNv, Av, Dv, Gv) do { if (!(Av) && (Gv) == 0 && stats_partial == nullptr) PP_LAUNCH1(BNv, false, Dv, 0, true); else PP_LAUNCH1(BNv, Av, Dv, Gv, false); } while (0)
+#define PP_LAUNCH1(BNv, Av, Dv, Gv, Tv)                                                                                            \
     do {                                                                                                                          \
-        auto kf = k_conv3x3_pp<BNv, Av, Dv, Gv>;                                                                                  \
+        auto kf = k_conv3x3_pp<BNv, Av, Dv, Gv, Tv>;                                                                                  \
         static bool at = false;                                                                                                   \
         if (!at) { PHX_CHECK_HIP(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); at = true; } \
         hipLaunchKernelGGL(kf, dim3(grid), dim3(512), BNv == 64 ? lds64 : lds32, (hipStream_t)stream, (const unsigned short*)x,    \
@@ -574,6 +603,7 @@ int phx_pp_launch(const void* x, const void* wpk, void* y, const float* bias, in
     }
     (void)dbg;
 #undef PP_LAUNCH
+#undef PP_LAUNCH1
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }
