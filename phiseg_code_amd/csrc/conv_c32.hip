@@ -133,7 +133,9 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const unsigned short* __
         // stores are younger than its DMA instructions, so they may stay in flight -- and the other stage is free: every wave has
         // issued the stores that read it.  (Raw barriers throughout: __syncthreads() would drain the DMA in flight with vmcnt(0).)
         C32_TRACE(it * 8 + 0);
-        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        // (first tile of the block: nothing but the DMA instructions is outstanding, so "all but 8" would not cover them)
+        if (it == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
         C32_TRACE(it * 8 + 1);
         // the next tile's patch: two DMA instructions behind the MFMAs of each of the first five groups (issued back to back they
         // take ~200 cycles apiece out of this wave's instruction stream; the matrix pipe drains its queue meanwhile)

@@ -28,6 +28,7 @@ static bool fwd_big_tiles(int B, int H, int W, int K, int N) {
 // SLOWER at K = 192 (the patch is staged once per 32 output channels).
 static bool fwd_ws64(int B, int H, int W, int K, int N) {
     if (!g_ws_policy || H % 16 != 0 || W % 32 != 0 || N % 32 != 0 || K % 32 != 0) return false;
+    if ((long)B * (H / 16) * (W / 32) >= 65536 || (double)B * H * W * (K > N ? K : N) >= 2147483648.0) return false;      // (tile index arithmetic of the large-map kernels)
     if (g_ws_policy >= 2) return true;
     if (N % 64 != 0 && K > 64) return false;
     return (long)B * (H / 16) * (W / 32) * (N / (N % 64 == 0 ? 64 : 32)) >= 512;

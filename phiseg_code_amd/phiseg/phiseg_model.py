@@ -205,6 +205,7 @@ class phiseg():
         self._multi = {}
         self.keep_checkpoint_every_n_hours = 3.0          # tf.train.Saver(max_to_keep=1, keep_checkpoint_every_n_hours=3) (phiseg_model.py:144)
         self._ckpt_permanent, self._ckpt_last_permanent = {}, time.time()
+        self._ckpt_written, self._ckpt_order = {}, {}      # per saver prefix: the steps this instance wrote (set / in write order)
         self.sess = Session(self, getattr(exp_config, 'compute_dtype', 'f32'), rng_seed=rng_seed, dist=dist)
         self.dist = dist
 
@@ -363,17 +364,31 @@ class phiseg():
             store.state.copy_(avg)
             engine.device_sync()
 
+    def _note_checkpoint(self, keep_prefix, path):
+        import re
+        m = re.search(re.escape(keep_prefix) + r'-(\d+)(?:\.npz)?$', os.path.basename(path))
+        if m:
+            st = int(m.group(1))
+            self._ckpt_written.setdefault(keep_prefix, set()).add(st)
+            order = self._ckpt_order.setdefault(keep_prefix, [])
+            if st in order:
+                order.remove(st)
+            order.append(st)
+
     def _prune_checkpoints(self, directory, keep_prefix, max_to_keep):
         """tf.train.Saver(max_to_keep=...) (phiseg_model.py:144-148): delete all but the newest `max_to_keep` checkpoints named
         <keep_prefix>-<step>(.npz | .index + .data-*); -> the retained prefixes, oldest first."""
         import glob
         import re
         found = {}
+        # like Saver._last_checkpoints: only checkpoints THIS instance has written are rotated -- files an earlier run left in the
+        # directory (a fresh run into an old log_dir writes model.ckpt-0 while model.ckpt-5000 is still there) are never touched
+        mine = self._ckpt_written.setdefault(keep_prefix, set())
         for f in glob.glob(os.path.join(directory, keep_prefix + '-*')):
             m = re.match(re.escape(keep_prefix) + r'-(\d+)(\.npz|\.index|\.data-\d+-of-\d+)$', os.path.basename(f))
-            if m:
+            if m and int(m.group(1)) in mine:
                 found.setdefault(int(m.group(1)), []).append(f)
-        steps = sorted(found)
+        steps = [st for st in self._ckpt_order.get(keep_prefix, []) if st in found]      # write order, as tf.train.Saver keeps it
         # keep_checkpoint_every_n_hours (3 for the training saver): a checkpoint that falls out of the max_to_keep window is kept for
         # good when that many hours of training have passed since the last one kept this way
         keep_h = self.keep_checkpoint_every_n_hours if keep_prefix == 'model.ckpt' else None
@@ -427,6 +442,8 @@ class phiseg():
             blob['global_step'] = np.asarray(step, dtype=np.int64)
             tf_checkpoint.write(path, blob)
             d = os.path.dirname(os.path.abspath(path))
+            if keep_prefix:
+                self._note_checkpoint(keep_prefix, path)
             kept = self._prune_checkpoints(d, keep_prefix, max_to_keep) if keep_prefix else None
             tf_checkpoint.update_checkpoint_state(d, os.path.basename(path), all_paths=[os.path.basename(k) for k in kept] if kept else None)
             return
@@ -439,6 +456,7 @@ class phiseg():
         np.savez(tmp, __step__=np.asarray([step], dtype=np.int32), **blob)
         os.replace(tmp, path)
         if keep_prefix:
+            self._note_checkpoint(keep_prefix, path)
             self._prune_checkpoints(os.path.dirname(os.path.abspath(path)), keep_prefix, max_to_keep)
 
     def load_weights(self, log_dir=None, type='latest', **kwargs):
