@@ -563,6 +563,221 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_dma_multi(const WgMJob
                                      (local / j.gdx) % j.gdy, local / (j.gdx * j.gdy), j.gdx, j.gdy, j.x2, j.K1);
 }
 
+// ---- filter gradient, 16x16 tiles, 64 x 64 channel blocks: the ANTI-PHASE form (round 4) -------------------------------------------
+// The two-blocks-per-CU kernel above has the structure the forward kernel had until round 3 -- "DMA a tile -> wait -> 144 MFMAs ->
+// barrier", two independent blocks drifting in and out of phase (matrix-pipe utilisation 0.56 in situ).  Here ONE 512-thread
+// work-group holds two halves of four waves (waves w and w + 4 share a SIMD); the halves take alternate pixel tiles of the block's
+// range into their own 73 KiB stage and run one phase apart, an s_barrier per phase:
+//     phase 2k      A: 16 k-steps x 9 MFMAs on its tile k          B: LDS-DMA of its tile k
+//     phase 2k + 1  A: LDS-DMA of its tile k + 1                   B: 16 k-steps x 9 MFMAs on its tile k
+// so a SIMD's matrix pipe is fed by one wave at a time while its partner issues the DMA instructions.  There is no per-tile
+// epilogue (the nine accumulators per wave run over all tiles); at the end B hands its accumulators to A through LDS and the block
+// writes ONE partial filter -- half the partial filters (workspace traffic, reduction work) of two 256-thread blocks.
+// The 20 transpose reads of the next k-step are pinned between the 9 MFMAs of the running one (two or four behind each): a burst
+// in front of them stalls a lone wave's matrix pipe.
+__device__ __forceinline__ void conv3x3_wgrad_pp_body(const unsigned short* __restrict__ x0, const unsigned short* __restrict__ dy,
+                                                      float* __restrict__ ws, int B, int H, int W, int Cin, int Cout, MTile g,
+                                                      int ntiles, int tiles_per_block, const int bx, const int by, const int bz,
+                                                      const int gdx, const int gdy,
+                                                      const unsigned short* __restrict__ x2 = nullptr, const int K1 = 0) {
+    constexpr int TCI = 64, TCO = 64;
+    const bool src2 = x2 != nullptr && by * TCI >= K1;       // concat-free input: see conv3x3_wgrad_body
+    const unsigned short* __restrict__ x = src2 ? x2 : x0;
+    const int xC = x2 == nullptr ? Cin : (src2 ? Cin - K1 : K1);
+    const int xc0 = by * TCI - (src2 ? K1 : 0);
+    constexpr int RBX = 128, RBD = 128, QX = 8, QD = 8, NPATCH = 324;
+    constexpr int XI = (NPATCH * QX + 63) / 64, DI = 256 * QD / 64;      // 41 + 32 wave-instructions (1 KiB each) per tile
+    constexpr int XN = (XI + 3) / 4, DN = DI / 4;
+    constexpr int SD_OFF = XI * 1024, STAGE = SD_OFF + 256 * RBD;        // 74 752 B per half
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int co0 = bz * TCO;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int half = wave >> 2, lw = wave & 3;
+    const int wi = lw & 1, wj = lw >> 1;
+    const unsigned sbase = (unsigned)(half * STAGE);
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    unsigned dcon[2], xcon[2][3][2];             // per-lane LDS constants, see k_conv3x3_wgrad
+    {
+        const int c16 = lane & 15, cb16 = (lane >> 4) & 1, khalf = lane >> 5;
+        const int chan_byte_x = (wi * 32 + cb16 * 16 + (c16 & 3) * 4) * 2;
+        const int chan_byte_d = (wj * 32 + cb16 * 16 + (c16 & 3) * 4) * 2;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int lxr = khalf * 8 + r * 4 + (c16 >> 2);
+            dcon[r] = sbase + (unsigned)(SD_OFF + wswz<RBD>(lxr, chan_byte_d));
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int par = 0; par < 2; ++par)
+                    xcon[r][kw][par] = sbase + (unsigned)((lxr + kw) * RBX + (chan_byte_x ^ (((((lxr + kw) >> 1) & 1) ^ par) << 6)));
+        }
+    }
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * xC * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * H * W * Cout * 2u), 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    // DMA of tile t into this half's stage: lane `lane` of wave-instruction j = lw + 4 n fills LDS slot e = 64 j + lane with the
+    // SOURCE piece p of patch pixel (px, py) / tile pixel m (the 64-byte half swizzle of the 128-byte rows is applied on the source
+    // side); recomputed per tile from an opaque copy of the lane id (no registers to spare beside the MFMA stream)
+    auto load_tile = [&](int t) __attribute__((always_inline)) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        int tt = t;
+        const int tx0 = (tt % g.tiles_x) << 4; tt /= g.tiles_x;
+        const int ty0 = (tt % g.tiles_y) << 4; tt /= g.tiles_y;
+        const int b0 = tt;
+#pragma unroll
+        for (int n = 0; n < XN; ++n) {
+            const int j = lw + 4 * n;
+            if (j < XI) {
+                const int e = j * 64 + ln;
+                const int pp = e >> 3, ps = e & 7;
+                const int p = ps ^ (((pp >> 1) & 1) << 2);
+                const int py = (int)(((unsigned)pp * 3641u) >> 16), px = pp - py * 18;        // pp / 18 for pp < 512
+                const int gx = tx0 + px - 1, gy = ty0 + py - 1;
+                const bool ok = pp < NPATCH && gx >= 0 && gx < W && gy >= 0 && gy < H;
+                const unsigned vo = ok ? (unsigned)((((b0 * H + gy) * W + gx) * xC) * 2 + p * 16) : 0xffffffffu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + sbase + j * 1024), 16, vo, xc0 * 2, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < DN; ++n) {
+            const int j = lw + 4 * n;
+            const int e = j * 64 + ln;
+            const int m = e >> 3, ps = e & 7;
+            const int p = ps ^ (((m >> 1) & 1) << 2);
+            const int ox = tx0 + (m & 15), oy = ty0 + (m >> 4);
+            const bool ok = ox < W && oy < H;
+            const unsigned vo = ok ? (unsigned)((((b0 * H + oy) * W + ox) * Cout) * 2 + p * 16) : 0xffffffffu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lds_ptr_t)(smem + sbase + SD_OFF + j * 1024), 16, vo, co0 * 2, 0, 0);
+        }
+    };
+    // the 16 k-steps of a tile.  k-step s (tile row s) multiplies the dy fragment of row s with the x fragments of patch rows s, s + 1,
+    // s + 2 (kh = 0, 1, 2) at the three column shifts kw: the fragment of (patch row R, kw) serves three k-steps, so it is read ONCE and
+    // kept in a rotating window of four rows -- 8 transpose reads per step (one patch row + the dy row) instead of 20; with four waves
+    // reading beside the partner half's DMA the 20-read form was bound by LDS bandwidth (5.1 K cycles a tile against 4.6 K of MFMA).
+    // The reads of step s + 1 (dy first, then patch row s + 3, used last by the kh = 2 MFMAs) sit one behind each MFMA of step s.
+    auto compute = [&]() __attribute__((always_inline)) {
+        s16x4 fd[2][2], fx[4][3][2];
+        auto rd_d = [&](auto stepc, auto rc) {
+            constexpr int SI = decltype(stepc)::value, r = decltype(rc)::value;
+            fd[SI & 1][r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(smem + (unsigned)(SI * 16 * RBD) + dcon[r]));
+        };
+        auto rd_x = [&](auto rowc, auto kwc, auto rc) {
+            constexpr int R = decltype(rowc)::value, kw = decltype(kwc)::value, r = decltype(rc)::value;
+            fx[R & 3][kw][r] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (s16x4 __attribute__((address_space(3)))*)(smem + (unsigned)(R * 18 * RBX) + xcon[r][kw][R & 1]));
+        };
+#define IC(v) std::integral_constant<int, (v)>()
+        rd_d(IC(0), IC(0)); rd_d(IC(0), IC(1));
+        {
+            auto head = [&](auto self, auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i < 9) { rd_x(IC(i / 3), IC(i % 3), IC(0)); rd_x(IC(i / 3), IC(i % 3), IC(1)); self(self, IC(i + 1)); }
+            };
+            head(head, IC(0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        auto steps = [&](auto self, auto stepc) {
+            constexpr int SI = decltype(stepc)::value;
+            if constexpr (SI < 16) {
+                constexpr int Bf = SI & 1;
+                constexpr bool more = SI + 1 < 16;
+                const s16x8 dtmp = {fd[Bf][0][0], fd[Bf][0][1], fd[Bf][0][2], fd[Bf][0][3], fd[Bf][1][0], fd[Bf][1][1], fd[Bf][1][2], fd[Bf][1][3]};
+                const bf16x8 bfrag = __builtin_bit_cast(bf16x8, dtmp);
+                auto slot = [&](auto kc) {
+                    constexpr int k = decltype(kc)::value, kh = k / 3, kw = k % 3, Rs = (SI + kh) & 3;
+                    const s16x8 atmp = {fx[Rs][kw][0][0], fx[Rs][kw][0][1], fx[Rs][kw][0][2], fx[Rs][kw][0][3],
+                                        fx[Rs][kw][1][0], fx[Rs][kw][1][1], fx[Rs][kw][1][2], fx[Rs][kw][1][3]};
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, atmp), bfrag, acc[k], 0, 0, 0);
+                    if constexpr (more) {
+                        if constexpr (k < 2) rd_d(IC(SI + 1), kc);
+                        else if constexpr (k < 8) rd_x(IC(SI + 3), IC((k - 2) >> 1), IC((k - 2) & 1));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                slot(IC(0)); slot(IC(1)); slot(IC(2)); slot(IC(3)); slot(IC(4)); slot(IC(5)); slot(IC(6)); slot(IC(7)); slot(IC(8));
+                self(self, IC(SI + 1));
+            }
+        };
+        steps(steps, IC(0));
+#undef IC
+    };
+#define WPP_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    const int t_begin = bx * tiles_per_block;
+    const int t_end = min(ntiles, t_begin + tiles_per_block);
+    const int n = t_end - t_begin;
+    const int nA = (n + 1) >> 1, nh = half ? (n >> 1) : nA;       // tiles of A / of this half: t_begin + half + 2 k
+    PHX_BLOCKLOG_BEGIN();
+    if (half == 0 && nh > 0) load_tile(t_begin);
+    WPP_BARRIER();
+    if (half) {
+        if (nh > 0) load_tile(t_begin + 1);
+        WPP_BARRIER();
+    }
+    for (int k = 0; k < nA; ++k) {
+        if (k < nh) compute();
+        WPP_BARRIER();
+        if (k + 1 < nh) load_tile(t_begin + half + 2 * (k + 1));
+        WPP_BARRIER();
+    }
+    if (half == 0) WPP_BARRIER();
+    // B -> A through LDS (both stages are free), then ONE partial filter per block: ws[(cblock * gdx + bx)][9][64][64]; C layout:
+    // col = lane & 31 -> co, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> ci
+    typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+    f32x4_t* const pr = reinterpret_cast<f32x4_t*>(smem) + (size_t)lw * (9 * 4 * 64) + lane;
+    if (half)
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pr[(k * 4 + q) * 64] = f32x4_t{acc[k][4 * q], acc[k][4 * q + 1], acc[k][4 * q + 2], acc[k][4 * q + 3]};
+    WPP_BARRIER();
+#undef WPP_BARRIER
+    if (half == 0) {
+        const size_t cb = (size_t)bz * gdy + by;
+        float* wp = ws + (cb * gdx + bx) * (size_t)(9 * TCI * TCO);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4_t v = pr[(k * 4 + q) * 64];
+                acc[k][4 * q] += v[0]; acc[k][4 * q + 1] += v[1]; acc[k][4 * q + 2] += v[2]; acc[k][4 * q + 3] += v[3];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cil = wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                wp[(k * TCI + cil) * TCO + wj * 32 + (lane & 31)] = acc[k][r];
+            }
+        }
+    }
+    PHX_BLOCKLOG_END();
+}
+
+__global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_pp(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
+                                                             float* __restrict__ ws, int B, int H, int W, int Cin, int Cout, MTile g,
+                                                             int ntiles, int tiles_per_block, const unsigned short* __restrict__ x2,
+                                                             int K1) {
+    conv3x3_wgrad_pp_body(x, dy, ws, B, H, W, Cin, Cout, g, ntiles, tiles_per_block, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x,
+                          gridDim.y, x2, K1);
+}
+__global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_pp_multi(const WgMJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const WgMJob j = jobs[lo];
+    const int local = blockIdx.x - j.blk0;
+    conv3x3_wgrad_pp_body(j.x, j.dy, j.ws, j.B, j.H, j.W, j.Cin, j.Cout, j.g, j.ntiles, j.tpb, local % j.gdx,
+                          (local / j.gdx) % j.gdy, local / (j.gdx * j.gdy), j.gdx, j.gdy, j.x2, j.K1);
+}
+
 // dw[k][ci][co] += sum over the nslice partial tiles written by the filter-gradient kernels.  A thread owns four
 // consecutive co entries (16-byte loads); block = 64 such quads x 4 slice groups; gridDim.y further splits the slices
 // (one atomic per entry per y-block); four slices are in flight per thread.
@@ -634,6 +849,7 @@ extern "C" {
 static bool wgrad_dma_enabled() { return true; }
 // dynamic LDS of the LDS-DMA filter-gradient kernels: the staged tile, or the 2 x 36 KiB of the wave-group reduction
 static size_t wgrad_dma_lds(int tci, int tco) {
+    if (tci == 64 && tco == 64) return (size_t)2 * (41 * 1024 + 256 * 128);      // k_conv3x3_wgrad_pp: a stage per half
     const size_t stage = (size_t)((324 * (tci / 8) + 63) / 64) * 1024 + (size_t)256 * tco * 2;
     const size_t red = (tci == 64 && tco == 64) ? 0 : (size_t)2 * 9 * 16 * 64 * sizeof(float);
     return stage > red ? stage : red;
@@ -653,8 +869,14 @@ static int wgrad_plan(int B, int H, int W, int Cin, int Cout, MTile* g, int* tci
     // re-reads) a full 9*TCI*TCO partial filter
     int target_blocks = cblocks <= 4 && *tci == 64 && *tco == 64 ? 512 : 384;
     if (ntiles <= 256 && target_blocks > 256) target_blocks = 256;
-    if (target_override > 0) target_blocks = target_override;                     // deferred multi-layer launches (see below)
+    // the anti-phase kernel (64 x 64 channel blocks on 16 x 16 tiles) runs ONE 512-thread work-group per CU
+    const bool pp = wgrad_dma_enabled() && g->tws == 4 && g->ths == 4 && g->tb == 1 && *tci == 64 && *tco == 64;
+    if (pp) target_blocks = 256;
+    // deferred multi-layer launches (see below); a 512-thread anti-phase block is two of the 256-thread blocks the target counts
+    // (measured in situ, pp jobs at 96 / 64 / 48 / 32: launch 0.690 / 0.669 / 0.633 / 0.723 ms, reduction 0.276 / 0.254 / 0.226 / 0.222 ms)
+    if (target_override > 0) target_blocks = pp ? (target_override + 1) / 2 : target_override;
     int split = (target_blocks + cblocks - 1) / cblocks;
+    if (pp && target_override <= 0) split = target_blocks / cblocks;              // (never a second round of a few blocks)
     if (split > ntiles) split = ntiles;
     if (split < 1) split = 1;
     *tpb = (ntiles + split - 1) / split;
@@ -757,7 +979,8 @@ int phx_conv3x3_wgrad_multi(const void* jobs_dev, int njobs, int total_blocks, i
         WM_ATTR(32, 32, false); WM_ATTR(32, 64, false); WM_ATTR(64, 32, false); WM_ATTR(64, 64, false);
         WM_ATTR(32, 32, true); WM_ATTR(32, 64, true); WM_ATTR(64, 32, true); WM_ATTR(64, 64, true);
 #define WMD_ATTR(A, Bq) PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_dma_multi<A, Bq>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-        WMD_ATTR(32, 32); WMD_ATTR(32, 64); WMD_ATTR(64, 32); WMD_ATTR(64, 64);
+        WMD_ATTR(32, 32); WMD_ATTR(32, 64); WMD_ATTR(64, 32);
+        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_pp_multi, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef WMD_ATTR
         attr_set = true;
     }
@@ -780,7 +1003,10 @@ int phx_conv3x3_wgrad_multi(const void* jobs_dev, int njobs, int total_blocks, i
         case 8: WMD_LAUNCH(32, 32); break;
         case 9: WMD_LAUNCH(32, 64); break;
         case 10: WMD_LAUNCH(64, 32); break;
-        default: WMD_LAUNCH(64, 64); break;
+        default:
+            hipLaunchKernelGGL(k_conv3x3_wgrad_pp_multi, dim3((unsigned)total_blocks), dim3(512), lds_bytes, (hipStream_t)stream,
+                               (const WgMJob*)jobs_dev, njobs);
+            break;
 #undef WMD_LAUNCH
     }
 #undef WM_LAUNCH
@@ -830,14 +1056,21 @@ static int wgrad_impl(const void* x, const void* dy, float* dw_hwio, void* works
     if (wgrad_dma_enabled() && ws && g.tws == 4 && g.ths == 4 && g.tb == 1) {
         static bool dattr = false;
 #define WD_ATTR(A, Bq) PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_dma<A, Bq>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-        if (!dattr) { WD_ATTR(64, 64); WD_ATTR(64, 32); WD_ATTR(32, 64); WD_ATTR(32, 32); dattr = true; }
+        if (!dattr) {
+            WD_ATTR(64, 32); WD_ATTR(32, 64); WD_ATTR(32, 32);
+            PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_pp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            dattr = true;
+        }
 #undef WD_ATTR
 #define WD_LAUNCH(A, Bq)                                                                                              \
     hipLaunchKernelGGL((k_conv3x3_wgrad_dma<A, Bq>), dim3(gx, Cin / A, Cout / Bq), dim3(256),                         \
                        wgrad_dma_lds(A, Bq), (hipStream_t)stream,                                                     \
                        (const unsigned short*)x, (const unsigned short*)dy, ws, B, H, W, Cin, Cout, g, ntiles, tpb,    \
                        (const unsigned short*)x2, K1)
-        if (tci == 64 && tco == 64) WD_LAUNCH(64, 64);
+        if (tci == 64 && tco == 64)
+            hipLaunchKernelGGL(k_conv3x3_wgrad_pp, dim3(gx, Cin / 64, Cout / 64), dim3(512), wgrad_dma_lds(64, 64), (hipStream_t)stream,
+                               (const unsigned short*)x, (const unsigned short*)dy, ws, B, H, W, Cin, Cout, g, ntiles, tpb,
+                               (const unsigned short*)x2, K1);
         else if (tci == 64) WD_LAUNCH(64, 32);
         else if (tco == 64) WD_LAUNCH(32, 64);
         else WD_LAUNCH(32, 32);

@@ -301,6 +301,32 @@ def _mfma_case(L, case):
     close(host(dw2), wr.grad.numpy(), 1e-4, "mfma wgrad (workspace)")
 
 
+# the anti-phase filter-gradient kernel (k_conv3x3_wgrad_pp: 64 x 64 channel blocks on 16 x 16 pixel tiles): one tile (half B idle), odd
+# and even tile counts per block, maps that are not multiples of the tile, several channel blocks, the two-tensor (concat-free) input
+@pytest.mark.parametrize("case", [(5, 16, 16, 64, 64, 0), (3, 16, 32, 64, 64, 0), (6, 16, 16, 64, 128, 0), (2, 40, 24, 128, 64, 0),
+                                  (9, 48, 48, 192, 192, 0), (2, 64, 64, 192, 192, 0), (3, 32, 32, 128, 64, 64), (67, 16, 16, 64, 64, 0)])
+def test_conv3x3_wgrad_anti_phase_64x64(L, case):
+    B, H, W, K, N, K1 = case
+    x, dy = RNG.standard_normal((B, H, W, K)), RNG.standard_normal((B, H, W, N))
+    xr = rounded(x, BF16)
+    wr = torch.zeros(3, 3, K, N, dtype=torch.float64, requires_grad=True)
+    (T.conv2d_same(xr, wr) * rounded(dy, BF16)).sum().backward()
+    dyd = dev(dy, BF16)
+    wsb = int(L.conv3x3_wgrad_ws_bytes_dual(B, H, W, K, N, K1))
+    plan = (ctypes.c_int * 6)()
+    L.conv3x3_wgrad_reduce_plan_dual(B, H, W, K, N, K1, plan)
+    assert plan[0] and plan[2] == 64 and plan[3] == 64          # workspace path, 64 x 64 channel blocks
+    ws = torch.empty(wsb // 4, dtype=torch.float32).cuda()
+    dw = torch.full((3, 3, K, N), 0.5, dtype=torch.float32).cuda()      # accumulate semantics
+    if K1:
+        xa, xb = dev(x[..., :K1], BF16), dev(x[..., K1:], BF16)
+        L.conv3x3_wgrad_mfma_bf16_dual(xa.data_ptr(), xb.data_ptr(), K1, dyd.data_ptr(), dw.data_ptr(), ws.data_ptr(), wsb, B, H, W, K, N, 1, S())
+    else:
+        xd = dev(x, BF16)
+        L.conv3x3_wgrad_mfma_bf16(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), ws.data_ptr(), wsb, B, H, W, K, N, S())
+    close(host(dw) - 0.5, wr.grad.numpy(), 1e-4, "anti-phase filter gradient")
+
+
 def test_wgrad_deferred_multi_layer_reduction(L):
     """phx_conv3x3_wgrad_mfma_bf16_partial + ONE phx_wgrad_reduce_multi over several layers == the per-layer launches."""
     import ctypes
