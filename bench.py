@@ -294,11 +294,13 @@ def main():
             hb = {}
             for tag, by, ms_, shp in rows_all:
                 if tag.startswith("bytes_"):
-                    a = hb.setdefault((tag, by >= 64e6), [0.0, 0.0, 0])
+                    cls = sum(by >= lim for lim in (1e6, 4e6, 16e6, 64e6))
+                    a = hb.setdefault((tag, cls), [0.0, 0.0, 0])
                     a[0] += by; a[1] += ms_; a[2] += 1
             for key in sorted(hb):
                 a = hb[key]
-                print("### %-24s %-8s launches=%3d %8.3f ms  %8.1f GB/s" % (key[0], ">=64MB" if key[1] else "<64MB", a[2], a[1], a[0] / a[1] / 1e6),
+                print("### %-24s %-8s launches=%3d %8.3f ms  %8.1f GB/s  %6.1f us/launch" % (
+                    key[0], ("<1MB", "1-4MB", "4-16MB", "16-64MB", ">=64MB")[key[1]], a[2], a[1], a[0] / a[1] / 1e6, 1e3 * a[1] / a[2]),
                       file=sys.stderr)
         if args.profile_table:
             for tag, fl_, ms_, shp in sorted(rows, key=lambda r: -r[2]):
