@@ -773,9 +773,16 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_pp_multi(const WgMJob*
         if (jobs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const WgMJob j = jobs[lo];
+    // XCD-aware order (work-group id mod 8 is the XCD; every job starts on a multiple of 8): the gdy x gdz channel blocks that read the
+    // same pixel slice are 8 ids apart -- one XCD, dispatched together -- so the slice is fetched into ONE L2 instead of up to four
     const int local = blockIdx.x - j.blk0;
-    conv3x3_wgrad_pp_body(j.x, j.dy, j.ws, j.B, j.H, j.W, j.Cin, j.Cout, j.g, j.ntiles, j.tpb, local % j.gdx,
-                          (local / j.gdx) % j.gdy, local / (j.gdx * j.gdy), j.gdx, j.gdy, j.x2, j.K1);
+    const int cb = j.gdy * j.gdz, t = local >> 3;
+    // (wgrad_plan gives deferred jobs a multiple of 8 slices whenever the layer has that many tiles: padding holes leave XCDs idle --
+    // work-groups are bound to XCDs statically -- and cost 0.81 ms instead of 0.65 for the launch)
+    const int c = t % cb, bx = (t / cb) * 8 + (local & 7);
+    if (bx >= j.gdx) return;
+    conv3x3_wgrad_pp_body(j.x, j.dy, j.ws, j.B, j.H, j.W, j.Cin, j.Cout, j.g, j.ntiles, j.tpb, bx, c % j.gdy, c / j.gdy, j.gdx, j.gdy,
+                          j.x2, j.K1);
 }
 
 // dw[k][ci][co] += sum over the nslice partial tiles written by the filter-gradient kernels.  A thread owns four
@@ -877,6 +884,7 @@ static int wgrad_plan(int B, int H, int W, int Cin, int Cout, MTile* g, int* tci
     if (target_override > 0) target_blocks = pp ? (target_override + 1) / 2 : target_override;
     int split = (target_blocks + cblocks - 1) / cblocks;
     if (pp && target_override <= 0) split = target_blocks / cblocks;              // (never a second round of a few blocks)
+    if (pp && target_override > 0) split = (split + 7) & ~7;                      // whole slices per XCD (k_conv3x3_wgrad_pp_multi)
     if (split > ntiles) split = ntiles;
     if (split < 1) split = 1;
     *tpb = (ntiles + split - 1) / split;
@@ -965,6 +973,7 @@ int phx_conv3x3_wgrad_multi_job_dual(const void* x, const void* x2, int K1, cons
     memcpy(job_out, &j, sizeof(j));
     info4[0] = 1 + (tco == 64 ? 1 : 0) + (tci == 64 ? 2 : 0) + (fast16 ? 8 : npatch > 400 ? 4 : 0);     // 9..12: LDS-DMA kernels
     info4[1] = j.gdx * j.gdy * j.gdz;
+    if (info4[0] == 12) info4[1] = (j.gdx + 7) / 8 * 8 * j.gdy * j.gdz;      // k_conv3x3_wgrad_pp_multi: slices padded to the 8 XCDs
     info4[2] = fast16 ? (int)wgrad_dma_lds(tci, tco) : npatch * tci * 2 + 256 * tco * 2;
     info4[3] = use_ws;
     info4[4] = gx * wk; info4[5] = tci; info4[6] = tco;                       // reduction job of this launch (phx_wgrad_reduce_multi)
