@@ -25,12 +25,16 @@ def _launch(nproc, out_dir, case, dtype, steps, port, extra_env=None):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-def test_two_rank_engine_step_equals_single_process_big_batch(tmp_path):
+@pytest.mark.parametrize("mode", ["atomics", "deterministic"])
+def test_two_rank_engine_step_equals_single_process_big_batch(tmp_path, mode):
+    """mode "deterministic" (PHX_DETERMINISTIC=1: ordered reductions, no atomics) holds the tight 2e-3 gradient bound; the default
+    mode's bound absorbs the run-to-run order of its atomic accumulations (advisor finding, round 3)."""
     import json
     case = "tiny_phiseg_gn4"
+    xenv = {"PHX_DETERMINISTIC": "1"} if mode == "deterministic" else None
     d2, d1 = tmp_path / "dp2", tmp_path / "single"
     d2.mkdir(); d1.mkdir()
-    _launch(2, str(d2), case, "f32", 2, 29541)
+    _launch(2, str(d2), case, "f32", 2, 29541 if xenv is None else 29547, xenv)
     # the single-process reference: the same worker with a fixture whose batch is twice as large
     g = np.load(os.path.join(ROOT, "tests", "golden", case + ".npz"))
     cfg = json.loads(str(g["meta/cfg_json"]))
@@ -41,7 +45,7 @@ def test_two_rank_engine_step_equals_single_process_big_batch(tmp_path):
     env_golden = os.environ.get("PHX_TEST_GOLDEN_DIR")
     os.environ["PHX_TEST_GOLDEN_DIR"] = str(big)
     try:
-        _launch(1, str(d1), case + "_x2", "f32", 2, 0)
+        _launch(1, str(d1), case + "_x2", "f32", 2, 0, xenv)
     finally:
         if env_golden is None:
             os.environ.pop("PHX_TEST_GOLDEN_DIR", None)
@@ -59,7 +63,8 @@ def test_two_rank_engine_step_equals_single_process_big_batch(tmp_path):
             # test_model_gpu.GRAD_RTOL); Adam moves a weight by ~lr = 1e-5 per step whatever the gradient's size
             # (atomic accumulation order varies run to run: 3.2e-3 of a tensor's largest entry seen once in eight runs of this test,
             # always in the first run on a cold device -- 1e-2 stays 3x under the conditioning bound)
-            tol = 1e-2 * max(np.abs(ref[k]).max(), 1e-6) if k.startswith("grad/") else 5e-5
+            gtol = 2e-3 if mode == "deterministic" else 1e-2
+            tol = gtol * max(np.abs(ref[k]).max(), 1e-6) if k.startswith("grad/") else 5e-5
             np.testing.assert_allclose(r0[k], ref[k], rtol=0, atol=tol, err_msg=k)
             np.testing.assert_allclose(r1[k], r0[k], rtol=0, atol=0, err_msg=k + " (replicas diverged)")
             n += 1
