@@ -35,6 +35,9 @@ for (B, H, W, K, N) in shapes:
     a = log.cpu().numpy().reshape(-1, 4)
     a = a[a[:, 1] != 0]
     nb = len(a)
+    if nb == 0:
+        print(which, (B, H, W, K, N), 'kernel %.1f us: no block log (pair kernel)' % us)
+        continue
     os.makedirs('gpurun_out', exist_ok=True); np.save('gpurun_out/blocklog_%s_%d_%d.npy' % (which, H, K), a)
     # the shader-clock counter is per XCD (unsynchronised): cluster the blocks by counter epoch
     order = np.argsort(a[:, 0])
