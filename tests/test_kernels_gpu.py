@@ -327,6 +327,71 @@ def test_conv3x3_wgrad_anti_phase_64x64(L, case):
     close(host(dw) - 0.5, wr.grad.numpy(), 1e-4, "anti-phase filter gradient")
 
 
+@pytest.mark.parametrize("case", [(64, 128, 128, 128, 128), (64, 64, 64, 192, 192), (64, 128, 128, 64, 128), (64, 128, 128, 192, 32),
+                                  (64, 128, 128, 32, 32), (64, 32, 32, 128, 128), (64, 16, 16, 192, 192)])
+def test_conv3x3_forward_full_size_vs_direct_kernel_and_statistics(L, case):
+    """BASELINE-size forward launches (the default policy's kernels: pair kernel, k_conv3x3_c32, 256-pixel kernels), where the oracle
+    takes minutes: the bf16 output and the epilogue's per-channel statistics against the fp32 direct kernel (itself checked against
+    the oracle above) on the same bf16 input and bf16-rounded filter; the data gradient is the same launch with the flipped pack."""
+    B, H, W, K, N = case
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.relu(torch.randn(B, H, W, K, device="cuda", generator=g)).to(torch.bfloat16)
+    w = (torch.randn(3, 3, K, N, device="cuda", generator=g) / np.sqrt(9 * K)).to(torch.bfloat16).float().contiguous()
+    wf = torch.empty(9 * N * K, dtype=torch.bfloat16, device="cuda")
+    wg = torch.empty(9 * N * K, dtype=torch.bfloat16, device="cuda")
+    L.pack_conv3x3_bf16(w.data_ptr(), wf.data_ptr(), wg.data_ptr(), K, N, S())
+    ntile = L.conv3x3_mfma_bf16_tiles(B, H, W, K, N)
+    part = torch.zeros(ntile, 2, N, dtype=torch.float32, device="cuda")
+    y = torch.empty(B, H, W, N, dtype=torch.bfloat16, device="cuda")
+    L.conv3x3_mfma_bf16(x.data_ptr(), wf.data_ptr(), y.data_ptr(), None, 0, part.data_ptr(), B, H, W, K, N, S())
+    ref = torch.empty(B, H, W, N, dtype=torch.float32, device="cuda")
+    L.conv2d_direct(x.data_ptr(), BF16, w.data_ptr(), None, ref.data_ptr(), F32, B, H, W, K, N, 3, 0, 0, None, S())
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    assert float((y.float() - ref).abs().max()) <= 6e-3 * scale            # bf16 output rounding (2^-9 of the value, values up to `scale`)
+    sums = torch.zeros(N, 2, dtype=torch.float32, device="cuda")
+    L.norm_reduce_partials(part.data_ptr(), ntile, N, sums.data_ptr(), S())
+    torch.cuda.synchronize()
+    yf = y.float().reshape(-1, N).double()
+    close(host(sums)[:, 0], yf.sum(0).cpu().numpy(), 1e-4, "epilogue sum (of the stored bf16 values)")
+    close(host(sums)[:, 1], (yf * yf).sum(0).cpu().numpy(), 1e-4, "epilogue sum of squares")
+    # data gradient: dx = conv(dy, flipped / transposed filter) -- the direct kernel's dgrad mode on the same tensors
+    dy = (torch.randn(B, H, W, N, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    dx = torch.empty(B, H, W, K, dtype=torch.bfloat16, device="cuda")
+    L.conv3x3_mfma_bf16(dy.data_ptr(), wg.data_ptr(), dx.data_ptr(), None, 0, None, B, H, W, N, K, S())
+    dref = torch.empty(B, H, W, K, dtype=torch.float32, device="cuda")
+    L.conv2d_direct(dy.data_ptr(), BF16, w.data_ptr(), None, dref.data_ptr(), F32, B, H, W, K, N, 3, 0, 1, None, S())
+    torch.cuda.synchronize()
+    assert float((dx.float() - dref).abs().max()) <= 6e-3 * float(dref.abs().max())
+
+
+@pytest.mark.parametrize("case", [(64, 128, 128, 128, 128), (64, 64, 64, 192, 192)])
+def test_conv3x3_wgrad_full_size_batch_additivity_and_direct_kernel(L, case):
+    """BASELINE-size filter gradients (the shapes bench.py's roofline names), where the oracle takes minutes: (1) against the fp32
+    direct kernel (itself checked against the oracle above) on the same bf16 tensors, (2) additivity over the batch -- the gradient of
+    the 64 images equals the sum of the gradients of the two halves (other pixel-slice plans, other partial-filter counts)."""
+    B, H, W, K, N = case
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.relu(torch.randn(B, H, W, K, device="cuda", generator=g)).to(torch.bfloat16)
+    dy = (torch.randn(B, H, W, N, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+
+    def wgrad(xb, dyb):
+        b = xb.shape[0]
+        wsb = int(L.conv3x3_wgrad_ws_bytes(b, H, W, K, N))
+        ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device="cuda")
+        dw = torch.zeros(3, 3, K, N, dtype=torch.float32, device="cuda")
+        L.conv3x3_wgrad_mfma_bf16(xb.data_ptr(), dyb.data_ptr(), dw.data_ptr(), ws.data_ptr(), wsb, b, H, W, K, N, S())
+        torch.cuda.synchronize()
+        return dw
+    full = wgrad(x, dy)
+    halves = wgrad(x[:B // 2].contiguous(), dy[:B // 2].contiguous()) + wgrad(x[B // 2:].contiguous(), dy[B // 2:].contiguous())
+    close(host(halves), host(full), 2e-5, "batch additivity")
+    ref = torch.zeros(3, 3, K, N, dtype=torch.float32, device="cuda")
+    L.conv2d_direct_wgrad(x.data_ptr(), BF16, dy.data_ptr(), BF16, ref.data_ptr(), None, B, H, W, K, N, 3, S())
+    torch.cuda.synchronize()
+    close(host(full), host(ref), 1e-4, "MFMA filter gradient vs the fp32 direct kernel")
+
+
 def test_wgrad_deferred_multi_layer_reduction(L):
     """phx_conv3x3_wgrad_mfma_bf16_partial + ONE phx_wgrad_reduce_multi over several layers == the per-layer launches."""
     import ctypes
