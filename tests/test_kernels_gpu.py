@@ -365,6 +365,46 @@ def test_conv3x3_forward_full_size_vs_direct_kernel_and_statistics(L, case):
     assert float((dx.float() - dref).abs().max()) <= 6e-3 * float(dref.abs().max())
 
 
+@pytest.mark.parametrize("case", [(64, 128, 128, 128, 128), (64, 64, 64, 192, 192), (64, 128, 128, 32, 32), (64, 16, 16, 192, 192),
+                                  (64, 4, 4, 192, 192)])
+def test_conv3x3_full_size_adjoint_identities(L, case):
+    """The three MFMA launches of a layer at BASELINE sizes are each other's adjoints (no reference kernel involved):
+    <conv(x, w), dy> = <x, dgrad(dy, w)> = <w, wgrad(x, dy)> -- forward, data gradient (flipped pack) and filter gradient agree on one
+    number up to the bf16 rounding of y and dx, which averages out over >= 10^6 terms."""
+    B, H, W, K, N = case
+    g = torch.Generator(device="cuda").manual_seed(13)
+    x = torch.randn(B, H, W, K, device="cuda", generator=g).to(torch.bfloat16)
+    dy = torch.randn(B, H, W, N, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(3, 3, K, N, device="cuda", generator=g) / np.sqrt(9 * K)).to(torch.bfloat16).float().contiguous()
+    wf = torch.empty(9 * N * K, dtype=torch.bfloat16, device="cuda")
+    wg = torch.empty(9 * N * K, dtype=torch.bfloat16, device="cuda")
+    L.pack_conv3x3_bf16(w.data_ptr(), wf.data_ptr(), wg.data_ptr(), K, N, S())
+
+    def conv(src, pack, k, n):
+        nb = int(L.conv3x3_mfma_ws_bytes(B, H, W, k, n))
+        ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device="cuda")
+        out = torch.empty(B, H, W, n, dtype=torch.bfloat16, device="cuda")
+        L.conv3x3_mfma_bf16_ws(src.data_ptr(), pack.data_ptr(), out.data_ptr(), None, 0, None, ws.data_ptr() if nb else None, nb, B, H, W,
+                               k, n, S())
+        torch.cuda.synchronize()
+        return out
+    y, dx = conv(x, wf, K, N), conv(dy, wg, N, K)
+    wsb = int(L.conv3x3_wgrad_ws_bytes(B, H, W, K, N))
+    ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device="cuda")
+    dw = torch.zeros(3, 3, K, N, dtype=torch.float32, device="cuda")
+    L.conv3x3_wgrad_mfma_bf16(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr() if wsb else None, wsb, B, H, W, K, N, S())
+    torch.cuda.synchronize()
+    a = float((y.double() * dy.double()).sum())
+    b = float((dx.double() * x.double()).sum())
+    c = float((dw.double() * w.double()).sum())
+    # the bf16 rounding of y (relative 2^-9 / sqrt(3) per element, independent) moves <y, dy> by ~1.1e-3 |y| |dy| / sqrt(n); likewise dx.
+    # Measured: -3187.2 / -3161.3 / -3161.0 on 128 -> 128 @ 128 x 128 (bound 92), 108.28 / 107.85 / 107.63 on 192 -> 192 @ 4 x 4 (bound 2.9);
+    # a launch that dropped one of the nine taps would be off by a ninth of the inner product's own spread |y| |dy| / sqrt(n) ~ 10^4.
+    tol = 8e-3 * float(np.sqrt(float((y.double() ** 2).sum()) * float((dy.double() ** 2).sum()))) / np.sqrt(y.numel())
+    print("adjoint identities %s: <y, dy> %.6e  <dx, x> %.6e  <dw, w> %.6e  (bound %.3e)" % (case, a, b, c, tol))
+    assert abs(a - c) <= tol and abs(b - c) <= tol, (a, b, c, tol)
+
+
 @pytest.mark.parametrize("case", [(64, 128, 128, 128, 128), (64, 64, 64, 192, 192)])
 def test_conv3x3_wgrad_full_size_batch_additivity_and_direct_kernel(L, case):
     """BASELINE-size filter gradients (the shapes bench.py's roofline names), where the oracle takes minutes: (1) against the fp32
