@@ -831,6 +831,42 @@ def test_avgpool_and_bilinear(L, case):
     close(host(dx), xr.grad.numpy(), tol if dt == F32 else 1e-2, "bilinear bwd")
 
 
+@pytest.mark.parametrize("case", [(64, 64, 64, 64), (64, 128, 128, 32), (64, 32, 32, 192)])
+def test_avgpool_and_bilinear_full_size(L, case):
+    """BASELINE-size pooling / up-sampling launches (bf16): 2 x 2 average pooling against torch's on the device (the windows never
+    straddle the border at even sizes, where TF's SAME padding and count-excluding average coincide with the plain one); its backward
+    and the legacy bilinear x2 pair through the adjoint identity <op(x), g> = <x, op^T(g)> and, for the bilinear forward, the
+    interpolation property that a constant image stays constant (each output is a convex combination)."""
+    B, H, W, C = case
+    g = torch.Generator(device="cuda").manual_seed(17)
+    x = torch.randn(B, H, W, C, device="cuda", generator=g).to(torch.bfloat16)
+    p = torch.empty(B, H // 2, W // 2, C, dtype=torch.bfloat16, device="cuda")
+    L.avgpool2x2_fwd(x.data_ptr(), BF16, p.data_ptr(), B, H, W, C, S())
+    ref = torch.nn.functional.avg_pool2d(x.float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    torch.cuda.synchronize()
+    assert float((p.float() - ref).abs().max()) <= 6e-3 * float(ref.abs().max())
+    gp = torch.randn(B, H // 2, W // 2, C, device="cuda", generator=g).to(torch.bfloat16)
+    dx = torch.empty_like(x)
+    L.avgpool2x2_bwd(gp.data_ptr(), BF16, dx.data_ptr(), B, H, W, C, S())
+    u = torch.empty(B, 2 * H, 2 * W, C, dtype=torch.bfloat16, device="cuda")
+    L.bilinear_up2x_fwd(x.data_ptr(), BF16, u.data_ptr(), B, H, W, C, S())
+    gu = torch.randn(B, 2 * H, 2 * W, C, device="cuda", generator=g).to(torch.bfloat16)
+    dxu = torch.empty_like(x)
+    L.bilinear_up2x_bwd(gu.data_ptr(), BF16, dxu.data_ptr(), B, H, W, C, S())
+    ones = torch.full_like(x, 1.5)
+    uc = torch.empty_like(u)
+    L.bilinear_up2x_fwd(ones.data_ptr(), BF16, uc.data_ptr(), B, H, W, C, S())
+    torch.cuda.synchronize()
+    assert float((uc.float() - 1.5).abs().max()) == 0.0
+
+    def adjoint(out, gout, xin, gin, what):
+        a, b = float((out.double() * gout.double()).sum()), float((xin.double() * gin.double()).sum())
+        tol = 8e-3 * float(np.sqrt(float((out.double() ** 2).sum()) * float((gout.double() ** 2).sum()))) / np.sqrt(min(out.numel(), xin.numel()))
+        assert abs(a - b) <= tol, (what, a, b, tol)
+    adjoint(p, gp, x, dx, "average pool")
+    adjoint(u, gu, x, dxu, "bilinear x2")
+
+
 def test_concat_split_add_cast_misc(L):
     for (Ca, Cb, dt) in [(32, 32, BF16), (128, 64, BF16), (32, 6, F32), (1, 2, F32), (8, 4, F32)]:
         a, b = RNG.standard_normal((2, 4, 4, Ca)), RNG.standard_normal((2, 4, 4, Cb))
