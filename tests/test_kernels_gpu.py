@@ -985,6 +985,28 @@ def test_kl_and_adam(L):
     assert int(step.cpu()[0]) == 3
 
 
+def test_adam_full_parameter_arena(L):
+    """phx_adam_tf1 over an arena of the benchmark's size (17.8 M parameters, not a multiple of 4) for three steps with a fresh
+    gradient each: against the oracle's TF 1.12 epsilon-hat update evaluated in float64 on the device."""
+    n = 17824003
+    g = torch.Generator(device="cuda").manual_seed(19)
+    p = torch.randn(n, device="cuda", generator=g)
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    lr = torch.tensor([1e-3], device="cuda")
+    pr, mr, vr = p.double(), m.double(), v.double()
+    for t in range(3):
+        gr = torch.randn(n, device="cuda", generator=g) * (10.0 ** (t - 1))
+        L.adam_tf1(p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr.data_ptr(), 0.9, 0.999, 1e-8, step.data_ptr(), S())
+        L.step_increment(step.data_ptr(), S())
+        pr, mr, vr = T.adam_tf1_step(pr, gr.double(), mr, vr, t + 1, 1e-3)
+    torch.cuda.synchronize()
+    assert float((p.double() - pr).abs().max()) <= 2e-6
+    # (the slots are fp32 with fp32 coefficients, as TF's: 1 - 0.999f = 0.00100005, 4.7e-5 off the float64 oracle's 0.001)
+    assert float((m.double() - mr).abs().max()) <= 1e-5 * float(mr.abs().max())
+    assert float((v.double() - vr).abs().max()) <= 1e-4 * float(vr.abs().max())
+
+
 def test_reparam_and_graph_capture(L):
     B, per = 4, 2 * 8 * 8
     mu, sg = RNG.standard_normal((B, per)), RNG.random((B, per)) + 0.1
