@@ -1066,6 +1066,34 @@ def test_head1x1_kernels(L, case):
     close(host(db), br.grad.numpy(), 3e-5, "head dbias")
 
 
+@pytest.mark.parametrize("case", [(64, 128, 128, 32, 2), (64, 64, 64, 64, 2), (16, 192, 192, 32, 4), (64, 16, 16, 192, 2)])
+def test_head1x1_full_size_vs_device_matmul(L, case):
+    """The 1x1 heads (mu / sigma / per-level logits: posteriors.py:125-127, likelihoods.py:220) at BASELINE sizes against float64
+    matrix products on the device from the same bf16 activations: forward with bias, data gradient, filter / bias gradient."""
+    B, H, W, C, NO = case
+    npix = B * H * W
+    g = torch.Generator(device="cuda").manual_seed(23)
+    x = torch.randn(npix, C, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(C, NO, device="cuda", generator=g) / np.sqrt(C)).float()
+    b = (torch.randn(NO, device="cuda", generator=g) * 0.3).float()
+    dy = torch.randn(npix, NO, device="cuda", generator=g).float()
+    y = torch.empty(npix, NO, dtype=torch.float32, device="cuda")
+    L.head1x1_fwd(x.data_ptr(), BF16, w.data_ptr(), b.data_ptr(), y.data_ptr(), npix, C, NO, 0, S())
+    dx = torch.empty(npix, C, dtype=torch.bfloat16, device="cuda")
+    L.head1x1_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), BF16, npix, C, NO, S())
+    dw = torch.zeros(C, NO, dtype=torch.float32, device="cuda")
+    db = torch.zeros(NO, dtype=torch.float32, device="cuda")
+    L.head1x1_wgrad(x.data_ptr(), BF16, dy.data_ptr(), dw.data_ptr(), db.data_ptr(), npix, C, NO, S())
+    torch.cuda.synchronize()
+    x64, w64, d64 = x.double(), w.double(), dy.double()
+    yr, dxr, dwr, dbr = x64 @ w64 + b.double(), d64 @ w64.t(), x64.t() @ d64, d64.sum(0)
+    assert float((y.double() - yr).abs().max()) <= 2e-5 * float(yr.abs().max())
+    assert float((dx.double() - dxr).abs().max()) <= 6e-3 * float(dxr.abs().max())
+    # (sums over up to 10^6 pixels in fp32 partials: relative to the spread sqrt(npix) of such a sum)
+    assert float((dw.double() - dwr).abs().max()) <= 1e-4 * np.sqrt(npix)
+    assert float((db.double() - dbr).abs().max()) <= 1e-4 * np.sqrt(npix)
+
+
 @pytest.mark.parametrize("nout", [2, 4])
 def test_head1x1_wgrad_multi_matches_per_head_launches(L, nout):
     """One phx_head1x1_wgrad_multi launch over heads of different widths / map sizes == the per-head launches (accumulating)."""
