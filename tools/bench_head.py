@@ -18,4 +18,4 @@ for (H, C) in [(128, 32), (64, 64), (32, 128), (16, 192), (8, 192), (4, 192)]:
     for _ in range(20): fn()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 50
-    print("cap=%s H=%-4d C=%-4d %6.1f us %6.0f GB/s" % (os.environ.get("PHX_HEADW_BLOCKS", "1024"), H, C, us, npix * (C * 2 + 8) / us / 1e3))
+    print("H=%-4d C=%-4d %6.1f us %6.0f GB/s" % (H, C, us, npix * (C * 2 + 8) / us / 1e3))

@@ -25,7 +25,7 @@ for (B, H, W, K, N) in shapes:
     ntile = L.conv3x3_mfma_bf16_tiles(B, H, W, K, N)
     part = torch.zeros(max(ntile, 1) * 2 * N, device="cuda")
     row = []
-    for env in sys.argv[1:] or ["", "PHX_FWD_SPLITK=0"]:
+    for env in sys.argv[1:] or [""]:
         for kv in env.split(","):
             if kv: os.environ[kv.split("=")[0]] = kv.split("=")[1]
         wsb = int(L.conv3x3_mfma_ws_bytes(B, H, W, K, N))

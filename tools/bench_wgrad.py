@@ -1,4 +1,4 @@
-"""Micro-benchmark (GPU box): bf16 MFMA conv kernels on chosen shapes; env PHX_WGRAD_BLOCKS tunes the wgrad split."""
+"""Micro-benchmark (GPU box): bf16 MFMA filter-gradient (+ reduction) / forward launches on chosen shapes, back to back on one stream."""
 import ctypes, sys, os
 import torch
 sys.path.insert(0, ".")
@@ -32,4 +32,4 @@ for (B, H, W, K, N) in shapes:
     for _ in range(10): run()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
-    print("%s blocks=%s %-26s %8.3f ms %8.1f TFLOP/s" % (which, os.environ.get("PHX_WGRAD_BLOCKS", "512"), (B, H, W, K, N), ms, 18.0 * K * N * B * H * W / ms / 1e9))
+    print("%s %-26s %8.3f ms %8.1f TFLOP/s" % (which, (B, H, W, K, N), ms, 18.0 * K * N * B * H * W / ms / 1e9))
