@@ -142,7 +142,7 @@ def side_workload(args, ctx, exp, norm, generate, steps=10, warmup=3):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out = {"images_per_s": batch * max(spi, 1) * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
-           "launches_per_step": len(plan.launches) + len(plan.opt_launches)}
+           "launches_per_step": len(plan.launches) + len(plan.opt_launches), "abi_launch_calls_per_step": plan.kernel_launch_count()}
     _, _, _, fl, ms, nl = conv_family(plan)
     if ms > 0:
         out["conv_frac_of_mfma_peak"] = fl / ms / 1e9 / PEAK_BF16_TFLOPS
@@ -287,7 +287,10 @@ def main():
                                                                    args.dtype, args.norm, args.batch,
                                                                    " + RCCL grad all-reduce" if ctx.world > 1 else ""),
                    "global_batch": args.batch * ctx.world, "parallelism": "dp%d" % ctx.world,
-                   "launches_per_step": len(plan.launches) + len(plan.opt_launches), "final_loss": loss,
+                   # plan entries (launch calls + the event records / waits between the two lanes) and the launch calls into the C ABI
+                   # alone (a split-K convolution's finishing kernel rides inside its call: a kernel trace counts ~50 more)
+                   "launches_per_step": len(plan.launches) + len(plan.opt_launches),
+                   "abi_launch_calls_per_step": plan.kernel_launch_count(), "final_loss": loss,
                    # which transport carried the timed gradient exchange (a fallback cannot be timed unnoticed)
                    "comm": {"path": ctx.comm_path(), "ranks_seen": ranks_seen}},
     }

@@ -64,6 +64,13 @@ int phx_conv2d_direct(const void* x, int x_dt, const float* w_hwio, const float*
  * dw[kh][kw][ci][co] += sum_{b,y,x} x[b,y+kh-p,x+kw-p,ci] * dy[b,y,x,co];  dbias[co] += sum dy. */
 int phx_conv2d_direct_wgrad(const void* x, int x_dt, const void* dy, int dy_dt, float* dw_hwio, float* dbias,
                             int B, int H, int W, int Cin, int Cout, int ksize, void* stream);
+/* The same gradient with a FIXED summation order at full parallelism (what the engine launches under PHX_DETERMINISTIC=1, where
+ * phx_conv2d_direct_wgrad falls back to one block per channel block): up to 64 pixel slices leave partial filters in `workspace`
+ * (phx_conv2d_direct_wgrad_ordered_ws_bytes; 0 = one slice, no workspace needed) and a second launch adds them in slice order. */
+size_t phx_conv2d_direct_wgrad_ordered_ws_bytes(int B, int H, int W, int Cin, int Cout, int ksize);
+int phx_conv2d_direct_wgrad_ordered(const void* x, int x_dt, const void* dy, int dy_dt, float* dw_hwio, float* dbias,
+                                    void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int ksize,
+                                    void* stream);
 
 /* bf16 MFMA path (v_mfma_f32_32x32x16_bf16), 3x3 only, Cin % 32 == 0, Cout % 32 == 0.
  * wpk is the packed bf16 filter [K / 32][9][N][32] (element (tap t, row n, channel k) at (((k / 32) * 9 + t) * N + n) * 32

@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void k_conv_direct(const TI* __restrict__ x, c
 template <typename TX, typename TD, int KS>
 __global__ __launch_bounds__(256) void k_conv_direct_wgrad(const TX* __restrict__ x, const TD* __restrict__ dy,
                                                            float* __restrict__ dw, float* __restrict__ dbias, int B,
-                                                           int H, int W, int Cin, int Cout, TileGeo g, int tiles_per_block) {
+                                                           int H, int W, int Cin, int Cout, TileGeo g, int tiles_per_block,
+                                                           float* __restrict__ part) {
     constexpr int PAD = KS / 2;
     const int tw = 1 << g.tws, th = 1 << g.ths;
     const int pw = tw + KS - 1, ph = th + KS - 1;
@@ -181,11 +182,33 @@ __global__ __launch_bounds__(256) void k_conv_direct_wgrad(const TX* __restrict_
         }
     }
     const int ci = ci0 + ci_l, co = co0 + co_l;
+    if (part) {
+        // ordered mode (phx_conv2d_direct_wgrad_ordered): pixel slice blockIdx.x leaves its sums in part[slice][KS*KS*Cin*Cout + Cout];
+        // k_direct_wgrad_fold adds the slices in index order
+        float* ps = part + (size_t)blockIdx.x * ((size_t)KS * KS * Cin * Cout + Cout);
+        if (ci < Cin && co < Cout) {
+#pragma unroll
+            for (int k = 0; k < KS * KS; ++k) ps[((size_t)k * Cin + ci) * Cout + co] = acc[k];
+        }
+        if (blockIdx.y == 0 && ci_l == 0 && co < Cout) ps[(size_t)KS * KS * Cin * Cout + co] = accb;
+        return;
+    }
     if (ci < Cin && co < Cout) {
 #pragma unroll
         for (int k = 0; k < KS * KS; ++k) atomicAdd(&dw[((size_t)k * Cin + ci) * Cout + co], acc[k]);
     }
     if (dbias && blockIdx.y == 0 && ci_l == 0 && co < Cout) atomicAdd(&dbias[co], accb);
+}
+// dw[i] += part[0][i] + part[1][i] + ... in slice order (i < nw); dbias[c] += the same over the slices' bias tails
+__global__ void k_direct_wgrad_fold(const float* __restrict__ part, int nslice, size_t nw, int Cout, float* __restrict__ dw,
+                                    float* __restrict__ dbias) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = nw + Cout;
+    if (i >= stride) return;
+    float a = 0.f;
+    for (int s = 0; s < nslice; ++s) a += part[(size_t)s * stride + i];
+    if (i < nw) dw[i] += a;
+    else if (dbias) dbias[i - nw] += a;
 }
 
 // ---- small maps (B*H*W <= 4096 pixels) with a handful of channels on one side: the top-level 3x3 mu convolution (192 -> 2
@@ -337,6 +360,60 @@ int phx_conv2d_direct(const void* x, int x_dt, const float* w_hwio, const float*
     return PHX_OK;
 }
 
+// pixel slices of the ordered form: enough that slices x channel blocks fill the chip, at most 64
+static int ordered_slices(int B, int H, int W, int Cin, int Cout) {
+    TileGeo g = make_geo(B, H, W);
+    const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
+    const int cblocks = ((Cin + WG_CI - 1) / WG_CI) * ((Cout + WG_CO - 1) / WG_CO);
+    int want = 256 / cblocks;
+    if (want > 64) want = 64;
+    if (want > ntiles) want = ntiles;
+    if (want < 1) want = 1;
+    const int tpb = (ntiles + want - 1) / want;
+    return (ntiles + tpb - 1) / tpb;
+}
+size_t phx_conv2d_direct_wgrad_ordered_ws_bytes(int B, int H, int W, int Cin, int Cout, int ksize) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3)) return 0;
+    const int ns = ordered_slices(B, H, W, Cin, Cout);
+    return ns > 1 ? (size_t)ns * ((size_t)ksize * ksize * Cin * Cout + Cout) * sizeof(float) : 0;
+}
+int phx_conv2d_direct_wgrad_ordered(const void* x, int x_dt, const void* dy, int dy_dt, float* dw_hwio, float* dbias,
+                                    void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int ksize,
+                                    void* stream) {
+    PHX_REQUIRE(ksize == 1 || ksize == 3, PHX_E_SHAPE, "conv2d_direct_wgrad_ordered: ksize must be 1 or 3");
+    PHX_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, PHX_E_SHAPE, "conv2d_direct_wgrad_ordered: bad shape");
+    const size_t need = phx_conv2d_direct_wgrad_ordered_ws_bytes(B, H, W, Cin, Cout, ksize);
+    PHX_REQUIRE(workspace_bytes >= need && (need == 0 || workspace != nullptr), PHX_E_INVAL,
+                "conv2d_direct_wgrad_ordered: workspace smaller than phx_conv2d_direct_wgrad_ordered_ws_bytes");
+    TileGeo g = make_geo(B, H, W);
+    const int tw = 1 << g.tws, th = 1 << g.ths;
+    const int npatch = g.tb * (th + ksize - 1) * (tw + ksize - 1);
+    const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
+    const int ns = ordered_slices(B, H, W, Cin, Cout);
+    const int tpb = (ntiles + ns - 1) / ns;
+    // one slice: the block adds straight into dw (a single add per element, as in phx_conv2d_direct_wgrad's deterministic launch)
+    float* part = ns > 1 ? (float*)workspace : nullptr;
+    const size_t sh = (size_t)(WG_CI * npatch + 256 * WG_CO) * sizeof(float);
+    PHX_DT_SWITCH(x_dt, TX, PHX_DT_SWITCH(dy_dt, TD, {
+        if (ksize == 3)
+            hipLaunchKernelGGL((k_conv_direct_wgrad<TX, TD, 3>), dim3(ns, (Cin + WG_CI - 1) / WG_CI, (Cout + WG_CO - 1) / WG_CO),
+                               dim3(256), sh, (hipStream_t)stream, (const TX*)x, (const TD*)dy, dw_hwio, dbias, B, H, W,
+                               Cin, Cout, g, tpb, part);
+        else
+            hipLaunchKernelGGL((k_conv_direct_wgrad<TX, TD, 1>), dim3(ns, (Cin + WG_CI - 1) / WG_CI, (Cout + WG_CO - 1) / WG_CO),
+                               dim3(256), sh, (hipStream_t)stream, (const TX*)x, (const TD*)dy, dw_hwio, dbias, B, H, W,
+                               Cin, Cout, g, tpb, part);
+    }));
+    PHX_CHECK_LAUNCH();
+    if (part) {
+        const size_t nw = (size_t)ksize * ksize * Cin * Cout, tot = nw + Cout;
+        hipLaunchKernelGGL(k_direct_wgrad_fold, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, ns, nw,
+                           Cout, dw_hwio, dbias);
+        PHX_CHECK_LAUNCH();
+    }
+    return PHX_OK;
+}
+
 int phx_conv2d_direct_wgrad(const void* x, int x_dt, const void* dy, int dy_dt, float* dw_hwio, float* dbias, int B,
                             int H, int W, int Cin, int Cout, int ksize, void* stream) {
     PHX_REQUIRE(ksize == 1 || ksize == 3, PHX_E_SHAPE, "conv2d_direct_wgrad: ksize must be 1 or 3");
@@ -363,11 +440,11 @@ int phx_conv2d_direct_wgrad(const void* x, int x_dt, const void* dy, int dy_dt, 
         if (ksize == 3)
             hipLaunchKernelGGL((k_conv_direct_wgrad<TX, TD, 3>), dim3(gx, (Cin + WG_CI - 1) / WG_CI, (Cout + WG_CO - 1) / WG_CO),
                                dim3(256), sh, (hipStream_t)stream, (const TX*)x, (const TD*)dy, dw_hwio, dbias, B, H, W,
-                               Cin, Cout, g, tpb);
+                               Cin, Cout, g, tpb, (float*)nullptr);
         else
             hipLaunchKernelGGL((k_conv_direct_wgrad<TX, TD, 1>), dim3(gx, (Cin + WG_CI - 1) / WG_CI, (Cout + WG_CO - 1) / WG_CO),
                                dim3(256), sh, (hipStream_t)stream, (const TX*)x, (const TD*)dy, dw_hwio, dbias, B, H, W,
-                               Cin, Cout, g, tpb);
+                               Cin, Cout, g, tpb, (float*)nullptr);
     }));
     PHX_CHECK_LAUNCH();
     return PHX_OK;

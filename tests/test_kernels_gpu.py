@@ -150,6 +150,21 @@ def test_conv2d_direct_fwd_dgrad_wgrad(L, case):
     close(host(dw), wr.grad.numpy(), 2e-5, "wgrad")
     if use_bias:
         close(host(db), br.grad.numpy(), 2e-5, "dbias")
+    # the ordered form (pixel slices -> partial filters -> fold in slice order; what PHX_DETERMINISTIC=1 plans launch): the same
+    # gradients, accumulated onto what dw / db hold, and bit-identical from call to call
+    wsb = int(L.conv2d_direct_wgrad_ordered_ws_bytes(B, H, W, Cin, Cout, k))
+    ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32).cuda()
+    outs = []
+    for _ in range(2):
+        dw2 = torch.full((k, k, Cin, Cout), 0.5, dtype=torch.float32).cuda()
+        db2 = torch.full((Cout,), 0.25, dtype=torch.float32).cuda()
+        L.conv2d_direct_wgrad_ordered(xd.data_ptr(), xdt, dyd.data_ptr(), ydt, dw2.data_ptr(), db2.data_ptr(), ws.data_ptr(), wsb,
+                                      B, H, W, Cin, Cout, k, S())
+        outs.append((host(dw2), host(db2)))
+    close(outs[0][0] - 0.5, wr.grad.numpy(), 2e-5, "wgrad (ordered)")
+    if use_bias:
+        close(outs[0][1] - 0.25, br.grad.numpy(), 2e-5, "dbias (ordered)")
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
 MFMA_CASES = [
