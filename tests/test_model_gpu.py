@@ -796,13 +796,20 @@ def test_bf16_trains_like_fp32_n0_32_batch12_200_steps():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONPATH=root, PHX_DETERMINISTIC="1")
-    procs = [(dt, so, subprocess.Popen([sys.executable, os.path.join(root, "tests", "convergence_worker.py"), "200", "50", dt, str(so)],
-                                       env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-             for dt in ("f32", "bf16") for so in (0, 1)]        # four runs side by side on the one GPU
+    import tempfile
+    procs = []
+    for dt in ("f32", "bf16"):
+        for so in (0, 1):               # four runs side by side on the one GPU; output to files (nothing can block on a full pipe)
+            log = tempfile.TemporaryFile(mode="w+")
+            procs.append((dt, so, log, subprocess.Popen([sys.executable, os.path.join(root, "tests", "convergence_worker.py"), "200", "50",
+                                                         dt, str(so)], env=env, cwd=root, stdout=log, stderr=subprocess.STDOUT, text=True)))
     rec = {"runs": {"f32": [], "bf16": []}}
-    for dt, so, pr in procs:
-        out, err = pr.communicate(timeout=1500)
-        assert pr.returncode == 0, (dt, so, out[-2000:] + err[-3000:])
+    for dt, so, log, pr in procs:
+        pr.wait(timeout=1500)
+        log.seek(0)
+        out = log.read()
+        log.close()
+        assert pr.returncode == 0, (dt, so, out[-4000:])
         run = json.loads([l for l in out.splitlines() if l.startswith("CONVERGENCE ")][-1][len("CONVERGENCE "):])
         rec["keys"] = run["keys"]
         rec["runs"][dt].append(run)
