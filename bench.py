@@ -60,16 +60,33 @@ def cpu_baseline(batch=12, steps=5):
     var_specs = [(n, v.shape) for n, v in model.graph.variables.items()]
     params = otrain.make_params(var_specs, 0, torch.float32, perturbed=False)
     x, s = oinit.synthetic_batch(batch, 128, 2, 1234)
-    tw = time.time()
     first = otrain.train_steps(params, [(x, s)], cfg, 42, lr=1e-3, n_steps=1, dtype=torch.float32)      # warm-up (= step 0)
-    tw = time.time() - tw
-    # a box whose host cores are busy with other tenants takes 30 s per step instead of 14: keep the default run within minutes
-    if tw * steps > 100.0:
-        steps = max(2, int(100.0 / tw))
-    t0 = time.time()
-    otrain.train_steps(params, [(x, s)], cfg, 42, lr=1e-3, n_steps=steps, dtype=torch.float32)
-    dt = time.time() - t0
-    return {"value": batch * steps / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+
+    def timed(n):
+        t0 = time.time()
+        otrain.train_steps(params, [(x, s)], cfg, 42, lr=1e-3, n_steps=n, dtype=torch.float32)
+        return time.time() - t0
+    # The CPU leg gets its best thread count: one timed step on every hardware thread torch took and one on 32 threads (on a
+    # multi-tenant 128-thread host the latter can be the faster one: an 8-core container runs this step in 4.4 s where 128 oversubscribed
+    # threads took 13 - 30 s) -- the sample continues on the faster setting and `cores` reports it.
+    nt_all = torch.get_num_threads()
+    dt = timed(1)
+    nthr = nt_all
+    if nt_all > 32:
+        torch.set_num_threads(32)
+        dt32 = timed(1)
+        if dt32 < dt:
+            nthr, dt = 32, dt32
+        else:
+            torch.set_num_threads(nt_all)
+    # ... then as many more steps as fit: a box whose host cores are busy with other tenants takes 30 s per step, and the default
+    # run has to stay within minutes (~100 s of CPU sample).  (The warm-up call is no yardstick: its one-time costs made it 20+ s
+    # on boxes whose timed steps then took 13 s, and the sample shrank to 2 steps.)
+    more = max(1, min(steps - 1, int((100.0 - dt) / max(dt, 1e-3))))
+    dt += timed(more)
+    steps = 1 + more
+    torch.set_num_threads(nt_all)
+    return {"value": batch * steps / dt, "unit": "images/s", "cores": nthr, "kind": "port",
             "first_step_loss": first[0]["total_loss"],
             "sample": "%d training steps (fwd+ELBO+autograd+Adam) of phiseg_7_5 128x128 at batch %d, torch-CPU fp32 "
                       "oracle, %.1f s; same initial weights and images as the GPU leg" % (steps, batch, dt)}
