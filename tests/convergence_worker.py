@@ -16,6 +16,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     nsteps, tail, dt, seed_off = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+    torch.set_num_threads(min(8, torch.get_num_threads()))       # (four workers side by side; the host work is the weight initialiser)
     from oracle import init as oinit
     from oracle import train as otrain
     from phiseg_code_amd.phiseg import phiseg_model
