@@ -101,8 +101,7 @@ int phx_unpad_filter_grad_center(const float* dw_pad, float* dw_1x1, int Cin, in
  * fp32 slices and applies bias / activation.  Otherwise identical to phx_conv3x3_mfma_bf16. */
 size_t phx_conv3x3_mfma_ws_bytes(int B, int H, int W, int K, int N);
 /* number of fp32 slices that launch leaves (1: no split).  With y == NULL (and no bias / activation) the finishing pass is
- * skipped and the slices ws[z][B*H*W][N] stay in the workspace for a consumer that sums them itself
- * (phx_bn_small_fwd_splitk). */
+ * skipped and the slices ws[z][B*H*W][N] stay in the workspace for a consumer that sums them itself. */
 int phx_conv3x3_mfma_ksplit(int B, int H, int W, int K, int N);
 int phx_conv3x3_mfma_bf16_ws(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
                              void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream);
@@ -125,6 +124,13 @@ int phx_conv3x3_mfma_bf16_stats_atomic(const void* x, const void* wpk, void* y, 
 int phx_conv3x3_mfma_bf16_dual(const void* x, const void* x2, int K1, const void* wpk, void* y, void* y2, int N1, const float* bias,
                                const float* oscale, int act, float* stats, int stats_mode, void* workspace, size_t workspace_bytes,
                                int B, int H, int W, int K, int N, void* stream);
+/* The plain convolution with an fp32 output tensor y_f32[B*H*W][N] on small maps (the shapes the 256-pixel kernels take; not the
+ * large-map / 16 x 32-tile shapes): the fp32 accumulators of the split-K instantiations reach y_f32 without a bf16 rounding (round 5:
+ * input of phx_bn_small_fwd with x_dt = PHX_F32 -- tfwrapper/layers.py:123 + normalisation.py:145-163 on the 2 x 2 / 4 x 4 levels).
+ * workspace: phx_conv3x3_mfma_ws_bytes bytes (NULL / 0 when that is 0); x2 / K1: concat-free input as phx_conv3x3_mfma_bf16_dual. */
+int phx_conv3x3_mfma_f32out_supported(int B, int H, int W, int K, int N);
+int phx_conv3x3_mfma_bf16_f32out(const void* x, const void* x2, int K1, const void* wpk, float* y_f32, void* workspace,
+                                 size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream);
 size_t phx_conv3x3_wgrad_ws_bytes_dual(int B, int H, int W, int Cin, int Cout, int K1);
 int phx_conv3x3_wgrad_reduce_plan_dual(int B, int H, int W, int Cin, int Cout, int K1, int* plan6);
 int phx_conv3x3_wgrad_multi_job_dual(const void* x, const void* x2, int K1, const void* dy, float* dw_hwio, void* workspace,
@@ -156,12 +162,7 @@ int phx_conv3x3_mfma_bf16_tiles_dual(int B, int H, int W, int K, int N);
 int phx_debug_set_trace(void* dev_buf);
 /* debug: device buffer of 4 uint64 per block {start, end, HW_ID | XCC_ID << 32, realtime} written by the MFMA conv kernels */
 int phx_debug_set_blocklog(void* dev_buf);
-/* debug / tests: kernel-selection policy of the forward / data-gradient launches, process-wide (1 = the measured policy, the
- * default; 0 = never; 2 = whenever the shape is eligible) -- large_maps: the 16 x 32-tile large-map kernels (k_conv3x3_pp,
- * k_conv3x3_c32); big_tiles: the 16 x 32-tile instantiations of the 256-pixel kernel.  The tests force every family onto small
- * shapes with it; phx_debug_pair_kernel_grid: persistent grid of the pair kernel (0: one work-group per CU). */
-int phx_debug_conv_policy(int large_maps, int big_tiles);
-int phx_debug_pair_kernel_grid(int blocks);
+/* (the kernel-selection policy is a constant of libphx.so; the test build libphx_dbg.so can set it: include/phx_debug.h) */
 /* dw_hwio[kh][kw][ci][co] += sum x * dy, Cin % 32 == 0, Cout % 32 == 0.  With a workspace (>= phx_conv3x3_wgrad_ws_bytes)
  * the per-block partial filters are stored with plain writes and summed by a second kernel; workspace == NULL falls back
  * to fp32 atomics straight into dw_hwio (a CU issues those at ~1 lane/clock: 46 us per block on MI355X). */
@@ -297,15 +298,13 @@ int phx_norm_bwd_apply_fused_bias(const void* dA, int da_dt, const void* x, int 
  * moving-average update (moving -= (moving - batch) * momentum, unbiased variance).
  * bwd: dx from dA, the saved x and statistics; dgamma / dbeta are accumulated (+=). */
 int phx_bn_small_supported(int P, int C, int dt);
-int phx_bn_small_fwd(const void* x, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd,
+/* x_dt = PHX_BF16, or PHX_F32 for P <= 1024 (round 5): the pre-normalisation tensor of the 2 x 2 / 4 x 4 levels stays in fp32
+ * (phx_conv3x3_mfma_bf16_f32out) -- a channel is normalised from a few dozen to a few hundred values there, and bf16 rounding of x
+ * (2^-9 of the channel MEAN) is blown up with the spread: the benchmarked precision's two coarsest KL terms trained 40 % high. */
+int phx_bn_small_fwd(const void* x, int x_dt, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd,
                      float* scale, float* shift, float* moving_mean, float* moving_var, float momentum, int P, int C,
                      int act, void* stream);
-/* the same layer fed by a split-K convolution that skipped its finishing pass (phx_conv3x3_mfma_bf16_ws with y == NULL):
- * sums the nz fp32 slices ws[z][P][C], writes the bf16 pre-normalisation tensor x_out and normalises it */
-int phx_bn_small_fwd_splitk(const float* ws, int nz, void* x_out, const float* gamma, const float* beta, float eps, void* y,
-                            float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,
-                            float momentum, int P, int C, int act, void* stream);
-int phx_bn_small_bwd(const void* dA, const void* x, const float* scale, const float* shift, const float* mean,
+int phx_bn_small_bwd(const void* dA, const void* x, int x_dt, const float* scale, const float* shift, const float* mean,
                      const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, int P, int C, int act,
                      void* stream);
 /* Group / instance norm (tfwrapper/normalisation.py:3-36), bf16 NHWC, the whole layer in ONE launch when a sample has

@@ -5,6 +5,7 @@ cd "$(dirname "$0")"
 OUT=../libphx.so
 SRCS="runtime.hip elementwise.hip losses_opt.hip conv_direct.hip conv_mfma.hip conv_wgrad.hip conv_pp.hip conv_c32.hip heads.hip metrics.hip comm.hip augment.hip tconv.hip gconv.hip"
 OBJS=""
+DOBJS=""
 for s in $SRCS; do
   o="build_${s%.hip}.o"
   if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ phx_common.h -nt "$o" ] || [ conv_common.h -nt "$o" ] || [ philox.h -nt "$o" ] || [ ../../include/phx.h -nt "$o" ]; then
@@ -17,10 +18,26 @@ for s in $SRCS; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics $EXTRA -c "$s" -o "$o" &
   fi
   OBJS="$OBJS $o"
+  # the test build libphx_dbg.so: the two translation units that hold the kernel-selection policy compiled with -DPHX_DEBUG_BUILD
+  # (phx_debug_conv_policy / phx_debug_pair_kernel_grid, include/phx_debug.h), every other object shared with libphx.so
+  if [ "$s" = "conv_mfma.hip" ] || [ "$s" = "conv_pp.hip" ]; then
+    d="build_${s%.hip}_dbg.o"
+    if [ ! -f "$d" ] || [ "$s" -nt "$d" ] || [ phx_common.h -nt "$d" ] || [ conv_common.h -nt "$d" ] || [ ../../include/phx.h -nt "$d" ] || [ ../../include/phx_debug.h -nt "$d" ]; then
+      rm -f "$d"
+      EXTRA=""
+      [ "$s" = "conv_pp.hip" ] && EXTRA="-fno-slp-vectorize"
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -DPHX_DEBUG_BUILD $EXTRA -c "$s" -o "$d" &
+    fi
+    DOBJS="$DOBJS $d"
+  else
+    DOBJS="$DOBJS $o"
+  fi
 done
 wait
-for o in $OBJS; do
+for o in $OBJS $DOBJS; do
   [ -f "$o" ] || { echo "build.sh: compiling ${o#build_} failed" >&2; exit 1; }
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -ldl -o $OUT
 echo "built $(realpath $OUT)"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $DOBJS -ldl -o ../libphx_dbg.so
+echo "built $(realpath ../libphx_dbg.so) (test build: settable kernel policy, include/phx_debug.h)"

@@ -9,10 +9,16 @@
 // re-used by all nine filter taps from LDS.
 #include "conv_common.h"
 
-// Kernel-selection policy of the forward / data-gradient launches: 1 = the measured policy below (the default), 0 = never, 2 =
-// whenever the shape is eligible.  Process-wide; phx_debug_conv_policy sets it -- the tests force every kernel family onto small shapes.
+// Kernel-selection policy of the forward / data-gradient launches: 1 = the measured policy below, 0 = never, 2 = whenever the shape
+// is eligible.  In libphx.so it is a CONSTANT (1): the product library has no mutable policy, so a plan's tile counts and statistics
+// rows cannot go stale under it.  Only the test build (libphx_dbg.so: the same sources with -DPHX_DEBUG_BUILD, include/phx_debug.h)
+// can set it -- the kernel tests force every kernel family onto small shapes the CPU oracle finishes in seconds.
+#ifdef PHX_DEBUG_BUILD
 static int g_ws_policy = 1;                // large-map kernels on 16 x 32-pixel tiles (k_conv3x3_pp, k_conv3x3_c32)
 static int g_tile_policy = 1;              // 16 x 32-pixel / 8-wave instantiations of k_conv3x3_mfma
+#else
+static constexpr int g_ws_policy = 1, g_tile_policy = 1;
+#endif
 
 // forward / data-gradient tiles.  16 x 32 tiles (512 pixels, 8-wave blocks, one per CU) halve the filter-slab bytes staged
 // per FLOP but give up the overlap of two independent blocks per CU: measured, they win for 128-wide output-channel blocks
@@ -167,6 +173,7 @@ int phx_pp_launch(const void* x, const void* wpk, void* y, const float* bias, in
 struct EpiOpts {
     int stats_atomic;         // stats_partial is the accumulator sums[N][2] itself, added to atomically (few pixel tiles)
     const float* oscale;      // per-output-channel scale of the bias / activation epilogue (inference-mode batch norm folded in)
+    float* y_f32;             // fp32 output tensor [B * H * W][N] (phx_conv3x3_mfma_bf16_f32out): the split-K kernel's fp32 slices, summed
 };
 
 // Arguments of the one-launch conv + bias + group / instance norm + activation epilogue (FGN instantiations).
@@ -759,7 +766,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
 // y[pix][n] = bf16(act(sum_z ws[z][pix][n] + bias[n])), four channels per thread
 __global__ void k_splitk_finish(const float* __restrict__ ws, int nz, size_t total, int N, const float* __restrict__ bias,
                                 int act, unsigned short* __restrict__ y, const float* __restrict__ oscale,
-                                unsigned short* __restrict__ y2, int N1) {
+                                unsigned short* __restrict__ y2, int N1, float* __restrict__ yf) {
     for (size_t i4 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i4 * 4 < total; i4 += (size_t)gridDim.x * blockDim.x) {
         const size_t i = i4 * 4;
         // (loads first, four slices at a time -- the plain loop compiled to load / wait / add per slice -- and the slices are added
@@ -803,6 +810,10 @@ __global__ void k_splitk_finish(const float* __restrict__ ws, int nz, size_t tot
         } else if (act != PHX_ACT_ID) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) a[q] = act_fwd(a[q], act);
+        }
+        if (yf != nullptr) {                       // fp32 output (the small-map batch-norm layers normalise unrounded values)
+            *reinterpret_cast<f32x4*>(yf + i) = a;
+            continue;
         }
         uint2 o;
         o.x = f2bf_pk(a[0], a[1]);
@@ -880,6 +891,7 @@ int phx_debug_set_trace(void* dev_buf) {
     return PHX_OK;
 }
 
+#ifdef PHX_DEBUG_BUILD
 int phx_debug_conv_policy(int large_maps, int big_tiles) {
     PHX_REQUIRE(large_maps >= 0 && large_maps <= 2 && big_tiles >= 0 && big_tiles <= 2, PHX_E_INVAL, "debug_conv_policy: 0 never, 1 policy, 2 force");
     g_ws_policy = large_maps;
@@ -891,6 +903,7 @@ int phx_debug_pair_kernel_grid(int blocks) {
     PHX_REQUIRE(blocks >= 0, PHX_E_INVAL, "debug_pair_kernel_grid: blocks >= 0 (0: one per CU)");
     return phx_pp_set_grid(blocks);
 }
+#endif
 
 int phx_debug_set_blocklog(void* dev_buf) {
     if (int rc = phx_wgrad_set_debug(nullptr, dev_buf, 1)) return rc;
@@ -991,6 +1004,23 @@ int phx_conv3x3_mfma_bf16_dual(const void* x, const void* x2, int K1, const void
     return conv3x3_mfma_impl(x, wpk, y, bias, act, stats, workspace, workspace_bytes, B, H, W, K, N, b, du, stream);
 }
 
+// fp32 output on small maps: the plain convolution (no bias / activation / statistics) through the split-K instantiations of the
+// 256-pixel kernels -- their fp32 accumulators go to the workspace slices and k_splitk_finish sums them into y_f32 without rounding
+// (a single slice is written straight into y_f32).  For the one-launch batch norm of the 2 x 2 / 4 x 4 levels (phx_bn_small_fwd with
+// x_dt = PHX_F32).  workspace: phx_conv3x3_mfma_ws_bytes (may be NULL / 0 when that is 0).  x2 / K1: concat-free input, as _dual.
+int phx_conv3x3_mfma_f32out_supported(int B, int H, int W, int K, int N) {
+    return (K % KC == 0 && N % 32 == 0 && !fwd_ws64(B, H, W, K, N) && !fwd_big_tiles(B, H, W, K, N) && (double)B * H * W < 16777216.0) ? 1 : 0;
+}
+int phx_conv3x3_mfma_bf16_f32out(const void* x, const void* x2, int K1, const void* wpk, float* y_f32, void* workspace,
+                                 size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream) {
+    PHX_REQUIRE(y_f32 != nullptr && ((uintptr_t)y_f32 & 15) == 0, PHX_E_INVAL, "conv3x3_mfma_f32out: y_f32 (16-byte aligned) is required");
+    PHX_REQUIRE(x2 == nullptr || (K1 > 0 && K1 % 32 == 0 && ((uintptr_t)x2 & 15) == 0), PHX_E_INVAL, "conv3x3_mfma_f32out: x2 (16-byte aligned), K1 % 32 == 0");
+    EpiOpts b{};
+    b.y_f32 = y_f32;
+    Dual du{(const unsigned short*)x2, nullptr, x2 ? K1 : 0, 0};
+    return conv3x3_mfma_impl(x, wpk, nullptr, nullptr, PHX_ACT_ID, nullptr, workspace, workspace_bytes, B, H, W, K, N, b, du, stream);
+}
+
 // ---- conv + bias + group / instance norm + activation in one launch (FGN instantiations of k_conv3x3_mfma) ----------------------
 // Maps that fit ONE pixel tile (H, W in {2, 4, 8, 16}): a block then holds whole samples and whole 16-channel groups.  -> 32 / 64
 // (channels per block), 0: not supported.
@@ -1051,12 +1081,21 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
                 PHX_E_SHAPE, "conv3x3_mfma: dual output needs 0 < N1 < N, (N - N1) % 8 == 0, an output tensor and no statistics epilogue");
     PHX_REQUIRE((((uintptr_t)x | (uintptr_t)wpk | (uintptr_t)y) & 15) == 0, PHX_E_ALIGN, "conv3x3_mfma: 16-byte alignment");
     int ksplit = 1;
-    if (workspace && !stats_partial) {
+    const bool f32out = bws.y_f32 != nullptr;        // fp32 output: always the split-K instantiation (one slice: straight into y_f32)
+    if ((workspace && !stats_partial) || f32out) {
         ksplit = fwd_ksplit(B, H, W, K, N);
         PHX_REQUIRE(workspace_bytes >= (size_t)(ksplit > 1 ? ksplit : 0) * B * H * W * N * sizeof(float), PHX_E_INVAL,
                     "conv3x3_mfma: workspace too small");
     }
-    PHX_REQUIRE(y != nullptr || (ksplit > 1 && !bias && act == PHX_ACT_ID), PHX_E_INVAL,
+    if (f32out) {
+        PHX_REQUIRE(y == nullptr && !bias && act == PHX_ACT_ID && !bws.oscale && !stats_partial && !du.y2, PHX_E_INVAL,
+                    "conv3x3_mfma_f32out: plain convolution only (no bf16 output, bias, activation, statistics or dual output)");
+        PHX_REQUIRE(!fwd_ws64(B, H, W, K, N) && !fwd_big_tiles(B, H, W, K, N), PHX_E_SHAPE,
+                    "conv3x3_mfma_f32out: small maps only (the 256-pixel split-K kernels)");
+        PHX_REQUIRE(ksplit == 1 || workspace != nullptr, PHX_E_INVAL, "conv3x3_mfma_f32out: this shape runs split-K and needs its workspace");
+        if (ksplit == 1) workspace = bws.y_f32;
+    }
+    PHX_REQUIRE(y != nullptr || f32out || (ksplit > 1 && !bias && act == PHX_ACT_ID), PHX_E_INVAL,
                 "conv3x3_mfma: y == NULL only for a split-K launch without bias / activation (slices left in the workspace)");
     const bool dual = du.x2 != nullptr || du.y2 != nullptr;
     if (fwd_ws64(B, H, W, K, N)) {
@@ -1110,7 +1149,7 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
     } while (0)
 #define CM_LAUNCH(BNv, NAv, Fv, NWv)                                                                                 \
     do {                                                                                                             \
-        if (NWv == 4 && ksplit > 1) CM_LAUNCH1(BNv, NAv, Fv, false, NWv, (NWv == 4));                                \
+        if (NWv == 4 && (ksplit > 1 || f32out)) CM_LAUNCH1(BNv, NAv, Fv, false, NWv, (NWv == 4));                    \
         else if (biasact) CM_LAUNCH1(BNv, NAv, Fv, true, NWv, false);                                                \
         else CM_LAUNCH1(BNv, NAv, Fv, false, NWv, false);                                                            \
     } while (0)
@@ -1133,7 +1172,7 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
     } while (0)
 #define CM_DUAL(BNv, NAv, Fv)                                                                                        \
     do {                                                                                                             \
-        if (ksplit > 1) CM_DUAL1(BNv, NAv, Fv, false, true);                                                         \
+        if (ksplit > 1 || f32out) CM_DUAL1(BNv, NAv, Fv, false, true);                                               \
         else if (biasact) CM_DUAL1(BNv, NAv, Fv, true, false);                                                       \
         else CM_DUAL1(BNv, NAv, Fv, false, false);                                                                   \
     } while (0)
@@ -1155,10 +1194,10 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
 #undef CM_DUAL
 #undef CM_DUAL1
     PHX_CHECK_LAUNCH();
-    if (ksplit > 1 && y != nullptr) {                // (y == NULL: the caller consumes the fp32 slices itself)
+    if (ksplit > 1 && (y != nullptr || bws.y_f32 != nullptr)) {      // (neither: the caller consumes the fp32 slices itself)
         const size_t total = (size_t)B * H * W * N;
         hipLaunchKernelGGL(k_splitk_finish, dim3(phx_grid_for(total / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)workspace, ksplit, total, N, bias, act, (unsigned short*)y, bws.oscale, du.y2, du.N1);
+                           (const float*)workspace, ksplit, total, N, bias, act, (unsigned short*)y, bws.oscale, du.y2, du.N1, bws.y_f32);
         PHX_CHECK_LAUNCH();
     }
     return PHX_OK;

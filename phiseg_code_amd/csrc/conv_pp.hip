@@ -530,11 +530,15 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __r
 
 }  // namespace
 
-static int g_pp_grid = 0;                 // tests: persistent grid size (0: one block per CU)
+#ifdef PHX_DEBUG_BUILD                    // libphx_dbg.so (tests): persistent grid size, 0 = one block per CU -- a constant in libphx.so
+static int g_pp_grid = 0;
 int phx_pp_set_grid(int blocks) {
     g_pp_grid = blocks;
     return PHX_OK;
 }
+#else
+static constexpr int g_pp_grid = 0;
+#endif
 
 int phx_pp_set_trace(void* dev_buf) {
     PHX_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pp_trace), &dev_buf, sizeof(void*)));

@@ -884,7 +884,14 @@ static int wgrad_plan(int B, int H, int W, int Cin, int Cout, MTile* g, int* tci
     if (target_override > 0) target_blocks = pp ? (target_override + 1) / 2 : target_override;
     int split = (target_blocks + cblocks - 1) / cblocks;
     if (pp && target_override <= 0) split = target_blocks / cblocks;              // (never a second round of a few blocks)
-    if (pp && target_override > 0) split = (split + 7) & ~7;                      // whole slices per XCD (k_conv3x3_wgrad_pp_multi)
+    if (pp && target_override > 0) {
+        // whole slices per XCD (k_conv3x3_wgrad_pp_multi) -- but never more slices than the stand-alone plan takes (256 / cblocks):
+        // callers size the workspace with phx_conv3x3_wgrad_ws_bytes, i.e. from the stand-alone split (>= 33 channel blocks, e.g.
+        // 384 -> 384: the round-up to 8 exceeded the stand-alone 7 and the job rejected its own workspace)
+        const int alone = 256 / cblocks > 0 ? 256 / cblocks : 1;
+        split = (split + 7) & ~7;
+        if (split > alone) split = alone;
+    }
     if (split > ntiles) split = ntiles;
     if (split < 1) split = 1;
     *tpb = (ntiles + split - 1) / split;

@@ -37,6 +37,7 @@ _NREP_MINP = 4096
 _STAMPS = os.environ.get("PHX_STAMPS", "0") == "1"           # dev: per-operator device time stamps (tools/lane_timeline.py)
 _DETERMINISTIC = os.environ.get("PHX_DETERMINISTIC", "0") not in ("0", "")   # fixed summation orders everywhere (libphx reads the same variable)
 _BN_SMALL = 1024              # one-launch batch norm up to this many pixels
+_BN_SMALL_F32 = os.environ.get("PHX_BN_SMALL_F32", "1") != "0"      # dev A/B (tools/convergence_study.py): fp32 pre-normalisation tensor of those layers
 
 
 def _fgn_mode():
@@ -1037,8 +1038,19 @@ class Plan:
                 mm = self.store.ptr(nv["moving_mean"]) if upd else None
                 mv = self.store.ptr(nv["moving_variance"]) if upd else None
                 mom = (1.0 - tfnorm.BN_DECAY) if upd else 0.0
-                conv_into(y, 0)
-                self._emit(Lb.bn_small_fwd, y.ptr, gptr, beptr, eps, out.ptr, mean.ptr, rstd.ptr, scale.ptr, shift.ptr,
+                if mfma and not head1x1 and _BN_SMALL_F32 and Lb.conv3x3_mfma_f32out_supported(B, H, Wd, cin_eff, cout):
+                    # the 2 x 2 / 4 x 4 levels: the pre-normalisation tensor stays in fp32 (the split-K kernel's accumulators, summed) --
+                    # a channel is normalised from a few dozen to a few hundred values here, and the bf16 rounding of y (2^-9 of the
+                    # channel mean) is blown up with their spread: the two coarsest KL terms trained 40 % high
+                    y = self._alloc(out.shape, F32)
+                    wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cin_eff, cout))
+                    ws = self._alloc((wsb // 4,), F32) if wsb else None
+                    self._emit(Lb.conv3x3_mfma_bf16_f32out, x.ptr, dual.b.ptr if dual is not None else None,
+                               dual.k1 if dual is not None else 0, wf.ptr, y.ptr, ws.ptr if ws is not None else None, wsb,
+                               B, H, Wd, cin_eff, cout, S, tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
+                else:
+                    conv_into(y, 0)
+                self._emit(Lb.bn_small_fwd, y.ptr, y.dt, gptr, beptr, eps, out.ptr, mean.ptr, rstd.ptr, scale.ptr, shift.ptr,
                            mm, mv, mom, P, cout, act, S,
                            tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
                 st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn, bn_small=True)
@@ -1577,8 +1589,8 @@ class Plan:
             nv = a["norm_vars"]
             y, NS, P, Gn = sv["y"], sv["NS"], sv["P"], sv["G"]
             if sv.get("bn_small") and dA.dt == BF16:
-                dY = self._alloc(y.shape, y.dt)
-                self._emit(Lb.bn_small_bwd, dA.ptr, y.ptr, sv["scale"].ptr, sv["shift"].ptr, sv["mean"].ptr, sv["rstd"].ptr,
+                dY = self._alloc(y.shape, BF16)
+                self._emit(Lb.bn_small_bwd, dA.ptr, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr, sv["mean"].ptr, sv["rstd"].ptr,
                            self.store.ptr(nv["gamma"]), dY.ptr, self.store.grad_ptr(nv["gamma"]),
                            self.store.grad_ptr(nv["beta"]), P, cout, act, S,
                            tag="bytes_norm_bwd_apply", flops=float(dA.nbytes + y.nbytes + dY.nbytes))

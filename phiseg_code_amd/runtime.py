@@ -10,6 +10,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "phx.h")
+DEBUG_HEADER = os.path.join(os.path.dirname(_HERE), "include", "phx_debug.h")
 LIB_PATH = os.environ.get("PHX_LIB") or os.path.join(_HERE, "libphx.so")   # PHX_LIB: dev builds (tools/build_ablate.sh)
 
 F32, BF16 = 0, 1
@@ -47,17 +48,19 @@ def parse_header(path=HEADER):
 
 
 class _Lib:
-    def __init__(self):
-        if not os.path.exists(LIB_PATH):
-            raise PhxError("libphx.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
-                           "(phiseg_code_amd/csrc/build.sh); there is no CPU fallback" % LIB_PATH)
-        self._dll = ctypes.CDLL(LIB_PATH)
+    def __init__(self, path=LIB_PATH, extra_headers=()):
+        if not os.path.exists(path):
+            raise PhxError("%s not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(phiseg_code_amd/csrc/build.sh); there is no CPU fallback" % (os.path.basename(path), path))
+        self._dll = ctypes.CDLL(path)
         self.protos = parse_header()
+        for h in extra_headers:
+            self.protos.update(parse_header(h))
         for name, argtypes in self.protos.items():
             fn = getattr(self._dll, name)        # AttributeError if the symbol is not exported
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
-            if name in ("phx_abi_version", "phx_last_error", "phx_conv3x3_mfma_bf16_tiles", "phx_conv3x3_mfma_bf16_tiles_dual", "phx_bn_small_supported", "phx_norm_small_supported", "phx_conv3x3_mfma_stats_atomic_supported", "phx_norm_head_supported", "phx_conv3x3_mfma_ksplit", "phx_conv3x3_fgn_supported", "phx_conv3x3_wgrad_multi_job_bytes", "phx_conv3x3_wgrad_ws_bytes", "phx_conv3x3_wgrad_ws_bytes_dual", "phx_augment_param_bytes",
+            if name in ("phx_abi_version", "phx_last_error", "phx_conv3x3_mfma_bf16_tiles", "phx_conv3x3_mfma_bf16_tiles_dual", "phx_bn_small_supported", "phx_norm_small_supported", "phx_conv3x3_mfma_stats_atomic_supported", "phx_norm_head_supported", "phx_conv3x3_mfma_ksplit", "phx_conv3x3_fgn_supported", "phx_conv3x3_mfma_f32out_supported", "phx_conv3x3_wgrad_multi_job_bytes", "phx_conv3x3_wgrad_ws_bytes", "phx_conv3x3_wgrad_ws_bytes_dual", "phx_augment_param_bytes",
                         "phx_conv3x3_mfma_ws_bytes", "phx_validation_metrics_ws_bytes", "phx_conv2d_direct_wgrad_ordered_ws_bytes"):
                 if name.endswith("_ws_bytes"):
                     fn.restype = ctypes.c_size_t
@@ -77,6 +80,7 @@ class _Lib:
 
 
 _lib = None
+_lib_dbg = None
 
 
 def lib():
@@ -84,6 +88,15 @@ def lib():
     if _lib is None:
         _lib = _Lib()
     return _lib
+
+
+def debug_lib():
+    """The TEST build of the library (libphx_dbg.so: the same sources with -DPHX_DEBUG_BUILD): everything include/phx.h declares plus
+    the settable kernel-selection policy of include/phx_debug.h.  For the kernel tests and dev tools only -- the engine never loads it."""
+    global _lib_dbg
+    if _lib_dbg is None:
+        _lib_dbg = _Lib(os.path.join(_HERE, "libphx_dbg.so"), (DEBUG_HEADER,))
+    return _lib_dbg
 
 
 def ptr_array(ptrs):

@@ -85,6 +85,21 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.abi_version() == 1
 
 
+def test_product_library_has_no_settable_kernel_policy():
+    """libphx.so exports exactly what include/phx.h declares -- and none of the test build's policy setters (include/phx_debug.h):
+    the kernel-selection policy is a compile-time constant there.  libphx_dbg.so (same sources, -DPHX_DEBUG_BUILD) exports both sets."""
+    import ctypes
+    from phiseg_code_amd import runtime as rt
+    dbg = rt.parse_header(rt.DEBUG_HEADER)
+    assert set(dbg) == {"phx_debug_conv_policy", "phx_debug_pair_kernel_grid"}
+    assert not (set(dbg) & set(rt.parse_header()))
+    dll = ctypes.CDLL(rt.LIB_PATH)
+    for name in dbg:
+        assert not hasattr(dll, name), name + " is exported by the product library"
+    d = rt.debug_lib()                   # binds phx.h + phx_debug.h: a missing symbol raises
+    assert d.abi_version() == 1 and callable(d.debug_conv_policy)
+
+
 def test_dropin_aliases():
     import phiseg_code_amd
     phiseg_code_amd.install_dropin_aliases()
@@ -123,3 +138,25 @@ def test_launch_plans_host_side():
     assert L.conv3x3_mfma_bf16_tiles(64, 128, 128, 128, 128) == 64 * 8 * 4
     assert L.conv3x3_mfma_bf16_tiles(64, 16, 16, 192, 192) == 64
     assert L.conv3x3_mfma_stats_atomic_supported(64, 16, 16, 192, 192) == 1 and L.conv3x3_mfma_stats_atomic_supported(64, 128, 128, 32, 32) == 0
+
+
+@pytest.mark.parametrize("shape", [(64, 16, 16, 384, 384), (64, 16, 16, 768, 384), (64, 32, 32, 384, 384), (12, 16, 16, 512, 512),
+                                   (64, 16, 16, 384, 192), (64, 64, 64, 192, 192), (64, 32, 32, 128, 128)])
+def test_deferred_filter_gradient_job_fits_the_stand_alone_workspace(shape):
+    """A deferred filter-gradient job (phx_conv3x3_wgrad_multi_job_dual with the engine's blocks_target) must accept the workspace
+    phx_conv3x3_wgrad_ws_bytes sizes from the stand-alone plan -- with >= 33 64 x 64 channel blocks (n0 = 64 PHiSeg's 384 -> 384
+    layers, any 512-wide layer) the XCD round-up of the slice count once exceeded the stand-alone split.  Host-side only."""
+    import ctypes
+    from phiseg_code_amd import engine
+    from phiseg_code_amd import runtime as rt
+    L = rt.lib()
+    B, H, W, K, N = shape
+    wsb = int(L.conv3x3_wgrad_ws_bytes(B, H, W, K, N))
+    assert wsb > 0
+    jb = ctypes.create_string_buffer(int(L.conv3x3_wgrad_multi_job_bytes()))
+    info = (ctypes.c_int * 9)()
+    fake = 1 << 20                                             # (pointers are only recorded, never dereferenced on the host)
+    L.conv3x3_wgrad_multi_job_dual(fake, None, 0, fake, fake, fake, wsb, B, H, W, K, N, engine._WGRAD_DEFER_BLOCKS, 0, jb, info)
+    assert info[0] != 0 and info[1] > 0 and info[3] == 1       # deferred, with blocks, through the workspace
+    nslice, tci, tco = info[4], info[5], info[6]
+    assert (K // tci) * (N // tco) * nslice * 9 * tci * tco * 4 <= wsb

@@ -26,16 +26,25 @@ def L():
     return rt.lib()
 
 
+@pytest.fixture(scope="module")
+def Ld():
+    """The test build of the library (libphx_dbg.so, include/phx_debug.h): libphx.so's sources with a SETTABLE kernel-selection policy.
+    Only the tests that force a kernel family onto small shapes use it; everything else runs on the product library `L`."""
+    from phiseg_code_amd import runtime as rt
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return rt.debug_lib()
+
+
 @pytest.fixture
-def policy(L):
-    """Kernel-selection policy of the forward / data-gradient launches (phx_debug_conv_policy / phx_debug_pair_kernel_grid), restored
-    to the defaults afterwards: policy(large_maps, big_tiles, pair_grid)."""
+def policy(Ld):
+    """Kernel-selection policy of the forward / data-gradient launches in the test build (phx_debug_conv_policy /
+    phx_debug_pair_kernel_grid), restored to the product library's constants afterwards: policy(large_maps, big_tiles, pair_grid)."""
     def set_(large_maps=1, big_tiles=1, pair_grid=0):
-        L.debug_conv_policy(large_maps, big_tiles)
-        L.debug_pair_kernel_grid(pair_grid)
+        Ld.debug_conv_policy(large_maps, big_tiles)
+        Ld.debug_pair_kernel_grid(pair_grid)
     yield set_
-    L.debug_conv_policy(1, 1)
-    L.debug_pair_kernel_grid(0)
+    Ld.debug_conv_policy(1, 1)
+    Ld.debug_pair_kernel_grid(0)
 
 
 def S():
@@ -189,7 +198,8 @@ def test_conv3x3_mfma_fwd_dgrad_wgrad(L, case):
 
 # the 16 x 32-pixel-tile / 8-wave forward kernels (chosen by policy only for large maps): forced here on small ones
 @pytest.mark.parametrize("case", [(2, 32, 32, 64, 128), (1, 64, 32, 32, 32), (3, 32, 16, 96, 64), (1, 32, 48, 32, 256)])
-def test_conv3x3_mfma_big_tiles(L, case, policy):
+def test_conv3x3_mfma_big_tiles(Ld, case, policy):
+    L = Ld                                   # (the test build: this test sets the kernel policy)
     policy(big_tiles=2)
     _mfma_case(L, case)
 
@@ -261,6 +271,37 @@ def test_conv3x3_mfma_statistics_by_atomics(L, case):
     from phiseg_code_amd.runtime import PhxError
     with pytest.raises(PhxError):
         L.conv3x3_mfma_bf16_stats_atomic(xd.data_ptr(), wf.data_ptr(), y.data_ptr(), None, 0, None, B, H, W, K, N, S())
+
+
+@pytest.mark.parametrize("case", [(64, 2, 2, 192, 192, 0), (64, 4, 4, 192, 192, 0), (12, 4, 4, 256, 192, 64), (12, 2, 2, 32, 64, 0), (12, 8, 8, 192, 192, 0),
+                                  (5, 3, 3, 64, 96, 0), (64, 4, 4, 32, 192, 0), (3, 16, 16, 384, 64, 192)])
+def test_conv3x3_mfma_fp32_output(L, case):
+    """phx_conv3x3_mfma_bf16_f32out (round 5): the plain convolution of a small map with its fp32 accumulators written out unrounded --
+    split-K slices summed by the finishing pass, a single slice written directly, plain and concat-free input -- against the oracle
+    on the bf16-rounded operands: 2e-5 of the output's range where the bf16 tensor is good to 4e-3."""
+    B, H, W, K, N, K1 = case
+    assert L.conv3x3_mfma_f32out_supported(B, H, W, K, N) == 1 and L.conv3x3_mfma_f32out_supported(64, 128, 128, 128, 128) == 0
+    x = RNG.standard_normal((B, H, W, K))
+    w = RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K)
+    xd, wd = dev(x, BF16), dev(w)
+    wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    L.pack_conv3x3_bf16(wd.data_ptr(), wf.data_ptr(), None, K, N, S())
+    ref = T.conv2d_same(rounded(x, BF16), rounded(w, BF16)).numpy()
+    wsb = int(L.conv3x3_mfma_ws_bytes(B, H, W, K, N))
+    assert (wsb > 0) == (int(L.conv3x3_mfma_ksplit(B, H, W, K, N)) > 1)
+    ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32).cuda()
+    y = torch.full((B, H, W, N), 7.0, dtype=torch.float32).cuda()
+    if K1:
+        xa, xb = dev(x[..., :K1], BF16), dev(x[..., K1:], BF16)
+        L.conv3x3_mfma_bf16_f32out(xa.data_ptr(), xb.data_ptr(), K1, wf.data_ptr(), y.data_ptr(), ws.data_ptr() if wsb else None, wsb,
+                                   B, H, W, K, N, S())
+    else:
+        L.conv3x3_mfma_bf16_f32out(xd.data_ptr(), None, 0, wf.data_ptr(), y.data_ptr(), ws.data_ptr() if wsb else None, wsb, B, H, W, K, N, S())
+    close(host(y), ref, 2e-5, "fp32-output convolution")
+    from phiseg_code_amd.runtime import PhxError
+    if wsb:
+        with pytest.raises(PhxError):            # a split-K shape without its workspace
+            L.conv3x3_mfma_bf16_f32out(xd.data_ptr(), None, 0, wf.data_ptr(), y.data_ptr(), None, 0, B, H, W, K, N, S())
 
 
 def _mfma_case(L, case):
@@ -665,7 +706,7 @@ def test_bn_small_one_launch_layer(L, case):
     mv = dev(1.0 + 0.3 * RNG.random(C))
     mm0, mv0 = host(mm).copy(), host(mv).copy()
     a = torch.empty(B, H, W, C, dtype=torch.bfloat16).cuda()
-    L.bn_small_fwd(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-3, a.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+    L.bn_small_fwd(xd.data_ptr(), BF16, gd.data_ptr(), bd.data_ptr(), 1e-3, a.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                    scale.data_ptr(), shift.data_ptr(), mm.data_ptr(), mv.data_ptr(), 0.01, P, C, act, S())
     close(host(a), ar.detach().numpy(), 6e-3, "bn_small fwd")
     close(host(mean), mean_r.detach().numpy(), 1e-5, "bn_small mean")
@@ -686,19 +727,6 @@ def test_bn_small_one_launch_layer(L, case):
                        act, S())
     close(host(scale), host(scale3), 2e-5, "bn_small vs three-launch scale")
     close(host(shift), host(shift3), 2e-5, "bn_small vs three-launch shift")
-    # fed by split-K slices (the convolution skipped its finishing pass): same layer, plus the bf16 copy of the summed input
-    nz = 3
-    parts = RNG.standard_normal((nz, B, H, W, C)).astype(np.float32)
-    parts[nz - 1] = x.astype(np.float32) - parts[:nz - 1].sum(axis=0)
-    pd = torch.as_tensor(parts).cuda()
-    xs = torch.as_tensor(parts).cuda().sum(0)                    # what the kernel rounds to bf16
-    xsr = xs.to(torch.bfloat16).double().cpu()
-    ys, _, _ = T.batch_norm_train(xsr, gr.detach(), br.detach())
-    a4, x4 = torch.empty_like(a), torch.empty_like(a)
-    L.bn_small_fwd_splitk(pd.data_ptr(), nz, x4.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-3, a4.data_ptr(), mean3.data_ptr(),
-                          rstd3.data_ptr(), scale3.data_ptr(), shift3.data_ptr(), None, None, 0.0, P, C, act, S())
-    close(host(x4), xsr.numpy(), 4e-3, "bn_small split-K summed input")      # (summation order may flip a bf16 rounding)
-    close(host(a4), (T.relu(ys) if act else ys).numpy(), 8e-3, "bn_small split-K fwd")
     dA = RNG.standard_normal((B, H, W, C))
     dAr = rounded(dA, BF16)
     (ar * dAr).sum().backward()
@@ -706,11 +734,45 @@ def test_bn_small_one_launch_layer(L, case):
     dx = torch.empty(B, H, W, C, dtype=torch.bfloat16).cuda()
     dgamma = torch.full((C,), 0.5, dtype=torch.float32).cuda()        # accumulated (+=), not overwritten
     dbeta = torch.full((C,), -0.25, dtype=torch.float32).cuda()
-    L.bn_small_bwd(dAd.data_ptr(), xd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+    L.bn_small_bwd(dAd.data_ptr(), xd.data_ptr(), BF16, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                    gd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), P, C, act, S())
     close(host(dx), xr.grad.numpy(), 8e-3, "bn_small dx")
     close(host(dgamma) - 0.5, gr.grad.numpy(), 2e-3, "bn_small dgamma")
     close(host(dbeta) + 0.25, br.grad.numpy(), 2e-3, "bn_small dbeta")
+    if P > 1024:
+        return
+    # fp32 pre-normalisation tensor (round 5: what phx_conv3x3_mfma_bf16_f32out leaves on the 2 x 2 / 4 x 4 levels).  The case bf16
+    # storage cannot do: channels whose values spread by 2 % around a mean of 8 -- a bf16 grid step there (2^-4 = 0.0625) is 40 % of the
+    # standard deviation, the fp32 path normalises the values as they are: compared with the oracle on the UNROUNDED input.
+    xw = 8.0 + 0.16 * RNG.standard_normal((B, H, W, C))
+    xw32 = torch.as_tensor(xw, dtype=torch.float32)
+    xwr = xw32.double().requires_grad_(True)
+    gr2, br2 = gr.detach().clone().requires_grad_(True), br.detach().clone().requires_grad_(True)
+    yw, mean_w, _ = T.batch_norm_train(xwr, gr2, br2)
+    aw = T.relu(yw) if act else yw
+    xwd = xw32.cuda()
+    a5 = torch.empty_like(a)
+    L.bn_small_fwd(xwd.data_ptr(), F32, gd.data_ptr(), bd.data_ptr(), 1e-3, a5.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                   scale.data_ptr(), shift.data_ptr(), None, None, 0.0, P, C, act, S())
+    close(host(a5), aw.detach().numpy(), 6e-3, "bn_small fwd, fp32 input")
+    close(host(mean), mean_w.detach().numpy(), 1e-5, "bn_small mean, fp32 input")
+    if P >= 64:                          # the same layer through bf16 storage of x is off by tenths of the output's spread
+        a6 = torch.empty_like(a)
+        m6, r6, s6, h6 = (torch.empty_like(t) for t in (mean, rstd, scale, shift))
+        L.bn_small_fwd(xwd.to(torch.bfloat16).data_ptr(), BF16, gd.data_ptr(), bd.data_ptr(), 1e-3, a6.data_ptr(), m6.data_ptr(), r6.data_ptr(),
+                       s6.data_ptr(), h6.data_ptr(), None, None, 0.0, P, C, act, S())
+        e_bf16 = np.abs(host(a6) - aw.detach().numpy()).max()
+        e_f32 = np.abs(host(a5) - aw.detach().numpy()).max()
+        assert e_bf16 > 10 * e_f32 and e_bf16 > 0.1, (e_bf16, e_f32)
+    (aw * dAr).sum().backward()
+    dgamma.fill_(0.5); dbeta.fill_(-0.25)
+    L.bn_small_bwd(dAd.data_ptr(), xwd.data_ptr(), F32, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                   gd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), P, C, act, S())
+    # (dx is large here -- rstd ~ 6 -- and bf16 on output: relative bound)
+    ref = xwr.grad.numpy()
+    assert np.abs(host(dx) - ref).max() <= 8e-3 * max(1.0, np.abs(ref).max()), np.abs(host(dx) - ref).max()
+    close(host(dgamma) - 0.5, gr2.grad.numpy(), 4e-3, "bn_small dgamma, fp32 input")
+    close(host(dbeta) + 0.25, br2.grad.numpy(), 2e-3, "bn_small dbeta, fp32 input")
 
 
 @pytest.mark.parametrize("case", [("group", 3, 8, 8, 32, 2, 1), ("group", 2, 4, 4, 192, 12, 1), ("group", 64, 2, 2, 192, 12, 1),
@@ -1208,7 +1270,7 @@ def test_abi_rejects_bad_arguments_loudly(L):
     with pytest.raises(PhxError, match="nout"):
         L.head1x1_wgrad(x.data_ptr(), BF16, f.data_ptr(), f.data_ptr(), f.data_ptr(), 512, 64, 3, S())
     with pytest.raises(PhxError, match="P <= 4096"):
-        L.bn_small_fwd(x.data_ptr(), f.data_ptr(), f.data_ptr(), 1e-3, y.data_ptr(), f.data_ptr(), f.data_ptr(), f.data_ptr(), f.data_ptr(),
+        L.bn_small_fwd(x.data_ptr(), BF16, f.data_ptr(), f.data_ptr(), 1e-3, y.data_ptr(), f.data_ptr(), f.data_ptr(), f.data_ptr(), f.data_ptr(),
                        None, None, 0.0, 5000, 64, 1, S())
     with pytest.raises(PhxError, match="empty job list"):
         L.wgrad_reduce_multi(None, 0, 0, S())
@@ -1240,10 +1302,11 @@ def test_comm_abi_single_rank_rccl(L):
 @pytest.mark.parametrize("case", [(2, 16, 16, 32, 64), (3, 4, 4, 192, 64), (1, 32, 64, 96, 128), (2, 12, 12, 32, 32), (40, 2, 2, 64, 96),
                                   (1, 16, 64, 32, 32), (2, 16, 32, 64, 96)])
 @pytest.mark.parametrize("act", ["relu", "identity"])
-def test_conv3x3_mfma_affine_epilogue(L, case, act):
+def test_conv3x3_mfma_affine_epilogue(Ld, case, act):
     """Inference-mode batch norm + activation folded into the convolution (reference: conv2d -> batch_norm(is_training=False)
     -> relu, tfwrapper/layers.py:123-135, normalisation.py:145-163): y = act(conv(x) * scale + shift) in one launch, on the
     256-pixel tiles, the split-K small-map path and (forced) the large-map kernels."""
+    L = Ld                                   # (the test build: this test sets the kernel policy)
     B, H, W, K, N = case
     x = RNG.standard_normal((B, H, W, K))
     w = RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K)
@@ -1430,10 +1493,11 @@ def test_norm_layer_with_fused_head(L, case):
                                   # BASELINE-size concatenations (the default policy's kernels; the CPU oracle is skipped there)
                                   (64, 128, 128, 32, 32, 128), (64, 64, 64, 128, 64, 192)])
 @pytest.mark.parametrize("force_dma", [0, 1, 2])
-def test_conv3x3_concat_free(L, case, force_dma, policy):
+def test_conv3x3_concat_free(Ld, case, force_dma, policy):
     """Concat-free convolution (tf.concat([a, b], axis=3) -> conv2D 3x3: posteriors.py:87,120, priors.py:112, likelihoods.py:210):
     forward with a dual input, data gradient with a dual output and the filter gradient with a dual input equal the same launches on
     the materialised concatenation (forward / data gradient bit for bit), and the forward pass matches the oracle's concat + conv."""
+    L = Ld                                   # (the test build: this test sets the kernel policy)
     from oracle import tf1_ops as O
     B, H, W, K1, K2, N = case
     if force_dma and B * H * W > 65536:
@@ -1514,10 +1578,11 @@ def test_conv3x3_concat_free(L, case, force_dma, policy):
 
 
 @pytest.mark.parametrize("case", [(64, 16, 32), (5, 48, 96), (3, 16, 64), (2, 32, 32)])
-def test_conv3x3_c32_against_the_general_kernel(L, case, policy):
+def test_conv3x3_c32_against_the_general_kernel(Ld, case, policy):
     """k_conv3x3_c32 (32 -> 32 channels on large maps: filter in registers, persistent tiles; forced here on small maps) against the
     256-pixel kernel through the same entry points -- plain output, bias + activation epilogue, per-tile partial statistics -- and
     against the oracle's conv2d."""
+    L = Ld                                   # (the test build: this test sets the kernel policy)
     B, H, W = case
     K = N = 32
     x = RNG.standard_normal((B, H, W, K))
@@ -1645,6 +1710,7 @@ def test_conv3x3_split_k_finish_slice_counts(L):
                                   (1, 16, 64, 160, 128), (2, 32, 32, 32, 32), (1, 16, 64, 192, 32), (3, 16, 32, 64, 96),
                                   (5, 16, 32, 64, 64), (1, 16, 32, 32, 64)])
 @pytest.mark.parametrize("grid", [0, 1, 3])
-def test_conv3x3_mfma_pair_kernel(L, case, grid, policy):
+def test_conv3x3_mfma_pair_kernel(Ld, case, grid, policy):
+    L = Ld                                   # (the test build: this test sets the kernel policy)
     policy(large_maps=2, pair_grid=grid)
     _mfma_case(L, case)

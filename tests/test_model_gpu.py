@@ -777,21 +777,46 @@ def test_bf16_training_step_probunet_n0_32_vs_oracle():
     assert n >= 100
 
 
-def test_bf16_trains_like_fp32_n0_32_batch12_200_steps():
-    """Does the benchmarked precision train?  (round-3 review: the single-step bf16 gradients deviate ~30 % from the exact ones --
-    bf16 storage of the activations -- and nothing showed that such a model reaches the ELBO the fp32 path reaches.)
+def test_bf16_trains_like_fp32_default_mode_four_seeds():
+    """Does the benchmarked precision train, in the mode that is benchmarked?  (round-4 review: the deterministic-mode gate below is
+    evidence for a sibling of the benchmarked path, and its tolerance could not see a bias of several per cent.)
     phiseg_7_5 at the benchmark's width (n0 = 32, 128 x 128, batch norm), batch 12 (the reference's batch size, phiseg_7_5.py:40),
-    200 training steps (TF1 Adam, lr 1e-3: the reference's schedule) cycling over EIGHT fixed synthetic batches, on the bf16 engine
-    and on the fp32 engine (the path pinned to the oracle at 1e-4) from the same initial weights and batches -- each with TWO Philox
-    noise seeds, because training is chaotic: two fp32 runs that differ only in the noise seed end 6-9 % apart (measured), so
-    that spread, not a fixed 3 %, is the resolution of the experiment.  The four runs are four worker processes side by side under
-    PHX_DETERMINISTIC=1 (tests/convergence_worker.py): with ordered reductions the trajectories are bit-reproducible, so the outcome
-    is one fixed set of numbers -- in the default mode the atomics' summation order made every repetition a different draw (five
-    repetitions: ELBO bf16 / fp32 = 1.052 ... 1.103, summed cross-entropy 1.016 ... 1.049) and a fixed floor failed on noise alone
-    about one run in ten.  Asserted on the means over the last 50 steps: every run has come down > 10x from its first ELBO; the bf16
-    ELBO (mean of the two seeds) lies within max(3 %, 1.5 x the larger seed spread) of the fp32 one, the summed cross-entropy (the
-    well-conditioned 70 % of the ELBO) and every cross-entropy level within max(7.5 %, 1.5 x the larger seed spread).  A model
-    that does not train in bf16 is off by tens of per cent."""
+    200 training steps (TF1 Adam, lr 1e-3: the reference's schedule, phiseg_model.py:186-207) cycling over eight fixed synthetic
+    batches, from the same initial weights on the bf16 engine and on the fp32 engine (the path pinned to the oracle at 1e-4), FOUR
+    Philox noise seeds per dtype, DEFAULT (atomics) mode -- eight worker processes side by side (tests/convergence_worker.py).
+    Asserted on the means over the last 50 steps: every run has come down > 10x from its first ELBO, and
+    |mean(bf16) / mean(fp32) - 1| <= max(2 %, 2 x standard error of the ratio) on the ELBO, on the KL sum and on the cross-entropy
+    sum separately (the KL terms, phiseg_model.py:210-226, are where bf16 storage showed: round 4 measured ELBO + 5-10 %, the two
+    coarsest KL levels + 40 % -- the bf16 pre-normalisation tensor of the 2 x 2 / 4 x 4 batch-norm layers, fp32 since round 5).
+    Training is chaotic -- two fp32 runs that differ only in the noise seed end 6-13 % apart -- so four seeds resolve ~10 %;
+    the 32-seed study behind the fix is profiles/r05_convergence_study_32_seeds.txt (tools/convergence_study.py):
+    ELBO ratio 1.00 +- 0.03 after, 1.08 before."""
+    from tests.convergence_lib import run_all, summarise
+    env_was = os.environ.pop("PHX_DETERMINISTIC", None)
+    try:
+        res = run_all([(dt, so) for so in range(4) for dt in ("f32", "bf16")], 8, 200, 50)
+    finally:
+        if env_was is not None:
+            os.environ["PHX_DETERMINISTIC"] = env_was
+    assert len(res) == 8, sorted(res)
+    it = next(iter(res.values()))["keys"].index("total_loss")
+    for key, run in res.items():
+        assert run["finite"], key
+        assert run["tail"][it] < 0.1 * run["first"][it], (key, run["first"][it], run["tail"][it])      # it trained
+    rows = {name: (r, rse) for name, _, r, rse in summarise(res, ("f32", "bf16"))}
+    bad = {name: rows[name] for name in ("ELBO", "KL sum (unweighted)", "CE sum")
+           if not abs(rows[name][0] - 1.0) <= max(0.02, 2.0 * rows[name][1])}
+    assert not bad, bad
+
+
+def test_bf16_trains_like_fp32_n0_32_batch12_200_steps():
+    """The REPRODUCIBLE record of the same experiment (see the four-seed default-mode gate above): two noise seeds per dtype under
+    PHX_DETERMINISTIC=1 -- with ordered reductions the trajectories are bit-reproducible, so the outcome is one fixed set of numbers
+    (in the default mode the atomics' summation order makes every repetition a different draw of a chaotic system).  Note that the
+    deterministic mode swaps in other kernels for the reductions (ordered filter-gradient folds, two-launch group norm): it is the
+    record, the default-mode test is the gate.  Asserted on the means over the last 50 steps: every run has come down > 10x from
+    its first ELBO; the bf16 ELBO (mean of the two seeds) lies within max(3 %, 1.5 x the larger seed spread) of the fp32 one, the
+    summed cross-entropy and every cross-entropy level within max(7.5 %, 1.5 x the larger seed spread)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

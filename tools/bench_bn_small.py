@@ -22,9 +22,9 @@ for (P, C) in [(256, 192), (1024, 192), (1024, 384), (4096, 192)]:
     gamma, beta = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
     mean, rstd, scale, shift = (torch.empty(C, device="cuda") for _ in range(4))
     dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
-    f = lambda: L.bn_small_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-3, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+    f = lambda: L.bn_small_fwd(x.data_ptr(), 1, gamma.data_ptr(), beta.data_ptr(), 1e-3, y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                scale.data_ptr(), shift.data_ptr(), None, None, 0.0, P, C, 1, st)
-    b = lambda: L.bn_small_bwd(dA.data_ptr(), x.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+    b = lambda: L.bn_small_bwd(dA.data_ptr(), x.data_ptr(), 1, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                gamma.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), P, C, 1, st)
     f()
     print("P=%5d C=%3d | fwd %6.2f us | bwd %6.2f us" % (P, C, timeit(f), timeit(b)), flush=True)

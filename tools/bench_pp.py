@@ -5,7 +5,7 @@ import os, sys
 import torch
 sys.path.insert(0, ".")
 from phiseg_code_amd import runtime as rt
-L = rt.lib()
+L = rt.debug_lib()
 st = torch.cuda.current_stream().cuda_stream
 shapes = [(64, 128, 128, 128, 128), (64, 64, 64, 192, 192), (64, 128, 128, 64, 128), (64, 64, 64, 128, 192), (64, 128, 128, 192, 32),
           (64, 128, 128, 64, 64), (64, 64, 64, 64, 64), (64, 128, 128, 32, 32), (64, 128, 128, 32, 64), (64, 32, 32, 128, 128)]

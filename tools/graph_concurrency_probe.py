@@ -15,7 +15,7 @@ def mk():
 A, B_ = mk(), mk()
 def chain(t, stream, n):
     for _ in range(n):
-        L.bn_small_fwd(t["x"].data_ptr(), t["g"].data_ptr(), t["b"].data_ptr(), 1e-3, t["y"].data_ptr(), t["m"].data_ptr(), t["r"].data_ptr(),
+        L.bn_small_fwd(t["x"].data_ptr(), 1, t["g"].data_ptr(), t["b"].data_ptr(), 1e-3, t["y"].data_ptr(), t["m"].data_ptr(), t["r"].data_ptr(),
                        t["sc"].data_ptr(), t["sh"].data_ptr(), None, None, 0.0, P, C, 1, stream)
 def new_stream():
     s = ctypes.c_void_p(); L.stream_create(ctypes.byref(s)); return s

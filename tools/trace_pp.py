@@ -4,7 +4,7 @@ import numpy as np
 import torch
 sys.path.insert(0, ".")
 from phiseg_code_amd import runtime as rt
-L = rt.lib()
+L = rt.debug_lib()
 st = torch.cuda.current_stream().cuda_stream
 L.debug_conv_policy(2, 1)
 B, H, W, K, N = [int(v) for v in (sys.argv[1:6] if len(sys.argv) >= 6 else (64, 128, 128, 128, 128))]
