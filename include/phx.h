@@ -34,6 +34,8 @@ int phx_last_error(char* buf, size_t n);
 int phx_crc32c(const void* data, size_t n, unsigned* crc);
 int phx_device_info(int* cu_count, int* clock_khz, size_t* hbm_bytes, char* name, size_t name_n);
 int phx_stream_create(void** stream);
+/* ... with a scheduling priority (0: default, negative: higher; clamped to the device's range) */
+int phx_stream_create_priority(void** stream, int priority);
 int phx_stream_destroy(void* stream);
 int phx_stream_sync(void* stream);
 int phx_event_create(void** ev);
@@ -257,18 +259,12 @@ int phx_norm_apply_fused(const void* x, int x_dt, const float* sums, const float
                          const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
                          float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
                          int G, int act, void* stream);
-/* the same reading REPLICATED sums[nrep][NS][C][2] (summed per block in the prologue): what phx_conv3x3_mfma_bf16_stats_rep leaves;
- * nrep > 1 only for one channel per statistic (batch / instance norm) and pivot == NULL */
-int phx_norm_apply_fused_rep(const void* x, int x_dt, const float* sums, int nrep, const float* pivot, const float* gamma,
-                             const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
-                             float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
-                             int G, int act, void* stream);
 /* ... and with a 1x1 HEAD fused in (the likelihood's top layer feeding y_lvl0, likelihoods.py:220: the head is the only reader of
  * a = act(norm(x))): y receives a as usual and y_head[NS * P][nout] = b_head + a w_head (w_head the HWIO 1x1 filter [C][nout]), computed
  * from the values just produced instead of by a pass of its own over a.  bf16 in / out, C / 8 a power of two <= 64, nout in {2, 4}
  * (phx_norm_head_supported).  Backward: phx_norm_bwd_reduce_head / phx_norm_bwd_apply_fused_head form dA = dy_head w_head^T on the fly. */
 int phx_norm_head_supported(int C, int nout, int x_dt, int y_dt);
-int phx_norm_apply_fused_head(const void* x, int x_dt, const float* sums, int nrep, const float* pivot, const float* gamma,
+int phx_norm_apply_fused_head(const void* x, int x_dt, const float* sums, const float* pivot, const float* gamma,
                               const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
                               float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
                               int G, int act, const float* w_head, const float* b_head, int nout, float* y_head, void* stream);

@@ -857,7 +857,7 @@ __global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __rest
         float mu, var;
         if (cg == 1) {                                      // batch / instance norm: one channel per statistic
             float2 sq = *reinterpret_cast<const float2*>(sums + ((size_t)ns * C + g) * 2);
-            for (int r = 1; r < nrep; ++r) {                    // replicated accumulators (phx_conv3x3_mfma_bf16_stats_rep)
+            for (int r = 1; r < nrep; ++r) {                    // (replicated accumulators: nrep is 1 on every shipped path)
                 const float2 q = *reinterpret_cast<const float2*>(sums + (((size_t)r * gridDim.y + ns) * C + g) * 2);
                 sq.x += q.x; sq.y += q.y;
             }
@@ -1650,24 +1650,17 @@ static int norm_apply_impl(const void* x, int x_dt, const float* sums, int nrep,
                            const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
                            float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
                            int G, int act, HeadFw hd, int hn, void* stream);
-int phx_norm_apply_fused_rep(const void* x, int x_dt, const float* sums, int nrep, const float* pivot, const float* gamma,
-                             const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
-                             float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
-                             int G, int act, void* stream) {
-    return norm_apply_impl(x, x_dt, sums, nrep, pivot, gamma, beta, eps, y, y_dt, mean, rstd, scale, shift, moving_mean, moving_var, momentum,
-                           NS, P, C, G, act, HeadFw{nullptr, nullptr, nullptr}, 0, stream);
-}
 int phx_norm_head_supported(int C, int nout, int x_dt, int y_dt) {
     const int cv = C / 8;
     return (x_dt == PHX_BF16 && y_dt == PHX_BF16 && C % 8 == 0 && (nout == 2 || nout == 4) && cv >= 1 && cv <= 64 && (cv & (cv - 1)) == 0) ? 1 : 0;
 }
-int phx_norm_apply_fused_head(const void* x, int x_dt, const float* sums, int nrep, const float* pivot, const float* gamma,
+int phx_norm_apply_fused_head(const void* x, int x_dt, const float* sums, const float* pivot, const float* gamma,
                               const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
                               float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
                               int G, int act, const float* w_head, const float* b_head, int nout, float* y_head, void* stream) {
     PHX_REQUIRE(phx_norm_head_supported(C, nout, x_dt, y_dt) && w_head && b_head && y_head, PHX_E_SHAPE,
                 "norm_apply_fused_head: bf16, C / 8 a power of two <= 64, nout in {2, 4}");
-    return norm_apply_impl(x, x_dt, sums, nrep, pivot, gamma, beta, eps, y, y_dt, mean, rstd, scale, shift, moving_mean, moving_var, momentum,
+    return norm_apply_impl(x, x_dt, sums, 1, pivot, gamma, beta, eps, y, y_dt, mean, rstd, scale, shift, moving_mean, moving_var, momentum,
                            NS, P, C, G, act, HeadFw{w_head, b_head, y_head}, nout, stream);
 }
 static int norm_apply_impl(const void* x, int x_dt, const float* sums, int nrep, const float* pivot, const float* gamma,
@@ -1675,7 +1668,7 @@ static int norm_apply_impl(const void* x, int x_dt, const float* sums, int nrep,
                            float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
                            int G, int act, HeadFw hd, int hn, void* stream) {
     PHX_REQUIRE(G > 0 && C % G == 0, PHX_E_SHAPE, "norm_apply_fused: C % G != 0");
-    PHX_REQUIRE(nrep == 1 || (nrep > 1 && G == C && pivot == nullptr), PHX_E_INVAL, "norm_apply_fused_rep: replicas only for one channel per statistic, no pivot");
+    PHX_REQUIRE(nrep == 1 || (nrep > 1 && G == C && pivot == nullptr), PHX_E_INVAL, "norm_apply_fused: replicas only for one channel per statistic, no pivot");
     if (hn > 0) {
         int PL, threads, chunk, nchunks;
         PHX_REQUIRE(stream_geometry(P, C, 8, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_apply_fused_head: C too large");
@@ -1703,8 +1696,8 @@ int phx_norm_apply_fused(const void* x, int x_dt, const float* sums, const float
                          const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
                          float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
                          int G, int act, void* stream) {
-    return phx_norm_apply_fused_rep(x, x_dt, sums, 1, pivot, gamma, beta, eps, y, y_dt, mean, rstd, scale, shift, moving_mean, moving_var,
-                                    momentum, NS, P, C, G, act, stream);
+    return norm_apply_impl(x, x_dt, sums, 1, pivot, gamma, beta, eps, y, y_dt, mean, rstd, scale, shift, moving_mean, moving_var, momentum,
+                           NS, P, C, G, act, HeadFw{nullptr, nullptr, nullptr}, 0, stream);
 }
 
 int phx_norm_bwd_apply_fused(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,

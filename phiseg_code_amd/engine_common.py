@@ -1,0 +1,125 @@
+"""Shared by the engine modules (engine.py: parameter store, plan construction, capture and replay; engine_forward.py: lowering of
+the forward operators; engine_backward.py: the reverse-mode backward pass): dtype codes, schedule constants, device buffers."""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from phiseg_code_amd import graph as G
+from phiseg_code_amd import runtime as rt
+from phiseg_code_amd.tfwrapper import normalisation as tfnorm
+
+__all__ = ['F32', 'BF16', 'U8', '_TORCH_DT', '_NP_DT', '_ESIZE', '_LIK_SIDE_MAXLVL', '_WGRAD_DEFER_BLOCKS', '_NREP', '_NREP_MINP', '_STAMPS', '_DETERMINISTIC', '_BN_SMALL', '_BN_SMALL_F32', '_fgn_mode', '_dual_enabled', '_noop', '_device', 'live_variables', 'device_sync', 'Buf', 'DualBuf', 'HeadGrad']
+
+F32, BF16, U8 = rt.F32, rt.BF16, 2
+_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, U8: torch.uint8}
+_NP_DT = {F32: np.float32, U8: np.uint8}
+_ESIZE = {F32: 4, BF16: 2, U8: 1}
+# two lanes: likelihood chains of levels <= this go to the prior's lane; the coarsest chain stays on lane 0, in front of the top-down
+# path that starts with it: lane 0 then enters the likelihood without waiting for lane 1 (with all five chains there it started only
+# when the LAST of them was done, whatever the order: 12.38 vs 11.95 ms)
+_LIK_SIDE_MAXLVL = 3
+_WGRAD_DEFER_BLOCKS = 96      # pixel-tile split target of a deferred layer (measured 16 .. 192: fewer slices are long tail blocks)
+_NREP = 4                     # accumulator replicas of the norm backward reduction (re-measured with the LDS-shared prologues; 8 before)
+_NREP_MINP = 4096
+_STAMPS = os.environ.get("PHX_STAMPS", "0") == "1"           # dev: per-operator device time stamps (tools/lane_timeline.py)
+_DETERMINISTIC = os.environ.get("PHX_DETERMINISTIC", "0") not in ("0", "")   # fixed summation orders everywhere (libphx reads the same variable)
+_BN_SMALL = 1024              # one-launch batch norm up to this many pixels
+_BN_SMALL_F32 = os.environ.get("PHX_BN_SMALL_F32", "1") != "0"      # dev A/B (tools/convergence_study.py): fp32 pre-normalisation tensor of those layers
+
+
+def _fgn_mode():
+    # conv + bias + group norm + activation in one launch on maps <= 16 x 16 (phx_conv3x3_mfma_bf16_fgn).  1: group norm (16-channel
+    # groups); 2: instance norm too (per-channel statistics: every lane adds to the LDS table -- measured 11.24 vs 11.15 ms, so not
+    # by default); 0: off.  Group norm, phiseg_7_5 B = 64: 11.28 vs 11.28 - 11.30 ms with 57 launches fewer.
+    return int(os.environ.get("PHX_FGN", "1"))
+
+
+def _dual_enabled():
+    return os.environ.get("PHX_DUAL", "1") == "1"      # concat -> conv3x3 edges without the concatenated tensor (A/B hook; read when a plan is built)
+
+
+def _noop():
+    pass
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise rt.PhxError("no GPU visible: the PHiSeg engine has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def live_variables(loss):
+    """Names of the variables the scalar `loss` depends on (TF: the variables optimizer.minimize gets a gradient for)."""
+    seen, live, stack = set(), set(), [loss.op]
+    while stack:
+        op = stack.pop()
+        if op in seen:
+            continue
+        seen.add(op)
+        if op.type == "l2_weights":            # weight decay reaches every member of the collection (never-consumed branches too)
+            live.update(v.name for v in op.attrs["vars"])
+        if op.type == "conv_unit":
+            a = op.attrs
+            for v in (a["W"], a["b"]):
+                if v is not None:
+                    live.add(v.name)
+            for v in (a.get("norm_vars") or {}).values():
+                live.add(v.name)
+        if op.type == "norm_act":
+            for v in (op.attrs.get("norm_vars") or {}).values():
+                live.add(v.name)
+        stack.extend(i.op for i in op.inputs)
+    return live
+
+
+def device_sync():
+    """Order work enqueued through torch (parameter loads, lr / step updates, broadcasts) before plan replays, which run on
+    the plans' own non-blocking HIP streams."""
+    torch.cuda.synchronize()
+
+
+class Buf:
+    """A device buffer: torch owns the memory, libphx sees the raw pointer."""
+
+    def __init__(self, shape, dt, zero=False, like=None):
+        self.shape = tuple(int(s) for s in shape)
+        self.dt = dt
+        n = int(np.prod(self.shape)) if self.shape else 1
+        self.n = n
+        if like is not None:
+            self.t = like
+        else:
+            self.t = (torch.zeros if zero else torch.empty)(max(n, 1), dtype=_TORCH_DT[dt], device=_device())
+        self.ptr = self.t.data_ptr()
+        self.shift = 0           # nearest-neighbour view: logical size = stored size << shift
+
+    @property
+    def nbytes(self):
+        return self.n * _ESIZE[self.dt]
+
+    def numpy(self):
+        torch.cuda.synchronize()
+        a = self.t[:self.n].float().cpu().numpy() if self.dt != U8 else self.t[:self.n].cpu().numpy()
+        return a.reshape(self.shape)
+
+
+class DualBuf:
+    """The value of tf.concat([a, b], axis=3) whose only reader is a 3x3 convolution: never materialised -- the convolution reads
+    the two tensors in place (struct Dual in csrc/conv_mfma.hip), its data gradient writes their two gradients directly."""
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+        self.shape = tuple(a.shape[:-1]) + (a.shape[-1] + b.shape[-1],)
+        self.dt, self.ptr, self.n, self.shift = a.dt, a.ptr, a.n + b.n, 0
+        self.k1 = a.shape[-1]
+
+
+class HeadGrad:
+    """Placeholder for the gradient of a = act(norm(y)) whose only reader is a 1x1 head: dA = dy_head w_head^T is never materialised,
+    the producer's norm backward launches form it on the fly (phx_norm_bwd_reduce_head / phx_norm_bwd_apply_fused_head)."""
+
+    def __init__(self, like, dy, w_ptr, nout):
+        self.shape, self.dt, self.n = like.shape, like.dt, like.n
+        self.dy, self.w_ptr, self.nout = dy, w_ptr, nout

@@ -743,35 +743,34 @@ def test_bn_small_one_launch_layer(L, case):
         return
     # fp32 pre-normalisation tensor (round 5: what phx_conv3x3_mfma_bf16_f32out leaves on the 2 x 2 / 4 x 4 levels).  The case bf16
     # storage cannot do: channels whose values spread by 2 % around a mean of 8 -- a bf16 grid step there (2^-4 = 0.0625) is 40 % of the
-    # standard deviation, the fp32 path normalises the values as they are: compared with the oracle on the UNROUNDED input.
+    # standard deviation, the fp32 path normalises the values as they are: compared with the oracle on the UNROUNDED input
+    # (identity activation here: with a ReLU the handful of elements whose pre-activation is within fp32 round-off of zero take
+    # the other branch than the float64 oracle, and one such element moves dbeta by a whole dA)
     xw = 8.0 + 0.16 * RNG.standard_normal((B, H, W, C))
     xw32 = torch.as_tensor(xw, dtype=torch.float32)
     xwr = xw32.double().requires_grad_(True)
     gr2, br2 = gr.detach().clone().requires_grad_(True), br.detach().clone().requires_grad_(True)
-    yw, mean_w, _ = T.batch_norm_train(xwr, gr2, br2)
-    aw = T.relu(yw) if act else yw
+    aw, mean_w, _ = T.batch_norm_train(xwr, gr2, br2)
     xwd = xw32.cuda()
     a5 = torch.empty_like(a)
     L.bn_small_fwd(xwd.data_ptr(), F32, gd.data_ptr(), bd.data_ptr(), 1e-3, a5.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                   scale.data_ptr(), shift.data_ptr(), None, None, 0.0, P, C, act, S())
+                   scale.data_ptr(), shift.data_ptr(), None, None, 0.0, P, C, 0, S())
     close(host(a5), aw.detach().numpy(), 6e-3, "bn_small fwd, fp32 input")
     close(host(mean), mean_w.detach().numpy(), 1e-5, "bn_small mean, fp32 input")
     if P >= 64:                          # the same layer through bf16 storage of x is off by tenths of the output's spread
         a6 = torch.empty_like(a)
         m6, r6, s6, h6 = (torch.empty_like(t) for t in (mean, rstd, scale, shift))
         L.bn_small_fwd(xwd.to(torch.bfloat16).data_ptr(), BF16, gd.data_ptr(), bd.data_ptr(), 1e-3, a6.data_ptr(), m6.data_ptr(), r6.data_ptr(),
-                       s6.data_ptr(), h6.data_ptr(), None, None, 0.0, P, C, act, S())
+                       s6.data_ptr(), h6.data_ptr(), None, None, 0.0, P, C, 0, S())
         e_bf16 = np.abs(host(a6) - aw.detach().numpy()).max()
         e_f32 = np.abs(host(a5) - aw.detach().numpy()).max()
         assert e_bf16 > 10 * e_f32 and e_bf16 > 0.1, (e_bf16, e_f32)
     (aw * dAr).sum().backward()
     dgamma.fill_(0.5); dbeta.fill_(-0.25)
     L.bn_small_bwd(dAd.data_ptr(), xwd.data_ptr(), F32, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                   gd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), P, C, act, S())
-    # (dx is large here -- rstd ~ 6 -- and bf16 on output: relative bound)
-    ref = xwr.grad.numpy()
-    assert np.abs(host(dx) - ref).max() <= 8e-3 * max(1.0, np.abs(ref).max()), np.abs(host(dx) - ref).max()
-    close(host(dgamma) - 0.5, gr2.grad.numpy(), 4e-3, "bn_small dgamma, fp32 input")
+                   gd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), P, C, 0, S())
+    close(host(dx), xwr.grad.numpy(), 8e-3, "bn_small dx, fp32 input")            # (bf16 on output)
+    close(host(dgamma) - 0.5, gr2.grad.numpy(), 2e-3, "bn_small dgamma, fp32 input")
     close(host(dbeta) + 0.25, br2.grad.numpy(), 2e-3, "bn_small dbeta, fp32 input")
 
 
@@ -1452,13 +1451,13 @@ def test_norm_layer_with_fused_head(L, case):
         return (torch.empty(B, H, W, C, dtype=torch.bfloat16).cuda(), torch.empty(NS * G).cuda(), torch.empty(NS * G).cuda(),
                 torch.empty(NS * C).cuda(), torch.empty(NS * C).cuda())
     a1, mean, rstd, scale, shift = bufs()
-    L.norm_apply_fused_rep(y.data_ptr(), BF16, sums.data_ptr(), 1, None, gamma.data_ptr(), beta.data_ptr(), eps, a1.data_ptr(), BF16,
+    L.norm_apply_fused(y.data_ptr(), BF16, sums.data_ptr(), None, gamma.data_ptr(), beta.data_ptr(), eps, a1.data_ptr(), BF16,
                            mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, None, 0.0, NS, P, C, G, 1, S())
     yh1 = torch.empty(npix, NO, dtype=torch.float32).cuda()
     L.head1x1_fwd(a1.data_ptr(), BF16, wh.data_ptr(), bh.data_ptr(), yh1.data_ptr(), npix, C, NO, 0, S())
     a2, mean2, rstd2, scale2, shift2 = bufs()
     yh2 = torch.empty(npix, NO, dtype=torch.float32).cuda()
-    L.norm_apply_fused_head(y.data_ptr(), BF16, sums.data_ptr(), 1, None, gamma.data_ptr(), beta.data_ptr(), eps, a2.data_ptr(), BF16,
+    L.norm_apply_fused_head(y.data_ptr(), BF16, sums.data_ptr(), None, gamma.data_ptr(), beta.data_ptr(), eps, a2.data_ptr(), BF16,
                             mean2.data_ptr(), rstd2.data_ptr(), scale2.data_ptr(), shift2.data_ptr(), None, None, 0.0, NS, P, C, G, 1,
                             wh.data_ptr(), bh.data_ptr(), NO, yh2.data_ptr(), S())
     assert torch.equal(a1, a2) and torch.equal(scale, scale2)

