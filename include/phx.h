@@ -34,8 +34,6 @@ int phx_last_error(char* buf, size_t n);
 int phx_crc32c(const void* data, size_t n, unsigned* crc);
 int phx_device_info(int* cu_count, int* clock_khz, size_t* hbm_bytes, char* name, size_t name_n);
 int phx_stream_create(void** stream);
-/* ... with a scheduling priority (0: default, negative: higher; clamped to the device's range) */
-int phx_stream_create_priority(void** stream, int priority);
 int phx_stream_destroy(void* stream);
 int phx_stream_sync(void* stream);
 int phx_event_create(void** ev);
@@ -129,9 +127,11 @@ int phx_conv3x3_mfma_bf16_dual(const void* x, const void* x2, int K1, const void
 /* The plain convolution with an fp32 output tensor y_f32[B*H*W][N] on small maps (the shapes the 256-pixel kernels take; not the
  * large-map / 16 x 32-tile shapes): the fp32 accumulators of the split-K instantiations reach y_f32 without a bf16 rounding (round 5:
  * input of phx_bn_small_fwd with x_dt = PHX_F32 -- tfwrapper/layers.py:123 + normalisation.py:145-163 on the 2 x 2 / 4 x 4 levels).
- * workspace: phx_conv3x3_mfma_ws_bytes bytes (NULL / 0 when that is 0); x2 / K1: concat-free input as phx_conv3x3_mfma_bf16_dual. */
+ * workspace: phx_conv3x3_mfma_ws_bytes bytes (NULL / 0 when that is 0); x2 / K1: concat-free input as phx_conv3x3_mfma_bf16_dual.
+ * sum_slices = 0: a split-K launch (phx_conv3x3_mfma_ksplit > 1) skips its finishing pass and leaves the slices ws[z][B*H*W][N] in the
+ * workspace for a consumer that sums them itself (phx_bn_wide_fwd); y_f32 is then not written (a single slice still goes to y_f32). */
 int phx_conv3x3_mfma_f32out_supported(int B, int H, int W, int K, int N);
-int phx_conv3x3_mfma_bf16_f32out(const void* x, const void* x2, int K1, const void* wpk, float* y_f32, void* workspace,
+int phx_conv3x3_mfma_bf16_f32out(const void* x, const void* x2, int K1, const void* wpk, float* y_f32, int sum_slices, void* workspace,
                                  size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream);
 size_t phx_conv3x3_wgrad_ws_bytes_dual(int B, int H, int W, int Cin, int Cout, int K1);
 int phx_conv3x3_wgrad_reduce_plan_dual(int B, int H, int W, int Cin, int Cout, int K1, int* plan6);
@@ -303,6 +303,19 @@ int phx_bn_small_fwd(const void* x, int x_dt, const float* gamma, const float* b
 int phx_bn_small_bwd(const void* dA, const void* x, int x_dt, const float* scale, const float* shift, const float* mean,
                      const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, int P, int C, int act,
                      void* stream);
+/* The WIDE form of the same layer for P <= 1024 (the 2 x 2 / 4 x 4 levels at batch 64; round 5): the fp32 pre-normalisation tensor is
+ * given as the nz split-K slices xs[z][P][C] the convolution left in its workspace (phx_conv3x3_mfma_bf16_f32out with sum_slices = 0;
+ * nz = phx_conv3x3_mfma_ksplit; nz = 1: xs is the tensor itself) -- this launch is also the split-K finishing pass: it adds the slices
+ * in slice order, writes their sum to xsum[P][C] (nz > 1; what the backward pass reads) and normalises.  A block owns four channels of
+ * all pixels: C / 4 blocks.  bwd: dA as a bf16 tensor, or as the nzd fp32 slices the consumer's split-K data gradient left
+ * (rounded to bf16 after the sum, as its finishing pass would have); x is the fp32 tensor. */
+int phx_bn_wide_supported(int P, int C);
+int phx_bn_wide_fwd(const float* xs, int nz, float* xsum, const float* gamma, const float* beta, float eps, void* y, float* mean,
+                    float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var, float momentum, int P, int C,
+                    int act, void* stream);
+int phx_bn_wide_bwd(const void* dA, const float* dA_slices, int nzd, const float* x, const float* scale, const float* shift,
+                    const float* mean, const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, int P, int C,
+                    int act, void* stream);
 /* Group / instance norm (tfwrapper/normalisation.py:3-36), bf16 NHWC, the whole layer in ONE launch when a sample has
  * P = H*W <= 256 pixels (maps up to 16 x 16) and the statistic is per channel (G == C: instance norm) or per 16-channel
  * group (G * 16 == C: group_norm2D's default groups for C >= 32): a wave owns (sample, 16-channel slice) pairs, keeps the

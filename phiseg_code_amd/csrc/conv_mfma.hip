@@ -174,6 +174,7 @@ struct EpiOpts {
     int stats_atomic;         // stats_partial is the accumulator sums[N][2] itself, added to atomically (few pixel tiles)
     const float* oscale;      // per-output-channel scale of the bias / activation epilogue (inference-mode batch norm folded in)
     float* y_f32;             // fp32 output tensor [B * H * W][N] (phx_conv3x3_mfma_bf16_f32out): the split-K kernel's fp32 slices, summed
+    bool keep_slices;         // ... or left in the workspace: no finishing pass (the consumer sums them: phx_bn_wide_fwd)
 };
 
 // Arguments of the one-launch conv + bias + group / instance norm + activation epilogue (FGN instantiations).
@@ -385,7 +386,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
         // issued before the MFMAs of group gi (fragment registers double-buffered by group parity)
         // (NJ = 4 keeps a single fragment set -- 128 accumulator registers leave no room for two; its 8 MFMAs per group
         // cover the LDS latency of the next group's reads, which are issued right behind them)
-        constexpr int FB = NJ <= 2 ? (PHX_FRAG_DEPTH + 1) : 1;      // fragment sets: reads run PHX_FRAG_DEPTH groups ahead
+        // (64-channel blocks on the 4 x 4 x 16 / 2 x 2 x 64 tiles -- NA = 16 staging registers -- read ONE group ahead: with three
+        // fragment sets the instantiation needs 265 registers and spilled 36 - 84 bytes per lane to scratch, the only scratch user
+        // among the kernels of the headline step; the DUAL ones are compiled for one block per CU and have room)
+        constexpr int FB = NJ <= 2 ? ((NA > 8 && NJ == 2 && !DUAL) ? PHX_FRAG_DEPTH : PHX_FRAG_DEPTH + 1) : 1;      // fragment sets: reads run FB - 1 groups ahead
         bf16x8 fa[FB][2], fb[FB][NJ];
         auto read_frags = [&](auto gc) {
             constexpr int gi = decltype(gc)::value;
@@ -1011,12 +1015,13 @@ int phx_conv3x3_mfma_bf16_dual(const void* x, const void* x2, int K1, const void
 int phx_conv3x3_mfma_f32out_supported(int B, int H, int W, int K, int N) {
     return (K % KC == 0 && N % 32 == 0 && !fwd_ws64(B, H, W, K, N) && !fwd_big_tiles(B, H, W, K, N) && (double)B * H * W < 16777216.0) ? 1 : 0;
 }
-int phx_conv3x3_mfma_bf16_f32out(const void* x, const void* x2, int K1, const void* wpk, float* y_f32, void* workspace,
+int phx_conv3x3_mfma_bf16_f32out(const void* x, const void* x2, int K1, const void* wpk, float* y_f32, int sum_slices, void* workspace,
                                  size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream) {
     PHX_REQUIRE(y_f32 != nullptr && ((uintptr_t)y_f32 & 15) == 0, PHX_E_INVAL, "conv3x3_mfma_f32out: y_f32 (16-byte aligned) is required");
     PHX_REQUIRE(x2 == nullptr || (K1 > 0 && K1 % 32 == 0 && ((uintptr_t)x2 & 15) == 0), PHX_E_INVAL, "conv3x3_mfma_f32out: x2 (16-byte aligned), K1 % 32 == 0");
     EpiOpts b{};
     b.y_f32 = y_f32;
+    b.keep_slices = sum_slices == 0;
     Dual du{(const unsigned short*)x2, nullptr, x2 ? K1 : 0, 0};
     return conv3x3_mfma_impl(x, wpk, nullptr, nullptr, PHX_ACT_ID, nullptr, workspace, workspace_bytes, B, H, W, K, N, b, du, stream);
 }
@@ -1194,7 +1199,7 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
 #undef CM_DUAL
 #undef CM_DUAL1
     PHX_CHECK_LAUNCH();
-    if (ksplit > 1 && (y != nullptr || bws.y_f32 != nullptr)) {      // (neither: the caller consumes the fp32 slices itself)
+    if (ksplit > 1 && (y != nullptr || bws.y_f32 != nullptr) && !bws.keep_slices) {      // (else: the caller consumes the fp32 slices itself)
         const size_t total = (size_t)B * H * W * N;
         hipLaunchKernelGGL(k_splitk_finish, dim3(phx_grid_for(total / 4, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)workspace, ksplit, total, N, bias, act, (unsigned short*)y, bws.oscale, du.y2, du.N1, bws.y_f32);

@@ -333,6 +333,192 @@ __global__ __launch_bounds__(1024) void k_bn_small_bwd(const bf16_t* __restrict_
     }
 }
 
+// ---- the WIDE form of the one-launch batch norm (round 5): P <= 1024 pixels (the 2 x 2 / 4 x 4 levels at batch 64), fp32
+// pre-normalisation tensor given as the nz split-K slices the convolution left -- this launch is also the split-K finishing pass.
+// A block of 256 threads owns FOUR channels of all pixels (one float4 per pixel and slice), so a 192-channel layer is 48 blocks on
+// 48 CUs instead of 12: the layer is a few hundred KB to a few MB of slices, and what a launch of this size costs is the number of
+// loads a CU has in flight, not arithmetic (k_splitk_finish + k_bn_small_fwd: 4.8 + 10.6 us and a launch boundary; this: one launch).
+// The slices are added in slice order, as k_splitk_finish adds them: xsum (written for the backward pass when nz > 1) is bit-identical.
+__device__ __forceinline__ f32x4 wide_block_sum(f32x4 s, float* red /* [4 waves][4] */) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] += __shfl_xor(s[j], m);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) *reinterpret_cast<f32x4*>(red + wave * 4) = s;
+    __syncthreads();
+    f32x4 t = *reinterpret_cast<const f32x4*>(red);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(red + w * 4);
+    return t;
+}
+template <int NPT>
+__global__ __launch_bounds__(256) void k_bn_wide_fwd(const float* __restrict__ xs, int nz, size_t zstride, float* __restrict__ xsum,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                     bf16_t* __restrict__ y, float* mean_out, float* rstd_out, float* scale_out,
+                                                     float* shift_out, float* moving_mean, float* moving_var, float momentum,
+                                                     int P, int C, int act) {
+    __shared__ __attribute__((aligned(16))) float red[2][16];
+    const int c0 = blockIdx.x * 4;
+    f32x4 v[NPT];
+#pragma unroll
+    for (int it = 0; it < NPT; ++it) {
+        const int p = threadIdx.x + it * 256;
+        v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p < P) v[it] = *reinterpret_cast<const f32x4*>(xs + (size_t)p * C + c0);
+    }
+    for (int z0 = 1; z0 < nz; z0 += 4) {                 // four slices of every pixel in flight; added in slice order
+        f32x4 t[NPT][4];
+#pragma unroll
+        for (int it = 0; it < NPT; ++it) {
+            const int p = threadIdx.x + it * 256;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                t[it][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p < P && z0 + k < nz) t[it][k] = *reinterpret_cast<const f32x4*>(xs + (size_t)(z0 + k) * zstride + (size_t)p * C + c0);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NPT; ++it)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (z0 + k < nz) v[it] += t[it][k];
+    }
+    if (nz > 1 && xsum != nullptr) {
+#pragma unroll
+        for (int it = 0; it < NPT; ++it) {
+            const int p = threadIdx.x + it * 256;
+            if (p < P) *reinterpret_cast<f32x4*>(xsum + (size_t)p * C + c0) = v[it];
+        }
+    }
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+    f32x4 s = v[0];
+#pragma unroll
+    for (int it = 1; it < NPT; ++it) s += v[it];                         // (pixels past P hold zeros)
+    const float invP = 1.f / (float)P;
+    const f32x4 mu = wide_block_sum(s, red[0]) * invP;
+    s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < NPT; ++it)
+        if ((int)threadIdx.x + it * 256 < P) { const f32x4 d = v[it] - mu; s += d * d; }
+    const f32x4 var = wide_block_sum(s, red[1]) * invP;
+    f32x4 sc, sh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float rs = rsqrtf(var[j] + eps);
+        sc[j] = gm[j] * rs;
+        sh[j] = be[j] - mu[j] * sc[j];
+        if (threadIdx.x == 0) {
+            const int c = c0 + j;
+            mean_out[c] = mu[j];
+            rstd_out[c] = rs;
+            scale_out[c] = sc[j];
+            shift_out[c] = sh[j];
+            if (momentum > 0.f && moving_mean) {          // TF1 fused-batch-norm moving update (unbiased variance)
+                const float m = (float)P;
+                moving_mean[c] -= (moving_mean[c] - mu[j]) * momentum;
+                moving_var[c] -= (moving_var[c] - var[j] * (m / fmaxf(m - 1.f, 1.f))) * momentum;
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NPT; ++it) {
+        const int p = threadIdx.x + it * 256;
+        if (p < P) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = act_fwd(fmaf(v[it][j], sc[j], sh[j]), act);
+            *reinterpret_cast<uint2*>(y + (size_t)p * C + c0) = make_uint2(f2bf_pk(o[0], o[1]), f2bf_pk(o[2], o[3]));
+        }
+    }
+}
+// ... and its backward: dA (bf16, or the nzd fp32 split-K slices the consumer's data gradient left -- das != NULL), the fp32 x
+template <int NPT>
+__global__ __launch_bounds__(256) void k_bn_wide_bwd(const bf16_t* __restrict__ dA, const float* __restrict__ das, int nzd, size_t zstride,
+                                                     const float* __restrict__ x, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                     bf16_t* __restrict__ dx, float* dgamma, float* dbeta, int P, int C, int act) {
+    __shared__ __attribute__((aligned(16))) float red[2][16];
+    const int c0 = blockIdx.x * 4;
+    f32x4 xv[NPT], g[NPT];
+#pragma unroll
+    for (int it = 0; it < NPT; ++it) {
+        const int p = threadIdx.x + it * 256;
+        xv[it] = g[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p < P) {
+            xv[it] = *reinterpret_cast<const f32x4*>(x + (size_t)p * C + c0);
+            if (das == nullptr) {
+                const uint2 r = *reinterpret_cast<const uint2*>(dA + (size_t)p * C + c0);
+                g[it] = f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+            } else g[it] = *reinterpret_cast<const f32x4*>(das + (size_t)p * C + c0);
+        }
+    }
+    if (das != nullptr) {
+        for (int z0 = 1; z0 < nzd; z0 += 4) {
+            f32x4 t[NPT][4];
+#pragma unroll
+            for (int it = 0; it < NPT; ++it) {
+                const int p = threadIdx.x + it * 256;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    t[it][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (p < P && z0 + k < nzd) t[it][k] = *reinterpret_cast<const f32x4*>(das + (size_t)(z0 + k) * zstride + (size_t)p * C + c0);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NPT; ++it)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (z0 + k < nzd) g[it] += t[it][k];
+        }
+        // (the bf16 tensor the finishing pass would have written is what every other consumer of this gradient sees: round the
+        // same way, so that the two forms of this launch agree bit for bit)
+#pragma unroll
+        for (int it = 0; it < NPT; ++it) {
+            const unsigned w0 = f2bf_pk(g[it][0], g[it][1]), w1 = f2bf_pk(g[it][2], g[it][3]);
+            g[it] = f32x4{__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u), __uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u)};
+        }
+    }
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c0), sh = *reinterpret_cast<const f32x4*>(shift + c0);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c0), rs = *reinterpret_cast<const f32x4*>(rstd + c0);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c0);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < NPT; ++it) {                  // (pixels past P: dA = 0 -> g = 0)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            g[it][j] *= act_grad_pre(fmaf(xv[it][j], sc[j], sh[j]), act);
+            s1[j] += g[it][j];
+            s2[j] = fmaf(g[it][j] * (xv[it][j] - mu[j]), rs[j], s2[j]);
+        }
+    }
+    s1 = wide_block_sum(s1, red[0]);
+    s2 = wide_block_sum(s2, red[1]);
+    const float inv_m = 1.f / (float)P;
+    f32x4 ca, cb, cc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ca[j] = rs[j] * gm[j];
+        cc[j] = -rs[j] * rs[j] * gm[j] * s2[j] * inv_m;
+        cb[j] = -rs[j] * gm[j] * s1[j] * inv_m - cc[j] * mu[j];
+        if (threadIdx.x == 0) {                         // (accumulate: a variable may be used by several layers)
+            atomicAdd(&dbeta[c0 + j], s1[j]);
+            atomicAdd(&dgamma[c0 + j], s2[j]);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NPT; ++it) {
+        const int p = threadIdx.x + it * 256;
+        if (p < P) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fmaf(ca[j], g[it][j], fmaf(cc[j], xv[it][j], cb[j]));
+            *reinterpret_cast<uint2*>(dx + (size_t)p * C + c0) = make_uint2(f2bf_pk(o[0], o[1]), f2bf_pk(o[2], o[3]));
+        }
+    }
+}
+
 // =================================================================================================
 // Group / instance norm on small maps (a sample has P = H*W <= 256 pixels: the H <= 16 levels), bf16 NHWC: the whole layer
 // in one launch, like k_bn_small_* -- but the statistics are per SAMPLE, so nothing is reduced across waves: a wave owns
@@ -1813,6 +1999,37 @@ int phx_bn_small_bwd(const void* dA, const void* x, int x_dt, const float* scale
     if (x_dt == PHX_F32) { if (P <= 512) BNS_B(1, true); else BNS_B(2, true); }
     else if (P <= 512) BNS_B(1, false); else if (P <= 1024) BNS_B(2, false); else if (P <= 2048) BNS_B(4, false); else BNS_B(8, false);
 #undef BNS_B
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+// the wide form (k_bn_wide_*): fp32 x given as nz split-K slices xs[z][P][C] (nz >= 1), 4 channels per block
+int phx_bn_wide_supported(int P, int C) { return (P >= 1 && P <= 1024 && C % 4 == 0) ? 1 : 0; }
+int phx_bn_wide_fwd(const float* xs, int nz, float* xsum, const float* gamma, const float* beta, float eps, void* y, float* mean,
+                    float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var, float momentum, int P, int C,
+                    int act, void* stream) {
+    PHX_REQUIRE(phx_bn_wide_supported(P, C) && nz >= 1, PHX_E_SHAPE, "bn_wide_fwd: needs P <= 1024, C % 4 == 0, nz >= 1");
+    PHX_REQUIRE(xs && y && mean && rstd && scale && shift && (nz == 1 || xsum), PHX_E_INVAL, "bn_wide_fwd: null argument (xsum is required when nz > 1)");
+    PHX_REQUIRE((((uintptr_t)xs | (uintptr_t)xsum | (uintptr_t)y) & 15) == 0, PHX_E_ALIGN, "bn_wide_fwd: 16-byte alignment");
+#define BNW_F(NPTv)                                                                                                    \
+    hipLaunchKernelGGL((k_bn_wide_fwd<NPTv>), dim3(C / 4), dim3(256), 0, (hipStream_t)stream, xs, nz, (size_t)P * C, xsum, gamma, \
+                       beta, eps, (bf16_t*)y, mean, rstd, scale, shift, moving_mean, moving_var, momentum, P, C, act)
+    if (P <= 256) BNW_F(1); else if (P <= 512) BNW_F(2); else BNW_F(4);
+#undef BNW_F
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+int phx_bn_wide_bwd(const void* dA, const float* dA_slices, int nzd, const float* x, const float* scale, const float* shift,
+                    const float* mean, const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, int P, int C,
+                    int act, void* stream) {
+    PHX_REQUIRE(phx_bn_wide_supported(P, C), PHX_E_SHAPE, "bn_wide_bwd: needs P <= 1024, C % 4 == 0");
+    PHX_REQUIRE((dA != nullptr) != (dA_slices != nullptr) && (dA_slices == nullptr || nzd >= 1) && x && dx, PHX_E_INVAL,
+                "bn_wide_bwd: exactly one of dA / dA_slices");
+#define BNW_B(NPTv)                                                                                                    \
+    hipLaunchKernelGGL((k_bn_wide_bwd<NPTv>), dim3(C / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dA, dA_slices, nzd, \
+                       (size_t)P * C, x, scale, shift, mean, rstd, gamma, (bf16_t*)dx, dgamma, dbeta, P, C, act)
+    if (P <= 256) BNW_B(1); else if (P <= 512) BNW_B(2); else BNW_B(4);
+#undef BNW_B
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }

@@ -47,17 +47,6 @@ int phx_stream_create(void** stream) {
     *stream = (void*)s;
     return PHX_OK;
 }
-// priority: 0 = the device's default, negative = higher (clamped to hipDeviceGetStreamPriorityRange)
-int phx_stream_create_priority(void** stream, int priority) {
-    int least = 0, greatest = 0;
-    PHX_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    if (priority < greatest) priority = greatest;
-    if (priority > least) priority = least;
-    hipStream_t s;
-    PHX_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority));
-    *stream = (void*)s;
-    return PHX_OK;
-}
 int phx_stream_destroy(void* stream) { PHX_CHECK_HIP(hipStreamDestroy((hipStream_t)stream)); return PHX_OK; }
 int phx_stream_sync(void* stream) { PHX_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream)); return PHX_OK; }
 

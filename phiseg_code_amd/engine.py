@@ -170,13 +170,9 @@ class Plan(ForwardLowering, BackwardLowering):
         if n_lanes is None:
             n_lanes = int(os.environ.get("PHX_LANES", "2"))
         if stream is None:
-            prio = [int(v) for v in os.environ.get("PHX_LANE_PRIO", "").split(",") if v]      # dev experiment: per-lane stream priority
-            for i in range(max(1, int(n_lanes))):
+            for _ in range(max(1, int(n_lanes))):
                 st = ctypes.c_void_p()
-                if i < len(prio):
-                    self.L.stream_create_priority(ctypes.byref(st), prio[i])
-                else:
-                    self.L.stream_create(ctypes.byref(st))
+                self.L.stream_create(ctypes.byref(st))
                 self._lanes.append(st)
             self._own_stream = True
         else:

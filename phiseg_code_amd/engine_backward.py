@@ -11,7 +11,7 @@ from phiseg_code_amd import graph as G
 from phiseg_code_amd import runtime as rt
 from phiseg_code_amd.tfwrapper import normalisation as tfnorm
 from phiseg_code_amd.engine_common import *  # noqa: F401,F403
-from phiseg_code_amd.engine_common import _BN_SMALL, _BN_SMALL_F32, _DETERMINISTIC, _NREP, _NREP_MINP, _fgn_mode, _dual_enabled, _noop, _device, _TORCH_DT, _NP_DT, _ESIZE, _LIK_SIDE_MAXLVL, _WGRAD_DEFER_BLOCKS, _STAMPS  # noqa: F401
+from phiseg_code_amd.engine_common import _BN_SMALL, _BN_SMALL_F32, _BN_WIDE, _BN_WIDE_MAXLINES, _DETERMINISTIC, _NREP, _NREP_MINP, _fgn_mode, _dual_enabled, _noop, _device, _TORCH_DT, _NP_DT, _ESIZE, _LIK_SIDE_MAXLVL, _WGRAD_DEFER_BLOCKS, _STAMPS  # noqa: F401
 
 
 class BackwardLowering:
@@ -87,6 +87,23 @@ class BackwardLowering:
         # the producer's backward (possibly on another lane) folds this contribution in: _finalize_grad
         evl = self._record(self._lane) if len(self._lanes) > 1 else None
         self.pending.setdefault(t, []).append((buf, evl))
+
+    def _slice_grad_ok(self, op, xin, B, H, Wd, K, N):
+        """May the data gradient of convolution `op` (reduction channels K = its Cout, N = its Cin) hand its split-K slices to the
+        producer of its input?  -- that producer is a one-launch wide batch-norm layer, this convolution is the input's ONLY
+        reader (so the slices are the whole gradient), on the same lane, nobody fetches the gradient, and the launch does run split-K."""
+        if _BN_WIDE < 2 or xin in self.fetches or self.act_dt != BF16:
+            return False
+        prod = self._real_producer(xin)
+        if prod is None or prod.type != "conv_unit" or not (self.saved.get(prod) or {}).get("bn_wide") or prod.outputs[0] is not xin:
+            return False
+        if self.op_lane.get(prod) != self.op_lane.get(op):
+            return False
+        cons = self._real_consumers(xin, self._opset)
+        if len(cons) != 1 or cons[0] is not op or xin in self.grad or self.pending.get(xin):
+            return False
+        nzd = int(self.L.conv3x3_mfma_ksplit(B, H, Wd, K, N))
+        return nzd > 1 and B * H * Wd * nzd <= _BN_WIDE_MAXLINES
 
     def _real_producer(self, t):
         """Producer op whose launches create the data behind tensor t (looks through launch-less view ops)."""
@@ -277,7 +294,15 @@ class BackwardLowering:
                 raise NotImplementedError("backward through inference-mode batch norm is not on the hot path")
             nv = a["norm_vars"]
             y, NS, P, Gn = sv["y"], sv["NS"], sv["P"], sv["G"]
-            if sv.get("bn_small") and dA.dt == BF16:
+            if sv.get("bn_wide") and dA.dt == BF16:
+                dY = self._alloc(y.shape, BF16)
+                sg = dA if isinstance(dA, SliceGrad) else None      # the consumer's split-K data gradient left its slices: summed here
+                self._emit(Lb.bn_wide_bwd, None if sg is not None else dA.ptr, sg.ws.ptr if sg is not None else None,
+                           sg.nz if sg is not None else 0, y.ptr, sv["scale"].ptr, sv["shift"].ptr, sv["mean"].ptr, sv["rstd"].ptr,
+                           self.store.ptr(nv["gamma"]), dY.ptr, self.store.grad_ptr(nv["gamma"]),
+                           self.store.grad_ptr(nv["beta"]), P, cout, act, S,
+                           tag="bytes_norm_bwd_apply", flops=float(dY.nbytes + y.nbytes + dY.nbytes))
+            elif sv.get("bn_small") and dA.dt == BF16:
                 dY = self._alloc(y.shape, BF16)
                 self._emit(Lb.bn_small_bwd, dA.ptr, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr, sv["mean"].ptr, sv["rstd"].ptr,
                            self.store.ptr(nv["gamma"]), dY.ptr, self.store.grad_ptr(nv["gamma"]),
@@ -466,6 +491,15 @@ class BackwardLowering:
                         tag="conv3x3_mfma_dgrad", flops=18.0 * cin * cout * B * H * Wd))
                 else:
                     self._add_grad(xin, write_fn=wr)
+            elif sv["mfma"] and self._slice_grad_ok(op, xin, B, H, Wd, cout, cin):
+                # 2 x 2 / 4 x 4 levels: the split-K data gradient leaves its fp32 slices for the producer's one-launch batch-norm
+                # backward (phx_bn_wide_bwd sums them): no finishing launch, no bf16 gradient tensor
+                _, wd = self._packed(W)
+                wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cout, cin))
+                ws = self._alloc((wsb // 4,), F32)
+                self._emit(Lb.conv3x3_mfma_bf16_ws, dY.ptr, wd.ptr, None, None, 0, None, ws.ptr, wsb,
+                           B, H, Wd, cout, cin, S, tag="conv3x3_mfma_dgrad", flops=18.0 * cin * cout * B * H * Wd)
+                self._add_grad(xin, buf=SliceGrad(self.val[xin], ws, int(Lb.conv3x3_mfma_ksplit(B, H, Wd, cout, cin))))
             elif sv["mfma"]:
                 _, wd = self._packed(W)
 

@@ -10,7 +10,7 @@ from phiseg_code_amd import graph as G
 from phiseg_code_amd import runtime as rt
 from phiseg_code_amd.tfwrapper import normalisation as tfnorm
 
-__all__ = ['F32', 'BF16', 'U8', '_TORCH_DT', '_NP_DT', '_ESIZE', '_LIK_SIDE_MAXLVL', '_WGRAD_DEFER_BLOCKS', '_NREP', '_NREP_MINP', '_STAMPS', '_DETERMINISTIC', '_BN_SMALL', '_BN_SMALL_F32', '_fgn_mode', '_dual_enabled', '_noop', '_device', 'live_variables', 'device_sync', 'Buf', 'DualBuf', 'HeadGrad']
+__all__ = ['F32', 'BF16', 'U8', '_TORCH_DT', '_NP_DT', '_ESIZE', '_LIK_SIDE_MAXLVL', '_WGRAD_DEFER_BLOCKS', '_NREP', '_NREP_MINP', '_STAMPS', '_DETERMINISTIC', '_BN_SMALL', '_BN_SMALL_F32', '_BN_WIDE', '_BN_WIDE_MAXLINES', '_fgn_mode', '_dual_enabled', '_noop', '_device', 'live_variables', 'device_sync', 'Buf', 'DualBuf', 'HeadGrad', 'SliceGrad']
 
 F32, BF16, U8 = rt.F32, rt.BF16, 2
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, U8: torch.uint8}
@@ -27,6 +27,8 @@ _STAMPS = os.environ.get("PHX_STAMPS", "0") == "1"           # dev: per-operator
 _DETERMINISTIC = os.environ.get("PHX_DETERMINISTIC", "0") not in ("0", "")   # fixed summation orders everywhere (libphx reads the same variable)
 _BN_SMALL = 1024              # one-launch batch norm up to this many pixels
 _BN_SMALL_F32 = os.environ.get("PHX_BN_SMALL_F32", "1") != "0"      # dev A/B (tools/convergence_study.py): fp32 pre-normalisation tensor of those layers
+_BN_WIDE_MAXLINES = int(os.environ.get("PHX_BN_WIDE_MAXLINES", "2048"))    # dev A/B: ... only up to this many (pixel, slice) rows per block
+_BN_WIDE = int(os.environ.get("PHX_BN_WIDE", "2"))                  # dev A/B: 1 = phx_bn_wide_fwd / _bwd take the split-K slices of the forward convolution, 2 = of the data gradient too
 
 
 def _fgn_mode():
@@ -123,3 +125,13 @@ class HeadGrad:
     def __init__(self, like, dy, w_ptr, nout):
         self.shape, self.dt, self.n = like.shape, like.dt, like.n
         self.dy, self.w_ptr, self.nout = dy, w_ptr, nout
+
+
+class SliceGrad:
+    """Placeholder for the gradient of a = act(bn(y)) of a 2 x 2 / 4 x 4 layer whose only reader is a 3x3 convolution: that
+    convolution's split-K data gradient skips its finishing pass and the producer's one-launch batch-norm backward sums the nz fp32
+    slices ws[z][P][C] itself (phx_bn_wide_bwd) -- rounded to bf16 after the sum, as the finishing pass would have."""
+
+    def __init__(self, like, ws, nz):
+        self.shape, self.dt, self.n = like.shape, like.dt, like.n
+        self.ws, self.nz = ws, nz

@@ -11,7 +11,7 @@ from phiseg_code_amd import graph as G
 from phiseg_code_amd import runtime as rt
 from phiseg_code_amd.tfwrapper import normalisation as tfnorm
 from phiseg_code_amd.engine_common import *  # noqa: F401,F403
-from phiseg_code_amd.engine_common import _BN_SMALL, _BN_SMALL_F32, _DETERMINISTIC, _NREP, _NREP_MINP, _fgn_mode, _dual_enabled, _noop, _device, _TORCH_DT, _NP_DT, _ESIZE, _LIK_SIDE_MAXLVL, _WGRAD_DEFER_BLOCKS, _STAMPS  # noqa: F401
+from phiseg_code_amd.engine_common import _BN_SMALL, _BN_SMALL_F32, _BN_WIDE, _BN_WIDE_MAXLINES, _DETERMINISTIC, _NREP, _NREP_MINP, _fgn_mode, _dual_enabled, _noop, _device, _TORCH_DT, _NP_DT, _ESIZE, _LIK_SIDE_MAXLVL, _WGRAD_DEFER_BLOCKS, _STAMPS  # noqa: F401
 
 
 class ForwardLowering:
@@ -377,9 +377,22 @@ class ForwardLowering:
                     y = self._alloc(out.shape, F32)
                     wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cin_eff, cout))
                     ws = self._alloc((wsb // 4,), F32) if wsb else None
+                    nz = int(Lb.conv3x3_mfma_ksplit(B, H, Wd, cin_eff, cout))
+                    # ... and the batch-norm launch is the split-K finishing pass as well (phx_bn_wide_fwd: four channels per block,
+                    # sums the slices in slice order): one launch fewer per layer, 48 blocks instead of 12 on a 192-channel layer
+                    # (a block of that launch pulls P x nz 128-byte lines through ONE CU whatever its channel count: measured + 5 us per
+                    # layer at 2 x 2 (P = 256, six slices), - 8 us at 4 x 4 (P = 1 024, three slices) against finishing pass + phx_bn_small_fwd)
+                    wide = bool(_BN_WIDE and Lb.bn_wide_supported(P, cout) and P * nz <= _BN_WIDE_MAXLINES)
                     self._emit(Lb.conv3x3_mfma_bf16_f32out, x.ptr, dual.b.ptr if dual is not None else None,
-                               dual.k1 if dual is not None else 0, wf.ptr, y.ptr, ws.ptr if ws is not None else None, wsb,
+                               dual.k1 if dual is not None else 0, wf.ptr, y.ptr, 0 if wide else 1, ws.ptr if ws is not None else None, wsb,
                                B, H, Wd, cin_eff, cout, S, tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
+                    if wide:
+                        self._emit(Lb.bn_wide_fwd, ws.ptr if nz > 1 else y.ptr, nz, y.ptr, gptr, beptr, eps, out.ptr, mean.ptr, rstd.ptr,
+                                   scale.ptr, shift.ptr, mm, mv, mom, P, cout, act, S,
+                                   tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
+                        st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn, bn_small=True, bn_wide=True)
+                        self.saved[op] = st
+                        return
                 else:
                     conv_into(y, 0)
                 self._emit(Lb.bn_small_fwd, y.ptr, y.dt, gptr, beptr, eps, out.ptr, mean.ptr, rstd.ptr, scale.ptr, shift.ptr,

@@ -293,15 +293,25 @@ def test_conv3x3_mfma_fp32_output(L, case):
     y = torch.full((B, H, W, N), 7.0, dtype=torch.float32).cuda()
     if K1:
         xa, xb = dev(x[..., :K1], BF16), dev(x[..., K1:], BF16)
-        L.conv3x3_mfma_bf16_f32out(xa.data_ptr(), xb.data_ptr(), K1, wf.data_ptr(), y.data_ptr(), ws.data_ptr() if wsb else None, wsb,
+        L.conv3x3_mfma_bf16_f32out(xa.data_ptr(), xb.data_ptr(), K1, wf.data_ptr(), y.data_ptr(), 1, ws.data_ptr() if wsb else None, wsb,
                                    B, H, W, K, N, S())
     else:
-        L.conv3x3_mfma_bf16_f32out(xd.data_ptr(), None, 0, wf.data_ptr(), y.data_ptr(), ws.data_ptr() if wsb else None, wsb, B, H, W, K, N, S())
+        L.conv3x3_mfma_bf16_f32out(xd.data_ptr(), None, 0, wf.data_ptr(), y.data_ptr(), 1, ws.data_ptr() if wsb else None, wsb, B, H, W, K, N, S())
     close(host(y), ref, 2e-5, "fp32-output convolution")
+    nz = int(L.conv3x3_mfma_ksplit(B, H, W, K, N))
+    if nz > 1 and not K1:            # sum_slices = 0: the slices stay in the workspace, in the order the finishing pass adds them
+        ws.zero_()
+        y2 = torch.full_like(y, 7.0)
+        L.conv3x3_mfma_bf16_f32out(xd.data_ptr(), None, 0, wf.data_ptr(), y2.data_ptr(), 0, ws.data_ptr(), wsb, B, H, W, K, N, S())
+        sl = ws[:nz * B * H * W * N].view(nz, B, H, W, N)
+        acc = sl[0].clone()
+        for z in range(1, nz):
+            acc += sl[z]
+        assert torch.equal(acc, y) and float(y2.min()) == 7.0          # bit-identical sum; y_f32 untouched
     from phiseg_code_amd.runtime import PhxError
     if wsb:
         with pytest.raises(PhxError):            # a split-K shape without its workspace
-            L.conv3x3_mfma_bf16_f32out(xd.data_ptr(), None, 0, wf.data_ptr(), y.data_ptr(), None, 0, B, H, W, K, N, S())
+            L.conv3x3_mfma_bf16_f32out(xd.data_ptr(), None, 0, wf.data_ptr(), y.data_ptr(), 1, None, 0, B, H, W, K, N, S())
 
 
 def _mfma_case(L, case):
@@ -772,6 +782,87 @@ def test_bn_small_one_launch_layer(L, case):
     close(host(dx), xwr.grad.numpy(), 8e-3, "bn_small dx, fp32 input")            # (bf16 on output)
     close(host(dgamma) - 0.5, gr2.grad.numpy(), 2e-3, "bn_small dgamma, fp32 input")
     close(host(dbeta) + 0.25, br2.grad.numpy(), 2e-3, "bn_small dbeta, fp32 input")
+
+
+@pytest.mark.parametrize("case", [(64, 2, 2, 192, 1, 6), (64, 4, 4, 192, 1, 3), (12, 4, 4, 64, 1, 1), (37, 3, 3, 36, 0, 5), (1, 1, 2, 32, 1, 2), (64, 4, 4, 32, 1, 9),
+                                  (12, 8, 8, 192, 1, 4)])
+def test_bn_wide_one_launch_layer_from_split_k_slices(L, case):
+    """phx_bn_wide_fwd / _bwd (round 5; the 2 x 2 / 4 x 4 batch-norm layers: normalisation.py:145-163 + the activation of
+    layers.py:134-135 in ONE launch that is also the split-K finishing pass of the convolution in front of it): the fp32 tensor given
+    as nz slices, against the oracle's batch norm + ReLU and its autograd on the UNROUNDED sum; the backward pass from a bf16 dA
+    and from the slices a split-K data gradient leaves.  Also against phx_bn_small_fwd / _bwd on the summed tensor (same math, other
+    blocking)."""
+    B, H, W, C, act, nz = case
+    P = B * H * W
+    assert L.bn_wide_supported(P, C) == 1 and L.bn_wide_supported(1025, C) == 0 and L.bn_wide_supported(P, 30) == 0
+    x = (3.0 + 0.4 * RNG.standard_normal((B, H, W, C))).astype(np.float32)
+    parts = RNG.standard_normal((nz, B, H, W, C)).astype(np.float32)
+    parts[nz - 1] = x - parts[:nz - 1].sum(axis=0)
+    pd = torch.as_tensor(parts).cuda()
+    xs = pd[0].clone()
+    for z in range(1, nz):
+        xs += pd[z]                                          # slice order: what the kernel (and k_splitk_finish) computes
+    gamma = 1.0 + 0.2 * RNG.standard_normal(C)
+    beta = 0.1 * RNG.standard_normal(C)
+    xr = xs.double().cpu().requires_grad_(True)
+    gr = torch.as_tensor(gamma, dtype=torch.float32).double().requires_grad_(True)
+    br = torch.as_tensor(beta, dtype=torch.float32).double().requires_grad_(True)
+    yr, mean_r, varu_r = T.batch_norm_train(xr, gr, br)
+    ar = T.relu(yr) if act else yr
+    gd, bd = dev(gamma), dev(beta)
+    mean, rstd, scale, shift = (torch.empty(C, dtype=torch.float32).cuda() for _ in range(4))
+    mm, mv = dev(0.1 * RNG.standard_normal(C)), dev(1.0 + 0.3 * RNG.random(C))
+    mm0, mv0 = host(mm).copy(), host(mv).copy()
+    a = torch.empty(B, H, W, C, dtype=torch.bfloat16).cuda()
+    xsum = torch.full((B, H, W, C), 5.0, dtype=torch.float32).cuda()
+    L.bn_wide_fwd(pd.data_ptr(), nz, xsum.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-3, a.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                  scale.data_ptr(), shift.data_ptr(), mm.data_ptr(), mv.data_ptr(), 0.01, P, C, act, S())
+    if nz > 1:
+        assert torch.equal(xsum, xs)                         # the finishing pass's sum, bit for bit
+    close(host(a), ar.detach().numpy(), 6e-3, "bn_wide fwd")
+    close(host(mean), mean_r.detach().numpy(), 1e-5, "bn_wide mean")
+    if P > 1:
+        close(host(mm), mm0 - (mm0 - mean_r.detach().numpy()) * 0.01, 1e-5, "bn_wide moving_mean")
+        close(host(mv), mv0 - (mv0 - varu_r.detach().numpy()) * 0.01, 1e-5, "bn_wide moving_var")
+    if C % 16 == 0:                                          # same layer through the 16-channel blocking
+        a2 = torch.empty_like(a)
+        m2, r2, s2, h2 = (torch.empty_like(t) for t in (mean, rstd, scale, shift))
+        L.bn_small_fwd(xs.data_ptr(), F32, gd.data_ptr(), bd.data_ptr(), 1e-3, a2.data_ptr(), m2.data_ptr(), r2.data_ptr(), s2.data_ptr(),
+                       h2.data_ptr(), None, None, 0.0, P, C, act, S())
+        close(host(scale), host(s2), 2e-5, "bn_wide vs bn_small scale")
+        close(host(shift), host(h2), 2e-5, "bn_wide vs bn_small shift")
+    dA = RNG.standard_normal((B, H, W, C))
+    dAr = rounded(dA, BF16)
+    (ar * dAr).sum().backward()
+    dAd = dev(dA, BF16)
+    dx = torch.empty(B, H, W, C, dtype=torch.bfloat16).cuda()
+    dgamma = torch.full((C,), 0.5, dtype=torch.float32).cuda()        # accumulated (+=), not overwritten
+    dbeta = torch.full((C,), -0.25, dtype=torch.float32).cuda()
+    L.bn_wide_bwd(dAd.data_ptr(), None, 0, xs.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gd.data_ptr(),
+                  dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), P, C, act, S())
+    ref = xr.grad.numpy()
+    flips = 0
+    if act:                                                  # (elements whose pre-activation is within fp32 round-off of zero may take the other ReLU branch)
+        flips = int((np.abs(yr.detach().numpy()) < 1e-5).sum())
+    if not flips:
+        close(host(dx), ref, 8e-3, "bn_wide dx")
+        close(host(dgamma) - 0.5, gr.grad.numpy(), 2e-3, "bn_wide dgamma")
+        close(host(dbeta) + 0.25, br.grad.numpy(), 2e-3, "bn_wide dbeta")
+    # dA as the fp32 slices of a split-K data gradient: summed, rounded to bf16 as the finishing pass would, same result bit for bit
+    nzd = max(2, nz)
+    dparts = RNG.standard_normal((nzd, B, H, W, C)).astype(np.float32)
+    dpd = torch.as_tensor(dparts).cuda()
+    dsum = dpd[0].clone()
+    for z in range(1, nzd):
+        dsum += dpd[z]
+    dA2 = dsum.to(torch.bfloat16)
+    dx_a, dx_b = torch.empty_like(dx), torch.empty_like(dx)
+    dg_a, db_a, dg_b, db_b = (torch.zeros(C, dtype=torch.float32).cuda() for _ in range(4))
+    L.bn_wide_bwd(dA2.data_ptr(), None, 0, xs.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gd.data_ptr(),
+                  dx_a.data_ptr(), dg_a.data_ptr(), db_a.data_ptr(), P, C, act, S())
+    L.bn_wide_bwd(None, dpd.data_ptr(), nzd, xs.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gd.data_ptr(),
+                  dx_b.data_ptr(), dg_b.data_ptr(), db_b.data_ptr(), P, C, act, S())
+    assert torch.equal(dx_a, dx_b) and torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b)
 
 
 @pytest.mark.parametrize("case", [("group", 3, 8, 8, 32, 2, 1), ("group", 2, 4, 4, 192, 12, 1), ("group", 64, 2, 2, 192, 12, 1),
