@@ -216,8 +216,11 @@ int phx_head1x1_wgrad(const void* x, int x_dt, const float* dy, float* dw, float
                       void* stream);
 /* Deferred form: the head filter gradients are leaves of the backward graph, so all heads of a plan can share ONE launch.
  * phx_head1x1_wgrad_plan (host) gives plan4 = {PL, chunk, grid, dynamic LDS bytes} for C % 8 == 0; jobs_dev is a device array
- * of {const void* x; const float* dy; float* dw; float* db; uint64 npix; int C, PL, chunk, blk0;} with blk0 = running sum
- * of the grids (ascending), all jobs with the same x dtype and nout; lds_bytes = max of the jobs' plan4[3]. */
+ * of {const void* x; const float* dy; float* dw; float* db; uint64 npix; int C, PL, chunk, blk0; const float* xscale; const float*
+ * xshift; int xact, pad;} (56 bytes) with blk0 = running sum of the grids (ascending), all jobs with the same x dtype and nout;
+ * lds_bytes = max of the jobs' plan4[3].  xscale != NULL (round 5): x is the PRE-normalisation tensor of the layer whose only reader
+ * is this head and a = act(x * xscale[c] + xshift[c]) is re-formed on load, rounded to bf16 as the stored tensor would have been --
+ * the training plan then never writes a (phx_norm_apply_fused_head with y == NULL; batch norm: one scale / shift per channel). */
 int phx_head1x1_wgrad_plan(size_t npix, int C, int nout, int* plan4);
 int phx_head1x1_wgrad_multi(const void* jobs_dev, int njobs, int total_blocks, int x_dt, int nout, size_t lds_bytes,
                             void* stream);
@@ -262,7 +265,8 @@ int phx_norm_apply_fused(const void* x, int x_dt, const float* sums, const float
 /* ... and with a 1x1 HEAD fused in (the likelihood's top layer feeding y_lvl0, likelihoods.py:220: the head is the only reader of
  * a = act(norm(x))): y receives a as usual and y_head[NS * P][nout] = b_head + a w_head (w_head the HWIO 1x1 filter [C][nout]), computed
  * from the values just produced instead of by a pass of its own over a.  bf16 in / out, C / 8 a power of two <= 64, nout in {2, 4}
- * (phx_norm_head_supported).  Backward: phx_norm_bwd_reduce_head / phx_norm_bwd_apply_fused_head form dA = dy_head w_head^T on the fly. */
+ * (phx_norm_head_supported).  Backward: phx_norm_bwd_reduce_head / phx_norm_bwd_apply_fused_head form dA = dy_head w_head^T on the fly.
+ * y == NULL: a is not written (its one other reader, the head's filter gradient, re-forms it: phx_head1x1_wgrad_multi, xscale). */
 int phx_norm_head_supported(int C, int nout, int x_dt, int y_dt);
 int phx_norm_apply_fused_head(const void* x, int x_dt, const float* sums, const float* pivot, const float* gamma,
                               const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,

@@ -1123,7 +1123,9 @@ __global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __rest
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
             for (int j = 0; j < V; ++j) v[u][j] = act_fwd(fmaf(v[u][j], sc[j], sh[j]), act);
-            VecIO<TO, V>::store(y, ((size_t)ns * P + p + u * PL) * C + (size_t)cv * V, v[u]);
+            // (HN > 0, y == NULL: a is not written at all -- in a training plan its only other reader, the head's filter gradient,
+            // re-forms it from x: 268 MB less to write for the likelihood's top layer)
+            if (HN == 0 || y != nullptr) VecIO<TO, V>::store(y, ((size_t)ns * P + p + u * PL) * C + (size_t)cv * V, v[u]);
             head((size_t)ns * P + p + u * PL, v[u]);
         }
     }
@@ -1133,7 +1135,7 @@ __global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __rest
         VecIO<TI, V>::load(x, off, v);
 #pragma unroll
         for (int j = 0; j < V; ++j) v[j] = act_fwd(fmaf(v[j], sc[j], sh[j]), act);
-        VecIO<TO, V>::store(y, off, v);
+        if (HN == 0 || y != nullptr) VecIO<TO, V>::store(y, off, v);
         head((size_t)ns * P + p, v);
     }
 }

@@ -274,9 +274,33 @@ __global__ void k_latent_bwd(const float* __restrict__ dz, const float* __restri
 template <typename TX, int V, int NOUT>
 __device__ __forceinline__ void head1x1_wgrad_body(const TX* __restrict__ x, const float* __restrict__ dy,
                                                    float* __restrict__ dw, float* __restrict__ db, size_t npix, int C, int PL,
-                                                   int chunk, int bx) {
+                                                   int chunk, int bx, const float* __restrict__ xscale = nullptr,
+                                                   const float* __restrict__ xshift = nullptr, int xact = 0) {
     const int CV = C / V;
     const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    // xscale != NULL (round 5): x is the PRE-normalisation tensor y of the layer whose only reader is this head -- its
+    // a = act(y * scale[c] + shift[c]) was never written (phx_norm_apply_fused_head with y == NULL) and is re-formed here, rounded to
+    // bf16 as the stored tensor would have been (batch norm: one scale / shift per channel)
+    float xsc[V], xsh[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        xsc[j] = xscale ? xscale[cv * V + j] : 1.f;
+        xsh[j] = xscale ? xshift[cv * V + j] : 0.f;
+    }
+    auto xform = [&](float (&v)[V]) {
+        if (xscale != nullptr) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) v[j] = act_fwd(fmaf(v[j], xsc[j], xsh[j]), xact);
+            if constexpr (V % 2 == 0) {
+#pragma unroll
+                for (int j = 0; j < V; j += 2) {
+                    const unsigned w2 = f2bf_pk(v[j], v[j + 1]);
+                    v[j] = __uint_as_float(w2 << 16);
+                    v[j + 1] = __uint_as_float(w2 & 0xffff0000u);
+                }
+            }
+        }
+    };
     extern __shared__ float red[];                  // [PL][C][NOUT]
     float acc[V][NOUT], accb[NOUT];
 #pragma unroll
@@ -294,6 +318,7 @@ __device__ __forceinline__ void head1x1_wgrad_body(const TX* __restrict__ x, con
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 HVec<TX, V>::load(x, (p + (size_t)u * PL) * C + (size_t)cv * V, xv[u]);
+                xform(xv[u]);
 #pragma unroll
                 for (int o = 0; o < NOUT; ++o) d[u][o] = dy[(p + (size_t)u * PL) * NOUT + o];
             }
@@ -310,6 +335,7 @@ __device__ __forceinline__ void head1x1_wgrad_body(const TX* __restrict__ x, con
         for (; p < p1; p += PL) {
             float xv[V], d[NOUT];
             HVec<TX, V>::load(x, p * C + (size_t)cv * V, xv);
+            xform(xv);
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) {
                 d[o] = dy[p * NOUT + o];
@@ -356,6 +382,8 @@ struct HeadWJob {
     const void* x; const float* dy; float* dw; float* db;
     unsigned long long npix;
     int C, PL, chunk, blk0;
+    const float *xscale, *xshift;             // non-NULL: x is the pre-normalisation tensor, a = act(x * xscale[c] + xshift[c]) is re-formed on load
+    int xact, pad_;
 };
 template <typename TX, int NOUT>
 __global__ __launch_bounds__(256) void k_head1x1_wgrad_multi(const HeadWJob* __restrict__ jobs, int njobs) {
@@ -366,7 +394,8 @@ __global__ __launch_bounds__(256) void k_head1x1_wgrad_multi(const HeadWJob* __r
     }
     const HeadWJob j = jobs[lo];
     // (256-thread blocks; C = 192 uses 240 of them -- the others have pl >= PL and only take part in the barriers)
-    head1x1_wgrad_body<TX, 8, NOUT>((const TX*)j.x, j.dy, j.dw, j.db, (size_t)j.npix, j.C, j.PL, j.chunk, (int)blockIdx.x - j.blk0);
+    head1x1_wgrad_body<TX, 8, NOUT>((const TX*)j.x, j.dy, j.dw, j.db, (size_t)j.npix, j.C, j.PL, j.chunk, (int)blockIdx.x - j.blk0,
+                                    j.xscale, j.xshift, j.xact);
 }
 
 static int head_geo(int C, int V, int* PL, int* threads) {

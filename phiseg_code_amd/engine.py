@@ -277,10 +277,12 @@ class Plan(ForwardLowering, BackwardLowering):
             self._emit(fn, *args, self.stream)
         for (xdt, nout), jobs in self._headw_jobs.items():
             rec = np.zeros(len(jobs), dtype=[("x", "<u8"), ("dy", "<u8"), ("dw", "<u8"), ("db", "<u8"), ("npix", "<u8"), ("C", "<i4"),
-                                             ("PL", "<i4"), ("chunk", "<i4"), ("blk0", "<i4")])
+                                             ("PL", "<i4"), ("chunk", "<i4"), ("blk0", "<i4"), ("xscale", "<u8"), ("xshift", "<u8"),
+                                             ("xact", "<i4"), ("pad", "<i4")])
             blk = lds = 0
             for i, j in enumerate(jobs):
-                rec[i] = (j[0], j[1], j[2], j[3], j[4], j[5], j[6], j[7], blk)
+                xf = j[10] if len(j) > 10 else (0, 0, 0)      # (scale ptr, shift ptr, act): x is a pre-normalisation tensor
+                rec[i] = (j[0], j[1], j[2], j[3], j[4], j[5], j[6], j[7], blk, xf[0], xf[1], xf[2], 0)
                 blk += j[8]
                 lds = max(lds, j[9])
             desc = torch.from_numpy(rec.view(np.uint8).copy()).to(_device())

@@ -388,8 +388,14 @@ class BackwardLowering:
             # a leaf of the backward graph: all heads share one launch after the lanes have joined (phx_head1x1_wgrad_multi)
             plan4 = (ctypes.c_int * 4)()
             Lb.head1x1_wgrad_plan(B * H * Wd, cin, cout, plan4)
-            self._headw_jobs.setdefault((x.dt, cout), []).append((x.ptr, dY.ptr, dw, db, B * H * Wd, cin, plan4[0], plan4[1],
-                                                                   plan4[2], plan4[3]))
+            prod = self._norm_head.get(op)
+            au = self.saved[prod].get("a_unwritten") if prod is not None else None
+            if au is not None:      # the producer never wrote a = act(bn(y)): the job re-forms it from y (phx_head1x1_wgrad_multi, xscale)
+                self._headw_jobs.setdefault((au["y"].dt, cout), []).append((au["y"].ptr, dY.ptr, dw, db, B * H * Wd, cin, plan4[0], plan4[1],
+                                                                            plan4[2], plan4[3], (au["scale"].ptr, au["shift"].ptr, au["act"])))
+            else:
+                self._headw_jobs.setdefault((x.dt, cout), []).append((x.ptr, dY.ptr, dw, db, B * H * Wd, cin, plan4[0], plan4[1],
+                                                                       plan4[2], plan4[3]))
         elif sv.get("head1x1"):
             self._emit(Lb.head1x1_wgrad, x.ptr, x.dt, dY.ptr, dw, db, B * H * Wd, cin, cout, S)
         elif sv.get("padded") or sv["mfma"]:

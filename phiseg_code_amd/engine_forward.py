@@ -11,7 +11,7 @@ from phiseg_code_amd import graph as G
 from phiseg_code_amd import runtime as rt
 from phiseg_code_amd.tfwrapper import normalisation as tfnorm
 from phiseg_code_amd.engine_common import *  # noqa: F401,F403
-from phiseg_code_amd.engine_common import _BN_SMALL, _BN_SMALL_F32, _BN_WIDE, _BN_WIDE_MAXLINES, _DETERMINISTIC, _NREP, _NREP_MINP, _fgn_mode, _dual_enabled, _noop, _device, _TORCH_DT, _NP_DT, _ESIZE, _LIK_SIDE_MAXLVL, _WGRAD_DEFER_BLOCKS, _STAMPS  # noqa: F401
+from phiseg_code_amd.engine_common import _BN_SMALL, _BN_SMALL_F32, _BN_WIDE, _BN_WIDE_MAXLINES, _SKIP_HEAD_A, _DETERMINISTIC, _NREP, _NREP_MINP, _fgn_mode, _dual_enabled, _noop, _device, _TORCH_DT, _NP_DT, _ESIZE, _LIK_SIDE_MAXLVL, _WGRAD_DEFER_BLOCKS, _STAMPS  # noqa: F401
 
 
 class ForwardLowering:
@@ -463,8 +463,15 @@ class ForwardLowering:
                 hW, hb = hop.attrs["W"], hop.attrs["b"]
                 yh = self._alloc_like(hop.outputs[0])
                 self.val[hop.outputs[0]] = yh
+                # training plan, batch norm: a itself is never written -- its one other reader, the head's filter gradient (a leaf of the
+                # backward graph), re-forms it from y with this layer's scale / shift (phx_head1x1_wgrad_multi, xscale): for the
+                # likelihood's top layer (128 channels @ 128 x 128) 268 MB less to write on the critical lane
+                skip_a = bool(bw and norm == "batch" and NS == 1 and _SKIP_HEAD_A)
+                if skip_a:
+                    apply_args = apply_args[:7] + (None,) + apply_args[8:]
+                    st["a_unwritten"] = dict(y=y, scale=scale, shift=shift, act=act)
                 self._emit(Lb.norm_apply_fused_head, *apply_args, self.store.ptr(hW), self.store.ptr(hb), hW.shape[-1], yh.ptr, S,
-                           tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
+                           tag="bytes_norm_apply", flops=float(y.nbytes + (0 if skip_a else out.nbytes)))
                 self._norm_head[hop] = op
             else:
                 self._emit(Lb.norm_apply_fused, *apply_args, S, tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))

@@ -1263,13 +1263,19 @@ def test_head1x1_full_size_vs_device_matmul(L, case):
 
 @pytest.mark.parametrize("nout", [2, 4])
 def test_head1x1_wgrad_multi_matches_per_head_launches(L, nout):
-    """One phx_head1x1_wgrad_multi launch over heads of different widths / map sizes == the per-head launches (accumulating)."""
+    """One phx_head1x1_wgrad_multi launch over heads of different widths / map sizes == the per-head launches (accumulating).  Every
+    second job is given the PRE-normalisation tensor and the layer's scale / shift / ReLU instead of a (round 5: a training plan does
+    not write the activation whose only reader is a head): same result as the launch on the bf16 a, bit for bit."""
     import ctypes
     heads = [(64, 2, 2, 192), (64, 16, 16, 192), (3, 32, 32, 128), (2, 64, 64, 64), (1, 128, 128, 32), (5, 7, 3, 40)]
     keep, rows, want, blk, lds = [], [], [], 0, 0
-    for (B, H, W, C) in heads:
+    for hi, (B, H, W, C) in enumerate(heads):
         npix = B * H * W
-        x, dy = dev(RNG.standard_normal((npix, C)), BF16), dev(RNG.standard_normal((npix, nout)))
+        ypre, dy = dev(RNG.standard_normal((npix, C)), BF16), dev(RNG.standard_normal((npix, nout)))
+        xsc, xsh = dev(1.0 + 0.3 * RNG.standard_normal(C)), dev(0.2 * RNG.standard_normal(C))
+        xform = hi % 2 == 1
+        # a = bf16(relu(y * scale + shift)) with the kernel's arithmetic (one fma in fp32)
+        x = torch.relu(torch.addcmul(xsh, ypre.float(), xsc)).to(torch.bfloat16) if xform else ypre
         dw_ref = torch.full((C, nout), 0.5, dtype=torch.float32).cuda()
         db_ref = torch.full((nout,), -1.0, dtype=torch.float32).cuda()
         L.head1x1_wgrad(x.data_ptr(), BF16, dy.data_ptr(), dw_ref.data_ptr(), db_ref.data_ptr(), npix, C, nout, S())
@@ -1277,12 +1283,13 @@ def test_head1x1_wgrad_multi_matches_per_head_launches(L, nout):
         db = torch.full((nout,), -1.0, dtype=torch.float32).cuda()
         plan = (ctypes.c_int * 4)()
         L.head1x1_wgrad_plan(npix, C, nout, plan)
-        rows.append((x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), npix, C, plan[0], plan[1], blk))
+        rows.append(((ypre if xform else x).data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), npix, C, plan[0], plan[1], blk,
+                     xsc.data_ptr() if xform else 0, xsh.data_ptr() if xform else 0, 1 if xform else 0, 0))
         blk += plan[2]
         lds = max(lds, plan[3])
-        keep.append((x, dy)); want.append((dw_ref, db_ref, dw, db))
+        keep.append((x, ypre, dy, xsc, xsh)); want.append((dw_ref, db_ref, dw, db))
     rec = np.zeros(len(rows), dtype=[("x", "<u8"), ("dy", "<u8"), ("dw", "<u8"), ("db", "<u8"), ("npix", "<u8"), ("C", "<i4"), ("PL", "<i4"),
-                                     ("chunk", "<i4"), ("blk0", "<i4")])
+                                     ("chunk", "<i4"), ("blk0", "<i4"), ("xscale", "<u8"), ("xshift", "<u8"), ("xact", "<i4"), ("pad", "<i4")])
     for i, r in enumerate(rows):
         rec[i] = r
     desc = torch.from_numpy(rec.view(np.uint8).copy()).cuda()
@@ -1553,6 +1560,12 @@ def test_norm_layer_with_fused_head(L, case):
                             wh.data_ptr(), bh.data_ptr(), NO, yh2.data_ptr(), S())
     assert torch.equal(a1, a2) and torch.equal(scale, scale2)
     close(host(yh2), host(yh1), 2e-6, "head output")
+    # y == NULL (training plans, round 5): a is not written, the head output is the same
+    yh3 = torch.empty_like(yh2)
+    L.norm_apply_fused_head(y.data_ptr(), BF16, sums.data_ptr(), None, gamma.data_ptr(), beta.data_ptr(), eps, None, BF16,
+                            mean2.data_ptr(), rstd2.data_ptr(), scale2.data_ptr(), shift2.data_ptr(), None, None, 0.0, NS, P, C, G, 1,
+                            wh.data_ptr(), bh.data_ptr(), NO, yh3.data_ptr(), S())
+    assert torch.equal(yh3, yh2)
     # backward
     dyh = dev(RNG.standard_normal((npix, NO)))
     dA = torch.empty(B, H, W, C, dtype=torch.bfloat16).cuda()

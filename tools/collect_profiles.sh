@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
 mkdir -p $O
 cd $R
-[ -n "$SKIP_BENCH" ] || python bench.py --steps 20 --warmup 5 --profile-table > $O/bench.json 2> $O/bench_table.txt
+[ -n "$SKIP_BENCH" ] || python bench.py --profile-table > $O/bench.json 2> $O/bench_table.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/stats -- python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-roofline --no-other-workloads > $O/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
