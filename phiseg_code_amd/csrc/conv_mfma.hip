@@ -166,7 +166,8 @@ bool phx_pp_shape_ok(int B, int H, int W, int K, int N);
 int phx_pp_set_trace(void* dev_buf);
 int phx_pp_set_grid(int blocks);
 int phx_pp_launch(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial, int B, int H, int W,
-                  int K, int N, const float* oscale, int stats_nrep, Dual du, int dbg, void* stream);
+                  int K, int N, const float* oscale, int stats_nrep, Dual du, int dbg, void* stream, const float* xscale = nullptr,
+                  const float* xshift = nullptr);
 
 // ---- forward / dgrad ----------------------------------------------------------------------------------
 // Options of the forward / data-gradient epilogue.

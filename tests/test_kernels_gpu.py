@@ -1265,7 +1265,8 @@ def test_head1x1_full_size_vs_device_matmul(L, case):
 def test_head1x1_wgrad_multi_matches_per_head_launches(L, nout):
     """One phx_head1x1_wgrad_multi launch over heads of different widths / map sizes == the per-head launches (accumulating).  Every
     second job is given the PRE-normalisation tensor and the layer's scale / shift / ReLU instead of a (round 5: a training plan does
-    not write the activation whose only reader is a head): same result as the launch on the bf16 a, bit for bit."""
+    not write the activation whose only reader is a head): same result as the launch on the materialised bf16 a (up to the rare
+    bf16 rounding flip between the kernel's fused multiply-add and torch's multiply + add in the reference a)."""
     import ctypes
     heads = [(64, 2, 2, 192), (64, 16, 16, 192), (3, 32, 32, 128), (2, 64, 64, 64), (1, 128, 128, 32), (5, 7, 3, 40)]
     keep, rows, want, blk, lds = [], [], [], 0, 0
@@ -1287,7 +1288,7 @@ def test_head1x1_wgrad_multi_matches_per_head_launches(L, nout):
                      xsc.data_ptr() if xform else 0, xsh.data_ptr() if xform else 0, 1 if xform else 0, 0))
         blk += plan[2]
         lds = max(lds, plan[3])
-        keep.append((x, ypre, dy, xsc, xsh)); want.append((dw_ref, db_ref, dw, db))
+        keep.append((x, ypre, dy, xsc, xsh)); want.append((dw_ref, db_ref, dw, db, 1e-4 if xform else 1e-5))
     rec = np.zeros(len(rows), dtype=[("x", "<u8"), ("dy", "<u8"), ("dw", "<u8"), ("db", "<u8"), ("npix", "<u8"), ("C", "<i4"), ("PL", "<i4"),
                                      ("chunk", "<i4"), ("blk0", "<i4"), ("xscale", "<u8"), ("xshift", "<u8"), ("xact", "<i4"), ("pad", "<i4")])
     for i, r in enumerate(rows):
@@ -1295,8 +1296,8 @@ def test_head1x1_wgrad_multi_matches_per_head_launches(L, nout):
     desc = torch.from_numpy(rec.view(np.uint8).copy()).cuda()
     L.head1x1_wgrad_multi(desc.data_ptr(), len(rows), blk, BF16, nout, lds, S())
     torch.cuda.synchronize()
-    for k, (dw_ref, db_ref, dw, db) in enumerate(want):
-        close(host(dw), host(dw_ref), 1e-5, "multi head wgrad, head %d" % k)
+    for k, (dw_ref, db_ref, dw, db, tol) in enumerate(want):
+        close(host(dw), host(dw_ref), tol, "multi head wgrad, head %d" % k)
         close(host(db), host(db_ref), 1e-5, "multi head dbias, head %d" % k)
 
 
