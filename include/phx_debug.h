@@ -18,11 +18,6 @@ extern "C" {
 int phx_debug_conv_policy(int large_maps, int big_tiles);
 /* persistent grid of the pair kernel (0: one work-group per CU) */
 int phx_debug_pair_kernel_grid(int blocks);
-/* round-5 spike ("scale-shift-ReLU in the loader half"): y = conv3x3(relu(x * xscale[k] + xshift[k])) with the
- * transform applied by the pair kernel's LOADER half on the way global -> VGPR -> LDS; N % 64 == 0, the pair kernel's shapes;
- * stats_partial as phx_conv3x3_mfma_bf16 (may be NULL).  Exists to be timed against the LDS-DMA loader (tools/bench_pp_xf.py). */
-int phx_debug_pp_xf(const void* x, const void* wpk, void* y, const float* xscale, const float* xshift, float* stats_partial,
-                    int B, int H, int W, int K, int N, void* stream);
 #ifdef __cplusplus
 }
 #endif

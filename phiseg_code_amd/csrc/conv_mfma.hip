@@ -1027,6 +1027,19 @@ int phx_conv3x3_mfma_bf16_f32out(const void* x, const void* x2, int K1, const vo
     return conv3x3_mfma_impl(x, wpk, nullptr, nullptr, PHX_ACT_ID, nullptr, workspace, workspace_bytes, B, H, W, K, N, b, du, stream);
 }
 
+// conv2d on the PRE-normalisation tensor of the producing layer (round 5): y = conv3x3(relu(x * xscale[k] + xshift[k])) with the
+// transform in the loader half of the pair kernel (conv_pp.hip, XF) -- the shapes that kernel takes with 64-channel blocks.
+int phx_conv3x3_xf_supported(int B, int H, int W, int K, int N) {
+    return (fwd_ws64(B, H, W, K, N) && N % 64 == 0 && K % 32 == 0) ? 1 : 0;
+}
+int phx_conv3x3_mfma_bf16_xf(const void* x, const float* xscale, const float* xshift, const void* wpk, void* y, float* stats_partial,
+                             int B, int H, int W, int K, int N, void* stream) {
+    PHX_REQUIRE(phx_conv3x3_xf_supported(B, H, W, K, N), PHX_E_SHAPE, "conv3x3_mfma_xf: shape not supported (see phx_conv3x3_xf_supported)");
+    PHX_REQUIRE(x && xscale && xshift && wpk && y, PHX_E_INVAL, "conv3x3_mfma_xf: null argument");
+    PHX_REQUIRE((((uintptr_t)x | (uintptr_t)wpk | (uintptr_t)y | (uintptr_t)xscale | (uintptr_t)xshift) & 15) == 0, PHX_E_ALIGN, "conv3x3_mfma_xf: 16-byte alignment");
+    return phx_pp_launch(x, wpk, y, nullptr, PHX_ACT_ID, stats_partial, B, H, W, K, N, nullptr, 0, Dual{}, 0, stream, xscale, xshift);
+}
+
 // ---- conv + bias + group / instance norm + activation in one launch (FGN instantiations of k_conv3x3_mfma) ----------------------
 // Maps that fit ONE pixel tile (H, W in {2, 4, 8, 16}): a block then holds whole samples and whole 16-channel groups.  -> 32 / 64
 // (channels per block), 0: not supported.

@@ -68,10 +68,13 @@ __device__ unsigned long long* g_pp_trace = nullptr;      // dev: cycle stamps o
 // so that a lane holds ONE pixel and four consecutive output channels per accumulator quad: the epilogue packs and writes 8 bytes per
 // lane and quad (32 ds_write_b64 per tile and wave) instead of trading rows with the neighbour lane (64 DPP + 64 v_perm + 64
 // ds_write_b32).  The epilogue is LDS-issue-bound (~47 cycles per LDS instruction beside the partner's operand reads and the DMA).
-// XF (round-5 spike, test build only -- phx_debug_pp_xf): the input is a PRE-normalisation tensor and the loader half applies the
-// producer's a = relu(x * xscale[k] + xshift[k]) on the way in: global -> VGPR -> unpack / fma / max / pack -> ds_write_b128 instead of
-// the LDS-DMA.  A lane keeps ONE source piece (8 channels: 16 scale / shift registers per chunk) and writes it to the swizzled slot of
-// its pixel; out-of-image pieces are forced to zero after the transform (the zero padding is of a, not of x).
+// XF (round 5; phx_conv3x3_mfma_bf16_xf): the input is the PRE-normalisation tensor of the producing layer and the loader half applies
+// that layer's a = relu(x * xscale[k] + xshift[k]) on the way in -- global -> VGPR -> unpack / fma / max / pack -> ds_write_b128 instead
+// of the LDS-DMA -- so the producer's apply pass (read y, write a) and the tensor a itself disappear (conv2d -> batch_norm -> relu ->
+// conv2d, tfwrapper/layers.py:123-135).  A lane keeps ONE source piece (8 channels: 16 scale / shift registers per chunk) and writes
+// it to the swizzled slot of its pixel; out-of-image pieces are forced to zero AFTER the transform (the zero padding is of a, not
+// of x).  The values are rounded to bf16 exactly as the apply pass stores them: the launch is bit-identical to the LDS-DMA launch on
+// the materialised a (tools/bench_pp_xf.py: + 2 ... 22 % on the convolution against the 0.012 - 0.094 ms apply pass it deletes).
 template <int BN, bool BIASACT, bool DUAL, int DBG, bool TR = false, bool XF = false>
 __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __restrict__ x, const unsigned short* __restrict__ wpk,
                                                        unsigned short* __restrict__ y, const float* __restrict__ bias, int act,
@@ -601,14 +604,6 @@ bool phx_pp_shape_ok(int B, int H, int W, int K, int N) {
 int phx_pp_launch(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial, int B, int H, int W,
                   int K, int N, const float* oscale, int stats_nrep, Dual du, int dbg, void* stream, const float* xscale = nullptr,
                   const float* xshift = nullptr);
-#ifdef PHX_DEBUG_BUILD
-// round-5 spike (include/phx_debug.h): y = conv3x3(relu(x * xscale[k] + xshift[k])) with the transform in the pair kernel's loader half
-extern "C" int phx_debug_pp_xf(const void* x, const void* wpk, void* y, const float* xscale, const float* xshift, float* stats_partial,
-                               int B, int H, int W, int K, int N, void* stream) {
-    PHX_REQUIRE(xscale != nullptr && xshift != nullptr && N % 64 == 0, PHX_E_INVAL, "debug_pp_xf: xscale / xshift, N % 64 == 0");
-    return phx_pp_launch(x, wpk, y, nullptr, 0, stats_partial, B, H, W, K, N, nullptr, 0, Dual{}, 0, stream, xscale, xshift);
-}
-#endif
 int phx_pp_launch(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial, int B, int H, int W,
                   int K, int N, const float* oscale, int stats_nrep, Dual du, int dbg, void* stream, const float* xscale,
                   const float* xshift) {
@@ -649,8 +644,8 @@ int phx_pp_launch(const void* x, const void* wpk, void* y, const float* bias, in
                            (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, gm, oscale,   \
                            stats_nrep, du, (const float*)nullptr, (const float*)nullptr);                                         \
     } while (0)
-#ifdef PHX_DEBUG_BUILD
-    if (xscale != nullptr) {                 // the XF spike: 64-channel blocks, no bias / activation epilogue, statistics optional
+    if (xscale != nullptr) {                 // transform in the loader half (XF): 64-channel blocks, no bias / activation epilogue, statistics optional
+        PHX_REQUIRE(xshift != nullptr && bn == 64 && !ba && !dual, PHX_E_SHAPE, "conv3x3_pp: the input transform needs N % 64 == 0 and a plain epilogue");
         auto kf = k_conv3x3_pp<64, false, false, 0, false, true>;
         static bool at = false;
         if (!at) { PHX_CHECK_HIP(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); at = true; }
@@ -659,7 +654,6 @@ int phx_pp_launch(const void* x, const void* wpk, void* y, const float* bias, in
         PHX_CHECK_LAUNCH();
         return PHX_OK;
     }
-#endif
     if (bn == 64) {
         if (dual) { if (ba) PP_LAUNCH(64, true, true, 0); else PP_LAUNCH(64, false, true, 0); }
         else if (ba) PP_LAUNCH(64, true, false, 0);

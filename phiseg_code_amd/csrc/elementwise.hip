@@ -886,6 +886,34 @@ __global__ void k_reduce_partials_ns(const float* __restrict__ partial, int T, i
     sums[((size_t)ns * C + c) * 2 + which] = (a0 + a1) + (a2 + a3);
 }
 
+// Per-channel batch / instance-norm coefficients from the accumulated sums -- ONE definition with floating-point contraction off, used
+// by the fused apply kernels AND by k_norm_finalize: a layer whose apply pass is replaced by the consumers' loader transform (engine
+// XfBuf, phx_conv3x3_mfma_bf16_xf) must get bit-identical scale / shift from the stand-alone finalisation (round 5: with the
+// compiler free to contract `sq * invP - d1 * d1` differently in the two kernels the variances differed in the last place, and two
+// training steps later so did 30 % of the ELBO of a deliberately ill-conditioned test network).
+__device__ __forceinline__ void chan_coeffs(float s1, float s2, float pv, float invP, float eps, float* mu, float* var, float* rs) {
+#pragma clang fp contract(off)
+    const float d1 = s1 * invP;
+    const float m2 = s2 * invP;
+    const float dd = d1 * d1;
+    *mu = pv + d1;
+    *var = fmaxf(m2 - dd, 0.f);
+    *rs = rsqrtf(*var + eps);
+}
+__device__ __forceinline__ void moving_update(float* mm, float* mv, float mu, float var, float m, float momentum) {
+#pragma clang fp contract(off)       // TF1 fused-batch-norm moving update (unbiased variance): moving -= (moving - batch) * momentum
+    const float ub = var * (m / fmaxf(m - 1.f, 1.f));
+    const float dm = (*mm - mu) * momentum, dv = (*mv - ub) * momentum;
+    *mm = *mm - dm;
+    *mv = *mv - dv;
+}
+__device__ __forceinline__ void chan_scale_shift(float gamma, float beta, float mu, float rs, float* sc, float* sh) {
+#pragma clang fp contract(off)
+    const float scv = gamma * rs;
+    const float t = mu * scv;
+    *sc = scv;
+    *sh = beta - t;
+}
 // per (ns, g): mean / rstd; per (ns, c): scale / shift; optional TF1 fused-batch-norm moving update
 __global__ void k_norm_finalize(const float* __restrict__ sums, const float* __restrict__ pivot,
                                 const float* __restrict__ gamma,
@@ -898,6 +926,18 @@ __global__ void k_norm_finalize(const float* __restrict__ sums, const float* __r
     // per-channel mean / variance from the (pivot-shifted) sums, then the stable parallel-variance combination
     // over the channels of the group: var_g = mean_c[var_c + (mu_c - mu_g)^2]
     const float invP = 1.f / (float)P;
+    if (cg == 1) {                            // batch / instance norm: the fused apply kernels' arithmetic, bit for bit (chan_coeffs)
+        float mu1, var1, rs1, sc1, sh1;
+        chan_coeffs(sums[((size_t)ns * C + g) * 2], sums[((size_t)ns * C + g) * 2 + 1], pivot ? pivot[(size_t)ns * C + g] : 0.f, invP, eps,
+                    &mu1, &var1, &rs1);
+        chan_scale_shift(gamma[g], beta[g], mu1, rs1, &sc1, &sh1);
+        mean[idx] = mu1;
+        rstd[idx] = rs1;
+        scale[(size_t)ns * C + g] = sc1;
+        shift[(size_t)ns * C + g] = sh1;
+        if (momentum > 0.f && moving_mean) moving_update(&moving_mean[g], &moving_var[g], mu1, var1, (float)P, momentum);
+        return;
+    }
     float mu = 0.f;
     for (int c = g * cg; c < (g + 1) * cg; ++c) {
         const float pv = pivot ? pivot[(size_t)ns * C + c] : 0.f;
@@ -1047,9 +1087,8 @@ __global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __rest
                 const float2 q = *reinterpret_cast<const float2*>(sums + (((size_t)r * gridDim.y + ns) * C + g) * 2);
                 sq.x += q.x; sq.y += q.y;
             }
-            const float d1 = sq.x * invP;
-            mu = (pivot ? pivot[(size_t)ns * C + g] : 0.f) + d1;
-            var = fmaxf(sq.y * invP - d1 * d1, 0.f);
+            float rs1;
+            chan_coeffs(sq.x, sq.y, pivot ? pivot[(size_t)ns * C + g] : 0.f, invP, eps, &mu, &var, &rs1);
         } else {
             group_stats(sums, pivot, ns, C, g, cg, invP, eps, &mu, &var);
         }
@@ -1059,18 +1098,15 @@ __global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __rest
         if (pub) {
             mean_out[ns * G + g] = mu;
             rstd_out[ns * G + g] = rs;
-            if (momentum > 0.f && moving_mean) {          // batch norm (G == C): TF1 fused-batch-norm moving update
-                const float m = (float)P * (float)cg;
-                moving_mean[g] -= (moving_mean[g] - mu) * momentum;
-                moving_var[g] -= (moving_var[g] - var * (m / fmaxf(m - 1.f, 1.f))) * momentum;
-            }
+            if (momentum > 0.f && moving_mean)            // batch norm (G == C): TF1 fused-batch-norm moving update
+                moving_update(&moving_mean[g], &moving_var[g], mu, var, (float)P * (float)cg, momentum);
         }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const int g = c / cg;
-        const float scv = gamma[c] * gst[2 * g + 1];
-        const float shv = beta[c] - gst[2 * g] * scv;
+        float scv, shv;
+        chan_scale_shift(gamma[c], beta[c], gst[2 * g], gst[2 * g + 1], &scv, &shv);
         cof[2 * c] = scv;
         cof[2 * c + 1] = shv;
         if (pub) {
