@@ -133,31 +133,11 @@ int phx_conv3x3_mfma_bf16_dual(const void* x, const void* x2, int K1, const void
 int phx_conv3x3_mfma_f32out_supported(int B, int H, int W, int K, int N);
 int phx_conv3x3_mfma_bf16_f32out(const void* x, const void* x2, int K1, const void* wpk, float* y_f32, int sum_slices, void* workspace,
                                  size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream);
-/* conv2d straight on the PRE-normalisation tensor of the layer in front (round 5; conv2d -> batch_norm -> relu -> conv2d,
- * tfwrapper/layers.py:123-135): y = conv3x3(relu(x * xscale[k] + xshift[k])) with the producer's scale / shift (phx_norm_finalize)
- * applied in the LOADER half of the pair kernel -- the producer's apply pass and its activation tensor are never made.  Shapes:
- * phx_conv3x3_xf_supported (the large-map shapes with N % 64 == 0).  Bit-identical to phx_conv3x3_mfma_bf16 on the materialised
- * bf16 activation.  stats_partial as phx_conv3x3_mfma_bf16 (rows: phx_conv3x3_mfma_bf16_tiles). */
-int phx_conv3x3_xf_supported(int B, int H, int W, int K, int N);
-int phx_conv3x3_mfma_bf16_xf(const void* x, const float* xscale, const float* xshift, const void* wpk, void* y, float* stats_partial,
-                             int B, int H, int W, int K, int N, void* stream);
 size_t phx_conv3x3_wgrad_ws_bytes_dual(int B, int H, int W, int Cin, int Cout, int K1);
 int phx_conv3x3_wgrad_reduce_plan_dual(int B, int H, int W, int Cin, int Cout, int K1, int* plan6);
 int phx_conv3x3_wgrad_multi_job_dual(const void* x, const void* x2, int K1, const void* dy, float* dw_hwio, void* workspace,
                                      size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int blocks_target, int blk0,
                                      void* job_out, int* info9);
-/* Filter gradient of a convolution that read the PRE-normalisation tensor of the layer in front (phx_conv3x3_mfma_bf16_xf): x is that
- * tensor, xscale / xshift [Cin] the producer's coefficients; a = relu(x * xscale + xshift) is re-formed by the loading half of the
- * anti-phase kernel (64 x 64 channel blocks, 16 x 16 tiles, workspace required: phx_conv3x3_wgrad_xf_supported).  _multi_job_xf fills a
- * job record of the deferred launch (info[0] == 12 or 0 as phx_conv3x3_wgrad_multi_job); _partial_xf is the stand-alone launch (partial
- * filters into the workspace of phx_conv3x3_wgrad_ws_bytes, reduction by phx_wgrad_reduce_multi / the plan of
- * phx_conv3x3_wgrad_reduce_plan). */
-int phx_conv3x3_wgrad_xf_supported(int B, int H, int W, int Cin, int Cout);
-int phx_conv3x3_wgrad_multi_job_xf(const void* x, const float* xscale, const float* xshift, const void* dy, float* dw_hwio,
-                                   void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int blocks_target,
-                                   int blk0, void* job_out, int* info9);
-int phx_conv3x3_wgrad_mfma_bf16_partial_xf(const void* x, const float* xscale, const float* xshift, const void* dy, void* workspace,
-                                           size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, void* stream);
 int phx_conv3x3_wgrad_mfma_bf16_dual(const void* x, const void* x2, int K1, const void* dy, float* dw_hwio, void* workspace,
                                      size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int reduce, void* stream);
 /* Convolution + bias + group norm (16-channel groups) / instance norm + activation in ONE launch (the fused block of north_star:

@@ -166,8 +166,7 @@ bool phx_pp_shape_ok(int B, int H, int W, int K, int N);
 int phx_pp_set_trace(void* dev_buf);
 int phx_pp_set_grid(int blocks);
 int phx_pp_launch(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial, int B, int H, int W,
-                  int K, int N, const float* oscale, int stats_nrep, Dual du, int dbg, void* stream, const float* xscale = nullptr,
-                  const float* xshift = nullptr);
+                  int K, int N, const float* oscale, int stats_nrep, Dual du, int dbg, void* stream);
 
 // ---- forward / dgrad ----------------------------------------------------------------------------------
 // Options of the forward / data-gradient epilogue.
@@ -1025,19 +1024,6 @@ int phx_conv3x3_mfma_bf16_f32out(const void* x, const void* x2, int K1, const vo
     b.keep_slices = sum_slices == 0;
     Dual du{(const unsigned short*)x2, nullptr, x2 ? K1 : 0, 0};
     return conv3x3_mfma_impl(x, wpk, nullptr, nullptr, PHX_ACT_ID, nullptr, workspace, workspace_bytes, B, H, W, K, N, b, du, stream);
-}
-
-// conv2d on the PRE-normalisation tensor of the producing layer (round 5): y = conv3x3(relu(x * xscale[k] + xshift[k])) with the
-// transform in the loader half of the pair kernel (conv_pp.hip, XF) -- the shapes that kernel takes with 64-channel blocks.
-int phx_conv3x3_xf_supported(int B, int H, int W, int K, int N) {
-    return (fwd_ws64(B, H, W, K, N) && N % 64 == 0 && K % 32 == 0) ? 1 : 0;
-}
-int phx_conv3x3_mfma_bf16_xf(const void* x, const float* xscale, const float* xshift, const void* wpk, void* y, float* stats_partial,
-                             int B, int H, int W, int K, int N, void* stream) {
-    PHX_REQUIRE(phx_conv3x3_xf_supported(B, H, W, K, N), PHX_E_SHAPE, "conv3x3_mfma_xf: shape not supported (see phx_conv3x3_xf_supported)");
-    PHX_REQUIRE(x && xscale && xshift && wpk && y, PHX_E_INVAL, "conv3x3_mfma_xf: null argument");
-    PHX_REQUIRE((((uintptr_t)x | (uintptr_t)wpk | (uintptr_t)y | (uintptr_t)xscale | (uintptr_t)xshift) & 15) == 0, PHX_E_ALIGN, "conv3x3_mfma_xf: 16-byte alignment");
-    return phx_pp_launch(x, wpk, y, nullptr, PHX_ACT_ID, stats_partial, B, H, W, K, N, nullptr, 0, Dual{}, 0, stream, xscale, xshift);
 }
 
 // ---- conv + bias + group / instance norm + activation in one launch (FGN instantiations of k_conv3x3_mfma) ----------------------

@@ -68,19 +68,11 @@ __device__ unsigned long long* g_pp_trace = nullptr;      // dev: cycle stamps o
 // so that a lane holds ONE pixel and four consecutive output channels per accumulator quad: the epilogue packs and writes 8 bytes per
 // lane and quad (32 ds_write_b64 per tile and wave) instead of trading rows with the neighbour lane (64 DPP + 64 v_perm + 64
 // ds_write_b32).  The epilogue is LDS-issue-bound (~47 cycles per LDS instruction beside the partner's operand reads and the DMA).
-// XF (round 5; phx_conv3x3_mfma_bf16_xf): the input is the PRE-normalisation tensor of the producing layer and the loader half applies
-// that layer's a = relu(x * xscale[k] + xshift[k]) on the way in -- global -> VGPR -> unpack / fma / max / pack -> ds_write_b128 instead
-// of the LDS-DMA -- so the producer's apply pass (read y, write a) and the tensor a itself disappear (conv2d -> batch_norm -> relu ->
-// conv2d, tfwrapper/layers.py:123-135).  A lane keeps ONE source piece (8 channels: 16 scale / shift registers per chunk) and writes
-// it to the swizzled slot of its pixel; out-of-image pieces are forced to zero AFTER the transform (the zero padding is of a, not
-// of x).  The values are rounded to bf16 exactly as the apply pass stores them: the launch is bit-identical to the LDS-DMA launch on
-// the materialised a (tools/bench_pp_xf.py: + 2 ... 22 % on the convolution against the 0.012 - 0.094 ms apply pass it deletes).
-template <int BN, bool BIASACT, bool DUAL, int DBG, bool TR = false, bool XF = false>
+template <int BN, bool BIASACT, bool DUAL, int DBG, bool TR = false>
 __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __restrict__ x, const unsigned short* __restrict__ wpk,
                                                        unsigned short* __restrict__ y, const float* __restrict__ bias, int act,
                                                        float* __restrict__ stats_partial, int B, int H, int W, int K, int N,
-                                                       PPGeom gm, const float* __restrict__ oscale, int stats_nrep, Dual du,
-                                                       const float* __restrict__ xscale = nullptr, const float* __restrict__ xshift = nullptr) {
+                                                       PPGeom gm, const float* __restrict__ oscale, int stats_nrep, Dual du) {
     constexpr int NJ = BN / 32;                       // 32-channel MFMA columns per wave
     constexpr int SLAB = 9 * BN * 64;                 // bytes per slab buffer
     constexpr int SP = SLAB / 2048;                   // 1 KiB DMA instructions per slab HALF (18 / 9)
@@ -174,48 +166,6 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __r
         const int xlo = (int)(pout & 1u), xw = 33 - (int)((pout >> 1) & 1u) - xlo;
         const int ylo = (int)((pout >> 2) & 1u), yw = 17 - (int)((pout >> 3) & 1u) - ylo;
         const bool none = (pout & 32u) != 0u;
-        if constexpr (XF) {
-            // lane -> (pixel sub-index ln >> 2, source piece sp = ln & 3): the piece's eight channels are the same for all ten pieces
-            const int sp = ln & 3;
-            typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-            const f32x4_t sc0 = *reinterpret_cast<const f32x4_t*>(xscale + c * 32 + sp * 8), sc1 = *reinterpret_cast<const f32x4_t*>(xscale + c * 32 + sp * 8 + 4);
-            const f32x4_t sh0 = *reinterpret_cast<const f32x4_t*>(xshift + c * 32 + sp * 8), sh1 = *reinterpret_cast<const f32x4_t*>(xshift + c * 32 + sp * 8 + 4);
-            u32x4_t r[PP_APW];
-            unsigned dsto[PP_APW];
-#pragma unroll
-            for (int n = 0; n < PP_APW; ++n) {
-                const int j = lw * PP_APW + n;
-                r[n] = u32x4_t{0u, 0u, 0u, 0u};
-                dsto[n] = 0xffffffffu;
-                if (j < PP_AI) {
-                    const int pp = pp0 + n * 16;
-                    const int py = (int)(((unsigned)pp * 1928u) >> 16), px = pp - py * 34;
-                    const bool bad = none || (unsigned)(px - xlo) > (unsigned)xw || (unsigned)(py - ylo) > (unsigned)yw;
-                    const unsigned vo = bad ? 0xffffffffu : pb + __umul24((unsigned)(py * W + px), stride) + (unsigned)(sp << 4);
-                    r[n] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)vo, so, 0));
-                    // LDS slot of (pixel pp, source piece sp): the swizzled image the operand reads expect; bit 31 = "force zero"
-                    dsto[n] = (unsigned)(pp * 64 + ((sp ^ ((px >> 2) & 3)) << 4)) | (bad ? 0x80000000u : 0u);
-                }
-            }
-#pragma unroll
-            for (int n = 0; n < PP_APW; ++n) {
-                const int j = lw * PP_APW + n;
-                if (j < PP_AI) {
-                    unsigned o[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const unsigned w = r[n][k];
-                        const float s0 = k < 2 ? sc0[2 * k] : sc1[2 * k - 4], s1 = k < 2 ? sc0[2 * k + 1] : sc1[2 * k - 3];
-                        const float t0 = k < 2 ? sh0[2 * k] : sh1[2 * k - 4], t1 = k < 2 ? sh0[2 * k + 1] : sh1[2 * k - 3];
-                        const float a0 = fmaxf(fmaf(__uint_as_float(w << 16), s0, t0), 0.f);
-                        const float a1 = fmaxf(fmaf(__uint_as_float(w & 0xffff0000u), s1, t1), 0.f);
-                        o[k] = (dsto[n] & 0x80000000u) ? 0u : f2bf_pk(a0, a1);
-                    }
-                    *reinterpret_cast<u32x4_t*>(patch + (dsto[n] & 0x7fffffffu)) = u32x4_t{o[0], o[1], o[2], o[3]};
-                }
-            }
-            return;
-        }
 #pragma unroll
         for (int n = 0; n < PP_APW; ++n) {
             const int j = lw * PP_APW + n;
@@ -602,11 +552,7 @@ bool phx_pp_shape_ok(int B, int H, int W, int K, int N) {
 }
 
 int phx_pp_launch(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial, int B, int H, int W,
-                  int K, int N, const float* oscale, int stats_nrep, Dual du, int dbg, void* stream, const float* xscale = nullptr,
-                  const float* xshift = nullptr);
-int phx_pp_launch(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial, int B, int H, int W,
-                  int K, int N, const float* oscale, int stats_nrep, Dual du, int dbg, void* stream, const float* xscale,
-                  const float* xshift) {
+                  int K, int N, const float* oscale, int stats_nrep, Dual du, int dbg, void* stream) {
     PHX_REQUIRE(phx_pp_shape_ok(B, H, W, K, N), PHX_E_SHAPE, "conv3x3_pp: H % 16, W % 32, K % 32, N % 32 == 0 required");
     PHX_REQUIRE(act == PHX_ACT_ID || act == PHX_ACT_RELU, PHX_E_INVAL, "conv3x3_pp: identity / ReLU epilogue only");
     const int bn = N % 64 == 0 ? 64 : 32;
@@ -642,18 +588,8 @@ int phx_pp_launch(const void* x, const void* wpk, void* y, const float* bias, in
         if (!at) { PHX_CHECK_HIP(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); at = true; } \
         hipLaunchKernelGGL(kf, dim3(grid), dim3(512), BNv == 64 ? lds64 : lds32, (hipStream_t)stream, (const unsigned short*)x,    \
                            (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, gm, oscale,   \
-                           stats_nrep, du, (const float*)nullptr, (const float*)nullptr);                                         \
+                           stats_nrep, du);                                                                                       \
     } while (0)
-    if (xscale != nullptr) {                 // transform in the loader half (XF): 64-channel blocks, no bias / activation epilogue, statistics optional
-        PHX_REQUIRE(xshift != nullptr && bn == 64 && !ba && !dual, PHX_E_SHAPE, "conv3x3_pp: the input transform needs N % 64 == 0 and a plain epilogue");
-        auto kf = k_conv3x3_pp<64, false, false, 0, false, true>;
-        static bool at = false;
-        if (!at) { PHX_CHECK_HIP(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); at = true; }
-        hipLaunchKernelGGL(kf, dim3(grid), dim3(512), lds64, (hipStream_t)stream, (const unsigned short*)x, (const unsigned short*)wpk,
-                           (unsigned short*)y, bias, act, stats_partial, B, H, W, K, N, gm, oscale, stats_nrep, du, xscale, xshift);
-        PHX_CHECK_LAUNCH();
-        return PHX_OK;
-    }
     if (bn == 64) {
         if (dual) { if (ba) PP_LAUNCH(64, true, true, 0); else PP_LAUNCH(64, false, true, 0); }
         else if (ba) PP_LAUNCH(64, true, false, 0);

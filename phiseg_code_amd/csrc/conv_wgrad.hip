@@ -326,7 +326,6 @@ struct WgMJob {
     MTile g;
     int ntiles, tpb, gdx, gdy, gdz, blk0;
     const unsigned short* x2; int K1, pad_;      // concat-free input (struct Dual); x2 == NULL: single tensor
-    const float *xscale, *xshift;                // non-NULL (k_conv3x3_wgrad_pp_multi only): x is a PRE-normalisation tensor, see XF below
 };
 template <int TCI, int TCO, bool BIGP>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_wgrad_multi(const WgMJob* __restrict__ jobs, int njobs) {
@@ -576,17 +575,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_dma_multi(const WgMJob
 // writes ONE partial filter -- half the partial filters (workspace traffic, reduction work) of two 256-thread blocks.
 // The 20 transpose reads of the next k-step are pinned between the 9 MFMAs of the running one (two or four behind each): a burst
 // in front of them stalls a lone wave's matrix pipe.
-// XF (round 5): x is the PRE-normalisation tensor of the layer in front and the loading half applies that layer's
-// a = relu(x * xscale[ci] + xshift[ci]) to the patch on its way global -> VGPR -> LDS (a lane keeps one 8-channel source piece of
-// eleven patch pixels; out-of-image pieces are forced to zero after the transform), exactly as the forward pair kernel does
-// (conv_pp.hip): the filter gradient of a convolution whose input activation was never written (phx_conv3x3_mfma_bf16_xf).
-template <bool XF = false>
 __device__ __forceinline__ void conv3x3_wgrad_pp_body(const unsigned short* __restrict__ x0, const unsigned short* __restrict__ dy,
                                                       float* __restrict__ ws, int B, int H, int W, int Cin, int Cout, MTile g,
                                                       int ntiles, int tiles_per_block, const int bx, const int by, const int bz,
                                                       const int gdx, const int gdy,
-                                                      const unsigned short* __restrict__ x2 = nullptr, const int K1 = 0,
-                                                      const float* __restrict__ xscale = nullptr, const float* __restrict__ xshift = nullptr) {
+                                                      const unsigned short* __restrict__ x2 = nullptr, const int K1 = 0) {
     constexpr int TCI = 64, TCO = 64;
     const bool src2 = x2 != nullptr && by * TCI >= K1;       // concat-free input: see conv3x3_wgrad_body
     const unsigned short* __restrict__ x = src2 ? x2 : x0;
@@ -638,48 +631,6 @@ __device__ __forceinline__ void conv3x3_wgrad_pp_body(const unsigned short* __re
         const int tx0 = (tt % g.tiles_x) << 4; tt /= g.tiles_x;
         const int ty0 = (tt % g.tiles_y) << 4; tt /= g.tiles_y;
         const int b0 = tt;
-        if constexpr (XF) {
-            typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-            const int sp = ln & 7;                             // this lane's SOURCE piece: channels xc0 + 8 sp .. + 7 of every pixel it loads
-            const f32x4_t sc0 = *reinterpret_cast<const f32x4_t*>(xscale + by * TCI + sp * 8), sc1 = *reinterpret_cast<const f32x4_t*>(xscale + by * TCI + sp * 8 + 4);
-            const f32x4_t sh0 = *reinterpret_cast<const f32x4_t*>(xshift + by * TCI + sp * 8), sh1 = *reinterpret_cast<const f32x4_t*>(xshift + by * TCI + sp * 8 + 4);
-            u32x4_t rr[XN];
-            unsigned dsto[XN];
-#pragma unroll
-            for (int n = 0; n < XN; ++n) {
-                const int j = lw + 4 * n;
-                rr[n] = u32x4_t{0u, 0u, 0u, 0u};
-                dsto[n] = 0xffffffffu;
-                if (j < XI) {
-                    const int pp = j * 8 + (ln >> 3);
-                    const int py = (int)(((unsigned)pp * 3641u) >> 16), px = pp - py * 18;
-                    const int gx = tx0 + px - 1, gy = ty0 + py - 1;
-                    const bool ok = pp < NPATCH && gx >= 0 && gx < W && gy >= 0 && gy < H;
-                    const unsigned vo = ok ? (unsigned)((((b0 * H + gy) * W + gx) * xC) * 2 + sp * 16) : 0xffffffffu;
-                    rr[n] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)vo, xc0 * 2, 0));
-                    // LDS slot of (pixel pp, source piece sp) in the half-swizzled 128-byte rows; bit 31: force zero (padding of a)
-                    dsto[n] = (unsigned)(pp * 128 + ((sp ^ (((pp >> 1) & 1) << 2)) << 4)) | (ok ? 0u : 0x80000000u);
-                }
-            }
-#pragma unroll
-            for (int n = 0; n < XN; ++n) {
-                const int j = lw + 4 * n;
-                if (j < XI) {
-                    unsigned o[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const unsigned w = rr[n][k];
-                        const float s0 = k < 2 ? sc0[2 * k] : sc1[2 * k - 4], s1 = k < 2 ? sc0[2 * k + 1] : sc1[2 * k - 3];
-                        const float t0 = k < 2 ? sh0[2 * k] : sh1[2 * k - 4], t1 = k < 2 ? sh0[2 * k + 1] : sh1[2 * k - 3];
-                        const float a0 = fmaxf(fmaf(__uint_as_float(w << 16), s0, t0), 0.f);
-                        const float a1 = fmaxf(fmaf(__uint_as_float(w & 0xffff0000u), s1, t1), 0.f);
-                        o[k] = (dsto[n] & 0x80000000u) ? 0u : f2bf_pk(a0, a1);
-                    }
-                    *reinterpret_cast<u32x4_t*>(smem + sbase + (dsto[n] & 0x7fffffffu)) = u32x4_t{o[0], o[1], o[2], o[3]};
-                }
-            }
-        } else {
 #pragma unroll
         for (int n = 0; n < XN; ++n) {
             const int j = lw + 4 * n;
@@ -693,7 +644,6 @@ __device__ __forceinline__ void conv3x3_wgrad_pp_body(const unsigned short* __re
                 const unsigned vo = ok ? (unsigned)((((b0 * H + gy) * W + gx) * xC) * 2 + p * 16) : 0xffffffffu;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(smem + sbase + j * 1024), 16, vo, xc0 * 2, 0, 0);
             }
-        }
         }
 #pragma unroll
         for (int n = 0; n < DN; ++n) {
@@ -813,15 +763,8 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_pp(const unsigned shor
                                                              float* __restrict__ ws, int B, int H, int W, int Cin, int Cout, MTile g,
                                                              int ntiles, int tiles_per_block, const unsigned short* __restrict__ x2,
                                                              int K1) {
-    conv3x3_wgrad_pp_body<false>(x, dy, ws, B, H, W, Cin, Cout, g, ntiles, tiles_per_block, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x,
-                                 gridDim.y, x2, K1);
-}
-__global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_pp_xf(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy,
-                                                                float* __restrict__ ws, int B, int H, int W, int Cin, int Cout, MTile g,
-                                                                int ntiles, int tiles_per_block, const float* __restrict__ xscale,
-                                                                const float* __restrict__ xshift) {
-    conv3x3_wgrad_pp_body<true>(x, dy, ws, B, H, W, Cin, Cout, g, ntiles, tiles_per_block, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x,
-                                gridDim.y, nullptr, 0, xscale, xshift);
+    conv3x3_wgrad_pp_body(x, dy, ws, B, H, W, Cin, Cout, g, ntiles, tiles_per_block, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x,
+                          gridDim.y, x2, K1);
 }
 __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_pp_multi(const WgMJob* __restrict__ jobs, int njobs) {
     int lo = 0, hi = njobs - 1;
@@ -838,12 +781,8 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_wgrad_pp_multi(const WgMJob*
     // work-groups are bound to XCDs statically -- and cost 0.81 ms instead of 0.65 for the launch)
     const int c = t % cb, bx = (t / cb) * 8 + (local & 7);
     if (bx >= j.gdx) return;
-    if (j.xscale != nullptr)       // (uniform per work-group)
-        conv3x3_wgrad_pp_body<true>(j.x, j.dy, j.ws, j.B, j.H, j.W, j.Cin, j.Cout, j.g, j.ntiles, j.tpb, bx, c % j.gdy, c / j.gdy, j.gdx, j.gdy,
-                                    nullptr, 0, j.xscale, j.xshift);
-    else
-        conv3x3_wgrad_pp_body<false>(j.x, j.dy, j.ws, j.B, j.H, j.W, j.Cin, j.Cout, j.g, j.ntiles, j.tpb, bx, c % j.gdy, c / j.gdy, j.gdx, j.gdy,
-                                     j.x2, j.K1);
+    conv3x3_wgrad_pp_body(j.x, j.dy, j.ws, j.B, j.H, j.W, j.Cin, j.Cout, j.g, j.ntiles, j.tpb, bx, c % j.gdy, c / j.gdy, j.gdx, j.gdy,
+                          j.x2, j.K1);
 }
 
 // dw[k][ci][co] += sum over the nslice partial tiles written by the filter-gradient kernels.  A thread owns four
@@ -1009,50 +948,9 @@ int phx_conv3x3_wgrad_multi_job(const void* x, const void* dy, float* dw_hwio, v
     return phx_conv3x3_wgrad_multi_job_dual(x, nullptr, 0, dy, dw_hwio, workspace, workspace_bytes, B, H, W, Cin, Cout, blocks_target, blk0,
                                             job_out, info4);
 }
-static int wgrad_multi_job_impl(const void* x, const void* x2, int K1, const void* dy, float* dw_hwio, void* workspace,
-                                size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int blocks_target, int blk0,
-                                void* job_out, int* info4, const float* xscale, const float* xshift);
 int phx_conv3x3_wgrad_multi_job_dual(const void* x, const void* x2, int K1, const void* dy, float* dw_hwio, void* workspace,
                                      size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int blocks_target, int blk0,
                                      void* job_out, int* info4) {
-    return wgrad_multi_job_impl(x, x2, K1, dy, dw_hwio, workspace, workspace_bytes, B, H, W, Cin, Cout, blocks_target, blk0, job_out, info4,
-                                nullptr, nullptr);
-}
-// Filter gradient of a convolution that read the PRE-normalisation tensor of the layer in front (phx_conv3x3_mfma_bf16_xf): x is that
-// tensor, xscale / xshift [Cin] the producer's coefficients, a = relu(x * xscale + xshift) is re-formed by the loading half of the
-// anti-phase kernel (k_conv3x3_wgrad_pp, XF).  Shapes: 64 x 64 channel blocks on 16 x 16 tiles with a workspace.
-int phx_conv3x3_wgrad_xf_supported(int B, int H, int W, int Cin, int Cout) {
-    if (Cin % 64 != 0 || Cout % 64 != 0 || !wgrad_dma_enabled()) return 0;
-    MTile g; int tci, tco, gx, tpb, wk;
-    const int ntiles = wgrad_plan(B, H, W, Cin, Cout, &g, &tci, &tco, &gx, &tpb, &wk, 0, 0);
-    return (tci == 64 && tco == 64 && g.tws == 4 && g.ths == 4 && g.tb == 1 && ntiles > wgrad_atomic_tiles()) ? 1 : 0;
-}
-int phx_conv3x3_wgrad_multi_job_xf(const void* x, const float* xscale, const float* xshift, const void* dy, float* dw_hwio,
-                                   void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int blocks_target,
-                                   int blk0, void* job_out, int* info4) {
-    PHX_REQUIRE(xscale != nullptr && xshift != nullptr && workspace != nullptr && phx_conv3x3_wgrad_xf_supported(B, H, W, Cin, Cout), PHX_E_SHAPE,
-                "conv3x3_wgrad_multi_job_xf: xscale / xshift / workspace, shape see phx_conv3x3_wgrad_xf_supported");
-    return wgrad_multi_job_impl(x, nullptr, 0, dy, dw_hwio, workspace, workspace_bytes, B, H, W, Cin, Cout, blocks_target, blk0, job_out, info4,
-                                xscale, xshift);
-}
-/* the stand-alone launch (partial filters into the workspace, no reduction: as phx_conv3x3_wgrad_mfma_bf16_partial) */
-int phx_conv3x3_wgrad_mfma_bf16_partial_xf(const void* x, const float* xscale, const float* xshift, const void* dy, void* workspace,
-                                           size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, void* stream) {
-    PHX_REQUIRE(xscale != nullptr && xshift != nullptr && workspace != nullptr && phx_conv3x3_wgrad_xf_supported(B, H, W, Cin, Cout), PHX_E_SHAPE,
-                "conv3x3_wgrad_partial_xf: xscale / xshift / workspace, shape see phx_conv3x3_wgrad_xf_supported");
-    PHX_REQUIRE(workspace_bytes >= phx_conv3x3_wgrad_ws_bytes(B, H, W, Cin, Cout), PHX_E_INVAL, "conv3x3_wgrad_partial_xf: workspace too small");
-    MTile g; int tci, tco, gx, tpb, wk;
-    const int ntiles = wgrad_plan(B, H, W, Cin, Cout, &g, &tci, &tco, &gx, &tpb, &wk, 0, 0);
-    static bool at = false;
-    if (!at) { PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_wgrad_pp_xf, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); at = true; }
-    hipLaunchKernelGGL(k_conv3x3_wgrad_pp_xf, dim3(gx, Cin / 64, Cout / 64), dim3(512), wgrad_dma_lds(64, 64), (hipStream_t)stream,
-                       (const unsigned short*)x, (const unsigned short*)dy, (float*)workspace, B, H, W, Cin, Cout, g, ntiles, tpb, xscale, xshift);
-    PHX_CHECK_LAUNCH();
-    return PHX_OK;
-}
-static int wgrad_multi_job_impl(const void* x, const void* x2, int K1, const void* dy, float* dw_hwio, void* workspace,
-                                size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int blocks_target, int blk0,
-                                void* job_out, int* info4, const float* xscale, const float* xshift) {
     PHX_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, PHX_E_SHAPE, "conv3x3_wgrad_multi_job: Cin % 32 == 0 and Cout % 32 == 0 required");
     PHX_REQUIRE(x2 == nullptr || (K1 > 0 && K1 < Cin && K1 % 32 == 0), PHX_E_SHAPE, "conv3x3_wgrad_multi_job: 0 < K1 < Cin, K1 % 32 == 0");
     if (x2 == nullptr) K1 = 0;
@@ -1079,10 +977,8 @@ static int wgrad_multi_job_impl(const void* x, const void* x2, int K1, const voi
     j.B = B; j.H = H; j.W = W; j.Cin = Cin; j.Cout = Cout; j.g = g; j.ntiles = ntiles; j.tpb = tpb;
     j.gdx = gx; j.gdy = Cin / tci; j.gdz = Cout / tco; j.blk0 = blk0;
     j.x2 = (const unsigned short*)x2; j.K1 = K1; j.pad_ = 0;
-    j.xscale = xscale; j.xshift = xshift;
     memcpy(job_out, &j, sizeof(j));
     info4[0] = 1 + (tco == 64 ? 1 : 0) + (tci == 64 ? 2 : 0) + (fast16 ? 8 : npatch > 400 ? 4 : 0);     // 9..12: LDS-DMA kernels
-    PHX_REQUIRE(xscale == nullptr || info4[0] == 12, PHX_E_SHAPE, "conv3x3_wgrad_multi_job_xf: not a job of the anti-phase kernel");
     info4[1] = j.gdx * j.gdy * j.gdz;
     if (info4[0] == 12) info4[1] = (j.gdx + 7) / 8 * 8 * j.gdy * j.gdz;      // k_conv3x3_wgrad_pp_multi: slices padded to the 8 XCDs
     info4[2] = fast16 ? (int)wgrad_dma_lds(tci, tco) : npatch * tci * 2 + 256 * tco * 2;

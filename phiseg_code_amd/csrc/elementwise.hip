@@ -887,10 +887,9 @@ __global__ void k_reduce_partials_ns(const float* __restrict__ partial, int T, i
 }
 
 // Per-channel batch / instance-norm coefficients from the accumulated sums -- ONE definition with floating-point contraction off, used
-// by the fused apply kernels AND by k_norm_finalize: a layer whose apply pass is replaced by the consumers' loader transform (engine
-// XfBuf, phx_conv3x3_mfma_bf16_xf) must get bit-identical scale / shift from the stand-alone finalisation (round 5: with the
-// compiler free to contract `sq * invP - d1 * d1` differently in the two kernels the variances differed in the last place, and two
-// training steps later so did 30 % of the ELBO of a deliberately ill-conditioned test network).
+// by the fused apply kernels AND by k_norm_finalize, so that the stand-alone finalisation and the fused one agree bit for bit (round 5:
+// with the compiler free to contract `s2 * invP - d1 * d1` differently in the two kernels the variances differed in the last place --
+// a bf16 flip per few thousand activations, and two Adam steps later 30 % of the ELBO of a deliberately ill-conditioned test network).
 __device__ __forceinline__ void chan_coeffs(float s1, float s2, float pv, float invP, float eps, float* mu, float* var, float* rs) {
 #pragma clang fp contract(off)
     const float d1 = s1 * invP;

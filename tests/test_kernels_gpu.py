@@ -367,72 +367,6 @@ def _mfma_case(L, case):
     close(host(dw2), wr.grad.numpy(), 1e-4, "mfma wgrad (workspace)")
 
 
-@pytest.mark.parametrize("case", [(2, 16, 32, 64, 64), (3, 32, 64, 128, 64), (1, 48, 32, 32, 128), (5, 16, 64, 192, 192), (2, 32, 32, 64, 128)])
-@pytest.mark.parametrize("grid", [0, 3])
-def test_conv3x3_input_transform_in_the_loader(Ld, case, grid, policy):
-    """phx_conv3x3_mfma_bf16_xf / phx_conv3x3_wgrad_mfma_bf16_partial_xf / _multi_job_xf (round 5): conv2d on the PRE-normalisation
-    tensor of the layer in front -- a = relu(x * scale + shift) (tfwrapper/layers.py:123-135: conv2d -> batch_norm -> relu -> conv2d) is
-    re-formed in the loaders of the pair kernel and of the anti-phase filter gradient, never written -- forced onto small shapes
-    (odd tile counts, image edges on every side, persistent grids of 3 blocks): bit-identical to the same launches on the
-    materialised bf16 activation (phx_affine_act), and against the oracle's conv2d of relu(x * scale + shift)."""
-    L = Ld
-    B, H, W, K, N = case
-    policy(large_maps=2, pair_grid=grid)
-    assert L.conv3x3_xf_supported(B, H, W, K, N) == 1 and L.conv3x3_xf_supported(B, H, W, K, 32) == 0
-    x = RNG.standard_normal((B, H, W, K))
-    w = RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K)
-    sc, sh = 1.0 + 0.3 * RNG.standard_normal(K), 0.2 * RNG.standard_normal(K)
-    xd, wd, scd, shd = dev(x, BF16), dev(w), dev(sc), dev(sh)
-    P = B * H * W
-    a = torch.empty_like(xd)
-    L.affine_act(xd.data_ptr(), BF16, scd.data_ptr(), shd.data_ptr(), a.data_ptr(), BF16, 1, P, K, 1, S())
-    wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
-    L.pack_conv3x3_bf16(wd.data_ptr(), wf.data_ptr(), None, K, N, S())
-    nt = L.conv3x3_mfma_bf16_tiles(B, H, W, K, N)
-    y1, y2 = (torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda() for _ in range(2))
-    p1, p2 = (torch.zeros(nt, 2, N, dtype=torch.float32).cuda() for _ in range(2))
-    L.conv3x3_mfma_bf16(a.data_ptr(), wf.data_ptr(), y1.data_ptr(), None, 0, p1.data_ptr(), B, H, W, K, N, S())
-    L.conv3x3_mfma_bf16_xf(xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), wf.data_ptr(), y2.data_ptr(), p2.data_ptr(), B, H, W, K, N, S())
-    assert torch.equal(y1, y2) and torch.equal(p1, p2)
-    ar = torch.relu(rounded(x, BF16) * torch.as_tensor(sc, dtype=torch.float32).double() + torch.as_tensor(sh, dtype=torch.float32).double())
-    ref = T.conv2d_same(rounded(ar.float().numpy(), BF16), rounded(w, BF16))
-    close(host(y2), ref.numpy(), 8e-3, "conv on the transformed input")
-    y3 = torch.empty_like(y2)                                   # no statistics epilogue
-    L.conv3x3_mfma_bf16_xf(xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), wf.data_ptr(), y3.data_ptr(), None, B, H, W, K, N, S())
-    assert torch.equal(y3, y1)
-    if grid or K % 64 or N % 64 or not L.conv3x3_wgrad_xf_supported(B, H, W, K, N):
-        return
-    # filter gradient: stand-alone launch + reduction, and one deferred job, against the launch on the materialised activation
-    dy = dev(RNG.standard_normal((B, H, W, N)), BF16)
-    wsb = int(L.conv3x3_wgrad_ws_bytes(B, H, W, K, N))
-    ws1, ws2 = (torch.zeros(wsb // 4, dtype=torch.float32).cuda() for _ in range(2))
-    dw1, dw2, dw3 = (torch.zeros(3, 3, K, N, dtype=torch.float32).cuda() for _ in range(3))
-    L.conv3x3_wgrad_mfma_bf16_partial(a.data_ptr(), dy.data_ptr(), dw1.data_ptr(), ws1.data_ptr(), wsb, B, H, W, K, N, S())
-    L.conv3x3_wgrad_mfma_bf16_partial_xf(xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), dy.data_ptr(), ws2.data_ptr(), wsb, B, H, W, K, N, S())
-    torch.cuda.synchronize()
-    assert torch.equal(ws1, ws2)
-    plan = (ctypes.c_int * 6)()
-    L.conv3x3_wgrad_reduce_plan(B, H, W, K, N, plan)
-    nb = int(L.conv3x3_wgrad_multi_job_bytes())
-    for fn, args, dw in ((L.conv3x3_wgrad_multi_job, (a.data_ptr(),), dw2), (L.conv3x3_wgrad_multi_job_xf, (xd.data_ptr(), scd.data_ptr(), shd.data_ptr()), dw3)):
-        jb, info = ctypes.create_string_buffer(nb), (ctypes.c_int * 9)()
-        wsj = torch.zeros(wsb // 4, dtype=torch.float32).cuda()
-        fn(*args, dy.data_ptr(), dw.data_ptr(), wsj.data_ptr(), wsb, B, H, W, K, N, 96, 0, jb, info)
-        assert info[0] == 12 and info[3] == 1
-        desc = torch.from_numpy(np.frombuffer(jb.raw, dtype=np.uint8).copy()).cuda()
-        L.conv3x3_wgrad_multi(desc.data_ptr(), 1, info[1], info[0], info[2], S())
-        rec = np.zeros(1, dtype=[("ws", "<u8"), ("dw", "<u8"), ("nslice", "<i4"), ("Cin", "<i4"), ("Cout", "<i4"), ("tci", "<i4"), ("tco", "<i4"),
-                                 ("gx", "<i4"), ("gy", "<i4"), ("blk0", "<i4")])
-        rec[0] = (wsj.data_ptr(), dw.data_ptr(), info[4], K, N, info[5], info[6], info[7], info[8], 0)
-        rdesc = torch.from_numpy(rec.view(np.uint8).copy()).cuda()
-        L.wgrad_reduce_multi(rdesc.data_ptr(), 1, info[7] * info[8], S())
-        torch.cuda.synchronize()
-    assert torch.equal(dw2, dw3)
-    wr = torch.zeros(3, 3, K, N, dtype=torch.float64, requires_grad=True)
-    (T.conv2d_same(rounded(host(a), BF16), wr) * rounded(host(dy), BF16)).sum().backward()
-    close(host(dw3), wr.grad.numpy(), 1e-4, "filter gradient on the transformed input")
-
-
 # the anti-phase filter-gradient kernel (k_conv3x3_wgrad_pp: 64 x 64 channel blocks on 16 x 16 pixel tiles): one tile (half B idle), odd
 # and even tile counts per block, maps that are not multiples of the tile, several channel blocks, the two-tensor (concat-free) input
 @pytest.mark.parametrize("case", [(5, 16, 16, 64, 64, 0), (3, 16, 32, 64, 64, 0), (6, 16, 16, 64, 128, 0), (2, 40, 24, 128, 64, 0),
