@@ -133,6 +133,20 @@ int phx_conv3x3_mfma_bf16_dual(const void* x, const void* x2, int K1, const void
 int phx_conv3x3_mfma_f32out_supported(int B, int H, int W, int K, int N);
 int phx_conv3x3_mfma_bf16_f32out(const void* x, const void* x2, int K1, const void* wpk, float* y_f32, int sum_slices, void* workspace,
                                  size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream);
+/* conv2d straight on the PRE-normalisation tensor of the layer in front (round 5; conv2d -> batch_norm -> relu -> conv2d,
+ * tfwrapper/layers.py:123-135): y = conv3x3(relu(x * xscale[k] + xshift[k])) with the producer's scale / shift (phx_norm_finalize); the
+ * producer's apply pass and its activation tensor are never made.  Shapes (phx_conv3x3_xf_supported): the 32 -> 32 layers of the large
+ * maps -- k_conv3x3_c32 re-forms the activation in place in its staged patch; these launches are HBM-bound, the transform is free
+ * and the bytes are not (on the matrix-bound shapes it is the other way round: measured and removed).
+ * Bit-identical to phx_conv3x3_mfma_bf16 on the materialised bf16 activation.  stats_partial as phx_conv3x3_mfma_bf16.
+ * _wgrad_..._partial_xf: the filter gradient of such a convolution (x = the pre-normalisation tensor; Cin == 32, 16 x 16 tiles, more than
+ * 1 024 of them, workspace of phx_conv3x3_wgrad_ws_bytes required; partial filters only, as phx_conv3x3_wgrad_mfma_bf16_partial). */
+int phx_conv3x3_xf_supported(int B, int H, int W, int K, int N);
+int phx_conv3x3_mfma_bf16_xf(const void* x, const float* xscale, const float* xshift, const void* wpk, void* y, float* stats_partial,
+                             int B, int H, int W, int K, int N, void* stream);
+int phx_conv3x3_wgrad_xf_supported(int B, int H, int W, int Cin, int Cout);
+int phx_conv3x3_wgrad_mfma_bf16_partial_xf(const void* x, const float* xscale, const float* xshift, const void* dy, float* dw_hwio,
+                                           void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, void* stream);
 size_t phx_conv3x3_wgrad_ws_bytes_dual(int B, int H, int W, int Cin, int Cout, int K1);
 int phx_conv3x3_wgrad_reduce_plan_dual(int B, int H, int W, int Cin, int Cout, int K1, int* plan6);
 int phx_conv3x3_wgrad_multi_job_dual(const void* x, const void* x2, int K1, const void* dy, float* dw_hwio, void* workspace,

@@ -41,11 +41,19 @@ __device__ unsigned long long* g_c32_trace = nullptr;      // dev: cycle stamps 
             g_c32_trace[slot] = __builtin_readcyclecounter();                                     \
     } while (0)
 
-template <bool BIASACT>
+// XF (round 5; phx_conv3x3_mfma_bf16_xf): x is the PRE-normalisation tensor of the layer in front and this kernel re-forms that layer's
+// a = relu(x * xscale[k] + xshift[k]) itself (conv2d -> batch_norm -> relu -> conv2d, tfwrapper/layers.py:123-135: the producer's apply
+// pass and its activation tensor are never made).  The patch still arrives by LDS-DMA; when it has landed every thread rewrites ten
+// 16-byte pieces of it IN PLACE (ds_read_b128 -> unpack, fma, max, pack -> ds_write_b128; a thread keeps one source piece = eight
+// channels, 16 coefficient registers) and out-of-image pieces are forced back to zero -- the padding is of a, not of x.  This kernel
+// is HBM-bound (matrix pipe ~18 % busy): the extra VALU / LDS work runs under the other block's loads, and the bytes it removes are
+// the ones that bound the level (the lesson of the pair-kernel attempt, DESIGN.md section 5: it pays only on the HBM side of the ridge).
+template <bool BIASACT, bool XF = false>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const unsigned short* __restrict__ x, const unsigned short* __restrict__ wpk,
                                                         unsigned short* __restrict__ y, const float* __restrict__ bias, int act,
                                                         float* __restrict__ stats_partial, int B, int H, int W, int tiles_x,
-                                                        int tiles_y, int ntiles, const float* __restrict__ oscale, int stats_nrep, unsigned mgx, unsigned mgy) {
+                                                        int tiles_y, int ntiles, const float* __restrict__ oscale, int stats_nrep, unsigned mgx, unsigned mgy,
+                                                        const float* __restrict__ xscale = nullptr, const float* __restrict__ xshift = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int l31 = lane & 31, khalf = lane >> 5;
@@ -137,6 +145,42 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const unsigned short* __
         if (it == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
         C32_TRACE(it * 8 + 1);
+        if constexpr (XF) {
+            // in-place transform of the landed patch: thread -> (source piece sp = tid & 3, patch pixels (tid >> 2) + 64 n)
+            int tx0c, ty0c, b0c;
+            decode(t, &tx0c, &ty0c, &b0c);
+            const bool e_l = tx0c == 0, e_r = tx0c + 32 >= W, e_t = ty0c == 0, e_b = ty0c + 16 >= H;
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));                  // (opaque: nothing of this pass is hoisted out of the tile loop and kept live across the MFMAs)
+            const int sp = tid & 3;
+            unsigned char* const stw = smem + cur * C32_STAGE;
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+            typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+            // (the sixteen coefficients are re-loaded per tile -- L1 hits -- rather than held: the kernel has no registers to spare)
+            const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(xscale + sp * 8), c1 = *reinterpret_cast<const f32x4_t*>(xscale + sp * 8 + 4);
+            const f32x4_t d0 = *reinterpret_cast<const f32x4_t*>(xshift + sp * 8), d1 = *reinterpret_cast<const f32x4_t*>(xshift + sp * 8 + 4);
+            const float xsc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+            const float xsh[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+#pragma unroll
+            for (int n = 0; n < 10; ++n) {
+                const int pp = (tid >> 2) + 64 * n;
+                if (pp < 612) {
+                    const int py = (int)(((unsigned)pp * 1928u) >> 16), px = pp - py * 34;      // pp / 34, pp % 34
+                    const bool outside = (px == 0 && e_l) || (px == 33 && e_r) || (py == 0 && e_t) || (py == 17 && e_b);
+                    u32x4_t* const q = reinterpret_cast<u32x4_t*>(stw + pp * 64 + ((sp ^ ((px >> 2) & 3)) << 4));
+                    const u32x4_t r = *q;
+                    u32x4_t o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float a0 = fmaxf(fmaf(__uint_as_float(r[k] << 16), xsc[2 * k], xsh[2 * k]), 0.f);
+                        const float a1 = fmaxf(fmaf(__uint_as_float(r[k] & 0xffff0000u), xsc[2 * k + 1], xsh[2 * k + 1]), 0.f);
+                        o[k] = outside ? 0u : f2bf_pk(a0, a1);
+                    }
+                    *q = o;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         // the next tile's patch: two DMA instructions behind the MFMAs of each of the first five groups (issued back to back they
         // take ~200 cycles apiece out of this wave's instruction stream; the matrix pipe drains its queue meanwhile)
         const bool more = t + (int)gridDim.x < ntiles;
@@ -280,23 +324,29 @@ bool phx_c32_enabled() { return true; }
 // same contract as the pair-kernel launch inside conv3x3_mfma_impl (K = N = 32, H % 16 == 0, W % 32 == 0): statistics as
 // per-tile partial rows [tile][2][32] (stats_nrep == 0) or added to stats_nrep accumulator replicas
 int phx_c32_launch(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial, int B, int H, int W,
-                   const float* oscale, int stats_nrep, void* stream) {
+                   const float* oscale, int stats_nrep, void* stream, const float* xscale, const float* xshift) {
     const int tiles_x = W / 32, tiles_y = H / 16, ntiles = B * tiles_x * tiles_y;
     const int cap = 512;                          // persistent grid: two blocks per CU
     const int grid = ntiles < cap ? ntiles : cap;
     const bool ba = bias != nullptr || act != PHX_ACT_ID || oscale != nullptr;
     PHX_REQUIRE(ntiles < 65536, PHX_E_SHAPE, "conv3x3_c32: more than 65535 tiles");
     const unsigned mgx = (unsigned)((0x100000000ull + tiles_x - 1) / tiles_x), mgy = (unsigned)((0x100000000ull + tiles_y - 1) / tiles_y);
-    if (ba) {
+    if (xscale != nullptr) {
+        PHX_REQUIRE(xshift != nullptr && !ba, PHX_E_INVAL, "conv3x3_c32: the input transform takes a plain epilogue");
+        PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_c32<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((k_conv3x3_c32<false, true>), dim3(grid), dim3(256), C32_LDS, (hipStream_t)stream, (const unsigned short*)x,
+                           (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, H, W, tiles_x, tiles_y, ntiles,
+                           oscale, stats_nrep, mgx, mgy, xscale, xshift);
+    } else if (ba) {
         PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_c32<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipLaunchKernelGGL((k_conv3x3_c32<true>), dim3(grid), dim3(256), C32_LDS, (hipStream_t)stream, (const unsigned short*)x,
                            (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, H, W, tiles_x, tiles_y, ntiles,
-                           oscale, stats_nrep, mgx, mgy);
+                           oscale, stats_nrep, mgx, mgy, (const float*)nullptr, (const float*)nullptr);
     } else {
         PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_c32<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         hipLaunchKernelGGL((k_conv3x3_c32<false>), dim3(grid), dim3(256), C32_LDS, (hipStream_t)stream, (const unsigned short*)x,
                            (const unsigned short*)wpk, (unsigned short*)y, bias, act, stats_partial, B, H, W, tiles_x, tiles_y, ntiles,
-                           oscale, stats_nrep, mgx, mgy);
+                           oscale, stats_nrep, mgx, mgy, (const float*)nullptr, (const float*)nullptr);
     }
     PHX_CHECK_LAUNCH();
     return PHX_OK;

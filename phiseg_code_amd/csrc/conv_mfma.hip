@@ -159,7 +159,7 @@ int phx_c32_set_trace(void* dev_buf);
 int phx_wgrad_set_debug(void* trace_buf, void* blocklog_buf, int which);      // conv_wgrad.hip
 bool phx_c32_enabled();                       // conv_c32.hip: the 32 -> 32-channel layers on large maps (filter in registers, persistent)
 int phx_c32_launch(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial, int B, int H, int W,
-                   const float* oscale, int stats_nrep, void* stream);
+                   const float* oscale, int stats_nrep, void* stream, const float* xscale = nullptr, const float* xshift = nullptr);
 // anti-phase pair kernel for large maps (conv_pp.hip)
 struct Dual;
 bool phx_pp_shape_ok(int B, int H, int W, int K, int N);
@@ -1024,6 +1024,19 @@ int phx_conv3x3_mfma_bf16_f32out(const void* x, const void* x2, int K1, const vo
     b.keep_slices = sum_slices == 0;
     Dual du{(const unsigned short*)x2, nullptr, x2 ? K1 : 0, 0};
     return conv3x3_mfma_impl(x, wpk, nullptr, nullptr, PHX_ACT_ID, nullptr, workspace, workspace_bytes, B, H, W, K, N, b, du, stream);
+}
+
+// conv2d on the PRE-normalisation tensor of the producing layer (round 5): y = conv3x3(relu(x * xscale[k] + xshift[k])) -- the 32 -> 32
+// layers of the large maps (k_conv3x3_c32, XF: the HBM-bound 128 x 128 level, where the transform is free and the bytes are not).
+int phx_conv3x3_xf_supported(int B, int H, int W, int K, int N) {
+    return (K == 32 && N == 32 && fwd_ws64(B, H, W, K, N) && phx_c32_enabled()) ? 1 : 0;
+}
+int phx_conv3x3_mfma_bf16_xf(const void* x, const float* xscale, const float* xshift, const void* wpk, void* y, float* stats_partial,
+                             int B, int H, int W, int K, int N, void* stream) {
+    PHX_REQUIRE(phx_conv3x3_xf_supported(B, H, W, K, N), PHX_E_SHAPE, "conv3x3_mfma_xf: shape not supported (see phx_conv3x3_xf_supported)");
+    PHX_REQUIRE(x && xscale && xshift && wpk && y, PHX_E_INVAL, "conv3x3_mfma_xf: null argument");
+    PHX_REQUIRE((((uintptr_t)x | (uintptr_t)wpk | (uintptr_t)y) & 15) == 0, PHX_E_ALIGN, "conv3x3_mfma_xf: 16-byte alignment");
+    return phx_c32_launch(x, wpk, y, nullptr, PHX_ACT_ID, stats_partial, B, H, W, nullptr, 0, stream, xscale, xshift);
 }
 
 // ---- conv + bias + group / instance norm + activation in one launch (FGN instantiations of k_conv3x3_mfma) ----------------------

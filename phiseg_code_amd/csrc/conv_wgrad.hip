@@ -352,7 +352,12 @@ __device__ __forceinline__ void conv3x3_wgrad_dma_body(const unsigned short* __r
                                                        float* __restrict__ ws, int B, int H, int W, int Cin, int Cout, MTile g,
                                                        int ntiles, int tiles_per_block, const int bx, const int by, const int bz,
                                                        const int gdx, const int gdy,
-                                                       const unsigned short* __restrict__ x2 = nullptr, const int K1 = 0) {
+                                                       const unsigned short* __restrict__ x2 = nullptr, const int K1 = 0,
+                                                       const float* __restrict__ xscale = nullptr, const float* __restrict__ xshift = nullptr) {
+    // xscale != NULL (round 5, the 32-channel input blocks only: TCI == 32): x is the PRE-normalisation tensor of the layer in front; when
+    // the patch has landed every thread rewrites its pieces of it in place as a = relu(x * xscale[ci] + xshift[ci]) (out-of-image pieces
+    // back to zero), as k_conv3x3_c32 does in the forward pass -- the filter gradient of a convolution whose input activation was never
+    // written (phx_conv3x3_mfma_bf16_xf).  These launches are HBM-bound (matrix pipe 17 % busy): the pass is free, the bytes are not.
     const bool src2 = x2 != nullptr && by * TCI >= K1;       // concat-free input: see conv3x3_wgrad_body
     const unsigned short* __restrict__ x = src2 ? x2 : x0;
     const int xC = x2 == nullptr ? Cin : (src2 ? Cin - K1 : K1);
@@ -448,6 +453,37 @@ __device__ __forceinline__ void conv3x3_wgrad_dma_body(const unsigned short* __r
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if constexpr (TCI == 32) {
+            if (xscale != nullptr) {                 // (uniform per launch)
+                typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+                typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+                const int sp = threadIdx.x & 3;
+                const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(xscale + ci0 + sp * 8), c1 = *reinterpret_cast<const f32x4_t*>(xscale + ci0 + sp * 8 + 4);
+                const f32x4_t d0 = *reinterpret_cast<const f32x4_t*>(xshift + ci0 + sp * 8), d1 = *reinterpret_cast<const f32x4_t*>(xshift + ci0 + sp * 8 + 4);
+                const float xsc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                const float xsh[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+#pragma unroll
+                for (int n = 0; n < 6; ++n) {
+                    const int pp = (int)(threadIdx.x >> 2) + 64 * n;
+                    if (pp < NPATCH) {
+                        const int py = (int)(((unsigned)pp * 3641u) >> 16), px = pp - py * 18;        // pp / 18 for pp < 512
+                        const int gx = tx0 + px - 1, gy = ty0 + py - 1;
+                        const bool inside = gx >= 0 && gx < W && gy >= 0 && gy < H;
+                        u32x4_t* const q = reinterpret_cast<u32x4_t*>(smem + pp * RBX + sp * 16);
+                        const u32x4_t r = *q;
+                        u32x4_t o;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float a0 = fmaxf(fmaf(__uint_as_float(r[k] << 16), xsc[2 * k], xsh[2 * k]), 0.f);
+                            const float a1 = fmaxf(fmaf(__uint_as_float(r[k] & 0xffff0000u), xsc[2 * k + 1], xsh[2 * k + 1]), 0.f);
+                            o[k] = inside ? f2bf_pk(a0, a1) : 0u;
+                        }
+                        *q = o;
+                    }
+                }
+                __syncthreads();
+            }
+        }
 
         // k-steps of this wave, software pipelined as in k_conv3x3_wgrad
         constexpr int NSTEP = 16 / WK;
@@ -545,9 +581,10 @@ template <int TCI, int TCO>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_wgrad_dma(const unsigned short* __restrict__ x,
                                                               const unsigned short* __restrict__ dy, float* __restrict__ ws,
                                                               int B, int H, int W, int Cin, int Cout, MTile g, int ntiles,
-                                                              int tiles_per_block, const unsigned short* __restrict__ x2, int K1) {
+                                                              int tiles_per_block, const unsigned short* __restrict__ x2, int K1,
+                                                              const float* __restrict__ xscale, const float* __restrict__ xshift) {
     conv3x3_wgrad_dma_body<TCI, TCO>(x, dy, ws, B, H, W, Cin, Cout, g, ntiles, tiles_per_block, blockIdx.x, blockIdx.y, blockIdx.z,
-                                     gridDim.x, gridDim.y, x2, K1);
+                                     gridDim.x, gridDim.y, x2, K1, xscale, xshift);
 }
 // multi-layer form (see k_conv3x3_wgrad_multi): the 16x16-tile layers with few tiles (H = 16 at batch 64)
 template <int TCI, int TCO>
@@ -937,7 +974,8 @@ int phx_wgrad_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, vo
     return PHX_OK;
 }
 static int wgrad_impl(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes, int B, int H,
-                      int W, int Cin, int Cout, bool reduce, void* stream, const void* x2 = nullptr, int K1 = 0);
+                      int W, int Cin, int Cout, bool reduce, void* stream, const void* x2 = nullptr, int K1 = 0,
+                      const float* xscale = nullptr, const float* xshift = nullptr);
 /* Deferred small-map filter gradients (see k_conv3x3_wgrad_multi).  phx_conv3x3_wgrad_multi_job fills ONE job record of
  * phx_conv3x3_wgrad_multi_job_bytes() bytes in HOST memory for the launch phx_conv3x3_wgrad_mfma_bf16_partial would make;
  * info = {variant (0: not deferred), blocks, dynamic LDS bytes, uses_workspace, nslice, tci, tco, reduce grid x, y} (9 ints).  The caller concatenates the records of one variant (blk0 = running sum of blocks), copies them to the
@@ -1037,13 +1075,30 @@ int phx_conv3x3_wgrad_mfma_bf16_partial(const void* x, const void* dy, float* dw
                                         int B, int H, int W, int Cin, int Cout, void* stream) {
     return wgrad_impl(x, dy, dw_hwio, workspace, workspace_bytes, B, H, W, Cin, Cout, false, stream);
 }
+// Filter gradient of a convolution that read the PRE-normalisation tensor of the layer in front (phx_conv3x3_mfma_bf16_xf): x is that
+// tensor, xscale / xshift [Cin] the producer's coefficients; the LDS-DMA kernel with 32-channel input blocks re-forms
+// a = relu(x * xscale + xshift) in place in its staged patch.  Stand-alone launch, partial filters into the workspace, no reduction
+// (as phx_conv3x3_wgrad_mfma_bf16_partial).
+int phx_conv3x3_wgrad_xf_supported(int B, int H, int W, int Cin, int Cout) {
+    if (Cin != 32 || Cout % 32 != 0 || !wgrad_dma_enabled()) return 0;
+    MTile g; int tci, tco, gx, tpb, wk;
+    const int ntiles = wgrad_plan(B, H, W, Cin, Cout, &g, &tci, &tco, &gx, &tpb, &wk, 0, 0);
+    return (tci == 32 && g.tws == 4 && g.ths == 4 && g.tb == 1 && ntiles > 1024) ? 1 : 0;      // (> 1024 tiles: never a deferred multi-layer job)
+}
+int phx_conv3x3_wgrad_mfma_bf16_partial_xf(const void* x, const float* xscale, const float* xshift, const void* dy, float* dw_hwio,
+                                           void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, void* stream) {
+    PHX_REQUIRE(xscale != nullptr && xshift != nullptr && workspace != nullptr && phx_conv3x3_wgrad_xf_supported(B, H, W, Cin, Cout), PHX_E_SHAPE,
+                "conv3x3_wgrad_partial_xf: xscale / xshift / workspace, shape see phx_conv3x3_wgrad_xf_supported");
+    return wgrad_impl(x, dy, dw_hwio, workspace, workspace_bytes, B, H, W, Cin, Cout, false, stream, nullptr, 0, xscale, xshift);
+}
 int phx_conv3x3_wgrad_mfma_bf16_dual(const void* x, const void* x2, int K1, const void* dy, float* dw_hwio, void* workspace,
                                      size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int reduce, void* stream) {
     PHX_REQUIRE(x2 != nullptr && K1 > 0 && K1 < Cin && K1 % 32 == 0, PHX_E_SHAPE, "conv3x3_wgrad_mfma_dual: x2, 0 < K1 < Cin, K1 % 32 == 0");
     return wgrad_impl(x, dy, dw_hwio, workspace, workspace_bytes, B, H, W, Cin, Cout, reduce != 0, stream, x2, K1);
 }
 static int wgrad_impl(const void* x, const void* dy, float* dw_hwio, void* workspace, size_t workspace_bytes, int B, int H,
-                      int W, int Cin, int Cout, bool reduce, void* stream, const void* x2, int K1) {
+                      int W, int Cin, int Cout, bool reduce, void* stream, const void* x2, int K1, const float* xscale,
+                      const float* xshift) {
     PHX_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, PHX_E_SHAPE, "conv3x3_wgrad_mfma: Cin % 32 == 0 and Cout % 32 == 0 required");
     if (x2 == nullptr) K1 = 0;
     MTile g; int tci, tco, gx, tpb, wk;
@@ -1082,7 +1137,8 @@ static int wgrad_impl(const void* x, const void* dy, float* dw_hwio, void* works
     hipLaunchKernelGGL((k_conv3x3_wgrad_dma<A, Bq>), dim3(gx, Cin / A, Cout / Bq), dim3(256),                         \
                        wgrad_dma_lds(A, Bq), (hipStream_t)stream,                                                     \
                        (const unsigned short*)x, (const unsigned short*)dy, ws, B, H, W, Cin, Cout, g, ntiles, tpb,    \
-                       (const unsigned short*)x2, K1)
+                       (const unsigned short*)x2, K1, xscale, xshift)
+        PHX_REQUIRE(xscale == nullptr || tci == 32, PHX_E_SHAPE, "conv3x3_wgrad_xf: 32-channel input blocks only");
         if (tci == 64 && tco == 64)
             hipLaunchKernelGGL(k_conv3x3_wgrad_pp, dim3(gx, Cin / 64, Cout / 64), dim3(512), wgrad_dma_lds(64, 64), (hipStream_t)stream,
                                (const unsigned short*)x, (const unsigned short*)dy, ws, B, H, W, Cin, Cout, g, ntiles, tpb,
@@ -1093,6 +1149,7 @@ static int wgrad_impl(const void* x, const void* dy, float* dw_hwio, void* works
 #undef WD_LAUNCH
         PHX_CHECK_LAUNCH();
     } else {
+    PHX_REQUIRE(xscale == nullptr, PHX_E_SHAPE, "conv3x3_wgrad_xf: the LDS-DMA kernel's shapes only (16 x 16 tiles, workspace)");
     const size_t sh = (size_t)npatch * tci * 2 + (size_t)256 * tco * 2;
 #define WG_LAUNCH(A, Bq, C, F)                                                                                            \
     hipLaunchKernelGGL((k_conv3x3_wgrad<A, Bq, C, F>), dim3(gx, Cin / A, Cout / Bq), dim3(256), sh, (hipStream_t)stream,  \

@@ -405,14 +405,16 @@ class BackwardLowering:
             ce = sv["cin_eff"] if padded else cin
             tgt = self._alloc_zeroed(9 * ce * cout).ptr if padded else dw
             dual = x if isinstance(x, DualBuf) else None       # concat-free input: the filter gradient reads the two tensors in place
+            xf = x if isinstance(x, XfBuf) else None           # unmaterialised input activation: re-formed from y by the kernel's loader
             k1d = dual.k1 if dual is not None else 0
             wsb = int(Lb.conv3x3_wgrad_ws_bytes_dual(B, H, Wd, ce, cout, k1d))
             wsp = self._alloc((wsb // 4,), F32)      # per-layer workspace of partial filters (no cross-lane sharing)
             plan6 = (ctypes.c_int * 6)()
             Lb.conv3x3_wgrad_reduce_plan_dual(B, H, Wd, ce, cout, k1d, plan6)
             rjob = (wsp.ptr, tgt, plan6[1], ce, cout, plan6[2], plan6[3], plan6[4], plan6[5])
-            wargs = (x.ptr, dY.ptr, tgt, wsp.ptr, wsb, B, H, Wd, ce, cout)
-            dargs = (x.ptr, dual.b.ptr if dual is not None else None, k1d) + wargs[1:]      # (x, x2, K1, dy, ...)
+            if xf is None:
+                wargs = (x.ptr, dY.ptr, tgt, wsp.ptr, wsb, B, H, Wd, ce, cout)
+                dargs = (x.ptr, dual.b.ptr if dual is not None else None, k1d) + wargs[1:]      # (x, x2, K1, dy, ...)
             wflops = 18.0 * cin * cout * B * H * Wd
             deferred = False
             # The filter gradients are leaves of the backward graph.  Small and mid-size maps: the launch itself is
@@ -420,7 +422,8 @@ class BackwardLowering:
             # (phx_conv3x3_wgrad_multi); their latency leaves the posterior / prior / likelihood chains.
             nb = int(Lb.conv3x3_wgrad_multi_job_bytes())
             jb, info = ctypes.create_string_buffer(nb), (ctypes.c_int * 9)()
-            Lb.conv3x3_wgrad_multi_job_dual(*dargs, _WGRAD_DEFER_BLOCKS, 0, jb, info)
+            if xf is None:       # (an unmaterialised input only exists on maps too large for the deferred launches: _xf_edge_ok)
+                Lb.conv3x3_wgrad_multi_job_dual(*dargs, _WGRAD_DEFER_BLOCKS, 0, jb, info)
             if info[0]:
                 grp = self._wgm_jobs.setdefault(int(info[0]), dict(recs=[], blocks=0, lds=0))
                 Lb.conv3x3_wgrad_multi_job_dual(*dargs, _WGRAD_DEFER_BLOCKS, grp["blocks"], jb, info)
@@ -435,12 +438,17 @@ class BackwardLowering:
             elif plan6[0]:
                 # large maps: the launch stays here, only the sum over its partial filters is deferred to ONE launch for all
                 # layers (phx_wgrad_reduce_multi)
-                if dual is not None:
+                if xf is not None:
+                    self._emit(Lb.conv3x3_wgrad_mfma_bf16_partial_xf, xf.y.ptr, xf.scale.ptr, xf.shift.ptr, dY.ptr, tgt, wsp.ptr, wsb,
+                               B, H, Wd, ce, cout, S, tag="conv3x3_mfma_wgrad", flops=wflops)
+                elif dual is not None:
                     self._emit(Lb.conv3x3_wgrad_mfma_bf16_dual, *dargs, 0, S, tag="conv3x3_mfma_wgrad", flops=wflops)
                 else:
                     self._emit(Lb.conv3x3_wgrad_mfma_bf16_partial, *wargs, S, tag="conv3x3_mfma_wgrad", flops=wflops)
                 self._wgr_jobs.append(rjob)
                 deferred = True
+            elif xf is not None:
+                raise rt.PhxError("filter gradient of an unmaterialised input activation without a workspace plan (see _xf_edge_ok)")
             elif dual is not None:
                 self._emit(Lb.conv3x3_wgrad_mfma_bf16_dual, *dargs, 1, S, tag="conv3x3_mfma_wgrad", flops=wflops)
             else:

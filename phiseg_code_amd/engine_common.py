@@ -10,7 +10,7 @@ from phiseg_code_amd import graph as G
 from phiseg_code_amd import runtime as rt
 from phiseg_code_amd.tfwrapper import normalisation as tfnorm
 
-__all__ = ['F32', 'BF16', 'U8', '_TORCH_DT', '_NP_DT', '_ESIZE', '_LIK_SIDE_MAXLVL', '_WGRAD_DEFER_BLOCKS', '_NREP', '_NREP_MINP', '_STAMPS', '_DETERMINISTIC', '_BN_SMALL', '_BN_SMALL_F32', '_BN_WIDE', '_BN_WIDE_MAXLINES', '_SKIP_HEAD_A', '_fgn_mode', '_dual_enabled', '_noop', '_device', 'live_variables', 'device_sync', 'Buf', 'DualBuf', 'HeadGrad', 'SliceGrad']
+__all__ = ['F32', 'BF16', 'U8', '_TORCH_DT', '_NP_DT', '_ESIZE', '_LIK_SIDE_MAXLVL', '_WGRAD_DEFER_BLOCKS', '_NREP', '_NREP_MINP', '_STAMPS', '_DETERMINISTIC', '_BN_SMALL', '_BN_SMALL_F32', '_BN_WIDE', '_BN_WIDE_MAXLINES', '_SKIP_HEAD_A', '_xf_enabled', '_fgn_mode', '_dual_enabled', '_noop', '_device', 'live_variables', 'device_sync', 'Buf', 'DualBuf', 'HeadGrad', 'SliceGrad', 'XfBuf']
 
 F32, BF16, U8 = rt.F32, rt.BF16, 2
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, U8: torch.uint8}
@@ -37,6 +37,14 @@ def _fgn_mode():
     # groups); 2: instance norm too (per-channel statistics: every lane adds to the LDS table -- measured 11.24 vs 11.15 ms, so not
     # by default); 0: off.  Group norm, phiseg_7_5 B = 64: 11.28 vs 11.28 - 11.30 ms with 57 launches fewer.
     return int(os.environ.get("PHX_FGN", "1"))
+
+
+def _xf_enabled():
+    # conv2d -> batch_norm -> relu -> conv2d edges of the 32-channel 128 x 128 level: the apply pass and the activation tensor are
+    # never made, the readers (k_conv3x3_c32, k_conv3x3_wgrad_dma<32, *>) re-form the activation in their staged patches
+    # (phx_conv3x3_mfma_bf16_xf, phx_conv3x3_wgrad_mfma_bf16_partial_xf).
+    # A/B hook like PHX_DUAL (read when a plan is built; tests/test_plan_variants_gpu.py compares the plan with and without).
+    return os.environ.get("PHX_XF", "1") == "1"
 
 
 def _dual_enabled():
@@ -136,3 +144,13 @@ class SliceGrad:
     def __init__(self, like, ws, nz):
         self.shape, self.dt, self.n = like.shape, like.dt, like.n
         self.ws, self.nz = ws, nz
+
+
+class XfBuf:
+    """The value of a = relu(bn(y)) whose only readers are 3x3 convolutions on large maps: never materialised -- the readers'
+    forward (phx_conv3x3_mfma_bf16_xf) and filter-gradient (phx_conv3x3_wgrad_*_xf) launches re-form it from the pre-normalisation
+    tensor y and the layer's scale / shift in their loaders.  `ptr` is deliberately absent: nothing may read it as a tensor."""
+
+    def __init__(self, like, y, scale, shift):
+        self.shape, self.dt, self.n = like.shape, like.dt, like.n
+        self.y, self.scale, self.shift = y, scale, shift

@@ -243,6 +243,30 @@ class ForwardLowering:
             return None
         return c
 
+    def _xf_edge_ok(self, op, B, H, Wd, C):
+        """May conv unit `op` leave its activation a = relu(bn(y)) unwritten?  -- every real reader is a 3x3 conv unit with batch norm
+        (no bias, statistics epilogue) that reads it directly (not through a concat), trains, and whose forward and filter-gradient
+        kernels take the input transform at this shape (phx_conv3x3_xf_supported / phx_conv3x3_wgrad_xf_supported: the HBM-bound 32 -> 32
+        layers of the 128 x 128 level -- on the matrix-bound shapes the transform costs more than the apply pass it deletes,
+        DESIGN.md section 5); nobody fetches it."""
+        out = op.outputs[0]
+        if out in self.fetches:
+            return False
+        cons = self._real_consumers(out, self._opset)
+        if not cons:
+            return False
+        for c in cons:
+            ca = c.attrs
+            if (c.type != "conv_unit" or c in self._lat or ca.get("transposed") is not None or ca.get("general") is not None
+                    or ca["ksize"] != 3 or ca["norm"] != "batch" or ca["b"] is not None or c.inputs[0] is not out):
+                return False
+            tr = ca["training"] if isinstance(ca["training"], bool) else self.training
+            cin, cout = ca["W"].shape[-2], ca["W"].shape[-1]
+            if (not tr or cin != C or not self.L.conv3x3_xf_supported(B, H, Wd, cin, cout)
+                    or not self.L.conv3x3_wgrad_xf_supported(B, H, Wd, cin, cout)):
+                return False
+        return True
+
     def _fw_conv_unit(self, op, bw):
         a = op.attrs
         if a.get("transposed") is not None or a.get("general") is not None:
@@ -273,9 +297,17 @@ class ForwardLowering:
         S, Lb = self.stream, self.L
         dual = x if isinstance(x, DualBuf) else None
         assert dual is None or mfma, "concat-free input reached a convolution off the MFMA path"
+        xf = x if isinstance(x, XfBuf) else None      # the producer's activation was never written: this launch re-forms it (see _xf_edge_ok)
+        assert xf is None or (mfma and a["norm"] == "batch" and b is None), "unmaterialised activation reached a convolution that cannot re-form it"
 
         def mfma_conv(y, bias_p, oscale_p, act_code, stats, stats_mode, ws, wsb):
             """One forward launch on the bf16 MFMA path (plain or concat-free input): phx_conv3x3_mfma_bf16_dual takes every option"""
+            if xf is not None:
+                assert bias_p is None and oscale_p is None and act_code == 0 and stats_mode in (0, 1) and ws is None
+                self._emit(Lb.conv3x3_mfma_bf16_xf, xf.y.ptr, xf.scale.ptr, xf.shift.ptr, wf.ptr, y.ptr,
+                           stats.ptr if stats is not None else None, B, H, Wd, cin_eff, cout, S,
+                           tag="conv3x3_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
+                return
             self._emit(Lb.conv3x3_mfma_bf16_dual, x.ptr, dual.b.ptr if dual is not None else None, dual.k1 if dual is not None else 0,
                        wf.ptr, y.ptr if y is not None else None, None, 0, bias_p, oscale_p, act_code,
                        stats.ptr if stats is not None else None, stats_mode, ws.ptr if ws is not None else None, wsb,
@@ -428,11 +460,13 @@ class ForwardLowering:
             # shifted (pivot) sums in a stand-alone pass: always on the fp32 parity path, and on the bf16 path when
             # a statistic has few samples (cheap there); otherwise the sums come from the conv epilogue.
             small = P <= 16384 or self.act_dt == F32
+            xf_producer_ok = False
             if norm == "batch" and mfma and not small:
                 ntile = tiles_fn()
                 part = self._alloc((ntile * 2 * cout,), F32)
                 conv_into(y, 0, stats_part=part)
                 self._emit(Lb.norm_reduce_partials, part.ptr, ntile, cout, sums.ptr, S)
+                xf_producer_ok = bool(training and act == rt.ACT_RELU and y.dt == BF16 and out.dt == BF16 and not head1x1 and _xf_enabled())
             elif (norm == "batch" and mfma and small and not _DETERMINISTIC and not head1x1 and self.act_dt == BF16
                   and Lb.conv3x3_mfma_stats_atomic_supported(B, H, Wd, cin_eff, cout)):
                 # few pixel tiles (the H <= 16 levels): the convolution adds its statistics straight into `sums` -- no pass over y
@@ -455,6 +489,15 @@ class ForwardLowering:
             mmp = self.store.ptr(nv["moving_mean"]) if upd else None
             mvp = self.store.ptr(nv["moving_variance"]) if upd else None
             mom = (1.0 - tfnorm.BN_DECAY) if upd else 0.0
+            if (bw and xf_producer_ok and pivot is None and self._xf_edge_ok(op, B, H, Wd, cout)):
+                # every reader of a = relu(bn(y)) is a large-map 3x3 convolution (and its filter gradient): no apply pass, no tensor a --
+                # the statistics are finalised by a one-block launch and the readers transform y in their loaders (XfBuf)
+                self._emit(Lb.norm_finalize, sums.ptr, None, gptr, beptr, eps, NS, P, cout, Gn, mean.ptr, rstd.ptr, scale.ptr, shift.ptr,
+                           mmp, mvp, mom, S)
+                self.val[op.outputs[0]] = XfBuf(out, y, scale, shift)
+                st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn, out=None)
+                self.saved[op] = st
+                return
             apply_args = (y.ptr, y.dt, sums.ptr, pivot.ptr if pivot is not None else None, gptr, beptr, eps, out.ptr, out.dt,
                           mean.ptr, rstd.ptr, scale.ptr, shift.ptr, mmp, mvp, mom, NS, P, cout, Gn, act)
             hop = self._norm_head_consumer(op) if (y.dt == BF16 and out.dt == BF16) else None

@@ -12,11 +12,14 @@ sys.path.insert(0, ROOT)
 
 def main():
     case, dtype, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    batch = int(sys.argv[4]) if len(sys.argv) > 4 else 0          # 0: the fixture's own batch
     from oracle import train as otrain
     from phiseg_code_amd.phiseg import phiseg_model
     from tests.helpers import golden_inputs, load_golden
     from tests.test_graph_cpu import make_config
     g, cfg, var_order = load_golden(case)
+    if batch:
+        cfg = dict(cfg, B=batch)
     model = phiseg_model.phiseg(make_config(cfg, dtype), rng_seed=cfg["eps_seed"])
     params, x, s = golden_inputs(cfg, var_order, dtype=torch.float64)
     model.set_weights({k: v.detach().numpy() for k, v in params.items()})

@@ -367,6 +367,50 @@ def _mfma_case(L, case):
     close(host(dw2), wr.grad.numpy(), 1e-4, "mfma wgrad (workspace)")
 
 
+@pytest.mark.parametrize("case", [(3, 16, 32), (2, 48, 64), (5, 32, 32), (1, 16, 96), (17, 128, 128)])
+def test_conv3x3_32_channel_layers_on_the_pre_normalisation_tensor(Ld, case, policy):
+    """phx_conv3x3_mfma_bf16_xf / phx_conv3x3_wgrad_mfma_bf16_partial_xf (round 5): conv2d -> batch_norm -> relu -> conv2d
+    (tfwrapper/layers.py:123-135) on the 32-channel large-map layers WITHOUT the activation tensor -- k_conv3x3_c32 and the LDS-DMA filter
+    gradient re-form a = relu(x * scale + shift) in place in their staged patches (image edges on every side: the zero padding is of a,
+    not of x; odd tile counts).  Bit-identical to the same launches on the bf16 activation phx_affine_act materialises, and against the
+    oracle's conv2d of relu(x * scale + shift) on the small cases."""
+    L = Ld
+    B, H, W = case
+    K = N = 32
+    policy(large_maps=2)
+    assert L.conv3x3_xf_supported(B, H, W, K, N) == 1 and L.conv3x3_xf_supported(B, H, W, 64, 64) == 0
+    x = RNG.standard_normal((B, H, W, K)).astype(np.float32)
+    w = RNG.standard_normal((3, 3, K, N)) / np.sqrt(9 * K)
+    sc, sh = 1.0 + 0.3 * RNG.standard_normal(K), 0.2 * RNG.standard_normal(K)
+    xd, wd, scd, shd = dev(x, BF16), dev(w), dev(sc), dev(sh)
+    P = B * H * W
+    a = torch.empty_like(xd)
+    L.affine_act(xd.data_ptr(), BF16, scd.data_ptr(), shd.data_ptr(), a.data_ptr(), BF16, 1, P, K, 1, S())
+    wf = torch.empty(9 * N * K, dtype=torch.bfloat16).cuda()
+    L.pack_conv3x3_bf16(wd.data_ptr(), wf.data_ptr(), None, K, N, S())
+    nt = L.conv3x3_mfma_bf16_tiles(B, H, W, K, N)
+    y1, y2 = (torch.empty(B, H, W, N, dtype=torch.bfloat16).cuda() for _ in range(2))
+    p1, p2 = (torch.zeros(nt, 2, N, dtype=torch.float32).cuda() for _ in range(2))
+    L.conv3x3_mfma_bf16(a.data_ptr(), wf.data_ptr(), y1.data_ptr(), None, 0, p1.data_ptr(), B, H, W, K, N, S())
+    L.conv3x3_mfma_bf16_xf(xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), wf.data_ptr(), y2.data_ptr(), p2.data_ptr(), B, H, W, K, N, S())
+    assert torch.equal(y1, y2) and torch.equal(p1, p2)
+    if P <= 65536:
+        ar = torch.relu(rounded(x, BF16) * torch.as_tensor(sc, dtype=torch.float32).double() + torch.as_tensor(sh, dtype=torch.float32).double())
+        ref = T.conv2d_same(rounded(ar.float().numpy(), BF16), rounded(w, BF16))
+        close(host(y2), ref.numpy(), 8e-3, "conv on the transformed input")
+    if not L.conv3x3_wgrad_xf_supported(B, H, W, K, N):
+        assert B < 17
+        return
+    dy = dev(RNG.standard_normal((B, H, W, N)).astype(np.float32), BF16)
+    wsb = int(L.conv3x3_wgrad_ws_bytes(B, H, W, K, N))
+    ws1, ws2 = (torch.zeros(wsb // 4, dtype=torch.float32).cuda() for _ in range(2))
+    dw = torch.zeros(3, 3, K, N, dtype=torch.float32).cuda()
+    L.conv3x3_wgrad_mfma_bf16_partial(a.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws1.data_ptr(), wsb, B, H, W, K, N, S())
+    L.conv3x3_wgrad_mfma_bf16_partial_xf(xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws2.data_ptr(), wsb, B, H, W, K, N, S())
+    torch.cuda.synchronize()
+    assert torch.equal(ws1, ws2) and float(ws1.abs().max()) > 0
+
+
 # the anti-phase filter-gradient kernel (k_conv3x3_wgrad_pp: 64 x 64 channel blocks on 16 x 16 pixel tiles): one tile (half B idle), odd
 # and even tile counts per block, maps that are not multiples of the tile, several channel blocks, the two-tensor (concat-free) input
 @pytest.mark.parametrize("case", [(5, 16, 16, 64, 64, 0), (3, 16, 32, 64, 64, 0), (6, 16, 16, 64, 128, 0), (2, 40, 24, 128, 64, 0),

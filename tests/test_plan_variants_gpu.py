@@ -48,3 +48,45 @@ def test_training_plan_concat_free_and_one_launch_layers_equal_the_plain_plan(sw
     for name in p0:
         if "moving_" in name:
             np.testing.assert_allclose(p1[name], p0[name], rtol=1e-2, atol=3e-3)
+
+
+def test_training_plan_without_materialised_activations_at_batch_24(monkeypatch):
+    """The XF rewrite (engine XfBuf: conv -> batch norm -> ReLU -> conv edges on large maps without the apply pass / activation tensor)
+    in the DEFAULT mode at batch 24, where the four 32-channel edges of encoder level 0 (posteriors.py:84-90, priors.py:80-86: z0_pre_1 ->
+    z0_pre_2 -> z0_pre_3 at 128 x 128) qualify: the plan has fewer launches, uses the transforming kernels, and agrees with the plain plan (PHX_XF=0) to the run-to-run
+    noise of the atomics' summation order (the bit-identity proof is tests/test_deterministic_gpu.py at batch 64)."""
+    import torch
+    from oracle import init as oinit
+    from oracle import train as otrain
+    from phiseg_code_amd.phiseg import phiseg_model
+    from tests.helpers import load_golden
+    from tests.test_graph_cpu import make_config
+    g, cfg, var_order = load_golden("lidc_phiseg_bn")
+    cfg = dict(cfg, B=24)
+    params = otrain.make_params(var_order, cfg["weight_seed"], torch.float32, perturbed=True)
+    x_np, s_np = oinit.synthetic_batch(cfg["B"], cfg["H"], cfg["nlabels"], cfg["data_seed"])
+    res = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("PHX_XF", v)
+        model = phiseg_model.phiseg(make_config(cfg, "bf16"), rng_seed=cfg["eps_seed"])
+        model.set_weights({k: t.detach().numpy() for k, t in params.items()})
+        plan = model.sess.plan_for([model.loss_tot], True, cfg["B"], True)
+        plan.set_input("x_input", x_np)
+        plan.set_input("s_input", s_np)
+        model.sess.store.set_lr(0.0)
+        plan.run()
+        plan.sync()
+        names = [getattr(fn, "__name__", "") for fn, _ in plan.launches]
+        res[v] = (float(plan.fetch(model.loss_tot)), model.sess.store.export(grads=True), len(plan.launches),
+                  sum(n == "phx_conv3x3_mfma_bf16_xf" for n in names), sum(n == "phx_conv3x3_wgrad_mfma_bf16_partial_xf" for n in names))
+        del plan, model
+    l0, g0, n0, f0, w0 = res["0"]
+    l1, g1, n1, f1, w1 = res["1"]
+    assert f0 == 0 and w0 == 0 and f1 == 4 and w1 == 4, (f0, w0, f1, w1)
+    assert abs(l1 - l0) <= 2e-2 * abs(l0), (l0, l1)
+    errs = []
+    for name, ga in g0.items():
+        nrm = np.linalg.norm(ga)
+        if nrm >= 1e-8 * max(1.0, np.sqrt(ga.size)):
+            errs.append(np.linalg.norm(g1[name] - ga) / nrm)
+    assert len(errs) >= 360 and np.mean(errs) <= 0.5, (len(errs), np.mean(errs))
