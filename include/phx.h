@@ -276,6 +276,13 @@ int phx_norm_apply_fused(const void* x, int x_dt, const float* sums, const float
                          const float* beta, float eps, void* y, int y_dt, float* mean, float* rstd, float* scale,
                          float* shift, float* moving_mean, float* moving_var, float momentum, int NS, int P, int C,
                          int G, int act, void* stream);
+/* ... and with the 2 x 2 average pool of its output fused in (round 5; averagepool2D of pre_z[i - 1], posteriors.py:80-82 / priors.py:76-78,
+ * tfwrapper/layers.py:44-54): a thread takes a 2 x 2 pixel quad, writes the four activations and their average (of the values as stored,
+ * in phx_avgpool2x2_fwd's order: bit-identical to the two launches).  bf16, C % 8 == 0, H and W even; P = pixels per statistic. */
+int phx_norm_apply_pool_supported(int H, int W, int C);
+int phx_norm_apply_pool(const void* x, const float* sums, const float* pivot, const float* gamma, const float* beta, float eps, void* y,
+                        void* y_pool, float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,
+                        float momentum, int NS, int P, int C, int G, int H, int W, int act, void* stream);
 /* ... and with a 1x1 HEAD fused in (the likelihood's top layer feeding y_lvl0, likelihoods.py:220: the head is the only reader of
  * a = act(norm(x))): y receives a as usual and y_head[NS * P][nout] = b_head + a w_head (w_head the HWIO 1x1 filter [C][nout]), computed
  * from the values just produced instead of by a pass of its own over a.  bf16 in / out, C / 8 a power of two <= 64, nout in {2, 4}

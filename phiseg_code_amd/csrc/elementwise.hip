@@ -1175,6 +1175,95 @@ __global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __rest
     }
 }
 
+// The apply pass of a layer whose output also feeds a 2 x 2 average pool (round 5; posteriors.py:80-82, priors.py:76-78: averagepool2D
+// of pre_z[i - 1] in front of every encoder level): a thread takes a 2 x 2 pixel quad -- four loads, four stores of a = act(norm(x)) and
+// ONE store of their average -- so the pooled tensor costs no pass of its own over a (tfwrapper/layers.py:44-54, tf.nn.avg_pool 2x2
+// stride 2; H and W even).  The average is taken of the values AS STORED (bf16), in k_avgpool_fwd's order: bit-identical to the two
+// launches.  bf16 in / out, 16-byte channel vectors; statistics finalised once per block as in k_norm_apply_fused.
+__global__ void k_norm_apply_pool(const bf16_t* __restrict__ x, const float* __restrict__ sums, const float* __restrict__ pivot,
+                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps, bf16_t* __restrict__ y,
+                                  bf16_t* __restrict__ ypool, float* mean_out, float* rstd_out, float* scale_out, float* shift_out,
+                                  float* moving_mean, float* moving_var, float momentum, int P, int C, int G, int H, int W, int PL,
+                                  int chunk, int act) {
+    constexpr int V = 8;
+    const int CV = C / V, cg = C / G;
+    const int ns = blockIdx.y;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    extern __shared__ float lds_f[];
+    float* gst = lds_f;                          // [G][2]  mean, rstd
+    float* cof = lds_f + 2 * G;                  // [C][2]  scale, shift
+    const float invP = 1.f / (float)P;
+    const bool pub = blockIdx.x == 0;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        float mu, var;
+        if (cg == 1) {
+            const float2 sq = *reinterpret_cast<const float2*>(sums + ((size_t)ns * C + g) * 2);
+            float rs1;
+            chan_coeffs(sq.x, sq.y, pivot ? pivot[(size_t)ns * C + g] : 0.f, invP, eps, &mu, &var, &rs1);
+        } else {
+            group_stats(sums, pivot, ns, C, g, cg, invP, eps, &mu, &var);
+        }
+        const float rs = rsqrtf(var + eps);
+        gst[2 * g] = mu;
+        gst[2 * g + 1] = rs;
+        if (pub) {
+            mean_out[ns * G + g] = mu;
+            rstd_out[ns * G + g] = rs;
+            if (momentum > 0.f && moving_mean) moving_update(&moving_mean[g], &moving_var[g], mu, var, (float)P * (float)cg, momentum);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cg;
+        float scv, shv;
+        chan_scale_shift(gamma[c], beta[c], gst[2 * g], gst[2 * g + 1], &scv, &shv);
+        cof[2 * c] = scv;
+        cof[2 * c + 1] = shv;
+        if (pub) {
+            scale_out[(size_t)ns * C + c] = scv;
+            shift_out[(size_t)ns * C + c] = shv;
+        }
+    }
+    __syncthreads();
+    if (pl >= PL) return;
+    float sc[V], sh[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        sc[j] = cof[2 * (cv * V + j)];
+        sh[j] = cof[2 * (cv * V + j) + 1];
+    }
+    const int Hh = H >> 1, Wh = W >> 1, Q = P >> 2;               // quads of this sample group (P = images x H x W)
+    const int q0 = blockIdx.x * chunk, q1 = min(Q, q0 + chunk);
+    for (int q = q0 + pl; q < q1; q += PL) {
+        const int bl = q / (Hh * Wh), r = q - bl * (Hh * Wh);
+        const int yq = r / Wh, xq = r - yq * Wh;
+        const size_t p00 = (size_t)ns * P + ((size_t)bl * H + 2 * yq) * W + 2 * xq;
+        const size_t off[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};      // k_avgpool_fwd's order: (0,0), (0,1), (1,0), (1,1)
+        float v[4][V];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) VecIO<bf16_t, V>::load(x, off[u] * C + (size_t)cv * V, v[u]);
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            unsigned w[4];
+#pragma unroll
+            for (int j = 0; j < V; j += 2) {
+                const float a0 = act_fwd(fmaf(v[u][j], sc[j], sh[j]), act), a1 = act_fwd(fmaf(v[u][j + 1], sc[j + 1], sh[j + 1]), act);
+                w[j >> 1] = f2bf_pk(a0, a1);
+                acc[j] += __uint_as_float(w[j >> 1] << 16);                      // the values as stored
+                acc[j + 1] += __uint_as_float(w[j >> 1] & 0xffff0000u);
+            }
+            *reinterpret_cast<uint4*>(y + off[u] * C + (size_t)cv * V) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] *= 0.25f;
+        const size_t po = (size_t)ns * Q + q;
+        VecIO<bf16_t, V>::store(ypool, po * C + (size_t)cv * V, acc);
+    }
+}
+
 // HN > 0 (backward of the layer whose only reader is a 1x1 head, see HeadFw): the upstream gradient dA = dyh wh^T is a rank-HN
 // function of the head's tiny gradient -- it is formed here per element (rounded to the storage type, as the head's data-gradient
 // launch would have stored it) instead of being written by that launch and read back by the two backward passes.
@@ -1912,6 +2001,23 @@ static int norm_apply_impl(const void* x, int x_dt, const float* sums, int nrep,
                            (const TI*)x, sums, pivot, gamma, beta, eps, (TO*)y, mean, rstd, scale, shift, moving_mean,
                            moving_var, momentum, P, C, G, PL, chunk, act, nrep, hd);
     })));
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+/* the apply pass + the 2 x 2 average pool of its output in one launch (bf16, C % 8 == 0, H and W even; P = images per statistic x H x W) */
+int phx_norm_apply_pool_supported(int H, int W, int C) { return (H % 2 == 0 && W % 2 == 0 && C % 8 == 0 && C / 8 <= 256) ? 1 : 0; }
+int phx_norm_apply_pool(const void* x, const float* sums, const float* pivot, const float* gamma, const float* beta, float eps, void* y,
+                        void* y_pool, float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,
+                        float momentum, int NS, int P, int C, int G, int H, int W, int act, void* stream) {
+    PHX_REQUIRE(phx_norm_apply_pool_supported(H, W, C) && G > 0 && C % G == 0 && P % (H * W) == 0, PHX_E_SHAPE,
+                "norm_apply_pool: H, W even, C % 8 == 0, C % G == 0, P a multiple of H * W");
+    PHX_REQUIRE(x && y && y_pool && sums, PHX_E_INVAL, "norm_apply_pool: null argument");
+    PHX_REQUIRE(momentum == 0.f || (NS == 1 && G == C), PHX_E_INVAL, "moving update only for batch norm");
+    int PL, threads, chunk, nchunks;
+    PHX_REQUIRE(stream_geometry(P / 4, C, 8, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_apply_pool: C too large");
+    hipLaunchKernelGGL(k_norm_apply_pool, dim3(nchunks, NS), dim3(threads), (size_t)2 * (C + G) * sizeof(float), (hipStream_t)stream,
+                       (const bf16_t*)x, sums, pivot, gamma, beta, eps, (bf16_t*)y, (bf16_t*)y_pool, mean, rstd, scale, shift, moving_mean,
+                       moving_var, momentum, P, C, G, H, W, PL, chunk, act);
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }

@@ -437,6 +437,7 @@ class Plan(ForwardLowering, BackwardLowering):
                 self._kl_group = dict(ops=kls, recs=[], gscale=ws[0])
         self._bw_skip = set()
         self._norm_head = {}          # 1x1 head op -> the conv unit whose apply pass computed it (phx_norm_apply_fused_head)
+        self._pool_done = set()       # avgpool ops whose output the producer's apply pass wrote (phx_norm_apply_pool)
         fork = self._record(0) if nl > 1 else None          # lanes 1.. join the capture / wait for the memsets
         for ln in range(1, nl):
             self._lane = ln

@@ -10,7 +10,7 @@ from phiseg_code_amd import graph as G
 from phiseg_code_amd import runtime as rt
 from phiseg_code_amd.tfwrapper import normalisation as tfnorm
 
-__all__ = ['F32', 'BF16', 'U8', '_TORCH_DT', '_NP_DT', '_ESIZE', '_LIK_SIDE_MAXLVL', '_WGRAD_DEFER_BLOCKS', '_NREP', '_NREP_MINP', '_STAMPS', '_DETERMINISTIC', '_BN_SMALL', '_BN_SMALL_F32', '_BN_WIDE', '_BN_WIDE_MAXLINES', '_SKIP_HEAD_A', '_xf_enabled', '_fgn_mode', '_dual_enabled', '_noop', '_device', 'live_variables', 'device_sync', 'Buf', 'DualBuf', 'HeadGrad', 'SliceGrad', 'XfBuf']
+__all__ = ['F32', 'BF16', 'U8', '_TORCH_DT', '_NP_DT', '_ESIZE', '_LIK_SIDE_MAXLVL', '_WGRAD_DEFER_BLOCKS', '_NREP', '_NREP_MINP', '_STAMPS', '_DETERMINISTIC', '_BN_SMALL', '_BN_SMALL_F32', '_BN_WIDE', '_BN_WIDE_MAXLINES', '_SKIP_HEAD_A', '_POOL_FUSE', '_xf_enabled', '_fgn_mode', '_dual_enabled', '_noop', '_device', 'live_variables', 'device_sync', 'Buf', 'DualBuf', 'HeadGrad', 'SliceGrad', 'XfBuf']
 
 F32, BF16, U8 = rt.F32, rt.BF16, 2
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, U8: torch.uint8}
@@ -29,6 +29,7 @@ _BN_SMALL = 1024              # one-launch batch norm up to this many pixels
 _BN_SMALL_F32 = True          # ... with an fp32 pre-normalisation tensor (section 4 of DESIGN.md, Round 5 additions)
 _BN_WIDE_MAXLINES = 2048      # ... up to this many (pixel, slice) rows per block: the 2 x 2 level (measured: 4096 = the 4 x 4 level too is 0.2 % slower, 0 = off 0.7 % slower)
 _SKIP_HEAD_A = True           # the activation whose only reader is a 1x1 head is never written in a training plan (time-neutral same box, - 0.4 GB/step)
+_POOL_FUSE = True             # averagepool2D of a conv unit's output is written by that unit's apply pass (phx_norm_apply_pool: 10 launches, 0.3 GB; + 0.1 % same box)
 _BN_WIDE = 2                  # phx_bn_wide_fwd / _bwd take the split-K slices of the forward convolution (1) and of the data gradient too (2)
 
 

@@ -517,7 +517,17 @@ class ForwardLowering:
                            tag="bytes_norm_apply", flops=float(y.nbytes + (0 if skip_a else out.nbytes)))
                 self._norm_head[hop] = op
             else:
-                self._emit(Lb.norm_apply_fused, *apply_args, S, tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
+                pop = self._pool_consumer(op, H, Wd, cout) if (y.dt == BF16 and out.dt == BF16) else None
+                if pop is not None:
+                    # one of the readers is averagepool2D (the next encoder level): the apply pass writes the pooled tensor too
+                    pooled = self._alloc(self._cshape(pop.outputs[0]), out.dt)
+                    self.val[pop.outputs[0]] = pooled
+                    self._pool_done.add(pop)
+                    self._emit(Lb.norm_apply_pool, y.ptr, sums.ptr, pivot.ptr if pivot is not None else None, gptr, beptr, eps, out.ptr,
+                               pooled.ptr, mean.ptr, rstd.ptr, scale.ptr, shift.ptr, mmp, mvp, mom, NS, P, cout, Gn, H, Wd, act, S,
+                               tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes + pooled.nbytes))
+                else:
+                    self._emit(Lb.norm_apply_fused, *apply_args, S, tag="bytes_norm_apply", flops=float(y.nbytes + out.nbytes))
         st.update(y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, NS=NS, P=P, G=Gn)
         if norm != "batch":
             st.update(fsums=sums, fpivot=pivot)          # forward per-channel sums: the bias gradient is closed-form from them
@@ -616,7 +626,19 @@ class ForwardLowering:
         x = self.val[op.inputs[0]]
         self.val[op.outputs[0]] = Buf(self._cshape(op.outputs[0]), x.dt, like=x.t)      # same memory, new shape
 
+    def _pool_consumer(self, op, H, Wd, C):
+        """The averagepool2D op that reads this conv unit's output directly, on the same lane, on an even map -- or None."""
+        if not _POOL_FUSE or not self.L.norm_apply_pool_supported(H, Wd, C):
+            return None
+        out = op.outputs[0]
+        for c in self._real_consumers(out, self._opset):
+            if c.type == "avgpool" and c.inputs[0] is out and self.op_lane.get(c) == self.op_lane.get(op) and c not in self._pool_done:
+                return c
+        return None
+
     def _fw_avgpool(self, op, bw):
+        if op in self._pool_done:                # the producer's apply pass wrote it (phx_norm_apply_pool)
+            return
         x = self.val[op.inputs[0]]
         out = self._alloc(self._cshape(op.outputs[0]), x.dt)
         self.val[op.outputs[0]] = out

@@ -909,6 +909,50 @@ def test_bn_wide_one_launch_layer_from_split_k_slices(L, case):
     assert torch.equal(dx_a, dx_b) and torch.equal(dg_a, dg_b) and torch.equal(db_a, db_b)
 
 
+@pytest.mark.parametrize("case", [("batch", 3, 16, 16, 32, 1), ("batch", 5, 8, 12, 192, 1), ("batch", 2, 64, 32, 64, 0), ("group", 3, 16, 8, 64, 1),
+                                  ("instance", 2, 6, 10, 48, 1), ("batch", 64, 4, 4, 192, 1), ("batch", 9, 128, 128, 32, 1)])
+def test_norm_apply_with_the_average_pool_fused_in(L, case):
+    """phx_norm_apply_pool (round 5): the apply pass of a layer whose output also feeds averagepool2D (tfwrapper/layers.py:44-54;
+    posteriors.py:80-82, priors.py:76-78) writes the 2 x 2 averages too -- bit-identical to phx_norm_apply_fused followed by
+    phx_avgpool2x2_fwd (same statistics finalisation, the average taken of the values as stored, in the pool kernel's order), batch /
+    group / instance norm, rectangular maps; and both against the oracle."""
+    kind, B, H, W, C, act = case
+    x = RNG.standard_normal((B, H, W, C)) * 1.5 + 0.3
+    gamma, beta = 1.0 + 0.2 * RNG.standard_normal(C), 0.1 * RNG.standard_normal(C)
+    xd, gd, bd = dev(x, BF16), dev(gamma), dev(beta)
+    NS, P, G = (1, B * H * W, C) if kind == "batch" else (B, H * W, C if kind == "instance" else max(2, C // 16))
+    eps = 1e-3 if kind == "batch" else 1e-5
+    sums = torch.zeros(NS, C, 2, dtype=torch.float32).cuda()
+    pivot = torch.zeros(NS, C, dtype=torch.float32).cuda()
+    L.norm_stats(xd.data_ptr(), BF16, sums.data_ptr(), pivot.data_ptr(), NS, P, C, S())
+    assert L.norm_apply_pool_supported(H, W, C) == 1 and L.norm_apply_pool_supported(H + 1, W, C) == 0
+
+    def bufs():
+        return [torch.empty(NS * G).cuda(), torch.empty(NS * G).cuda(), torch.empty(NS * C).cuda(), torch.empty(NS * C).cuda()]
+    a1, a2 = torch.empty_like(xd), torch.empty_like(xd)
+    p1, p2 = (torch.full((B, H // 2, W // 2, C), 9.0, dtype=torch.bfloat16).cuda() for _ in range(2))
+    st1, st2 = bufs(), bufs()
+    mm1, mv1 = dev(0.1 * RNG.standard_normal(C)), dev(1.0 + 0.3 * RNG.random(C))
+    mm2, mv2 = mm1.clone(), mv1.clone()
+    mom = 0.01 if kind == "batch" else 0.0
+    L.norm_apply_fused(xd.data_ptr(), BF16, sums.data_ptr(), pivot.data_ptr(), gd.data_ptr(), bd.data_ptr(), eps, a1.data_ptr(), BF16,
+                       *[t.data_ptr() for t in st1], mm1.data_ptr() if mom else None, mv1.data_ptr() if mom else None, mom, NS, P, C, G, act, S())
+    L.avgpool2x2_fwd(a1.data_ptr(), BF16, p1.data_ptr(), B, H, W, C, S())
+    L.norm_apply_pool(xd.data_ptr(), sums.data_ptr(), pivot.data_ptr(), gd.data_ptr(), bd.data_ptr(), eps, a2.data_ptr(), p2.data_ptr(),
+                      *[t.data_ptr() for t in st2], mm2.data_ptr() if mom else None, mv2.data_ptr() if mom else None, mom, NS, P, C, G, H, W, act, S())
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a2) and torch.equal(p1, p2)
+    for u, v in zip(st1 + [mm1, mv1], st2 + [mm2, mv2]):
+        assert torch.equal(u, v)
+    if B * H * W * C <= 1 << 21:
+        xr = rounded(x, BF16)
+        g64, b64 = torch.as_tensor(gamma, dtype=torch.float32).double(), torch.as_tensor(beta, dtype=torch.float32).double()
+        yr = T.batch_norm_train(xr, g64, b64)[0] if kind == "batch" else (T.group_norm(xr, g64, b64, G) if kind == "group" else T.instance_norm(xr, g64, b64))
+        ar = T.relu(yr) if act else yr
+        close(host(a2), ar.numpy(), 6e-3, "apply + pool: a")
+        close(host(p2), T.avg_pool_2x2_same(rounded(ar.float().numpy(), BF16)).numpy(), 6e-3, "apply + pool: pooled")
+
+
 @pytest.mark.parametrize("case", [("group", 3, 8, 8, 32, 2, 1), ("group", 2, 4, 4, 192, 12, 1), ("group", 64, 2, 2, 192, 12, 1),
                                   ("group", 5, 16, 16, 64, 4, 1), ("group", 70, 4, 4, 32, 2, 0), ("group", 3, 12, 12, 48, 3, 1),
                                   ("group", 131, 2, 2, 32, 2, 1), ("group", 9, 5, 6, 32, 2, 1), ("group", 2, 11, 13, 32, 2, 1),
