@@ -129,12 +129,12 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const unsigned short* __
     }
     const int odd = lane & 1;
 
-    int t = blockIdx.x;
-    if (t < ntiles) {
+    int slot = blockIdx.x, t = phx_band8(slot, ntiles);       // (slot -> tile: conv_common.h, XCD bands)
+    if (slot < ntiles) {
         patch_setup(t, 0);
         issue_range(issue_range, std::integral_constant<int, 0>(), std::integral_constant<int, C32_NPL>());
     }
-    for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
+    for (int it = 0; slot < ntiles; slot += gridDim.x, t = phx_band8(slot, ntiles), ++it) {
         const int cur = it & 1;
         const unsigned char* st = smem + cur * C32_STAGE;
         // this tile's patch (issued a whole tile ago) has landed -- vmcnt retires in order and only the previous tile's 8 (wave 0: 9)
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_c32(const unsigned short* __
         }
         // the next tile's patch: two DMA instructions behind the MFMAs of each of the first five groups (issued back to back they
         // take ~200 cycles apiece out of this wave's instruction stream; the matrix pipe drains its queue meanwhile)
-        const bool more = t + (int)gridDim.x < ntiles;
-        if (more) patch_setup(t + gridDim.x, cur ^ 1);
+        const bool more = slot + (int)gridDim.x < ntiles;
+        if (more) patch_setup(phx_band8(slot + (int)gridDim.x, ntiles), cur ^ 1);
         C32_TRACE(it * 8 + 2);
 
         f32x16 acc[4];

@@ -9,7 +9,7 @@
 #include "phx_common.h"
 #include <cstring>
 
-#ifndef PHX_ABLATE      // dev only (tools/build_ablate.sh): fwd 1 no global loads, 2 no LDS staging stores, 4 no MFMAs, 8 no output stores; wgrad 16 no global loads, 32 no MFMAs
+#ifndef PHX_ABLATE      // dev only (tools/build_variant.sh): fwd 1 no global loads, 2 no LDS staging stores, 4 no MFMAs, 8 no output stores; wgrad 16 no global loads, 32 no MFMAs
 #define PHX_ABLATE 0
 #endif
 #ifndef PHX_FRAG_DEPTH  // operand-fragment prefetch distance (in 4-MFMA groups) of the 256-pixel kernels

@@ -233,14 +233,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
 
     // Linear block id -> (pixel tile, channel block).  Work-groups go round-robin over the 8 XCDs (id % 8), each with its
     // own L2: the N / BN channel blocks of a tile get ids 8 apart -- same XCD, dispatched back to back -- so the input
-    // patch they all read comes from HBM once.  (Placement only affects speed, never results.)
+    // patch they all read comes from HBM once; the tiles of an XCD are a contiguous band of the launch (phx_band8), so the halos
+    // of neighbouring tiles meet in that L2 too.  (Placement only affects speed, never results.)
     int tile_id, cob;
     {
         const int ncob = N / BN, ntl = g.tiles_x * g.tiles_y * g.tiles_b;
         const int id = blockIdx.x, full = (ntl >> 3) * 8 * ncob;
         if (id < full) {
             const int grp = id / (8 * ncob), r = id - grp * 8 * ncob;
-            tile_id = grp * 8 + (r & 7);
+            tile_id = phx_band8(grp * 8 + (r & 7), ntl);           // (XCD bands: phx_common.h)
             cob = r >> 3;
         } else {
             const int rem = ntl & 7, r = id - full;

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3_pp(const unsigned short* __r
         int pr, cob;
         if (w < full) {
             const int grp = w / (8 * gm.ncob), r = w - grp * 8 * gm.ncob;
-            pr = grp * 8 + (r & 7);
+            pr = phx_band8(grp * 8 + (r & 7), gm.npairs);          // (XCD bands: phx_common.h -- neighbouring pairs share halos in one L2)
             cob = r >> 3;
         } else {
             const int rem = gm.npairs & 7, r = w - full;

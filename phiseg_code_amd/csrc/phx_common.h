@@ -33,6 +33,19 @@ __device__ __forceinline__ unsigned f2bf_pk(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, phx_bf16x2));
 }
 
+#ifndef PHX_TILE_BANDS  // XCD k (work-group id mod 8) takes the k-th contiguous eighth of a launch: bit 0 the convolutions' pixel tiles (phx_band8), bit 1 the resize kernels' blocks; 0: round-robin (dev A/B builds, tools/build_variant.sh)
+#define PHX_TILE_BANDS 3
+#endif
+// Slot s of a launch's tile sequence (slots go round-robin over the 8 XCDs: XCD = s mod 8, each with its own L2) -> pixel tile.
+// Neighbouring tiles share a one-pixel halo (an 18 x 18 patch for a 16 x 16 tile: 27 % more than the tile, 34 x 18 for 32 x 16:
+// 20 %); handed out round-robin, the four neighbours of a tile sit in four other L2s and every halo comes from HBM again (measured,
+// round 5: the convolution family fetches 1.25x its algorithmic bytes).  Banded, XCD k walks tiles k n/8 .. (k + 1) n/8 - 1 in
+// row-major order: the horizontal neighbour is the next slot of the same XCD, the vertical one tiles_x slots later -- in flight
+// in the same L2 at the same time.  The last n mod 8 tiles keep their slots.  Placement only: the tile -> value map is untouched.
+__device__ __forceinline__ int phx_band8(int s, int n) {
+    return ((PHX_TILE_BANDS & 1) && s < (n & ~7)) ? (s & 7) * (n >> 3) + (s >> 3) : s;
+}
+
 template <typename T> __device__ __forceinline__ float ldf(const T* p, size_t i);
 template <> __device__ __forceinline__ float ldf<float>(const float* p, size_t i) { return p[i]; }
 template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p, size_t i) { return bf2f(p[i].u); }

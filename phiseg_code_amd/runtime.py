@@ -11,7 +11,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "phx.h")
 DEBUG_HEADER = os.path.join(os.path.dirname(_HERE), "include", "phx_debug.h")
-LIB_PATH = os.environ.get("PHX_LIB") or os.path.join(_HERE, "libphx.so")   # PHX_LIB: dev builds (tools/build_ablate.sh)
+LIB_PATH = os.environ.get("PHX_LIB") or os.path.join(_HERE, "libphx.so")   # PHX_LIB: dev A/B builds (tools/build_variant.sh)
 
 F32, BF16 = 0, 1
 ACT_ID, ACT_RELU, ACT_SOFTPLUS = 0, 1, 2
