@@ -383,6 +383,7 @@ def test_bf16_gradients_n0_32_vs_simulated_bf16_oracle(norm):
     to leave almost untouched; the ratio of a single small variable has a tail, so up to two variables may reach 4x (see below),
     and the mean over all variables is the sharp assertion."""
     from oracle import nets
+    tight = os.environ.get("PHX_TEST_TIGHT_GRADIENT_BOUND") == "1" and os.environ.get("PHX_DETERMINISTIC") == "1"
     cfg, model, params, x_np, s_np = _lidc_setup("bf16", perturbed=True, norm=norm)
     xt, st = torch.as_tensor(x_np, dtype=torch.float32), torch.as_tensor(s_np)
 
@@ -425,9 +426,11 @@ def test_bf16_gradients_n0_32_vs_simulated_bf16_oracle(norm):
         # Group norm, same build run eight times (round 4): one run had ONE variable at 2.61x (posterior/z4_sigma/W, the 192 -> 2 head of
         # the 2 x 2 level, 0.143 against its usual 0.105 - 0.107; the atomics' summation order moves bf16 rounding flips upstream of it), the
         # other seven runs stayed below 2.0x everywhere.  So: at most two variables (of 474) may lie between 2.5x and 4x, none above 4x.
+        # Under PHX_DETERMINISTIC=1 (fixed summation order; test_bf16_gradients_group_norm_deterministic_mode_tight_bound below runs
+        # this test that way in a child process) there is no run-to-run tail to allow for: every variable inside 2.5x, none between.
         fac = 4.0 if norm is None else 2.5
         bound = (fac if ge.size >= 64 else fac + 1.0) * max(inh, 0.03)
-        hard = bound * (1.0 if norm is None else 1.6)
+        hard = bound * (1.0 if (norm is None or tight) else 1.6)
         assert e <= hard and e_s <= hard, (name, e, e_s, inh)
         if e > bound or e_s > bound:
             n_tail += 1
@@ -437,8 +440,22 @@ def test_bf16_gradients_n0_32_vs_simulated_bf16_oracle(norm):
     print("bf16 gradients: %d variables, mean rel. L2 error %.4f (simulated policy itself %.4f), worst %s" %
           (n_checked, tot_e / n_checked, tot_inh / n_checked, worst))
     assert n_checked >= 360                           # 368 live trainable tensors
-    assert n_tail <= 2, n_tail
+    assert n_tail <= (0 if tight else 2), n_tail
     assert tot_e <= 1.3 * tot_inh + 0.03 * n_checked  # on average the HIP path deviates no more than the simulated policy itself
+
+
+def test_bf16_gradients_group_norm_deterministic_mode_tight_bound():
+    """The group-norm instance of the test above in the deterministic mode (child process: the mode is read when the engine is
+    imported), where the fp32 atomics' summation order cannot move a bf16 rounding flip: the per-variable bound is the original 2.5x
+    for EVERY variable -- no 1.6x head-room, no two-variable tail (those are for the default mode's run-to-run draw)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, PHX_DETERMINISTIC="1", PHX_TEST_TIGHT_GRADIENT_BOUND="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.abspath(__file__) + "::test_bf16_gradients_n0_32_vs_simulated_bf16_oracle[group_norm]"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 NSTEP = 8          # (12 in round 2: the oracle trajectory is ~15 s per step on a busy test box -- the fixture was a third of the suite)
