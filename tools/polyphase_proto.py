@@ -97,7 +97,44 @@ def border_terms(x, W, A_h, At_h, A_w, At_w):
     return y
 
 
+def frame_form(x, W):
+    """The form a first implementation can take with NO new matrix kernel: the phase convolution gives every
+    hi-res pixel except the frame (rows / columns 0, 2n - 2, 2n - 1) exactly; the frame comes from the ordinary 3x3 convolution run on
+    two small gathered images -- per image six rows (one zero row, u[0], u[1], u[2n - 3], u[2n - 2], u[2n - 1]) stacked into ONE tall
+    image [1, 6 B, 2w, Ci] (the zero row is the padding between neighbours; outputs of rows 1, 4, 5 of each group of six are hi rows
+    0, 2n - 2, 2n - 1), and the same for the columns with the filter transposed.  Returns the assembled hi-res map."""
+    B, h, w, Ci = x.shape
+    Co = W.shape[3]
+    u = T.resize_bilinear_legacy(x, 2 * h, 2 * w)                     # (only its six frame rows / columns are gathered: 6 / 2n of it)
+    y = depth_to_space(T.conv2d_same(x, weff(W)), Co)
+    zr = torch.zeros(B, 1, 2 * w, Ci, dtype=D64)
+    rows = torch.cat([zr, u[:, 0:2], u[:, 2 * h - 3:2 * h]], dim=1).reshape(1, 6 * B, 2 * w, Ci)
+    fr = T.conv2d_same(rows, W).reshape(B, 6, 2 * w, Co)
+    ut = u.transpose(1, 2)                                             # columns as rows
+    zc = torch.zeros(B, 1, 2 * h, Ci, dtype=D64)
+    cols = torch.cat([zc, ut[:, 0:2], ut[:, 2 * w - 3:2 * w]], dim=1).reshape(1, 6 * B, 2 * h, Ci)
+    fc = T.conv2d_same(cols, W.transpose(0, 1)).reshape(B, 6, 2 * h, Co)
+    out = y.clone()
+    for src, dst in ((1, 0), (4, 2 * w - 2), (5, 2 * w - 1)):
+        out[:, :, dst] = fc[:, src]                                   # frame columns (all rows; the corners are overwritten next)
+    for src, dst in ((1, 0), (4, 2 * h - 2), (5, 2 * h - 1)):
+        out[:, dst] = fr[:, src]                                      # frame rows
+    return out, y
+
+
 def main():
+    for (B, h, w, Ci, Co) in [(2, 4, 6, 5, 3), (3, 8, 8, 4, 2)]:
+        x = torch.randn(B, h, w, Ci, dtype=D64, requires_grad=True)
+        W = torch.randn(3, 3, Ci, Co, dtype=D64, requires_grad=True)
+        ref = T.conv2d_same(T.resize_bilinear_legacy(x, 2 * h, 2 * w), W)
+        got, y_main = frame_form(x, W)
+        inner = (y_main - ref)[:, 1:2 * h - 2, 1:2 * w - 2].abs().max().item()
+        dy = torch.randn_like(ref)
+        gx_r, gw_r = torch.autograd.grad((ref * dy).sum(), (x, W), retain_graph=True)
+        gx_g, gw_g = torch.autograd.grad((got * dy).sum(), (x, W))
+        print("frame form (B, h, w, Ci, Co) = %-16s interior of the phase convolution %.2e   assembled map %.2e   d/dx %.2e   d/dW %.2e"
+              % ((B, h, w, Ci, Co), inner, (got - ref).abs().max().item(), (gx_g - gx_r).abs().max().item(), (gw_g - gw_r).abs().max().item()))
+        assert inner < 1e-12 and (got - ref).abs().max() < 1e-12 and (gx_g - gx_r).abs().max() < 1e-11 and (gw_g - gw_r).abs().max() < 1e-11
     for n in (2, 3, 5, 8):
         check_1d(n)
     print("1-D: phase tables and the three border coefficients (-1/2 w[-1] x[0] at 0, +1/2 w[+1] x[n-1] at 2n-2, +1/2 w[0] x[n-1] at 2n-1) exact")
