@@ -440,9 +440,10 @@ def test_conv3x3_wgrad_anti_phase_64x64(L, case):
 @pytest.mark.parametrize("case", [(64, 128, 128, 128, 128), (64, 64, 64, 192, 192), (64, 128, 128, 64, 128), (64, 128, 128, 192, 32),
                                   (64, 128, 128, 32, 32), (64, 32, 32, 128, 128), (64, 16, 16, 192, 192)])
 def test_conv3x3_forward_full_size_vs_direct_kernel_and_statistics(L, case):
-    """BASELINE-size forward launches (the default policy's kernels: pair kernel, k_conv3x3_c32, 256-pixel kernels), where the oracle
-    takes minutes: the bf16 output and the epilogue's per-channel statistics against the fp32 direct kernel (itself checked against
-    the oracle above) on the same bf16 input and bf16-rounded filter; the data gradient is the same launch with the flipped pack."""
+    """BASELINE-size forward launches (the default policy's kernels: pair kernel, k_conv3x3_c32, 256-pixel kernels): the bf16 output
+    and the epilogue's per-channel statistics against the fp32 direct kernel (itself checked against the oracle above) on the same bf16
+    input and bf16-rounded filter -- every image of the batch, on the device; the data gradient is the same launch with the flipped
+    pack.  (test_conv3x3_full_size_against_the_cpu_oracle below compares the same launches with the oracle directly.)"""
     B, H, W, K, N = case
     g = torch.Generator(device="cuda").manual_seed(11)
     x = torch.relu(torch.randn(B, H, W, K, device="cuda", generator=g)).to(torch.bfloat16)
@@ -473,6 +474,45 @@ def test_conv3x3_forward_full_size_vs_direct_kernel_and_statistics(L, case):
     L.conv2d_direct(dy.data_ptr(), BF16, w.data_ptr(), None, dref.data_ptr(), F32, B, H, W, K, N, 3, 0, 1, None, S())
     torch.cuda.synchronize()
     assert float((dx.float() - dref).abs().max()) <= 6e-3 * float(dref.abs().max())
+
+
+@pytest.mark.parametrize("case", [(64, 128, 128, 128, 128), (64, 64, 64, 192, 192), (64, 128, 128, 192, 32), (64, 128, 128, 32, 32)])
+def test_conv3x3_full_size_against_the_cpu_oracle(L, case):
+    """The same BASELINE-size launches against the ORACLE ITSELF (oracle/tf1_ops.py conv2d_same = tf.nn.conv2d 3x3 SAME,
+    tfwrapper/layers.py:123, in fp32 on the host; a few seconds per shape with the host's threads, so no device kernel stands between
+    the MFMA kernels and the oracle at the sizes the benchmark runs): forward and data gradient on the first and the last eight images
+    of the batch-64 launch (first / last pixel tiles and XCD bands), the filter gradient -- a sum over all 64 images -- on the whole
+    batch through the oracle's autograd.  Same bf16 inputs and bf16-rounded filter on both sides; tolerances: the bf16 rounding of the
+    stored outputs (2^-9 of a value <= `scale`), 1e-4 of the largest entry for the fp32 filter gradient."""
+    from oracle import tf1_ops as T
+    B, H, W, K, N = case
+    g = torch.Generator(device="cuda").manual_seed(23)
+    x = torch.relu(torch.randn(B, H, W, K, device="cuda", generator=g)).to(torch.bfloat16)
+    dy = (torch.randn(B, H, W, N, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    w = (torch.randn(3, 3, K, N, device="cuda", generator=g) / np.sqrt(9 * K)).to(torch.bfloat16).float().contiguous()
+    wf = torch.empty(9 * N * K, dtype=torch.bfloat16, device="cuda")
+    wg = torch.empty(9 * N * K, dtype=torch.bfloat16, device="cuda")
+    L.pack_conv3x3_bf16(w.data_ptr(), wf.data_ptr(), wg.data_ptr(), K, N, S())
+    y = torch.empty(B, H, W, N, dtype=torch.bfloat16, device="cuda")
+    dx = torch.empty(B, H, W, K, dtype=torch.bfloat16, device="cuda")
+    L.conv3x3_mfma_bf16(x.data_ptr(), wf.data_ptr(), y.data_ptr(), None, 0, None, B, H, W, K, N, S())
+    L.conv3x3_mfma_bf16(dy.data_ptr(), wg.data_ptr(), dx.data_ptr(), None, 0, None, B, H, W, N, K, S())
+    wsb = int(L.conv3x3_wgrad_ws_bytes(B, H, W, K, N))
+    ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device="cuda")
+    dw = torch.zeros(3, 3, K, N, dtype=torch.float32, device="cuda")
+    L.conv3x3_wgrad_mfma_bf16(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr() if wsb else None, wsb, B, H, W, K, N, S())
+    torch.cuda.synchronize()
+    xc, dyc, wc = x.float().cpu(), dy.float().cpu(), w.cpu()
+    for sl in (slice(0, 8), slice(B - 8, B)):
+        xs = xc[sl].clone().requires_grad_(True)
+        ref = T.conv2d_same(xs, wc)
+        ref.backward(dyc[sl])
+        close(y[sl].float().cpu().numpy(), ref.detach().numpy(), 6e-3, "forward, images %s" % (sl,))
+        close(dx[sl].float().cpu().numpy(), xs.grad.numpy(), 6e-3, "data gradient, images %s" % (sl,))
+    wr = wc.clone().requires_grad_(True)
+    for b0 in range(0, B, 16):                                 # (the oracle in four batches of 16: 0.5 GB of host memory at a time)
+        T.conv2d_same(xc[b0:b0 + 16], wr).backward(dyc[b0:b0 + 16])
+    close(host(dw), wr.grad.numpy(), 1e-4, "filter gradient")
 
 
 @pytest.mark.parametrize("case", [(64, 128, 128, 128, 128), (64, 64, 64, 192, 192), (64, 128, 128, 32, 32), (64, 16, 16, 192, 192),
