@@ -782,6 +782,24 @@ def test_bf16_training_step_batch8_batch_norm_vs_oracle():
     assert n >= 360
 
 
+def test_bf16_training_step_batch64_the_benchmarked_workload_vs_oracle():
+    """BASELINE.json config 2 AS BENCHMARKED -- phiseg_7_5, n0 = 32, 128 x 128, bf16, batch norm, BATCH 64: the plan bench.py times
+    (pair kernels, k_conv3x3_c32 with the unmaterialised level-0 activations, deferred multi-layer filter gradients, the one-launch
+    small-map norm layers, the XCD-banded tile order) -- one training step against the oracle on the host (torch CPU autograd, exact
+    fp32 and with the bf16 storage policy simulated; ~1 minute on the GPU box's 256 host cores): every loss term within 15 % (or 3x
+    the simulated policy's deviation), the mean gradient error within 1.3x the simulated policy's (measured 1.03 - 1.12x over eight
+    repetitions: 0.282 - 0.309 against 0.2755), every variable within 5x.
+    The per-variable bound is wider than at batch 8 for a measured reason (tools/grad_error_table.py, round 5): at this batch the
+    simulated policy's own deviation of the level-0 / level-1 latent heads is as small as 2 - 4 %, and what is left is not noise that
+    averages out but the realisation of the rounding on near-constant maps -- on the golden's seeds the KL gradient of level 1
+    (posterior/prior z1_mu/W, /b) came out 9 - 14 % short in EVERY one of eight repetitions (3.1 - 3.9x the simulated 3.8 %), with
+    seeds + 2 the simulated policy itself is 22 % short there and the engine follows it to 3.7 %, with seeds + 3 both are within 5 %."""
+    g, cfg, _ = load_golden("lidc_phiseg_bn")
+    cfg = dict(cfg, B=64)
+    n = _bf16_plan_vs_oracle(cfg, "batch norm, the benchmarked batch", fac=4.0, mean_slack=1.3, term_band=0.15)
+    assert n >= 360
+
+
 def test_bf16_training_step_probunet_n0_32_vs_oracle():
     """BASELINE.json config 4's real code path: prob_unet2D at n0 = 32, 128 x 128, bf16 -- the 1x1 recombination convolutions as the
     centre tap of the 3x3 MFMA kernels, the feature + z concat zero-padded from 38 to 64 channels, the global-average-pool latent
