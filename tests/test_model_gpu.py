@@ -789,11 +789,13 @@ def test_bf16_training_step_batch64_the_benchmarked_workload_vs_oracle():
     fp32 and with the bf16 storage policy simulated; ~1 minute on the GPU box's 256 host cores): every loss term within 15 % (or 3x
     the simulated policy's deviation), the mean gradient error within 1.3x the simulated policy's (measured 1.03 - 1.12x over eight
     repetitions: 0.282 - 0.309 against 0.2755), every variable within 5x.
-    The per-variable bound is wider than at batch 8 for a measured reason (tools/grad_error_table.py, round 5): at this batch the
-    simulated policy's own deviation of the level-0 / level-1 latent heads is as small as 2 - 4 %, and what is left is not noise that
-    averages out but the realisation of the rounding on near-constant maps -- on the golden's seeds the KL gradient of level 1
-    (posterior/prior z1_mu/W, /b) came out 9 - 14 % short in EVERY one of eight repetitions (3.1 - 3.9x the simulated 3.8 %), with
-    seeds + 2 the simulated policy itself is 22 % short there and the engine follows it to 3.7 %, with seeds + 3 both are within 5 %."""
+    The per-variable bound is wider than at batch 8 for a measured reason (tools/grad_error_table.py, tools/latent_forward_table.py,
+    DESIGN.md section 4): at this batch the simulated policy's own deviation of the level-0 / level-1 latent heads is as small as
+    2 - 4 %, while the KL gradient of such a level is the pixel sum of (mu_q - mu_p) / sigma_p^2, carried by the few pixels with a tiny
+    prior sigma_p -- the roundings of a handful of bf16 activations decide it, the same ones in every repetition.  On the golden's seeds
+    posterior/prior z1_mu/W, /b came out 9 - 14 % short in each of eight repetitions (3.1 - 3.9x the simulated 3.8 %), with seeds + 2 the
+    simulation itself is 22 % short there and the engine follows it to 3.7 %, with seeds + 3 both are within 5 %; the forward means of
+    mu_q, mu_p, sigma_p agree with the exact oracle to four digits in all of them."""
     g, cfg, _ = load_golden("lidc_phiseg_bn")
     cfg = dict(cfg, B=64)
     n = _bf16_plan_vs_oracle(cfg, "batch norm, the benchmarked batch", fac=4.0, mean_slack=1.3, term_band=0.15)
