@@ -381,6 +381,36 @@ int phx_avgpool2x2_bwd(const void* dy, int dt, void* dx, int B, int H, int W, in
 /* the same, ADDED to dx (a tensor with several readers: the later gradient contributions accumulate in place, no add pass) */
 int phx_avgpool2x2_bwd_acc(const void* dy, int dt, void* dx, int B, int H, int W, int C, void* stream);
 /* TF 1.12 ResizeBilinear(align_corners=False), legacy coordinates, factor 2 */
+/* ---- bilinear_upsample2D -> conv2D 3x3 without the up-sampled tensor (tfwrapper/layers.py:336-345 into :123; likelihoods.py:200-204):
+ * the elementwise half of the phase form (csrc/upconv.hip).  The matrix launches are the ordinary ones:
+ *   y_packed [B][h][w][4 Cout] = phx_conv3x3_mfma_bf16(x [B][h][w][Cin], weff_fwd)           exact outside the frame (hi rows / columns 0, 2n-2, 2n-1)
+ *   fr [1][6B][2w][Cout] = phx_conv3x3_mfma_bf16(f_rows, wpk_fwd of W),  fc [1][6B][2h][Cout] = phx_conv3x3_mfma_bf16(f_cols, wt_fwd)
+ * y_packed[b][i][j][(a, b', co)] is hi-res pixel (2i + a, 2j + b'): a channels-last tensor of 4 B h w pixels for the norm kernels.
+ * Backward: phx_upconv_frame_gather_dy moves the frame's gradient out of dy_packed (and zeroes it there), the three data gradients /
+ * filter gradients are the ordinary launches on (dy_packed, weff_dgrad), (dfr, wpk_dgrad of W), (dfc, wt_dgrad);
+ * phx_upconv_frame_scatter_dx adds the gathered rows' gradient into dx, phx_upconv_fold_wgrad folds dWeff [3][3][Cin][4 Cout] and
+ * dWt [3][3][Cin][Cout] (fp32) into dw_hwio (+=). */
+int phx_upconv_supported(int B, int h, int w, int Cin, int Cout);
+int phx_upconv_pack(const float* w_hwio, void* weff_fwd, void* weff_dgrad /* nullable */, void* wt_fwd, void* wt_dgrad /* nullable */,
+                    int Cin, int Cout, void* stream);
+int phx_upconv_fold_wgrad(const float* dweff, const float* dwt /* nullable */, float* dw_hwio, int Cin, int Cout, void* stream);
+int phx_upconv_frame_gather(const void* x, void* f_rows, void* f_cols, int B, int h, int w, int C, void* stream);
+int phx_upconv_frame_scatter(const void* fr, const void* fc, void* y_packed, int B, int h, int w, int Cout, void* stream);
+int phx_upconv_frame_gather_dy(void* dy_packed, void* dfr, void* dfc, int B, int h, int w, int Cout, void* stream);
+int phx_upconv_frame_scatter_dx(const void* df_rows, const void* df_cols, void* dx, int B, int h, int w, int C, void* stream);
+/* ... and the two permutations ride on the layer's own normalisation passes (batch norm; P = B * 4 h w): the apply pass reads the packed
+ * y and writes the hi-res activation, the two backward passes read the hi-res dA and the packed y and write the packed dy */
+int phx_norm_apply_fused_d2s(const void* x, int x_dt, const float* sums, const float* pivot, const float* gamma, const float* beta, float eps,
+                             void* y, int y_dt, float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,
+                             float momentum, int P, int C, int act, int h, int w, void* stream);
+int phx_norm_bwd_reduce_s2d(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
+                            const float* mean, const float* rstd, float* sums2, int P, int C, int act, int nrep, int h, int w,
+                            void* stream);
+int phx_norm_bwd_apply_fused_s2d(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
+                                 const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx, int dx_dt,
+                                 float* dgamma, float* dbeta, int P, int C, int act, int nrep, int h, int w, void* stream);
+int phx_depth_to_space2(const void* packed, void* hi, int B, int h, int w, int C, void* stream);
+int phx_space_to_depth2(const void* hi, void* packed, int B, int h, int w, int C, void* stream);
 int phx_bilinear_up2x_fwd(const void* x, int dt, void* y, int B, int h, int w, int C, void* stream);
 int phx_bilinear_up2x_bwd(const void* dy, int dt, void* dx, int B, int h, int w, int C, void* stream);
 /* the same, ADDED to dx (a tensor with several readers: the later gradient contributions accumulate in place, no add pass) */

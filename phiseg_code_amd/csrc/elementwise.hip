@@ -1058,7 +1058,15 @@ __device__ __forceinline__ void group_stats(const float* __restrict__ sums, cons
 struct HeadFw {
     const float *w, *b;
     float* y;
+    int ph, pw;          // > 0: x is in the packed pixel order of the phase-form convolution (csrc/upconv.hip: [B][ph][pw][(a, b)] pixels), y is
+                         // written as the hi-res map [B][2 ph][2 pw] -- the depth-to-space permutation rides on the apply pass
 };
+// pixel index in the packed order [B][h][w][(a, b)] -> pixel index of the hi-res map [B][2h][2w]
+__device__ __forceinline__ size_t packed_to_hi_pixel(size_t pix, int h, int w) {
+    const unsigned q = (unsigned)(pix >> 2), ab = (unsigned)pix & 3u;
+    const unsigned t = q / (unsigned)w, j = q - t * (unsigned)w, b = t / (unsigned)h, i = t - b * (unsigned)h;
+    return ((size_t)b * 2 * h + 2 * i + (ab >> 1)) * 2 * w + 2 * j + (ab & 1u);
+}
 template <typename TI, typename TO, int V, int HN = 0>
 __global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __restrict__ sums,
                                    const float* __restrict__ pivot, const float* __restrict__ gamma,
@@ -1149,6 +1157,7 @@ __global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __rest
                 for (int o = 0; o < HN; ++o) hd.y[pix * HN + o] = part[o] + hd.b[o];
         }
     };
+    auto yoff = [&](size_t pix) -> size_t { return (hd.pw > 0 ? packed_to_hi_pixel(pix, hd.ph, hd.pw) : pix) * C + (size_t)cv * V; };
     int p = p0 + pl;
     for (; p + 3 * PL < p1; p += 4 * PL) {       // four pixels per trip, loads first (see k_norm_stats)
         float v[4][V];
@@ -1160,7 +1169,7 @@ __global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __rest
             for (int j = 0; j < V; ++j) v[u][j] = act_fwd(fmaf(v[u][j], sc[j], sh[j]), act);
             // (HN > 0, y == NULL: a is not written at all -- in a training plan its only other reader, the head's filter gradient,
             // re-forms it from x: 268 MB less to write for the likelihood's top layer)
-            if (HN == 0 || y != nullptr) VecIO<TO, V>::store(y, ((size_t)ns * P + p + u * PL) * C + (size_t)cv * V, v[u]);
+            if (HN == 0 || y != nullptr) VecIO<TO, V>::store(y, yoff((size_t)ns * P + p + u * PL), v[u]);
             head((size_t)ns * P + p + u * PL, v[u]);
         }
     }
@@ -1170,7 +1179,7 @@ __global__ void k_norm_apply_fused(const TI* __restrict__ x, const float* __rest
         VecIO<TI, V>::load(x, off, v);
 #pragma unroll
         for (int j = 0; j < V; ++j) v[j] = act_fwd(fmaf(v[j], sc[j], sh[j]), act);
-        if (HN == 0 || y != nullptr) VecIO<TO, V>::store(y, off, v);
+        if (HN == 0 || y != nullptr) VecIO<TO, V>::store(y, yoff((size_t)ns * P + p), v);
         head((size_t)ns * P + p, v);
     }
 }
@@ -1269,11 +1278,13 @@ __global__ void k_norm_apply_pool(const bf16_t* __restrict__ x, const float* __r
 // launch would have stored it) instead of being written by that launch and read back by the two backward passes.
 struct HeadBw {
     const float *dy, *w;
+    int ph, pw, pc;      // pw > 0: x / dx are in the packed pixel order of the phase-form convolution, dA is the hi-res map [B][2 ph][2 pw][pc]
 };
 template <typename TD, int V, int HN>
 __device__ __forceinline__ void load_da(const TD* __restrict__ dA, size_t off, const HeadBw& hb, size_t pix,
                                         const float (&hw)[V][HN > 0 ? HN : 1], float (&dv)[V]) {
     if constexpr (HN == 0) {
+        if (hb.pw > 0) off = packed_to_hi_pixel(pix, hb.ph, hb.pw) * hb.pc + (off - pix * hb.pc);      // (space-to-depth on the fly)
         VecIO<TD, V>::load(dA, off, dv);
     } else {
         static_assert(HN == 0 || (V % 2 == 0 && std::is_same<TD, bf16_t>::value), "head-derived dA: bf16, even vector width");
@@ -2040,6 +2051,15 @@ int phx_norm_apply_fused(const void* x, int x_dt, const float* sums, const float
                            NS, P, C, G, act, HeadFw{nullptr, nullptr, nullptr}, 0, stream);
 }
 
+/* the phase-form convolution's layer (csrc/upconv.hip): x in the packed pixel order, y written as the hi-res map */
+int phx_norm_apply_fused_d2s(const void* x, int x_dt, const float* sums, const float* pivot, const float* gamma, const float* beta, float eps,
+                             void* y, int y_dt, float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,
+                             float momentum, int P, int C, int act, int h, int w, void* stream) {
+    PHX_REQUIRE(h > 0 && w > 0 && P % (4 * h * w) == 0, PHX_E_SHAPE, "norm_apply_fused_d2s: P = images x 4 h w");
+    return norm_apply_impl(x, x_dt, sums, 1, pivot, gamma, beta, eps, y, y_dt, mean, rstd, scale, shift, moving_mean, moving_var, momentum,
+                           1, P, C, C, act, HeadFw{nullptr, nullptr, nullptr, h, w}, 0, stream);
+}
+
 int phx_norm_bwd_apply_fused(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
                              const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx,
                              int dx_dt, float* dgamma, float* dbeta, int NS, int P, int C, int G, int act, int nrep,
@@ -2048,10 +2068,29 @@ int phx_norm_bwd_apply_fused(const void* dA, int da_dt, const void* x, int x_dt,
                                          nullptr, nullptr, nullptr, NS, P, C, G, act, nrep, stream);
 }
 
+static int norm_bwd_apply_impl(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
+                               const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx,
+                               int dx_dt, float* dgamma, float* dbeta, const float* fwd_sums, const float* fwd_pivot,
+                               float* dbias, int NS, int P, int C, int G, int act, int nrep, int ph, int pw, void* stream);
 int phx_norm_bwd_apply_fused_bias(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
                                   const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx,
                                   int dx_dt, float* dgamma, float* dbeta, const float* fwd_sums, const float* fwd_pivot,
                                   float* dbias, int NS, int P, int C, int G, int act, int nrep, void* stream) {
+    return norm_bwd_apply_impl(dA, da_dt, x, x_dt, scale, shift, mean, rstd, gamma, sums2, dx, dx_dt, dgamma, dbeta, fwd_sums, fwd_pivot, dbias,
+                               NS, P, C, G, act, nrep, 0, 0, stream);
+}
+/* the phase-form convolution's layer: dA is the hi-res map, x and dx are in the packed pixel order (batch norm: NS = 1, G = C) */
+int phx_norm_bwd_apply_fused_s2d(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
+                                 const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx, int dx_dt,
+                                 float* dgamma, float* dbeta, int P, int C, int act, int nrep, int h, int w, void* stream) {
+    PHX_REQUIRE(h > 0 && w > 0 && P % (4 * h * w) == 0, PHX_E_SHAPE, "norm_bwd_apply_fused_s2d: P = images x 4 h w");
+    return norm_bwd_apply_impl(dA, da_dt, x, x_dt, scale, shift, mean, rstd, gamma, sums2, dx, dx_dt, dgamma, dbeta, nullptr, nullptr, nullptr,
+                               1, P, C, C, act, nrep, h, w, stream);
+}
+static int norm_bwd_apply_impl(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
+                               const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx,
+                               int dx_dt, float* dgamma, float* dbeta, const float* fwd_sums, const float* fwd_pivot,
+                               float* dbias, int NS, int P, int C, int G, int act, int nrep, int ph, int pw, void* stream) {
     PHX_REQUIRE(da_dt == dx_dt, PHX_E_INVAL, "norm_bwd_apply_fused: dA and dx dtypes must match");
     PHX_REQUIRE(dbias == nullptr || fwd_sums != nullptr, PHX_E_INVAL, "norm_bwd_apply_fused_bias: dbias needs the forward sums");
     PHX_REQUIRE(nrep >= 1, PHX_E_INVAL, "norm_bwd_apply_fused: nrep >= 1");
@@ -2060,7 +2099,7 @@ int phx_norm_bwd_apply_fused_bias(const void* dA, int da_dt, const void* x, int 
         PHX_REQUIRE(stream_geometry(P, C, V, &PL, &threads, &chunk, &nchunks, NS) == 0, PHX_E_SHAPE, "norm_bwd_apply_fused: C too large");
         hipLaunchKernelGGL((k_norm_bwd_apply_fused<TD, TX, TD, V>), dim3(nchunks, NS), dim3(threads),
                            (size_t)(7 * C + 2 * G) * sizeof(float), (hipStream_t)stream, (const TD*)dA, (const TX*)x, scale, shift, mean, rstd, gamma, sums2,
-                           (TD*)dx, dgamma, dbeta, P, C, G, PL, chunk, act, nrep, fwd_sums, fwd_pivot, dbias, HeadBw{nullptr, nullptr});
+                           (TD*)dx, dgamma, dbeta, P, C, G, PL, chunk, act, nrep, fwd_sums, fwd_pivot, dbias, HeadBw{nullptr, nullptr, ph, pw, C});
     })));
     PHX_CHECK_LAUNCH();
     return PHX_OK;
@@ -2106,9 +2145,23 @@ int phx_norm_bwd_apply_fused_head(const float* dy_head, const float* w_head, int
     return PHX_OK;
 }
 
+static int norm_bwd_reduce_impl(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
+                                const float* mean, const float* rstd, float* sums2, int NS, int P, int C, int G, int act,
+                                int nrep, int ph, int pw, void* stream);
 int phx_norm_bwd_reduce(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
                         const float* mean, const float* rstd, float* sums2, int NS, int P, int C, int G, int act,
                         int nrep, void* stream) {
+    return norm_bwd_reduce_impl(dA, da_dt, x, x_dt, scale, shift, mean, rstd, sums2, NS, P, C, G, act, nrep, 0, 0, stream);
+}
+int phx_norm_bwd_reduce_s2d(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
+                            const float* mean, const float* rstd, float* sums2, int P, int C, int act, int nrep, int h, int w,
+                            void* stream) {
+    PHX_REQUIRE(h > 0 && w > 0 && P % (4 * h * w) == 0, PHX_E_SHAPE, "norm_bwd_reduce_s2d: P = images x 4 h w");
+    return norm_bwd_reduce_impl(dA, da_dt, x, x_dt, scale, shift, mean, rstd, sums2, 1, P, C, C, act, nrep, h, w, stream);
+}
+static int norm_bwd_reduce_impl(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
+                                const float* mean, const float* rstd, float* sums2, int NS, int P, int C, int G, int act,
+                                int nrep, int ph, int pw, void* stream) {
     PHX_REQUIRE(nrep >= 1, PHX_E_INVAL, "norm_bwd_reduce: nrep >= 1");
     PHX_DT_SWITCH(da_dt, TD, PHX_DT_SWITCH(x_dt, TX, PHX_VEC_SWITCH(C, V, {
         int PL, threads, chunk, nchunks;
@@ -2119,7 +2172,7 @@ int phx_norm_bwd_reduce(const void* dA, int da_dt, const void* x, int x_dt, cons
         }
         hipLaunchKernelGGL((k_norm_bwd_reduce<TD, TX, V>), dim3(nchunks, NS), dim3(threads),
                            (size_t)(PL > 2 ? PL : 2) * C * 2 * sizeof(float), (hipStream_t)stream, (const TD*)dA, (const TX*)x, scale,
-                           shift, mean, rstd, sums2, P, C, G, PL, chunk, act, nrep, HeadBw{nullptr, nullptr});
+                           shift, mean, rstd, sums2, P, C, G, PL, chunk, act, nrep, HeadBw{nullptr, nullptr, ph, pw, C});
     })));
     PHX_CHECK_LAUNCH();
     return PHX_OK;

@@ -9,6 +9,7 @@ import torch
 
 from phiseg_code_amd import graph as G
 from phiseg_code_amd import runtime as rt
+from phiseg_code_amd import upconv
 from phiseg_code_amd.tfwrapper import normalisation as tfnorm
 from phiseg_code_amd.engine_common import *  # noqa: F401,F403
 from phiseg_code_amd.engine_common import _BN_SMALL, _BN_SMALL_F32, _BN_WIDE, _BN_WIDE_MAXLINES, _DETERMINISTIC, _NREP, _NREP_MINP, _fgn_mode, _dual_enabled, _noop, _device, _TORCH_DT, _NP_DT, _ESIZE, _LIK_SIDE_MAXLVL, _WGRAD_DEFER_BLOCKS, _STAMPS  # noqa: F401
@@ -289,6 +290,11 @@ class BackwardLowering:
         act = rt.ACT_CODES[a["act"]]
         S, Lb = self.stream, self.L
         db_done = False
+        upc = sv.get("upconv")
+        if upc is not None:
+            # phase form (upconv.py): y and everything downstream of it live in the PACKED pixel order; dA is a hi-res map -- the two
+            # norm-backward passes read it through the space-to-depth permutation
+            assert isinstance(dA, Buf) and dA.dt == BF16 and sv["norm"] == "batch" and not sv.get("bn_small")
         if sv["norm"] is not None:
             if "y" not in sv or "mean" not in sv or (sv["norm"] == "batch" and not self.training):
                 raise NotImplementedError("backward through inference-mode batch norm is not on the hot path")
@@ -324,7 +330,11 @@ class BackwardLowering:
                 Sg = self._alloc((NS * Gn * 2,), F32)
                 dY = self._alloc(y.shape, y.dt)
                 hg = dA if isinstance(dA, HeadGrad) else None
-                if hg is not None:
+                if upc is not None:
+                    self._emit(Lb.norm_bwd_reduce_s2d, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr, sv["mean"].ptr,
+                               sv["rstd"].ptr, sums2.ptr, P, cout, act, nrep, H // 2, Wd // 2, S,
+                               tag="bytes_norm_bwd_reduce", flops=float(dA.nbytes + y.nbytes))
+                elif hg is not None:
                     self._emit(Lb.norm_bwd_reduce_head, hg.dy.ptr, hg.w_ptr, hg.nout, y.ptr, sv["scale"].ptr, sv["shift"].ptr,
                                sv["mean"].ptr, sv["rstd"].ptr, sums2.ptr, NS, P, cout, Gn, act, nrep, S,
                                tag="bytes_norm_bwd_reduce", flops=float(y.nbytes))
@@ -337,7 +347,12 @@ class BackwardLowering:
                 fs = sv.get("fsums") if b is not None else None
                 if fs is not None:
                     db_done = True
-                if hg is not None:
+                if upc is not None:
+                    self._emit(Lb.norm_bwd_apply_fused_s2d, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr, sv["mean"].ptr,
+                               sv["rstd"].ptr, self.store.ptr(nv["gamma"]), sums2.ptr, dY.ptr, dY.dt, self.store.grad_ptr(nv["gamma"]),
+                               self.store.grad_ptr(nv["beta"]), P, cout, act, nrep, H // 2, Wd // 2, S,
+                               tag="bytes_norm_bwd_apply", flops=float(dA.nbytes + y.nbytes + dY.nbytes))
+                elif hg is not None:
                     self._emit(Lb.norm_bwd_apply_fused_head, hg.dy.ptr, hg.w_ptr, hg.nout, y.ptr, sv["scale"].ptr, sv["shift"].ptr,
                                sv["mean"].ptr, sv["rstd"].ptr, self.store.ptr(nv["gamma"]), sums2.ptr, dY.ptr,
                                self.store.grad_ptr(nv["gamma"]), self.store.grad_ptr(nv["beta"]),
@@ -360,6 +375,15 @@ class BackwardLowering:
             dY = dA
         dw = self.store.grad_ptr(W)
         db = self.store.grad_ptr(b) if (b is not None and not db_done) else None
+        if upc is not None:
+            src = x.src                                  # the low-resolution tensor bilinear_upsample2D read
+            h, w = H // 2, Wd // 2
+            upconv.backward_filters(self._emit, self._alloc, self._alloc_zeroed, Lb, S, upc, src, dY, dw, B, h, w, cin, cout)
+            xin = op.inputs[0].op.inputs[0]              # the gradient goes straight to the resize's input (its adjoint is part of the form)
+            if self.req.get(xin, False):
+                _, wd_w = self._packed(W)
+                self._add_grad(xin, write_fn=lambda g: upconv.backward_data(self._emit, self._alloc, Lb, S, upc, dY, wd_w, g, B, h, w, cin, cout))
+            return
         if sv.get("general") is not None:
             geo = sv["geo"]
             self._emit(Lb.gconv2d_wgrad, x.ptr, x.dt, dY.ptr, dY.dt, dw, *geo, S)

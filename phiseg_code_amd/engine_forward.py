@@ -9,6 +9,7 @@ import torch
 
 from phiseg_code_amd import graph as G
 from phiseg_code_amd import runtime as rt
+from phiseg_code_amd import upconv
 from phiseg_code_amd.tfwrapper import normalisation as tfnorm
 from phiseg_code_amd.engine_common import *  # noqa: F401,F403
 from phiseg_code_amd.engine_common import _BN_SMALL, _BN_SMALL_F32, _BN_WIDE, _BN_WIDE_MAXLINES, _SKIP_HEAD_A, _DETERMINISTIC, _NREP, _NREP_MINP, _fgn_mode, _dual_enabled, _noop, _device, _TORCH_DT, _NP_DT, _ESIZE, _LIK_SIDE_MAXLVL, _WGRAD_DEFER_BLOCKS, _STAMPS  # noqa: F401
@@ -297,6 +298,7 @@ class ForwardLowering:
         S, Lb = self.stream, self.L
         dual = x if isinstance(x, DualBuf) else None
         assert dual is None or mfma, "concat-free input reached a convolution off the MFMA path"
+        up = x if isinstance(x, UpBuf) else None      # bilinear_upsample2D of up.src, never written: this unit runs in the phase form (upconv.py)
         xf = x if isinstance(x, XfBuf) else None      # the producer's activation was never written: this launch re-forms it (see _xf_edge_ok)
         assert xf is None or (mfma and a["norm"] == "batch" and b is None), "unmaterialised activation reached a convolution that cannot re-form it"
 
@@ -347,6 +349,13 @@ class ForwardLowering:
             return int(Lb.conv3x3_mfma_bf16_tiles(B, H, Wd, cin_eff, cout))
 
         def conv_into(y, act_code, stats_direct=None, stats_part=None, stats_atomic=None):
+            if up is not None:
+                # y <- the hi-res pre-normalisation map in PACKED pixel order [B, h, w, (a, b, cout)]: the per-channel norm kernels do not
+                # care about the order of the pixels; the apply pass's output is permuted to hi-res below
+                assert act_code == 0 and stats_direct is None and stats_part is None and stats_atomic is None and bptr is None
+                st["upconv"] = upconv.forward(self._emit, self._alloc, Lb, S, up.src, wptr, wf, y, B, H // 2, Wd // 2, cin, cout,
+                                              need_dgrad=bool(bw and self.req.get(op.inputs[0].op.inputs[0], False)))
+                return
             if stats_atomic is not None:
                 mfma_conv(y, bptr, None, act_code, stats_atomic, 2, None, 0)
             elif head1x1:
@@ -461,7 +470,12 @@ class ForwardLowering:
             # a statistic has few samples (cheap there); otherwise the sums come from the conv epilogue.
             small = P <= 16384 or self.act_dt == F32
             xf_producer_ok = False
-            if norm == "batch" and mfma and not small:
+            if up is not None:
+                # (the frame of the packed map is written after the phase convolution: its statistics epilogue cannot be used)
+                pivot = self._alloc((NS * cout,), F32)
+                conv_into(y, 0)
+                self._emit(Lb.norm_stats, y.ptr, y.dt, sums.ptr, pivot.ptr, NS, P, cout, S)
+            elif norm == "batch" and mfma and not small:
                 ntile = tiles_fn()
                 part = self._alloc((ntile * 2 * cout,), F32)
                 conv_into(y, 0, stats_part=part)
@@ -500,8 +514,12 @@ class ForwardLowering:
                 return
             apply_args = (y.ptr, y.dt, sums.ptr, pivot.ptr if pivot is not None else None, gptr, beptr, eps, out.ptr, out.dt,
                           mean.ptr, rstd.ptr, scale.ptr, shift.ptr, mmp, mvp, mom, NS, P, cout, Gn, act)
-            hop = self._norm_head_consumer(op) if (y.dt == BF16 and out.dt == BF16) else None
-            if hop is not None and Lb.norm_head_supported(cout, hop.attrs["W"].shape[-1], y.dt, out.dt):
+            hop = self._norm_head_consumer(op) if (y.dt == BF16 and out.dt == BF16 and up is None) else None
+            if up is not None:
+                # y is in the packed pixel order, the readers of a want hi-res rows: the apply pass writes them (depth-to-space on the fly)
+                self._emit(Lb.norm_apply_fused_d2s, *apply_args[:16], P, cout, act, H // 2, Wd // 2, S, tag="bytes_norm_apply",
+                           flops=float(y.nbytes + out.nbytes))
+            elif hop is not None and Lb.norm_head_supported(cout, hop.attrs["W"].shape[-1], y.dt, out.dt):
                 # the head rides on the apply pass (phx_norm_apply_fused_head): no pass of its own over a
                 hW, hb = hop.attrs["W"], hop.attrs["b"]
                 yh = self._alloc_like(hop.outputs[0])
@@ -645,8 +663,37 @@ class ForwardLowering:
         self._emit(self.L.avgpool2x2_fwd, x.ptr, x.dt, out.ptr, x.shape[0], x.shape[1], x.shape[2], x.shape[3],
                    self.stream)
 
+    def _upconv_consumer(self, op, x, bw):
+        """The 3x3 conv unit (batch norm, training plan) that is the ONLY reader of this resize and runs in the phase form -- or None."""
+        mh = _upconv_min_h()
+        if not (mh > 0 and bw and self.loss is not None and self.act_dt == BF16 and isinstance(x, Buf) and x.dt == BF16 and len(x.shape) == 4):
+            return None
+        ot = op.outputs[0]
+        cons = self._real_consumers(ot, self._opset)
+        if len(cons) != 1 or ot in self.fetches or x.shape[1] < mh or x.shape[2] < mh:
+            return None
+        c = cons[0]
+        a = c.attrs if c.type == "conv_unit" else None
+        if (a is None or c.inputs[0] is not ot or a["ksize"] != 3 or a.get("transposed") is not None or a.get("general") is not None
+                or a["norm"] != "batch" or a["b"] is not None or self.op_lane.get(c) != self.op_lane.get(op) or c in self._lat):
+            return None
+        training = a["training"] if isinstance(a["training"], bool) else self.training
+        cin, cout = a["W"].shape[-2], a["W"].shape[-1]
+        if not training or cin != x.shape[3] or not self.L.upconv_supported(x.shape[0], x.shape[1], x.shape[2], cin, cout):
+            return None
+        # Measured per edge at batch 64 (profiles/r05_ab_upconv.txt): 192 -> 32 from 64 x 64 + 1.0 % of the step; 192 -> 64 from 32 x 32 - 1.3 %,
+        # 32 -> 32 from 64 x 64 - 1 % (the form trades the 4 Cin-channel hi-res tensor for ten more launches and a 4 Cout-column filter
+        # gradient: it pays where the up-sampled tensor dominates the layer's bytes)
+        if cin < 4 * cout:
+            return None
+        return c
+
     def _fw_bilinear_up(self, op, bw):
         x = self.val[op.inputs[0]]
+        if self._upconv_consumer(op, x, bw) is not None:
+            # no launch, no hi-res tensor: the reader convolves the low-resolution map with the phase filters (_fw_conv_unit, upconv.py)
+            self.val[op.outputs[0]] = UpBuf(x, self._cshape(op.outputs[0]))
+            return
         out = self._alloc(self._cshape(op.outputs[0]), x.dt)
         self.val[op.outputs[0]] = out
         self._emit(self.L.bilinear_up2x_fwd, x.ptr, x.dt, out.ptr, x.shape[0], x.shape[1], x.shape[2], x.shape[3],

@@ -90,3 +90,51 @@ def test_training_plan_without_materialised_activations_at_batch_24(monkeypatch)
         if nrm >= 1e-8 * max(1.0, np.sqrt(ga.size)):
             errs.append(np.linalg.norm(g1[name] - ga) / nrm)
     assert len(errs) >= 360 and np.mean(errs) <= 0.5, (len(errs), np.mean(errs))
+
+
+def test_training_plan_with_the_phase_form_of_upsample_conv_at_batch_16(monkeypatch):
+    """bilinear_upsample2D -> conv2D -> batch norm in the phase form (engine UpBuf, upconv.py, csrc/upconv.hip: no up-sampled tensor, the resize's
+    adjoint is part of the form) on the one edge of phiseg_7_5 the policy picks -- likelihood/post_z1_ups -> post_z1_ups_c, 192 -> 32 from
+    64 x 64 (likelihoods.py:200-204) -- against the plan that materialises the up-sampled map (PHX_UPCONV=0): the launches are there, the
+    resize launches of that edge are gone, loss and every gradient agree to what two bf16 evaluations of the same step differ by."""
+    import torch
+    from oracle import init as oinit
+    from oracle import train as otrain
+    from phiseg_code_amd.phiseg import phiseg_model
+    from tests.helpers import load_golden
+    from tests.test_graph_cpu import make_config
+    g, cfg, var_order = load_golden("lidc_phiseg_bn")
+    cfg = dict(cfg, B=16)
+    params = otrain.make_params(var_order, cfg["weight_seed"], torch.float32, perturbed=True)
+    x_np, s_np = oinit.synthetic_batch(cfg["B"], cfg["H"], cfg["nlabels"], cfg["data_seed"])
+    res = {}
+    for v in ("0", "64"):
+        monkeypatch.setenv("PHX_UPCONV", v)
+        model = phiseg_model.phiseg(make_config(cfg, "bf16"), rng_seed=cfg["eps_seed"])
+        model.set_weights({k: t.detach().numpy() for k, t in params.items()})
+        plan = model.sess.plan_for([model.loss_tot], True, cfg["B"], True)
+        plan.set_input("x_input", x_np)
+        plan.set_input("s_input", s_np)
+        model.sess.store.set_lr(0.0)
+        plan.run()
+        plan.sync()
+        names = [getattr(fn, "__name__", "") for fn, _ in plan.launches]
+        res[v] = (float(plan.fetch(model.loss_tot)), model.sess.store.export(grads=True),
+                  {n: sum(m == n for m in names) for n in ("phx_upconv_pack", "phx_upconv_frame_scatter", "phx_upconv_frame_scatter_dx",
+                                                            "phx_upconv_fold_wgrad", "phx_norm_apply_fused_d2s", "phx_bilinear_up2x_fwd",
+                                                            "phx_bilinear_up2x_bwd", "phx_bilinear_up2x_bwd_acc")})
+        del plan, model
+    l0, g0, c0 = res["0"]
+    l1, g1, c1 = res["64"]
+    assert c0["phx_upconv_pack"] == 0 and c1["phx_upconv_pack"] == 1 and c1["phx_upconv_frame_scatter"] == 1, (c0, c1)
+    assert c1["phx_upconv_frame_scatter_dx"] == 1 and c1["phx_upconv_fold_wgrad"] == 1 and c1["phx_norm_apply_fused_d2s"] == 1, c1
+    assert c1["phx_bilinear_up2x_fwd"] == c0["phx_bilinear_up2x_fwd"] - 1, (c0, c1)
+    assert c1["phx_bilinear_up2x_bwd"] + c1["phx_bilinear_up2x_bwd_acc"] == c0["phx_bilinear_up2x_bwd"] + c0["phx_bilinear_up2x_bwd_acc"] - 1, (c0, c1)
+    assert abs(l1 - l0) <= 2e-2 * abs(l0), (l0, l1)
+    errs = []
+    for name, ga in g0.items():
+        nrm = np.linalg.norm(ga)
+        if nrm >= 1e-8 * max(1.0, np.sqrt(ga.size)):
+            errs.append(np.linalg.norm(g1[name] - ga) / nrm)
+    print("phase form vs materialised plan: loss %.6g / %.6g, mean relative gradient distance %.4f over %d variables" % (l1, l0, np.mean(errs), len(errs)))
+    assert len(errs) >= 360 and np.mean(errs) <= 0.5, (len(errs), np.mean(errs))
