@@ -10,18 +10,20 @@ from . import runtime as rt
 BF16 = rt.BF16
 
 
-def _conv(emit, alloc, L, S, src, pack, dst, B, H, W, K, N, tag):
+def _conv(emit, alloc, L, S, src, pack, dst, B, H, W, K, N, tag, algorithmic=True):
+    """(algorithmic=False: a frame launch -- it re-computes pixels the phase convolution also produced, so its time counts for the family and
+    its FLOPs do not: the layer's algorithmic FLOPs are the phase convolution's, 18 Cin Cout per hi-res pixel)"""
     nb = int(L.conv3x3_mfma_ws_bytes(B, H, W, K, N))
     ws = alloc((max(nb // 4, 1),), rt.F32) if nb else None
     emit(L.conv3x3_mfma_bf16_ws, src.ptr, pack.ptr, dst.ptr, None, 0, None, ws.ptr if ws is not None else None, nb, B, H, W, K, N, S,
-         tag=tag, flops=18.0 * K * N * B * H * W)
+         tag=tag, flops=18.0 * K * N * B * H * W if algorithmic else 0.0)
 
 
-def _wgrad(emit, alloc, L, S, x, dy, dw_ptr, B, H, W, K, N):
+def _wgrad(emit, alloc, L, S, x, dy, dw_ptr, B, H, W, K, N, algorithmic=True):
     wsb = int(L.conv3x3_wgrad_ws_bytes(B, H, W, K, N))
     ws = alloc((max(wsb // 4, 1),), rt.F32)
     emit(L.conv3x3_wgrad_mfma_bf16, x.ptr, dy.ptr, dw_ptr, ws.ptr if wsb else None, wsb, B, H, W, K, N, S,
-         tag="conv3x3_mfma_wgrad", flops=18.0 * K * N * B * H * W)
+         tag="conv3x3_mfma_wgrad", flops=18.0 * K * N * B * H * W if algorithmic else 0.0)
 
 
 def forward(emit, alloc, L, S, x, w_ptr, wf_w, y_packed, B, h, w, cin, cout, need_dgrad=True):
@@ -36,8 +38,8 @@ def forward(emit, alloc, L, S, x, w_ptr, wf_w, y_packed, B, h, w, cin, cout, nee
     emit(L.upconv_frame_gather, x.ptr, f_rows.ptr, f_cols.ptr, B, h, w, cin, S)
     _conv(emit, alloc, L, S, x, ef, y_packed, B, h, w, cin, 4 * cout, "conv3x3_mfma_fwd")
     fr, fc = alloc((6 * B, 2 * w, cout), BF16), alloc((6 * B, 2 * h, cout), BF16)
-    _conv(emit, alloc, L, S, f_rows, wf_w, fr, 1, 6 * B, 2 * w, cin, cout, "conv3x3_mfma_fwd")
-    _conv(emit, alloc, L, S, f_cols, tf, fc, 1, 6 * B, 2 * h, cin, cout, "conv3x3_mfma_fwd")
+    _conv(emit, alloc, L, S, f_rows, wf_w, fr, 1, 6 * B, 2 * w, cin, cout, "conv3x3_mfma_fwd", algorithmic=False)
+    _conv(emit, alloc, L, S, f_cols, tf, fc, 1, 6 * B, 2 * h, cin, cout, "conv3x3_mfma_fwd", algorithmic=False)
     emit(L.upconv_frame_scatter, fr.ptr, fc.ptr, y_packed.ptr, B, h, w, cout, S)
     return dict(ed=ed, td=td, f_rows=f_rows, f_cols=f_cols)
 
@@ -50,8 +52,8 @@ def backward_filters(emit, alloc, alloc_zeroed, L, S, ctx, x, dy_packed, dw_ptr,
     ctx["dfr"], ctx["dfc"] = dfr, dfc
     dweff, dwt = alloc_zeroed(9 * cin * 4 * cout), alloc_zeroed(9 * cin * cout)
     _wgrad(emit, alloc, L, S, x, dy_packed, dweff.ptr, B, h, w, cin, 4 * cout)
-    _wgrad(emit, alloc, L, S, ctx["f_rows"], dfr, dw_ptr, 1, 6 * B, 2 * w, cin, cout)
-    _wgrad(emit, alloc, L, S, ctx["f_cols"], dfc, dwt.ptr, 1, 6 * B, 2 * h, cin, cout)
+    _wgrad(emit, alloc, L, S, ctx["f_rows"], dfr, dw_ptr, 1, 6 * B, 2 * w, cin, cout, algorithmic=False)
+    _wgrad(emit, alloc, L, S, ctx["f_cols"], dfc, dwt.ptr, 1, 6 * B, 2 * h, cin, cout, algorithmic=False)
     emit(L.upconv_fold_wgrad, dweff.ptr, dwt.ptr, dw_ptr, cin, cout, S)
 
 
@@ -60,6 +62,6 @@ def backward_data(emit, alloc, L, S, ctx, dy_packed, wd_w, dx, B, h, w, cin, cou
     data-gradient filter of W itself."""
     _conv(emit, alloc, L, S, dy_packed, ctx["ed"], dx, B, h, w, 4 * cout, cin, "conv3x3_mfma_dgrad")
     dF_rows, dF_cols = alloc((6 * B, 2 * w, cin), BF16), alloc((6 * B, 2 * h, cin), BF16)
-    _conv(emit, alloc, L, S, ctx["dfr"], wd_w, dF_rows, 1, 6 * B, 2 * w, cout, cin, "conv3x3_mfma_dgrad")
-    _conv(emit, alloc, L, S, ctx["dfc"], ctx["td"], dF_cols, 1, 6 * B, 2 * h, cout, cin, "conv3x3_mfma_dgrad")
+    _conv(emit, alloc, L, S, ctx["dfr"], wd_w, dF_rows, 1, 6 * B, 2 * w, cout, cin, "conv3x3_mfma_dgrad", algorithmic=False)
+    _conv(emit, alloc, L, S, ctx["dfc"], ctx["td"], dF_cols, 1, 6 * B, 2 * h, cout, cin, "conv3x3_mfma_dgrad", algorithmic=False)
     emit(L.upconv_frame_scatter_dx, dF_rows.ptr, dF_cols.ptr, dx.ptr, B, h, w, cin, S)
