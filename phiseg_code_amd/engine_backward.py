@@ -378,6 +378,8 @@ class BackwardLowering:
         if upc is not None:
             src = x.src                                  # the low-resolution tensor bilinear_upsample2D read
             h, w = H // 2, Wd // 2
+            upconv.backward_prepare(self._emit, self._alloc, Lb, S, upc, dY, B, h, w, cout)
+            # (filter gradients before or after the data gradients: same step time, measured three alternating pairs)
             upconv.backward_filters(self._emit, self._alloc, self._alloc_zeroed, Lb, S, upc, src, dY, dw, B, h, w, cin, cout)
             xin = op.inputs[0].op.inputs[0]              # the gradient goes straight to the resize's input (its adjoint is part of the form)
             if self.req.get(xin, False):

@@ -44,12 +44,16 @@ def forward(emit, alloc, L, S, x, w_ptr, wf_w, y_packed, B, h, w, cin, cout, nee
     return dict(ed=ed, td=td, f_rows=f_rows, f_cols=f_cols)
 
 
-def backward_filters(emit, alloc, alloc_zeroed, L, S, ctx, x, dy_packed, dw_ptr, B, h, w, cin, cout):
-    """dw_hwio += the filter gradient.  Moves the frame's gradient out of dy_packed first (dy_packed is modified: its frame is zeroed);
-    call before backward_data, which reads what this leaves in ctx."""
+def backward_prepare(emit, alloc, L, S, ctx, dy_packed, B, h, w, cout):
+    """Moves the frame's gradient out of dy_packed into ctx (dy_packed is modified: its frame is zeroed).  First step of the backward pass."""
     dfr, dfc = alloc((6 * B, 2 * w, cout), BF16), alloc((6 * B, 2 * h, cout), BF16)
     emit(L.upconv_frame_gather_dy, dy_packed.ptr, dfr.ptr, dfc.ptr, B, h, w, cout, S)
     ctx["dfr"], ctx["dfc"] = dfr, dfc
+
+
+def backward_filters(emit, alloc, alloc_zeroed, L, S, ctx, x, dy_packed, dw_ptr, B, h, w, cin, cout):
+    """dw_hwio += the filter gradient (after backward_prepare)."""
+    dfr, dfc = ctx["dfr"], ctx["dfc"]
     dweff, dwt = alloc_zeroed(9 * cin * 4 * cout), alloc_zeroed(9 * cin * cout)
     _wgrad(emit, alloc, L, S, x, dy_packed, dweff.ptr, B, h, w, cin, 4 * cout)
     _wgrad(emit, alloc, L, S, ctx["f_rows"], dfr, dw_ptr, 1, 6 * B, 2 * w, cin, cout, algorithmic=False)
@@ -58,8 +62,8 @@ def backward_filters(emit, alloc, alloc_zeroed, L, S, ctx, x, dy_packed, dw_ptr,
 
 
 def backward_data(emit, alloc, L, S, ctx, dy_packed, wd_w, dx, B, h, w, cin, cout):
-    """dx [B, h, w, cin] <- the gradient with respect to the LOW-resolution input (resize adjoint included).  wd_w: the packed bf16
-    data-gradient filter of W itself."""
+    """dx [B, h, w, cin] <- the gradient with respect to the LOW-resolution input (resize adjoint included; after backward_prepare).
+    wd_w: the packed bf16 data-gradient filter of W itself."""
     _conv(emit, alloc, L, S, dy_packed, ctx["ed"], dx, B, h, w, 4 * cout, cin, "conv3x3_mfma_dgrad")
     dF_rows, dF_cols = alloc((6 * B, 2 * w, cin), BF16), alloc((6 * B, 2 * h, cin), BF16)
     _conv(emit, alloc, L, S, ctx["dfr"], wd_w, dF_rows, 1, 6 * B, 2 * w, cout, cin, "conv3x3_mfma_dgrad", algorithmic=False)

@@ -1998,6 +1998,7 @@ def test_upsample_conv_phase_form_vs_oracle(L, case):
     L.depth_to_space2(dyp.ptr, back.ptr, B, h, w, N, S())
     assert torch.equal(back.t.reshape(-1), dyd.reshape(-1))             # the two permutations are inverses
     dw = torch.full((3, 3, K, N), 0.25, dtype=torch.float32, device="cuda")      # accumulate semantics
+    upconv.backward_prepare(emit, alloc, L, S(), ctx, dyp, B, h, w, N)
     upconv.backward_filters(emit, alloc, alloc_zeroed, L, S(), ctx, xb, dyp, dw.data_ptr(), B, h, w, K, N)
     dx = alloc((B, h, w, K), BF16)
     upconv.backward_data(emit, alloc, L, S(), ctx, dyp, wg, dx, B, h, w, K, N)
