@@ -360,7 +360,7 @@ def main():
                 ks = [v for k, v in pj.items() if any(t in k for t in ("k_conv3x3_pp", "k_conv3x3_c32", "k_conv3x3_mfma"))]
                 calls = sum(v["calls_per_step"] for v in ks)
                 traffic = 1e6 * sum(v["fetch_x2_MB_per_step"] + v["write_MB_per_step"] for v in ks) / calls
-                traffic_src = "committed profile profiles/" + tf_ + " (collected at commit e2b831e by tools/collect_profiles.sh; not measured by this run)"
+                traffic_src = "committed profile profiles/" + tf_ + " (collected at commit 4d2999e by tools/collect_profiles.sh; not measured by this run)"
             except Exception:
                 pass
             try:
