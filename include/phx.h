@@ -391,24 +391,27 @@ int phx_avgpool2x2_bwd_acc(const void* dy, int dt, void* dx, int B, int H, int W
  * phx_upconv_frame_scatter_dx adds the gathered rows' gradient into dx, phx_upconv_fold_wgrad folds dWeff [3][3][Cin][4 Cout] and
  * dWt [3][3][Cin][Cout] (fp32) into dw_hwio (+=). */
 int phx_upconv_supported(int B, int h, int w, int Cin, int Cout);
+/* (bias / bias4, nullable together: the convolution bias repeated for the 4 Cout packed columns -- group / instance norm layers keep it) */
 int phx_upconv_pack(const float* w_hwio, void* weff_fwd, void* weff_dgrad /* nullable */, void* wt_fwd, void* wt_dgrad /* nullable */,
-                    int Cin, int Cout, void* stream);
+                    const float* bias, float* bias4, int Cin, int Cout, void* stream);
 int phx_upconv_fold_wgrad(const float* dweff, const float* dwt /* nullable */, float* dw_hwio, int Cin, int Cout, void* stream);
 int phx_upconv_frame_gather(const void* x, void* f_rows, void* f_cols, int B, int h, int w, int C, void* stream);
 int phx_upconv_frame_scatter(const void* fr, const void* fc, void* y_packed, int B, int h, int w, int Cout, void* stream);
 int phx_upconv_frame_gather_dy(void* dy_packed, void* dfr, void* dfc, int B, int h, int w, int Cout, void* stream);
 int phx_upconv_frame_scatter_dx(const void* df_rows, const void* df_cols, void* dx, int B, int h, int w, int C, void* stream);
-/* ... and the two permutations ride on the layer's own normalisation passes (batch norm; P = B * 4 h w): the apply pass reads the packed
- * y and writes the hi-res activation, the two backward passes read the hi-res dA and the packed y and write the packed dy */
+/* ... and the two permutations ride on the layer's own normalisation passes (NS * P = B * 4 h w pixels; a sample group is one image
+ * -- group / instance norm -- or the whole batch): the apply pass reads the packed y and writes the hi-res activation, the two backward
+ * passes read the hi-res dA and the packed y and write the packed dy (fwd_sums / fwd_pivot / dbias as phx_norm_bwd_apply_fused_bias) */
 int phx_norm_apply_fused_d2s(const void* x, int x_dt, const float* sums, const float* pivot, const float* gamma, const float* beta, float eps,
                              void* y, int y_dt, float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,
-                             float momentum, int P, int C, int act, int h, int w, void* stream);
+                             float momentum, int NS, int P, int C, int G, int act, int h, int w, void* stream);
 int phx_norm_bwd_reduce_s2d(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
-                            const float* mean, const float* rstd, float* sums2, int P, int C, int act, int nrep, int h, int w,
-                            void* stream);
+                            const float* mean, const float* rstd, float* sums2, int NS, int P, int C, int G, int act, int nrep, int h,
+                            int w, void* stream);
 int phx_norm_bwd_apply_fused_s2d(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
                                  const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx, int dx_dt,
-                                 float* dgamma, float* dbeta, int P, int C, int act, int nrep, int h, int w, void* stream);
+                                 float* dgamma, float* dbeta, const float* fwd_sums, const float* fwd_pivot, float* dbias, int NS, int P,
+                                 int C, int G, int act, int nrep, int h, int w, void* stream);
 int phx_depth_to_space2(const void* packed, void* hi, int B, int h, int w, int C, void* stream);
 int phx_space_to_depth2(const void* hi, void* packed, int B, int h, int w, int C, void* stream);
 int phx_bilinear_up2x_fwd(const void* x, int dt, void* y, int B, int h, int w, int C, void* stream);

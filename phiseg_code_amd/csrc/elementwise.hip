@@ -2054,10 +2054,11 @@ int phx_norm_apply_fused(const void* x, int x_dt, const float* sums, const float
 /* the phase-form convolution's layer (csrc/upconv.hip): x in the packed pixel order, y written as the hi-res map */
 int phx_norm_apply_fused_d2s(const void* x, int x_dt, const float* sums, const float* pivot, const float* gamma, const float* beta, float eps,
                              void* y, int y_dt, float* mean, float* rstd, float* scale, float* shift, float* moving_mean, float* moving_var,
-                             float momentum, int P, int C, int act, int h, int w, void* stream) {
-    PHX_REQUIRE(h > 0 && w > 0 && P % (4 * h * w) == 0, PHX_E_SHAPE, "norm_apply_fused_d2s: P = images x 4 h w");
+                             float momentum, int NS, int P, int C, int G, int act, int h, int w, void* stream) {
+    PHX_REQUIRE(h > 0 && w > 0 && ((size_t)NS * P) % ((size_t)4 * h * w) == 0 && (NS == 1 || P == 4 * h * w), PHX_E_SHAPE,
+                "norm_apply_fused_d2s: NS * P = images x 4 h w, a sample group = one image or all of them");
     return norm_apply_impl(x, x_dt, sums, 1, pivot, gamma, beta, eps, y, y_dt, mean, rstd, scale, shift, moving_mean, moving_var, momentum,
-                           1, P, C, C, act, HeadFw{nullptr, nullptr, nullptr, h, w}, 0, stream);
+                           NS, P, C, G, act, HeadFw{nullptr, nullptr, nullptr, h, w}, 0, stream);
 }
 
 int phx_norm_bwd_apply_fused(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
@@ -2079,13 +2080,16 @@ int phx_norm_bwd_apply_fused_bias(const void* dA, int da_dt, const void* x, int 
     return norm_bwd_apply_impl(dA, da_dt, x, x_dt, scale, shift, mean, rstd, gamma, sums2, dx, dx_dt, dgamma, dbeta, fwd_sums, fwd_pivot, dbias,
                                NS, P, C, G, act, nrep, 0, 0, stream);
 }
-/* the phase-form convolution's layer: dA is the hi-res map, x and dx are in the packed pixel order (batch norm: NS = 1, G = C) */
+/* the phase-form convolution's layer: dA is the hi-res map, x and dx are in the packed pixel order (fwd_sums / fwd_pivot / dbias as
+ * phx_norm_bwd_apply_fused_bias) */
 int phx_norm_bwd_apply_fused_s2d(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
                                  const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx, int dx_dt,
-                                 float* dgamma, float* dbeta, int P, int C, int act, int nrep, int h, int w, void* stream) {
-    PHX_REQUIRE(h > 0 && w > 0 && P % (4 * h * w) == 0, PHX_E_SHAPE, "norm_bwd_apply_fused_s2d: P = images x 4 h w");
-    return norm_bwd_apply_impl(dA, da_dt, x, x_dt, scale, shift, mean, rstd, gamma, sums2, dx, dx_dt, dgamma, dbeta, nullptr, nullptr, nullptr,
-                               1, P, C, C, act, nrep, h, w, stream);
+                                 float* dgamma, float* dbeta, const float* fwd_sums, const float* fwd_pivot, float* dbias, int NS, int P,
+                                 int C, int G, int act, int nrep, int h, int w, void* stream) {
+    PHX_REQUIRE(h > 0 && w > 0 && ((size_t)NS * P) % ((size_t)4 * h * w) == 0 && (NS == 1 || P == 4 * h * w), PHX_E_SHAPE,
+                "norm_bwd_apply_fused_s2d: NS * P = images x 4 h w, a sample group = one image or all of them");
+    return norm_bwd_apply_impl(dA, da_dt, x, x_dt, scale, shift, mean, rstd, gamma, sums2, dx, dx_dt, dgamma, dbeta, fwd_sums, fwd_pivot, dbias,
+                               NS, P, C, G, act, nrep, h, w, stream);
 }
 static int norm_bwd_apply_impl(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
                                const float* mean, const float* rstd, const float* gamma, const float* sums2, void* dx,
@@ -2154,10 +2158,11 @@ int phx_norm_bwd_reduce(const void* dA, int da_dt, const void* x, int x_dt, cons
     return norm_bwd_reduce_impl(dA, da_dt, x, x_dt, scale, shift, mean, rstd, sums2, NS, P, C, G, act, nrep, 0, 0, stream);
 }
 int phx_norm_bwd_reduce_s2d(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
-                            const float* mean, const float* rstd, float* sums2, int P, int C, int act, int nrep, int h, int w,
-                            void* stream) {
-    PHX_REQUIRE(h > 0 && w > 0 && P % (4 * h * w) == 0, PHX_E_SHAPE, "norm_bwd_reduce_s2d: P = images x 4 h w");
-    return norm_bwd_reduce_impl(dA, da_dt, x, x_dt, scale, shift, mean, rstd, sums2, 1, P, C, C, act, nrep, h, w, stream);
+                            const float* mean, const float* rstd, float* sums2, int NS, int P, int C, int G, int act, int nrep, int h,
+                            int w, void* stream) {
+    PHX_REQUIRE(h > 0 && w > 0 && ((size_t)NS * P) % ((size_t)4 * h * w) == 0 && (NS == 1 || P == 4 * h * w), PHX_E_SHAPE,
+                "norm_bwd_reduce_s2d: NS * P = images x 4 h w, a sample group = one image or all of them");
+    return norm_bwd_reduce_impl(dA, da_dt, x, x_dt, scale, shift, mean, rstd, sums2, NS, P, C, G, act, nrep, h, w, stream);
 }
 static int norm_bwd_reduce_impl(const void* dA, int da_dt, const void* x, int x_dt, const float* scale, const float* shift,
                                 const float* mean, const float* rstd, float* sums2, int NS, int P, int C, int G, int act,

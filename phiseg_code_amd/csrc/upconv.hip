@@ -50,8 +50,11 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
 // fp32 W[3][3][Ci][Co] -> packed bf16 Weff (forward: N = 4 Co rows, K = Ci; data gradient: N = Ci rows, K = 4 Co, taps flipped) and
 // packed bf16 W^T (W^T[kh][kw] = W[kw][kh]: the column frame's filter; forward and data-gradient forms)
 __global__ void k_upconv_pack(const float* __restrict__ w, unsigned short* __restrict__ ef, unsigned short* __restrict__ ed,
-                              unsigned short* __restrict__ tf, unsigned short* __restrict__ td, int Ci, int Co) {
+                              unsigned short* __restrict__ tf, unsigned short* __restrict__ td, const float* __restrict__ bias,
+                              float* __restrict__ bias4, int Ci, int Co) {
     const size_t ne = (size_t)9 * Ci * 4 * Co, nt = (size_t)9 * Ci * Co;
+    if (bias4 && blockIdx.x == 0)                     // the convolution bias for the 4 Cout packed columns (group / instance norm keep it)
+        for (int i = threadIdx.x; i < 4 * Co; i += blockDim.x) bias4[i] = bias[i % Co];
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < ne + nt; i += (size_t)gridDim.x * blockDim.x) {
         if (i < ne) {
             const int c4 = (int)(i % (4 * Co)), ci = (int)((i / (4 * Co)) % Ci), t = (int)(i / ((size_t)4 * Co * Ci));
@@ -293,10 +296,12 @@ extern "C" {
 int phx_upconv_supported(int B, int h, int w, int Cin, int Cout) {
     return (B > 0 && h >= 4 && w >= 4 && Cin % 32 == 0 && Cout % 32 == 0 && (size_t)B * 4 * h * w * (Cin > Cout ? Cin : Cout) < 2147483648ull) ? 1 : 0;
 }
-int phx_upconv_pack(const float* w_hwio, void* weff_fwd, void* weff_dgrad, void* wt_fwd, void* wt_dgrad, int Cin, int Cout, void* stream) {
+int phx_upconv_pack(const float* w_hwio, void* weff_fwd, void* weff_dgrad, void* wt_fwd, void* wt_dgrad, const float* bias, float* bias4,
+                    int Cin, int Cout, void* stream) {
     PHX_REQUIRE(w_hwio && weff_fwd && wt_fwd && Cin % 32 == 0 && Cout % 32 == 0, PHX_E_INVAL, "upconv_pack: Cin % 32 == 0, Cout % 32 == 0");
+    PHX_REQUIRE((bias == nullptr) == (bias4 == nullptr), PHX_E_INVAL, "upconv_pack: bias and bias4 go together");
     UPCONV_LAUNCH(k_upconv_pack, (size_t)9 * Cin * 5 * Cout, w_hwio, (unsigned short*)weff_fwd, (unsigned short*)weff_dgrad,
-                  (unsigned short*)wt_fwd, (unsigned short*)wt_dgrad, Cin, Cout);
+                  (unsigned short*)wt_fwd, (unsigned short*)wt_dgrad, bias, bias4, Cin, Cout);
 }
 int phx_upconv_fold_wgrad(const float* dweff, const float* dwt, float* dw_hwio, int Cin, int Cout, void* stream) {
     PHX_REQUIRE(dweff && dw_hwio, PHX_E_INVAL, "upconv_fold_wgrad: null argument");

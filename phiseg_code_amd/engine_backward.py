@@ -294,7 +294,7 @@ class BackwardLowering:
         if upc is not None:
             # phase form (upconv.py): y and everything downstream of it live in the PACKED pixel order; dA is a hi-res map -- the two
             # norm-backward passes read it through the space-to-depth permutation
-            assert isinstance(dA, Buf) and dA.dt == BF16 and sv["norm"] == "batch" and not sv.get("bn_small")
+            assert isinstance(dA, Buf) and dA.dt == BF16 and not sv.get("bn_small") and not sv.get("norm_small")
         if sv["norm"] is not None:
             if "y" not in sv or "mean" not in sv or (sv["norm"] == "batch" and not self.training):
                 raise NotImplementedError("backward through inference-mode batch norm is not on the hot path")
@@ -332,7 +332,7 @@ class BackwardLowering:
                 hg = dA if isinstance(dA, HeadGrad) else None
                 if upc is not None:
                     self._emit(Lb.norm_bwd_reduce_s2d, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr, sv["mean"].ptr,
-                               sv["rstd"].ptr, sums2.ptr, P, cout, act, nrep, H // 2, Wd // 2, S,
+                               sv["rstd"].ptr, sums2.ptr, NS, P, cout, Gn, act, nrep, H // 2, Wd // 2, S,
                                tag="bytes_norm_bwd_reduce", flops=float(dA.nbytes + y.nbytes))
                 elif hg is not None:
                     self._emit(Lb.norm_bwd_reduce_head, hg.dy.ptr, hg.w_ptr, hg.nout, y.ptr, sv["scale"].ptr, sv["shift"].ptr,
@@ -350,7 +350,9 @@ class BackwardLowering:
                 if upc is not None:
                     self._emit(Lb.norm_bwd_apply_fused_s2d, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr, sv["mean"].ptr,
                                sv["rstd"].ptr, self.store.ptr(nv["gamma"]), sums2.ptr, dY.ptr, dY.dt, self.store.grad_ptr(nv["gamma"]),
-                               self.store.grad_ptr(nv["beta"]), P, cout, act, nrep, H // 2, Wd // 2, S,
+                               self.store.grad_ptr(nv["beta"]), fs.ptr if fs is not None else None,
+                               sv["fpivot"].ptr if (fs is not None and sv.get("fpivot") is not None) else None,
+                               self.store.grad_ptr(b) if fs is not None else None, NS, P, cout, Gn, act, nrep, H // 2, Wd // 2, S,
                                tag="bytes_norm_bwd_apply", flops=float(dA.nbytes + y.nbytes + dY.nbytes))
                 elif hg is not None:
                     self._emit(Lb.norm_bwd_apply_fused_head, hg.dy.ptr, hg.w_ptr, hg.nout, y.ptr, sv["scale"].ptr, sv["shift"].ptr,
@@ -378,6 +380,8 @@ class BackwardLowering:
         if upc is not None:
             src = x.src                                  # the low-resolution tensor bilinear_upsample2D read
             h, w = H // 2, Wd // 2
+            if db is not None:                           # (not reached with the closed-form bias gradient of the norm backward; kept exact)
+                self._emit(Lb.channel_sum_accumulate, dY.ptr, dY.dt, db, B * H * Wd, cout, S)
             upconv.backward_prepare(self._emit, self._alloc, Lb, S, upc, dY, B, h, w, cout)
             # (filter gradients before or after the data gradients: same step time, measured three alternating pairs)
             upconv.backward_filters(self._emit, self._alloc, self._alloc_zeroed, Lb, S, upc, src, dY, dw, B, h, w, cin, cout)

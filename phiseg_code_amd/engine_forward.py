@@ -352,9 +352,9 @@ class ForwardLowering:
             if up is not None:
                 # y <- the hi-res pre-normalisation map in PACKED pixel order [B, h, w, (a, b, cout)]: the per-channel norm kernels do not
                 # care about the order of the pixels; the apply pass's output is permuted to hi-res below
-                assert act_code == 0 and stats_direct is None and stats_part is None and stats_atomic is None and bptr is None
+                assert act_code == 0 and stats_direct is None and stats_part is None and stats_atomic is None
                 st["upconv"] = upconv.forward(self._emit, self._alloc, Lb, S, up.src, wptr, wf, y, B, H // 2, Wd // 2, cin, cout,
-                                              need_dgrad=bool(bw and self.req.get(op.inputs[0].op.inputs[0], False)))
+                                              need_dgrad=bool(bw and self.req.get(op.inputs[0].op.inputs[0], False)), bias_ptr=bptr)
                 return
             if stats_atomic is not None:
                 mfma_conv(y, bptr, None, act_code, stats_atomic, 2, None, 0)
@@ -517,7 +517,7 @@ class ForwardLowering:
             hop = self._norm_head_consumer(op) if (y.dt == BF16 and out.dt == BF16 and up is None) else None
             if up is not None:
                 # y is in the packed pixel order, the readers of a want hi-res rows: the apply pass writes them (depth-to-space on the fly)
-                self._emit(Lb.norm_apply_fused_d2s, *apply_args[:16], P, cout, act, H // 2, Wd // 2, S, tag="bytes_norm_apply",
+                self._emit(Lb.norm_apply_fused_d2s, *apply_args[:16], NS, P, cout, Gn, act, H // 2, Wd // 2, S, tag="bytes_norm_apply",
                            flops=float(y.nbytes + out.nbytes))
             elif hop is not None and Lb.norm_head_supported(cout, hop.attrs["W"].shape[-1], y.dt, out.dt):
                 # the head rides on the apply pass (phx_norm_apply_fused_head): no pass of its own over a
@@ -675,7 +675,8 @@ class ForwardLowering:
         c = cons[0]
         a = c.attrs if c.type == "conv_unit" else None
         if (a is None or c.inputs[0] is not ot or a["ksize"] != 3 or a.get("transposed") is not None or a.get("general") is not None
-                or a["norm"] != "batch" or a["b"] is not None or self.op_lane.get(c) != self.op_lane.get(op) or c in self._lat):
+                or a["norm"] not in ("batch", "group", "instance") or (a["norm"] == "batch") != (a["b"] is None)
+                or self.op_lane.get(c) != self.op_lane.get(op) or c in self._lat):
             return None
         training = a["training"] if isinstance(a["training"], bool) else self.training
         cin, cout = a["W"].shape[-2], a["W"].shape[-1]

@@ -10,12 +10,12 @@ from . import runtime as rt
 BF16 = rt.BF16
 
 
-def _conv(emit, alloc, L, S, src, pack, dst, B, H, W, K, N, tag, algorithmic=True):
+def _conv(emit, alloc, L, S, src, pack, dst, B, H, W, K, N, tag, algorithmic=True, bias_ptr=None):
     """(algorithmic=False: a frame launch -- it re-computes pixels the phase convolution also produced, so its time counts for the family and
     its FLOPs do not: the layer's algorithmic FLOPs are the phase convolution's, 18 Cin Cout per hi-res pixel)"""
     nb = int(L.conv3x3_mfma_ws_bytes(B, H, W, K, N))
     ws = alloc((max(nb // 4, 1),), rt.F32) if nb else None
-    emit(L.conv3x3_mfma_bf16_ws, src.ptr, pack.ptr, dst.ptr, None, 0, None, ws.ptr if ws is not None else None, nb, B, H, W, K, N, S,
+    emit(L.conv3x3_mfma_bf16_ws, src.ptr, pack.ptr, dst.ptr, bias_ptr, 0, None, ws.ptr if ws is not None else None, nb, B, H, W, K, N, S,
          tag=tag, flops=18.0 * K * N * B * H * W if algorithmic else 0.0)
 
 
@@ -26,20 +26,22 @@ def _wgrad(emit, alloc, L, S, x, dy, dw_ptr, B, H, W, K, N, algorithmic=True):
          tag="conv3x3_mfma_wgrad", flops=18.0 * K * N * B * H * W if algorithmic else 0.0)
 
 
-def forward(emit, alloc, L, S, x, w_ptr, wf_w, y_packed, B, h, w, cin, cout, need_dgrad=True):
-    """y_packed <- conv3x3_SAME(resize_x2(x), W), frame included.  wf_w: the packed bf16 forward filter of W itself (the row frame's).
-    Returns what the backward sequence needs."""
+def forward(emit, alloc, L, S, x, w_ptr, wf_w, y_packed, B, h, w, cin, cout, need_dgrad=True, bias_ptr=None):
+    """y_packed <- conv3x3_SAME(resize_x2(x), W) [+ bias], frame included.  wf_w: the packed bf16 forward filter of W itself (the row
+    frame's).  Returns what the backward sequence needs."""
     ef = alloc((9 * cin * 4 * cout,), BF16)
     ed = alloc((9 * cin * 4 * cout,), BF16) if need_dgrad else None
     tf = alloc((9 * cin * cout,), BF16)
     td = alloc((9 * cin * cout,), BF16) if need_dgrad else None
-    emit(L.upconv_pack, w_ptr, ef.ptr, ed.ptr if ed is not None else None, tf.ptr, td.ptr if td is not None else None, cin, cout, S)
+    b4 = alloc((4 * cout,), rt.F32) if bias_ptr is not None else None
+    emit(L.upconv_pack, w_ptr, ef.ptr, ed.ptr if ed is not None else None, tf.ptr, td.ptr if td is not None else None, bias_ptr,
+         b4.ptr if b4 is not None else None, cin, cout, S)
     f_rows, f_cols = alloc((6 * B, 2 * w, cin), BF16), alloc((6 * B, 2 * h, cin), BF16)
     emit(L.upconv_frame_gather, x.ptr, f_rows.ptr, f_cols.ptr, B, h, w, cin, S)
-    _conv(emit, alloc, L, S, x, ef, y_packed, B, h, w, cin, 4 * cout, "conv3x3_mfma_fwd")
+    _conv(emit, alloc, L, S, x, ef, y_packed, B, h, w, cin, 4 * cout, "conv3x3_mfma_fwd", bias_ptr=b4.ptr if b4 is not None else None)
     fr, fc = alloc((6 * B, 2 * w, cout), BF16), alloc((6 * B, 2 * h, cout), BF16)
-    _conv(emit, alloc, L, S, f_rows, wf_w, fr, 1, 6 * B, 2 * w, cin, cout, "conv3x3_mfma_fwd", algorithmic=False)
-    _conv(emit, alloc, L, S, f_cols, tf, fc, 1, 6 * B, 2 * h, cin, cout, "conv3x3_mfma_fwd", algorithmic=False)
+    _conv(emit, alloc, L, S, f_rows, wf_w, fr, 1, 6 * B, 2 * w, cin, cout, "conv3x3_mfma_fwd", algorithmic=False, bias_ptr=bias_ptr)
+    _conv(emit, alloc, L, S, f_cols, tf, fc, 1, 6 * B, 2 * h, cin, cout, "conv3x3_mfma_fwd", algorithmic=False, bias_ptr=bias_ptr)
     emit(L.upconv_frame_scatter, fr.ptr, fc.ptr, y_packed.ptr, B, h, w, cout, S)
     return dict(ed=ed, td=td, f_rows=f_rows, f_cols=f_cols)
 

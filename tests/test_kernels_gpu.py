@@ -1950,7 +1950,7 @@ def test_conv3x3_mfma_pair_kernel(Ld, case, grid, policy):
     _mfma_case(L, case)
 
 
-@pytest.mark.parametrize("case", [(2, 16, 16, 32, 32), (3, 16, 32, 64, 32), (1, 32, 16, 96, 64), (5, 8, 8, 32, 32), (2, 4, 4, 32, 32)])
+@pytest.mark.parametrize("case", [(2, 16, 16, 32, 32, 0), (3, 16, 32, 64, 32, 1), (1, 32, 16, 96, 64, 0), (5, 8, 8, 32, 32, 1), (2, 4, 4, 32, 32, 0)])
 def test_upsample_conv_phase_form_vs_oracle(L, case):
     """bilinear_upsample2D -> conv2D 3x3 SAME (tfwrapper/layers.py:336-345 into :123) WITHOUT the up-sampled tensor (csrc/upconv.hip +
     the ordinary matrix launches, phiseg_code_amd/upconv.py): the forward map, the gradient with respect to the LOW-resolution input
@@ -1959,13 +1959,14 @@ def test_upsample_conv_phase_form_vs_oracle(L, case):
     value), 2e-3 for the fp32 filter gradient of bf16 operands whose frame part passes through bf16 up-sampled rows."""
     from oracle import tf1_ops as T
     from phiseg_code_amd import upconv
-    B, h, w, K, N = case
+    B, h, w, K, N, with_bias = case                     # (with_bias: the convolution bias group / instance norm layers keep, layers.py:126-132)
     rng = np.random.default_rng(5)
+    bias = torch.as_tensor(rng.standard_normal(N) * 0.3, dtype=torch.float32)
     x = rounded(rng.standard_normal((B, h, w, K)), BF16)
     W = torch.as_tensor(rng.standard_normal((3, 3, K, N)) / np.sqrt(9 * K), dtype=torch.float32)
     dy = rounded(rng.standard_normal((B, 2 * h, 2 * w, N)) * 0.1, BF16)
     xr, wr = x.clone().requires_grad_(True), W.double().clone().requires_grad_(True)
-    ref = T.conv2d_same(T.resize_bilinear_legacy(xr, 2 * h, 2 * w), wr)
+    ref = T.conv2d_same(T.resize_bilinear_legacy(xr, 2 * h, 2 * w), wr) + (bias.double() if with_bias else 0.0)
     ref.backward(dy)
     keep = []
 
@@ -1986,7 +1987,8 @@ def test_upsample_conv_phase_form_vs_oracle(L, case):
     wf, wg = alloc((9 * K * N,), BF16), alloc((9 * K * N,), BF16)
     L.pack_conv3x3_bf16(wd32.data_ptr(), wf.ptr, wg.ptr, K, N, S())
     yp = alloc((B, h, w, 4 * N), BF16)
-    ctx = upconv.forward(emit, alloc, L, S(), xb, wd32.data_ptr(), wf, yp, B, h, w, K, N)
+    bd = bias.cuda()
+    ctx = upconv.forward(emit, alloc, L, S(), xb, wd32.data_ptr(), wf, yp, B, h, w, K, N, bias_ptr=bd.data_ptr() if with_bias else None)
     yhi = alloc((B, 2 * h, 2 * w, N), BF16)
     L.depth_to_space2(yp.ptr, yhi.ptr, B, h, w, N, S())
     close(host(yhi.t).reshape(B, 2 * h, 2 * w, N), ref.detach().numpy(), 1.2e-2, "forward")
@@ -2006,50 +2008,57 @@ def test_upsample_conv_phase_form_vs_oracle(L, case):
     close(host(dx.t).reshape(B, h, w, K), xr.grad.numpy(), 1.2e-2, "gradient with respect to the low-resolution input")
 
 
-@pytest.mark.parametrize("case", [(3, 8, 8, 32), (2, 16, 4, 64), (5, 4, 12, 192)])
+@pytest.mark.parametrize("case", [(3, 8, 8, 32, "batch"), (2, 16, 4, 64, "batch"), (5, 4, 12, 192, "batch"), (3, 8, 4, 64, "group"),
+                                  (2, 4, 8, 32, "instance")])
 def test_norm_passes_with_the_pixel_permutation_of_the_phase_form(L, case):
-    """The batch-norm layer behind a phase-form convolution (csrc/upconv.hip): y is stored in the packed pixel order [B, h, w, (a, b)],
+    """The normalisation layer behind a phase-form convolution (csrc/upconv.hip): y is stored in the packed pixel order [B, h, w, (a, b)],
     its readers want hi-res rows.  phx_norm_apply_fused_d2s == phx_norm_apply_fused followed by phx_depth_to_space2 (bit for bit);
     phx_norm_bwd_reduce_s2d / phx_norm_bwd_apply_fused_s2d == phx_space_to_depth2 of dA followed by the plain passes (sums to 1e-5:
-    the reduction's atomics; dy to the last bf16 bit of that)."""
-    B, h, w, C = case
-    P = B * 4 * h * w
+    the reduction's atomics; dy and the closed-form bias gradient to the last bit of that).  Batch norm (one statistic over all images)
+    and group / instance norm (one per image, bias kept)."""
+    B, h, w, C, norm = case
+    NS, P, G = (1, B * 4 * h * w, C) if norm == "batch" else (B, 4 * h * w, C if norm == "instance" else C // 8)
+    NP = NS * P
     g = torch.Generator(device="cuda").manual_seed(3)
-    y = torch.randn(P, C, device="cuda", generator=g).to(torch.bfloat16)
+    y = torch.randn(NP, C, device="cuda", generator=g).to(torch.bfloat16)
     gamma = (1.0 + 0.2 * torch.randn(C, device="cuda", generator=g)).float()
     beta = (0.1 * torch.randn(C, device="cuda", generator=g)).float()
     dA_hi = torch.randn(B, 2 * h, 2 * w, C, device="cuda", generator=g).to(torch.bfloat16)
-
-    def stats():
-        sums, piv = torch.zeros(C * 2, device="cuda"), torch.zeros(C, device="cuda")
-        L.norm_stats(y.data_ptr(), BF16, sums.data_ptr(), piv.data_ptr(), 1, P, C, S())
-        return sums, piv
-    sums, piv = stats()
-    f = lambda: [torch.zeros(C, device="cuda") for _ in range(4)]
+    sums, piv = torch.zeros(NS * C * 2, device="cuda"), torch.zeros(NS * C, device="cuda")
+    L.norm_stats(y.data_ptr(), BF16, sums.data_ptr(), piv.data_ptr(), NS, P, C, S())
+    f = lambda: [torch.zeros(NS * G, device="cuda"), torch.zeros(NS * G, device="cuda"), torch.zeros(NS * C, device="cuda"), torch.zeros(NS * C, device="cuda")]
     m1, r1, sc1, sh1 = f()
     m2, r2, sc2, sh2 = f()
-    a_p, a_hi, a_ref = [torch.empty(P, C, device="cuda", dtype=torch.bfloat16) for _ in range(3)]
+    a_p, a_hi, a_ref = [torch.empty(NP, C, device="cuda", dtype=torch.bfloat16) for _ in range(3)]
     L.norm_apply_fused(y.data_ptr(), BF16, sums.data_ptr(), piv.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-3, a_p.data_ptr(), BF16,
-                       m1.data_ptr(), r1.data_ptr(), sc1.data_ptr(), sh1.data_ptr(), None, None, 0.0, 1, P, C, C, 1, S())
+                       m1.data_ptr(), r1.data_ptr(), sc1.data_ptr(), sh1.data_ptr(), None, None, 0.0, NS, P, C, G, 1, S())
     L.depth_to_space2(a_p.data_ptr(), a_ref.data_ptr(), B, h, w, C, S())
     L.norm_apply_fused_d2s(y.data_ptr(), BF16, sums.data_ptr(), piv.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-3, a_hi.data_ptr(), BF16,
-                           m2.data_ptr(), r2.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), None, None, 0.0, P, C, 1, h, w, S())
+                           m2.data_ptr(), r2.data_ptr(), sc2.data_ptr(), sh2.data_ptr(), None, None, 0.0, NS, P, C, G, 1, h, w, S())
     torch.cuda.synchronize()
     assert torch.equal(a_hi, a_ref) and torch.equal(sc1, sc2) and torch.equal(sh1, sh2)
     # backward
-    dA_p = torch.empty(P, C, device="cuda", dtype=torch.bfloat16)
+    dA_p = torch.empty(NP, C, device="cuda", dtype=torch.bfloat16)
     L.space_to_depth2(dA_hi.data_ptr(), dA_p.data_ptr(), B, h, w, C, S())
-    s_ref, s_got = torch.zeros(C * 2, device="cuda"), torch.zeros(C * 2, device="cuda")
+    s_ref, s_got = torch.zeros(NS * C * 2, device="cuda"), torch.zeros(NS * C * 2, device="cuda")
     L.norm_bwd_reduce(dA_p.data_ptr(), BF16, y.data_ptr(), BF16, sc1.data_ptr(), sh1.data_ptr(), m1.data_ptr(), r1.data_ptr(), s_ref.data_ptr(),
-                      1, P, C, C, 1, 1, S())
+                      NS, P, C, G, 1, 1, S())
     L.norm_bwd_reduce_s2d(dA_hi.data_ptr(), BF16, y.data_ptr(), BF16, sc1.data_ptr(), sh1.data_ptr(), m1.data_ptr(), r1.data_ptr(),
-                          s_got.data_ptr(), P, C, 1, 1, h, w, S())
+                          s_got.data_ptr(), NS, P, C, G, 1, 1, h, w, S())
     close(host(s_got), host(s_ref), 1e-5, "backward sums")
     dy_ref, dy_got = torch.empty_like(dA_p), torch.empty_like(dA_p)
-    dg1, db1, dg2, db2 = [torch.zeros(C, device="cuda") for _ in range(4)]
-    L.norm_bwd_apply_fused(dA_p.data_ptr(), BF16, y.data_ptr(), BF16, sc1.data_ptr(), sh1.data_ptr(), m1.data_ptr(), r1.data_ptr(),
-                           gamma.data_ptr(), s_ref.data_ptr(), dy_ref.data_ptr(), BF16, dg1.data_ptr(), db1.data_ptr(), 1, P, C, C, 1, 1, S())
+    dg1, db1, dg2, db2, dbias1, dbias2 = [torch.zeros(C, device="cuda") for _ in range(6)]
+    withb = norm != "batch"
+    L.norm_bwd_apply_fused_bias(dA_p.data_ptr(), BF16, y.data_ptr(), BF16, sc1.data_ptr(), sh1.data_ptr(), m1.data_ptr(), r1.data_ptr(),
+                                gamma.data_ptr(), s_ref.data_ptr(), dy_ref.data_ptr(), BF16, dg1.data_ptr(), db1.data_ptr(),
+                                sums.data_ptr() if withb else None, piv.data_ptr() if withb else None, dbias1.data_ptr() if withb else None,
+                                NS, P, C, G, 1, 1, S())
     L.norm_bwd_apply_fused_s2d(dA_hi.data_ptr(), BF16, y.data_ptr(), BF16, sc1.data_ptr(), sh1.data_ptr(), m1.data_ptr(), r1.data_ptr(),
-                               gamma.data_ptr(), s_ref.data_ptr(), dy_got.data_ptr(), BF16, dg2.data_ptr(), db2.data_ptr(), P, C, 1, 1, h, w, S())
+                               gamma.data_ptr(), s_ref.data_ptr(), dy_got.data_ptr(), BF16, dg2.data_ptr(), db2.data_ptr(),
+                               sums.data_ptr() if withb else None, piv.data_ptr() if withb else None, dbias2.data_ptr() if withb else None,
+                               NS, P, C, G, 1, 1, h, w, S())
     torch.cuda.synchronize()
-    assert torch.equal(dy_got, dy_ref) and torch.equal(dg1, dg2) and torch.equal(db1, db2)
+    assert torch.equal(dy_got, dy_ref)
+    close(host(dg2), host(dg1), 1e-6, "dgamma")          # (atomics over the sample groups)
+    close(host(db2), host(db1), 1e-6, "dbeta")
+    close(host(dbias2), host(dbias1), 1e-6, "dbias")
