@@ -72,6 +72,27 @@ int phx_conv2d_direct_wgrad_ordered(const void* x, int x_dt, const void* dy, int
                                     void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int ksize,
                                     void* stream);
 
+/* fp32 MFMA path (v_mfma_f32_32x32x2_f32: an fp32 fused-multiply-add chain on the matrix cores, the arithmetic class of
+ * phx_conv2d_direct -- only the summation order differs), 3x3 only, f32 tensors, N % 32 == 0, any K.  What the fp32 parity plan
+ * runs for tf.nn.conv2d (tfwrapper/layers.py:123) and the two gradients optimizer.minimize derives (phiseg_model.py:141).
+ * wpk is the packed fp32 filter [K8 / 8][9][N][8], K8 = K rounded up to a multiple of 8, zero-filled (element (tap t, row n,
+ * channel k) at (((k / 8) * 9 + t) * N + n) * 8 + k % 8), phx_conv3x3_f32_mfma_packed_floats(K, N) floats:
+ *   forward:  N = Cout, K = Cin, tap t = kh*3+kw;   data gradient: N = Cin, K = Cout, t = (2-kh)*3+(2-kw), call with x := dy.
+ * phx_pack_conv3x3_f32_multi: every filter of a step in one launch; descs_dev = device array of n records
+ * { const float* w_hwio; float* wpk_fwd; float* wpk_dgrad (nullable); int32 Cin, Cout }  (32 bytes each). */
+int phx_conv3x3_f32_mfma_supported(int B, int H, int W, int K, int N);
+size_t phx_conv3x3_f32_mfma_packed_floats(int K, int N);
+int phx_pack_conv3x3_f32_multi(const void* descs_dev, int n, void* stream);
+int phx_conv3x3_f32_mfma(const float* x, const float* wpk, const float* bias, float* y, int B, int H, int W, int K, int N,
+                         int act, void* stream);
+/* Filter / bias gradient of the same op (dw += ..., dbias += ...; dbias nullable), Cout % 32 == 0, any Cin: persistent blocks leave
+ * partial filters in `workspace` (phx_conv3x3_f32_mfma_wgrad_ws_bytes) and a second launch adds them in slice order -- a fixed
+ * summation order in every mode. */
+int phx_conv3x3_f32_mfma_wgrad_supported(int B, int H, int W, int Cin, int Cout);
+size_t phx_conv3x3_f32_mfma_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int with_bias);
+int phx_conv3x3_f32_mfma_wgrad(const float* x, const float* dy, float* dw_hwio, float* dbias, void* workspace,
+                               size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, void* stream);
+
 /* bf16 MFMA path (v_mfma_f32_32x32x16_bf16), 3x3 only, Cin % 32 == 0, Cout % 32 == 0.
  * wpk is the packed bf16 filter [K / 32][9][N][32] (element (tap t, row n, channel k) at (((k / 32) * 9 + t) * N + n) * 32
  * + k % 32: the slab of one 32-channel chunk is contiguous) written by phx_pack_conv3x3_bf16:

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libphx.so
-SRCS="runtime.hip elementwise.hip losses_opt.hip conv_direct.hip conv_mfma.hip conv_wgrad.hip conv_pp.hip conv_c32.hip heads.hip metrics.hip comm.hip augment.hip tconv.hip gconv.hip upconv.hip"
+SRCS="runtime.hip elementwise.hip losses_opt.hip conv_direct.hip conv_f32_mfma.hip conv_mfma.hip conv_wgrad.hip conv_pp.hip conv_c32.hip heads.hip metrics.hip comm.hip augment.hip tconv.hip gconv.hip upconv.hip"
 OBJS=""
 DOBJS=""
 for s in $SRCS; do

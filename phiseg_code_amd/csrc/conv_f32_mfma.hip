@@ -1,0 +1,481 @@
+// fp32 3x3 SAME convolution (tf.nn.conv2d, tfwrapper/layers.py:122-135), its data gradient and its filter gradient on the fp32
+// matrix instruction v_mfma_f32_32x32x2_f32: the arithmetic of the fp32 parity path -- the path that is pinned to the reference's
+// per-level logits and ELBO at 1e-4 -- on the matrix cores instead of the vector ALU (conv_direct.hip).  The instruction is a
+// k-ordered chain of fp32 fused multiply-adds (one rounding per product, no wider accumulator), i.e. the same arithmetic class as
+// the direct kernel; only the summation order differs.
+//
+// Peak: 64 FLOP/clk/SIMD = 157 TFLOP/s, a sixteenth of the bf16 rate, so one 64-cycle instruction pays for ~2 KB of LDS reads:
+// these kernels are bound by the matrix pipe alone and keep their staging simple (global -> registers -> LDS, next chunk's loads
+// in flight under the running chunk's matrix instructions; two blocks per CU).
+//
+// Implicit GEMM, im2col-free.  Forward / data gradient (one kernel; the data gradient is the forward kernel on the flipped,
+// transposed packed filter): M = 256 output pixels (tb images x th x tw), N = BN output channels, K walked in chunks of 8 channels x
+// 9 taps; operand fragments are 16-byte LDS reads (lane (i, h) holds channels 4h .. 4h + 3 of row i: four instructions per read).
+// Filter gradient: M = 32 input channels, N = 32 output channels per wave, K = pixels (pairs of horizontally adjacent pixels), nine
+// accumulators (one per tap) per wave; blocks are persistent over a slice of the pixel tiles and leave partial filters in a
+// workspace, summed in slice order by a second launch (always a fixed order: the same result in every run).
+#include "phx_common.h"
+
+namespace {
+
+struct F32Geo {
+    int tws, ths;                 // log2 of the tile width / height
+    int tb;                       // images per tile
+    int tiles_x, tiles_y, tiles_b;
+    int pw, ph, npatch;           // patch width, height, tb * ph * pw
+    int rows;                     // tb << (tws + ths)
+    unsigned mpw, mpp;            // v / pw == (v * mpw) >> 20, v / (ph * pw) == (v * mpp) >> 20 for v < 2048
+};
+
+static unsigned magic20(int d) {
+    unsigned m = ((1u << 20) + d - 1) / d;
+    for (unsigned v = 0; v < 2048; ++v)
+        if (((v * m) >> 20) != v / (unsigned)d) return 0;
+    return m;
+}
+
+// forward / data gradient: 256-row tiles
+static bool make_geo_fwd(int B, int H, int W, F32Geo* g) {
+    int tw = 1, th = 1;
+    g->tws = g->ths = 0;
+    while (tw < W && tw < 16) { tw <<= 1; g->tws++; }
+    while (th < H && th < 16) { th <<= 1; g->ths++; }
+    g->tb = 256 / (tw * th);
+    g->tiles_x = (W + tw - 1) / tw;
+    g->tiles_y = (H + th - 1) / th;
+    g->tiles_b = (B + g->tb - 1) / g->tb;
+    g->pw = tw + 2; g->ph = th + 2;
+    g->npatch = g->tb * g->ph * g->pw;
+    g->rows = 256;
+    g->mpw = magic20(g->pw); g->mpp = magic20(g->ph * g->pw);
+    return g->mpw && g->mpp && g->npatch <= 1024;
+}
+
+// filter gradient: tiles of at most 128 rows and at most 192 patch pixels
+static bool make_geo_wgrad(int B, int H, int W, F32Geo* g) {
+    int tw = 1, th = 1;
+    g->tws = g->ths = 0;
+    while (tw < W && tw < 16) { tw <<= 1; g->tws++; }
+    while (th < H && th < 8) { th <<= 1; g->ths++; }
+    g->pw = tw + 2; g->ph = th + 2;
+    int tb = 128 / (tw * th);
+    if (tb > 192 / (g->ph * g->pw)) tb = 192 / (g->ph * g->pw);
+    if (tb < 1) tb = 1;
+    if (tb > B) tb = B;
+    g->tb = tb;
+    g->tiles_x = (W + tw - 1) / tw;
+    g->tiles_y = (H + th - 1) / th;
+    g->tiles_b = (B + tb - 1) / tb;
+    g->npatch = tb * g->ph * g->pw;
+    g->rows = tb * tw * th;
+    g->mpw = magic20(g->pw); g->mpp = magic20(g->ph * g->pw);
+    return g->mpw && g->mpp && (g->rows & 1) == 0;
+}
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+// ---- packed filters ---------------------------------------------------------------------------------------------------------
+// wpk[K8 / 8][9][N][8]: element (tap t, row n, reduction channel k) at (((k / 8) * 9 + t) * N + n) * 8 + k % 8, K8 = K rounded up to
+// a multiple of 8 (zero-filled).  forward: N = Cout, K = Cin, t = kh * 3 + kw; data gradient: N = Cin, K = Cout, t = (2 - kh) * 3 + (2 - kw).
+struct PackF32Job {
+    const float* w;
+    float* wf;
+    float* wd;
+    int cin, cout;
+};
+
+__global__ __launch_bounds__(256) void k_pack_conv3x3_f32_multi(const PackF32Job* __restrict__ jobs) {
+    const PackF32Job j = jobs[blockIdx.y];
+    const int cin = j.cin, cout = j.cout;
+    const int k8f = (cin + 7) & ~7, k8d = (cout + 7) & ~7;
+    const size_t nf = (size_t)k8f * 9 * cout, nd = j.wd ? (size_t)k8d * 9 * cin : 0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nf + nd; e += (size_t)gridDim.x * 256) {
+        if (e < nf) {
+            const int kk = (int)(e & 7);
+            size_t r = e >> 3;
+            const int n = (int)(r % cout); r /= cout;
+            const int t = (int)(r % 9);
+            const int k = (int)(r / 9) * 8 + kk;
+            j.wf[e] = k < cin ? j.w[((size_t)t * cin + k) * cout + n] : 0.f;
+        } else {
+            const size_t d = e - nf;
+            const int kk = (int)(d & 7);
+            size_t r = d >> 3;
+            const int n = (int)(r % cin); r /= cin;
+            const int t = (int)(r % 9);
+            const int k = (int)(r / 9) * 8 + kk;
+            j.wd[d] = k < cout ? j.w[((size_t)(8 - t) * cin + n) * cout + k] : 0.f;
+        }
+    }
+}
+
+// ---- forward / data gradient -----------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_f32_mfma(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                              const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
+                                                              int K, int N, int act, F32Geo g) {
+    constexpr int NT = BN / 32;
+    constexpr int NWP = (9 * BN * 2 + 255) / 256;        // 16-byte filter pieces per thread and chunk
+    extern __shared__ float smem[];
+    const int npatch = g.npatch;
+    float* sp = smem;                        // [2][npatch][4]: plane h holds channels 4h .. 4h + 3 of the chunk
+    float* sw = smem + 8 * npatch;           // [9][2][BN][4]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int tw = 1 << g.tws, th = 1 << g.ths, pw = g.pw, ph = g.ph;
+    int t = blockIdx.x;
+    const int tx0 = (t % g.tiles_x) << g.tws; t /= g.tiles_x;
+    const int ty0 = (t % g.tiles_y) << g.ths; t /= g.tiles_y;
+    const int b0 = t * g.tb;
+    const int n0 = blockIdx.y * BN;
+
+    int pbase[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int r = 64 * wv + 32 * mi + l31;
+        const int lx = r & (tw - 1), ly = (r >> g.tws) & (th - 1), bi = r >> (g.tws + g.ths);
+        pbase[mi] = (bi * ph + ly) * pw + lx;
+    }
+    // this thread's pieces of the patch: fixed over the chunks
+    int goff[8];
+    const int np2 = npatch * 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = tid + 256 * j;
+        goff[j] = -1;
+        if (i < np2) {
+            const unsigned pp = (unsigned)i >> 1;
+            const int bi = (int)((pp * g.mpp) >> 20);
+            const unsigned rem = pp - bi * ph * pw;
+            const int py = (int)((rem * g.mpw) >> 20);
+            const int px = (int)rem - py * pw;
+            const int gy = ty0 + py - 1, gx = tx0 + px - 1, gb = b0 + bi;
+            if (gb < B && gy >= 0 && gy < H && gx >= 0 && gx < W) goff[j] = ((gb * H + gy) * W + gx) * K;
+        }
+    }
+    const bool kvec = (K & 3) == 0;
+    const int nkc = (K + 7) >> 3;
+    f32x4 rp[8], rw[NWP];
+
+    auto load_chunk = [&](int kc) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = tid + 256 * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i < np2 && goff[j] >= 0) {
+                const int c = kc * 8 + (i & 1) * 4;
+                const float* p = x + (size_t)goff[j] + c;
+                if (kvec) {
+                    if (c < K) v = *(const f32x4*)p;
+                } else {
+                    if (c + 0 < K) v[0] = p[0];
+                    if (c + 1 < K) v[1] = p[1];
+                    if (c + 2 < K) v[2] = p[2];
+                    if (c + 3 < K) v[3] = p[3];
+                }
+            }
+            rp[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NWP; ++j) {
+            const int i = tid + 256 * j;
+            if (i < 9 * BN * 2) {
+                const int t9 = i / (BN * 2), rem = i % (BN * 2);
+                rw[j] = *(const f32x4*)(wpk + (((size_t)kc * 9 + t9) * N + n0 + (rem >> 1)) * 8 + (rem & 1) * 4);
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = tid + 256 * j;
+            if (i < np2) *(f32x4*)(sp + ((size_t)(i & 1) * npatch + (i >> 1)) * 4) = rp[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NWP; ++j) {
+            const int i = tid + 256 * j;
+            if (i < 9 * BN * 2) {
+                const int t9 = i / (BN * 2), rem = i % (BN * 2);
+                *(f32x4*)(sw + ((t9 * 2 + (rem & 1)) * BN + (rem >> 1)) * 4) = rw[j];
+            }
+        }
+    };
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    for (int kc = 0; kc < nkc; ++kc) {
+        if (kc + 1 < nkc) load_chunk(kc + 1);            // in flight under this chunk's matrix instructions
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) {
+            const int toff = (t9 / 3) * pw + (t9 % 3);
+            f32x4 a[2], b[NT];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) a[mi] = *(const f32x4*)(sp + ((size_t)hh * npatch + pbase[mi] + toff) * 4);
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) b[ni] = *(const f32x4*)(sw + ((t9 * 2 + hh) * BN + ni * 32 + l31) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma32(a[mi][j], b[ni][j], acc[mi][ni]);
+        }
+        __syncthreads();
+        if (kc + 1 < nkc) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+    // epilogue: lane holds column l31 of rows (e & 3) + 8 (e >> 2) + 4 hh of each 32 x 32 block
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        const int n = n0 + ni * 32 + l31;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = 64 * wv + 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const int ox = tx0 + (r & (tw - 1)), oy = ty0 + ((r >> g.tws) & (th - 1)), ob = b0 + (r >> (g.tws + g.ths));
+                if (ox < W && oy < H && ob < B) y[((size_t)(ob * H + oy) * W + ox) * N + n] = act_fwd(acc[mi][ni][e] + bv, act);
+            }
+    }
+}
+
+// ---- filter gradient --------------------------------------------------------------------------------------------------------
+// Block = CIW x COW sub-blocks of 32 x 32 (ci x co), PS = 4 / (CIW COW) waves share a sub-block and split the tile's pixel pairs.
+// ws[slice * PS + ps][9][Cin][Cout] (every element written exactly once), wsb[slice][Cout] column sums of dy (bias gradient).
+template <int CIW, int COW>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_f32_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ ws, float* __restrict__ wsb, int B, int H, int W,
+                                                               int Cin, int Cout, int ciblocks, int tps, int ntiles, F32Geo g) {
+    constexpr int PS = 4 / (CIW * COW), CIB = 32 * CIW, COB = 32 * COW;
+    extern __shared__ float smem[];
+    const int npatch = g.npatch, rows = g.rows;
+    float* sx = smem;                        // [npatch][CIB]
+    float* sd = smem + (size_t)npatch * CIB; // [rows][COB]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int ps = wv / (CIW * COW), cis = (wv % (CIW * COW)) % CIW, cos = (wv % (CIW * COW)) / CIW;
+    const int ci0 = (blockIdx.y % ciblocks) * CIB, co0 = (blockIdx.y / ciblocks) * COB;
+    const int tw = 1 << g.tws, th = 1 << g.ths, pw = g.pw, ph = g.ph;
+    const int slice = blockIdx.x;
+    const int t_lo = slice * tps, t_hi = min(ntiles, t_lo + tps);
+    const bool cvec = (Cin & 3) == 0;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t9][e] = 0.f;
+    float dbacc = 0.f;
+    const bool do_bias = wsb != nullptr && (blockIdx.y % ciblocks) == 0;
+    const int npairs = rows >> 1;
+    const int j_lo = ps * npairs / PS, j_hi = (ps + 1) * npairs / PS;
+
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+        int t = tile;
+        const int tx0 = (t % g.tiles_x) << g.tws; t /= g.tiles_x;
+        const int ty0 = (t % g.tiles_y) << g.ths; t /= g.tiles_y;
+        const int b0 = t * g.tb;
+        __syncthreads();
+        for (int i = tid; i < npatch * (CIB / 4); i += 256) {
+            const unsigned pp = (unsigned)i / (CIB / 4);
+            const int c = ci0 + (i % (CIB / 4)) * 4;
+            const int bi = (int)((pp * g.mpp) >> 20);
+            const unsigned rem = pp - bi * ph * pw;
+            const int py = (int)((rem * g.mpw) >> 20);
+            const int px = (int)rem - py * pw;
+            const int gy = ty0 + py - 1, gx = tx0 + px - 1, gb = b0 + bi;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gb < B && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const float* p = x + ((size_t)(gb * H + gy) * W + gx) * Cin + c;
+                if (cvec) {
+                    if (c < Cin) v = *(const f32x4*)p;
+                } else {
+                    if (c + 0 < Cin) v[0] = p[0];
+                    if (c + 1 < Cin) v[1] = p[1];
+                    if (c + 2 < Cin) v[2] = p[2];
+                    if (c + 3 < Cin) v[3] = p[3];
+                }
+            }
+            *(f32x4*)(sx + (size_t)i * 4) = v;
+        }
+        for (int i = tid; i < rows * (COB / 4); i += 256) {
+            const int r = i / (COB / 4);
+            const int c = co0 + (i % (COB / 4)) * 4;
+            const int ox = tx0 + (r & (tw - 1)), oy = ty0 + ((r >> g.tws) & (th - 1)), ob = b0 + (r >> (g.tws + g.ths));
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ox < W && oy < H && ob < B && c < Cout) v = *(const f32x4*)(dy + ((size_t)(ob * H + oy) * W + ox) * Cout + c);
+            *(f32x4*)(sd + (size_t)i * 4) = v;
+        }
+        __syncthreads();
+        for (int j = j_lo; j < j_hi; ++j) {
+            const int r = 2 * j + hh;
+            const int lx = r & (tw - 1), ly = (r >> g.tws) & (th - 1), bi = r >> (g.tws + g.ths);
+            const float* pa = sx + (size_t)((bi * ph + ly) * pw + lx) * CIB + cis * 32 + l31;
+            const float bv = sd[(size_t)r * COB + cos * 32 + l31];
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) acc[t9] = mfma32(pa[(size_t)((t9 / 3) * pw + (t9 % 3)) * CIB], bv, acc[t9]);
+        }
+        if (do_bias && tid < COB)
+            for (int r = 0; r < rows; ++r) dbacc += sd[(size_t)r * COB + tid];
+    }
+    float* wo = ws + (size_t)(slice * PS + ps) * 9 * Cin * Cout;
+    const int co = co0 + cos * 32 + l31;
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ci = ci0 + cis * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            if (ci < Cin && co < Cout) wo[((size_t)t9 * Cin + ci) * Cout + co] = acc[t9][e];
+        }
+    if (do_bias && tid < COB && co0 + tid < Cout) wsb[(size_t)slice * Cout + co0 + tid] = dbacc;
+}
+
+// dst[e] += sum over the slices, in slice order
+__global__ __launch_bounds__(256) void k_f32_wgrad_reduce(const float* __restrict__ ws, int nslice, size_t n, float* __restrict__ dst,
+                                                          const float* __restrict__ wsb, int nslice_b, int nb, float* __restrict__ db) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < n) {
+        float s = 0.f;
+        for (int k = 0; k < nslice; ++k) s += ws[(size_t)k * n + e];
+        dst[e] += s;
+    } else if (db != nullptr && e - n < (size_t)nb) {
+        const size_t c = e - n;
+        float s = 0.f;
+        for (int k = 0; k < nslice_b; ++k) s += wsb[(size_t)k * nb + c];
+        db[c] += s;
+    }
+}
+
+struct WgradPlan {
+    F32Geo g;
+    int ciw, cow, ps, ciblocks, coblocks, ntiles, tps, nslice;
+    size_t lds, ws_floats, wsb_floats;
+};
+
+static bool plan_wgrad(int B, int H, int W, int Cin, int Cout, bool with_bias, WgradPlan* p) {
+    if (!make_geo_wgrad(B, H, W, &p->g)) return false;
+    p->ciw = Cin > 32 ? 2 : 1;
+    p->cow = Cout > 32 ? 2 : 1;
+    p->ps = 4 / (p->ciw * p->cow);
+    p->ciblocks = (Cin + 32 * p->ciw - 1) / (32 * p->ciw);
+    p->coblocks = (Cout + 32 * p->cow - 1) / (32 * p->cow);
+    p->ntiles = p->g.tiles_x * p->g.tiles_y * p->g.tiles_b;
+    int want = 1024 / (p->ciblocks * p->coblocks);          // ~4 blocks per CU in all: two resident, two queued
+    if (want < 1) want = 1;
+    if (want > 256) want = 256;                              // bound the workspace (256 partial filters)
+    if (want > p->ntiles) want = p->ntiles;
+    p->tps = (p->ntiles + want - 1) / want;
+    p->nslice = (p->ntiles + p->tps - 1) / p->tps;
+    p->lds = ((size_t)p->g.npatch * 32 * p->ciw + (size_t)p->g.rows * 32 * p->cow) * 4;
+    p->ws_floats = (size_t)p->nslice * p->ps * 9 * Cin * Cout;
+    p->wsb_floats = with_bias ? (size_t)p->nslice * Cout : 0;
+    return p->lds <= 160 * 1024;
+}
+
+}  // namespace
+
+extern "C" {
+
+int phx_conv3x3_f32_mfma_supported(int B, int H, int W, int K, int N) {
+    F32Geo g;
+    return (B >= 1 && H >= 2 && W >= 2 && K >= 1 && N >= 32 && N % 32 == 0 && (size_t)B * H * W * (K > N ? K : N) < (1u << 31)
+            && make_geo_fwd(B, H, W, &g)) ? 1 : 0;
+}
+
+size_t phx_conv3x3_f32_mfma_packed_floats(int K, int N) { return (size_t)((K + 7) & ~7) * 9 * N; }
+
+int phx_pack_conv3x3_f32_multi(const void* descs_dev, int n, void* stream) {
+    PHX_REQUIRE(descs_dev != nullptr && n >= 1, PHX_E_INVAL, "phx_pack_conv3x3_f32_multi: no jobs");
+    k_pack_conv3x3_f32_multi<<<dim3(48, n), 256, 0, (hipStream_t)stream>>>((const PackF32Job*)descs_dev);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_conv3x3_f32_mfma(const float* x, const float* wpk, const float* bias, float* y, int B, int H, int W, int K, int N, int act,
+                         void* stream) {
+    PHX_REQUIRE(x && wpk && y, PHX_E_INVAL, "phx_conv3x3_f32_mfma: null pointer");
+    PHX_REQUIRE(phx_conv3x3_f32_mfma_supported(B, H, W, K, N), PHX_E_SHAPE, "phx_conv3x3_f32_mfma: N must be a multiple of 32");
+    F32Geo g;
+    make_geo_fwd(B, H, W, &g);
+    const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
+    hipStream_t s = (hipStream_t)stream;
+    if (N % 64 == 0) {
+        const size_t lds = ((size_t)8 * g.npatch + 9 * 2 * 64 * 4) * 4;
+        static bool attr = false;
+        if (!attr) {
+            PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_f32_mfma<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+        k_conv3x3_f32_mfma<64><<<dim3(ntiles, N / 64), 256, lds, s>>>(x, wpk, bias, y, B, H, W, K, N, act, g);
+    } else {
+        const size_t lds = ((size_t)8 * g.npatch + 9 * 2 * 32 * 4) * 4;
+        static bool attr = false;
+        if (!attr) {
+            PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_f32_mfma<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+        k_conv3x3_f32_mfma<32><<<dim3(ntiles, N / 32), 256, lds, s>>>(x, wpk, bias, y, B, H, W, K, N, act, g);
+    }
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+int phx_conv3x3_f32_mfma_wgrad_supported(int B, int H, int W, int Cin, int Cout) {
+    WgradPlan p;
+    return (B >= 1 && H >= 2 && W >= 2 && Cin >= 1 && Cout >= 32 && Cout % 32 == 0
+            && (size_t)B * H * W * (Cin > Cout ? Cin : Cout) < (1u << 31) && plan_wgrad(B, H, W, Cin, Cout, true, &p)) ? 1 : 0;
+}
+
+size_t phx_conv3x3_f32_mfma_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int with_bias) {
+    WgradPlan p;
+    if (!plan_wgrad(B, H, W, Cin, Cout, with_bias != 0, &p)) return 0;
+    return (p.ws_floats + p.wsb_floats) * 4;
+}
+
+int phx_conv3x3_f32_mfma_wgrad(const float* x, const float* dy, float* dw_hwio, float* dbias, void* workspace, size_t workspace_bytes,
+                               int B, int H, int W, int Cin, int Cout, void* stream) {
+    PHX_REQUIRE(x && dy && dw_hwio && workspace, PHX_E_INVAL, "phx_conv3x3_f32_mfma_wgrad: null pointer");
+    PHX_REQUIRE(phx_conv3x3_f32_mfma_wgrad_supported(B, H, W, Cin, Cout), PHX_E_SHAPE, "phx_conv3x3_f32_mfma_wgrad: unsupported shape");
+    WgradPlan p;
+    plan_wgrad(B, H, W, Cin, Cout, dbias != nullptr, &p);
+    PHX_REQUIRE(workspace_bytes >= (p.ws_floats + p.wsb_floats) * 4, PHX_E_INVAL, "phx_conv3x3_f32_mfma_wgrad: workspace too small");
+    float* ws = (float*)workspace;
+    float* wsb = dbias ? ws + p.ws_floats : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(p.nslice, p.ciblocks * p.coblocks);
+#define PHX_F32_WGRAD(CIW, COW)                                                                                                      \
+    do {                                                                                                                             \
+        static bool attr = false;                                                                                                    \
+        if (!attr) {                                                                                                                 \
+            PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_f32_wgrad<CIW, COW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                              160 * 1024));                                                                          \
+            attr = true;                                                                                                             \
+        }                                                                                                                            \
+        k_conv3x3_f32_wgrad<CIW, COW><<<grid, 256, p.lds, s>>>(x, dy, ws, wsb, B, H, W, Cin, Cout, p.ciblocks, p.tps, p.ntiles, p.g); \
+    } while (0)
+    if (p.ciw == 2 && p.cow == 2) PHX_F32_WGRAD(2, 2);
+    else if (p.ciw == 1 && p.cow == 2) PHX_F32_WGRAD(1, 2);
+    else if (p.ciw == 2 && p.cow == 1) PHX_F32_WGRAD(2, 1);
+    else PHX_F32_WGRAD(1, 1);
+#undef PHX_F32_WGRAD
+    PHX_CHECK_LAUNCH();
+    const size_t n = (size_t)9 * Cin * Cout;
+    const size_t tot = n + (dbias ? (size_t)Cout : 0);
+    k_f32_wgrad_reduce<<<(unsigned)((tot + 255) / 256), 256, 0, s>>>(ws, p.nslice * p.ps, n, dw_hwio, wsb, p.nslice, Cout, dbias);
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+}  // extern "C"

@@ -193,6 +193,7 @@ class Plan(ForwardLowering, BackwardLowering):
         self._headw_jobs = {}         # deferred 1x1-head filter gradients by (x dtype, nout): (x, dy, dw, db, npix, C, PL, chunk, grid, lds)
         self._wgr_jobs = []           # deferred filter-gradient reductions: (ws, dw, nslice, Cin, Cout, tci, tco, gx, gy)
         self._pack_jobs = []          # (w, wpk_fwd, wpk_dgrad, Cin, Cin_pad, Cout): ONE multi-filter pack launch per run
+        self._wpk32, self._pack32_jobs = {}, []     # fp32 plans: packed fp32 filters of the fp32 matrix kernels, [w, wpk_fwd, wpk_dgrad, Cin, Cout]
         self._bninfer_jobs = []       # (gamma, beta, moving_mean, moving_var, scale, shift, C, eps): ONE launch per run
         self._zarena = torch.zeros(8 << 20, dtype=torch.float32, device=_device())     # 32 MB of per-step accumulators
         self._zused = 0
@@ -518,6 +519,14 @@ class Plan(ForwardLowering, BackwardLowering):
             self._pack_desc = torch.from_numpy(rec.view(np.uint8).copy()).to(_device())
             self._keep.append(self._pack_desc)
             self.launches[1] = (self.L.pack_conv3x3_bf16_multi, (self._pack_desc.data_ptr(), len(self._pack_jobs), self.stream))
+        if self._pack32_jobs:         # fp32 plans: the packed fp32 filters of csrc/conv_f32_mfma.hip, same slot (a plan packs one kind)
+            assert not self._pack_jobs, "a plan packs either bf16 or fp32 filters"
+            rec = np.zeros(len(self._pack32_jobs), dtype=[("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("cin", "<i4"), ("cout", "<i4")])
+            for i, j in enumerate(self._pack32_jobs):
+                rec[i] = tuple(j)
+            self._pack_desc = torch.from_numpy(rec.view(np.uint8).copy()).to(_device())
+            self._keep.append(self._pack_desc)
+            self.launches[1] = (self.L.pack_conv3x3_f32_multi, (self._pack_desc.data_ptr(), len(self._pack32_jobs), self.stream))
         if self._bninfer_jobs:        # slot 2: scale / shift of every inference-mode batch-norm layer in one launch
             rec = np.zeros(len(self._bninfer_jobs), dtype=[("gamma", "<u8"), ("beta", "<u8"), ("mm", "<u8"), ("mv", "<u8"),
                                                             ("scale", "<u8"), ("shift", "<u8"), ("C", "<i4"), ("eps", "<f4")])

@@ -491,6 +491,14 @@ class BackwardLowering:
                     self._emit(unpad[0], *unpad[1], S)
             if db is not None:
                 self._emit(Lb.channel_sum_accumulate, dY.ptr, dY.dt, db, B * H * Wd, cout, S)
+        elif (sv.get("f32m") and k == 3 and x.dt == F32 and dY.dt == F32 and isinstance(x, Buf)
+              and Lb.conv3x3_f32_mfma_wgrad_supported(B, H, Wd, cin, cout)):
+            # fp32 plans: the filter gradient on the fp32 matrix instruction; partial filters in a workspace, summed in slice order
+            # (a fixed order in every mode)
+            wsb = int(Lb.conv3x3_f32_mfma_wgrad_ws_bytes(B, H, Wd, cin, cout, 1 if db is not None else 0))
+            ws = self._alloc((wsb // 4,), F32)
+            self._emit(Lb.conv3x3_f32_mfma_wgrad, x.ptr, dY.ptr, dw, db, ws.ptr, wsb, B, H, Wd, cin, cout, S,
+                       tag="conv3x3_f32_mfma_wgrad", flops=18.0 * cin * cout * B * H * Wd)
         else:
             if _DETERMINISTIC:
                 # ordered partial filters: the fixed summation order at full parallelism (the plain entry point's deterministic
@@ -553,6 +561,14 @@ class BackwardLowering:
                     self._emit(Lb.conv3x3_mfma_bf16_ws, dY.ptr, wd.ptr, g.ptr, None, 0, None, ws.ptr if ws else None, wsb,
                                B, H, Wd, cout, cin, S, tag="conv3x3_mfma_dgrad", flops=18.0 * cin * cout * B * H * Wd)
                 self._add_grad(xin, write_fn=wr_mfma)
+            elif sv.get("f32m") and cin % 32 == 0 and dY.dt == F32 and self._wpk32.get(W.name, (None, None))[1] is not None:
+                wd32 = self._wpk32[W.name][1]
+
+                def wr_f32m(g):
+                    assert g.dt == F32
+                    self._emit(Lb.conv3x3_f32_mfma, dY.ptr, wd32.ptr, None, g.ptr, B, H, Wd, cout, cin, 0, S,
+                               tag="conv3x3_f32_mfma_dgrad", flops=18.0 * cin * cout * B * H * Wd)
+                self._add_grad(xin, write_fn=wr_f32m)
             else:
                 self._add_grad(xin, write_fn=lambda g: self._emit(
                     Lb.conv2d_direct, dY.ptr, dY.dt, self.store.ptr(W), None, g.ptr, g.dt, B, H, Wd, cin, cout, k, 0,

@@ -110,6 +110,20 @@ class ForwardLowering:
             self._pack_jobs.append((self.store.ptr(W), wf.ptr, wd.ptr, cin, cin, cout))
         return self._wpk[W.name]
 
+    def _packed_f32(self, W, need_dgrad):
+        """fp32 packed copies of a 3x3 filter for the fp32 matrix kernels (csrc/conv_f32_mfma.hip: [K8 / 8][9][N][8]), refreshed at the
+        head of every run; the data-gradient copy only where a data gradient is taken."""
+        kh, kw, cin, cout = W.shape
+        rec = self._wpk32.get(W.name)
+        if rec is None:
+            wf = self._alloc((int(self.L.conv3x3_f32_mfma_packed_floats(cin, cout)),), F32)
+            rec = self._wpk32[W.name] = [wf, None, len(self._pack32_jobs)]
+            self._pack32_jobs.append([self.store.ptr(W), wf.ptr, 0, cin, cout])
+        if need_dgrad and rec[1] is None:
+            rec[1] = self._alloc((int(self.L.conv3x3_f32_mfma_packed_floats(cout, cin)),), F32)
+            self._pack32_jobs[rec[2]][2] = rec[1].ptr
+        return rec[0], rec[1]
+
     def _fw_tconv_unit(self, op, bw):
         """tf.nn.conv2d_transpose -> [bias] -> [norm] -> act (tfwrapper/layers.py:197-258) on the direct kernels of tconv.hip;
         the normalisation runs as statistics pass + fused apply on the up-sampled tensor."""
@@ -342,6 +356,10 @@ class ForwardLowering:
 
         head1x1 = (k == 1 and out.dt == F32 and cout in (2, 4, 6, 8) and a["norm"] is None and b is not None)
         st["head1x1"] = head1x1
+        # fp32 plans: the 3x3 convolution on the fp32 matrix instruction (same arithmetic class as the direct kernel: an fp32 FMA chain)
+        f32m = bool(not mfma and self.act_dt == F32 and x.dt == F32 and out.dt == F32 and k == 3 and cout % 32 == 0 and _f32_mfma_enabled()
+                    and isinstance(x, Buf) and Lb.conv3x3_f32_mfma_supported(B, H, Wd, cin, cout))
+        st["f32m"] = f32m
 
         def tiles_fn():
             if dual is not None:
@@ -364,6 +382,11 @@ class ForwardLowering:
                 wsb = int(Lb.conv3x3_mfma_ws_bytes(B, H, Wd, cin_eff, cout)) if stats_part is None else 0
                 ws = self._alloc((wsb // 4,), F32) if wsb else None          # split-K slices (small maps)
                 mfma_conv(y, bptr, None, act_code, stats_part, 1 if stats_part is not None else 0, ws, wsb)
+            elif f32m and stats_direct is None and y.dt == F32:
+                need_dgrad = bool(bw and self.req.get(op.inputs[0], False) and cin % 32 == 0)
+                w32, _ = self._packed_f32(W, need_dgrad)
+                self._emit(Lb.conv3x3_f32_mfma, x.ptr, w32.ptr, bptr, y.ptr, B, H, Wd, cin, cout, act_code, S,
+                           tag="conv3x3_f32_mfma_fwd", flops=18.0 * cin * cout * B * H * Wd)
             else:
                 self._emit(Lb.conv2d_direct, x.ptr, x.dt, wptr, bptr, y.ptr, y.dt, B, H, Wd, cin, cout, k, act_code,
                            0, stats_direct.ptr if stats_direct is not None else None, S)

@@ -176,6 +176,79 @@ def test_conv2d_direct_fwd_dgrad_wgrad(L, case):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
+F32_MFMA_CASES = [
+    # B, H, W, Cin, Cout, act, bias -- csrc/conv_f32_mfma.hip: every tile geometry (16 x 16, whole small maps with several images per tile,
+    # partial tiles of the 192-type maps), narrow inputs (Cin = 1 / 2 / 3 / 6: scalar loader), 32- and 64-wide channel blocks, all four
+    # wave layouts of the filter gradient
+    (2, 16, 16, 32, 32, "identity", False),
+    (1, 32, 32, 64, 64, "relu", True),
+    (3, 8, 8, 64, 128, "identity", False),
+    (5, 4, 4, 192, 64, "relu", True),
+    (40, 2, 2, 32, 96, "identity", False),
+    (2, 12, 12, 3, 64, "softplus", True),
+    (3, 3, 3, 64, 32, "identity", False),
+    (1, 24, 24, 1, 32, "identity", True),
+    (2, 6, 6, 2, 192, "relu", False),
+    (1, 48, 48, 96, 32, "identity", False),
+    (2, 64, 64, 128, 192, "relu", False),
+    (1, 128, 128, 32, 32, "identity", True),
+    (3, 16, 32, 6, 160, "identity", False),
+]
+
+
+@pytest.mark.parametrize("case", F32_MFMA_CASES)
+def test_conv3x3_f32_mfma_fwd_dgrad_wgrad(L, case):
+    """The fp32 matrix-instruction convolution of the fp32 parity path (v_mfma_f32_32x32x2_f32: an fp32 FMA chain) against the oracle's
+    conv2d_same and its autograd in float64 -- forward with bias / activation, data gradient (the same kernel on the flipped,
+    transposed packed filter), filter and bias gradient (accumulated onto what dw / db hold; bit-identical from call to call: the
+    partial filters are summed in slice order)."""
+    B, H, W, Cin, Cout, act, use_bias = case
+    x = RNG.standard_normal((B, H, W, Cin))
+    w = RNG.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)
+    b = RNG.standard_normal(Cout) * 0.3
+    xr = rounded(x, F32).requires_grad_(True)
+    wr = torch.as_tensor(w, dtype=torch.float32).double().requires_grad_(True)
+    br = torch.as_tensor(b, dtype=torch.float32).double().requires_grad_(True)
+    yr = oracle_conv(xr, wr, br if use_bias else None, act)
+    xd, wd, bd = dev(x), dev(w), dev(b)
+    assert L.conv3x3_f32_mfma_supported(B, H, W, Cin, Cout)
+    wf = torch.empty(int(L.conv3x3_f32_mfma_packed_floats(Cin, Cout)), dtype=torch.float32).cuda()
+    dgrad = Cin % 32 == 0
+    wdg = torch.empty(int(L.conv3x3_f32_mfma_packed_floats(Cout, Cin)), dtype=torch.float32).cuda() if dgrad else None
+    rec = np.zeros(1, dtype=[("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("cin", "<i4"), ("cout", "<i4")])
+    rec[0] = (wd.data_ptr(), wf.data_ptr(), wdg.data_ptr() if dgrad else 0, Cin, Cout)
+    desc = torch.from_numpy(rec.view(np.uint8).copy()).cuda()
+    L.pack_conv3x3_f32_multi(desc.data_ptr(), 1, S())
+    y = torch.empty(B, H, W, Cout, dtype=torch.float32).cuda()
+    L.conv3x3_f32_mfma(xd.data_ptr(), wf.data_ptr(), bd.data_ptr() if use_bias else None, y.data_ptr(), B, H, W, Cin, Cout, ACT[act], S())
+    close(host(y), yr.detach().numpy(), 1e-5, "fwd")
+    dy = RNG.standard_normal((B, H, W, Cout))
+    dyr = rounded(dy, F32)
+    pre = T.conv2d_same(xr, wr) + (br.reshape(1, 1, 1, -1) if use_bias else 0.0)
+    (pre * dyr).sum().backward()
+    dyd = dev(dy)
+    if dgrad:
+        dx = torch.empty(B, H, W, Cin, dtype=torch.float32).cuda()
+        L.conv3x3_f32_mfma(dyd.data_ptr(), wdg.data_ptr(), None, dx.data_ptr(), B, H, W, Cout, Cin, 0, S())
+        close(host(dx), xr.grad.numpy(), 1e-5, "dgrad")
+    assert L.conv3x3_f32_mfma_wgrad_supported(B, H, W, Cin, Cout)
+    wsb = int(L.conv3x3_f32_mfma_wgrad_ws_bytes(B, H, W, Cin, Cout, 1 if use_bias else 0))
+    ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32).cuda()
+    outs = []
+    for _ in range(2):
+        dw = torch.full((3, 3, Cin, Cout), 0.5, dtype=torch.float32).cuda()
+        db = torch.full((Cout,), 0.25, dtype=torch.float32).cuda()
+        L.conv3x3_f32_mfma_wgrad(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), db.data_ptr() if use_bias else None, ws.data_ptr(), wsb,
+                                 B, H, W, Cin, Cout, S())
+        outs.append((host(dw), host(db)))
+    close(outs[0][0] - 0.5, wr.grad.numpy(), 2e-5, "wgrad")
+    if use_bias:
+        close(outs[0][1] - 0.25, br.grad.numpy(), 2e-5, "dbias")
+    else:
+        assert np.all(outs[0][1] == 0.25)
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 MFMA_CASES = [
     # B, H, W, K(Cin), N(Cout)
     (2, 16, 16, 32, 32),

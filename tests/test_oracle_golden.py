@@ -11,7 +11,7 @@ from oracle import train as otrain
 from tests.helpers import check_tensor, golden_inputs, load_golden
 
 CASES = ["tiny_phiseg_bn", "tiny_phiseg_gn4", "tiny_phiseg_in", "tiny_probunet_bn", "tiny_phiseg71_bn",
-         "tiny_phiseg_bn_192", "lidc_phiseg_bn", "tiny_detunet_bn"]
+         "tiny_phiseg_bn_192", "lidc_phiseg_bn", "lidc_phiseg_bn_b12", "tiny_detunet_bn"]
 RTOL = 1e-10
 
 

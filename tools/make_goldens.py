@@ -58,6 +58,9 @@ CASES = {
     "tiny_phiseg_bn_192": dict(arch="phiseg", norm="batch_norm", n0=4, zdim0=2, H=192, B=2, nlabels=4),
     "lidc_phiseg_bn": dict(arch="phiseg", norm="batch_norm", n0=32, zdim0=2, H=128, B=2, nlabels=2,
                            full=False),
+    # BASELINE config 1 / the reference's own batch size (phiseg/experiments/phiseg_7_5.py:40), SURVEY 8(c)
+    "lidc_phiseg_bn_b12": dict(arch="phiseg", norm="batch_norm", n0=32, zdim0=2, H=128, B=12, nlabels=2,
+                               full=False),
     # the deterministic U-Net baseline (experiments/detunet.py): dummy posterior / prior, no KL term
     "tiny_detunet_bn": dict(arch="det_unet2D", norm="batch_norm", n0=4, zdim0=6, H=128, B=3, nlabels=2, latent_levels=1,
                             KL_weight=None),
