@@ -51,6 +51,23 @@ static bool make_geo_fwd(int B, int H, int W, F32Geo* g) {
     return g->mpw && g->mpp && g->npatch <= 1024;
 }
 
+// forward / data gradient on few-tile problems: 64-row tiles (8 x 8 pixels, or whole small maps of several images)
+static bool make_geo_small(int B, int H, int W, F32Geo* g) {
+    int tw = 1, th = 1;
+    g->tws = g->ths = 0;
+    while (tw < W && tw < 8) { tw <<= 1; g->tws++; }
+    while (th < H && th < 8) { th <<= 1; g->ths++; }
+    g->tb = 64 / (tw * th);
+    g->tiles_x = (W + tw - 1) / tw;
+    g->tiles_y = (H + th - 1) / th;
+    g->tiles_b = (B + g->tb - 1) / g->tb;
+    g->pw = tw + 2; g->ph = th + 2;
+    g->npatch = g->tb * g->ph * g->pw;
+    g->rows = 64;
+    g->mpw = magic20(g->pw); g->mpp = magic20(g->ph * g->pw);
+    return g->mpw && g->mpp && g->npatch <= 256;
+}
+
 // filter gradient: tiles of at most 128 rows and at most 192 patch pixels
 static bool make_geo_wgrad(int B, int H, int W, F32Geo* g) {
     int tw = 1, th = 1;
@@ -251,9 +268,155 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f32_mfma(const float* __rest
     }
 }
 
+// ---- forward / data gradient, few-tile problems -------------------------------------------------------------------------------
+// The 256-row kernel above leaves most of the chip idle on the H <= 16 levels (a 192 -> 192 layer on 8 x 8 maps at batch 64 is 48
+// blocks of 221 K matrix cycles each).  Here a block owns 64 rows x 32 output channels and its four waves SPLIT THE REDUCTION: of
+// every group of 32 reduction channels wave w takes channels [8w, 8w + 8); the four accumulator sets are summed through LDS in wave
+// order at the end (a fixed order: bit-identical from run to run).  6x ... 8x the blocks, a quarter of the serial chain each.
+__global__ __launch_bounds__(256, 2) void k_conv3x3_f32_mfma_small(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                                    const float* __restrict__ bias, float* __restrict__ y, int B, int H,
+                                                                    int W, int K, int N, int act, F32Geo g) {
+    extern __shared__ float smem[];
+    const int npatch = g.npatch;
+    float* sp = smem;                            // [4 waves][2 planes][npatch][4]
+    float* sw = smem + 32 * npatch;              // [4 waves][9][2][32][4]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int tw = 1 << g.tws, th = 1 << g.ths, pw = g.pw, ph = g.ph;
+    int t = blockIdx.x;
+    const int tx0 = (t % g.tiles_x) << g.tws; t /= g.tiles_x;
+    const int ty0 = (t % g.tiles_y) << g.ths; t /= g.tiles_y;
+    const int b0 = t * g.tb;
+    const int n0 = blockIdx.y * 32;
+
+    int pbase[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int r = 32 * mi + l31;
+        const int lx = r & (tw - 1), ly = (r >> g.tws) & (th - 1), bi = r >> (g.tws + g.ths);
+        pbase[mi] = (bi * ph + ly) * pw + lx;
+    }
+    int goff[8];
+    const int np8 = npatch * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = tid + 256 * j;
+        goff[j] = -1;
+        if (i < np8) {
+            const unsigned pp = (unsigned)i >> 3;
+            const int bi = (int)((pp * g.mpp) >> 20);
+            const unsigned rem = pp - bi * ph * pw;
+            const int py = (int)((rem * g.mpw) >> 20);
+            const int px = (int)rem - py * pw;
+            const int gy = ty0 + py - 1, gx = tx0 + px - 1, gb = b0 + bi;
+            if (gb < B && gy >= 0 && gy < H && gx >= 0 && gx < W) goff[j] = ((gb * H + gy) * W + gx) * K;
+        }
+    }
+    const bool kvec = (K & 3) == 0;
+    const int nkc = (K + 7) >> 3, ngrp = (K + 31) >> 5;
+    f32x4 rp[8], rw[9];
+
+    auto load_group = [&](int kg) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = tid + 256 * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i < np8 && goff[j] >= 0) {
+                const int c = kg * 32 + (i & 7) * 4;
+                const float* p = x + (size_t)goff[j] + c;
+                if (kvec) {
+                    if (c < K) v = *(const f32x4*)p;
+                } else {
+                    if (c + 0 < K) v[0] = p[0];
+                    if (c + 1 < K) v[1] = p[1];
+                    if (c + 2 < K) v[2] = p[2];
+                    if (c + 3 < K) v[3] = p[3];
+                }
+            }
+            rp[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {            // 4 chunks x 9 taps x 32 rows x 2 halves = 2304 pieces
+            const int i = tid + 256 * j;
+            const int w4 = i / 576, r = i % 576, t9 = r >> 6, q = r & 63;
+            const int kc = kg * 4 + w4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (kc < nkc) v = *(const f32x4*)(wpk + (((size_t)kc * 9 + t9) * N + n0 + (q >> 1)) * 8 + (q & 1) * 4);
+            rw[j] = v;
+        }
+    };
+    auto store_group = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = tid + 256 * j;
+            if (i < np8) {
+                const int q = i & 7;
+                *(f32x4*)(sp + ((size_t)((q >> 1) * 2 + (q & 1)) * npatch + (i >> 3)) * 4) = rp[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int i = tid + 256 * j;
+            const int w4 = i / 576, r = i % 576, t9 = r >> 6, q = r & 63;
+            *(f32x4*)(sw + (((w4 * 9 + t9) * 2 + (q & 1)) * 32 + (q >> 1)) * 4) = rw[j];
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][e] = 0.f;
+    const float* spw = sp + (size_t)wv * 2 * npatch * 4;
+    const float* sww = sw + (size_t)wv * 9 * 2 * 32 * 4;
+
+    load_group(0);
+    store_group();
+    __syncthreads();
+    for (int kg = 0; kg < ngrp; ++kg) {
+        if (kg + 1 < ngrp) load_group(kg + 1);
+        if (kg * 4 + wv < nkc) {
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) {
+                const int toff = (t9 / 3) * pw + (t9 % 3);
+                f32x4 a[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) a[mi] = *(const f32x4*)(spw + ((size_t)hh * npatch + pbase[mi] + toff) * 4);
+                const f32x4 b = *(const f32x4*)(sww + ((t9 * 2 + hh) * 32 + l31) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) acc[mi] = mfma32(a[mi][j], b[j], acc[mi]);
+            }
+        }
+        __syncthreads();
+        if (kg + 1 < ngrp) {
+            store_group();
+            __syncthreads();
+        }
+    }
+    // the four partial tiles -> LDS [wave][mi * 16 + e][lane], summed in wave order
+    float* sr = smem;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sr[(size_t)(wv * 32 + mi * 16 + e) * 64 + lane] = acc[mi][e];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = tid + 256 * i, me = q >> 6, ln = q & 63;
+        const float v = ((sr[(size_t)me * 64 + ln] + sr[(size_t)(32 + me) * 64 + ln]) + sr[(size_t)(64 + me) * 64 + ln]) + sr[(size_t)(96 + me) * 64 + ln];
+        const int e = me & 15, mi = me >> 4;
+        const int r = 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5);
+        const int n = n0 + (ln & 31);
+        const int ox = tx0 + (r & (tw - 1)), oy = ty0 + ((r >> g.tws) & (th - 1)), ob = b0 + (r >> (g.tws + g.ths));
+        if (ox < W && oy < H && ob < B) y[((size_t)(ob * H + oy) * W + ox) * N + n] = act_fwd(v + (bias ? bias[n] : 0.f), act);
+    }
+}
+
 // ---- filter gradient --------------------------------------------------------------------------------------------------------
 // Block = CIW x COW sub-blocks of 32 x 32 (ci x co), PS = 4 / (CIW COW) waves share a sub-block and split the tile's pixel pairs.
-// ws[slice * PS + ps][9][Cin][Cout] (every element written exactly once), wsb[slice][Cout] column sums of dy (bias gradient).
+// ws[slice][9][Cin][Cout] (every element written exactly once), wsb[slice][Cout] column sums of dy (bias gradient).
 template <int CIW, int COW>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_f32_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
                                                                float* __restrict__ ws, float* __restrict__ wsb, int B, int H, int W,
@@ -330,31 +493,64 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f32_wgrad(const float* __res
         if (do_bias && tid < COB)
             for (int r = 0; r < rows; ++r) dbacc += sd[(size_t)r * COB + tid];
     }
-    float* wo = ws + (size_t)(slice * PS + ps) * 9 * Cin * Cout;
-    const int co = co0 + cos * 32 + l31;
+    if (PS > 1) {
+        // the PS waves of a sub-block hold partial sums over disjoint pixel pairs: added in wave order through LDS, tap by tap
+        float* sr = smem;                    // [PS - 1][CIW * COW][16][64]
+        const int sub = wv % (CIW * COW);
 #pragma unroll
-    for (int t9 = 0; t9 < 9; ++t9)
+        for (int t9 = 0; t9 < 9; ++t9) {
+            __syncthreads();
+            if (ps > 0)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int ci = ci0 + cis * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-            if (ci < Cin && co < Cout) wo[((size_t)t9 * Cin + ci) * Cout + co] = acc[t9][e];
+                for (int e = 0; e < 16; ++e) sr[(size_t)(((ps - 1) * CIW * COW + sub) * 16 + e) * 64 + lane] = acc[t9][e];
+            __syncthreads();
+            if (ps == 0)
+                for (int p = 0; p < PS - 1; ++p)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[t9][e] += sr[(size_t)((p * CIW * COW + sub) * 16 + e) * 64 + lane];
         }
+    }
+    float* wo = ws + (size_t)slice * 9 * Cin * Cout;
+    const int co = co0 + cos * 32 + l31;
+    if (ps == 0) {
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ci = ci0 + cis * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                if (ci < Cin && co < Cout) wo[((size_t)t9 * Cin + ci) * Cout + co] = acc[t9][e];
+            }
+    }
     if (do_bias && tid < COB && co0 + tid < Cout) wsb[(size_t)slice * Cout + co0 + tid] = dbacc;
 }
 
-// dst[e] += sum over the slices, in slice order
+// dst[e] += sum over the slices: a block takes 64 consecutive elements, its four waves every fourth slice each; the four partial
+// sums are added in wave order (a fixed order)
 __global__ __launch_bounds__(256) void k_f32_wgrad_reduce(const float* __restrict__ ws, int nslice, size_t n, float* __restrict__ dst,
-                                                          const float* __restrict__ wsb, int nslice_b, int nb, float* __restrict__ db) {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e < n) {
-        float s = 0.f;
-        for (int k = 0; k < nslice; ++k) s += ws[(size_t)k * n + e];
-        dst[e] += s;
-    } else if (db != nullptr && e - n < (size_t)nb) {
-        const size_t c = e - n;
-        float s = 0.f;
-        for (int k = 0; k < nslice_b; ++k) s += wsb[(size_t)k * nb + c];
-        db[c] += s;
+                                                          const float* __restrict__ wsb, int nb, float* __restrict__ db) {
+    __shared__ float part[4][64];
+    const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const size_t e = (size_t)blockIdx.x * 64 + el;
+    const size_t nn = n + (db != nullptr ? (size_t)nb : 0);
+    float s = 0.f;
+    if (e < nn) {
+        const float* src = e < n ? ws + e : wsb + (e - n);
+        const size_t stride = e < n ? n : (size_t)nb;
+        int k = q;
+        float s1 = 0.f;
+        for (; k + 4 < nslice; k += 8) {
+            s += src[(size_t)k * stride];
+            s1 += src[(size_t)(k + 4) * stride];
+        }
+        if (k < nslice) s += src[(size_t)k * stride];
+        s += s1;
+    }
+    part[q][el] = s;
+    __syncthreads();
+    if (q == 0 && e < nn) {
+        const float v = ((part[0][el] + part[1][el]) + part[2][el]) + part[3][el];
+        if (e < n) dst[e] += v;
+        else db[e - n] += v;
     }
 }
 
@@ -379,7 +575,8 @@ static bool plan_wgrad(int B, int H, int W, int Cin, int Cout, bool with_bias, W
     p->tps = (p->ntiles + want - 1) / want;
     p->nslice = (p->ntiles + p->tps - 1) / p->tps;
     p->lds = ((size_t)p->g.npatch * 32 * p->ciw + (size_t)p->g.rows * 32 * p->cow) * 4;
-    p->ws_floats = (size_t)p->nslice * p->ps * 9 * Cin * Cout;
+    if (p->lds < (size_t)(p->ps - 1) * p->ciw * p->cow * 4096) p->lds = (size_t)(p->ps - 1) * p->ciw * p->cow * 4096;
+    p->ws_floats = (size_t)p->nslice * 9 * Cin * Cout;
     p->wsb_floats = with_bias ? (size_t)p->nslice * Cout : 0;
     return p->lds <= 160 * 1024;
 }
@@ -411,6 +608,19 @@ int phx_conv3x3_f32_mfma(const float* x, const float* wpk, const float* bias, fl
     make_geo_fwd(B, H, W, &g);
     const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
     hipStream_t s = (hipStream_t)stream;
+    F32Geo gs;
+    if (ntiles * (N % 64 == 0 ? N / 64 : N / 32) < 512 && make_geo_small(B, H, W, &gs)) {
+        // fewer than two 256-row blocks per CU: the 64-row tiles with the reduction split over the waves
+        const size_t lds = ((size_t)32 * gs.npatch + 4 * 9 * 2 * 32 * 4) * 4;
+        static bool attr = false;
+        if (!attr) {
+            PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_f32_mfma_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+        k_conv3x3_f32_mfma_small<<<dim3(gs.tiles_x * gs.tiles_y * gs.tiles_b, N / 32), 256, lds, s>>>(x, wpk, bias, y, B, H, W, K, N, act, gs);
+        PHX_CHECK_LAUNCH();
+        return PHX_OK;
+    }
     if (N % 64 == 0) {
         const size_t lds = ((size_t)8 * g.npatch + 9 * 2 * 64 * 4) * 4;
         static bool attr = false;
@@ -473,7 +683,7 @@ int phx_conv3x3_f32_mfma_wgrad(const float* x, const float* dy, float* dw_hwio, 
     PHX_CHECK_LAUNCH();
     const size_t n = (size_t)9 * Cin * Cout;
     const size_t tot = n + (dbias ? (size_t)Cout : 0);
-    k_f32_wgrad_reduce<<<(unsigned)((tot + 255) / 256), 256, 0, s>>>(ws, p.nslice * p.ps, n, dw_hwio, wsb, p.nslice, Cout, dbias);
+    k_f32_wgrad_reduce<<<(unsigned)((tot + 63) / 64), 256, 0, s>>>(ws, p.nslice, n, dw_hwio, wsb, Cout, dbias);
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }
