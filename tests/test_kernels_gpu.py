@@ -193,6 +193,11 @@ F32_MFMA_CASES = [
     (2, 64, 64, 128, 192, "relu", False),
     (1, 128, 128, 32, 32, "identity", True),
     (3, 16, 32, 6, 160, "identity", False),
+    # at least 512 blocks of 256 rows: the large-tile kernel (everything above takes the 64-row tiles whose waves split the reduction)
+    (8, 128, 128, 32, 64, "relu", True),
+    (32, 64, 64, 3, 32, "identity", False),
+    (57, 48, 48, 8, 64, "identity", True),
+    (130, 16, 16, 64, 96, "relu", False),
 ]
 
 
