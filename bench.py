@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 F_TRAIN_GFLOP_PER_IMAGE = 75.08       # fwd 25.026 + dgrad + wgrad, live graph, 128x128, 2 classes
 PEAK_BF16_TFLOPS = 2500.0             # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3               # fp32 matrix peak (v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD): the fp32 parity path's roofline
 
 
 def make_config(batch, compute_dtype, exp="phiseg_7_5", image_size=128, nlabels=None, norm="batch"):
@@ -164,7 +165,64 @@ def side_workload(args, ctx, exp, norm, generate, steps=10, warmup=3, dtype=None
         _, _, _, fl, ms, nl = conv_family(plan)
         if ms > 0:
             out["conv_frac_of_mfma_peak"] = fl / ms / 1e9 / PEAK_BF16_TFLOPS
+    else:
+        out["roofline"] = f32_roofline(plan)
     return out
+
+
+def f32_roofline(plan):
+    """The fp32 parity path's own roofline block: its 3x3 convolutions run on v_mfma_f32_32x32x2_f32 (csrc/conv_f32_mfma.hip), peak
+    157.3 TFLOP/s.  Every tagged launch of one step timed alone with HIP events on the plan's stream, as for the bf16 family."""
+    rows = [r for r in plan.time_tagged_kernels(repeats=2) if r[0].startswith("conv3x3_f32_mfma")]
+    fam = {}
+    for tag, fl, ms, shp in rows:
+        a = fam.setdefault(tag, [0.0, 0.0, 0])
+        a[0] += fl; a[1] += ms; a[2] += 1
+    fl = sum(v[0] for v in fam.values())
+    ms = sum(v[1] for v in fam.values())
+    if ms <= 0:
+        return None
+    return {"bound": "mfma", "kernel": "k_conv3x3_f32_mfma<BN> / k_conv3x3_f32_mfma_small (forward + data gradient) + k_conv3x3_f32_wgrad<CIW,COW> "
+                                       "(all three launches of every 3x3 layer of one step, each launch alone)",
+            "achieved": fl / ms / 1e9, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_F32_TFLOPS,
+            "launches": sum(v[2] for v in fam.values()), "conv_ms_per_step": ms, "traffic": None,
+            "families": {k: {"tflops": v[0] / v[1] / 1e9, "frac": v[0] / v[1] / 1e9 / PEAK_F32_TFLOPS, "ms_per_step": v[1], "launches": v[2]}
+                         for k, v in fam.items()}}
+
+
+def conv_in_situ(model, args, x, s, steps=6):
+    """The bf16 convolution family's time INSIDE the running step, measured by this run: a second plan of the same graph on the same
+    parameter store whose forward / data-gradient / filter-gradient convolution launches sit between wall-clock stamps on their lanes
+    (engine.Plan(stamp_tagged=True)); `steps` replays, the last one read.  A launch's figure is stamp-to-stamp time minus the
+    back-to-back stamp gap = its duration plus one launch boundary, beside whatever the other lane runs."""
+    import torch
+    sess = model.sess
+    plan = sess.plan_for([model.loss_tot], True, args.batch, True, stamp_tagged=True)
+    plan.set_input("x_input", x)
+    plan.set_input("s_input", s)
+    for _ in range(3):
+        plan.run()
+    plan.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.run()
+    plan.sync()
+    dt = time.perf_counter() - t0
+    rows, gap = plan.tagged_in_situ()
+    fam = {}
+    for tag, fl, us, shp in rows:
+        if tag.startswith("conv"):
+            a = fam.setdefault(tag, [0.0, 0.0, 0])
+            a[0] += fl; a[1] += us * 1e-3; a[2] += 1
+    fl = sum(v[0] for k, v in fam.items() if k != "conv3x3_mfma_wgrad")
+    ms = sum(v[1] for k, v in fam.items() if k != "conv3x3_mfma_wgrad")
+    nl = sum(v[2] for k, v in fam.items() if k != "conv3x3_mfma_wgrad")
+    return {"conv_fwd_dgrad_ms_per_step": ms, "conv_fwd_dgrad_launches_per_step": nl, "flops": fl, "stamp_gap_us": gap,
+            "ms_per_step_with_stamps": 1e3 * dt / steps,
+            "families": {k: {"tflops": v[0] / v[1] / 1e9, "ms_per_step": v[1], "launches": v[2]} for k, v in fam.items() if v[1] > 0},
+            "source": "measured by this run: wall-clock stamps around every convolution launch of a replayed step (second plan, same "
+                      "store; launch duration + one launch boundary each, two lanes running)"}
 
 
 def train_api_rate(args, model, steps=10):
@@ -285,9 +343,41 @@ def main():
     plan.sync()
     torch.cuda.synchronize()
     ctx.barrier()
-    dt = ctx.max_float(time.perf_counter() - t0)
+    dt_own = time.perf_counter() - t0
+    dt = ctx.max_float(dt_own)
     loss = None if generate else float(plan.fetch(model.loss_tot))
     ranks_seen = int(round(ctx.sum_float(1.0)))          # every rank that really took part in the timed collectives
+    dp_diag = None
+    if ctx.active and not generate:
+        # after the timed region: what a first multi-GPU run needs to diagnose itself -- every rank's own time for the timed steps and
+        # the duration of the gradient exchange (HIP events on the plan's stream around phx_comm_allreduce_sum_f32, ten more steps)
+        import ctypes
+        from phiseg_code_amd import runtime as rt
+        Lb = rt.lib()
+        evs = []
+        for _ in range(10):
+            e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+            Lb.event_create(ctypes.byref(e0)); Lb.event_create(ctypes.byref(e1))
+            plan.run_main()
+            Lb.event_record(e0, ctypes.c_void_p(plan.stream_handle()))
+            ctx.allreduce_sum(sess.store.grads[:sess.store.n_live], plan)
+            Lb.event_record(e1, ctypes.c_void_p(plan.stream_handle()))
+            plan.run_opt()
+            evs.append((e0, e1))
+        plan.sync()
+        torch.cuda.synchronize()
+        ar = []
+        for e0, e1 in evs:
+            ms_ = ctypes.c_float()
+            Lb.event_elapsed_ms(e0, e1, ctypes.byref(ms_))
+            ar.append(ms_.value)
+            Lb.event_destroy(e0); Lb.event_destroy(e1)
+        ar_ms = float(np.median(ar))
+        dp_diag = {"allreduce_ms_median_rank0": ar_ms, "allreduce_ms_max_over_ranks": ctx.max_float(ar_ms),
+                   "allreduce_mbytes": sess.store.n_live * 4 / 1e6,
+                   "ms_per_step_per_rank": [1e3 * v / args.steps for v in ctx.gather_floats(dt_own)],
+                   "note": "measured after the timed region (ten extra steps); allreduce_ms includes the wait for the slowest rank's backward"}
+        ctx.barrier()
     images = args.batch * max(spi, 1) * ctx.world * args.steps
     out = {
         "metric": ("segmentation samples/sec (prior sample + likelihood decode) %s %dx%d" % (args.exp, args.image_size, args.image_size))
@@ -312,6 +402,8 @@ def main():
                    # which transport carried the timed gradient exchange (a fallback cannot be timed unnoticed)
                    "comm": {"path": ctx.comm_path(), "ranks_seen": ranks_seen}},
     }
+    if dp_diag is not None:
+        out["config"]["comm"].update(dp_diag)
     if not generate and args.exp == "phiseg_7_5" and args.image_size == 128:
         out["step_tflops"] = images / dt * F_TRAIN_GFLOP_PER_IMAGE / 1e3
     if ctx.rank == 0 and not args.no_roofline and args.dtype == "bf16":
@@ -355,20 +447,21 @@ def main():
         headline_cfg = (not generate and args.exp == "phiseg_7_5" and args.image_size == 128 and args.norm == "batch" and args.batch == 64)
         if headline_cfg:
             try:
-                tf_ = next(f for f in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                tf_ = next(f for f in ("r06_pmc_hbm_traffic.json", "r05_pmc_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
                 pj = json.load(open(os.path.join(ROOT, "profiles", tf_)))
-                ks = [v for k, v in pj.items() if any(t in k for t in ("k_conv3x3_pp", "k_conv3x3_c32", "k_conv3x3_mfma"))]
+                ks = [v for k, v in pj.items() if isinstance(v, dict) and any(t in k for t in ("k_conv3x3_pp", "k_conv3x3_c32", "k_conv3x3_mfma"))]
                 calls = sum(v["calls_per_step"] for v in ks)
                 traffic = 1e6 * sum(v["fetch_x2_MB_per_step"] + v["write_MB_per_step"] for v in ks) / calls
-                traffic_src = "committed profile profiles/" + tf_ + " (collected at commit 4d2999e by tools/collect_profiles.sh; not measured by this run)"
+                meta = pj.get("_meta") or {}
+                traffic_src = ("PMC counters cannot be read by the timed process: committed profile profiles/" + tf_ +
+                               (" collected at commit " + meta["commit"] if meta.get("commit") else "") + " by tools/collect_profiles.sh")
             except Exception:
                 pass
             try:
-                isf = next(f for f in ("r05_conv_in_situ.json", "r04_conv_in_situ.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
-                in_situ = json.load(open(os.path.join(ROOT, "profiles", isf)))
-                in_situ["source"] = "committed profile profiles/" + isf + " (not measured by this run)"
-            except Exception:
-                pass
+                in_situ = conv_in_situ(model, args, x, s)
+            except Exception as e:        # the headline line must not depend on the diagnostic
+                in_situ = None
+                print("bench.py: in-situ measurement failed: %r" % (e,), file=sys.stderr)
         alg_bytes = 0.0
         for tag, flp, ms_, shp in rows:
             if tag != "conv3x3_mfma_wgrad":
@@ -377,6 +470,7 @@ def main():
         out["roofline"] = {
             "bound": "mfma", "kernel": "k_conv3x3_pp / k_conv3x3_c32 (large maps) + k_conv3x3_mfma<BN> (forward + data-gradient launches of one step)",
             "achieved": fl / ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS,
+            "frac_isolated": fl / ms / 1e9 / PEAK_BF16_TFLOPS,
             "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 passes)",
             "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch_avg": alg_bytes / max(nl, 1),
@@ -385,9 +479,12 @@ def main():
             "families": {k: {"tflops": v[0] / v[1] / 1e9, "ms_per_step": v[1], "launches": v[2]} for k, v in fam.items()},
             "conv_ms_per_step": sum(v[1] for v in fam.values()),
         }
-        if in_situ:       # the family's time inside the step (profiles/r04_rocprofv3_kernel_stats.txt) against the same FLOPs
-            out["roofline"]["frac_in_situ"] = fl / in_situ["conv_fwd_dgrad_ms_per_step"] / 1e9 / PEAK_BF16_TFLOPS
-            out["roofline"]["in_situ"] = in_situ
+        if in_situ and in_situ["conv_fwd_dgrad_ms_per_step"] > 0:
+            # the family's time inside the running step, measured by this run, against the same FLOPs: THE roofline fraction;
+            # `frac_isolated` (each launch alone, HIP events) stays beside it
+            fi = fl / in_situ["conv_fwd_dgrad_ms_per_step"] / 1e9
+            out["roofline"].update(achieved=fi, frac=fi / PEAK_BF16_TFLOPS, frac_in_situ=fi / PEAK_BF16_TFLOPS,
+                                   achieved_isolated=fl / ms / 1e9, in_situ=in_situ)
         # launches of the family that also carry the layer's group norm (phx_conv3x3_mfma_bf16_fgn: statistics, second pass):
         # counted in `achieved` with their whole duration, listed here so that the convolution-only part can be read off
         fb = [(fl_, ms_) for tag, fl_, ms_, shp in rows if shp and shp[0] == "fgn"]
@@ -403,7 +500,8 @@ def main():
     if ctx.rank == 0 and ctx.world == 1 and headline and not args.no_other_workloads:
         # the other BASELINE.json configurations and the reference's own loop, inside the same invocation (the headline line above is
         # unchanged by them: they run after its timed region)
-        out["config"]["train_api_images_per_s"] = train_api_rate(args, model)
+        # the reference's own loop (sess.run with a host batch and the loss fetched every step, phiseg_model.py:193-194): the like-for-like figure
+        out["train_api_images_per_s"] = out["config"]["train_api_images_per_s"] = train_api_rate(args, model)
         ow = {}
         ow["phiseg_7_5 group norm (config 2 as named), training step"] = side_workload(args, ctx, "phiseg_7_5", "group", False)
         ow["probunet (config 4), training step"] = side_workload(args, ctx, "probunet", "batch", False)

@@ -252,7 +252,7 @@ int phx_head1x1_wgrad(const void* x, int x_dt, const float* dy, float* dw, float
 /* Deferred form: the head filter gradients are leaves of the backward graph, so all heads of a plan can share ONE launch.
  * phx_head1x1_wgrad_plan (host) gives plan4 = {PL, chunk, grid, dynamic LDS bytes} for C % 8 == 0; jobs_dev is a device array
  * of {const void* x; const float* dy; float* dw; float* db; uint64 npix; int C, PL, chunk, blk0; const float* xscale; const float*
- * xshift; int xact, pad;} (56 bytes) with blk0 = running sum of the grids (ascending), all jobs with the same x dtype and nout;
+ * xshift; int xact, pad;} (80 bytes) with blk0 = running sum of the grids (ascending), all jobs with the same x dtype and nout;
  * lds_bytes = max of the jobs' plan4[3].  xscale != NULL (round 5): x is the PRE-normalisation tensor of the layer whose only reader
  * is this head and a = act(x * xscale[c] + xshift[c]) is re-formed on load, rounded to bf16 as the stored tensor would have been --
  * the training plan then never writes a (phx_norm_apply_fused_head with y == NULL; batch norm: one scale / shift per channel). */

@@ -385,6 +385,7 @@ struct HeadWJob {
     const float *xscale, *xshift;             // non-NULL: x is the pre-normalisation tensor, a = act(x * xscale[c] + xshift[c]) is re-formed on load
     int xact, pad_;
 };
+static_assert(sizeof(HeadWJob) == 80, "HeadWJob is packed by the host (include/phx.h, engine.py): 80 bytes");
 template <typename TX, int NOUT>
 __global__ __launch_bounds__(256) void k_head1x1_wgrad_multi(const HeadWJob* __restrict__ jobs, int njobs) {
     int lo = 0, hi = njobs - 1;

@@ -165,6 +165,15 @@ class DistContext:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
+    def gather_floats(self, v):
+        """-> [v of rank 0, v of rank 1, ...] on every rank."""
+        if not self.active:
+            return [float(v)]
+        t = torch.zeros(self.world, dtype=torch.float64, device=self._scalar_device())
+        t[self.rank] = float(v)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(a) for a in t.cpu().tolist()]
+
     def _scalar_device(self):
         return "cuda" if (self.cuda and dist.get_backend() == "nccl") else "cpu"
 

@@ -149,7 +149,7 @@ class Plan(ForwardLowering, BackwardLowering):
 
     def __init__(self, store, fetches, loss=None, batch=1, training=True, compute_dtype="f32", optimize=True,
                  rng_seed=42, sample_offset=0, loss_inv_batch=None, stream=None, use_hip_graph=True,
-                 split_optimizer=False, n_lanes=None):
+                 split_optimizer=False, n_lanes=None, stamp_tagged=False):
         self.L = rt.lib()
         self.store = store
         self.graph = store.graph
@@ -185,6 +185,11 @@ class Plan(ForwardLowering, BackwardLowering):
         self._cur = self.launches
         self.val, self.grad, self.saved = {}, {}, {}
         self.tags = {}
+        # stamp_tagged: every tagged launch (the convolution family) sits between two wall-clock stamps on its lane -- bench.py's
+        # measurement of the family's time INSIDE the replayed two-lane step (tagged_in_situ())
+        self._stamp_tagged = bool(stamp_tagged)
+        self.tag_stamps, self._tstamp_n = [], 16
+        self._tstamp_buf = torch.zeros(8192, dtype=torch.int64, device=_device()) if self._stamp_tagged else None
         self.feeds = {}
         self._keep = []
         self._wpk = {}
@@ -324,10 +329,28 @@ class Plan(ForwardLowering, BackwardLowering):
 
     # ---------------------------------------------------------------------------------------------
     def _emit(self, fn, *args, tag=None, flops=0.0, shape=None):
+        st = tag is not None and self._stamp_tagged and self._cur is self.launches and self._tstamp_n + 2 <= self._tstamp_buf.numel()
+        if st:
+            i = self._tstamp_n
+            self._tstamp_n += 2
+            self._cur.append((self.L.stamp, (self._tstamp_buf.data_ptr() + 8 * i, self.stream)))
         if tag is not None:
             self.tags[(id(self._cur), len(self._cur))] = (tag, float(flops), shape)
         self._cur.append((fn, args))
+        if st:
+            self._cur.append((self.L.stamp, (self._tstamp_buf.data_ptr() + 8 * (i + 1), self.stream)))
+            self.tag_stamps.append((tag, float(flops), shape, i))
         self._lane_seq[self._lane] = self._lane_seq.get(self._lane, 0) + 1
+
+    def tagged_in_situ(self):
+        """stamp_tagged plans, after at least one replay: -> (rows, gap_us); rows = [(tag, flops, us, shape)] with us = the wall-clock
+        time between the stamps around each tagged launch in the LAST replay minus gap_us, the median distance of back-to-back
+        stamps (eight calibration pairs at the head of lane 0): the launch's duration plus one launch boundary, with whatever the
+        other lane ran beside it."""
+        self.sync()
+        t = self._tstamp_buf.cpu().numpy().astype(np.int64)          # 100 MHz wall clock
+        gap = float(np.median([(t[2 * k + 1] - t[2 * k]) / 100.0 for k in range(8)]))
+        return [(tag, fl, max((t[i + 1] - t[i]) / 100.0 - gap, 0.0), shp) for tag, fl, shp, i in self.tag_stamps], gap
 
     def _alloc(self, shape, dt, zero=False):
         b = Buf(shape, dt, zero=zero)
@@ -421,6 +444,9 @@ class Plan(ForwardLowering, BackwardLowering):
         self._emit(_noop)                                                            # slot 2: inference-mode batch-norm scale / shift of all layers
         if with_bw:
             self._emit(self.L.memset, self.store.grads.data_ptr(), 0, self.store.grads.numel() * 4, self.stream)
+        if self._stamp_tagged:            # calibration: eight back-to-back stamp pairs
+            for k in range(16):
+                self._cur.append((self.L.stamp, (self._tstamp_buf.data_ptr() + 8 * k, self.stream)))
         nl = len(self._lanes)
         self.op_lane = {op: self._lane_of(op) for op in ops}
         opset = set(ops)

@@ -672,8 +672,13 @@ class ForwardLowering:
         if not _POOL_FUSE or not self.L.norm_apply_pool_supported(H, Wd, C):
             return None
         out = op.outputs[0]
+        ln = self.op_lane.get(op)
         for c in self._real_consumers(out, self._opset):
-            if c.type == "avgpool" and c.inputs[0] is out and self.op_lane.get(c) == self.op_lane.get(op) and c not in self._pool_done:
+            if c.type == "avgpool" and c.inputs[0] is out and self.op_lane.get(c) == ln and c not in self._pool_done:
+                # the pool then emits no launch of its own and records no forward event: every reader of the pooled tensor has to sit
+                # on the producer's lane too (stream order is its only ordering), and the pooled tensor may not be a fetch
+                if c.outputs[0] in self.fetches or any(self.op_lane.get(r) != ln for r in self._real_consumers(c.outputs[0], self._opset)):
+                    continue
                 return c
         return None
 
@@ -693,7 +698,9 @@ class ForwardLowering:
             return None
         ot = op.outputs[0]
         cons = self._real_consumers(ot, self._opset)
-        if len(cons) != 1 or ot in self.fetches or x.shape[1] < mh or x.shape[2] < mh:
+        # (the small-map forms of _fw_conv_unit -- one-launch batch norm, fused group norm, wave-per-sample norm: maps up to 16 x 16 --
+        # read x.ptr and an UpBuf has none: the phase form starts at 32 x 32 low-resolution maps whatever PHX_UPCONV says)
+        if len(cons) != 1 or ot in self.fetches or x.shape[1] < max(mh, 32) or x.shape[2] < max(mh, 32):
             return None
         c = cons[0]
         a = c.attrs if c.type == "conv_unit" else None

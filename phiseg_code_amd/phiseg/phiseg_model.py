@@ -68,15 +68,15 @@ class Session:
                 engine.device_sync()
         return self.store
 
-    def plan_for(self, fetch_tensors, train, batch, training):
-        key = (tuple(id(t) for t in fetch_tensors), bool(train), int(batch), bool(training))
+    def plan_for(self, fetch_tensors, train, batch, training, stamp_tagged=False):
+        key = (tuple(id(t) for t in fetch_tensors), bool(train), int(batch), bool(training)) + (("stamped",) if stamp_tagged else ())
         if key not in self.plans:
             store = self._ensure_store()
             world, rank = (self.dist.world, self.dist.rank) if self.dist else (1, 0)
             self.plans[key] = engine.Plan(
                 store, fetch_tensors, loss=self.model.loss_tot if train else None, batch=batch, training=training,
                 compute_dtype=self.compute_dtype, rng_seed=self.rng_seed, sample_offset=rank * batch,
-                loss_inv_batch=1.0 / (batch * world), split_optimizer=bool(self.dist and self.dist.active))
+                loss_inv_batch=1.0 / (batch * world), split_optimizer=bool(self.dist and self.dist.active), stamp_tagged=stamp_tagged)
         return self.plans[key]
 
     def run(self, fetches, feed_dict=None):

@@ -831,7 +831,7 @@ def test_bf16_training_step_probunet_n0_32_vs_oracle():
     assert n >= 100
 
 
-def test_bf16_trains_like_fp32_default_mode_four_seeds():
+def test_bf16_trains_like_fp32_default_mode_eight_seeds():
     """Does the benchmarked precision train, in the mode that is benchmarked?  (round-4 review: the deterministic-mode gate below is
     evidence for a sibling of the benchmarked path, and its tolerance could not see a bias of several per cent.)
     phiseg_7_5 at the benchmark's width (n0 = 32, 128 x 128, batch norm), batch 12 (the reference's batch size, phiseg_7_5.py:40),
@@ -854,17 +854,20 @@ def test_bf16_trains_like_fp32_default_mode_four_seeds():
     from tests.convergence_lib import run_all, summarise
     env_was = os.environ.pop("PHX_DETERMINISTIC", None)
     try:
-        res = run_all([(dt, so) for so in range(4) for dt in ("f32", "bf16")], 8, 200, 50)
+        res = run_all([(dt, so) for so in range(8) for dt in ("f32", "bf16")], 8, 200, 50)
     finally:
         if env_was is not None:
             os.environ["PHX_DETERMINISTIC"] = env_was
-    assert len(res) == 8, sorted(res)
+    assert len(res) == 16, sorted(res)
     it = next(iter(res.values()))["keys"].index("total_loss")
     for key, run in res.items():
         assert run["finite"], key
         assert run["tail"][it] < 0.1 * run["first"][it], (key, run["first"][it], run["tail"][it])      # it trained
     rows = {name: (r, rse) for name, _, r, rse in summarise(res, ("f32", "bf16"))}
-    floors = {"ELBO": 0.02, "KL sum (unweighted)": 0.02, "CE sum": 0.10}
+    # round 6 (advisor, round 5): EIGHT seeds per arm since the fp32 arm runs on the fp32 matrix kernels (4.7x faster): the standard
+    # error of the cross-entropy ratio is ~2.4 % with eight, so its floor comes down from 10 % to 6 % -- a bias of the size the
+    # round-5 KL defect had (+ 40 % on two levels, + 8 % on the ELBO) fails the ELBO / KL rows at three standard errors
+    floors = {"ELBO": 0.02, "KL sum (unweighted)": 0.02, "CE sum": 0.06}
     bad = {name: rows[name] for name, fl in floors.items() if not abs(rows[name][0] - 1.0) <= max(fl, 3.0 * rows[name][1])}
     assert not bad, bad
 
