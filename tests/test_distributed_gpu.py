@@ -171,5 +171,9 @@ def test_bench_self_launches_its_ranks(tmp_path):
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
-    assert out["config"]["comm"] == {"path": "torch_gloo_host_staged", "ranks_seen": 2}
+    comm = out["config"]["comm"]
+    assert comm["path"] == "torch_gloo_host_staged" and comm["ranks_seen"] == 2
+    # the line diagnoses a multi-GPU run by itself: the exchange's duration (HIP events around it on the plan's stream) and every rank's own step time
+    assert comm["allreduce_ms_median_rank0"] > 0 and comm["allreduce_ms_max_over_ranks"] >= comm["allreduce_ms_median_rank0"] * 0.999
+    assert len(comm["ms_per_step_per_rank"]) == 2 and all(v > 0 for v in comm["ms_per_step_per_rank"]) and comm["allreduce_mbytes"] > 1
     assert out["value"] > 0 and np.isfinite(out["config"]["final_loss"])
