@@ -386,6 +386,17 @@ int phx_norm_bwd_reduce(const void* dA, int da_dt, const void* x, int x_dt, cons
                         const float* shift, const float* mean, const float* rstd, float* sums2,
                         int NS, int P, int C, int G, int act, int nrep, void* stream);
 /* per (ns,g): S[ns][g][2] = sum_{c in g} gamma_c * sums2[ns][c][*];  dgamma[c] += sum_ns sums2[..][1], dbeta += [..][0] */
+/* One-pass batch-norm backward (round 6): what phx_norm_bwd_reduce + phx_norm_bwd_apply_fused compute for batch norm (NS = 1,
+ * G = C), bf16 dA / x / dx, in ONE launch -- every thread keeps its (dA, x) values in registers across a grid barrier, so both
+ * tensors are read once.  For tensors of at most 256 blocks x 256 threads x 16 pixels x 8 channels (phx_bn_bwd_onepass_supported; relu layers;
+ * never in deterministic mode: the partial sums are added atomically).  sums2[nrep][C][2] and barrier[phx_bn_bwd_onepass_barrier_words()]
+ * must be ZERO at launch (the engine carves both from its per-step zero arena); barrier[288] != 0 afterwards = the barrier timed out.
+ * At most two such launches may run concurrently (one block per CU each: both stay resident). */
+int phx_bn_bwd_onepass_supported(int P, int C, int act);
+int phx_bn_bwd_onepass_barrier_words(void);
+int phx_bn_bwd_onepass(const void* dA, const void* x, const float* scale, const float* shift, const float* mean, const float* rstd,
+                       const float* gamma, float* sums2, unsigned* barrier, void* dx, float* dgamma, float* dbeta, int P, int C, int act,
+                       int nrep, void* stream);
 int phx_norm_bwd_finalize(const float* sums2, const float* gamma, float* S, float* dgamma, float* dbeta,
                           int NS, int C, int G, void* stream);
 /* dx = rstd * (gamma*g - S0/m - xhat*S1/m),  m = P*C/G */

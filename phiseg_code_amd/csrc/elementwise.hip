@@ -1506,6 +1506,173 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const TD* __restrict__ 
     }
 }
 
+// ---- one-pass batch-norm backward (round 6) ------------------------------------------------------------------------------------
+// k_norm_bwd_reduce + k_norm_bwd_apply_fused read dA and x twice (two launches, 4 + 6 B per element).  For tensors that fit the
+// register file -- up to 256 blocks x 256 threads x NSLOT pixels x 8 channels -- ONE launch reads them once: every thread keeps its
+// (dA, x) vectors packed in registers, the block adds its per-channel partial sums into sums2, a GRID BARRIER follows, and the
+// gradient is formed from the registers (4 + 2 B per element, one launch).  Batch norm only (one statistic per channel), bf16.
+// Grid barrier (cdna_hip_programming.md, Guideline 16): eight arrival shards (block % 8: one per XCD when blocks land round-robin --
+// a speed heuristic, never a correctness assumption) and a top word counting finished shards; every word is an agent-scope atomic,
+// zeroed before the launch by the caller (the plan's per-step memset); release fence + drained vmcnt before the arrival, one relaxed
+// poll loop with s_sleep, one acquire fence after it.  RESIDENCY: the grid is at most 256 blocks (one per CU) of 256 threads with at
+// most 256 registers and < 40 KB of LDS, so that TWO such launches -- the engine replays two lanes side by side -- are resident
+// together and neither waits for a block the other one keeps off the chip; the spin is bounded and reports through bar[PHX_BAR_TIMEOUT].
+#define PHX_BAR_STRIDE 32
+#define PHX_BAR_TOP (8 * PHX_BAR_STRIDE)
+#define PHX_BAR_TIMEOUT (9 * PHX_BAR_STRIDE)
+#define PHX_BAR_WORDS (10 * PHX_BAR_STRIDE)
+__device__ __forceinline__ void phx_grid_barrier(unsigned* __restrict__ bar, int nblocks) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every wave: its stores / atomics have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the compiler may drop the fence's own wait: restated)
+        const int shard = blockIdx.x & 7;
+        const unsigned nshard = (unsigned)((nblocks - shard + 7) >> 3);
+        const unsigned prev = __hip_atomic_fetch_add(bar + shard * PHX_BAR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev + 1 == nshard) __hip_atomic_fetch_add(bar + PHX_BAR_TOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned want = nblocks < 8 ? (unsigned)nblocks : 8u;
+        unsigned spins = 0;
+        while (__hip_atomic_load(bar + PHX_BAR_TOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 21)) {                       // ~ seconds: never on a healthy launch; the result is then wrong, not hung
+                __hip_atomic_store(bar + PHX_BAR_TIMEOUT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+template <int NSLOT, int ACT>
+__global__ __launch_bounds__(256, 2) void k_bn_bwd_onepass(const bf16_t* __restrict__ dA, const bf16_t* __restrict__ x,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, float* __restrict__ sums2,
+                                                            unsigned* __restrict__ bar, bf16_t* __restrict__ dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int P, int C, int PL,
+                                                            int chunk, int nrep) {
+    constexpr int act = ACT;          // (a run-time activation code makes every element evaluate all three derivatives)
+    constexpr int V = 8;
+    const int CV = C / V;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    extern __shared__ float red[];               // phase 1: 4 C constants, then PL x 2C partial sums; phase 2: 2C sums + 5C coefficients
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        red[4 * c] = scale[c];
+        red[4 * c + 1] = shift[c];
+        red[4 * c + 2] = mean[c];
+        red[4 * c + 3] = rstd[c];
+    }
+    __syncthreads();
+    float sc[V], sh[V], mu[V], rs[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int c = cv * V + j;
+        sc[j] = red[4 * c]; sh[j] = red[4 * c + 1]; mu[j] = red[4 * c + 2]; rs[j] = red[4 * c + 3];
+    }
+    __syncthreads();
+    const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
+    uint4 xq[NSLOT], dq[NSLOT];
+    if (pl < PL) {
+#pragma unroll
+        for (int u = 0; u < NSLOT; ++u) {
+            const int p = p0 + pl + u * PL;
+            const size_t off = (size_t)(p < p1 ? p : p1 - 1) * C + (size_t)cv * V;      // (clamped: always a valid address)
+            xq[u] = *reinterpret_cast<const uint4*>(x + off);
+            dq[u] = *reinterpret_cast<const uint4*>(dA + off);
+            if (p >= p1) dq[u] = make_uint4(0u, 0u, 0u, 0u);                             // dA = 0: contributes nothing
+        }
+        float s1[V], s2[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+        for (int u = 0; u < NSLOT; ++u) {
+            const unsigned xw[4] = {xq[u].x, xq[u].y, xq[u].z, xq[u].w}, dw[4] = {dq[u].x, dq[u].y, dq[u].z, dq[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float x0 = __uint_as_float(xw[k] << 16), x1 = __uint_as_float(xw[k] & 0xffff0000u);
+                const float d0 = __uint_as_float(dw[k] << 16), d1 = __uint_as_float(dw[k] & 0xffff0000u);
+                const float g0 = d0 * act_grad_pre(x0 * sc[2 * k] + sh[2 * k], act);
+                const float g1 = d1 * act_grad_pre(x1 * sc[2 * k + 1] + sh[2 * k + 1], act);
+                s1[2 * k] += g0;
+                s2[2 * k] += g0 * (x0 - mu[2 * k]) * rs[2 * k];
+                s1[2 * k + 1] += g1;
+                s2[2 * k + 1] += g1 * (x1 - mu[2 * k + 1]) * rs[2 * k + 1];
+            }
+            __builtin_amdgcn_sched_barrier(0);           // slot by slot: the unpacked values of one slot are dead before the next is opened
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            red[(pl * C + cv * V + j) * 2 + 0] = s1[j];
+            red[(pl * C + cv * V + j) * 2 + 1] = s2[j];
+        }
+    }
+    __syncthreads();
+    float* srep = sums2 + (size_t)(blockIdx.x % nrep) * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        float a = 0.f;
+        for (int q = 0; q < PL; ++q) a += red[q * 2 * C + i];
+        atomicAdd(&srep[i], a);
+    }
+    phx_grid_barrier(bar, gridDim.x);
+    // (the packed registers are opaque from here on: otherwise the compiler keeps phase 1's unpacked x and g values alive across the
+    // barrier -- 16 floats per slot instead of 8 packed registers -- and spills)
+#pragma unroll
+    for (int u = 0; u < NSLOT; ++u)
+        asm volatile("" : "+v"(xq[u].x), "+v"(xq[u].y), "+v"(xq[u].z), "+v"(xq[u].w), "+v"(dq[u].x), "+v"(dq[u].y), "+v"(dq[u].z), "+v"(dq[u].w));
+    // every block finalises for itself (k_norm_bwd_apply_fused's arithmetic, one statistic per channel: S0 = gamma t0, S1 = gamma t1)
+    float* st = red;
+    float* cof = red + 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        float a = 0.f;
+        for (int r = 0; r < nrep; ++r) a += __hip_atomic_load(sums2 + (size_t)r * 2 * C + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st[i] = a;
+    }
+    __syncthreads();
+    const float inv_m = 1.f / (float)P;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float gm = gamma[c], r_ = rstd[c], m_ = mean[c];
+        const float t0 = st[2 * c], t1 = st[2 * c + 1];
+        const float S0 = gm * t0, S1 = gm * t1;
+        const float ca = r_ * gm;
+        const float cc = -r_ * r_ * S1 * inv_m;
+        cof[3 * c] = ca;
+        cof[3 * c + 1] = -r_ * S0 * inv_m - cc * m_;
+        cof[3 * c + 2] = cc;
+        if (blockIdx.x == 0) {
+            atomicAdd(&dbeta[c], t0);
+            atomicAdd(&dgamma[c], t1);
+        }
+    }
+    __syncthreads();
+    if (pl >= PL) return;
+    float ca[V], cb[V], cc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const float* q = cof + 3 * (cv * V + j);
+        ca[j] = q[0]; cb[j] = q[1]; cc[j] = q[2];
+    }
+#pragma unroll
+    for (int u = 0; u < NSLOT; ++u) {
+        const int p = p0 + pl + u * PL;
+        if (p < p1) {
+            const unsigned xw[4] = {xq[u].x, xq[u].y, xq[u].z, xq[u].w}, dw[4] = {dq[u].x, dq[u].y, dq[u].z, dq[u].w};
+            unsigned o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float x0 = __uint_as_float(xw[k] << 16), x1 = __uint_as_float(xw[k] & 0xffff0000u);
+                const float d0 = __uint_as_float(dw[k] << 16), d1 = __uint_as_float(dw[k] & 0xffff0000u);
+                const float g0 = d0 * act_grad_pre(fmaf(x0, sc[2 * k], sh[2 * k]), act);
+                const float g1 = d1 * act_grad_pre(fmaf(x1, sc[2 * k + 1], sh[2 * k + 1]), act);
+                o[k] = f2bf_pk(fmaf(ca[2 * k], g0, fmaf(cc[2 * k], x0, cb[2 * k])), fmaf(ca[2 * k + 1], g1, fmaf(cc[2 * k + 1], x1, cb[2 * k + 1])));
+            }
+            *reinterpret_cast<uint4*>(dx + (size_t)p * C + (size_t)cv * V) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 __global__ void k_norm_bwd_finalize(const float* __restrict__ sums2, const float* __restrict__ gamma, float* S,
                                     float* dgamma, float* dbeta, int NS, int C, int G) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2179,6 +2346,47 @@ static int norm_bwd_reduce_impl(const void* dA, int da_dt, const void* x, int x_
                            (size_t)(PL > 2 ? PL : 2) * C * 2 * sizeof(float), (hipStream_t)stream, (const TD*)dA, (const TX*)x, scale,
                            shift, mean, rstd, sums2, P, C, G, PL, chunk, act, nrep, HeadBw{nullptr, nullptr, ph, pw, C});
     })));
+    PHX_CHECK_LAUNCH();
+    return PHX_OK;
+}
+
+// one-pass batch-norm backward: geometry (at most 256 blocks of <= 256 threads; slots = pixels per thread)
+static bool bn_onepass_geometry(int P, int C, int* PL, int* threads, int* chunk, int* nblocks, int* nslot) {
+    if (C % 8 != 0 || C / 8 > 256 || P < 1) return false;
+    const int CV = C / 8;
+    *PL = 256 / CV;
+    *threads = CV * (*PL);
+    int want = (P + (*PL) * 8 - 1) / ((*PL) * 8);            // ~8 pixels per thread ...
+    if (want > 256) want = 256;                               // ... on at most one block per CU
+    if (want < 1) want = 1;
+    *chunk = (P + want - 1) / want;
+    *nblocks = (P + *chunk - 1) / (*chunk);
+    const int slots = (*chunk + *PL - 1) / (*PL);
+    *nslot = slots <= 4 ? 4 : slots <= 8 ? 8 : slots <= 16 ? 16 : 0;
+    return *nslot != 0 && (size_t)(*PL) * C * 2 * sizeof(float) <= 40 * 1024 && (size_t)5 * C * sizeof(float) <= 40 * 1024;
+}
+int phx_bn_bwd_onepass_supported(int P, int C, int act) {
+    int PL, threads, chunk, nblocks, nslot;
+    return (act == PHX_ACT_RELU && !phx_deterministic()
+            && bn_onepass_geometry(P, C, &PL, &threads, &chunk, &nblocks, &nslot)) ? 1 : 0;
+}
+int phx_bn_bwd_onepass_barrier_words(void) { return PHX_BAR_WORDS; }
+int phx_bn_bwd_onepass(const void* dA, const void* x, const float* scale, const float* shift, const float* mean, const float* rstd,
+                       const float* gamma, float* sums2, unsigned* barrier, void* dx, float* dgamma, float* dbeta, int P, int C, int act,
+                       int nrep, void* stream) {
+    int PL, threads, chunk, nblocks, nslot;
+    PHX_REQUIRE(dA && x && sums2 && barrier && dx && nrep >= 1, PHX_E_INVAL, "bn_bwd_onepass: null pointer");
+    PHX_REQUIRE(bn_onepass_geometry(P, C, &PL, &threads, &chunk, &nblocks, &nslot), PHX_E_SHAPE,
+                "bn_bwd_onepass: the tensor does not fit 256 blocks x 16 pixels per thread (phx_bn_bwd_onepass_supported)");
+    size_t lds = (size_t)(PL > 2 ? PL : 2) * C * 2 * sizeof(float);
+    if (lds < (size_t)5 * C * sizeof(float)) lds = (size_t)5 * C * sizeof(float);
+    if (lds < (size_t)4 * C * sizeof(float)) lds = (size_t)4 * C * sizeof(float);
+#define PHX_ONEPASS(NS_, ACT_)                                                                                                      \
+    hipLaunchKernelGGL((k_bn_bwd_onepass<NS_, ACT_>), dim3(nblocks), dim3(threads), lds, (hipStream_t)stream, (const bf16_t*)dA,     \
+                       (const bf16_t*)x, scale, shift, mean, rstd, gamma, sums2, barrier, (bf16_t*)dx, dgamma, dbeta, P, C, PL, chunk, nrep)
+    PHX_REQUIRE(act == PHX_ACT_RELU, PHX_E_INVAL, "bn_bwd_onepass: relu layers only (every conv + batch norm of the zoo)");
+    if (nslot == 4) PHX_ONEPASS(4, PHX_ACT_RELU); else if (nslot == 8) PHX_ONEPASS(8, PHX_ACT_RELU); else PHX_ONEPASS(16, PHX_ACT_RELU);
+#undef PHX_ONEPASS
     PHX_CHECK_LAUNCH();
     return PHX_OK;
 }

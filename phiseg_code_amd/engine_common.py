@@ -10,7 +10,7 @@ from phiseg_code_amd import graph as G
 from phiseg_code_amd import runtime as rt
 from phiseg_code_amd.tfwrapper import normalisation as tfnorm
 
-__all__ = ['F32', 'BF16', 'U8', '_TORCH_DT', '_NP_DT', '_ESIZE', '_LIK_SIDE_MAXLVL', '_WGRAD_DEFER_BLOCKS', '_NREP', '_NREP_MINP', '_STAMPS', '_DETERMINISTIC', '_BN_SMALL', '_BN_SMALL_F32', '_BN_WIDE', '_BN_WIDE_MAXLINES', '_SKIP_HEAD_A', '_POOL_FUSE', '_xf_enabled', '_upconv_min_h', 'UpBuf', '_fgn_mode', '_dual_enabled', '_f32_mfma_enabled', '_noop', '_device', 'live_variables', 'device_sync', 'Buf', 'DualBuf', 'HeadGrad', 'SliceGrad', 'XfBuf']
+__all__ = ['F32', 'BF16', 'U8', '_TORCH_DT', '_NP_DT', '_ESIZE', '_LIK_SIDE_MAXLVL', '_WGRAD_DEFER_BLOCKS', '_NREP', '_NREP_MINP', '_STAMPS', '_DETERMINISTIC', '_BN_SMALL', '_BN_SMALL_F32', '_BN_WIDE', '_BN_WIDE_MAXLINES', '_SKIP_HEAD_A', '_POOL_FUSE', '_xf_enabled', '_upconv_min_h', 'UpBuf', '_fgn_mode', '_dual_enabled', '_f32_mfma_enabled', '_onepass_enabled', '_noop', '_device', 'live_variables', 'device_sync', 'Buf', 'DualBuf', 'HeadGrad', 'SliceGrad', 'XfBuf']
 
 F32, BF16, U8 = rt.F32, rt.BF16, 2
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16, U8: torch.uint8}
@@ -62,6 +62,12 @@ def _f32_mfma_enabled():
     # fp32 plans: the 3x3 convolutions and both gradients on the fp32 matrix instruction (csrc/conv_f32_mfma.hip) instead of the vector
     # kernels of conv_direct.hip.  A/B hook (read when a plan is built); 0 = the direct kernels everywhere.
     return os.environ.get("PHX_F32_MFMA", "1") == "1"
+
+
+def _onepass_enabled():
+    # batch-norm backward of the mid-size layers in ONE launch (phx_bn_bwd_onepass: (dA, y) held in registers across a grid barrier)
+    # instead of phx_norm_bwd_reduce + phx_norm_bwd_apply_fused.  A/B hook, read when a plan is built.
+    return os.environ.get("PHX_ONEPASS", "1") == "1"
 
 
 def _noop():

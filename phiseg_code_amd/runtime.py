@@ -63,7 +63,7 @@ class _Lib:
             if name in ("phx_abi_version", "phx_last_error", "phx_conv3x3_mfma_bf16_tiles", "phx_conv3x3_mfma_bf16_tiles_dual", "phx_bn_small_supported", "phx_bn_wide_supported", "phx_norm_apply_pool_supported", "phx_upconv_supported", "phx_norm_small_supported", "phx_conv3x3_mfma_stats_atomic_supported", "phx_norm_head_supported", "phx_conv3x3_mfma_ksplit", "phx_conv3x3_fgn_supported", "phx_conv3x3_mfma_f32out_supported", "phx_conv3x3_xf_supported", "phx_conv3x3_wgrad_xf_supported", "phx_conv3x3_wgrad_multi_job_bytes", "phx_conv3x3_wgrad_ws_bytes", "phx_conv3x3_wgrad_ws_bytes_dual", "phx_augment_param_bytes",
                         "phx_conv3x3_mfma_ws_bytes", "phx_validation_metrics_ws_bytes", "phx_conv2d_direct_wgrad_ordered_ws_bytes",
                         "phx_conv3x3_f32_mfma_supported", "phx_conv3x3_f32_mfma_packed_floats", "phx_conv3x3_f32_mfma_wgrad_supported",
-                        "phx_conv3x3_f32_mfma_wgrad_ws_bytes"):
+                        "phx_conv3x3_f32_mfma_wgrad_ws_bytes", "phx_bn_bwd_onepass_supported", "phx_bn_bwd_onepass_barrier_words"):
                 if name.endswith("_ws_bytes") or name.endswith("_packed_floats"):
                     fn.restype = ctypes.c_size_t
                 setattr(self, name[4:], fn)

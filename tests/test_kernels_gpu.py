@@ -744,6 +744,74 @@ def test_batch_norm_full_size_vs_fp64_reference(L, case):
     assert float(((dx.double() - dx_r) * away).abs().max()) <= 8e-3 * float(dx_r.abs().max())
 
 
+@pytest.mark.parametrize("case", [(64, 32, 32, 128), (64, 16, 16, 192), (64, 16, 16, 384), (64, 8, 8, 192), (64, 32, 32, 64), (7, 12, 12, 96),
+                                  (64, 32, 32, 32), (3, 5, 7, 8), (64, 16, 16, 64)])
+def test_bn_bwd_onepass_vs_float64_and_the_two_pass_kernels(L, case):
+    """phx_bn_bwd_onepass (round 6: batch-norm backward in ONE launch, (dA, x) held in registers across a grid barrier) at the sizes the
+    benchmark runs it and on ragged ones: dx, dgamma, dbeta against the defining formulas in float64 on the device (as the two-pass
+    test above) AND against phx_norm_bwd_reduce + phx_norm_bwd_apply_fused on the same tensors -- dx within one bf16 rounding step of
+    the two-pass result (the per-channel sums differ in summation order only).  The barrier must not have timed out, and a second
+    launch on re-zeroed state gives the same answer with other launches in flight beside it."""
+    B, H, W, C = case
+    P, eps, nrep = B * H * W, 1e-3, 4
+    if not L.bn_bwd_onepass_supported(P, C, 1):
+        pytest.skip("tensor too large for the register-resident form")
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = (torch.randn(P, C, device="cuda", generator=g) * 1.5 + 0.3).to(torch.bfloat16)
+    dA = torch.randn(P, C, device="cuda", generator=g).to(torch.bfloat16)
+    gamma = (1.0 + 0.2 * torch.randn(C, device="cuda", generator=g)).float()
+    beta = (0.1 * torch.randn(C, device="cuda", generator=g)).float()
+    x64, d64, g64, b64 = x.double(), dA.double(), gamma.double(), beta.double()
+    mean_r = x64.mean(0)
+    rstd_r = 1.0 / torch.sqrt(((x64 - mean_r) ** 2).mean(0) + eps)
+    xhat = (x64 - mean_r) * rstd_r
+    pre = g64 * xhat + b64
+    gq = d64 * (pre > 0)
+    dbeta_r, dgamma_r = gq.sum(0), (gq * xhat).sum(0)
+    dx_r = g64 * rstd_r * (gq - dbeta_r / P - xhat * dgamma_r / P)
+    mean, rstd = mean_r.float().contiguous(), rstd_r.float().contiguous()
+    scale = (gamma * rstd).contiguous()
+    shift = (beta - mean * scale).contiguous()
+    # two-pass reference launches
+    sums2 = torch.zeros(nrep, C, 2, dtype=torch.float32, device="cuda")
+    L.norm_bwd_reduce(dA.data_ptr(), BF16, x.data_ptr(), BF16, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                      sums2.data_ptr(), 1, P, C, C, 1, nrep, S())
+    dx2 = torch.empty_like(x)
+    dg2, db2 = torch.zeros(C, dtype=torch.float32, device="cuda"), torch.zeros(C, dtype=torch.float32, device="cuda")
+    L.norm_bwd_apply_fused(dA.data_ptr(), BF16, x.data_ptr(), BF16, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                           gamma.data_ptr(), sums2.data_ptr(), dx2.data_ptr(), BF16, dg2.data_ptr(), db2.data_ptr(), 1, P, C, C, 1, nrep, S())
+    nbar = int(L.bn_bwd_onepass_barrier_words())
+    outs = []
+    side = torch.empty(1 << 24, dtype=torch.float32, device="cuda")
+    s2 = torch.cuda.Stream()
+    for rep in range(2):
+        sums1 = torch.zeros(nrep, C, 2, dtype=torch.float32, device="cuda")
+        bar = torch.zeros(nbar, dtype=torch.int32, device="cuda")
+        dx1 = torch.full_like(x, float("nan"))
+        dg1, db1 = torch.zeros(C, dtype=torch.float32, device="cuda"), torch.zeros(C, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        if rep == 1:                        # other work in flight on another stream while the barrier kernel runs
+            with torch.cuda.stream(s2):
+                for _ in range(4):
+                    side.mul_(1.0001)
+        L.bn_bwd_onepass(dA.data_ptr(), x.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                         sums1.data_ptr(), bar.data_ptr(), dx1.data_ptr(), dg1.data_ptr(), db1.data_ptr(), P, C, 1, nrep, S())
+        torch.cuda.synchronize()
+        assert int(bar[288]) == 0, "grid barrier timed out"
+        outs.append((dx1.double(), host(dg1), host(db1)))
+    for dx1, dg1, db1 in outs:
+        close(db1, dbeta_r.cpu().numpy(), 1e-3, "dbeta")
+        close(dg1, dgamma_r.cpu().numpy(), 1e-3, "dgamma")
+        close(db1, host(db2), 2e-5, "dbeta vs two-pass")
+        close(dg1, host(dg2), 2e-5, "dgamma vs two-pass")
+        away = pre.abs() > 1e-4
+        assert float(((dx1 - dx_r) * away).abs().max()) <= 8e-3 * float(dx_r.abs().max())
+        # against the two-pass launches: the same formula on sums that differ in the last bits -> at most one bf16 step apart
+        d = (dx1 - dx2.double()).abs()
+        assert float(d.max()) <= 2.0 ** -7 * float(dx_r.abs().max()), float(d.max())
+        assert float((d > 0).double().mean()) < 0.02
+
+
 NORM_CASES = [
     # kind, B, H, W, C, G, dt
     ("batch", 3, 8, 8, 32, None, F32),
