@@ -1521,12 +1521,17 @@ __global__ __launch_bounds__(256) void k_norm_bwd_reduce(const TD* __restrict__ 
 #define PHX_BAR_TOP (8 * PHX_BAR_STRIDE)
 #define PHX_BAR_TIMEOUT (9 * PHX_BAR_STRIDE)
 #define PHX_BAR_WORDS (10 * PHX_BAR_STRIDE)
+// PLAIN_STORES: the blocks exchange data written by plain stores (needs the L2 write-back of a release fence, ~1.7 us and more with
+// dirty lines); false: everything exchanged went through agent-scope atomics, which are performed at the coherence point already.
+template <bool PLAIN_STORES>
 __device__ __forceinline__ void phx_grid_barrier(unsigned* __restrict__ bar, int nblocks) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every wave: its stores / atomics have left
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the compiler may drop the fence's own wait: restated)
+        if (PLAIN_STORES) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop the fence's own wait: restated)
+        }
         const int shard = blockIdx.x & 7;
         const unsigned nshard = (unsigned)((nblocks - shard + 7) >> 3);
         const unsigned prev = __hip_atomic_fetch_add(bar + shard * PHX_BAR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1615,7 +1620,7 @@ __global__ __launch_bounds__(256, 2) void k_bn_bwd_onepass(const bf16_t* __restr
         for (int q = 0; q < PL; ++q) a += red[q * 2 * C + i];
         atomicAdd(&srep[i], a);
     }
-    phx_grid_barrier(bar, gridDim.x);
+    phx_grid_barrier<false>(bar, gridDim.x);      // (the only exchanged data are the atomically added sums)
     // (the packed registers are opaque from here on: otherwise the compiler keeps phase 1's unpacked x and g values alive across the
     // barrier -- 16 floats per slot instead of 8 packed registers -- and spills)
 #pragma unroll

@@ -331,10 +331,12 @@ class BackwardLowering:
                 dY = self._alloc(y.shape, y.dt)
                 hg = dA if isinstance(dA, HeadGrad) else None
                 fs0 = sv.get("fsums") if b is not None else None
+                onepass = False
                 if (upc is None and hg is None and fs0 is None and sv["norm"] == "batch" and NS == 1 and Gn == cout and isinstance(dA, Buf)
                         and dA.dt == BF16 and y.dt == BF16 and _onepass_enabled() and Lb.bn_bwd_onepass_supported(P, cout, act)):
                     # mid-size batch-norm layers: ONE launch, (dA, y) read once and held in registers across a grid barrier
                     bar = self._alloc_zeroed(int(Lb.bn_bwd_onepass_barrier_words()))
+                    onepass = True
                     self._emit(Lb.bn_bwd_onepass, dA.ptr, y.ptr, sv["scale"].ptr, sv["shift"].ptr, sv["mean"].ptr, sv["rstd"].ptr,
                                self.store.ptr(nv["gamma"]), sums2.ptr, bar.ptr, dY.ptr, self.store.grad_ptr(nv["gamma"]),
                                self.store.grad_ptr(nv["beta"]), P, cout, act, nrep, S,
@@ -356,7 +358,9 @@ class BackwardLowering:
                 fs = sv.get("fsums") if b is not None else None
                 if fs is not None:
                     db_done = True
-                if upc is not None:
+                if onepass:
+                    pass                                  # (the one launch above formed dY, dgamma and dbeta)
+                elif upc is not None:
                     self._emit(Lb.norm_bwd_apply_fused_s2d, dA.ptr, dA.dt, y.ptr, y.dt, sv["scale"].ptr, sv["shift"].ptr, sv["mean"].ptr,
                                sv["rstd"].ptr, self.store.ptr(nv["gamma"]), sums2.ptr, dY.ptr, dY.dt, self.store.grad_ptr(nv["gamma"]),
                                self.store.grad_ptr(nv["beta"]), fs.ptr if fs is not None else None,
