@@ -68,7 +68,7 @@ static bool make_geo_small(int B, int H, int W, F32Geo* g) {
     return g->mpw && g->mpp && g->npatch <= 256;
 }
 
-// filter gradient: tiles of at most 128 rows and at most 192 patch pixels
+// filter gradient: tiles of at most 128 rows and at most 180 patch pixels (two stages of a 64 x 64-channel block: 157.7 KB of LDS)
 static bool make_geo_wgrad(int B, int H, int W, F32Geo* g) {
     int tw = 1, th = 1;
     g->tws = g->ths = 0;
@@ -76,7 +76,7 @@ static bool make_geo_wgrad(int B, int H, int W, F32Geo* g) {
     while (th < H && th < 8) { th <<= 1; g->ths++; }
     g->pw = tw + 2; g->ph = th + 2;
     int tb = 128 / (tw * th);
-    if (tb > 192 / (g->ph * g->pw)) tb = 192 / (g->ph * g->pw);
+    if (tb > 180 / (g->ph * g->pw)) tb = 180 / (g->ph * g->pw);
     if (tb < 1) tb = 1;
     if (tb > B) tb = B;
     g->tb = tb;
@@ -524,6 +524,134 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f32_wgrad(const float* __res
     if (do_bias && tid < COB && co0 + tid < Cout) wsb[(size_t)slice * Cout + co0 + tid] = dbacc;
 }
 
+// The same filter gradient with the tiles staged by LDS-DMA (buffer_load ... lds: no staging registers, no ds_write pass) into TWO
+// LDS stages: the next tile's patch and dy rows land while the running tile's matrix instructions issue -- one block per CU, its four
+// waves one per SIMD, the matrix pipe never waits for a load phase.  Lane-linear destination: lane l of wave-instruction j fills the
+// 16-byte slot 64 j + l, i.e. piece (64 j + l) % Q of pixel (64 j + l) / Q with Q = channels / 4 pieces per pixel -- exactly the
+// [pixel][channel] image the operand reads want; out-of-image pieces (and channels beyond Cin / Cout) get offset 0xffffffff, which
+// the buffer's range check turns into zeros.  Needs Cin % 4 == 0 (16-byte pieces); the register-staged kernel above takes the rest.
+template <int CIW, int COW>
+__global__ __launch_bounds__(256, 1) void k_conv3x3_f32_wgrad_dma(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                   float* __restrict__ ws, float* __restrict__ wsb, int B, int H, int W,
+                                                                   int Cin, int Cout, int ciblocks, int tps, int ntiles, F32Geo g) {
+    constexpr int PS = 4 / (CIW * COW), CIB = 32 * CIW, COB = 32 * COW, QX = CIB / 4, QD = COB / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int npatch = g.npatch, rows = g.rows;
+    const int nx = npatch * QX, nd = rows * QD;                     // 16-byte pieces of the patch / of the dy tile
+    const int nxi = (nx + 63) >> 6, ndi = (nd + 63) >> 6;           // wave-instructions
+    const int stage_floats = (nxi + ndi) * 256;                     // (each instruction fills 1 KB)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int ps = wv / (CIW * COW), cis = (wv % (CIW * COW)) % CIW, cos = (wv % (CIW * COW)) / CIW;
+    const int ci0 = (blockIdx.y % ciblocks) * CIB, co0 = (blockIdx.y / ciblocks) * COB;
+    const int tw = 1 << g.tws, th = 1 << g.ths, pw = g.pw, ph = g.ph;
+    const int slice = blockIdx.x;
+    const int t_lo = slice * tps, t_hi = min(ntiles, t_lo + tps);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * Cin * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * H * W * Cout * 4u), 0x00020000);
+
+    auto issue = [&](int tile, int stage) {
+        int t = tile;
+        const int tx0 = (t % g.tiles_x) << g.tws; t /= g.tiles_x;
+        const int ty0 = (t % g.tiles_y) << g.ths; t /= g.tiles_y;
+        const int b0 = t * g.tb;
+        char* base = (char*)(smem + (size_t)stage * stage_floats);
+        for (int j = wv; j < nxi; j += 4) {
+            const int e = j * 64 + lane;
+            const unsigned pp = (unsigned)e / QX;
+            const int c = ci0 + (e % QX) * 4;
+            const int bi = (int)((pp * g.mpp) >> 20);
+            const unsigned rem = pp - bi * ph * pw;
+            const int py = (int)((rem * g.mpw) >> 20);
+            const int px = (int)rem - py * pw;
+            const int gy = ty0 + py - 1, gx = tx0 + px - 1, gb = b0 + bi;
+            const bool ok = e < nx && gb < B && gy >= 0 && gy < H && gx >= 0 && gx < W && c < Cin;
+            const unsigned vo = ok ? (unsigned)(((gb * H + gy) * W + gx) * Cin + c) * 4u : 0xffffffffu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(base + j * 1024), 16, vo, 0, 0, 0);
+        }
+        for (int j = wv; j < ndi; j += 4) {
+            const int e = j * 64 + lane;
+            const int r = e / QD;
+            const int c = co0 + (e % QD) * 4;
+            const int ox = tx0 + (r & (tw - 1)), oy = ty0 + ((r >> g.tws) & (th - 1)), ob = b0 + (r >> (g.tws + g.ths));
+            const bool ok = e < nd && ox < W && oy < H && ob < B && c < Cout;
+            const unsigned vo = ok ? (unsigned)(((ob * H + oy) * W + ox) * Cout + c) * 4u : 0xffffffffu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsd, (lds_ptr_t)(base + (nxi + j) * 1024), 16, vo, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t9][e] = 0.f;
+    float dbacc = 0.f;
+    const bool do_bias = wsb != nullptr && (blockIdx.y % ciblocks) == 0;
+    const int npairs = rows >> 1;
+    const int j_lo = ps * npairs / PS, j_hi = (ps + 1) * npairs / PS;
+
+    if (t_lo < t_hi) issue(t_lo, 0);
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+        const int stage = (tile - t_lo) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of the running tile have landed ...
+        __syncthreads();                                             // ... and everybody's; the other stage is free (its tile is consumed)
+        if (tile + 1 < t_hi) issue(tile + 1, stage ^ 1);
+        const float* sx = smem + (size_t)stage * stage_floats;
+        const float* sd = sx + (size_t)nxi * 256;
+        auto operands = [&](int j, float (&a)[9], float& bv) {
+            const int r = 2 * j + hh;
+            const int lx = r & (tw - 1), ly = (r >> g.tws) & (th - 1), bi = r >> (g.tws + g.ths);
+            const float* pa = sx + (size_t)((bi * ph + ly) * pw + lx) * CIB + cis * 32 + l31;
+            bv = sd[(size_t)r * COB + cos * 32 + l31];
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) a[t9] = pa[(size_t)((t9 / 3) * pw + (t9 % 3)) * CIB];
+        };
+        float a0[9], b0v, a1[9], b1v;
+        if (j_lo < j_hi) operands(j_lo, a0, b0v);
+        for (int j = j_lo; j < j_hi; j += 2) {                       // operands of the next pair are read under this pair's instructions
+            if (j + 1 < j_hi) operands(j + 1, a1, b1v);
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) acc[t9] = mfma32(a0[t9], b0v, acc[t9]);
+            if (j + 1 < j_hi) {
+                if (j + 2 < j_hi) operands(j + 2, a0, b0v);
+#pragma unroll
+                for (int t9 = 0; t9 < 9; ++t9) acc[t9] = mfma32(a1[t9], b1v, acc[t9]);
+            }
+        }
+        if (do_bias && tid < COB)
+            for (int r = 0; r < rows; ++r) dbacc += sd[(size_t)r * COB + tid];
+    }
+    if (PS > 1) {
+        float* sr = smem;
+        const int sub = wv % (CIW * COW);
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) {
+            __syncthreads();
+            if (ps > 0)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sr[(size_t)(((ps - 1) * CIW * COW + sub) * 16 + e) * 64 + lane] = acc[t9][e];
+            __syncthreads();
+            if (ps == 0)
+                for (int p = 0; p < PS - 1; ++p)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[t9][e] += sr[(size_t)((p * CIW * COW + sub) * 16 + e) * 64 + lane];
+        }
+    }
+    float* wo = ws + (size_t)slice * 9 * Cin * Cout;
+    const int co = co0 + cos * 32 + l31;
+    if (ps == 0) {
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ci = ci0 + cis * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                if (ci < Cin && co < Cout) wo[((size_t)t9 * Cin + ci) * Cout + co] = acc[t9][e];
+            }
+    }
+    if (do_bias && tid < COB && co0 + tid < Cout) wsb[(size_t)slice * Cout + co0 + tid] = dbacc;
+}
+
 // dst[e] += sum over the slices: a block takes 64 consecutive elements, its four waves every fourth slice each; the four partial
 // sums are added in wave order (a fixed order)
 __global__ __launch_bounds__(256) void k_f32_wgrad_reduce(const float* __restrict__ ws, int nslice, size_t n, float* __restrict__ dst,
@@ -557,6 +685,7 @@ __global__ __launch_bounds__(256) void k_f32_wgrad_reduce(const float* __restric
 struct WgradPlan {
     F32Geo g;
     int ciw, cow, ps, ciblocks, coblocks, ntiles, tps, nslice;
+    bool dma;
     size_t lds, ws_floats, wsb_floats;
 };
 
@@ -568,13 +697,17 @@ static bool plan_wgrad(int B, int H, int W, int Cin, int Cout, bool with_bias, W
     p->ciblocks = (Cin + 32 * p->ciw - 1) / (32 * p->ciw);
     p->coblocks = (Cout + 32 * p->cow - 1) / (32 * p->cow);
     p->ntiles = p->g.tiles_x * p->g.tiles_y * p->g.tiles_b;
-    int want = 1024 / (p->ciblocks * p->coblocks);          // ~4 blocks per CU in all: two resident, two queued
+    // LDS-DMA form: 16-byte pieces (Cin % 4 == 0), 32-bit byte offsets, two stages within 160 KB
+    const size_t stage = (size_t)(((p->g.npatch * 8 * p->ciw + 63) >> 6) + ((p->g.rows * 8 * p->cow + 63) >> 6)) * 1024;
+    p->dma = Cin % 4 == 0 && (double)B * H * W * (Cin > Cout ? Cin : Cout) * 4.0 < 4294967296.0 && 2 * stage <= 160 * 1024;
+    int want = (p->dma ? 512 : 1024) / (p->ciblocks * p->coblocks);     // two rounds of resident blocks (DMA form: one block per CU)
     if (want < 1) want = 1;
     if (want > 256) want = 256;                              // bound the workspace (256 partial filters)
     if (want > p->ntiles) want = p->ntiles;
     p->tps = (p->ntiles + want - 1) / want;
     p->nslice = (p->ntiles + p->tps - 1) / p->tps;
     p->lds = ((size_t)p->g.npatch * 32 * p->ciw + (size_t)p->g.rows * 32 * p->cow) * 4;
+    if (p->dma) p->lds = 2 * stage;
     if (p->lds < (size_t)(p->ps - 1) * p->ciw * p->cow * 4096) p->lds = (size_t)(p->ps - 1) * p->ciw * p->cow * 4096;
     p->ws_floats = (size_t)p->nslice * 9 * Cin * Cout;
     p->wsb_floats = with_bias ? (size_t)p->nslice * Cout : 0;
@@ -675,10 +808,27 @@ int phx_conv3x3_f32_mfma_wgrad(const float* x, const float* dy, float* dw_hwio, 
         }                                                                                                                            \
         k_conv3x3_f32_wgrad<CIW, COW><<<grid, 256, p.lds, s>>>(x, dy, ws, wsb, B, H, W, Cin, Cout, p.ciblocks, p.tps, p.ntiles, p.g); \
     } while (0)
-    if (p.ciw == 2 && p.cow == 2) PHX_F32_WGRAD(2, 2);
+#define PHX_F32_WGRAD_DMA(CIW, COW)                                                                                                  \
+    do {                                                                                                                             \
+        static bool attr = false;                                                                                                    \
+        if (!attr) {                                                                                                                 \
+            PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_f32_wgrad_dma<CIW, COW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                              160 * 1024));                                                                          \
+            attr = true;                                                                                                             \
+        }                                                                                                                            \
+        k_conv3x3_f32_wgrad_dma<CIW, COW><<<grid, 256, p.lds, s>>>(x, dy, ws, wsb, B, H, W, Cin, Cout, p.ciblocks, p.tps, p.ntiles, p.g); \
+    } while (0)
+    if (p.dma) {
+        if (p.ciw == 2 && p.cow == 2) PHX_F32_WGRAD_DMA(2, 2);
+        else if (p.ciw == 1 && p.cow == 2) PHX_F32_WGRAD_DMA(1, 2);
+        else if (p.ciw == 2 && p.cow == 1) PHX_F32_WGRAD_DMA(2, 1);
+        else PHX_F32_WGRAD_DMA(1, 1);
+    }
+    else if (p.ciw == 2 && p.cow == 2) PHX_F32_WGRAD(2, 2);
     else if (p.ciw == 1 && p.cow == 2) PHX_F32_WGRAD(1, 2);
     else if (p.ciw == 2 && p.cow == 1) PHX_F32_WGRAD(2, 1);
     else PHX_F32_WGRAD(1, 1);
+#undef PHX_F32_WGRAD_DMA
 #undef PHX_F32_WGRAD
     PHX_CHECK_LAUNCH();
     const size_t n = (size_t)9 * Cin * Cout;

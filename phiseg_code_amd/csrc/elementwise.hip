@@ -1532,11 +1532,17 @@ __device__ __forceinline__ void phx_grid_barrier(unsigned* __restrict__ bar, int
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop the fence's own wait: restated)
         }
-        const int shard = blockIdx.x & 7;
-        const unsigned nshard = (unsigned)((nblocks - shard + 7) >> 3);
-        const unsigned prev = __hip_atomic_fetch_add(bar + shard * PHX_BAR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev + 1 == nshard) __hip_atomic_fetch_add(bar + PHX_BAR_TOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned want = nblocks < 8 ? (unsigned)nblocks : 8u;
+        unsigned want;
+        if (nblocks <= 64) {                                  // few blocks: one level (one atomic round trip less)
+            __hip_atomic_fetch_add(bar + PHX_BAR_TOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            want = (unsigned)nblocks;
+        } else {
+            const int shard = blockIdx.x & 7;
+            const unsigned nshard = (unsigned)((nblocks - shard + 7) >> 3);
+            const unsigned prev = __hip_atomic_fetch_add(bar + shard * PHX_BAR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev + 1 == nshard) __hip_atomic_fetch_add(bar + PHX_BAR_TOP, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            want = 8u;
+        }
         unsigned spins = 0;
         while (__hip_atomic_load(bar + PHX_BAR_TOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
             __builtin_amdgcn_s_sleep(4);
