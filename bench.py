@@ -346,6 +346,7 @@ def main():
     dt_own = time.perf_counter() - t0
     dt = ctx.max_float(dt_own)
     loss = None if generate else float(plan.fetch(model.loss_tot))
+    assert plan.barrier_timeouts() == 0, "an in-kernel grid barrier timed out during the timed steps: the result is invalid"
     ranks_seen = int(round(ctx.sum_float(1.0)))          # every rank that really took part in the timed collectives
     dp_diag = None
     if ctx.active and not generate:

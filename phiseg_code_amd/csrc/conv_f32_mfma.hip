@@ -531,9 +531,11 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f32_wgrad(const float* __res
 // [pixel][channel] image the operand reads want; out-of-image pieces (and channels beyond Cin / Cout) get offset 0xffffffff, which
 // the buffer's range check turns into zeros.  Needs Cin % 4 == 0 (16-byte pieces); the register-staged kernel above takes the rest.
 template <int CIW, int COW>
-__global__ __launch_bounds__(256, 1) void k_conv3x3_f32_wgrad_dma(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(512, 2) void k_conv3x3_f32_wgrad_dma(const float* __restrict__ x, const float* __restrict__ dy,
                                                                    float* __restrict__ ws, float* __restrict__ wsb, int B, int H, int W,
                                                                    int Cin, int Cout, int ciblocks, int tps, int ntiles, F32Geo g) {
+    // 512 threads: waves 0-3 compute (one per SIMD), waves 4-7 only issue the DMA of the next tile (their address arithmetic -- ~40
+    // integer instructions per 1 KB piece row -- fills the issue slots under the matrix instructions of the wave they share a SIMD with)
     constexpr int PS = 4 / (CIW * COW), CIB = 32 * CIW, COB = 32 * COW, QX = CIB / 4, QD = COB / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -541,7 +543,9 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f32_wgrad_dma(const float* _
     const int nx = npatch * QX, nd = rows * QD;                     // 16-byte pieces of the patch / of the dy tile
     const int nxi = (nx + 63) >> 6, ndi = (nd + 63) >> 6;           // wave-instructions
     const int stage_floats = (nxi + ndi) * 256;                     // (each instruction fills 1 KB)
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool loader = tid >= 256;
+    const int wv = (tid >> 6) & 3;
     const int l31 = lane & 31, hh = lane >> 5;
     const int ps = wv / (CIW * COW), cis = (wv % (CIW * COW)) % CIW, cos = (wv % (CIW * COW)) / CIW;
     const int ci0 = (blockIdx.y % ciblocks) * CIB, co0 = (blockIdx.y / ciblocks) * COB;
@@ -591,12 +595,15 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f32_wgrad_dma(const float* _
     const int npairs = rows >> 1;
     const int j_lo = ps * npairs / PS, j_hi = (ps + 1) * npairs / PS;
 
-    if (t_lo < t_hi) issue(t_lo, 0);
+    if (loader && t_lo < t_hi) issue(t_lo, 0);
     for (int tile = t_lo; tile < t_hi; ++tile) {
         const int stage = (tile - t_lo) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of the running tile have landed ...
-        __syncthreads();                                             // ... and everybody's; the other stage is free (its tile is consumed)
-        if (tile + 1 < t_hi) issue(tile + 1, stage ^ 1);
+        if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the loader waves' pieces of the running tile have landed ...
+        __syncthreads();                                                   // ... for everybody; the other stage's tile is consumed
+        if (loader) {
+            if (tile + 1 < t_hi) issue(tile + 1, stage ^ 1);
+            continue;
+        }
         const float* sx = smem + (size_t)stage * stage_floats;
         const float* sd = sx + (size_t)nxi * 256;
         auto operands = [&](int j, float (&a)[9], float& bv) {
@@ -628,16 +635,17 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_f32_wgrad_dma(const float* _
 #pragma unroll
         for (int t9 = 0; t9 < 9; ++t9) {
             __syncthreads();
-            if (ps > 0)
+            if (!loader && ps > 0)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) sr[(size_t)(((ps - 1) * CIW * COW + sub) * 16 + e) * 64 + lane] = acc[t9][e];
             __syncthreads();
-            if (ps == 0)
+            if (!loader && ps == 0)
                 for (int p = 0; p < PS - 1; ++p)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[t9][e] += sr[(size_t)((p * CIW * COW + sub) * 16 + e) * 64 + lane];
         }
     }
+    if (loader) return;
     float* wo = ws + (size_t)slice * 9 * Cin * Cout;
     const int co = co0 + cos * 32 + l31;
     if (ps == 0) {
@@ -816,7 +824,7 @@ int phx_conv3x3_f32_mfma_wgrad(const float* x, const float* dy, float* dw_hwio, 
                                               160 * 1024));                                                                          \
             attr = true;                                                                                                             \
         }                                                                                                                            \
-        k_conv3x3_f32_wgrad_dma<CIW, COW><<<grid, 256, p.lds, s>>>(x, dy, ws, wsb, B, H, W, Cin, Cout, p.ciblocks, p.tps, p.ntiles, p.g); \
+        k_conv3x3_f32_wgrad_dma<CIW, COW><<<grid, 512, p.lds, s>>>(x, dy, ws, wsb, B, H, W, Cin, Cout, p.ciblocks, p.tps, p.ntiles, p.g); \
     } while (0)
     if (p.dma) {
         if (p.ciw == 2 && p.cow == 2) PHX_F32_WGRAD_DMA(2, 2);

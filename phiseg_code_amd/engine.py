@@ -198,6 +198,7 @@ class Plan(ForwardLowering, BackwardLowering):
         self._headw_jobs = {}         # deferred 1x1-head filter gradients by (x dtype, nout): (x, dy, dw, db, npix, C, PL, chunk, grid, lds)
         self._wgr_jobs = []           # deferred filter-gradient reductions: (ws, dw, nslice, Cin, Cout, tci, tco, gx, gy)
         self._pack_jobs = []          # (w, wpk_fwd, wpk_dgrad, Cin, Cin_pad, Cout): ONE multi-filter pack launch per run
+        self._barriers = []           # grid-barrier words of the one-launch kernels (zero arena): word 288 != 0 = that barrier timed out
         self._wpk32, self._pack32_jobs = {}, []     # fp32 plans: packed fp32 filters of the fp32 matrix kernels, [w, wpk_fwd, wpk_dgrad, Cin, Cout]
         self._bninfer_jobs = []       # (gamma, beta, moving_mean, moving_var, scale, shift, C, eps): ONE launch per run
         self._zarena = torch.zeros(8 << 20, dtype=torch.float32, device=_device())     # 32 MB of per-step accumulators
@@ -647,6 +648,12 @@ class Plan(ForwardLowering, BackwardLowering):
 
     def sync(self):
         self.L.stream_sync(self.stream)
+
+    def barrier_timeouts(self):
+        """Number of in-kernel grid barriers of the LAST replay that gave up waiting (phx_bn_bwd_onepass: bounded spin).  0 on a healthy
+        run; anything else means that launch's result was wrong -- callers that time or publish results check it."""
+        self.sync()
+        return sum(int(b.t[288].item() != 0) for b in self._barriers)
 
     def kernel_launch_count(self):
         """Entries of the launch lists that call a launching entry point of the C ABI (kernels and fills): everything but the event

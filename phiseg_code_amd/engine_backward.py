@@ -336,6 +336,7 @@ class BackwardLowering:
                         and dA.dt == BF16 and y.dt == BF16 and _onepass_enabled() and Lb.bn_bwd_onepass_supported(P, cout, act)):
                     # mid-size batch-norm layers: ONE launch, (dA, y) read once and held in registers across a grid barrier
                     bar = self._alloc_zeroed(int(Lb.bn_bwd_onepass_barrier_words()))
+                    self._barriers.append(bar)
                     onepass = True
                     self._emit(Lb.bn_bwd_onepass, dA.ptr, y.ptr, sv["scale"].ptr, sv["shift"].ptr, sv["mean"].ptr, sv["rstd"].ptr,
                                self.store.ptr(nv["gamma"]), sums2.ptr, bar.ptr, dY.ptr, self.store.grad_ptr(nv["gamma"]),

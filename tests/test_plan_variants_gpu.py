@@ -138,3 +138,84 @@ def test_training_plan_with_the_phase_form_of_upsample_conv_at_batch_16(monkeypa
             errs.append(np.linalg.norm(g1[name] - ga) / nrm)
     print("phase form vs materialised plan: loss %.6g / %.6g, mean relative gradient distance %.4f over %d variables" % (l1, l0, np.mean(errs), len(errs)))
     assert len(errs) >= 360 and np.mean(errs) <= 0.5, (len(errs), np.mean(errs))
+
+
+def _one_step(cfg, dtype, params, x_np, s_np, count=()):
+    from phiseg_code_amd.phiseg import phiseg_model
+    from tests.test_graph_cpu import make_config
+    model = phiseg_model.phiseg(make_config(cfg, dtype), rng_seed=cfg["eps_seed"])
+    model.set_weights({k: t.detach().numpy() for k, t in params.items()})
+    plan = model.sess.plan_for([model.loss_tot], True, cfg["B"], True)
+    plan.set_input("x_input", x_np)
+    plan.set_input("s_input", s_np)
+    model.sess.store.set_lr(0.0)
+    plan.run()
+    plan.sync()
+    assert plan.barrier_timeouts() == 0
+    names = [getattr(fn, "__name__", "") for fn, _ in plan.launches]
+    return float(plan.fetch(model.loss_tot)), model.sess.store.export(grads=True), {n: sum(m == n for m in names) for n in count}
+
+
+def test_training_plan_with_one_launch_batch_norm_backward_at_batch_64(monkeypatch):
+    """Round 6: the batch-norm backward of the mid-size layers in ONE launch (phx_bn_bwd_onepass: (dA, y) in registers across a grid
+    barrier; tfwrapper/normalisation.py:145-163's gradient) at the benchmark's batch, where ~60 layers qualify, against the plan with the
+    two-pass launches (PHX_ONEPASS=0): the launches are there, their two-pass twins are gone, no barrier timed out, loss and every
+    gradient agree to what two bf16 evaluations of the same step differ by (same formulas; per-channel sums in another order)."""
+    import torch
+    from oracle import init as oinit
+    from oracle import train as otrain
+    from tests.helpers import load_golden
+    g, cfg, var_order = load_golden("lidc_phiseg_bn")
+    cfg = dict(cfg, B=64)
+    params = otrain.make_params(var_order, cfg["weight_seed"], torch.float32, perturbed=True)
+    x_np, s_np = oinit.synthetic_batch(cfg["B"], cfg["H"], cfg["nlabels"], cfg["data_seed"])
+    cnt = ("phx_bn_bwd_onepass", "phx_norm_bwd_reduce", "phx_norm_bwd_apply_fused_bias")
+    res = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("PHX_ONEPASS", v)
+        res[v] = _one_step(cfg, "bf16", params, x_np, s_np, cnt)
+    (l0, g0, c0), (l1, g1, c1) = res["0"], res["1"]
+    assert c0["phx_bn_bwd_onepass"] == 0 and c1["phx_bn_bwd_onepass"] >= 40, (c0, c1)
+    assert c1["phx_norm_bwd_reduce"] == c0["phx_norm_bwd_reduce"] - c1["phx_bn_bwd_onepass"], (c0, c1)
+    assert c1["phx_norm_bwd_apply_fused_bias"] == c0["phx_norm_bwd_apply_fused_bias"] - c1["phx_bn_bwd_onepass"], (c0, c1)
+    assert abs(l1 - l0) <= 2e-2 * abs(l0), (l0, l1)
+    errs = []
+    for name, ga in g0.items():
+        nrm = np.linalg.norm(ga)
+        if nrm >= 1e-8 * max(1.0, np.sqrt(ga.size)):
+            errs.append(np.linalg.norm(g1[name] - ga) / nrm)
+    print("one-launch vs two-pass batch-norm backward: loss %.6g / %.6g, mean relative gradient distance %.4f over %d variables" % (l1, l0, np.mean(errs), len(errs)))
+    assert len(errs) >= 360 and np.mean(errs) <= 0.5, (len(errs), np.mean(errs))
+
+
+def test_fp32_plan_on_the_matrix_kernels_equals_the_direct_kernels(monkeypatch):
+    """Round 6: the fp32 parity plan with its 3x3 convolutions on v_mfma_f32_32x32x2_f32 (csrc/conv_f32_mfma.hip) against the same plan on
+    the vector kernels of csrc/conv_direct.hip (PHX_F32_MFMA=0), phiseg_7_5 n0 = 32, 128 x 128, batch 2: the matrix launches are there,
+    loss to 1e-5 and every variable's gradient to fp32's conditioning of this step (both are fp32 FMA chains; the order differs)."""
+    from tests.test_model_gpu import _lidc_setup
+    cnt = ("phx_conv3x3_f32_mfma", "phx_conv3x3_f32_mfma_wgrad", "phx_conv2d_direct", "phx_conv2d_direct_wgrad")
+    res = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("PHX_F32_MFMA", v)
+        cfg, model, params, x_np, s_np = _lidc_setup("f32", perturbed=True)
+        plan = model.sess.plan_for([model.loss_tot], True, cfg["B"], True)
+        plan.set_input("x_input", x_np)
+        plan.set_input("s_input", s_np)
+        model.sess.store.set_lr(0.0)
+        plan.run()
+        plan.sync()
+        names = [getattr(fn, "__name__", "") for fn, _ in plan.launches]
+        res[v] = (float(plan.fetch(model.loss_tot)), model.sess.store.export(grads=True), {n: sum(m == n for m in names) for n in cnt})
+        del plan, model
+    (l0, g0, c0), (l1, g1, c1) = res["0"], res["1"]
+    assert c0["phx_conv3x3_f32_mfma"] == 0 and c1["phx_conv3x3_f32_mfma"] >= 150 and c1["phx_conv3x3_f32_mfma_wgrad"] >= 100, (c0, c1)
+    assert c1["phx_conv2d_direct"] <= 30 and c1["phx_conv2d_direct_wgrad"] <= 12, c1      # (the Cout = 2 heads and the image-input data gradients stay)
+    assert abs(l1 - l0) <= 1e-5 * abs(l0), (l0, l1)
+    errs = []
+    for name, ga in g0.items():
+        nrm = np.linalg.norm(ga)
+        if nrm >= 1e-8 * max(1.0, np.sqrt(ga.size)):
+            errs.append(np.linalg.norm(g1[name] - ga) / nrm)
+    print("fp32 matrix vs direct kernels: loss %.8g / %.8g, mean / max relative gradient distance %.2e / %.2e over %d variables" %
+          (l1, l0, np.mean(errs), np.max(errs), len(errs)))
+    assert len(errs) >= 360 and np.mean(errs) <= 1e-3, (len(errs), np.mean(errs))
