@@ -348,7 +348,7 @@ def test_full_size_bench_configuration_properties_bf16():
     # A second evaluation is NOT bit-identical on the bf16 path: the statistics of the small-map layers and the
     # gradient reductions use fp32 atomics, whose order varies; bf16 rounding flips amplify that 1e-7 noise, and the level-0
     # KL term of a freshly initialised net (sigma ~ 0: 95 % of this ELBO) is ill-conditioned -- measured spread +-5 %
-    # (tools/debug_repro.py; the fp32 path reproduces to 2e-5).  Bound it, do not pretend equality.
+    # (measured in round 2; the fp32 path reproduces to 2e-5).  Bound it, do not pretend equality.
     tot2 = float(model.sess.run(model.loss_tot, fd))
     np.testing.assert_allclose(tot2, float(tot), rtol=0.2)
     _, tot3 = model.sess.run([model.train_step, model.loss_tot], fd)

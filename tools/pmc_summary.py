@@ -1,5 +1,7 @@
-"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE csv passes into a per-kernel HBM traffic table (+ json)."""
-import collections, csv, json, sys
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE csv passes into a per-kernel HBM traffic table (+ json).
+The json carries `_meta` = {commit, collected_by}: bench.py reports where its `roofline.traffic` comes from (PHX_COMMIT in the
+environment of tools/collect_profiles.sh: the GPU box has no .git)."""
+import collections, csv, json, os, sys
 d, steps, out_txt, out_json = sys.argv[1], float(sys.argv[2]), sys.argv[3], sys.argv[4]
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -9,7 +11,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         agg[k][0] += float(row["Counter_Value"]); agg[k][1] += 1
     res[c] = agg
 names = sorted(res["FETCH_SIZE"], key=lambda k: -(2 * res["FETCH_SIZE"][k][0] + res["WRITE_SIZE"].get(k, [0, 0])[0]))
-lines = ["# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, with --kernel-trace only), python bench.py --steps 2 --warmup 2",
+lines = ["# commit %s" % os.environ.get("PHX_COMMIT", "?"),
+         "# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, with --kernel-trace only), python bench.py --steps 2 --warmup 2",
          "# phiseg_7_5 128x128 bf16 B=64, per training step.  Counters are in KB.  gfx950: FETCH_SIZE tallies 64 B per 128-B request for",
          "# wide coalesced reads (MI355X_MICROARCH.md, HBM) -> 'fetch x2' is the corrected read traffic; WRITE_SIZE uncalibrated.",
          "%-64s %9s %12s %12s %12s %14s" % ("kernel", "calls/st", "fetch MB/st", "fetch x2", "write MB/st", "MB/launch(x2+w)")]
@@ -21,9 +24,10 @@ for k in names:
     per = (2 * f + w) / n / 1024 if n else 0
     js[k] = {"calls_per_step": n / steps, "fetch_x2_MB_per_step": 2 * f / steps / 1024, "write_MB_per_step": w / steps / 1024,
              "MB_per_launch": per}
-    if len(lines) < 34:
+    if len(lines) < 35:
         lines.append("%-64s %9.1f %12.1f %12.1f %12.1f %14.2f" % (k[:64], n / steps, f / steps / 1024, 2 * f / steps / 1024, w / steps / 1024, per))
 lines.append("TOTAL per step: fetch x2 %.1f MB + write %.1f MB = %.1f GB" % (2 * tf / steps / 1024, tw / steps / 1024, (2 * tf + tw) / steps / 1024 / 1024))
 open(out_txt, "w").write("\n".join(lines) + "\n")
+js["_meta"] = {"commit": os.environ.get("PHX_COMMIT", ""), "collected_by": "tools/collect_profiles.sh"}
 json.dump(js, open(out_json, "w"), indent=1)
-print("\n".join(lines[:14] + lines[-1:]))
+print("\n".join(lines[:15] + lines[-1:]))
