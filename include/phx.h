@@ -93,19 +93,17 @@ size_t phx_conv3x3_f32_mfma_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cou
 int phx_conv3x3_f32_mfma_wgrad(const float* x, const float* dy, float* dw_hwio, float* dbias, void* workspace,
                                size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, void* stream);
 
-/* bf16 MFMA path (v_mfma_f32_32x32x16_bf16), 3x3 only, Cin % 32 == 0, Cout % 32 == 0.
+/* ---- bf16 MFMA path (v_mfma_f32_32x32x16_bf16): 3x3 SAME convolution, forward and data gradient -------------------------------
+ * tf.nn.conv2d + bias_add + activation of tfwrapper/layers.py:122-135 and what optimizer.minimize derives for its input
+ * (phiseg_model.py:141), Cin % 32 == 0, Cout % 32 == 0, bf16 NHWC tensors.
  * wpk is the packed bf16 filter [K / 32][9][N][32] (element (tap t, row n, channel k) at (((k / 32) * 9 + t) * N + n) * 32
  * + k % 32: the slab of one 32-channel chunk is contiguous) written by phx_pack_conv3x3_bf16:
  *   forward:  N = Cout, K = Cin, tap t = kh*3+kw          (wpk_fwd)
- *   dgrad:    N = Cin,  K = Cout, tap t = (2-kh)*3+(2-kw) (wpk_dgrad); call with x := dy, K := Cout, N := Cin.
- * Optional epilogue: + bias[N], act, and per-channel {sum, sumsq} of the bf16-rounded output into
- * stats_partial[gridDim.x][2][N] (one row per pixel-tile, no atomics; reduced by phx_norm_finalize). */
+ *   dgrad:    N = Cin,  K = Cout, tap t = (2-kh)*3+(2-kw) (wpk_dgrad); launch with x := dy, K := Cout, N := Cin. */
 int phx_pack_conv3x3_bf16(const float* w_hwio, void* wpk_fwd, void* wpk_dgrad, int Cin, int Cout, void* stream);
-int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* bias, int act,
-                          float* stats_partial, int B, int H, int W, int K, int N, void* stream);
 /* Narrow-input convolutions (image inputs Cin = 1 / 3, posteriors.py:87, priors.py:80; latent inputs Cin = zdim0 = 2,
- * likelihoods.py:197, posteriors.py:115): zero-pad the channel axis to Cin_pad = 32 so they run on the MFMA kernels: padded bf16 copy of the input, padded packed filter, and the filter gradient of the
- * padded problem folded back into dw_hwio[9][Cin][Cout]. */
+ * likelihoods.py:197, posteriors.py:115): zero-pad the channel axis to Cin_pad = 32 so they run on the MFMA kernels: padded bf16 copy
+ * of the input, padded packed filter, and the filter gradient of the padded problem folded back into dw_hwio[9][Cin][Cout]. */
 int phx_pack_conv3x3_bf16_pad(const float* w_hwio, void* wpk_fwd, void* wpk_dgrad /* nullable */, int Cin, int Cin_pad,
                               int Cout, void* stream);
 /* every filter of a step in one launch: descs_dev = device array of n records
@@ -117,54 +115,74 @@ int phx_unpad_filter_grad_accumulate(const float* dw_pad, float* dw_hwio, int Ci
 /* 1x1 convolutions run as the centre tap of a 3x3 (descriptor field k1 of phx_pack_conv3x3_bf16_multi):
  * dw_1x1[ci][co] += dw_pad[tap 4][ci][co] */
 int phx_unpad_filter_grad_center(const float* dw_pad, float* dw_1x1, int Cin, int Cin_pad, int Cout, void* stream);
-/* Split-K variant for small maps (few pixel tiles): with a workspace of phx_conv3x3_mfma_ws_bytes (0: not used for this
- * shape) and stats_partial == NULL, the K / 32 chunks are spread over several blocks per tile and a second kernel sums the
- * fp32 slices and applies bias / activation.  Otherwise identical to phx_conv3x3_mfma_bf16. */
-size_t phx_conv3x3_mfma_ws_bytes(int B, int H, int W, int K, int N);
-/* number of fp32 slices that launch leaves (1: no split).  With y == NULL (and no bias / activation) the finishing pass is
- * skipped and the slices ws[z][B*H*W][N] stay in the workspace for a consumer that sums them itself. */
-int phx_conv3x3_mfma_ksplit(int B, int H, int W, int K, int N);
-int phx_conv3x3_mfma_bf16_ws(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
-                             void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream);
-/* The same launch with its output statistics ADDED ATOMICALLY into sums[N][2] = {sum y, sum y^2} (zeroed by the caller; the
- * layout phx_norm_apply_fused takes, pivot = NULL) instead of per-tile partial sums: for layers with at most 64 pixel tiles (the
- * H <= 16 levels at batch 64), where neither a reduction launch nor a statistics pass over y pays.  Not in deterministic mode. */
-int phx_conv3x3_mfma_stats_atomic_supported(int B, int H, int W, int K, int N);
-int phx_conv3x3_mfma_bf16_stats_atomic(const void* x, const void* wpk, void* y, const float* bias, int act, float* sums, int B,
-                                       int H, int W, int K, int N, void* stream);
-/* Concat-free convolution (the reference feeds tf.concat([a, b], axis=3) to a 3x3 conv2D: posteriors.py:87,120, priors.py:112,
- * likelihoods.py:210): the forward / data-gradient launch with every option of the entry points above and a second tensor on
- * either side --
- *   x2 != NULL: reduction channels [0, K1) are read from x (pixel stride K1), [K1, K) from x2 (stride K - K1), K1 % 32 == 0
- *   y2 != NULL: output channels [0, N1) go to y (stride N1), [N1, N) to y2 (stride N - N1), N1 % 8 == 0; no statistics epilogue
- *   oscale     : per-channel scale of the epilogue (NULL: 1), bias: its shift -- see phx_conv3x3_mfma_bf16_affine
- *   stats_mode : 0 none (stats == NULL), 1 per-tile partial rows stats[tiles][2][N], 2 added atomically into stats[N][2]
- *                (phx_conv3x3_mfma_stats_atomic_supported)
- * The filter-gradient counterparts take the second tensor explicitly too (K1 % 32 == 0; a block's input channels lie in one
- * tensor, so K1 % 64 != 0 selects 32-channel tiles: use the ..._dual plan / workspace queries with the same K1). */
-int phx_conv3x3_mfma_bf16_dual(const void* x, const void* x2, int K1, const void* wpk, void* y, void* y2, int N1, const float* bias,
-                               const float* oscale, int act, float* stats, int stats_mode, void* workspace, size_t workspace_bytes,
-                               int B, int H, int W, int K, int N, void* stream);
-/* The plain convolution with an fp32 output tensor y_f32[B*H*W][N] on small maps (the shapes the 256-pixel kernels take; not the
- * large-map / 16 x 32-tile shapes): the fp32 accumulators of the split-K instantiations reach y_f32 without a bf16 rounding (round 5:
- * input of phx_bn_small_fwd with x_dt = PHX_F32 -- tfwrapper/layers.py:123 + normalisation.py:145-163 on the 2 x 2 / 4 x 4 levels).
- * workspace: phx_conv3x3_mfma_ws_bytes bytes (NULL / 0 when that is 0); x2 / K1: concat-free input as phx_conv3x3_mfma_bf16_dual.
- * sum_slices = 0: a split-K launch (phx_conv3x3_mfma_ksplit > 1) skips its finishing pass and leaves the slices ws[z][B*H*W][N] in the
- * workspace for a consumer that sums them itself (phx_bn_wide_fwd); y_f32 is then not written (a single slice still goes to y_f32). */
-int phx_conv3x3_mfma_f32out_supported(int B, int H, int W, int K, int N);
-int phx_conv3x3_mfma_bf16_f32out(const void* x, const void* x2, int K1, const void* wpk, float* y_f32, int sum_slices, void* workspace,
-                                 size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream);
-/* conv2d straight on the PRE-normalisation tensor of the layer in front (round 5; conv2d -> batch_norm -> relu -> conv2d,
- * tfwrapper/layers.py:123-135): y = conv3x3(relu(x * xscale[k] + xshift[k])) with the producer's scale / shift (phx_norm_finalize); the
- * producer's apply pass and its activation tensor are never made.  Shapes (phx_conv3x3_xf_supported): the 32 -> 32 layers of the large
- * maps -- k_conv3x3_c32 re-forms the activation in place in its staged patch; these launches are HBM-bound, the transform is free
- * and the bytes are not (on the matrix-bound shapes it is the other way round: measured and removed).
- * Bit-identical to phx_conv3x3_mfma_bf16 on the materialised bf16 activation.  stats_partial as phx_conv3x3_mfma_bf16.
- * _wgrad_..._partial_xf: the filter gradient of such a convolution (x = the pre-normalisation tensor; Cin == 32, 16 x 16 tiles, more than
- * 1 024 of them, workspace of phx_conv3x3_wgrad_ws_bytes required; partial filters only, as phx_conv3x3_wgrad_mfma_bf16_partial). */
-int phx_conv3x3_xf_supported(int B, int H, int W, int K, int N);
-int phx_conv3x3_mfma_bf16_xf(const void* x, const float* xscale, const float* xshift, const void* wpk, void* y, float* stats_partial,
-                             int B, int H, int W, int K, int N, void* stream);
+
+/* ONE launch entry for the whole family (round 6: it replaces the eleven phx_conv3x3_mfma_bf16* entry points and their *_supported
+ * probes of rounds 1-5).  Prologue, epilogue and statistics mode are fields of the descriptor; a field left 0 / NULL is off.
+ *   input      x [B,H,W,K]; x2 != NULL: concat-free input (tf.concat([a, b], 3) -> conv2D: posteriors.py:87,120, priors.py:112,
+ *              likelihoods.py:210) -- reduction channels [0, K1) from x (pixel stride K1), [K1, K) from x2 (stride K - K1), K1 % 32 == 0
+ *   prologue   xscale / xshift != NULL: x is the PRE-normalisation tensor of the layer in front and the loader re-forms
+ *              relu(x * xscale[k] + xshift[k]) (conv2d -> batch_norm -> relu -> conv2d without the activation tensor; plan.xf_ok:
+ *              the 32 -> 32 layers of the large maps, HBM-bound, where the transform is free and the bytes are not); bit-identical
+ *              to the launch on the materialised activation
+ *   output     y [B,H,W,N] bf16; y2 != NULL: output channels [0, N1) to y (stride N1), [N1, N) to y2 (stride N - N1), N1 % 8 == 0
+ *              (the data gradient of a concat-free layer); y_f32 != NULL (plan.f32out_ok, small maps): the fp32 accumulators reach
+ *              y_f32[B*H*W][N] without a bf16 rounding, no epilogue; sum_slices = 0 then leaves the split-K slices ws[z][B*H*W][N] in
+ *              the workspace for a consumer that sums them itself (phx_bn_wide_fwd) and y_f32 is not written
+ *   epilogue   y = act(acc * oscale[n] + bias[n]) (oscale NULL: 1, bias NULL: 0) -- bias_add + activation, or inference-mode
+ *              batch norm + activation folded into the convolution (normalisation.py:145-163 with is_training = False; scale / shift
+ *              from phx_bn_infer_scale_shift(_multi))
+ *   statistics stats_mode PHX_CONV_STATS_PARTIAL: per-channel {sum, sumsq} of the bf16-rounded output as rows stats[plan.tiles][2][N]
+ *              (no atomics; plan.tiles_dual rows for a launch with x2 / y2 set); PHX_CONV_STATS_ATOMIC (plan.stats_atomic_ok: at most 64
+ *              pixel tiles, never in deterministic mode): added into stats[N][2], the layout phx_norm_apply_fused takes
+ *   split-K    workspace of plan.ws_bytes (0: not used for this shape): the K / 32 chunks are spread over plan.ksplit blocks per tile
+ *              and a finishing kernel sums the fp32 slices and applies the epilogue (small maps; not with PARTIAL statistics)
+ *   fused group / instance norm (gn_groups > 0, plan.fgn_block != 0: H, W in {2, 4, 8, 16}; gn_groups == N: instance norm): convolution
+ *              + bias + normalisation + activation in ONE launch (layers.py:123-135 + normalisation.py:3-36) -- a block holds whole
+ *              samples and whole groups; writes y = bf16(conv + bias), a_out = act((y - mean) * rstd * gamma + beta) and the per-sample
+ *              mean_out / rstd_out [B][G], scale_out / shift_out [B][N] in phx_norm_small_bwd's layout. */
+enum { PHX_CONV_STATS_NONE = 0, PHX_CONV_STATS_PARTIAL = 1, PHX_CONV_STATS_ATOMIC = 2 };
+typedef struct phx_conv3x3_desc {
+    const void* x;
+    const void* x2;
+    const float* xscale;
+    const float* xshift;
+    const void* wpk;
+    void* y;
+    void* y2;
+    float* y_f32;
+    const float* bias;
+    const float* oscale;
+    float* stats;
+    void* workspace;
+    size_t workspace_bytes;
+    void* a_out;
+    const float* gamma;
+    const float* beta;
+    float* mean_out;
+    float* rstd_out;
+    float* scale_out;
+    float* shift_out;
+    int K1, N1, act, stats_mode, sum_slices, gn_groups;
+    float gn_eps;
+    int B, H, W, K, N;
+    int reserved[4];
+} phx_conv3x3_desc;                 /* 224 bytes */
+typedef struct phx_conv3x3_plan {
+    int tiles, tiles_dual;          /* rows of a PARTIAL statistics buffer: plain launch / launch with x2 or y2 */
+    int ksplit;                     /* fp32 slices a workspace launch leaves (1: no split) */
+    int stats_atomic_ok, f32out_ok, xf_ok;
+    int fgn_block;                  /* fused group norm with G groups: output channels per block (32 / 64), 0 = not supported */
+    int reserved;
+    size_t ws_bytes;
+} phx_conv3x3_plan;                 /* 40 bytes */
+int phx_conv3x3_desc_bytes(void);
+int phx_conv3x3_bf16_plan(int B, int H, int W, int K, int N, int G, phx_conv3x3_plan* out);
+int phx_conv3x3_bf16(const phx_conv3x3_desc* d, void* stream);
+
+/* Filter gradients of the two input forms above.  _partial_xf: x is the pre-normalisation tensor (prologue as above; Cin == 32, 16 x 16
+ * tiles, more than 1 024 of them, workspace of phx_conv3x3_wgrad_ws_bytes required; partial filters only, as
+ * phx_conv3x3_wgrad_mfma_bf16_partial).  _dual: the second tensor explicitly (K1 % 32 == 0; a block's input channels lie in one tensor,
+ * so K1 % 64 != 0 selects 32-channel tiles: use the ..._dual plan / workspace queries with the same K1). */
 int phx_conv3x3_wgrad_xf_supported(int B, int H, int W, int Cin, int Cout);
 int phx_conv3x3_wgrad_mfma_bf16_partial_xf(const void* x, const float* xscale, const float* xshift, const void* dy, float* dw_hwio,
                                            void* workspace, size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, void* stream);
@@ -175,26 +193,6 @@ int phx_conv3x3_wgrad_multi_job_dual(const void* x, const void* x2, int K1, cons
                                      void* job_out, int* info9);
 int phx_conv3x3_wgrad_mfma_bf16_dual(const void* x, const void* x2, int K1, const void* dy, float* dw_hwio, void* workspace,
                                      size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int reduce, void* stream);
-/* Convolution + bias + group norm (16-channel groups) / instance norm + activation in ONE launch (the fused block of north_star:
- * tfwrapper/layers.py:123-135 + normalisation.py:3-36) on maps that fit one pixel tile (H, W in {2, 4, 8, 16}): a block holds whole
- * samples and whole groups, so the two-pass statistics are block-local -- no statistics / reduction / apply launches and no
- * cross-block step.  Writes y = bf16(conv + bias) (the backward pass reads it), a_out = act((y - mean) * rstd * gamma + beta) and the
- * per-sample vectors mean / rstd [B][G], scale / shift [B][N] in phx_norm_small_bwd's layout.  G == N: instance norm. */
-int phx_conv3x3_fgn_supported(int B, int H, int W, int K, int N, int G);
-int phx_conv3x3_mfma_bf16_fgn(const void* x, const void* wpk, void* y, void* a_out, const float* bias, const float* gamma,
-                              const float* beta, float eps, int G, int act, float* mean_out, float* rstd_out, float* scale_out,
-                              float* shift_out, int B, int H, int W, int K, int N, void* stream);
-/* Convolution with an AFFINE epilogue: y = act(conv(x) * scale[n] + shift[n]) -- inference-mode batch norm
- * (normalisation.py:145-163 with is_training = False: y = gamma (x - moving_mean) / sqrt(moving_var + eps) + beta) and its
- * activation folded into the convolution that feeds it: one launch where the reference runs conv2d, batch_norm and relu.
- * scale / shift: phx_bn_infer_scale_shift(_multi).  workspace as for phx_conv3x3_mfma_bf16_ws (may be NULL / 0). */
-int phx_conv3x3_mfma_bf16_affine(const void* x, const void* wpk, void* y, const float* scale, const float* shift, int act,
-                                 void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream);
-/* number of pixel tiles (= rows of stats_partial) phx_conv3x3_mfma_bf16 uses for this shape */
-int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W, int K, int N);
-/* ... of a concat-free launch (phx_conv3x3_mfma_bf16_dual with x2 or y2 set): those never take the 16 x 32-tile instantiations
- * of the 256-pixel kernel, so their row count differs where the policy would pick them */
-int phx_conv3x3_mfma_bf16_tiles_dual(int B, int H, int W, int K, int N);
 /* debug: device buffer of >= 16 uint64 that receives shader-clock phase timestamps of block 0 (NULL disables) */
 int phx_debug_set_trace(void* dev_buf);
 /* debug: device buffer of 4 uint64 per block {start, end, HW_ID | XCC_ID << 32, realtime} written by the MFMA conv kernels */
@@ -341,7 +339,7 @@ int phx_norm_bwd_apply_fused_bias(const void* dA, int da_dt, const void* x, int 
  * bwd: dx from dA, the saved x and statistics; dgamma / dbeta are accumulated (+=). */
 int phx_bn_small_supported(int P, int C, int dt);
 /* x_dt = PHX_BF16, or PHX_F32 for P <= 1024 (round 5): the pre-normalisation tensor of the 2 x 2 / 4 x 4 levels stays in fp32
- * (phx_conv3x3_mfma_bf16_f32out) -- a channel is normalised from a few dozen to a few hundred values there, and bf16 rounding of x
+ * (phx_conv3x3_bf16 with y_f32) -- a channel is normalised from a few dozen to a few hundred values there, and bf16 rounding of x
  * (2^-9 of the channel MEAN) is blown up with the spread: the benchmarked precision's two coarsest KL terms trained 40 % high. */
 int phx_bn_small_fwd(const void* x, int x_dt, const float* gamma, const float* beta, float eps, void* y, float* mean, float* rstd,
                      float* scale, float* shift, float* moving_mean, float* moving_var, float momentum, int P, int C,
@@ -350,8 +348,8 @@ int phx_bn_small_bwd(const void* dA, const void* x, int x_dt, const float* scale
                      const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, int P, int C, int act,
                      void* stream);
 /* The WIDE form of the same layer for P <= 1024 (the 2 x 2 / 4 x 4 levels at batch 64; round 5): the fp32 pre-normalisation tensor is
- * given as the nz split-K slices xs[z][P][C] the convolution left in its workspace (phx_conv3x3_mfma_bf16_f32out with sum_slices = 0;
- * nz = phx_conv3x3_mfma_ksplit; nz = 1: xs is the tensor itself) -- this launch is also the split-K finishing pass: it adds the slices
+ * given as the nz split-K slices xs[z][P][C] the convolution left in its workspace (phx_conv3x3_bf16 with y_f32 and sum_slices = 0;
+ * nz = plan.ksplit; nz = 1: xs is the tensor itself) -- this launch is also the split-K finishing pass: it adds the slices
  * in slice order, writes their sum to xsum[P][C] (nz > 1; what the backward pass reads) and normalises.  A block owns four channels of
  * all pixels: C / 4 blocks.  bwd: dA as a bf16 tensor, or as the nzd fp32 slices the consumer's split-K data gradient left
  * (rounded to bf16 after the sum, as its finishing pass would have); x is the fp32 tensor. */
@@ -367,7 +365,7 @@ int phx_bn_wide_bwd(const void* dA, const float* dA_slices, int nzd, const float
  * group (G * 16 == C: group_norm2D's default groups for C >= 32): a wave owns (sample, 16-channel slice) pairs, keeps the
  * slice in registers, two-pass variance, wave shuffles only; no atomics in the forward pass, one add per channel and block in
  * the backward pass.
- *   fwd: ws == NULL: x is the input.  ws != NULL: the convolution ran split-K (phx_conv3x3_mfma_bf16_ws with y == NULL): the
+ *   fwd: ws == NULL: x is the input.  ws != NULL: the convolution ran split-K (phx_conv3x3_bf16 with a workspace and y == NULL): the
  *        nz fp32 slices ws[z][NS*P][C] are summed, `bias` (the convolution bias, may be NULL) added, the bf16 result written
  *        to x and normalised.  mean / rstd: [NS][G]; scale / shift: [NS][C].
  *   bwd: dx, dgamma += , dbeta += , and (dbias != NULL) the gradient of the convolution bias in front of the layer,
@@ -415,8 +413,8 @@ int phx_avgpool2x2_bwd_acc(const void* dy, int dt, void* dx, int B, int H, int W
 /* TF 1.12 ResizeBilinear(align_corners=False), legacy coordinates, factor 2 */
 /* ---- bilinear_upsample2D -> conv2D 3x3 without the up-sampled tensor (tfwrapper/layers.py:336-345 into :123; likelihoods.py:200-204):
  * the elementwise half of the phase form (csrc/upconv.hip).  The matrix launches are the ordinary ones:
- *   y_packed [B][h][w][4 Cout] = phx_conv3x3_mfma_bf16(x [B][h][w][Cin], weff_fwd)           exact outside the frame (hi rows / columns 0, 2n-2, 2n-1)
- *   fr [1][6B][2w][Cout] = phx_conv3x3_mfma_bf16(f_rows, wpk_fwd of W),  fc [1][6B][2h][Cout] = phx_conv3x3_mfma_bf16(f_cols, wt_fwd)
+ *   y_packed [B][h][w][4 Cout] = phx_conv3x3_bf16(x [B][h][w][Cin], weff_fwd)           exact outside the frame (hi rows / columns 0, 2n-2, 2n-1)
+ *   fr [1][6B][2w][Cout] = phx_conv3x3_bf16(f_rows, wpk_fwd of W),  fc [1][6B][2h][Cout] = phx_conv3x3_bf16(f_cols, wt_fwd)
  * y_packed[b][i][j][(a, b', co)] is hi-res pixel (2i + a, 2j + b'): a channels-last tensor of 4 B h w pixels for the norm kernels.
  * Backward: phx_upconv_frame_gather_dy moves the frame's gradient out of dy_packed (and zeroes it there), the three data gradients /
  * filter gradients are the ordinary launches on (dy_packed, weff_dgrad), (dfr, wpk_dgrad of W), (dfc, wt_dgrad);

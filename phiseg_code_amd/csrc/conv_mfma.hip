@@ -917,14 +917,14 @@ int phx_debug_set_blocklog(void* dev_buf) {
     return PHX_OK;
 }
 
-int phx_conv3x3_mfma_bf16_tiles(int B, int H, int W, int K, int N) {
+static int q_tiles(int B, int H, int W, int K, int N) {
     MTile g = make_mtile_fwd(B, H, W, K, N);
     return g.tiles_x * g.tiles_y * g.tiles_b;
 }
 
 // ... of a concat-free launch (phx_conv3x3_mfma_bf16_dual with x2 / y2): large maps as above, everything else the 256-pixel tiles
 // (the DUAL instantiations exist for those only)
-int phx_conv3x3_mfma_bf16_tiles_dual(int B, int H, int W, int K, int N) {
+static int q_tiles_dual(int B, int H, int W, int K, int N) {
     MTile g = fwd_ws64(B, H, W, K, N) ? make_mtile_fwd(B, H, W, K, N) : make_mtile(B, H, W);
     return g.tiles_x * g.tiles_y * g.tiles_b;
 }
@@ -944,9 +944,9 @@ static int fwd_ksplit(int B, int H, int W, int K, int N) {
     return (nck + per - 1) / per;                    // no empty slices
 }
 
-int phx_conv3x3_mfma_ksplit(int B, int H, int W, int K, int N) { return fwd_ksplit(B, H, W, K, N); }
 
-size_t phx_conv3x3_mfma_ws_bytes(int B, int H, int W, int K, int N) {
+
+static size_t q_ws_bytes(int B, int H, int W, int K, int N) {
     const int ks = fwd_ksplit(B, H, W, K, N);
     return ks > 1 ? (size_t)ks * B * H * W * N * sizeof(float) : 0;
 }
@@ -955,47 +955,20 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
                              void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, EpiOpts bws, Dual du,
                              void* stream);
 
-int phx_conv3x3_mfma_bf16(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
-                          int B, int H, int W, int K, int N, void* stream) {
-    return conv3x3_mfma_impl(x, wpk, y, bias, act, stats_partial, nullptr, 0, B, H, W, K, N, EpiOpts{}, Dual{}, stream);
-}
-
-int phx_conv3x3_mfma_bf16_ws(const void* x, const void* wpk, void* y, const float* bias, int act, float* stats_partial,
-                             void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream) {
-    return conv3x3_mfma_impl(x, wpk, y, bias, act, stats_partial, workspace, workspace_bytes, B, H, W, K, N, EpiOpts{}, Dual{}, stream);
-}
-
 // statistics added atomically into sums[N][2] (the layout phx_norm_apply_fused reads): for launches with few pixel tiles (the
 // H <= 16 levels), where a same-address atomic per tile and channel (~45 ns each) is cheaper than a reduction launch or a pass of
 // its own over y.  Generic 256-pixel-tile kernel only.
 static bool fwd_stats_atomic_ok(int B, int H, int W, int K, int N) {
     if (phx_deterministic() || K % KC != 0 || N % 32 != 0) return false;
     if (fwd_ws64(B, H, W, K, N) || fwd_big_tiles(B, H, W, K, N)) return false;
-    return phx_conv3x3_mfma_bf16_tiles(B, H, W, K, N) <= 64;
-}
-int phx_conv3x3_mfma_stats_atomic_supported(int B, int H, int W, int K, int N) { return fwd_stats_atomic_ok(B, H, W, K, N) ? 1 : 0; }
-int phx_conv3x3_mfma_bf16_stats_atomic(const void* x, const void* wpk, void* y, const float* bias, int act, float* sums, int B,
-                                       int H, int W, int K, int N, void* stream) {
-    PHX_REQUIRE(fwd_stats_atomic_ok(B, H, W, K, N), PHX_E_SHAPE, "conv3x3_mfma_stats_atomic: shape not supported (see ..._supported)");
-    PHX_REQUIRE(sums != nullptr, PHX_E_INVAL, "conv3x3_mfma_stats_atomic: sums is required");
-    EpiOpts b{};
-    b.stats_atomic = 1;
-    return conv3x3_mfma_impl(x, wpk, y, bias, act, sums, nullptr, 0, B, H, W, K, N, b, Dual{}, stream);
-}
-
-int phx_conv3x3_mfma_bf16_affine(const void* x, const void* wpk, void* y, const float* scale, const float* shift, int act,
-                                 void* workspace, size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream) {
-    PHX_REQUIRE(scale != nullptr && shift != nullptr, PHX_E_INVAL, "conv3x3_mfma_affine: scale and shift are required");
-    EpiOpts b{};
-    b.oscale = scale;
-    return conv3x3_mfma_impl(x, wpk, y, shift, act, nullptr, workspace, workspace_bytes, B, H, W, K, N, b, Dual{}, stream);
+    return q_tiles(B, H, W, K, N) <= 64;
 }
 
 // Concat-free forward / data gradient (struct Dual): every option of the entry points above in one call.
 //   x2 != NULL: reduction channels [0, K1) are read from x (pixel stride K1), [K1, K) from x2 (stride K - K1), K1 % 32 == 0
 //   y2 != NULL: output channels [0, N1) go to y (stride N1), [N1, N) to y2 (stride N - N1), N1 % 8 == 0; no statistics epilogue
 //   stats_mode : 0 none, 1 per-tile partial rows stats[tile][2][N], 2 atomically into stats[N][2] (see ..._stats_atomic)
-int phx_conv3x3_mfma_bf16_dual(const void* x, const void* x2, int K1, const void* wpk, void* y, void* y2, int N1, const float* bias,
+static int l_dual(const void* x, const void* x2, int K1, const void* wpk, void* y, void* y2, int N1, const float* bias,
                                const float* oscale, int act, float* stats, int stats_mode, void* workspace, size_t workspace_bytes,
                                int B, int H, int W, int K, int N, void* stream) {
     PHX_REQUIRE(x2 == nullptr || (K1 > 0 && K1 % 32 == 0 && ((uintptr_t)x2 & 15) == 0), PHX_E_INVAL, "conv3x3_mfma_dual: x2 (16-byte aligned), K1 % 32 == 0");
@@ -1013,10 +986,10 @@ int phx_conv3x3_mfma_bf16_dual(const void* x, const void* x2, int K1, const void
 // 256-pixel kernels -- their fp32 accumulators go to the workspace slices and k_splitk_finish sums them into y_f32 without rounding
 // (a single slice is written straight into y_f32).  For the one-launch batch norm of the 2 x 2 / 4 x 4 levels (phx_bn_small_fwd with
 // x_dt = PHX_F32).  workspace: phx_conv3x3_mfma_ws_bytes (may be NULL / 0 when that is 0).  x2 / K1: concat-free input, as _dual.
-int phx_conv3x3_mfma_f32out_supported(int B, int H, int W, int K, int N) {
+static int q_f32out_ok(int B, int H, int W, int K, int N) {
     return (K % KC == 0 && N % 32 == 0 && !fwd_ws64(B, H, W, K, N) && !fwd_big_tiles(B, H, W, K, N) && (double)B * H * W < 16777216.0) ? 1 : 0;
 }
-int phx_conv3x3_mfma_bf16_f32out(const void* x, const void* x2, int K1, const void* wpk, float* y_f32, int sum_slices, void* workspace,
+static int l_f32out(const void* x, const void* x2, int K1, const void* wpk, float* y_f32, int sum_slices, void* workspace,
                                  size_t workspace_bytes, int B, int H, int W, int K, int N, void* stream) {
     PHX_REQUIRE(y_f32 != nullptr && ((uintptr_t)y_f32 & 15) == 0, PHX_E_INVAL, "conv3x3_mfma_f32out: y_f32 (16-byte aligned) is required");
     PHX_REQUIRE(x2 == nullptr || (K1 > 0 && K1 % 32 == 0 && ((uintptr_t)x2 & 15) == 0), PHX_E_INVAL, "conv3x3_mfma_f32out: x2 (16-byte aligned), K1 % 32 == 0");
@@ -1029,12 +1002,12 @@ int phx_conv3x3_mfma_bf16_f32out(const void* x, const void* x2, int K1, const vo
 
 // conv2d on the PRE-normalisation tensor of the producing layer (round 5): y = conv3x3(relu(x * xscale[k] + xshift[k])) -- the 32 -> 32
 // layers of the large maps (k_conv3x3_c32, XF: the HBM-bound 128 x 128 level, where the transform is free and the bytes are not).
-int phx_conv3x3_xf_supported(int B, int H, int W, int K, int N) {
+static int q_xf_ok(int B, int H, int W, int K, int N) {
     return (K == 32 && N == 32 && fwd_ws64(B, H, W, K, N) && phx_c32_enabled()) ? 1 : 0;
 }
-int phx_conv3x3_mfma_bf16_xf(const void* x, const float* xscale, const float* xshift, const void* wpk, void* y, float* stats_partial,
+static int l_xf(const void* x, const float* xscale, const float* xshift, const void* wpk, void* y, float* stats_partial,
                              int B, int H, int W, int K, int N, void* stream) {
-    PHX_REQUIRE(phx_conv3x3_xf_supported(B, H, W, K, N), PHX_E_SHAPE, "conv3x3_mfma_xf: shape not supported (see phx_conv3x3_xf_supported)");
+    PHX_REQUIRE(q_xf_ok(B, H, W, K, N), PHX_E_SHAPE, "conv3x3_mfma_xf: shape not supported (see phx_conv3x3_xf_supported)");
     PHX_REQUIRE(x && xscale && xshift && wpk && y, PHX_E_INVAL, "conv3x3_mfma_xf: null argument");
     PHX_REQUIRE((((uintptr_t)x | (uintptr_t)wpk | (uintptr_t)y) & 15) == 0, PHX_E_ALIGN, "conv3x3_mfma_xf: 16-byte alignment");
     return phx_c32_launch(x, wpk, y, nullptr, PHX_ACT_ID, stats_partial, B, H, W, nullptr, 0, stream, xscale, xshift);
@@ -1051,8 +1024,8 @@ static int fgn_plan(int B, int H, int W, int K, int N, int G) {
     const int ntiles = g.tiles_x * g.tiles_y * g.tiles_b;
     return (N % 64 == 0 && ntiles * (N / 64) > 256) ? 64 : 32;
 }
-int phx_conv3x3_fgn_supported(int B, int H, int W, int K, int N, int G) { return fgn_plan(B, H, W, K, N, G); }
-int phx_conv3x3_mfma_bf16_fgn(const void* x, const void* wpk, void* y, void* a_out, const float* bias, const float* gamma,
+
+static int l_fgn(const void* x, const void* wpk, void* y, void* a_out, const float* bias, const float* gamma,
                               const float* beta, float eps, int G, int act, float* mean_out, float* rstd_out, float* scale_out,
                               float* shift_out, int B, int H, int W, int K, int N, void* stream) {
     const int bn = fgn_plan(B, H, W, K, N, G);
@@ -1220,6 +1193,50 @@ static int conv3x3_mfma_impl(const void* x, const void* wpk, void* y, const floa
         PHX_CHECK_LAUNCH();
     }
     return PHX_OK;
+}
+
+
+// ---- the ONE launch entry and the ONE plan query of the bf16 forward / data-gradient family (include/phx.h) ------------------------
+static_assert(sizeof(phx_conv3x3_desc) == 224, "phx_conv3x3_desc is packed by the host (phiseg_code_amd/runtime.py): 224 bytes");
+int phx_conv3x3_desc_bytes(void) { return (int)sizeof(phx_conv3x3_desc); }
+
+int phx_conv3x3_bf16_plan(int B, int H, int W, int K, int N, int G, phx_conv3x3_plan* out) {
+    PHX_REQUIRE(out != nullptr, PHX_E_INVAL, "conv3x3_bf16_plan: out is required");
+    memset(out, 0, sizeof(*out));
+    if (B < 1 || H < 1 || W < 1 || K < 32 || N < 32 || K % 32 != 0 || N % 32 != 0) return PHX_OK;       // (everything 0: not an MFMA shape)
+    out->tiles = q_tiles(B, H, W, K, N);
+    out->tiles_dual = q_tiles_dual(B, H, W, K, N);
+    out->ksplit = fwd_ksplit(B, H, W, K, N);
+    out->ws_bytes = q_ws_bytes(B, H, W, K, N);
+    out->stats_atomic_ok = fwd_stats_atomic_ok(B, H, W, K, N) ? 1 : 0;
+    out->f32out_ok = q_f32out_ok(B, H, W, K, N);
+    out->xf_ok = q_xf_ok(B, H, W, K, N);
+    out->fgn_block = G > 0 ? fgn_plan(B, H, W, K, N, G) : 0;
+    return PHX_OK;
+}
+
+int phx_conv3x3_bf16(const phx_conv3x3_desc* d, void* stream) {
+    PHX_REQUIRE(d != nullptr, PHX_E_INVAL, "conv3x3_bf16: descriptor is required");
+    if (d->gn_groups > 0) {
+        PHX_REQUIRE(d->x2 == nullptr && d->y2 == nullptr && d->xscale == nullptr && d->y_f32 == nullptr && d->oscale == nullptr
+                    && d->stats_mode == PHX_CONV_STATS_NONE, PHX_E_INVAL, "conv3x3_bf16: the fused group-norm epilogue takes the plain input / output only");
+        return l_fgn(d->x, d->wpk, d->y, d->a_out, d->bias, d->gamma, d->beta, d->gn_eps, d->gn_groups, d->act, d->mean_out, d->rstd_out,
+                     d->scale_out, d->shift_out, d->B, d->H, d->W, d->K, d->N, stream);
+    }
+    if (d->xscale != nullptr || d->xshift != nullptr) {
+        PHX_REQUIRE(d->x2 == nullptr && d->y2 == nullptr && d->y_f32 == nullptr && d->bias == nullptr && d->oscale == nullptr && d->act == PHX_ACT_ID
+                    && d->stats_mode != PHX_CONV_STATS_ATOMIC, PHX_E_INVAL, "conv3x3_bf16: the transforming loader takes the plain epilogue only");
+        return l_xf(d->x, d->xscale, d->xshift, d->wpk, d->y, d->stats_mode == PHX_CONV_STATS_PARTIAL ? d->stats : nullptr, d->B, d->H, d->W,
+                    d->K, d->N, stream);
+    }
+    if (d->y_f32 != nullptr) {
+        PHX_REQUIRE(d->y == nullptr && d->y2 == nullptr && d->bias == nullptr && d->oscale == nullptr && d->act == PHX_ACT_ID
+                    && d->stats_mode == PHX_CONV_STATS_NONE, PHX_E_INVAL, "conv3x3_bf16: the fp32 output takes no epilogue");
+        PHX_REQUIRE(q_f32out_ok(d->B, d->H, d->W, d->K, d->N), PHX_E_SHAPE, "conv3x3_bf16: fp32 output not supported for this shape (plan.f32out_ok)");
+        return l_f32out(d->x, d->x2, d->K1, d->wpk, d->y_f32, d->sum_slices, d->workspace, d->workspace_bytes, d->B, d->H, d->W, d->K, d->N, stream);
+    }
+    return l_dual(d->x, d->x2, d->K1, d->wpk, d->y, d->y2, d->N1, d->bias, d->oscale, d->act, d->stats, d->stats_mode, d->workspace,
+                  d->workspace_bytes, d->B, d->H, d->W, d->K, d->N, stream);
 }
 
 }  // extern "C"
