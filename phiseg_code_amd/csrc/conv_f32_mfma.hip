@@ -268,6 +268,136 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_f32_mfma(const float* __rest
     }
 }
 
+// The same forward / data-gradient launch with LDS-DMA staging into two LDS stages and LOADER WAVES (as the filter gradient below):
+// 512 threads, waves 0-3 compute (one per SIMD, 64 rows x BN channels each), waves 4-7 issue the next chunk's buffer_load ... lds.
+// LDS images are lane-linear: patch [pixel][2 halves][4 channels], filter slab [tap][row][2 halves][4] -- exactly the order of the packed
+// filter in memory.  Needs K % 4 == 0 (16-byte pieces); the register-staged kernel above takes the narrow inputs.
+template <int BN>
+__global__ __launch_bounds__(512, 2) void k_conv3x3_f32_mfma_dma(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                                  const float* __restrict__ bias, float* __restrict__ y, int B, int H, int W,
+                                                                  int K, int N, int act, F32Geo g) {
+    constexpr int NT = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int npatch = g.npatch;
+    const int nxp = npatch * 2, nwp = 9 * BN * 2;                  // 16-byte pieces of the patch / of the filter slab
+    const int nxi = (nxp + 63) >> 6, nwi = (nwp + 63) >> 6;
+    const int stage_floats = (nxi + nwi) * 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool loader = tid >= 256;
+    const int wv = (tid >> 6) & 3;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int tw = 1 << g.tws, th = 1 << g.ths, pw = g.pw, ph = g.ph;
+    int t = blockIdx.x;
+    const int tx0 = (t % g.tiles_x) << g.tws; t /= g.tiles_x;
+    const int ty0 = (t % g.tiles_y) << g.ths; t /= g.tiles_y;
+    const int b0 = t * g.tb;
+    const int n0 = blockIdx.y * BN;
+    const int nkc = (K + 7) >> 3;
+
+    // One barrier per chunk, S_k = "chunk k has landed AND chunk k - 1 is consumed":
+    //   loader waves : issue(0); for k: { wait for their own DMA; S_k; issue(k + 1) into the stage chunk k - 1 used }
+    //   compute waves: for k: { S_k; matrix instructions of chunk k }
+    if (loader) {
+        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((unsigned)B * H * W * K * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, (int)((unsigned)nkc * 9 * N * 32u), 0x00020000);
+        // this lane's pieces of the patch are the same pixels in every chunk: byte offset of (pixel, half) at channel 0, or out of range
+        unsigned poff[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = (wv + 4 * q) * 64 + lane;
+            const unsigned pp = (unsigned)e >> 1;
+            const int bi = (int)((pp * g.mpp) >> 20);
+            const unsigned rem = pp - bi * ph * pw;
+            const int py = (int)((rem * g.mpw) >> 20);
+            const int px = (int)rem - py * pw;
+            const int gy = ty0 + py - 1, gx = tx0 + px - 1, gb = b0 + bi;
+            const bool ok = e < nxp && gb < B && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            poff[q] = ok ? (unsigned)(((gb * H + gy) * W + gx) * K + (e & 1) * 4) * 4u : 0xffffffffu;
+        }
+        auto issue = [&](int kc) {
+            char* base = (char*)(smem + (size_t)(kc & 1) * stage_floats);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = wv + 4 * q;
+                if (j < nxi) {
+                    const int c = kc * 8 + (lane & 1) * 4;             // ((j * 64 + lane) & 1) == (lane & 1)
+                    const unsigned vo = (poff[q] != 0xffffffffu && c < K) ? poff[q] + (unsigned)(kc * 32) : 0xffffffffu;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(base + j * 1024), 16, vo, 0, 0, 0);
+                }
+            }
+            for (int j = wv; j < nwi; j += 4) {
+                const int e = j * 64 + lane;                           // ((t9 * BN + n) * 2 + h)
+                const int t9 = e / (BN * 2), r = e % (BN * 2);
+                const unsigned vo = e < nwp ? (unsigned)(((kc * 9 + t9) * N + n0) * 8 + r * 4) * 4u : 0xffffffffu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr_t)(base + (nxi + j) * 1024), 16, vo, 0, 0, 0);
+            }
+        };
+        issue(0);
+        for (int kc = 0; kc < nkc; ++kc) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kc + 1 < nkc) issue(kc + 1);
+        }
+        return;
+    }
+
+    int pbase[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int r = 64 * wv + 32 * mi + l31;
+        const int lx = r & (tw - 1), ly = (r >> g.tws) & (th - 1), bi = r >> (g.tws + g.ths);
+        pbase[mi] = (bi * ph + ly) * pw + lx;
+    }
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+    for (int kc = 0; kc < nkc; ++kc) {
+        __syncthreads();                                               // S_kc: chunk kc has landed, chunk kc - 1 is consumed by every wave
+        const float* sp = smem + (size_t)(kc & 1) * stage_floats;
+        const float* sw = sp + (size_t)nxi * 256;
+        // one wave per SIMD: the fragments of tap t + 1 are read under the sixteen matrix instructions of tap t (pinned: nothing else hides the LDS latency)
+        f32x4 a[2][2], b[2][NT];
+        auto frags = [&](int t9, f32x4 (&aa)[2], f32x4 (&bb)[NT]) {
+            const int toff = (t9 / 3) * pw + (t9 % 3);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) aa[mi] = *(const f32x4*)(sp + ((size_t)(pbase[mi] + toff) * 2 + hh) * 4);
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) bb[ni] = *(const f32x4*)(sw + ((size_t)(t9 * BN + ni * 32 + l31) * 2 + hh) * 4);
+        };
+        frags(0, a[0], b[0]);
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) {
+            if (t9 + 1 < 9) frags(t9 + 1, a[(t9 + 1) & 1], b[(t9 + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma32(a[t9 & 1][mi][j], b[t9 & 1][ni][j], acc[mi][ni]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        const int n = n0 + ni * 32 + l31;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = 64 * wv + 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const int ox = tx0 + (r & (tw - 1)), oy = ty0 + ((r >> g.tws) & (th - 1)), ob = b0 + (r >> (g.tws + g.ths));
+                if (ox < W && oy < H && ob < B) y[((size_t)(ob * H + oy) * W + ox) * N + n] = act_fwd(acc[mi][ni][e] + bv, act);
+            }
+    }
+}
+
 // ---- forward / data gradient, few-tile problems -------------------------------------------------------------------------------
 // The 256-row kernel above leaves most of the chip idle on the H <= 16 levels (a 192 -> 192 layer on 8 x 8 maps at batch 64 is 48
 // blocks of 221 K matrix cycles each).  Here a block owns 64 rows x 32 output channels and its four waves SPLIT THE REDUCTION: of
@@ -759,6 +889,34 @@ int phx_conv3x3_f32_mfma(const float* x, const float* wpk, const float* bias, fl
             attr = true;
         }
         k_conv3x3_f32_mfma_small<<<dim3(gs.tiles_x * gs.tiles_y * gs.tiles_b, N / 32), 256, lds, s>>>(x, wpk, bias, y, B, H, W, K, N, act, gs);
+        PHX_CHECK_LAUNCH();
+        return PHX_OK;
+    }
+    // Which staging: the register-staged kernel keeps two blocks per CU (each covers the other's barriers: 0.70 of the fp32 peak on
+    // 128 -> 128 @ 128 x 128), the LDS-DMA kernel one 512-thread block (0.65 there) -- but it is the faster one on the 32-channel
+    // blocks (192 -> 32: 0.77 against 0.73, 32 -> 32: 0.63 against 0.57) and where 512 block slots leave a half-empty last round
+    // (256 -> 192 @ 32 x 32, 768 blocks: 0.76 against 0.61).  Measured, tools/bench_f32_mfma.py.
+    const long nblk = (long)ntiles * (N % 64 == 0 ? N / 64 : N / 32);
+    const double eff_regs = 0.70 * (double)nblk / (double)(((nblk + 511) / 512) * 512);
+    const double eff_dma = 0.65 * (double)nblk / (double)(((nblk + 255) / 256) * 256);
+    if (K % 4 == 0 && (double)B * H * W * K * 4.0 < 4294967296.0 && g.npatch * 2 <= 8 * 4 * 64 && (N % 64 != 0 || eff_dma > eff_regs)) {
+        // LDS-DMA staging into two stages, loader waves beside the computing waves (one 512-thread block per CU)
+        const int bn = N % 64 == 0 ? 64 : 32;
+        const size_t lds = (size_t)2 * (((g.npatch * 2 + 63) >> 6) + ((9 * bn * 2 + 63) >> 6)) * 1024;
+        static bool attr64 = false, attr32 = false;
+        if (bn == 64) {
+            if (!attr64) {
+                PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_f32_mfma_dma<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr64 = true;
+            }
+            k_conv3x3_f32_mfma_dma<64><<<dim3(ntiles, N / 64), 512, lds, s>>>(x, wpk, bias, y, B, H, W, K, N, act, g);
+        } else {
+            if (!attr32) {
+                PHX_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv3x3_f32_mfma_dma<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr32 = true;
+            }
+            k_conv3x3_f32_mfma_dma<32><<<dim3(ntiles, N / 32), 512, lds, s>>>(x, wpk, bias, y, B, H, W, K, N, act, g);
+        }
         PHX_CHECK_LAUNCH();
         return PHX_OK;
     }

@@ -198,6 +198,10 @@ F32_MFMA_CASES = [
     (32, 64, 64, 3, 32, "identity", False),
     (57, 48, 48, 8, 64, "identity", True),
     (130, 16, 16, 64, 96, "relu", False),
+    # ... and its LDS-DMA form with loader waves: 32-channel blocks (N % 64 != 0), and a block count that leaves 512 slots half empty
+    (8, 128, 128, 64, 32, "relu", True),
+    (9, 128, 64, 12, 96, "identity", False),
+    (24, 64, 64, 32, 128, "identity", True),
 ]
 
 
