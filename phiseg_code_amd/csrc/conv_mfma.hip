@@ -364,7 +364,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || (NA > 8 && DUAL)) ? 1 : 2) voi
     // one 32-channel chunk: registers -> LDS, then 18 (tap, k-step) groups of 2 x NJ MFMAs; with PF the global loads of the
     // NEXT chunk are issued one or two per group, so the texture-address unit (64 B/clk: ~1 K cycles per chunk for the four
     // waves) works underneath the matrix pipe instead of in a phase of its own.
-    constexpr int IPG = (NA + NB + 17) / 18;
+#ifndef PHX_PF_GROUPS   // the next chunk's global loads are spread over the first PHX_PF_GROUPS of the 18 (tap, k-step) groups (dev A/B: tools/build_variant.sh)
+#define PHX_PF_GROUPS 18
+#endif
+    constexpr int IPG = (NA + NB + PHX_PF_GROUPS - 1) / PHX_PF_GROUPS;
     auto chunk = [&](int ccur, int cnext, auto pfc, bool tr) {   // ccur: first channel of the chunk in registers; cnext: of the chunk to prefetch
         constexpr bool PF = decltype(pfc)::value;
         __syncthreads();                         // every wave is done reading the previous chunk / epilogue tile from LDS
