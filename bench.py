@@ -459,7 +459,8 @@ def main():
             except Exception:
                 pass
             try:
-                in_situ = conv_in_situ(model, args, x, s)
+                # (single process only: a data-parallel rank 0 would step its replica alone)
+                in_situ = conv_in_situ(model, args, x, s) if ctx.world == 1 else None
             except Exception as e:        # the headline line must not depend on the diagnostic
                 in_situ = None
                 print("bench.py: in-situ measurement failed: %r" % (e,), file=sys.stderr)
