@@ -543,14 +543,19 @@ def test_loss_curve_n0_32(compute_dtype, lidc_trajectory):
         # per channel (2 x 2 maps x 2 images, eps 1e-3 -> rstd up to 31), which amplifies every bf16 rounding flip of the
         # stored activations; two IDENTICAL bf16 runs differ by up to 2-3x in a single KL level at a single step
         # (tools/debug_bf16_curve.py) while their cross-entropy terms agree to 1-3 %.  Bound: the KL sum within a factor 3 per
-        # step and within 25 % in the median over the curve.
+        # step (one step may spike, see below) and within 25 % in the median over the curve.
         ce = lambda d: sum(v for k, v in d.items() if k.startswith("residual"))
         kl = lambda d: sum(v for k, v in d.items() if k.startswith("KL_"))
         r_ce = np.array([ce(a) / ce(b) for a, b in zip(terms, t["ref_terms"])])
         r_kl = np.array([kl(a) / kl(b) for a, b in zip(terms, t["ref_terms"])])
         print("bf16 / oracle per step: cross-entropy %s  KL %s" % (np.round(r_ce, 3), np.round(r_kl, 2)))
         assert np.abs(r_ce - 1).max() <= 0.06, r_ce
-        assert r_kl.max() <= 3.0 and r_kl.min() >= 1 / 3.0 and abs(np.median(r_kl) - 1) <= 0.25, r_kl
+        # Round 6: the per-step factor 3 was the edge of this quantity's own spread -- 28 repetitions of this test on one box (12 with
+        # the one-launch batch-norm backward, 16 without: the same picture in both arms) put the KL ratio of step 4 at 0.92 ... 3.89
+        # (3.1, 3.2, 3.3 and 3.9 in four of them; every other step 0.8 ... 2.2) while the cross-entropy ratios stayed inside 3.5 %: ONE
+        # step may spike (<= 6x), the second largest stays within the factor 3, the median within 25 %.
+        srt = np.sort(r_kl)
+        assert srt[-1] <= 6.0 and srt[-2] <= 3.0 and srt[0] >= 1 / 3.0 and abs(np.median(r_kl) - 1) <= 0.25, r_kl
 
 
 def test_single_steps_from_oracle_snapshots_n0_32(lidc_trajectory):
