@@ -487,6 +487,15 @@ def main():
             fi = fl / in_situ["conv_fwd_dgrad_ms_per_step"] / 1e9
             out["roofline"].update(achieved=fi, frac=fi / PEAK_BF16_TFLOPS, frac_in_situ=fi / PEAK_BF16_TFLOPS,
                                    achieved_isolated=fl / ms / 1e9, in_situ=in_situ)
+            # cross-reference, NOT measured by this run: the same family's kernel durations in the committed rocprofv3 kernel trace
+            # (no launch boundaries in it: the figure earlier rounds quoted as "in situ")
+            try:
+                kt = json.load(open(os.path.join(ROOT, "profiles", "r06_conv_in_situ.json")))
+                out["roofline"]["frac_kernel_trace_committed"] = {
+                    "frac": fl / kt["conv_fwd_dgrad_ms_per_step"] / 1e9 / PEAK_BF16_TFLOPS, "ms_per_step": kt["conv_fwd_dgrad_ms_per_step"],
+                    "source": "profiles/r06_conv_in_situ.json (rocprofv3 --kernel-trace of bench.py, tools/collect_profiles.sh; another box, another run)"}
+            except Exception:
+                pass
         # launches of the family that also carry the layer's group norm (phx_conv3x3_mfma_bf16_fgn: statistics, second pass):
         # counted in `achieved` with their whole duration, listed here so that the convolution-only part can be read off
         fb = [(fl_, ms_) for tag, fl_, ms_, shp in rows if shp and shp[0] == "fgn"]
