@@ -350,34 +350,37 @@ def main():
     ranks_seen = int(round(ctx.sum_float(1.0)))          # every rank that really took part in the timed collectives
     dp_diag = None
     if ctx.active and not generate:
-        # after the timed region: what a first multi-GPU run needs to diagnose itself -- every rank's own time for the timed steps and
-        # the duration of the gradient exchange (HIP events on the plan's stream around phx_comm_allreduce_sum_f32, ten more steps)
-        import ctypes
-        from phiseg_code_amd import runtime as rt
-        Lb = rt.lib()
-        evs = []
-        for _ in range(10):
-            e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
-            Lb.event_create(ctypes.byref(e0)); Lb.event_create(ctypes.byref(e1))
-            plan.run_main()
-            Lb.event_record(e0, ctypes.c_void_p(plan.stream_handle()))
-            ctx.allreduce_sum(sess.store.grads[:sess.store.n_live], plan)
-            Lb.event_record(e1, ctypes.c_void_p(plan.stream_handle()))
-            plan.run_opt()
-            evs.append((e0, e1))
-        plan.sync()
-        torch.cuda.synchronize()
-        ar = []
-        for e0, e1 in evs:
-            ms_ = ctypes.c_float()
-            Lb.event_elapsed_ms(e0, e1, ctypes.byref(ms_))
-            ar.append(ms_.value)
-            Lb.event_destroy(e0); Lb.event_destroy(e1)
-        ar_ms = float(np.median(ar))
-        dp_diag = {"allreduce_ms_median_rank0": ar_ms, "allreduce_ms_max_over_ranks": ctx.max_float(ar_ms),
-                   "allreduce_mbytes": sess.store.n_live * 4 / 1e6,
-                   "ms_per_step_per_rank": [1e3 * v / args.steps for v in ctx.gather_floats(dt_own)],
-                   "note": "measured after the timed region (ten extra steps); allreduce_ms includes the wait for the slowest rank's backward"}
+        try:
+            # after the timed region: what a first multi-GPU run needs to diagnose itself -- every rank's own time for the timed steps and
+            # the duration of the gradient exchange (HIP events on the plan's stream around phx_comm_allreduce_sum_f32, ten more steps)
+            import ctypes
+            from phiseg_code_amd import runtime as rt
+            Lb = rt.lib()
+            evs = []
+            for _ in range(10):
+                e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+                Lb.event_create(ctypes.byref(e0)); Lb.event_create(ctypes.byref(e1))
+                plan.run_main()
+                Lb.event_record(e0, ctypes.c_void_p(plan.stream_handle()))
+                ctx.allreduce_sum(sess.store.grads[:sess.store.n_live], plan)
+                Lb.event_record(e1, ctypes.c_void_p(plan.stream_handle()))
+                plan.run_opt()
+                evs.append((e0, e1))
+            plan.sync()
+            torch.cuda.synchronize()
+            ar = []
+            for e0, e1 in evs:
+                ms_ = ctypes.c_float()
+                Lb.event_elapsed_ms(e0, e1, ctypes.byref(ms_))
+                ar.append(ms_.value)
+                Lb.event_destroy(e0); Lb.event_destroy(e1)
+            ar_ms = float(np.median(ar))
+            dp_diag = {"allreduce_ms_median_rank0": ar_ms, "allreduce_ms_max_over_ranks": ctx.max_float(ar_ms),
+                       "allreduce_mbytes": sess.store.n_live * 4 / 1e6,
+                       "ms_per_step_per_rank": [1e3 * v / args.steps for v in ctx.gather_floats(dt_own)],
+                       "note": "measured after the timed region (ten extra steps); allreduce_ms includes the wait for the slowest rank's backward"}
+        except Exception as e:      # (the diagnostic must never cost the line; every rank runs the same code, so a failure is symmetric)
+            dp_diag = {"error": repr(e)}
         ctx.barrier()
     images = args.batch * max(spi, 1) * ctx.world * args.steps
     out = {
